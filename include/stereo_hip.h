@@ -1,0 +1,139 @@
+/* stereo_hip.h -- C ABI of libstereo_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the 3D-label stereo energy-minimisation path of
+ * johannesu/stereo.  Every entry point replaces one reference interface; the
+ * citation says which (paths relative to the reference tree).  Plain pointers
+ * and sizes only; all functions return 0 on success, non-zero on failure,
+ * never throw and never exit().  On failure a message is copied into `err`
+ * (if errcap > 0) and is also available from stereo_hip_last_error().
+ *
+ * Array conventions are MATLAB's at the mex boundary: column-major, i.e. a
+ * K x N matrix is N consecutive K-vectors (label fastest).  `conn` is the
+ * 2 x E uint32 connectivity, ZERO based as passed to the mex gateways
+ * (rd.m:21 / trws.m:33 subtract 1 before the call).
+ */
+#ifndef STEREO_HIP_H_
+#define STEREO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STEREO_HIP_ABI_VERSION 1
+
+/* ---- library ---------------------------------------------------------- */
+
+int stereo_hip_abi_version(void);
+/* Number of visible HIP devices (0 if none / runtime failure). */
+int stereo_hip_device_count(void);
+/* Selects the device used by subsequent calls of this thread (default 0). */
+int stereo_hip_set_device(int device);
+/* Last error message of the calling thread ("" if none). */
+const char *stereo_hip_last_error(void);
+
+/* ---- TRW-S simultaneous fusion ---------------------------------------- *
+ * Replaces cpp/trws_mex.cpp:149-164 mexFunction -> solve_mrf<T> (:27-147):
+ *   [labelling, energy, lower_bound, iterations] =
+ *       trws_mex(kernel, unary, connectivity-1, q, qprim, alphas, tol, options)
+ * kernel      1 = truncated linear  (TypeStereoLinear),
+ *             2 = truncated quadratic (TypeStereoQuadratic); anything else fails
+ *             with "Unsupported kernel" (trws_mex.cpp:162).
+ * unary       K x N   q, qprim  K x E   alphas  E   tol = lambda (trws_mex.cpp:37)
+ * maxiter, max_relgap: the two fields of the options struct (trws_mex.cpp:40-41;
+ *             defaults 1000 and 0 are applied by the caller / gateway).
+ * labelling   N doubles, ONE based (trws_mex.cpp:137).
+ */
+int stereo_trws(int kernel, const double *unary, const uint32_t *conn, const double *q,
+                const double *qprim, const double *alphas, double tol, double maxiter,
+                double max_relgap, int K, int64_t N, int64_t E, double *labelling,
+                double *energy, double *lower_bound, double *iterations, char *err,
+                size_t errcap);
+
+/* Device-resident form of the same solver: graph analysis (SetAutomaticOrdering,
+ * ordering.cpp:7-157; CompleteGraphConstruction, MRFEnergy.cpp:137-229) is done
+ * once per connectivity, inputs live in HBM across calls, iterations can be
+ * issued without host round trips.  Used by the mex gateway for repeated
+ * simultaneous_fusion calls on one image (dispmap_super.m:153-198) and by
+ * bench.py (inputs resident before the timed region).
+ */
+typedef struct stereo_trws_plan stereo_trws_plan;
+
+/* flags */
+#define STEREO_TRWS_MESSAGES_EXACT 0   /* reference lower-envelope semantics (default) */
+#define STEREO_TRWS_MESSAGES_MINPLUS 1 /* plain min-plus; equal unless exact ties occur */
+
+int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint32_t *conn,
+                            int message_mode, stereo_trws_plan **plan, char *err,
+                            size_t errcap);
+void stereo_trws_plan_destroy(stereo_trws_plan *plan);
+
+/* Host -> HBM upload of the per-call inputs (same meaning as stereo_trws).
+ * q == NULL && qprim == NULL selects "shared positions": every edge uses the
+ * K-vector `positions` for both q(:,e) and qprim(:,e) (fronto-parallel labels,
+ * dispmap_super.m:177-183 with planes [0 0 1 -d]); nothing K x E is stored. */
+int stereo_trws_plan_upload(stereo_trws_plan *plan, const double *unary, const double *q,
+                            const double *qprim, const double *positions,
+                            const double *alphas, double tol, char *err, size_t errcap);
+/* Same, but the arrays are already DEVICE pointers (e.g. torch tensors, or the
+ * output of the cost-volume kernels); they are borrowed, not copied. */
+int stereo_trws_plan_bind_device(stereo_trws_plan *plan, const double *d_unary,
+                                 const double *d_q, const double *d_qprim,
+                                 const double *d_positions, const double *d_alphas,
+                                 double tol, char *err, size_t errcap);
+/* Zero all messages (MRFEnergy.cpp:115-133) and the iteration counter. */
+int stereo_trws_plan_reset(stereo_trws_plan *plan, char *err, size_t errcap);
+/* Runs up to `iters` further iterations of Minimize_TRW_S (minimize.cpp:31-113):
+ * forward sweep, backward sweep (+ lower bound), primal labelling + energy, stop
+ * test `(E-LB)/E < max_relgap`.  Returns in *done_iters the number executed in
+ * this call, *stopped != 0 if the relative-gap test fired.  `stream` is a
+ * hipStream_t (NULL = default stream); the call returns after the last
+ * iteration's scalars have reached the host. */
+int stereo_trws_plan_iterate(stereo_trws_plan *plan, int iters, double max_relgap,
+                             void *stream, int *done_iters, int *stopped, char *err,
+                             size_t errcap);
+/* Result of the most recent iteration (minimize.cpp:104: the LAST primal, not the
+ * best).  labelling: N doubles, one based; may be NULL. */
+int stereo_trws_plan_result(stereo_trws_plan *plan, double *labelling, double *energy,
+                            double *lower_bound, double *iterations, char *err,
+                            size_t errcap);
+/* Diagnostics: graph analysis results (all may be NULL). rank: N int64;
+ * levels: number of dependency levels of the node order. */
+int stereo_trws_plan_info(stereo_trws_plan *plan, int64_t *rank, int64_t *levels,
+                          int64_t *max_level_nodes, char *err, size_t errcap);
+/* Timing hooks for bench.py: total device time (ms, hipEvent on the plan's
+ * stream) and launch count of the sweep kernels since the last reset_stats. */
+int stereo_trws_plan_stats(stereo_trws_plan *plan, double *sweep_ms, int64_t *sweep_launches,
+                           int reset);
+
+/* Host-only graph analysis behind stereo_trws_plan_create (no device needed):
+ * node order of SetAutomaticOrdering (ordering.cpp:7-157), edge orientation and
+ * per-node forward/backward edge lists of CompleteGraphConstruction
+ * (MRFEnergy.cpp:137-229), and the dependency level of every node.
+ * rank: N; tail, head: E (after orientation); mdir: E (Swap parity);
+ * fwd_ptr, bwd_ptr: N+1 CSR offsets indexed by NODE ID; fwd_idx, bwd_idx: E
+ * edge ids in list order; level: N (indexed by node id).  Any output may be NULL. */
+int stereo_trws_analyze(int64_t N, int64_t E, const uint32_t *conn, int64_t *rank,
+                        int64_t *tail, int64_t *head, int32_t *mdir, int64_t *fwd_ptr,
+                        int64_t *fwd_idx, int64_t *bwd_ptr, int64_t *bwd_idx, int64_t *level,
+                        char *err, size_t errcap);
+
+/* ---- QPBO roof-duality binary fusion ---------------------------------- *
+ * Replaces cpp/rd_mex.cpp:14-100 mexFunction:
+ *   [labelling, energy, lower_bound, num_unlabelled] =
+ *       rd_mex(U0, U1, E00, E01, E10, E11, connectivity-1, options)
+ * U0,U1 N; E00..E11 E; improve = options.improve (rd_mex.cpp:34, default false).
+ * labelling N doubles in {-1,0,1}; num_unlabelled is counted BEFORE Improve
+ * (rd_mex.cpp:83-88).
+ */
+int stereo_rd(const double *U0, const double *U1, const double *E00, const double *E01,
+              const double *E10, const double *E11, const uint32_t *conn, int64_t N,
+              int64_t E, int improve, double *labelling, double *energy,
+              double *lower_bound, double *num_unlabelled, char *err, size_t errcap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STEREO_HIP_H_ */

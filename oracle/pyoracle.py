@@ -1,0 +1,178 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes front-end of the CPU oracle.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module.  The product package ``stereo_amd`` never does.
+
+Two libraries sit behind it:
+
+* ``oracle/liboracle.so``   -- this repo's own restatement (plain C, ``make -C oracle oracle``)
+* ``oracle/_ref/*.so``      -- the reference's own QPBO library and TRW-S type
+  classes, compiled from ``/root/reference`` where that tree exists (build
+  container); prebuilt files travel to the GPU box.  Optional: ``have_ref_*``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+_dp = C.POINTER(C.c_double)
+_u32p = C.POINTER(C.c_uint32)
+_i64p = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
+
+
+def _load(path):
+    return C.CDLL(path) if os.path.exists(path) else None
+
+
+_lib = None
+_ref_qpbo = None
+_ref_types = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        p = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(p):
+            raise RuntimeError("oracle/liboracle.so missing: run `make -C oracle oracle` "
+                               "(or __graft_entry__.build())")
+        _lib = C.CDLL(p)
+        _lib.oracle_update_message.restype = C.c_double
+        _lib.oracle_update_message_envelope.restype = C.c_double
+    return _lib
+
+
+def ref_qpbo():
+    global _ref_qpbo
+    if _ref_qpbo is None:
+        _ref_qpbo = _load(os.path.join(_HERE, "_ref", "libref_qpbo.so")) or False
+    return _ref_qpbo or None
+
+
+def ref_types():
+    global _ref_types
+    if _ref_types is None:
+        _ref_types = _load(os.path.join(_HERE, "_ref", "libref_trws_types.so")) or False
+        if _ref_types:
+            _ref_types.ref_update_message.restype = C.c_double
+            _ref_types.ref_vec_min.restype = C.c_double
+    return _ref_types or None
+
+
+def have_ref_qpbo():
+    return ref_qpbo() is not None
+
+
+def have_ref_types():
+    return ref_types() is not None
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def _conn(conn):
+    """conn: (E,2) zero-based pairs (row e = edge e) -> contiguous (E,2) uint32."""
+    c = np.asarray(conn)
+    if c.ndim != 2 or c.shape[1] != 2:
+        raise ValueError("connectivity must be E x 2")
+    c = np.ascontiguousarray(c, dtype=np.uint32)
+    return c, c.ctypes.data_as(_u32p)
+
+
+# --------------------------------------------------------------------- TRW-S
+
+def trws(kernel, unary, conn, q, qprim, alphas, tol, maxiter=1000, max_relgap=0.0, mode=0,
+         use_ref_types=False, want_trace=False):
+    """unary (N,K), q/qprim (E,K) row-major == MATLAB K x N / K x E column-major.
+    conn zero-based (E,2).  Returns labels (1-based float64 like the gateway),
+    energy, lower bound, iterations [, trace]."""
+    unary, pu = _d(unary)
+    q, pq = _d(q)
+    qprim, pqp = _d(qprim)
+    alphas, pa = _d(alphas)
+    c, pc = _conn(conn)
+    N, K = unary.shape
+    E = c.shape[0]
+    assert q.shape == (E, K) and qprim.shape == (E, K) and alphas.shape == (E,)
+    lab = np.zeros(N)
+    en, lb, it = C.c_double(), C.c_double(), C.c_double()
+    msg_fn = col_fn = None
+    if use_ref_types:
+        r = ref_types()
+        if r is None:
+            raise RuntimeError("oracle/_ref/libref_trws_types.so not available")
+        msg_fn = C.cast(r.ref_update_message, C.c_void_p)
+        col_fn = C.cast(r.ref_add_column, C.c_void_p)
+    trace = np.zeros((int(maxiter), 2)) if want_trace else None
+    rc = lib().oracle_trws(C.c_int(int(kernel)), pu, pc, pq, pqp, pa, C.c_double(tol),
+                           C.c_double(maxiter), C.c_double(max_relgap), C.c_int(K),
+                           C.c_int64(N), C.c_int64(E), C.c_int(mode), msg_fn, col_fn,
+                           lab.ctypes.data_as(_dp), C.byref(en), C.byref(lb), C.byref(it),
+                           trace.ctypes.data_as(_dp) if want_trace else None)
+    if rc:
+        raise RuntimeError("oracle_trws failed rc=%d" % rc)
+    out = (lab, en.value, lb.value, it.value)
+    if want_trace:
+        out = out + (trace[: int(it.value)],)
+    return out
+
+
+def trws_structure(N, conn):
+    c, pc = _conn(conn)
+    E = c.shape[0]
+    rank = np.zeros(N, np.int64)
+    tail = np.zeros(E, np.int64)
+    head = np.zeros(E, np.int64)
+    dirn = np.zeros(E, np.int32)
+    fptr = np.zeros(N + 1, np.int64)
+    bptr = np.zeros(N + 1, np.int64)
+    fidx = np.zeros(E, np.int64)
+    bidx = np.zeros(E, np.int64)
+    rc = lib().oracle_trws_structure(C.c_int64(N), C.c_int64(E), pc,
+                                     rank.ctypes.data_as(_i64p), tail.ctypes.data_as(_i64p),
+                                     head.ctypes.data_as(_i64p), dirn.ctypes.data_as(_i32p),
+                                     fptr.ctypes.data_as(_i64p), fidx.ctypes.data_as(_i64p),
+                                     bptr.ctypes.data_as(_i64p), bidx.ctypes.data_as(_i64p))
+    if rc:
+        raise RuntimeError("oracle_trws_structure failed rc=%d" % rc)
+    return dict(rank=rank, tail=tail, head=head, dir=dirn, fwd_ptr=fptr, fwd_idx=fidx,
+                bwd_ptr=bptr, bwd_idx=bidx)
+
+
+def _message(fn, kernel, Di, gamma, msg, q, qprim, alpha, lam, dirn, mdir):
+    Di, pD = _d(Di)
+    m = np.array(msg, dtype=np.float64, copy=True)
+    q, pq = _d(q)
+    qprim, pqp = _d(qprim)
+    K = Di.shape[0]
+    v = fn(C.c_int(kernel), C.c_int(K), pD, C.c_double(gamma), m.ctypes.data_as(_dp), pq, pqp,
+           C.c_double(alpha), C.c_double(lam), C.c_int(dirn), C.c_int(mdir))
+    return m, v
+
+
+def update_message(kernel, Di, gamma, msg, q, qprim, alpha, lam, dirn, mdir, impl="brute"):
+    """impl: 'brute' | 'envelope' (restatements) | 'ref' (reference type classes)."""
+    if impl == "brute":
+        fn = lib().oracle_update_message
+    elif impl == "envelope":
+        fn = lib().oracle_update_message_envelope
+    elif impl == "ref":
+        fn = ref_types().ref_update_message
+    else:
+        raise ValueError(impl)
+    return _message(fn, kernel, Di, gamma, msg, q, qprim, alpha, lam, dirn, mdir)
+
+
+def add_column(kernel, q, qprim, alpha, lam, ksource, dest, dirn, mdir, impl="brute"):
+    q, pq = _d(q)
+    qprim, pqp = _d(qprim)
+    d = np.array(dest, dtype=np.float64, copy=True)
+    fn = lib().oracle_add_column if impl == "brute" else ref_types().ref_add_column
+    fn(C.c_int(kernel), C.c_int(q.shape[0]), pq, pqp, C.c_double(alpha), C.c_double(lam),
+       C.c_int(int(ksource)), d.ctypes.data_as(_dp), C.c_int(dirn), C.c_int(mdir))
+    return d

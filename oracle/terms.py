@@ -1,0 +1,274 @@
+"""TEST INFRASTRUCTURE ONLY -- NumPy restatement of the MATLAB array math that
+feeds the two solvers (reference: dispmap_super.m, dispmap_ncc.m,
+dispmap_globalstereo.m, imrender/vgg/vgg_interp2.cxx).
+
+Parity status: **unpinned by an executable reference** -- there is no MATLAB /
+Octave in the image.  Every function follows the cited lines literally
+(column-major node ids, 1-based pixel coordinates, conv2(...,'same') zero
+padding, interp2 linear, first-max / last-nearest tie rules) and is the
+definition the HIP kernels are compared against.
+
+Conventions: images are (H, W, C) float64; node id = col*H + row (0-based,
+column major, dispmap_super.m:281-282); points(:, id) = [x = col+1, y = row+1]
+(dispmap_super.m:275-278); assignment is (4, N) planes [a b c d];
+disparity = -(a*x + b*y + d)/c (dispmap_super.m:318-328).
+"""
+import numpy as np
+
+
+# ------------------------------------------------------------------ geometry
+
+def construct_neighborhood(H, W):
+    """dispmap_super.m:279-302 -> (ind1, ind2) zero-based int64 arrays of the
+    directed edges: vertical down, vertical up, horizontal right, horizontal
+    left, each block in column-major order."""
+    nodenr = np.arange(H * W, dtype=np.int64).reshape(W, H).T  # nodenr[r, c] = c*H + r
+    start = nodenr[:-1, :].T.ravel()    # column-major flatten
+    finish = nodenr[1:, :].T.ravel()
+    ind1 = [start, finish]
+    ind2 = [finish, start]
+    start = nodenr[:, :-1].T.ravel()
+    finish = nodenr[:, 1:].T.ravel()
+    ind1 += [start, finish]
+    ind2 += [finish, start]
+    return np.concatenate(ind1), np.concatenate(ind2)
+
+
+def get_points(H, W):
+    """dispmap_super.m:275-278: 2 x N, x = column (1-based), y = row (1-based)."""
+    cols, rows = np.meshgrid(np.arange(1, W + 1, dtype=np.float64),
+                             np.arange(1, H + 1, dtype=np.float64))
+    return np.stack([cols.T.ravel(), rows.T.ravel()])  # column-major order
+
+
+def disparity_from_assignment(assignment, points):
+    """dispmap_super.m:318-328.  sum(a(1:2,:).*points) adds a*x then b*y."""
+    if np.any(assignment[2] == 0):
+        raise ValueError("Infinite disparity")
+    s = assignment[0] * points[0] + assignment[1] * points[1]
+    return -(s + assignment[3]) / assignment[2]
+
+
+def pairwise_cost(kernel, weights, p, q, tol):
+    """dispmap_super.m:226-235"""
+    d = p - q
+    if kernel == 1:
+        return weights * np.minimum(np.abs(d), tol)
+    if kernel == 2:
+        return weights * np.minimum(d ** 2, tol)
+    raise ValueError("Unkown kernel type")
+
+
+def all_pairwise_costs(kernel, weights, tol, assignment, proposal, ind1, ind2, points,
+                       disp_fn=disparity_from_assignment):
+    """dispmap_super.m:236-262 -> E00, E01, E10, E11 (each length E)."""
+    p2 = points[:, ind2]
+    q = disp_fn(assignment[:, ind2], p2)
+    qprim = disp_fn(assignment[:, ind1], p2)
+    new_q = disp_fn(proposal[:, ind2], p2)
+    new_qprim = disp_fn(proposal[:, ind1], p2)
+    E00 = pairwise_cost(kernel, weights, q, qprim, tol)
+    E11 = pairwise_cost(kernel, weights, new_q, new_qprim, tol)
+    E10 = pairwise_cost(kernel, weights, q, new_qprim, tol)
+    E01 = pairwise_cost(kernel, weights, new_q, qprim, tol)
+    return E00, E01, E10, E11
+
+
+def trws_positions(proposals, ind1, ind2, points, disp_fn=disparity_from_assignment):
+    """dispmap_super.m:177-183 -> q, qprim as (E, K) arrays (row e = MATLAB column e)."""
+    p2 = points[:, ind2]
+    q = np.stack([disp_fn(P[:, ind2], p2) for P in proposals], axis=1)
+    qprim = np.stack([disp_fn(P[:, ind1], p2) for P in proposals], axis=1)
+    return q, qprim
+
+
+def fronto_parallel(d, N):
+    """example_ncc.m:35-41: plane [0 0 1 -d] at every pixel."""
+    P = np.zeros((4, N))
+    P[2] = 1.0
+    P[3] = -float(d)
+    return P
+
+
+# ----------------------------------------------------------------- NCC volume
+
+def _conv2_same_box(a, r, scale=None):
+    """conv2(a, ones(2r+1), 'same') with zero padding; summation order is the
+    direct double loop over the window (rows inner), matching nothing in
+    particular -- MATLAB's conv2 order is unspecified, tolerance 1e-12 relative."""
+    H, W = a.shape
+    pad = np.zeros((H + 2 * r, W + 2 * r))
+    pad[r:r + H, r:r + W] = a
+    out = np.zeros((H, W))
+    for dx in range(2 * r + 1):
+        for dy in range(2 * r + 1):
+            out += pad[dy:dy + H, dx:dx + W]
+    if scale is not None:
+        out = out * scale
+    return out
+
+
+def _shift_image(im1, d):
+    """dispmap_ncc.m:145-154: imtr(:, ceil(d+1):W, c) = interp2(im1(:,:,c), X, Y) with
+    X = linspace(1, W-d, numel(y_span)); zero elsewhere."""
+    H, W, Cn = im1.shape
+    c0 = int(np.ceil(d + 1))          # 1-based first filled column
+    n = W - c0 + 1
+    out = np.zeros((H, W, Cn))
+    if n <= 0:
+        return out
+    X = np.linspace(1.0, W - d, n)    # 1-based sample columns
+    x0 = np.floor(X).astype(np.int64)
+    x0 = np.clip(x0, 1, W - 1) if W > 1 else x0
+    t = X - x0
+    for ch in range(Cn):
+        a = im1[:, :, ch]
+        left = a[:, x0 - 1]
+        right = a[:, np.minimum(x0, W - 1)]
+        out[:, c0 - 1:, ch] = left * (1 - t) + right * t if np.any(t != 0) else left
+    return out
+
+
+def compute_ncc(im0, im1, disparities, patchsize=2):
+    """dispmap_ncc.m:116-198 -> (H, W, D) volume."""
+    im0 = np.asarray(im0, np.float64)
+    im1 = np.asarray(im1, np.float64)
+    H, W, _ = im0.shape
+    r = patchsize
+    npatch = float((2 * r + 1) ** 2)
+    box = lambda a: _conv2_same_box(a, r)
+    mean_scale = 1.0 / npatch / 3.0
+    R0 = [im0[:, :, c] for c in range(3)]
+    box0 = [box(x) for x in R0]
+    mean0 = (box0[0] * mean_scale + box0[1] * mean_scale) + box0[2] * mean_scale
+    t1 = (box(R0[0] ** 2) + box(R0[1] ** 2)) + box(R0[2] ** 2)
+    t2 = (mean0 * box0[0] + mean0 * box0[1]) + mean0 * box0[2]
+    t4 = npatch * 3 * mean0 ** 2
+    norm0 = np.sqrt((t1 - 2 * t2 + t4).astype(np.complex128))
+    out = np.zeros((H, W, len(disparities)))
+    for i, d in enumerate(disparities):
+        bnd = np.zeros((H, W))
+        bnd[:, int(round(d + 1)) - 1:] = 1
+        tr = _shift_image(im1, d)
+        T = [tr[:, :, c] for c in range(3)]
+        boxT = [box(x) for x in T]
+        meanT = (boxT[0] * mean_scale + boxT[1] * mean_scale) + boxT[2] * mean_scale
+        u1 = (box(T[0] ** 2) + box(T[1] ** 2)) + box(T[2] ** 2)
+        u2 = (meanT * boxT[0] + meanT * boxT[1]) + meanT * boxT[2]
+        u4 = npatch * 3 * meanT ** 2
+        normT = np.sqrt((u1 - 2 * u2 + u4).astype(np.complex128))
+        c1 = (box(R0[0] * T[0]) + box(R0[1] * T[1])) + box(R0[2] * T[2])
+        c2 = (mean0 * boxT[0] + mean0 * boxT[1]) + mean0 * boxT[2]
+        c3 = (meanT * box0[0] + meanT * box0[1]) + meanT * box0[2]
+        c4 = npatch * 3 * meanT * mean0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ncci = (c1 - c2 - c3 + c4) / norm0 / normT
+        bad = ~(np.isfinite(ncci.real) & np.isfinite(ncci.imag))
+        ncci[bad] = 0
+        ncci[~(bnd >= 1 - 1e-8)] = 0
+        out[:, :, i] = ncci.real
+    return out
+
+
+def interpolate_ncc(ncc, disparities, t2, y2, okdepth):
+    """dispmap_ncc.m:250-276; t2 is 1-based like MATLAB."""
+    d = np.asarray(disparities, np.float64)
+    H, W, D = ncc.shape
+    t1 = np.where(okdepth, t2 - 1, t2)
+    t3 = np.where(okdepth, t2 + 1, t2)
+    d1, d2, d3 = d[t1 - 1], d[t2 - 1], d[t3 - 1]
+    rows, cols = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    y1 = ncc[rows, cols, t1 - 1]
+    y3 = ncc[rows, cols, t3 - 1]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        a = y1 / (d1 - d2) / (d1 - d3)
+        b = y2 / (d2 - d1) / (d2 - d3)
+        c = y3 / (d3 - d1) / (d3 - d2)
+        r = a + b + c
+        p = -(a * (d2 + d3) + b * (d1 + d3) + c * (d1 + d2))
+        q = a * d2 * d3 + b * d1 * d3 + c * d1 * d2
+    return r, p, q, d2
+
+
+def sample_ncc_from_disp(ncc, disparities, disps):
+    """dispmap_ncc.m:222-249: disps (N,) column-major -> nccs (H, W)."""
+    d = np.asarray(disparities, np.float64)
+    H, W, D = ncc.shape
+    x = np.asarray(disps, np.float64).reshape(W, H).T
+    t2 = np.ones((H, W), np.int64)
+    smallest = np.abs(x - d[0])
+    y2 = np.ones((H, W))
+    for i in range(D):
+        nd = np.abs(x - d[i])
+        m = nd <= smallest
+        t2[m] = i + 1
+        y2[m] = ncc[:, :, i][m]
+        smallest[m] = nd[m]
+    ok = (t2 < D) & (t2 > 1)
+    good = (x <= d.max()) & (x >= d.min())
+    r, p, q, _ = interpolate_ncc(ncc, d, t2, y2, ok)
+    with np.errstate(invalid="ignore"):
+        out = r * x ** 2 + p * x + q
+    out[t2 == 1] = ncc[:, :, 0][t2 == 1]
+    out[t2 == D] = ncc[:, :, -1][t2 == D]
+    out[~good] = -1e6
+    return out
+
+
+def ncc_unary_cost(ncc, disparities, unary_weight, assignment, points):
+    """dispmap_ncc.m:107-115 -> (N,) column-major."""
+    disps = disparity_from_assignment(assignment, points)
+    nccs = sample_ncc_from_disp(ncc, disparities, disps)
+    return unary_weight * (1 - nccs.T.ravel())
+
+
+def best_disp_from_ncc(ncc, disparities):
+    """dispmap_ncc.m:208-221 -> (H, W) WTA disparity with parabola refinement."""
+    D = ncc.shape[2]
+    t2 = np.argmax(ncc, axis=2) + 1          # first max, like MATLAB
+    y2 = np.max(ncc, axis=2)
+    ok = (t2 < D) & (t2 > 1)
+    r, p, q, d2 = interpolate_ncc(ncc, disparities, t2, y2, ok)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        best = -p / r / 2
+    best[~ok] = d2[~ok]
+    return best
+
+
+# ----------------------------------------------------------- globalstereo unary
+
+def vgg_interp2_linear(A, X, Y, oobv):
+    """imrender/vgg/vgg_interp2.cxx:245-322, 'linear' branch, 1-based X (col) / Y (row)."""
+    A = np.asarray(A, np.float64)
+    if A.ndim == 2:
+        A = A[:, :, None]
+    h, w, col = A.shape
+    X = np.asarray(X, np.float64)
+    Y = np.asarray(Y, np.float64)
+    out = np.full((X.shape[0], col), float(oobv))
+    for i in range(X.shape[0]):
+        xx, yy = X[i], Y[i]
+        if xx >= 1 and yy >= 1:
+            if xx < w:
+                if yy < h:
+                    x = int(xx); y = int(yy); u = xx - x; v = yy - y
+                    for c in range(col):
+                        a00 = A[y - 1, x - 1, c]; a01 = A[y - 1, x, c]
+                        a10 = A[y, x - 1, c]; a11 = A[y, x, c]
+                        o = a00 + (a01 - a00) * u
+                        o += ((a10 - o) + (a11 - a10) * u) * v
+                        out[i, c] = o
+                elif yy == h:
+                    x = int(xx); u = xx - x
+                    for c in range(col):
+                        a0 = A[h - 1, x - 1, c]; a1 = A[h - 1, x, c]
+                        out[i, c] = a0 + (a1 - a0) * u
+            elif xx == w:
+                if yy < h:
+                    y = int(yy); v = yy - y
+                    for c in range(col):
+                        a0 = A[y - 1, w - 1, c]; a1 = A[y, w - 1, c]
+                        out[i, c] = a0 + (a1 - a0) * v
+                elif yy == h:
+                    out[i] = A[h - 1, w - 1]
+    return out

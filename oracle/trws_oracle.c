@@ -1,0 +1,481 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's TRW-S path.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this.  The product (stereo_amd/, libstereo_hip.so) never does.
+ *
+ * What is restated (reference file:line, all under /root/reference/cpp):
+ *   trws_mex.cpp:27-147            gateway: argument meaning, 1-based labels out
+ *   trw-s/MRFEnergy.cpp:83-111     AddEdge: prepend to tail's forward / head's backward list
+ *   trw-s/ordering.cpp:7-157       SetAutomaticOrdering
+ *   trw-s/MRFEnergy.cpp:137-229    CompleteGraphConstruction (orientation, list rebuild)
+ *   trw-s/treeProbabilities.cpp:12-47  gamma = 1/max(nFwd,nBwd)
+ *   trw-s/minimize.cpp:7-116       Minimize_TRW_S (forward, backward + LB, stop test)
+ *   trw-s/minimize.cpp:223-264     ComputeSolutionAndEnergy
+ *   trw-s/typeStereoLinear.h:214-270,324-518 / typeStereoQuadratic.h:324-531
+ *                                  Vector ops, UpdateMessage, AddColumn
+ *
+ * Parity status: the message update / AddColumn / Vector::ComputeMin are pinned
+ * against the reference's own type classes (oracle/_ref/libref_trws_types.so,
+ * built from the reference headers).  The MRFEnergy core (ordering,
+ * orientation, sweeps) is "parity unpinned" by an executable reference: its
+ * sources include <mex.h>, which this image lacks and which is not faked.  It is
+ * pinned only by data recorded from the real reference in SURVEY.md Appendix B
+ * (6x8 rank table, per-node forward/backward counts, 375x450 level statistics),
+ * see tests/test_oracle_trws.py.
+ *
+ * Two message functions are provided and must agree bit for bit:
+ *   mode 0  brute force   out[kd] = min(vTrunc, min_ks alpha*dist(t[kd]-s[ks]) + H[ks])
+ *   mode 1  lower envelope over sorted source positions (the reference's O(K)
+ *           scheme, restated) -- used for the timed CPU baseline.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#if defined(__FMA__)
+#error "build without FMA contraction targets (no -march=native): reference is SSE2"
+#endif
+
+typedef double (*msg_fn_t)(int kernel, int K, const double *Di, double gamma, double *msg,
+                           const double *q, const double *qprim, double alpha, double lambda,
+                           int dir, int mdir);
+typedef void (*col_fn_t)(int kernel, int K, const double *q, const double *qprim, double alpha,
+                         double lambda, int ksource, double *dest, int dir, int mdir);
+
+/* ------------------------------------------------------------------ graph */
+
+typedef struct {
+  int64_t N, E;
+  int64_t *tail, *head; /* per edge, after orientation */
+  int *dir;             /* per edge: Swap() parity */
+  int64_t *order;       /* order[r] = node id with rank r */
+  int64_t *rank;        /* rank[node] */
+  int64_t *firstF, *firstB, *nextF, *nextB; /* linked lists (edge ids, -1 ends) */
+} graph_t;
+
+static void graph_free(graph_t *g) {
+  free(g->tail); free(g->head); free(g->dir); free(g->order); free(g->rank);
+  free(g->firstF); free(g->firstB); free(g->nextF); free(g->nextB);
+}
+
+/* MRFEnergy.cpp:83-111: edges are prepended, so lists end up in reverse insertion order */
+static int graph_init(graph_t *g, int64_t N, int64_t E, const uint32_t *conn) {
+  memset(g, 0, sizeof(*g));
+  g->N = N; g->E = E;
+  g->tail = malloc(sizeof(int64_t) * (E + 1)); g->head = malloc(sizeof(int64_t) * (E + 1));
+  g->dir = calloc(E + 1, sizeof(int));
+  g->order = malloc(sizeof(int64_t) * (N + 1)); g->rank = malloc(sizeof(int64_t) * (N + 1));
+  g->firstF = malloc(sizeof(int64_t) * (N + 1)); g->firstB = malloc(sizeof(int64_t) * (N + 1));
+  g->nextF = malloc(sizeof(int64_t) * (E + 1)); g->nextB = malloc(sizeof(int64_t) * (E + 1));
+  if (!g->tail || !g->head || !g->dir || !g->order || !g->rank || !g->firstF || !g->firstB ||
+      !g->nextF || !g->nextB)
+    return 1;
+  for (int64_t i = 0; i < N; ++i) g->firstF[i] = g->firstB[i] = -1;
+  for (int64_t e = 0; e < E; ++e) {
+    int64_t a = conn[2 * e], b = conn[2 * e + 1];
+    if (a >= N || b >= N) return 2;
+    g->tail[e] = a; g->head[e] = b;
+    g->nextF[e] = g->firstF[a]; g->firstF[a] = e;
+    g->nextB[e] = g->firstB[b]; g->firstB[b] = e;
+  }
+  return 0;
+}
+
+/* ordering.cpp:23-152.  Two doubly linked lists: `list` (untouched nodes, index
+ * order) and `boundary` (LIFO-prepended).  Always take the FIRST node of minimum
+ * remaining degree. */
+static int graph_order(graph_t *g) {
+  int64_t N = g->N;
+  int64_t *deg = malloc(sizeof(int64_t) * (N + 1));
+  int64_t *prv = malloc(sizeof(int64_t) * (N + 1)), *nxt = malloc(sizeof(int64_t) * (N + 1));
+  char *where = malloc(N + 1); /* 2 = list, 1 = boundary, 0 = ordered */
+  if (!deg || !prv || !nxt || !where) return 1;
+  for (int64_t i = 0; i < N; ++i) {
+    int64_t d = 0;
+    for (int64_t e = g->firstF[i]; e >= 0; e = g->nextF[e]) ++d;
+    for (int64_t e = g->firstB[i]; e >= 0; e = g->nextB[e]) ++d;
+    deg[i] = d; where[i] = 2; prv[i] = i - 1; nxt[i] = (i + 1 < N) ? i + 1 : -1;
+  }
+  int64_t list = N > 0 ? 0 : -1, boundary = -1, count = 0;
+  while (list >= 0) {
+    /* the reference starts from dMin = nodeNum, i.e. its pick is undefined when every
+     * candidate has degree >= N (heavy multigraphs); here the true minimum is taken */
+    int64_t dmin = INT64_MAX, imin = -1;
+    for (int64_t i = list; i >= 0; i = nxt[i])
+      if (dmin > deg[i]) { dmin = deg[i]; imin = i; }
+    int64_t i = imin;
+    if (prv[i] >= 0) nxt[prv[i]] = nxt[i]; else list = nxt[i];
+    if (nxt[i] >= 0) prv[nxt[i]] = prv[i];
+    boundary = i; prv[i] = nxt[i] = -1; where[i] = 1;
+    while (boundary >= 0) {
+      dmin = INT64_MAX; imin = -1;
+      for (i = boundary; i >= 0; i = nxt[i])
+        if (dmin > deg[i]) { dmin = deg[i]; imin = i; }
+      i = imin;
+      if (prv[i] >= 0) nxt[prv[i]] = nxt[i]; else boundary = nxt[i];
+      if (nxt[i] >= 0) prv[nxt[i]] = prv[i];
+      where[i] = 0; g->rank[i] = count; g->order[count++] = i;
+      int64_t last = i;
+      for (int pass = 0; pass < 2; ++pass) {
+        for (int64_t e = pass == 0 ? g->firstF[last] : g->firstB[last]; e >= 0;
+             e = pass == 0 ? g->nextF[e] : g->nextB[e]) {
+          int64_t j = pass == 0 ? g->head[e] : g->tail[e];
+          if (where[j] == 0) continue;
+          deg[j]--;
+          if (where[j] == 2) {
+            if (prv[j] >= 0) nxt[prv[j]] = nxt[j]; else list = nxt[j];
+            if (nxt[j] >= 0) prv[nxt[j]] = prv[j];
+            if (boundary >= 0) prv[boundary] = j;
+            prv[j] = -1; nxt[j] = boundary; boundary = j; where[j] = 1;
+          }
+        }
+      }
+    }
+  }
+  free(deg); free(prv); free(nxt); free(where);
+  return 0;
+}
+
+/* MRFEnergy.cpp:176-222 */
+static void graph_orient(graph_t *g) {
+  for (int64_t i = 0; i < g->N; ++i) g->firstB[i] = -1;
+  for (int64_t r = 0; r < g->N; ++r) {
+    int64_t i = g->order[r];
+    int64_t eprev = -1;
+    for (int64_t e = g->firstF[i]; e >= 0;) {
+      int64_t j = g->head[e];
+      if (g->rank[i] < g->rank[j]) {
+        g->nextB[e] = g->firstB[j]; g->firstB[j] = e;
+        eprev = e; e = g->nextF[e];
+      } else {
+        int64_t enext = g->nextF[e];
+        g->dir[e] = 1 - g->dir[e];
+        g->tail[e] = j; g->head[e] = i;
+        if (eprev >= 0) g->nextF[eprev] = enext; else g->firstF[i] = enext;
+        g->nextF[e] = g->firstF[j]; g->firstF[j] = e;
+        g->nextB[e] = g->firstB[i]; g->firstB[i] = e;
+        e = enext;
+      }
+    }
+  }
+}
+
+/* Exports the structure for tests of the product's own host-side builder.
+ * fwd_ptr/bwd_ptr are CSR offsets indexed by NODE ID, fwd_idx/bwd_idx hold edge
+ * ids in list order. */
+int oracle_trws_structure(int64_t N, int64_t E, const uint32_t *conn, int64_t *rank,
+                          int64_t *tail, int64_t *head, int32_t *dir, int64_t *fwd_ptr,
+                          int64_t *fwd_idx, int64_t *bwd_ptr, int64_t *bwd_idx) {
+  graph_t g;
+  int rc = graph_init(&g, N, E, conn);
+  if (rc) { graph_free(&g); return rc; }
+  if (graph_order(&g)) { graph_free(&g); return 3; }
+  graph_orient(&g);
+  int64_t pf = 0, pb = 0;
+  for (int64_t i = 0; i < N; ++i) {
+    rank[i] = g.rank[i];
+    fwd_ptr[i] = pf; bwd_ptr[i] = pb;
+    for (int64_t e = g.firstF[i]; e >= 0; e = g.nextF[e]) fwd_idx[pf++] = e;
+    for (int64_t e = g.firstB[i]; e >= 0; e = g.nextB[e]) bwd_idx[pb++] = e;
+  }
+  fwd_ptr[N] = pf; bwd_ptr[N] = pb;
+  for (int64_t e = 0; e < E; ++e) { tail[e] = g.tail[e]; head[e] = g.head[e]; dir[e] = g.dir[e]; }
+  graph_free(&g);
+  return 0;
+}
+
+/* ---------------------------------------------------------------- messages */
+
+static inline double dist_k(int kernel, double d) { return kernel == 1 ? fabs(d) : d * d; }
+
+/* typeStereoLinear.h:343-357: dir == m_dir -> sources are the qprim half,
+ * destinations the q half; otherwise the other way round. */
+static inline void pick_sides(const double *q, const double *qprim, int dir, int mdir,
+                              const double **s, const double **t) {
+  if (dir == mdir) { *s = qprim; *t = q; } else { *s = q; *t = qprim; }
+}
+
+/* Brute-force definition of the message. */
+double oracle_update_message(int kernel, int K, const double *Di, double gamma, double *msg,
+                             const double *q, const double *qprim, double alpha, double lambda,
+                             int dir, int mdir) {
+  const double *s, *t;
+  pick_sides(q, qprim, dir, mdir, &s, &t);
+  double *H = malloc(sizeof(double) * K);
+  double hmin = INFINITY;
+  for (int k = 0; k < K; ++k) {
+    H[k] = gamma * Di[k] - msg[k];
+    if (H[k] < hmin) hmin = H[k];
+  }
+  double vmin = INFINITY;
+  if (alpha == 0) {
+    for (int k = 0; k < K; ++k) msg[k] = hmin;
+    vmin = hmin;
+  } else {
+    double vtrunc = hmin + alpha * lambda;
+    for (int kd = 0; kd < K; ++kd) {
+      double best = vtrunc;
+      for (int ks = 0; ks < K; ++ks) {
+        double d = t[kd] - s[ks];
+        double c = kernel == 1 ? alpha * fabs(d) + H[ks] : alpha * d * d + H[ks];
+        if (c < best) best = c;
+      }
+      msg[kd] = best;
+      if (best < vmin) vmin = best;
+    }
+  }
+  for (int k = 0; k < K; ++k) msg[k] -= vmin;
+  free(H);
+  return vmin;
+}
+
+/* typeStereoLinear.h:491-518 / typeStereoQuadratic.h:505-531 */
+void oracle_add_column(int kernel, int K, const double *q, const double *qprim, double alpha,
+                       double lambda, int ksource, double *dest, int dir, int mdir) {
+  for (int k = 0; k < K; ++k) {
+    double d = (dir == mdir) ? qprim[ksource] - q[k] : qprim[k] - q[ksource];
+    double v = dist_k(kernel, d);
+    dest[k] += alpha * (v < lambda ? v : lambda);
+  }
+}
+
+typedef struct { double v; int i; } pair_t;
+static int cmp_pair(const void *a, const void *b) {
+  double x = ((const pair_t *)a)->v, y = ((const pair_t *)b)->v;
+  if (x < y) return -1;
+  if (x > y) return 1;
+  int i = ((const pair_t *)a)->i, j = ((const pair_t *)b)->i;
+  return (i > j) - (i < j);
+}
+static void argsort(const double *v, int K, int32_t *out, pair_t *tmp) {
+  for (int k = 0; k < K; ++k) { tmp[k].v = v[k]; tmp[k].i = k; }
+  qsort(tmp, K, sizeof(pair_t), cmp_pair);
+  for (int k = 0; k < K; ++k) out[k] = tmp[k].i;
+}
+
+/* Lower-envelope message: the reference's O(K) scheme (typeStereoLinear.h:401-479,
+ * typeStereoQuadratic.h:407-490) restated.  `so` / `to` are the ascending sort
+ * permutations of the source / destination positions; scratch holds K+1 doubles
+ * (breakpoints) and K ints (stack of envelope members). */
+static double envelope_message(int kernel, int K, const double *H, double hmin, double *msg,
+                               const double *s, const double *t, const int32_t *so,
+                               const int32_t *to, double alpha, double lambda, double *z,
+                               int32_t *v) {
+  double vtrunc = hmin + alpha * lambda, vmin = INFINITY;
+  int j = 0;
+  v[0] = so[0]; z[0] = -INFINITY; z[1] = INFINITY;
+  for (int k = 1; k < K; ++k) {
+    int ik = so[k];
+    double hk = H[ik], qk = s[ik];
+    for (int guard = k; guard >= 0; --guard) {
+      double hj = H[v[j]], qj = s[v[j]];
+      if (kernel == 1) {
+        double reach = alpha * fabs(qk - qj);
+        if (reach + hk < hj) { /* cone k lies below cone j everywhere: drop j */
+          if (j == 0) { v[0] = ik; z[0] = -INFINITY; z[1] = INFINITY; } else { --j; }
+          continue;
+        }
+        if (reach + hj <= hk) break; /* cone k never wins */
+        double x = ((hk - hj) + alpha * (qk + qj)) / (2 * alpha);
+        if (x >= qk || x <= qj) break; /* crossing not strictly between the apexes */
+        ++j; v[j] = ik; z[j] = x; z[j + 1] = INFINITY;
+        break;
+      } else {
+        if (qk - qj < 1e-8) { /* (near-)coincident apexes: keep the lower one */
+          if (hj > hk) {
+            if (j == 0) { v[0] = ik; z[0] = -INFINITY; z[1] = INFINITY; break; }
+            --j;
+            continue;
+          }
+          break;
+        }
+        double x = ((hk + alpha * qk * qk) - (hj + alpha * qj * qj)) / (2 * alpha * (qk - qj));
+        if (x <= z[j]) { --j; continue; }
+        ++j; v[j] = ik; z[j] = x; z[j + 1] = INFINITY;
+        break;
+      }
+    }
+  }
+  j = 0;
+  for (int k = 0; k < K; ++k) {
+    int id = to[k];
+    double p = t[id];
+    while (z[j + 1] < p) ++j;
+    double d = p - s[v[j]];
+    double c = kernel == 1 ? alpha * fabs(d) + H[v[j]] : alpha * d * d + H[v[j]];
+    double m = vtrunc < c ? vtrunc : c;
+    msg[id] = m;
+    if (m < vmin) vmin = m;
+  }
+  return vmin;
+}
+
+/* ---------------------------------------------------------------- the run */
+
+typedef struct {
+  int kernel, K, mode;
+  const double *q, *qprim, *alphas;
+  double lambda;
+  int32_t *sort_q, *sort_qp; /* mode 1: per-edge ascending permutations */
+  double *H, *z; int32_t *v;
+  msg_fn_t msg_fn; col_fn_t col_fn;
+} solver_t;
+
+static double do_update(solver_t *S, int64_t e, const double *Di, double gamma, double *msg,
+                        int dir, int mdir) {
+  int K = S->K;
+  const double *q = S->q + (size_t)e * K, *qp = S->qprim + (size_t)e * K;
+  double alpha = S->alphas[e];
+  if (S->msg_fn) return S->msg_fn(S->kernel, K, Di, gamma, msg, q, qp, alpha, S->lambda, dir, mdir);
+  if (S->mode == 0)
+    return oracle_update_message(S->kernel, K, Di, gamma, msg, q, qp, alpha, S->lambda, dir, mdir);
+  double hmin = INFINITY, vmin;
+  for (int k = 0; k < K; ++k) {
+    S->H[k] = gamma * Di[k] - msg[k];
+    if (S->H[k] < hmin) hmin = S->H[k];
+  }
+  if (alpha == 0) {
+    for (int k = 0; k < K; ++k) msg[k] = hmin;
+    vmin = hmin;
+  } else {
+    const double *s, *t; const int32_t *so, *to;
+    if (dir == mdir) { s = qp; t = q; so = S->sort_qp + (size_t)e * K; to = S->sort_q + (size_t)e * K; }
+    else { s = q; t = qp; so = S->sort_q + (size_t)e * K; to = S->sort_qp + (size_t)e * K; }
+    vmin = envelope_message(S->kernel, K, S->H, hmin, msg, s, t, so, to, alpha, S->lambda, S->z, S->v);
+  }
+  for (int k = 0; k < K; ++k) msg[k] -= vmin;
+  return vmin;
+}
+
+/* Full solver = trws_mex.cpp:27-147 behind the C boundary.
+ * unary K x N, q/qprim K x E (label fastest = MATLAB column major), conn 2 x E
+ * zero based, alphas E.  labelling is 1-based like the gateway's.
+ * mode: 0 brute-force messages, 1 envelope messages.  msg_fn / col_fn (may be
+ * NULL) let a test substitute the reference's own type classes from
+ * oracle/_ref.  iter_cb (may be NULL) is called after every iteration with
+ * (iter, energy, lb) -- used to record convergence traces. */
+int oracle_trws(int kernel, const double *unary, const uint32_t *conn, const double *q,
+                const double *qprim, const double *alphas, double tol, double maxiter,
+                double max_relgap, int K, int64_t N, int64_t E, int mode, void *msg_fn,
+                void *col_fn, double *labelling, double *energy, double *lower_bound,
+                double *iterations, double *trace /* may be NULL: 2*maxiter doubles */) {
+  if (kernel != 1 && kernel != 2) return 10; /* trws_mex.cpp:162 "Unsupported kernel" */
+  if (K < 1 || N < 0 || E < 0) return 11;
+  graph_t g;
+  int rc = graph_init(&g, N, E, conn);
+  if (rc) { graph_free(&g); return rc; }
+  if (graph_order(&g)) { graph_free(&g); return 3; }
+  graph_orient(&g);
+
+  solver_t S;
+  memset(&S, 0, sizeof(S));
+  S.kernel = kernel; S.K = K; S.mode = mode; S.q = q; S.qprim = qprim; S.alphas = alphas;
+  S.lambda = tol; S.msg_fn = (msg_fn_t)msg_fn; S.col_fn = (col_fn_t)col_fn;
+  S.H = malloc(sizeof(double) * K); S.z = malloc(sizeof(double) * (K + 2));
+  S.v = malloc(sizeof(int32_t) * (K + 1));
+  if (mode == 1 && !S.msg_fn) {
+    S.sort_q = malloc(sizeof(int32_t) * (size_t)E * K + 4);
+    S.sort_qp = malloc(sizeof(int32_t) * (size_t)E * K + 4);
+    pair_t *tmp = malloc(sizeof(pair_t) * K);
+    for (int64_t e = 0; e < E; ++e) {
+      argsort(q + (size_t)e * K, K, S.sort_q + (size_t)e * K, tmp);
+      argsort(qprim + (size_t)e * K, K, S.sort_qp + (size_t)e * K, tmp);
+    }
+    free(tmp);
+  }
+  double *M = calloc((size_t)E * K + 1, sizeof(double)); /* messages, zeroed (MRFEnergy.cpp:115-133) */
+  double *gam = malloc(sizeof(double) * (N + 1));
+  double *Di = malloc(sizeof(double) * K), *Db = malloc(sizeof(double) * K);
+  int32_t *x = calloc(N + 1, sizeof(int32_t));
+  /* treeProbabilities.cpp:24-45 */
+  for (int64_t i = 0; i < N; ++i) {
+    int nf = 0, nb = 0;
+    for (int64_t e = g.firstF[i]; e >= 0; e = g.nextF[e]) ++nf;
+    for (int64_t e = g.firstB[i]; e >= 0; e = g.nextB[e]) ++nb;
+    int ni = nf > nb ? nf : nb;
+    gam[i] = (double)1 / ni;
+  }
+  int itmax = (int)maxiter; /* trws_mex.cpp:125 */
+  double LB = 0, En = 0;
+  int iter;
+  for (iter = 1;; ++iter) {
+    /* forward pass, minimize.cpp:36-62 */
+    for (int64_t r = 0; r < N; ++r) {
+      int64_t i = g.order[r];
+      memcpy(Di, unary + (size_t)i * K, sizeof(double) * K);
+      for (int64_t e = g.firstF[i]; e >= 0; e = g.nextF[e])
+        for (int k = 0; k < K; ++k) Di[k] += M[(size_t)e * K + k];
+      for (int64_t e = g.firstB[i]; e >= 0; e = g.nextB[e])
+        for (int k = 0; k < K; ++k) Di[k] += M[(size_t)e * K + k];
+      for (int64_t e = g.firstF[i]; e >= 0; e = g.nextF[e])
+        do_update(&S, e, Di, gam[i], M + (size_t)e * K, 0, g.dir[e]);
+    }
+    /* backward pass, minimize.cpp:67-95 */
+    LB = 0;
+    for (int64_t r = N - 1; r >= 0; --r) {
+      int64_t i = g.order[r];
+      memcpy(Di, unary + (size_t)i * K, sizeof(double) * K);
+      for (int64_t e = g.firstB[i]; e >= 0; e = g.nextB[e])
+        for (int k = 0; k < K; ++k) Di[k] += M[(size_t)e * K + k];
+      for (int64_t e = g.firstF[i]; e >= 0; e = g.nextF[e])
+        for (int k = 0; k < K; ++k) Di[k] += M[(size_t)e * K + k];
+      double vmin = Di[0];
+      for (int k = 1; k < K; ++k) if (vmin > Di[k]) vmin = Di[k];
+      for (int k = 0; k < K; ++k) Di[k] -= vmin;
+      LB += vmin;
+      for (int64_t e = g.firstB[i]; e >= 0; e = g.nextB[e])
+        LB += do_update(&S, e, Di, gam[i], M + (size_t)e * K, 1, g.dir[e]);
+    }
+    /* primal, minimize.cpp:223-264 */
+    En = 0;
+    for (int64_t r = 0; r < N; ++r) {
+      int64_t i = g.order[r];
+      memcpy(Db, unary + (size_t)i * K, sizeof(double) * K);
+      for (int64_t e = g.firstB[i]; e >= 0; e = g.nextB[e]) {
+        int64_t j = g.tail[e];
+        if (S.col_fn)
+          S.col_fn(kernel, K, q + (size_t)e * K, qprim + (size_t)e * K, alphas[e], tol, x[j], Db, 0, g.dir[e]);
+        else
+          oracle_add_column(kernel, K, q + (size_t)e * K, qprim + (size_t)e * K, alphas[e], tol, x[j], Db, 0, g.dir[e]);
+      }
+      memcpy(Di, Db, sizeof(double) * K);
+      for (int64_t e = g.firstF[i]; e >= 0; e = g.nextF[e])
+        for (int k = 0; k < K; ++k) Di[k] += M[(size_t)e * K + k];
+      double vmin = Di[0]; int kmin = 0;
+      for (int k = 1; k < K; ++k) if (vmin > Di[k]) { vmin = Di[k]; kmin = k; }
+      x[i] = kmin;
+      En += Db[kmin];
+    }
+    if (trace) { trace[2 * (iter - 1)] = En; trace[2 * (iter - 1) + 1] = LB; }
+    int finish = iter >= itmax;
+    double rel_gap = (En - LB) / En;
+    if (rel_gap < max_relgap) finish = 1;
+    if (finish) break;
+  }
+  for (int64_t i = 0; i < N; ++i) labelling[i] = x[i] + 1;
+  *energy = En; *lower_bound = LB; *iterations = iter;
+  free(M); free(gam); free(Di); free(Db); free(x);
+  free(S.H); free(S.z); free(S.v); free(S.sort_q); free(S.sort_qp);
+  graph_free(&g);
+  return 0;
+}
+
+/* Single-message entry for the envelope variant (fuzzed against the brute force
+ * and against the reference's type classes). */
+double oracle_update_message_envelope(int kernel, int K, const double *Di, double gamma,
+                                      double *msg, const double *q, const double *qprim,
+                                      double alpha, double lambda, int dir, int mdir) {
+  solver_t S;
+  memset(&S, 0, sizeof(S));
+  S.kernel = kernel; S.K = K; S.mode = 1; S.q = q; S.qprim = qprim; S.alphas = &alpha;
+  S.lambda = lambda;
+  S.H = malloc(sizeof(double) * K); S.z = malloc(sizeof(double) * (K + 2));
+  S.v = malloc(sizeof(int32_t) * (K + 1));
+  S.sort_q = malloc(sizeof(int32_t) * K); S.sort_qp = malloc(sizeof(int32_t) * K);
+  pair_t *tmp = malloc(sizeof(pair_t) * K);
+  argsort(q, K, S.sort_q, tmp); argsort(qprim, K, S.sort_qp, tmp);
+  double v = do_update(&S, 0, Di, gamma, msg, dir, mdir);
+  free(tmp); free(S.H); free(S.z); free(S.v); free(S.sort_q); free(S.sort_qp);
+  return v;
+}

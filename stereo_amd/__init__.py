@@ -1,0 +1,11 @@
+"""stereo_amd -- MI355X-native 3D-label stereo energy minimisation.
+
+Host-side mirror (Python) of the reference's MATLAB solver surface
+(`trws.m`, `rd.m`) over the C ABI of ``libstereo_hip.so``
+(``include/stereo_hip.h``).  Names, argument meaning and error behaviour follow
+the reference wrappers; arrays use MATLAB shapes (K x N, 2 x E, ...).
+"""
+from ._lib import StereoHipError, device_count, LIB_PATH  # noqa: F401
+from .trws import trws, TrwsPlan  # noqa: F401
+
+__all__ = ["trws", "TrwsPlan", "StereoHipError", "device_count", "LIB_PATH"]

@@ -1,0 +1,55 @@
+"""ctypes binding of libstereo_hip.so (the C ABI declared in include/stereo_hip.h).
+
+There is NO CPU fallback: if the shared library is missing, or no HIP device is
+visible when a solver is called, the call raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstereo_hip.so")
+
+_dp = C.POINTER(C.c_double)
+_u32p = C.POINTER(C.c_uint32)
+_i64p = C.POINTER(C.c_int64)
+
+_lib = None
+
+
+class StereoHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise StereoHipError(
+                "%s not found: build it with stereo_amd/csrc/build.sh "
+                "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.stereo_hip_last_error.restype = C.c_char_p
+        L.stereo_trws_plan_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+def check(rc, err):
+    if rc != 0:
+        msg = err.value.decode("utf-8", "replace") if err is not None else ""
+        if not msg:
+            msg = lib().stereo_hip_last_error().decode("utf-8", "replace")
+        raise StereoHipError(msg or ("libstereo_hip call failed (rc=%d)" % rc))
+
+
+def errbuf():
+    return C.create_string_buffer(1024)
+
+
+def device_count():
+    return int(lib().stereo_hip_device_count())
+
+
+def require_device():
+    if device_count() < 1:
+        raise StereoHipError("no HIP device visible: the stereo_amd solvers only run on the GPU")

@@ -1,0 +1,80 @@
+// Shared helpers of libstereo_hip.so (error reporting, HIP checks).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+namespace stereo {
+
+std::string &last_error();  // thread local
+
+inline int fail(const std::string &msg, char *err, size_t errcap, int code = 1) {
+  last_error() = msg;
+  if (err && errcap) {
+    std::strncpy(err, msg.c_str(), errcap - 1);
+    err[errcap - 1] = 0;
+  }
+  return code;
+}
+
+struct HipError {
+  std::string msg;
+};
+
+#define STEREO_HIP_CHECK(expr)                                                          \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      char b_[512];                                                                     \
+      std::snprintf(b_, sizeof(b_), "HIP error %d (%s) at %s:%d: %s", (int)e_,          \
+                    hipGetErrorString(e_), __FILE__, __LINE__, #expr);                  \
+      throw ::stereo::HipError{b_};                                                     \
+    }                                                                                   \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    release();
+    if (count == 0) count = 1;
+    STEREO_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+    n = count;
+  }
+  void upload(const T *src, size_t count, hipStream_t s = nullptr) {
+    if (count > n || !p) alloc(count);
+    if (count == 0 || !src) return;
+    STEREO_HIP_CHECK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+};
+
+template <class T>
+struct PinnedBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  ~PinnedBuf() {
+    if (p) (void)hipHostFree(p);
+  }
+  void alloc(size_t count) {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    if (count == 0) count = 1;
+    STEREO_HIP_CHECK(hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault));
+    n = count;
+  }
+};
+
+}  // namespace stereo

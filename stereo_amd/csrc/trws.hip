@@ -1,0 +1,728 @@
+// TRW-S simultaneous fusion on MI355X (gfx950): kernels, plan object, C ABI.
+//
+// Replaces the reference's trws_mex gateway + MRFEnergy core + TypeStereo*
+// message update (cpp/trws_mex.cpp, cpp/trw-s/{minimize,ordering,MRFEnergy}.cpp,
+// cpp/trw-s/typeStereo{Linear,Quadratic}.h).  Built with -ffp-contract=off: the
+// reference runs SSE2 doubles without FMA and every value below is computed
+// with the same association of + - * / so results are bit identical.
+//
+// Layout in HBM (all label-fastest, exactly MATLAB's K x N / K x E column major):
+//   unary [N][K]   messages [E][K]   q,qprim [E][K] (or one shared positions[K])
+//   perm_q, perm_qp [E][K] uint16: ascending sort permutation of q(:,e), qprim(:,e)
+// Work decomposition: the reference node order induces a dependency DAG; nodes
+// of one DAG level are independent.  One workgroup (4 waves) per node, one wave
+// per outgoing message, lane = label.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/stereo_hip.h"
+#include "common.h"
+#include "trws_graph.h"
+
+namespace stereo {
+
+std::string &last_error() {
+  static thread_local std::string s;
+  return s;
+}
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kWaveVecs = 5;  // K-vectors of LDS scratch per wave
+
+struct DevParams {
+  int K, Kp, kernel;
+  double lambda;
+  const double *unary;
+  double *msg;
+  const double *q, *qprim;          // per edge, or null when `pos` is used
+  const double *pos;                // shared positions
+  const uint16_t *perm_q, *perm_qp;  // per edge sort permutations (null with pos)
+  const uint16_t *perm_pos;
+  const double *alpha;
+  const uint8_t *mdir;
+  const int32_t *tail;
+  const int32_t *order;
+  const int32_t *fptr, *fidx, *bptr, *bidx;
+  const double *gamma;
+  const int32_t *lb_pos_node, *lb_pos_edge;
+  double *lbterms, *eterms;
+  int32_t *x;
+};
+
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double o = __shfl_xor(v, off, kWave);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+// (value, index) lexicographic minimum: the FIRST minimum wins
+// (typeStereoLinear.h:242-249 strict '>').
+__device__ __forceinline__ void wave_argmin(double &v, int &i) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double ov = __shfl_xor(v, off, kWave);
+    int oi = __shfl_xor(i, off, kWave);
+    if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+
+template <int KERNEL>
+__device__ __forceinline__ double pair_cost(double alpha, double d, double h) {
+  // typeStereoLinear.h:474 m_alpha*std::abs(d) + hj ; typeStereoQuadratic.h:484 m_alpha*val*val + hj
+  if (KERNEL == 1) return alpha * fabs(d) + h;
+  return alpha * d * d + h;
+}
+
+// Serial construction of the lower envelope, executed by ONE lane, exactly as
+// typeStereoLinear.h:401-460 / typeStereoQuadratic.h:407-470 do it, including
+// their tie and "numerical stability" behaviour (stale breakpoints survive pops).
+// Hs/Qs: heights / positions in ascending position order.  Stack entries are
+// stored by value (sh, sq) with breakpoints z.
+template <int KERNEL>
+__device__ void build_envelope(int K, double alpha, const double *Hs, const double *Qs,
+                               double *sh, double *sq, double *z) {
+  const double inf = __builtin_huge_val();
+  int top = 0;
+  double hj = Hs[0], qj = Qs[0], zt = -inf;
+  sh[0] = hj; sq[0] = qj; z[0] = -inf; z[1] = inf;
+  for (int k = 1; k < K; ++k) {
+    const double hk = Hs[k], qk = Qs[k];
+    for (int guard = k; guard >= 0; --guard) {
+      if (KERNEL == 1) {
+        const double dist = alpha * fabs(qk - qj);
+        if (dist + hk < hj) {
+          if (top == 0) {
+            sh[0] = hk; sq[0] = qk; z[0] = -inf; z[1] = inf; hj = hk; qj = qk;
+            break;  // the reference re-compares the new bottom with itself and breaks
+          }
+          --top; hj = sh[top]; qj = sq[top];
+        } else if (dist + hj <= hk) {
+          break;
+        } else {
+          const double s = ((hk - hj) + alpha * (qk + qj)) / (2 * alpha);
+          if (s >= qk) break;
+          if (s <= qj) break;
+          ++top; sh[top] = hk; sq[top] = qk; z[top] = s; z[top + 1] = inf; hj = hk; qj = qk;
+          break;
+        }
+      } else {
+        if (qk - qj < 1e-8) {
+          if (hj > hk) {
+            if (top == 0) {
+              sh[0] = hk; sq[0] = qk; z[0] = -inf; z[1] = inf; hj = hk; qj = qk; zt = -inf;
+              break;
+            }
+            --top; hj = sh[top]; qj = sq[top]; zt = z[top];
+          } else {
+            break;
+          }
+        } else {
+          const double s = ((hk + alpha * qk * qk) - (hj + alpha * qj * qj)) / (2 * alpha * (qk - qj));
+          if (s <= zt) {
+            --top;
+            if (top < 0) { top = 0; break; }  // unreachable for finite input (z[0] = -inf)
+            hj = sh[top]; qj = sq[top]; zt = z[top];
+          } else {
+            ++top; sh[top] = hk; sq[top] = qk; z[top] = s; z[top + 1] = inf; hj = hk; qj = qk; zt = s;
+            break;
+          }
+        }
+      }
+    }
+  }
+}
+
+// One message update by one wave (typeStereo*.h UpdateMessage).  Di lives in
+// LDS.  Returns vMin (identical in all lanes).
+template <int KERNEL, bool BACKWARD, int MODE>
+__device__ double update_message(const DevParams &p, int e, const double *Di, double gamma,
+                                 double *scratch, int lane) {
+  const int K = p.K, Kp = p.Kp;
+  const double inf = __builtin_huge_val();
+  double *A = scratch;           // exact: Hs   | minplus: H
+  double *B = scratch + Kp;      // exact: Qs   | minplus: S
+  double *sh = scratch + 2 * Kp;
+  double *sq = scratch + 3 * Kp;
+  double *z = scratch + 4 * Kp;  // Kp + 2 entries (allocation has slack)
+  double *m = p.msg + (size_t)e * K;
+  const double alpha = p.alpha[e];
+  const int mdir = p.mdir[e];
+  const int dir = BACKWARD ? 1 : 0;
+  // typeStereoLinear.h:343-357: dir == m_dir -> sources sit in the qprim half
+  const bool src_is_qprim = (dir == mdir);
+  const double *src, *dst;
+  const uint16_t *perm;
+  if (p.pos) {
+    src = dst = p.pos; perm = p.perm_pos;
+  } else {
+    const size_t off = (size_t)e * K;
+    src = (src_is_qprim ? p.qprim : p.q) + off;
+    dst = (src_is_qprim ? p.q : p.qprim) + off;
+    perm = (src_is_qprim ? p.perm_qp : p.perm_q) + off;
+  }
+  double hmin = inf;
+  if (MODE == STEREO_TRWS_MESSAGES_EXACT) {
+    for (int k = lane; k < K; k += kWave) {
+      const int idx = perm[k];
+      const double h = gamma * Di[idx] - m[idx];
+      A[k] = h; B[k] = src[idx];
+      hmin = h < hmin ? h : hmin;
+    }
+  } else {
+    for (int k = lane; k < K; k += kWave) {
+      const double h = gamma * Di[k] - m[k];
+      A[k] = h; B[k] = src[k];
+      hmin = h < hmin ? h : hmin;
+    }
+  }
+  hmin = wave_min(hmin);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  double vmin = inf;
+  double outv[8];  // K <= 8*64
+  if (alpha == 0) {
+    // typeStereoLinear.h:390-396
+#pragma unroll
+    for (int it = 0; it < 8; ++it) outv[it] = hmin;
+    vmin = hmin;
+  } else {
+    const double vtrunc = hmin + alpha * p.lambda;
+    if (MODE == STEREO_TRWS_MESSAGES_EXACT) {
+      if (lane == 0) build_envelope<KERNEL>(K, alpha, A, B, sh, sq, z);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int kd = lane + it * kWave;
+        if (kd < K) {
+          const double t = dst[kd];
+          int j = 0;
+          while (z[j + 1] < t) ++j;
+          const double c = pair_cost<KERNEL>(alpha, t - sq[j], sh[j]);
+          const double v = c < vtrunc ? c : vtrunc;
+          outv[it] = v;
+          vmin = v < vmin ? v : vmin;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int kd = lane + it * kWave;
+        if (kd < K) {
+          const double t = dst[kd];
+          double best = vtrunc;
+          for (int ks = 0; ks < K; ++ks) {
+            const double c = pair_cost<KERNEL>(alpha, t - B[ks], A[ks]);
+            best = c < best ? c : best;
+          }
+          outv[it] = best;
+          vmin = best < vmin ? best : vmin;
+        }
+      }
+    }
+    vmin = wave_min(vmin);
+  }
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int kd = lane + it * kWave;
+    if (kd < K) m[kd] = outv[it] - vmin;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return vmin;
+}
+
+// One DAG level of a sweep: minimize.cpp:36-62 (forward) / :67-95 (backward).
+template <int KERNEL, bool BACKWARD, int MODE>
+__global__ __launch_bounds__(kBlock) void trws_sweep_kernel(DevParams p, const int32_t *ranks) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int K = p.K, Kp = p.Kp;
+  double *Di = lds;
+  double *red = lds + Kp;  // kWavesPerBlock doubles
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  double *scratch = lds + Kp + 8 + (size_t)wave * (kWaveVecs * Kp + 8);
+  const int r = ranks[blockIdx.x];
+  const int node = p.order[r];
+  const int f0 = p.fptr[r], f1 = p.fptr[r + 1], b0 = p.bptr[r], b1 = p.bptr[r + 1];
+  // Di = D + messages, summed in the reference's list order
+  double vloc = __builtin_huge_val();
+  for (int k = tid; k < K; k += kBlock) {
+    double acc = p.unary[(size_t)node * K + k];
+    if (!BACKWARD) {
+      for (int i = f0; i < f1; ++i) acc += p.msg[(size_t)p.fidx[i] * K + k];
+      for (int i = b0; i < b1; ++i) acc += p.msg[(size_t)p.bidx[i] * K + k];
+    } else {
+      for (int i = b0; i < b1; ++i) acc += p.msg[(size_t)p.bidx[i] * K + k];
+      for (int i = f0; i < f1; ++i) acc += p.msg[(size_t)p.fidx[i] * K + k];
+    }
+    Di[k] = acc;
+    vloc = acc < vloc ? acc : vloc;
+  }
+  if (BACKWARD) {
+    vloc = wave_min(vloc);
+    if (lane == 0) red[wave] = vloc;
+    __syncthreads();
+    double vmin = red[0];
+#pragma unroll
+    for (int w = 1; w < kWavesPerBlock; ++w) vmin = red[w] < vmin ? red[w] : vmin;
+    for (int k = tid; k < K; k += kBlock) Di[k] -= vmin;
+    if (tid == 0) p.lbterms[p.lb_pos_node[r]] = vmin;
+  }
+  __syncthreads();
+  const double gamma = p.gamma[r];
+  const int e0 = BACKWARD ? b0 : f0, e1 = BACKWARD ? b1 : f1;
+  const int32_t *elist = BACKWARD ? p.bidx : p.fidx;
+  for (int i = e0 + wave; i < e1; i += kWavesPerBlock) {
+    const int e = elist[i];
+    const double v = update_message<KERNEL, BACKWARD, MODE>(p, e, Di, gamma, scratch, lane);
+    if (BACKWARD && lane == 0) p.lbterms[p.lb_pos_edge[e]] = v;
+  }
+}
+
+// One DAG level of ComputeSolutionAndEnergy (minimize.cpp:223-264).
+template <int KERNEL>
+__global__ __launch_bounds__(kBlock) void trws_primal_kernel(DevParams p, const int32_t *ranks) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int K = p.K;
+  double *redv = lds;
+  int *redi = (int *)(lds + kWavesPerBlock);
+  double *Dbs = lds + 2 * kWavesPerBlock;  // K doubles: DiBackward
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const int r = ranks[blockIdx.x];
+  const int node = p.order[r];
+  const int f0 = p.fptr[r], f1 = p.fptr[r + 1], b0 = p.bptr[r], b1 = p.bptr[r + 1];
+  double bestv = __builtin_huge_val();
+  int besti = 0x7fffffff;
+  for (int k = tid; k < K; k += kBlock) {
+    double db = p.unary[(size_t)node * K + k];
+    for (int i = b0; i < b1; ++i) {
+      const int e = p.bidx[i];
+      const int ks = p.x[p.tail[e]];
+      const double alpha = p.alpha[e];
+      double d;
+      if (p.pos) {
+        d = p.mdir[e] == 0 ? p.pos[ks] - p.pos[k] : p.pos[k] - p.pos[ks];
+      } else {
+        const size_t off = (size_t)e * K;
+        // typeStereoLinear.h:505-517: AddColumn(dir = 0)
+        d = p.mdir[e] == 0 ? p.qprim[off + ks] - p.q[off + k] : p.qprim[off + k] - p.q[off + ks];
+      }
+      const double v = KERNEL == 1 ? fabs(d) : d * d;
+      db += alpha * (v < p.lambda ? v : p.lambda);
+    }
+    Dbs[k] = db;
+    double di = db;
+    for (int i = f0; i < f1; ++i) di += p.msg[(size_t)p.fidx[i] * K + k];
+    if (di < bestv) { bestv = di; besti = k; }  // ascending k per thread: first minimum kept
+  }
+  wave_argmin(bestv, besti);
+  if (lane == 0) { redv[wave] = bestv; redi[wave] = besti; }
+  __syncthreads();
+  if (tid == 0) {
+    double v = redv[0];
+    int bi = redi[0];
+    for (int w = 1; w < kWavesPerBlock; ++w)
+      if (redv[w] < v || (redv[w] == v && redi[w] < bi)) { v = redv[w]; bi = redi[w]; }
+    p.x[node] = bi;
+    p.eterms[r] = Dbs[bi];
+  }
+}
+
+// Ascending sort permutation of each K-vector (ties: lower index first), one
+// wave per vector, bitonic network in LDS.  Replaces the per-edge std::sort of
+// trws_mex.cpp:84-119 (which re-sorts after every push_back).
+__global__ __launch_bounds__(kWave) void argsort_kernel(const double *vals, uint16_t *perm, int K,
+                                                        int P, int64_t count) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double *v = lds;
+  int *id = (int *)(lds + P);
+  const int lane = threadIdx.x;
+  for (int64_t a = blockIdx.x; a < count; a += gridDim.x) {
+    const double *src = vals + (size_t)a * K;
+    for (int i = lane; i < P; i += kWave) {
+      v[i] = i < K ? src[i] : __builtin_huge_val();
+      id[i] = i < K ? i : (0x10000 + i);
+    }
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int t = lane; t < P / 2; t += kWave) {
+          const int lo = (t / stride) * (stride * 2) + (t % stride);
+          const int hi = lo + stride;
+          const bool up = ((lo & size) == 0);
+          const double a0 = v[lo], a1 = v[hi];
+          const int i0 = id[lo], i1 = id[hi];
+          const bool gt = (a0 > a1) || (a0 == a1 && i0 > i1);
+          if (gt == up) { v[lo] = a1; v[hi] = a0; id[lo] = i1; id[hi] = i0; }
+        }
+        __syncthreads();
+      }
+    }
+    uint16_t *dstp = perm + (size_t)a * K;
+    for (int i = lane; i < K; i += kWave) dstp[i] = (uint16_t)id[i];
+    __syncthreads();
+  }
+}
+
+}  // namespace
+}  // namespace stereo
+
+// --------------------------------------------------------------------- plan
+
+using namespace stereo;
+
+struct stereo_trws_plan {
+  int kernel = 1, K = 0, Kp = 0, mode = 0, device = 0;
+  int64_t N = 0, E = 0;
+  TrwsGraph g;
+  // device copies of the graph
+  DevBuf<int32_t> d_tail, d_order, d_fptr, d_fidx, d_bptr, d_bidx, d_lbn, d_lbe, d_levels, d_x;
+  DevBuf<uint8_t> d_mdir;
+  DevBuf<double> d_gamma, d_msg, d_lbterms, d_eterms;
+  // inputs (owned unless bound)
+  DevBuf<double> o_unary, o_q, o_qprim, o_pos, o_alpha;
+  DevBuf<uint16_t> d_perm_q, d_perm_qp, d_perm_pos;
+  const double *unary = nullptr, *q = nullptr, *qprim = nullptr, *pos = nullptr, *alpha = nullptr;
+  double lambda = 0;
+  bool have_inputs = false;
+  PinnedBuf<double> h_lb, h_en;
+  PinnedBuf<int32_t> h_x;
+  double energy = 0, lb = 0;
+  int64_t iterations = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double sweep_ms = 0;
+  int64_t sweep_launches = 0;
+  bool time_sweeps = false;
+  ~stereo_trws_plan() {
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+  }
+};
+
+namespace {
+
+size_t sweep_lds_bytes(int Kp) {
+  return sizeof(double) * (size_t)(Kp + 8 + kWavesPerBlock * (kWaveVecs * Kp + 8));
+}
+size_t primal_lds_bytes(int Kp) { return sizeof(double) * (size_t)(2 * kWavesPerBlock + Kp); }
+
+DevParams make_params(stereo_trws_plan *P) {
+  DevParams p{};
+  p.K = P->K; p.Kp = P->Kp; p.kernel = P->kernel; p.lambda = P->lambda;
+  p.unary = P->unary; p.msg = P->d_msg.p; p.q = P->q; p.qprim = P->qprim; p.pos = P->pos;
+  p.perm_q = P->d_perm_q.p; p.perm_qp = P->d_perm_qp.p; p.perm_pos = P->d_perm_pos.p;
+  p.alpha = P->alpha; p.mdir = P->d_mdir.p; p.tail = P->d_tail.p; p.order = P->d_order.p;
+  p.fptr = P->d_fptr.p; p.fidx = P->d_fidx.p; p.bptr = P->d_bptr.p; p.bidx = P->d_bidx.p;
+  p.gamma = P->d_gamma.p; p.lb_pos_node = P->d_lbn.p; p.lb_pos_edge = P->d_lbe.p;
+  p.lbterms = P->d_lbterms.p; p.eterms = P->d_eterms.p; p.x = P->d_x.p;
+  return p;
+}
+
+template <int KERNEL, int MODE>
+void launch_iteration(stereo_trws_plan *P, const DevParams &p, hipStream_t s) {
+  const TrwsGraph &g = P->g;
+  const int L = (int)g.level_ptr.size() - 1;
+  const size_t lds = sweep_lds_bytes(P->Kp), plds = primal_lds_bytes(P->Kp);
+  if (P->time_sweeps) STEREO_HIP_CHECK(hipEventRecord(P->ev0, s));
+  for (int l = 0; l < L; ++l) {
+    const int cnt = g.level_ptr[l + 1] - g.level_ptr[l];
+    hipLaunchKernelGGL((trws_sweep_kernel<KERNEL, false, MODE>), dim3(cnt), dim3(kBlock), lds, s, p,
+                       P->d_levels.p + g.level_ptr[l]);
+  }
+  for (int l = L - 1; l >= 0; --l) {
+    const int cnt = g.level_ptr[l + 1] - g.level_ptr[l];
+    hipLaunchKernelGGL((trws_sweep_kernel<KERNEL, true, MODE>), dim3(cnt), dim3(kBlock), lds, s, p,
+                       P->d_levels.p + g.level_ptr[l]);
+  }
+  if (P->time_sweeps) STEREO_HIP_CHECK(hipEventRecord(P->ev1, s));
+  for (int l = 0; l < L; ++l) {
+    const int cnt = g.level_ptr[l + 1] - g.level_ptr[l];
+    hipLaunchKernelGGL((trws_primal_kernel<KERNEL>), dim3(cnt), dim3(kBlock), plds, s, p,
+                       P->d_levels.p + g.level_ptr[l]);
+  }
+  STEREO_HIP_CHECK(hipGetLastError());
+  P->sweep_launches += 2 * L;
+}
+
+void run_argsort(const double *vals, uint16_t *perm, int K, int64_t count, hipStream_t s) {
+  int Pw = 2;
+  while (Pw < K) Pw <<= 1;
+  const size_t lds = (size_t)Pw * (sizeof(double) + sizeof(int));
+  const int64_t grid = std::min<int64_t>(count, 256 * 32);
+  hipLaunchKernelGGL(argsort_kernel, dim3((unsigned)grid), dim3(kWave), lds, s, vals, perm, K, Pw, count);
+  STEREO_HIP_CHECK(hipGetLastError());
+}
+
+void finish_inputs(stereo_trws_plan *P) {
+  if (P->pos) {
+    P->d_perm_pos.alloc(P->K);
+    run_argsort(P->pos, P->d_perm_pos.p, P->K, 1, nullptr);
+    P->d_perm_q.release(); P->d_perm_qp.release();
+  } else {
+    P->d_perm_q.alloc((size_t)P->E * P->K);
+    P->d_perm_qp.alloc((size_t)P->E * P->K);
+    run_argsort(P->q, P->d_perm_q.p, P->K, P->E, nullptr);
+    run_argsort(P->qprim, P->d_perm_qp.p, P->K, P->E, nullptr);
+  }
+  STEREO_HIP_CHECK(hipDeviceSynchronize());
+  P->have_inputs = true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int stereo_hip_abi_version(void) { return STEREO_HIP_ABI_VERSION; }
+
+int stereo_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int stereo_hip_set_device(int device) {
+  if (hipSetDevice(device) != hipSuccess) {
+    last_error() = "hipSetDevice failed";
+    return 1;
+  }
+  return 0;
+}
+
+const char *stereo_hip_last_error(void) { return last_error().c_str(); }
+
+int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint32_t *conn,
+                            int message_mode, stereo_trws_plan **plan, char *err, size_t errcap) {
+  if (!plan) return fail("stereo_trws_plan_create: plan is NULL", err, errcap);
+  *plan = nullptr;
+  if (kernel != 1 && kernel != 2) return fail("Unsupported kernel", err, errcap);
+  if (K < 1 || K > 8 * kWave) return fail("stereo_trws: K must be in [1, 512]", err, errcap);
+  if (message_mode != STEREO_TRWS_MESSAGES_EXACT && message_mode != STEREO_TRWS_MESSAGES_MINPLUS)
+    return fail("stereo_trws: unknown message mode", err, errcap);
+  if (stereo_hip_device_count() < 1)
+    return fail("stereo_trws: no HIP device available (the HIP path has no CPU fallback)", err, errcap);
+  try {
+    std::unique_ptr<stereo_trws_plan> P(new stereo_trws_plan);
+    P->kernel = kernel; P->K = K; P->Kp = (K + 1) & ~1; P->mode = message_mode; P->N = N; P->E = E;
+    std::string gerr;
+    if (!build_trws_graph(N, E, conn, P->g, gerr)) return fail(gerr, err, errcap);
+    const TrwsGraph &g = P->g;
+    if (sweep_lds_bytes(P->Kp) > 160 * 1024) return fail("stereo_trws: K too large for LDS", err, errcap);
+    P->d_tail.upload(g.tail.data(), g.tail.size());
+    P->d_order.upload(g.order.data(), g.order.size());
+    P->d_fptr.upload(g.fptr.data(), g.fptr.size());
+    P->d_fidx.upload(g.fidx.data(), g.fidx.size());
+    P->d_bptr.upload(g.bptr.data(), g.bptr.size());
+    P->d_bidx.upload(g.bidx.data(), g.bidx.size());
+    P->d_lbn.upload(g.lb_pos_node.data(), g.lb_pos_node.size());
+    P->d_lbe.upload(g.lb_pos_edge.data(), g.lb_pos_edge.size());
+    P->d_levels.upload(g.level_ranks.data(), g.level_ranks.size());
+    P->d_mdir.upload(g.mdir.data(), g.mdir.size());
+    P->d_gamma.upload(g.gamma.data(), g.gamma.size());
+    P->d_msg.alloc((size_t)E * K);
+    P->d_lbterms.alloc(g.lb_terms);
+    P->d_eterms.alloc(N);
+    P->d_x.alloc(N);
+    P->h_lb.alloc(g.lb_terms); P->h_en.alloc(N); P->h_x.alloc(N);
+    STEREO_HIP_CHECK(hipMemset(P->d_msg.p, 0, sizeof(double) * (size_t)E * K));
+    STEREO_HIP_CHECK(hipMemset(P->d_x.p, 0, sizeof(int32_t) * N));
+    STEREO_HIP_CHECK(hipEventCreate(&P->ev0));
+    STEREO_HIP_CHECK(hipEventCreate(&P->ev1));
+    STEREO_HIP_CHECK(hipDeviceSynchronize());
+    // every sweep kernel may need more than the default 64 KiB of dynamic LDS
+    const int lds = (int)sweep_lds_bytes(P->Kp);
+#define SET_LDS(KER, BW, MD)                                                                      \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_sweep_kernel<KER, BW, MD>,              \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds))
+    SET_LDS(1, false, 0); SET_LDS(1, true, 0); SET_LDS(2, false, 0); SET_LDS(2, true, 0);
+    SET_LDS(1, false, 1); SET_LDS(1, true, 1); SET_LDS(2, false, 1); SET_LDS(2, true, 1);
+#undef SET_LDS
+    *plan = P.release();
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  } catch (const std::exception &e) {
+    return fail(std::string("stereo_trws_plan_create: ") + e.what(), err, errcap);
+  }
+}
+
+void stereo_trws_plan_destroy(stereo_trws_plan *plan) { delete plan; }
+
+int stereo_trws_plan_upload(stereo_trws_plan *P, const double *unary, const double *q,
+                            const double *qprim, const double *positions, const double *alphas,
+                            double tol, char *err, size_t errcap) {
+  if (!P || !unary || !alphas) return fail("stereo_trws_plan_upload: NULL argument", err, errcap);
+  const bool shared = (q == nullptr && qprim == nullptr);
+  if (shared && !positions) return fail("stereo_trws_plan_upload: need q/qprim or positions", err, errcap);
+  if (!shared && (!q || !qprim)) return fail("stereo_trws_plan_upload: q and qprim must both be given", err, errcap);
+  try {
+    const size_t K = P->K;
+    P->o_unary.upload(unary, (size_t)P->N * K);
+    P->o_alpha.upload(alphas, (size_t)P->E);
+    P->unary = P->o_unary.p; P->alpha = P->o_alpha.p;
+    if (shared) {
+      P->o_pos.upload(positions, K);
+      P->pos = P->o_pos.p; P->q = P->qprim = nullptr;
+      P->o_q.release(); P->o_qprim.release();
+    } else {
+      P->o_q.upload(q, (size_t)P->E * K);
+      P->o_qprim.upload(qprim, (size_t)P->E * K);
+      P->q = P->o_q.p; P->qprim = P->o_qprim.p; P->pos = nullptr;
+    }
+    P->lambda = tol;
+    finish_inputs(P);
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+int stereo_trws_plan_bind_device(stereo_trws_plan *P, const double *d_unary, const double *d_q,
+                                 const double *d_qprim, const double *d_positions,
+                                 const double *d_alphas, double tol, char *err, size_t errcap) {
+  if (!P || !d_unary || !d_alphas) return fail("stereo_trws_plan_bind_device: NULL argument", err, errcap);
+  const bool shared = (d_q == nullptr && d_qprim == nullptr);
+  if (shared && !d_positions) return fail("stereo_trws_plan_bind_device: need q/qprim or positions", err, errcap);
+  if (!shared && (!d_q || !d_qprim)) return fail("stereo_trws_plan_bind_device: q and qprim must both be given", err, errcap);
+  try {
+    P->unary = d_unary; P->alpha = d_alphas; P->lambda = tol;
+    if (shared) { P->pos = d_positions; P->q = P->qprim = nullptr; }
+    else { P->q = d_q; P->qprim = d_qprim; P->pos = nullptr; }
+    finish_inputs(P);
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+int stereo_trws_plan_reset(stereo_trws_plan *P, char *err, size_t errcap) {
+  if (!P) return fail("stereo_trws_plan_reset: NULL plan", err, errcap);
+  try {
+    STEREO_HIP_CHECK(hipMemset(P->d_msg.p, 0, sizeof(double) * (size_t)P->E * P->K));
+    STEREO_HIP_CHECK(hipMemset(P->d_x.p, 0, sizeof(int32_t) * P->N));
+    STEREO_HIP_CHECK(hipDeviceSynchronize());
+    P->iterations = 0; P->energy = 0; P->lb = 0;
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+int stereo_trws_plan_iterate(stereo_trws_plan *P, int iters, double max_relgap, void *stream,
+                             int *done_iters, int *stopped, char *err, size_t errcap) {
+  if (!P) return fail("stereo_trws_plan_iterate: NULL plan", err, errcap);
+  if (!P->have_inputs) return fail("stereo_trws_plan_iterate: no inputs uploaded/bound", err, errcap);
+  if (done_iters) *done_iters = 0;
+  if (stopped) *stopped = 0;
+  hipStream_t s = (hipStream_t)stream;
+  try {
+    const DevParams p = make_params(P);
+    for (int it = 0; it < iters; ++it) {
+      if (P->kernel == 1) {
+        if (P->mode == 0) launch_iteration<1, 0>(P, p, s); else launch_iteration<1, 1>(P, p, s);
+      } else {
+        if (P->mode == 0) launch_iteration<2, 0>(P, p, s); else launch_iteration<2, 1>(P, p, s);
+      }
+      STEREO_HIP_CHECK(hipMemcpyAsync(P->h_lb.p, P->d_lbterms.p, sizeof(double) * P->g.lb_terms,
+                                      hipMemcpyDeviceToHost, s));
+      STEREO_HIP_CHECK(hipMemcpyAsync(P->h_en.p, P->d_eterms.p, sizeof(double) * P->N,
+                                      hipMemcpyDeviceToHost, s));
+      STEREO_HIP_CHECK(hipStreamSynchronize(s));
+      if (P->time_sweeps) {
+        float ms = 0;
+        STEREO_HIP_CHECK(hipEventElapsedTime(&ms, P->ev0, P->ev1));
+        P->sweep_ms += ms;
+      }
+      // sums in the reference's order (minimize.cpp:82,92 and :260): sequential, bit exact
+      double lb = 0, en = 0;
+      for (int64_t i = 0; i < P->g.lb_terms; ++i) lb += P->h_lb.p[i];
+      for (int64_t i = 0; i < P->N; ++i) en += P->h_en.p[i];
+      P->lb = lb; P->energy = en; P->iterations += 1;
+      if (done_iters) *done_iters += 1;
+      const double rel_gap = (en - lb) / en;  // minimize.cpp:105
+      if (rel_gap < max_relgap) {
+        if (stopped) *stopped = 1;
+        break;
+      }
+    }
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+int stereo_trws_plan_result(stereo_trws_plan *P, double *labelling, double *energy,
+                            double *lower_bound, double *iterations, char *err, size_t errcap) {
+  if (!P) return fail("stereo_trws_plan_result: NULL plan", err, errcap);
+  try {
+    if (labelling) {
+      STEREO_HIP_CHECK(hipMemcpy(P->h_x.p, P->d_x.p, sizeof(int32_t) * P->N, hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < P->N; ++i) labelling[i] = (double)(P->h_x.p[i] + 1);  // trws_mex.cpp:137
+    }
+    if (energy) *energy = P->energy;
+    if (lower_bound) *lower_bound = P->lb;
+    if (iterations) *iterations = (double)P->iterations;
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+int stereo_trws_plan_info(stereo_trws_plan *P, int64_t *rank, int64_t *levels,
+                          int64_t *max_level_nodes, char *err, size_t errcap) {
+  if (!P) return fail("stereo_trws_plan_info: NULL plan", err, errcap);
+  if (rank) for (int64_t i = 0; i < P->N; ++i) rank[i] = P->g.rank[i];
+  if (levels) *levels = (int64_t)P->g.level_ptr.size() - 1;
+  if (max_level_nodes) *max_level_nodes = P->g.max_level_nodes;
+  return 0;
+}
+
+int stereo_trws_plan_stats(stereo_trws_plan *P, double *sweep_ms, int64_t *sweep_launches, int reset) {
+  if (!P) return 1;
+  if (sweep_ms) *sweep_ms = P->sweep_ms;
+  if (sweep_launches) *sweep_launches = P->sweep_launches;
+  if (reset) { P->sweep_ms = 0; P->sweep_launches = 0; }
+  P->time_sweeps = true;
+  return 0;
+}
+
+int stereo_trws(int kernel, const double *unary, const uint32_t *conn, const double *q,
+                const double *qprim, const double *alphas, double tol, double maxiter,
+                double max_relgap, int K, int64_t N, int64_t E, double *labelling, double *energy,
+                double *lower_bound, double *iterations, char *err, size_t errcap) {
+  if (kernel != 1 && kernel != 2) return fail("Unsupported kernel", err, errcap);  // trws_mex.cpp:162
+  if (!unary || !conn || !q || !qprim || !alphas || !labelling || !energy || !lower_bound || !iterations)
+    return fail("stereo_trws: NULL argument", err, errcap);
+  stereo_trws_plan *P = nullptr;
+  int mode = STEREO_TRWS_MESSAGES_EXACT;
+  if (const char *m = std::getenv("STEREO_HIP_TRWS_MESSAGES"))
+    if (std::string(m) == "minplus") mode = STEREO_TRWS_MESSAGES_MINPLUS;
+  int rc = stereo_trws_plan_create(kernel, K, N, E, conn, mode, &P, err, errcap);
+  if (rc) return rc;
+  rc = stereo_trws_plan_upload(P, unary, q, qprim, nullptr, alphas, tol, err, errcap);
+  if (!rc) {
+    // Minimize_TRW_S always runs at least one iteration (minimize.cpp:31,100-101)
+    int itmax = (int)maxiter;  // trws_mex.cpp:125
+    if (itmax < 1) itmax = 1;
+    rc = stereo_trws_plan_iterate(P, itmax, max_relgap, nullptr, nullptr, nullptr, err, errcap);
+  }
+  if (!rc) rc = stereo_trws_plan_result(P, labelling, energy, lower_bound, iterations, err, errcap);
+  stereo_trws_plan_destroy(P);
+  return rc;
+}
+
+}  // extern "C"

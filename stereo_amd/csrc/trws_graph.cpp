@@ -1,0 +1,202 @@
+// Host-side graph analysis for the TRW-S path.  See trws_graph.h.
+#include "trws_graph.h"
+
+#include "../../include/stereo_hip.h"
+#include "common.h"
+
+#include <algorithm>
+#include <numeric>
+#include <queue>
+
+namespace stereo {
+namespace {
+
+// Boundary set of the ordering heuristic (ordering.cpp:70-152).  The reference
+// keeps a LIFO-prepended doubly linked list and scans it for the FIRST node of
+// minimum remaining degree, which is O(|boundary|) per pick.  The same pick is
+// "minimum degree, ties broken by most recent insertion": one max-heap of
+// insertion stamps per degree value, with lazy invalidation.
+class Boundary {
+ public:
+  explicit Boundary(int max_deg) : buckets_(max_deg + 1), cur_(max_deg + 1) {}
+  void push(int deg, int64_t stamp, int32_t node) {
+    buckets_[deg].emplace(stamp, node);
+    if (deg < cur_) cur_ = deg;
+    ++live_;
+  }
+  // entry is current iff the node is still in the boundary with this degree/stamp
+  template <class Valid>
+  bool pop(Valid valid, int32_t &node) {
+    const int nb = (int)buckets_.size();
+    while (cur_ < nb) {
+      auto &h = buckets_[cur_];
+      while (!h.empty()) {
+        auto top = h.top();
+        h.pop();
+        if (valid(top.second, cur_, top.first)) {
+          node = top.second;
+          return true;
+        }
+      }
+      ++cur_;
+    }
+    return false;
+  }
+
+ private:
+  std::vector<std::priority_queue<std::pair<int64_t, int32_t>>> buckets_;
+  int cur_;
+  int64_t live_ = 0;
+};
+
+}  // namespace
+
+bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
+                      std::string &err) {
+  if (N <= 0 || E < 0) { err = "build_trws_graph: empty problem"; return false; }
+  if (N >= INT32_MAX || E >= INT32_MAX) { err = "build_trws_graph: more than 2^31 nodes/edges"; return false; }
+  g = TrwsGraph();
+  g.N = N; g.E = E;
+  g.tail.resize(E); g.head.resize(E); g.mdir.assign(E, 0);
+  std::vector<int32_t> firstF(N, -1), firstB(N, -1), nextF(E), nextB(E);
+  std::vector<int32_t> deg(N, 0);
+  // AddEdge: prepend to the tail's forward and the head's backward list.
+  for (int64_t e = 0; e < E; ++e) {
+    uint32_t a = conn[2 * e], b = conn[2 * e + 1];
+    if (a >= (uint64_t)N || b >= (uint64_t)N) { err = "connectivity index out of range"; return false; }
+    if (a == b) { err = "self loops are not supported"; return false; }
+    g.tail[e] = (int32_t)a; g.head[e] = (int32_t)b;
+    nextF[e] = firstF[a]; firstF[a] = (int32_t)e;
+    nextB[e] = firstB[b]; firstB[b] = (int32_t)e;
+    ++deg[a]; ++deg[b];
+  }
+  // ---- SetAutomaticOrdering
+  g.order.resize(N); g.rank.assign(N, -1);
+  {
+    const int max_deg = *std::max_element(deg.begin(), deg.end());
+    std::vector<uint8_t> where(N, 2);  // 2 untouched list, 1 boundary, 0 ordered
+    std::vector<int64_t> stamp(N, 0);
+    // untouched nodes never change degree, so the outer "first node of minimum
+    // degree in index order" is a cursor over nodes sorted by (degree, index)
+    std::vector<int32_t> by_deg(N);
+    std::iota(by_deg.begin(), by_deg.end(), 0);
+    std::stable_sort(by_deg.begin(), by_deg.end(),
+                     [&](int32_t x, int32_t y) { return deg[x] < deg[y]; });
+    int64_t cursor = 0, counter = 0, count = 0;
+    Boundary bnd(max_deg);
+    auto valid = [&](int32_t n, int d, int64_t s) { return where[n] == 1 && deg[n] == d && stamp[n] == s; };
+    while (count < N) {
+      while (cursor < N && where[by_deg[cursor]] != 2) ++cursor;
+      if (cursor >= N) { err = "ordering: internal error"; return false; }
+      int32_t seed = by_deg[cursor];
+      where[seed] = 1; stamp[seed] = ++counter;
+      bnd.push(deg[seed], stamp[seed], seed);
+      int32_t i;
+      while (bnd.pop(valid, i)) {
+        where[i] = 0; g.rank[i] = (int32_t)count; g.order[count++] = i;
+        for (int pass = 0; pass < 2; ++pass) {
+          for (int32_t e = pass == 0 ? firstF[i] : firstB[i]; e >= 0;
+               e = pass == 0 ? nextF[e] : nextB[e]) {
+            int32_t j = pass == 0 ? g.head[e] : g.tail[e];
+            if (where[j] == 0) continue;
+            --deg[j];
+            if (where[j] == 2) { where[j] = 1; stamp[j] = ++counter; }
+            bnd.push(deg[j], stamp[j], j);
+          }
+        }
+      }
+    }
+  }
+  // ---- CompleteGraphConstruction: orient low -> high rank, rebuild lists
+  std::fill(firstB.begin(), firstB.end(), -1);
+  for (int64_t r = 0; r < N; ++r) {
+    int32_t i = g.order[r], eprev = -1;
+    for (int32_t e = firstF[i]; e >= 0;) {
+      int32_t j = g.head[e];
+      if (g.rank[i] < g.rank[j]) {
+        nextB[e] = firstB[j]; firstB[j] = e;
+        eprev = e; e = nextF[e];
+      } else {
+        int32_t enext = nextF[e];
+        g.mdir[e] ^= 1; g.tail[e] = j; g.head[e] = i;
+        if (eprev >= 0) nextF[eprev] = enext; else firstF[i] = enext;
+        nextF[e] = firstF[j]; firstF[j] = e;
+        nextB[e] = firstB[i]; firstB[i] = e;
+        e = enext;
+      }
+    }
+  }
+  // ---- flatten to CSR by rank, gamma, levels, lower-bound term positions
+  g.fptr.assign(N + 1, 0); g.bptr.assign(N + 1, 0);
+  g.fidx.resize(E); g.bidx.resize(E); g.gamma.resize(N);
+  int64_t pf = 0, pb = 0;
+  std::vector<int32_t> level(N, 0);
+  int32_t nlev = 0;
+  for (int64_t r = 0; r < N; ++r) {
+    int32_t i = g.order[r];
+    g.fptr[r] = (int32_t)pf; g.bptr[r] = (int32_t)pb;
+    for (int32_t e = firstF[i]; e >= 0; e = nextF[e]) g.fidx[pf++] = e;
+    int32_t lv = 0;
+    for (int32_t e = firstB[i]; e >= 0; e = nextB[e]) {
+      g.bidx[pb++] = e;
+      lv = std::max(lv, level[g.rank[g.tail[e]]] + 1);
+    }
+    level[r] = lv; nlev = std::max(nlev, lv + 1);
+    int nf = (int)(pf - g.fptr[r]), nbk = (int)(pb - g.bptr[r]);
+    int ni = std::max(nf, nbk);
+    g.gamma[r] = ni > 0 ? (double)1 / ni : 1.0;  // isolated node: no edge ever reads gamma
+  }
+  g.fptr[N] = (int32_t)pf; g.bptr[N] = (int32_t)pb;
+  g.level_ptr.assign(nlev + 1, 0);
+  for (int64_t r = 0; r < N; ++r) ++g.level_ptr[level[r] + 1];
+  for (int32_t l = 0; l < nlev; ++l) {
+    g.max_level_nodes = std::max<int64_t>(g.max_level_nodes, g.level_ptr[l + 1]);
+    g.level_ptr[l + 1] += g.level_ptr[l];
+  }
+  g.level_ranks.resize(N);
+  {
+    std::vector<int32_t> fill(g.level_ptr.begin(), g.level_ptr.end() - 1);
+    for (int64_t r = 0; r < N; ++r) g.level_ranks[fill[level[r]]++] = (int32_t)r;
+  }
+  g.lb_pos_node.resize(N); g.lb_pos_edge.assign(E, -1);
+  int64_t pos = 0;
+  for (int64_t r = N - 1; r >= 0; --r) {
+    g.lb_pos_node[r] = (int32_t)pos++;
+    for (int32_t k = g.bptr[r]; k < g.bptr[r + 1]; ++k) g.lb_pos_edge[g.bidx[k]] = (int32_t)pos++;
+  }
+  g.lb_terms = pos;
+  return true;
+}
+
+}  // namespace stereo
+
+extern "C" int stereo_trws_analyze(int64_t N, int64_t E, const uint32_t *conn, int64_t *rank,
+                                   int64_t *tail, int64_t *head, int32_t *mdir, int64_t *fwd_ptr,
+                                   int64_t *fwd_idx, int64_t *bwd_ptr, int64_t *bwd_idx,
+                                   int64_t *level, char *err, size_t errcap) {
+  stereo::TrwsGraph g;
+  std::string gerr;
+  if (!conn && E > 0) return stereo::fail("stereo_trws_analyze: NULL connectivity", err, errcap);
+  if (!stereo::build_trws_graph(N, E, conn, g, gerr)) return stereo::fail(gerr, err, errcap);
+  const int L = (int)g.level_ptr.size() - 1;
+  if (level)
+    for (int l = 0; l < L; ++l)
+      for (int32_t k = g.level_ptr[l]; k < g.level_ptr[l + 1]; ++k) level[g.order[g.level_ranks[k]]] = l;
+  int64_t pf = 0, pb = 0;
+  for (int64_t i = 0; i < N; ++i) {
+    const int32_t r = g.rank[i];
+    if (rank) rank[i] = r;
+    if (fwd_ptr) fwd_ptr[i] = pf;
+    if (bwd_ptr) bwd_ptr[i] = pb;
+    for (int32_t k = g.fptr[r]; k < g.fptr[r + 1]; ++k, ++pf) if (fwd_idx) fwd_idx[pf] = g.fidx[k];
+    for (int32_t k = g.bptr[r]; k < g.bptr[r + 1]; ++k, ++pb) if (bwd_idx) bwd_idx[pb] = g.bidx[k];
+  }
+  if (fwd_ptr) fwd_ptr[N] = pf;
+  if (bwd_ptr) bwd_ptr[N] = pb;
+  for (int64_t e = 0; e < E; ++e) {
+    if (tail) tail[e] = g.tail[e];
+    if (head) head[e] = g.head[e];
+    if (mdir) mdir[e] = g.mdir[e];
+  }
+  return 0;
+}

@@ -1,0 +1,44 @@
+// Host-side graph analysis for the TRW-S path (product code, C++).
+//
+// Produces, for an arbitrary directed edge list, exactly the node order, edge
+// orientation and per-node forward/backward edge lists that the reference
+// builds in MRFEnergy::AddEdge (cpp/trw-s/MRFEnergy.cpp:83-111),
+// SetAutomaticOrdering (cpp/trw-s/ordering.cpp:7-157) and
+// CompleteGraphConstruction (cpp/trw-s/MRFEnergy.cpp:137-229), plus the
+// dependency levels of that order that the level-synchronous HIP sweeps run on.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace stereo {
+
+struct TrwsGraph {
+  int64_t N = 0, E = 0;
+  // per edge, after orientation: tail has the lower rank
+  std::vector<int32_t> tail, head;
+  std::vector<uint8_t> mdir;  // Swap() parity (typeStereoLinear.h:318-321)
+  // node order
+  std::vector<int32_t> order;  // order[r] = node id
+  std::vector<int32_t> rank;   // rank[node]
+  // per RANK r: forward / backward edge ids in the reference's list order (CSR)
+  std::vector<int32_t> fptr, fidx, bptr, bidx;
+  std::vector<double> gamma;  // per rank: 1/max(nFwd,nBwd) (treeProbabilities.cpp:24-45)
+  // dependency levels of the forward sweep (longest path over backward edges)
+  std::vector<int32_t> level_ptr;    // size L+1
+  std::vector<int32_t> level_ranks;  // ranks grouped by level, ascending rank inside
+  int64_t max_level_nodes = 0;
+  // position of every lower-bound term in the reference's summation order
+  // (minimize.cpp:67-95: node minimum, then one term per backward edge, nodes
+  // visited in descending rank); energy terms are simply indexed by rank.
+  std::vector<int32_t> lb_pos_node;  // per rank
+  std::vector<int32_t> lb_pos_edge;  // per edge
+  int64_t lb_terms = 0;
+};
+
+// conn: 2 x E zero-based (column major: conn[2e] = tail, conn[2e+1] = head).
+// Returns false and sets `err` on invalid input.
+bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
+                      std::string &err);
+
+}  // namespace stereo

@@ -1,0 +1,197 @@
+"""Mirror of the reference's ``trws.m`` wrapper and a handle on the
+device-resident plan API.
+
+``trws(kernel, unary, connectivity, q, qprim, alphas, tol, options)`` has the
+argument meaning of trws.m:2-33: ``unary`` is K x N, ``connectivity`` 2 x E and
+ONE based (the wrapper subtracts 1 like trws.m:33), ``q`` / ``qprim`` K x E,
+``alphas`` E x 1, ``options`` a dict with ``maxiter`` (default 1000) and
+``max_relgap`` (default 0) as in trws_mex.cpp:40-41.  Returns
+``(solution, energy, lower_bound, iterations)`` with 1-based labels.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import StereoHipError
+
+MESSAGES_EXACT = 0
+MESSAGES_MINPLUS = 1
+
+
+def _f(a):
+    """MATLAB-shaped array -> column-major float64 buffer."""
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+def _conn0(connectivity):
+    c = np.asarray(connectivity)
+    if c.ndim != 2 or c.shape[0] != 2:
+        raise StereoHipError("connectivity must be 2 x E")  # trws_mex.cpp:43
+    if c.size and c.min() <= 0:
+        raise AssertionError("connectivity must be one based (trws.m:5)")
+    return np.asfortranarray(c.astype(np.int64) - 1, dtype=np.uint32)
+
+
+def _ptr(a, t=C.c_double):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def trws(kernel, unary, connectivity, q, qprim, alphas, tol, options=None):
+    options = dict(options or {})
+    maxiter = float(options.pop("maxiter", 1000))
+    max_relgap = float(options.pop("max_relgap", 0))
+    if options:
+        raise StereoHipError("unknown option(s): %s" % ", ".join(sorted(options)))
+    unary = _f(unary)
+    q = _f(q)
+    qprim = _f(qprim)
+    alphas = _f(np.asarray(alphas, dtype=np.float64).reshape(-1))
+    if np.isnan(q).any():
+        raise StereoHipError("q contains NaN")        # trws.m:9-11
+    if np.isnan(qprim).any():
+        raise StereoHipError("qprim contains NaN")    # trws.m:13-15
+    conn = _conn0(connectivity)
+    K, N = unary.shape
+    E = conn.shape[1]
+    # trws_mex.cpp:43-52
+    if not (q.shape == (K, E) and qprim.shape == (K, E)):
+        raise StereoHipError("q / qprim must be K x E")
+    if alphas.shape[0] != E:
+        raise StereoHipError("alphas must be E x 1")
+    if np.size(tol) != 1:
+        raise StereoHipError("tol must be a scalar")
+    kernel = int(np.int32(kernel))
+    lab = np.zeros(N)
+    en, lb, it = C.c_double(), C.c_double(), C.c_double()
+    err = _lib.errbuf()
+    rc = _lib.lib().stereo_trws(C.c_int(kernel), _ptr(unary), _ptr(conn, C.c_uint32), _ptr(q),
+                                _ptr(qprim), _ptr(alphas), C.c_double(float(np.reshape(tol, -1)[0])),
+                                C.c_double(maxiter), C.c_double(max_relgap), C.c_int(K),
+                                C.c_int64(N), C.c_int64(E), _ptr(lab), C.byref(en), C.byref(lb),
+                                C.byref(it), err, C.c_size_t(len(err)))
+    _lib.check(rc, err)
+    return lab, en.value, lb.value, it.value
+
+
+class TrwsPlan:
+    """Device-resident TRW-S solver for one connectivity (stereo_trws_plan_*)."""
+
+    def __init__(self, kernel, K, N, connectivity0, message_mode=MESSAGES_EXACT):
+        """connectivity0: 2 x E ZERO based pairs (MATLAB layout, as passed to trws_mex)."""
+        c = np.asarray(connectivity0)
+        if c.ndim != 2 or c.shape[0] != 2:
+            raise StereoHipError("connectivity must be 2 x E")
+        self._conn = np.asfortranarray(c, dtype=np.uint32)
+        self.K, self.N, self.E = int(K), int(N), int(self._conn.shape[1])
+        self._h = C.c_void_p()
+        self._keep = []
+        err = _lib.errbuf()
+        rc = _lib.lib().stereo_trws_plan_create(C.c_int(int(kernel)), C.c_int(self.K),
+                                                C.c_int64(self.N), C.c_int64(self.E),
+                                                _ptr(self._conn, C.c_uint32), C.c_int(message_mode),
+                                                C.byref(self._h), err, C.c_size_t(len(err)))
+        _lib.check(rc, err)
+
+    def close(self):
+        if self._h:
+            _lib.lib().stereo_trws_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, unary, alphas, tol, q=None, qprim=None, positions=None):
+        """unary K x N, q/qprim K x E (MATLAB shapes) or a shared `positions` K-vector."""
+        unary = _f(unary)
+        alphas = _f(np.asarray(alphas, dtype=np.float64).reshape(-1))
+        assert unary.shape == (self.K, self.N) and alphas.shape[0] == self.E
+        pq = pqp = ppos = None
+        if q is not None:
+            q = _f(q); qprim = _f(qprim)
+            assert q.shape == (self.K, self.E) and qprim.shape == (self.K, self.E)
+            pq, pqp = _ptr(q), _ptr(qprim)
+        else:
+            positions = _f(np.asarray(positions, dtype=np.float64).reshape(-1))
+            assert positions.shape[0] == self.K
+            ppos = _ptr(positions)
+        err = _lib.errbuf()
+        rc = _lib.lib().stereo_trws_plan_upload(self._h, _ptr(unary), pq, pqp, ppos, _ptr(alphas),
+                                                C.c_double(float(tol)), err, C.c_size_t(len(err)))
+        _lib.check(rc, err)
+
+    def bind_device(self, d_unary, d_alphas, tol, d_q=None, d_qprim=None, d_positions=None,
+                    keepalive=()):
+        """Device pointers (ints), e.g. torch_tensor.data_ptr(); tensors must stay alive."""
+        self._keep = list(keepalive)
+        vp = lambda x: C.c_void_p(int(x)) if x else None
+        err = _lib.errbuf()
+        rc = _lib.lib().stereo_trws_plan_bind_device(self._h, vp(d_unary), vp(d_q), vp(d_qprim),
+                                                     vp(d_positions), vp(d_alphas),
+                                                     C.c_double(float(tol)), err,
+                                                     C.c_size_t(len(err)))
+        _lib.check(rc, err)
+
+    def reset(self):
+        err = _lib.errbuf()
+        _lib.check(_lib.lib().stereo_trws_plan_reset(self._h, err, C.c_size_t(len(err))), err)
+
+    def iterate(self, iters, max_relgap=0.0, stream=None):
+        done, stopped = C.c_int(), C.c_int()
+        err = _lib.errbuf()
+        rc = _lib.lib().stereo_trws_plan_iterate(self._h, C.c_int(int(iters)),
+                                                 C.c_double(float(max_relgap)),
+                                                 C.c_void_p(int(stream)) if stream else None,
+                                                 C.byref(done), C.byref(stopped), err,
+                                                 C.c_size_t(len(err)))
+        _lib.check(rc, err)
+        return done.value, bool(stopped.value)
+
+    def result(self, want_labels=True):
+        lab = np.zeros(self.N) if want_labels else None
+        en, lb, it = C.c_double(), C.c_double(), C.c_double()
+        err = _lib.errbuf()
+        rc = _lib.lib().stereo_trws_plan_result(self._h, _ptr(lab) if want_labels else None,
+                                                C.byref(en), C.byref(lb), C.byref(it), err,
+                                                C.c_size_t(len(err)))
+        _lib.check(rc, err)
+        return lab, en.value, lb.value, it.value
+
+    def info(self):
+        rank = np.zeros(self.N, np.int64)
+        lv, mx = C.c_int64(), C.c_int64()
+        err = _lib.errbuf()
+        rc = _lib.lib().stereo_trws_plan_info(self._h, _ptr(rank, C.c_int64), C.byref(lv),
+                                              C.byref(mx), err, C.c_size_t(len(err)))
+        _lib.check(rc, err)
+        return dict(rank=rank, levels=lv.value, max_level_nodes=mx.value)
+
+    def stats(self, reset=False):
+        ms, n = C.c_double(), C.c_int64()
+        _lib.lib().stereo_trws_plan_stats(self._h, C.byref(ms), C.byref(n), C.c_int(int(reset)))
+        return ms.value, n.value
+
+
+def analyze(N, connectivity0):
+    """Host-only graph analysis (stereo_trws_analyze); connectivity zero based."""
+    c = np.asarray(connectivity0)
+    if c.ndim != 2 or c.shape[0] != 2:
+        raise StereoHipError("connectivity must be 2 x E")
+    c = np.asfortranarray(c, dtype=np.uint32)
+    E = c.shape[1]
+    i64 = lambda n: np.zeros(n, np.int64)
+    out = dict(rank=i64(N), tail=i64(E), head=i64(E), dir=np.zeros(E, np.int32),
+               fwd_ptr=i64(N + 1), fwd_idx=i64(E), bwd_ptr=i64(N + 1), bwd_idx=i64(E),
+               level=i64(N))
+    err = _lib.errbuf()
+    P = lambda a, t=C.c_int64: _ptr(a, t)
+    rc = _lib.lib().stereo_trws_analyze(C.c_int64(N), C.c_int64(E), _ptr(c, C.c_uint32),
+                                        P(out["rank"]), P(out["tail"]), P(out["head"]),
+                                        P(out["dir"], C.c_int32), P(out["fwd_ptr"]),
+                                        P(out["fwd_idx"]), P(out["bwd_ptr"]), P(out["bwd_idx"]),
+                                        P(out["level"]), err, C.c_size_t(len(err)))
+    _lib.check(rc, err)
+    return out
