@@ -1,0 +1,170 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the TRW-S fusion path on MI355X.
+
+Workload at N=1 (BASELINE.json configs[1]): a synthetic Teddy-sized cost volume,
+450 x 375 pixels x 60 fronto-parallel disparity labels (q = qprim = 0..59,
+alphas = 1, tol = 8, kernel 1 -- SURVEY.md 8(d) "Config 2").  A "step" is one
+TRW-S iteration (forward sweep, backward sweep with lower bound, primal
+labelling + energy, stop test), exactly what Minimize_TRW_S does per iteration
+(cpp/trw-s/minimize.cpp:31-113).  Inputs are resident in HBM before the timed
+region.  With --gpus N every rank solves its own image pair (independent
+objects, no data-path collective): weak scaling, value = total iterations/s.
+
+One JSON line is printed by rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def synthetic_volume(H, W, K, seed):
+    """Planted piecewise-planar disparity + noise, as a (N, K) unary in [0, 40)."""
+    rng = np.random.default_rng(seed)
+    rows, cols = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    truth = (0.25 * K + 0.5 * K * (cols / W) + 0.1 * K * np.sin(rows / 37.0)).clip(0, K - 1)
+    truth[(rows // 60 + cols // 75) % 2 == 0] *= 0.6
+    lab = np.arange(K)[None, None, :]
+    cost = np.minimum(np.abs(lab - truth[:, :, None]) / 4.0, 1.0) * 30.0
+    cost = cost + rng.uniform(0, 10, size=cost.shape)
+    return np.ascontiguousarray(cost.transpose(1, 0, 2).reshape(H * W, K))  # node id = col*H + row
+
+
+def algorithmic_bytes_per_sweep_pair(info_deg, K):
+    """per node and sweep read D (K) + every incident message,
+    write the outgoing ones; 8-byte reals.  info_deg = (nf, nb) arrays by node."""
+    nf, nb = info_deg
+    fwd = (1 + nf + nb + nf) * K * 8.0
+    bwd = (1 + nf + nb + nb) * K * 8.0
+    return float(fwd.sum() + bwd.sum())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--height", type=int, default=375)
+    ap.add_argument("--width", type=int, default=450)
+    ap.add_argument("--labels", type=int, default=60)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--message-mode", choices=["exact", "minplus"], default="exact")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    import stereo_amd
+    from stereo_amd import _lib
+    from stereo_amd.trws import TrwsPlan, analyze
+    from helpers import grid_conn
+    _lib.lib().stereo_hip_set_device(local_rank)
+
+    H, W, K = args.height, args.width, args.labels
+    N = H * W
+    conn = grid_conn(H, W)
+    E = conn.shape[0]
+    unary = synthetic_volume(H, W, K, seed=1 + rank)
+    plan = TrwsPlan(1, K, N, conn.T, message_mode=0 if args.message_mode == "exact" else 1)
+    # inputs live in HBM as torch tensors (plumbing only) and are bound, not copied
+    dev = torch.device("cuda", local_rank)
+    d_unary = torch.from_numpy(unary).to(dev)
+    d_alpha = torch.ones(E, dtype=torch.float64, device=dev)
+    d_pos = torch.arange(K, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    plan.bind_device(d_unary.data_ptr(), d_alpha.data_ptr(), 8.0, d_positions=d_pos.data_ptr(),
+                     keepalive=(d_unary, d_alpha, d_pos))
+    plan.stats(reset=True)  # enables per-iteration sweep timing with HIP events
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    plan.iterate(args.warmup)
+    plan.stats(reset=True)
+    plan.serial_messages(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    plan.iterate(args.steps)  # returns after the last iteration's scalars reached the host
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    sweep_ms, sweep_launches = plan.stats()
+    serial_msgs = plan.serial_messages()
+    _, energy, lb, iters = plan.result(want_labels=False)
+
+    if rank == 0:
+        a = analyze(N, conn.T)
+        nf = np.diff(a["fwd_ptr"]).astype(np.float64)
+        nb = np.diff(a["bwd_ptr"]).astype(np.float64)
+        bytes_pair = algorithmic_bytes_per_sweep_pair((nf, nb), K)
+        launches_per_iter = sweep_launches / max(args.steps, 1)
+        bytes_per_launch = bytes_pair / launches_per_iter
+        avg_launch_s = (sweep_ms * 1e-3) / max(sweep_launches, 1)
+        achieved = bytes_per_launch / avg_launch_s / 1e9
+        out = {
+            "metric": "TRW-S fusion iterations/sec, 450x375x60 labels",
+            "value": world * args.steps / dt,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic %dx%dx%d-label cost volume, TRW-S (trws.m drop-in), "
+                                   "kernel 1, tol 8, alphas 1, fronto-parallel labels" % (W, H, K),
+                       "nodes": N, "directed_edges": E, "message_mode": "exact (reference envelope)" if args.message_mode == "exact" else "minplus",
+                       "parallelism": "independent image pair per GPU" if world > 1 else "1 GPU"},
+            "serial_envelope_messages": serial_msgs, "final_energy": energy, "final_lower_bound": lb, "iterations_done": iters,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "trws_sweep_kernel", "bytes_per_launch": bytes_per_launch,
+                         "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches_per_iter},
+        }
+        if not args.no_cpu_baseline:
+            from oracle import pyoracle
+            q = np.tile(np.arange(K, dtype=np.float64), (E, 1))
+            ci = max(args.cpu_iters, 1)
+            r = pyoracle.trws(1, unary, conn, q, q, np.ones(E), 8.0, maxiter=ci, max_relgap=-1e300,
+                              mode=1, want_trace=True)
+            secs = float(r[4][-1, 2])
+            out["cpu_baseline"] = {"value": ci / secs, "unit": "iterations/s", "cores": 1,
+                                   "kind": "port",
+                                   "sample": "%d iterations of the same %dx%dx%d volume, oracle/trws_oracle.c "
+                                             "(envelope messages), setup excluded" % (ci, W, H, K)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

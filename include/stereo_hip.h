@@ -108,6 +108,11 @@ int stereo_trws_plan_info(stereo_trws_plan *plan, int64_t *rank, int64_t *levels
 int stereo_trws_plan_stats(stereo_trws_plan *plan, double *sweep_ms, int64_t *sweep_launches,
                            int reset);
 
+/* Diagnostics: number of message updates (since the last reset) for which the fast
+ * min-plus path could not certify equality with the reference's serial envelope
+ * construction and the serial construction was run instead. */
+int stereo_trws_plan_counters(stereo_trws_plan *plan, int64_t *serial_messages, int reset);
+
 /* Host-only graph analysis behind stereo_trws_plan_create (no device needed):
  * node order of SetAutomaticOrdering (ordering.cpp:7-157), edge orientation and
  * per-node forward/backward edge lists of CompleteGraphConstruction

@@ -108,7 +108,7 @@ def trws(kernel, unary, conn, q, qprim, alphas, tol, maxiter=1000, max_relgap=0.
             raise RuntimeError("oracle/_ref/libref_trws_types.so not available")
         msg_fn = C.cast(r.ref_update_message, C.c_void_p)
         col_fn = C.cast(r.ref_add_column, C.c_void_p)
-    trace = np.zeros((int(maxiter), 2)) if want_trace else None
+    trace = np.zeros((int(maxiter), 3)) if want_trace else None
     rc = lib().oracle_trws(C.c_int(int(kernel)), pu, pc, pq, pqp, pa, C.c_double(tol),
                            C.c_double(maxiter), C.c_double(max_relgap), C.c_int(K),
                            C.c_int64(N), C.c_int64(E), C.c_int(mode), msg_fn, col_fn,

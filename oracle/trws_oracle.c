@@ -32,6 +32,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #if defined(__FMA__)
 #error "build without FMA contraction targets (no -march=native): reference is SSE2"
@@ -313,6 +314,14 @@ static double envelope_message(int kernel, int K, const double *H, double hmin, 
 
 /* ---------------------------------------------------------------- the run */
 
+/* mode 2 diagnostics (linear + quadratic): per message, compare the envelope result with
+ * the brute-force min-plus and evaluate the "no near tangency + unique minimum"
+ * certificate the HIP fast path uses to prove both are bitwise equal. */
+static int64_t g_diag[8];
+void oracle_trws_diag(int64_t *out, int reset) {
+  for (int i = 0; i < 8; ++i) { if (out) out[i] = g_diag[i]; if (reset) g_diag[i] = 0; }
+}
+
 typedef struct {
   int kernel, K, mode;
   const double *q, *qprim, *alphas;
@@ -330,6 +339,12 @@ static double do_update(solver_t *S, int64_t e, const double *Di, double gamma, 
   if (S->msg_fn) return S->msg_fn(S->kernel, K, Di, gamma, msg, q, qp, alpha, S->lambda, dir, mdir);
   if (S->mode == 0)
     return oracle_update_message(S->kernel, K, Di, gamma, msg, q, qp, alpha, S->lambda, dir, mdir);
+  double *brute = NULL; double vbrute = 0;
+  if (S->mode == 2) {
+    brute = malloc(sizeof(double) * K);
+    memcpy(brute, msg, sizeof(double) * K);
+    vbrute = oracle_update_message(S->kernel, K, Di, gamma, brute, q, qp, alpha, S->lambda, dir, mdir);
+  }
   double hmin = INFINITY, vmin;
   for (int k = 0; k < K; ++k) {
     S->H[k] = gamma * Di[k] - msg[k];
@@ -343,8 +358,37 @@ static double do_update(solver_t *S, int64_t e, const double *Di, double gamma, 
     if (dir == mdir) { s = qp; t = q; so = S->sort_qp + (size_t)e * K; to = S->sort_q + (size_t)e * K; }
     else { s = q; t = qp; so = S->sort_q + (size_t)e * K; to = S->sort_qp + (size_t)e * K; }
     vmin = envelope_message(S->kernel, K, S->H, hmin, msg, s, t, so, to, alpha, S->lambda, S->z, S->v);
+    if (S->mode == 2 && S->kernel == 1) {
+      /* certificate */
+      double hmax = 0, qmin = INFINITY, qmax = -INFINITY;
+      for (int k = 0; k < K; ++k) { double a = fabs(S->H[k]); if (a > hmax) hmax = a; if (s[k] < qmin) qmin = s[k]; if (s[k] > qmax) qmax = s[k]; if (t[k] < qmin) qmin = t[k]; if (t[k] > qmax) qmax = t[k]; }
+      double delta = 1e-9 * (hmax + alpha * (qmax - qmin) + alpha * S->lambda);
+      int fail_nnt = 0, fail_margin = 0;
+      for (int j = 0; j < K && !fail_nnt; ++j)
+        for (int k = j + 1; k < K; ++k) {
+          double dq = fabs(s[k] - s[j]);
+          if (dq == 0) continue;
+          double dh = fabs(S->H[k] - S->H[j]);
+          if (fabs(dh - alpha * dq) <= delta) { fail_nnt = 1; break; }
+        }
+      double vtrunc = hmin + alpha * S->lambda;
+      for (int kd = 0; kd < K && !fail_margin; ++kd) {
+        double m1 = INFINITY;
+        for (int ks = 0; ks < K; ++ks) { double c = alpha * fabs(t[kd] - s[ks]) + S->H[ks]; if (c < m1) m1 = c; }
+        if (m1 >= vtrunc) continue;
+        for (int ks = 0; ks < K; ++ks) { double c = alpha * fabs(t[kd] - s[ks]) + S->H[ks]; if (c > m1 && c <= m1 + delta) { fail_margin = 1; break; } }
+      }
+      g_diag[2] += fail_nnt; g_diag[3] += fail_margin; g_diag[4] += (fail_nnt || fail_margin);
+    }
   }
   for (int k = 0; k < K; ++k) msg[k] -= vmin;
+  if (S->mode == 2) {
+    g_diag[0] += 1;
+    int neq = (vbrute != vmin);
+    for (int k = 0; k < K && !neq; ++k) if (brute[k] != msg[k]) neq = 1;
+    g_diag[1] += neq;
+    free(brute);
+  }
   return vmin;
 }
 
@@ -353,13 +397,13 @@ static double do_update(solver_t *S, int64_t e, const double *Di, double gamma, 
  * zero based, alphas E.  labelling is 1-based like the gateway's.
  * mode: 0 brute-force messages, 1 envelope messages.  msg_fn / col_fn (may be
  * NULL) let a test substitute the reference's own type classes from
- * oracle/_ref.  iter_cb (may be NULL) is called after every iteration with
- * (iter, energy, lb) -- used to record convergence traces. */
+ * oracle/_ref.  trace (may be NULL) receives (energy, lb, elapsed seconds) per
+ * iteration. */
 int oracle_trws(int kernel, const double *unary, const uint32_t *conn, const double *q,
                 const double *qprim, const double *alphas, double tol, double maxiter,
                 double max_relgap, int K, int64_t N, int64_t E, int mode, void *msg_fn,
                 void *col_fn, double *labelling, double *energy, double *lower_bound,
-                double *iterations, double *trace /* may be NULL: 2*maxiter doubles */) {
+                double *iterations, double *trace /* may be NULL: 3*maxiter doubles */) {
   if (kernel != 1 && kernel != 2) return 10; /* trws_mex.cpp:162 "Unsupported kernel" */
   if (K < 1 || N < 0 || E < 0) return 11;
   graph_t g;
@@ -374,7 +418,7 @@ int oracle_trws(int kernel, const double *unary, const uint32_t *conn, const dou
   S.lambda = tol; S.msg_fn = (msg_fn_t)msg_fn; S.col_fn = (col_fn_t)col_fn;
   S.H = malloc(sizeof(double) * K); S.z = malloc(sizeof(double) * (K + 2));
   S.v = malloc(sizeof(int32_t) * (K + 1));
-  if (mode == 1 && !S.msg_fn) {
+  if (mode >= 1 && !S.msg_fn) {
     S.sort_q = malloc(sizeof(int32_t) * (size_t)E * K + 4);
     S.sort_qp = malloc(sizeof(int32_t) * (size_t)E * K + 4);
     pair_t *tmp = malloc(sizeof(pair_t) * K);
@@ -399,6 +443,8 @@ int oracle_trws(int kernel, const double *unary, const uint32_t *conn, const dou
   int itmax = (int)maxiter; /* trws_mex.cpp:125 */
   double LB = 0, En = 0;
   int iter;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
   for (iter = 1;; ++iter) {
     /* forward pass, minimize.cpp:36-62 */
     for (int64_t r = 0; r < N; ++r) {
@@ -447,7 +493,11 @@ int oracle_trws(int kernel, const double *unary, const uint32_t *conn, const dou
       x[i] = kmin;
       En += Db[kmin];
     }
-    if (trace) { trace[2 * (iter - 1)] = En; trace[2 * (iter - 1) + 1] = LB; }
+    if (trace) { /* energy, lower bound, seconds since the first sweep started */
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      trace[3 * (iter - 1)] = En; trace[3 * (iter - 1) + 1] = LB;
+      trace[3 * (iter - 1) + 2] = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    }
     int finish = iter >= itmax;
     double rel_gap = (En - LB) / En;
     if (rel_gap < max_relgap) finish = 1;

@@ -59,7 +59,43 @@ struct DevParams {
   const int32_t *lb_pos_node, *lb_pos_edge;
   double *lbterms, *eterms;
   int32_t *x;
+  // persistent dataflow sweeps
+  const int32_t *run_ptr[2];
+  int nruns[2];
+  const int32_t *dep_ptr[2], *dep_rank[2];
+  const int8_t *in_slot[2];
+  int32_t *done;    // per rank: epoch of the last completed visit
+  int32_t *ticket;  // run dispenser of the current launch
+  int32_t *abort_flag;
+  int N;
+  unsigned long long *fallbacks;  // messages that needed the serial envelope (diagnostics)
+  int certificate;                // 0: always run the serial envelope
 };
+
+// ---- agent-scope (sc1) accesses: data handed between workgroups inside one launch
+// never sits in a per-CU L1 or a non-coherent L2 (cdna_hip_programming.md G16, R1/R2).
+__device__ __forceinline__ double ld_sc1(const double *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(double *p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_sc1(const int32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(int32_t *p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+// wave-uniform predicate -> scalar branch
+#define UNI(c) (__builtin_amdgcn_ballot_w64(c) != 0)
+
 
 __device__ __forceinline__ double wave_min(double v) {
 #pragma unroll
@@ -147,18 +183,86 @@ __device__ void build_envelope(int K, double alpha, const double *Hs, const doub
   }
 }
 
+// The same construction with the whole state in registers, for K <= 64: lane k
+// holds the k-th sorted source (hs, qs); afterwards lane j holds stack slot j
+// (sh, sq) and zz = z[j+1].  All arithmetic is wave-uniform (operands come from
+// v_readlane), so every lane computes exactly what the reference's scalar code
+// computes; branches are scalar.  Returns the highest slot ever written.
+template <int KERNEL>
+__device__ __forceinline__ int build_envelope_regs(int K, double alpha, double hs, double qs,
+                                                   double &sh, double &sq, double &zz, int lane) {
+  const double inf = __builtin_huge_val();
+  int top = 0, maxtop = 0;
+  double hj = readlane_f64(hs, 0), qj = readlane_f64(qs, 0), zt = -inf;
+  sh = hj; sq = qj; zz = inf;
+  for (int k = 1; k < K; ++k) {
+    const double hk = readlane_f64(hs, k), qk = readlane_f64(qs, k);
+    for (;;) {
+      if (KERNEL == 1) {
+        const double dist = alpha * fabs(qk - qj);
+        if (UNI(dist + hk < hj)) {
+          if (top == 0) {
+            if (lane == 0) { sh = hk; sq = qk; zz = inf; }
+            hj = hk; qj = qk;
+            break;
+          }
+          --top; hj = readlane_f64(sh, top); qj = readlane_f64(sq, top);
+        } else if (UNI(dist + hj <= hk)) {
+          break;
+        } else {
+          const double s = ((hk - hj) + alpha * (qk + qj)) / (2 * alpha);
+          if (UNI(s >= qk)) break;
+          if (UNI(s <= qj)) break;
+          if (lane == top) zz = s;  // z[top+1] = s
+          ++top;
+          if (lane == top) { sh = hk; sq = qk; zz = inf; }
+          hj = hk; qj = qk;
+          break;
+        }
+      } else {
+        if (UNI(qk - qj < 1e-8)) {
+          if (UNI(hj > hk)) {
+            if (top == 0) {
+              if (lane == 0) { sh = hk; sq = qk; zz = inf; }
+              hj = hk; qj = qk; zt = -inf;
+              break;
+            }
+            --top; hj = readlane_f64(sh, top); qj = readlane_f64(sq, top);
+            zt = top == 0 ? -inf : readlane_f64(zz, top - 1);
+          } else {
+            break;
+          }
+        } else {
+          const double s = ((hk + alpha * qk * qk) - (hj + alpha * qj * qj)) / (2 * alpha * (qk - qj));
+          if (UNI(s <= zt)) {
+            if (top == 0) break;  // unreachable for finite input (z[0] = -inf)
+            --top; hj = readlane_f64(sh, top); qj = readlane_f64(sq, top);
+            zt = top == 0 ? -inf : readlane_f64(zz, top - 1);
+          } else {
+            if (lane == top) zz = s;
+            ++top;
+            if (lane == top) { sh = hk; sq = qk; zz = inf; }
+            hj = hk; qj = qk; zt = s;
+            break;
+          }
+        }
+      }
+    }
+    maxtop = top > maxtop ? top : maxtop;
+  }
+  return maxtop;
+}
+
 // One message update by one wave (typeStereo*.h UpdateMessage).  Di lives in
-// LDS.  Returns vMin (identical in all lanes).
-template <int KERNEL, bool BACKWARD, int MODE>
+// LDS.  Returns vMin (identical in all lanes).  SC1: the new message is stored
+// write-through at agent scope (it is consumed by another workgroup inside the
+// same launch); `handoff` (LDS, may be null) additionally receives it for the
+// next node of the same run.
+template <int KERNEL, bool BACKWARD, int MODE, bool SC1>
 __device__ double update_message(const DevParams &p, int e, const double *Di, double gamma,
-                                 double *scratch, int lane) {
+                                 double *scratch, double *handoff, int lane) {
   const int K = p.K, Kp = p.Kp;
   const double inf = __builtin_huge_val();
-  double *A = scratch;           // exact: Hs   | minplus: H
-  double *B = scratch + Kp;      // exact: Qs   | minplus: S
-  double *sh = scratch + 2 * Kp;
-  double *sq = scratch + 3 * Kp;
-  double *z = scratch + 4 * Kp;  // Kp + 2 entries (allocation has slack)
   double *m = p.msg + (size_t)e * K;
   const double alpha = p.alpha[e];
   const int mdir = p.mdir[e];
@@ -175,6 +279,88 @@ __device__ double update_message(const DevParams &p, int e, const double *Di, do
     dst = (src_is_qprim ? p.q : p.qprim) + off;
     perm = (src_is_qprim ? p.perm_qp : p.perm_q) + off;
   }
+  if (MODE == STEREO_TRWS_MESSAGES_EXACT && K <= kWave) {
+    // ---- register path, lane = label
+    double h = inf, qsrc = 0, t = 0;
+    if (lane < K) {
+      h = gamma * Di[lane] - m[lane];
+      qsrc = src[lane];
+      t = dst[lane];
+    }
+    const double hmin = wave_min(h);
+    double out, vmin;
+    if (UNI(alpha == 0)) {
+      out = hmin; vmin = hmin;  // typeStereoLinear.h:390-396
+    } else {
+      const double vtrunc = hmin + alpha * p.lambda;
+      bool need_serial = true;
+      out = vtrunc;
+      if (KERNEL == 1 && p.certificate) {
+        // Fast path: plain min-plus over all sources plus a certificate that the
+        // reference's serial envelope construction yields the very same bits
+        // (DESIGN.md "message certificate"): (i) no cone apex lies within delta of
+        // another cone (u = h - alpha q and v = h + alpha q pairwise delta-separated
+        // for distinct positions), so every comparison the serial algorithm makes
+        // is decided as in real arithmetic and it builds the true lower envelope;
+        // (ii) the minimum over the cones is delta-separated from the next larger
+        // cost at every destination whose minimum beats the truncation value, so
+        // rounding in the envelope's breakpoints cannot select a different value.
+        const double aq = alpha * qsrc;
+        const double ui = h - aq, vi = h + aq;
+        double mag = lane < K ? fabs(h) + fabs(aq) + alpha * fabs(t) : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const double o = __shfl_xor(mag, off, kWave);
+          mag = o > mag ? o : mag;
+        }
+        const double delta = 1e-9 * (mag + fabs(alpha * p.lambda));
+        double m1 = inf, m2 = inf;
+        bool bad = !(delta < inf);
+        for (int j = 0; j < K; ++j) {
+          const double hj = readlane_f64(h, j), qj = readlane_f64(qsrc, j);
+          const double c = pair_cost<1>(alpha, t - qj, hj);
+          if (c < m1) { m2 = m1; m1 = c; } else if (c > m1 && c < m2) { m2 = c; }
+          const double aqj = alpha * qj;
+          const double uj = hj - aqj, vj = hj + aqj;
+          const bool near = (fabs(ui - uj) <= delta) || (fabs(vi - vj) <= delta);
+          bad = bad || (near && qsrc != qj);
+        }
+        bad = bad || (m1 < vtrunc && !(m2 - m1 > delta));
+        need_serial = UNI(lane < K && bad);
+        out = m1 < vtrunc ? m1 : vtrunc;
+        if (need_serial && lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
+      }
+      if (need_serial) {
+        // the reference's serial envelope, lane k = k-th source in ascending position order
+        const int idx = lane < K ? perm[lane] : lane;
+        const double hs = __shfl(h, idx, kWave), qs = __shfl(qsrc, idx, kWave);
+        double sh, sq, zz;
+        const int maxtop = build_envelope_regs<KERNEL>(K, alpha, hs, qs, sh, sq, zz, lane);
+        // while (z[j+1] < t) ++j, walked over the slots with uniform reads
+        double ch = 0, cq = 0;
+        bool walking = true;
+        for (int j = 0; j <= maxtop; ++j) {
+          const double shj = readlane_f64(sh, j), sqj = readlane_f64(sq, j), zj1 = readlane_f64(zz, j);
+          if (walking) { ch = shj; cq = sqj; walking = zj1 < t; }
+        }
+        const double c = pair_cost<KERNEL>(alpha, t - cq, ch);
+        out = c < vtrunc ? c : vtrunc;
+      }
+      vmin = wave_min(lane < K ? out : inf);
+    }
+    if (lane < K) {
+      const double v = out - vmin;
+      if (SC1) st_sc1(m + lane, v); else m[lane] = v;
+      if (handoff) handoff[lane] = v;
+    }
+    return vmin;
+  }
+  // ---- LDS path (K > 64, or plain min-plus)
+  double *A = scratch;           // exact: Hs   | minplus: H
+  double *B = scratch + Kp;      // exact: Qs   | minplus: S
+  double *sh = scratch + 2 * Kp;
+  double *sq = scratch + 3 * Kp;
+  double *z = scratch + 4 * Kp;  // Kp + 2 entries (allocation has slack)
   double hmin = inf;
   if (MODE == STEREO_TRWS_MESSAGES_EXACT) {
     for (int k = lane; k < K; k += kWave) {
@@ -240,7 +426,11 @@ __device__ double update_message(const DevParams &p, int e, const double *Di, do
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int kd = lane + it * kWave;
-    if (kd < K) m[kd] = outv[it] - vmin;
+    if (kd < K) {
+      const double v = outv[it] - vmin;
+      if (SC1) st_sc1(m + kd, v); else m[kd] = v;
+      if (handoff) handoff[kd] = v;
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -289,7 +479,7 @@ __global__ __launch_bounds__(kBlock) void trws_sweep_kernel(DevParams p, const i
   const int32_t *elist = BACKWARD ? p.bidx : p.fidx;
   for (int i = e0 + wave; i < e1; i += kWavesPerBlock) {
     const int e = elist[i];
-    const double v = update_message<KERNEL, BACKWARD, MODE>(p, e, Di, gamma, scratch, lane);
+    const double v = update_message<KERNEL, BACKWARD, MODE, false>(p, e, Di, gamma, scratch, nullptr, lane);
     if (BACKWARD && lane == 0) p.lbterms[p.lb_pos_edge[e]] = v;
   }
 }
@@ -340,6 +530,149 @@ __global__ __launch_bounds__(kBlock) void trws_primal_kernel(DevParams p, const 
       if (redv[w] < v || (redv[w] == v && redi[w] < bi)) { v = redv[w]; bi = redi[w]; }
     p.x[node] = bi;
     p.eterms[r] = Dbs[bi];
+  }
+}
+
+// ---- persistent dataflow sweep -------------------------------------------------
+// One launch = one whole sweep (minimize.cpp:36-62 or :67-95), optionally fused
+// with the primal pass of the previous iteration (minimize.cpp:223-264; both
+// visit the nodes in the same order and the primal only needs the forward
+// messages as they are BEFORE this visit overwrites them).  Workgroups draw
+// runs (grid rows, the border chain) from a ticket counter in processing order
+// and walk them node by node; a node starts when the completion flags of its
+// other incoming neighbours carry this launch's epoch.  Runs only ever wait on
+// runs with a smaller ticket, which are already held by resident workgroups, so
+// any grid size makes progress.  Messages produced in this launch travel
+// write-through (sc1 store -> vmcnt(0) -> barrier -> sc1 flag; consumer: sc1
+// poll -> sc1 loads), the hand-over to the next node of the same run goes
+// through LDS.
+constexpr int kMaxSlots = TrwsGraph::kMaxSlots;
+constexpr int kSpinLimit = 1 << 22;  // polls before a launch gives up (bounded spin)
+
+template <int KERNEL, bool BACKWARD, int MODE, bool PRIMAL, bool UPDATE>
+__global__ __launch_bounds__(kBlock) void trws_persistent_kernel(DevParams p, int epoch) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int K = p.K, Kp = p.Kp;
+  double *Di = lds;                       // Kp
+  double *red = lds + Kp;                 // 8
+  double *hand = lds + Kp + 8;            // kMaxSlots * Kp : messages for the next node of the run
+  double *Dbs = hand + kMaxSlots * Kp;    // Kp : DiBackward of the primal pass
+  double *wscratch = Dbs + Kp;            // per-wave scratch of the LDS message path
+  int *s_run = (int *)(red + 6);
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  double *scratch = wscratch + (size_t)wave * (kWaveVecs * Kp + 8);
+  constexpr int D = BACKWARD ? 1 : 0;
+  const int32_t *optr = BACKWARD ? p.bptr : p.fptr, *oidx = BACKWARD ? p.bidx : p.fidx;
+  const int32_t *iptr = BACKWARD ? p.fptr : p.bptr, *iidx = BACKWARD ? p.fidx : p.bidx;
+  const int8_t *in_slot = p.in_slot[D];
+  const int N = p.N;
+  for (;;) {
+    if (tid == 0) *s_run = atomicAdd(p.ticket, 1);
+    __syncthreads();
+    const int run = *s_run;
+    __syncthreads();
+    if (run >= p.nruns[D]) break;
+    const int p0 = p.run_ptr[D][run], p1 = p.run_ptr[D][run + 1];
+    for (int pos = p0; pos < p1; ++pos) {
+      const int r = BACKWARD ? N - 1 - pos : pos;
+      const int node = p.order[r];
+      const int o0 = optr[r], o1 = optr[r + 1], i0 = iptr[r], i1 = iptr[r + 1];
+      // ---- wait for the incoming neighbours that other workgroups own
+      const int d0 = p.dep_ptr[D][r], nd = p.dep_ptr[D][r + 1] - d0;
+      int gave_up = 0;
+      if (tid < nd) {
+        const int32_t *flag = p.done + p.dep_rank[D][d0 + tid];
+        int spins = 0;
+        while (ld_sc1(flag) < epoch) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > kSpinLimit || ((spins & 1023) == 0 && ld_sc1(p.abort_flag))) {
+            st_sc1(p.abort_flag, 1);
+            gave_up = 1;
+            break;
+          }
+        }
+      }
+      if (__syncthreads_or(gave_up)) return;  // bounded spin: the host reports the failure
+      // ---- primal of the previous iteration (needs the outgoing messages before the update)
+      if (PRIMAL) {
+        double bestv = __builtin_huge_val();
+        int besti = 0x7fffffff;
+        for (int k = tid; k < K; k += kBlock) {
+          double db = p.unary[(size_t)node * K + k];
+          // incoming list of the forward order = backward edges (minimize.cpp:240-247)
+          for (int i = i0; i < i1; ++i) {
+            const int e = iidx[i];
+            const int ks = ld_sc1(p.x + p.tail[e]);
+            const double alpha = p.alpha[e];
+            double d;
+            if (p.pos) {
+              d = p.mdir[e] == 0 ? p.pos[ks] - p.pos[k] : p.pos[k] - p.pos[ks];
+            } else {
+              const size_t off = (size_t)e * K;
+              d = p.mdir[e] == 0 ? p.qprim[off + ks] - p.q[off + k] : p.qprim[off + k] - p.q[off + ks];
+            }
+            const double v = KERNEL == 1 ? fabs(d) : d * d;
+            db += alpha * (v < p.lambda ? v : p.lambda);
+          }
+          Dbs[k] = db;
+          double di = db;
+          for (int i = o0; i < o1; ++i) di += p.msg[(size_t)oidx[i] * K + k];
+          if (di < bestv) { bestv = di; besti = k; }
+        }
+        wave_argmin(bestv, besti);
+        if (lane == 0) { red[wave] = bestv; ((int *)(red + 4))[wave] = besti; }
+        __syncthreads();
+        if (tid == 0) {
+          double v = red[0];
+          int bi = ((int *)(red + 4))[0];
+          for (int w = 1; w < kWavesPerBlock; ++w) {
+            const double rv = red[w];
+            const int ri = ((int *)(red + 4))[w];
+            if (rv < v || (rv == v && ri < bi)) { v = rv; bi = ri; }
+          }
+          st_sc1(p.x + node, bi);
+          p.eterms[r] = Dbs[bi];
+        }
+        __syncthreads();
+      }
+      if (UPDATE) {
+        // ---- Di = D + outgoing-list messages (from the previous sweep) + incoming ones
+        double vloc = __builtin_huge_val();
+        for (int k = tid; k < K; k += kBlock) {
+          double acc = p.unary[(size_t)node * K + k];
+          for (int i = o0; i < o1; ++i) acc += p.msg[(size_t)oidx[i] * K + k];
+          for (int i = i0; i < i1; ++i) {
+            const int sl = in_slot[i];
+            acc += sl >= 0 ? hand[sl * Kp + k] : ld_sc1(p.msg + (size_t)iidx[i] * K + k);
+          }
+          Di[k] = acc;
+          vloc = acc < vloc ? acc : vloc;
+        }
+        if (BACKWARD) {
+          vloc = wave_min(vloc);
+          if (lane == 0) red[wave] = vloc;
+          __syncthreads();
+          double vmin = red[0];
+#pragma unroll
+          for (int w = 1; w < kWavesPerBlock; ++w) vmin = red[w] < vmin ? red[w] : vmin;
+          for (int k = tid; k < K; k += kBlock) Di[k] -= vmin;
+          if (tid == 0) p.lbterms[p.lb_pos_node[r]] = vmin;
+        }
+        __syncthreads();  // Di complete, previous hand-over consumed
+        const double gamma = p.gamma[r];
+        for (int i = o0 + wave; i < o1; i += kWavesPerBlock) {
+          const int e = oidx[i];
+          const int sl = i - o0;
+          const double v = update_message<KERNEL, BACKWARD, MODE, true>(
+              p, e, Di, gamma, scratch, sl < kMaxSlots ? hand + sl * Kp : nullptr, lane);
+          if (BACKWARD && lane == 0) p.lbterms[p.lb_pos_edge[e]] = v;
+        }
+      }
+      // ---- publish: every storing wave drains, then one lane raises the flag
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) st_sc1(p.done + r, epoch);
+    }
   }
 }
 
@@ -394,6 +727,15 @@ struct stereo_trws_plan {
   DevBuf<int32_t> d_tail, d_order, d_fptr, d_fidx, d_bptr, d_bidx, d_lbn, d_lbe, d_levels, d_x;
   DevBuf<uint8_t> d_mdir;
   DevBuf<double> d_gamma, d_msg, d_lbterms, d_eterms;
+  // persistent sweep schedule
+  DevBuf<int32_t> d_run_ptr[2], d_dep_ptr[2], d_dep_rank[2], d_done, d_ctl;  // d_ctl: [ticket, abort]
+  DevBuf<int8_t> d_in_slot[2];
+  DevBuf<unsigned long long> d_fallbacks;
+  bool certificate = true;
+  int epoch = 0;
+  bool persistent = true;
+  bool fwd_pending = false;  // the forward sweep of the next iteration has already run
+  int grid_blocks = 0;
   // inputs (owned unless bound)
   DevBuf<double> o_unary, o_q, o_qprim, o_pos, o_alpha;
   DevBuf<uint16_t> d_perm_q, d_perm_qp, d_perm_pos;
@@ -420,6 +762,9 @@ size_t sweep_lds_bytes(int Kp) {
   return sizeof(double) * (size_t)(Kp + 8 + kWavesPerBlock * (kWaveVecs * Kp + 8));
 }
 size_t primal_lds_bytes(int Kp) { return sizeof(double) * (size_t)(2 * kWavesPerBlock + Kp); }
+size_t persistent_lds_bytes(int Kp) {
+  return sizeof(double) * (size_t)(Kp + 8 + kMaxSlots * Kp + Kp + kWavesPerBlock * (kWaveVecs * Kp + 8));
+}
 
 DevParams make_params(stereo_trws_plan *P) {
   DevParams p{};
@@ -430,7 +775,43 @@ DevParams make_params(stereo_trws_plan *P) {
   p.fptr = P->d_fptr.p; p.fidx = P->d_fidx.p; p.bptr = P->d_bptr.p; p.bidx = P->d_bidx.p;
   p.gamma = P->d_gamma.p; p.lb_pos_node = P->d_lbn.p; p.lb_pos_edge = P->d_lbe.p;
   p.lbterms = P->d_lbterms.p; p.eterms = P->d_eterms.p; p.x = P->d_x.p;
+  for (int d = 0; d < 2; ++d) {
+    p.run_ptr[d] = P->d_run_ptr[d].p; p.nruns[d] = (int)P->g.sweep[d].run_ptr.size() - 1;
+    p.dep_ptr[d] = P->d_dep_ptr[d].p; p.dep_rank[d] = P->d_dep_rank[d].p;
+    p.in_slot[d] = P->d_in_slot[d].p;
+  }
+  p.done = P->d_done.p; p.ticket = P->d_ctl.p; p.abort_flag = P->d_ctl.p + 1; p.N = (int)P->N;
+  p.fallbacks = P->d_fallbacks.p; p.certificate = P->certificate ? 1 : 0;
   return p;
+}
+
+// One persistent launch: 0 = forward, 1 = backward, 2 = forward + primal of the
+// previous iteration, 3 = primal only.
+template <int KERNEL, int MODE>
+void launch_persistent(stereo_trws_plan *P, const DevParams &p, int what, hipStream_t s) {
+  const size_t lds = persistent_lds_bytes(P->Kp);
+  const int epoch = ++P->epoch;
+  STEREO_HIP_CHECK(hipMemsetAsync(P->d_ctl.p, 0, sizeof(int32_t), s));  // ticket = 0
+  const dim3 grid(P->grid_blocks), block(kBlock);
+  switch (what) {
+    case 0: hipLaunchKernelGGL((trws_persistent_kernel<KERNEL, false, MODE, false, true>), grid, block, lds, s, p, epoch); break;
+    case 1: hipLaunchKernelGGL((trws_persistent_kernel<KERNEL, true, MODE, false, true>), grid, block, lds, s, p, epoch); break;
+    case 2: hipLaunchKernelGGL((trws_persistent_kernel<KERNEL, false, MODE, true, true>), grid, block, lds, s, p, epoch); break;
+    default: hipLaunchKernelGGL((trws_persistent_kernel<KERNEL, false, MODE, true, false>), grid, block, lds, s, p, epoch); break;
+  }
+  STEREO_HIP_CHECK(hipGetLastError());
+  if (what != 3) P->sweep_launches += 1;
+}
+
+template <int KERNEL, int MODE>
+void persistent_iteration(stereo_trws_plan *P, const DevParams &p, hipStream_t s) {
+  if (P->time_sweeps) STEREO_HIP_CHECK(hipEventRecord(P->ev0, s));
+  if (!P->fwd_pending) launch_persistent<KERNEL, MODE>(P, p, 0, s);
+  launch_persistent<KERNEL, MODE>(P, p, 1, s);
+  // forward sweep of the NEXT iteration fused with this iteration's primal
+  launch_persistent<KERNEL, MODE>(P, p, 2, s);
+  P->fwd_pending = true;
+  if (P->time_sweeps) STEREO_HIP_CHECK(hipEventRecord(P->ev1, s));
 }
 
 template <int KERNEL, int MODE>
@@ -533,6 +914,28 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
     P->d_levels.upload(g.level_ranks.data(), g.level_ranks.size());
     P->d_mdir.upload(g.mdir.data(), g.mdir.size());
     P->d_gamma.upload(g.gamma.data(), g.gamma.size());
+    for (int d = 0; d < 2; ++d) {
+      const TrwsGraph::Sweep &S = g.sweep[d];
+      P->d_run_ptr[d].upload(S.run_ptr.data(), S.run_ptr.size());
+      P->d_dep_ptr[d].upload(S.dep_ptr.data(), S.dep_ptr.size());
+      P->d_dep_rank[d].upload(S.dep_rank.data(), S.dep_rank.size());
+      P->d_in_slot[d].upload(S.in_slot.data(), S.in_slot.size());
+    }
+    P->d_done.alloc(N);
+    P->d_ctl.alloc(2);
+    P->d_fallbacks.alloc(1);
+    STEREO_HIP_CHECK(hipMemset(P->d_fallbacks.p, 0, sizeof(unsigned long long)));
+    if (const char *c = std::getenv("STEREO_HIP_TRWS_CERTIFICATE")) P->certificate = std::string(c) != "0";
+    STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * N));
+    STEREO_HIP_CHECK(hipMemset(P->d_ctl.p, 0, sizeof(int32_t) * 2));
+    if (const char *sc = std::getenv("STEREO_HIP_TRWS_SCHEDULE")) P->persistent = std::string(sc) != "levels";
+    {
+      // one workgroup per concurrently active run, capped by what stays resident
+      const int64_t runs = std::max<int64_t>((int64_t)g.sweep[0].run_ptr.size() - 1, 1);
+      const int64_t by_lds = std::max<int64_t>(1, (int64_t)(160 * 1024) / (int64_t)persistent_lds_bytes(P->Kp));
+      const int64_t per_cu = std::min<int64_t>(by_lds, 4);
+      P->grid_blocks = (int)std::min<int64_t>(runs, 256 * per_cu);
+    }
     P->d_msg.alloc((size_t)E * K);
     P->d_lbterms.alloc(g.lb_terms);
     P->d_eterms.alloc(N);
@@ -551,6 +954,17 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
     SET_LDS(1, false, 0); SET_LDS(1, true, 0); SET_LDS(2, false, 0); SET_LDS(2, true, 0);
     SET_LDS(1, false, 1); SET_LDS(1, true, 1); SET_LDS(2, false, 1); SET_LDS(2, true, 1);
 #undef SET_LDS
+    const int plds = (int)persistent_lds_bytes(P->Kp);
+    if (plds > 160 * 1024) return fail("stereo_trws: K too large for LDS", err, errcap);
+#define SET_PLDS(KER, BW, MD, PR, UP)                                                              \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_persistent_kernel<KER, BW, MD, PR, UP>,  \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, plds))
+#define SET_PLDS4(KER, MD)                                                                         \
+  SET_PLDS(KER, false, MD, false, true); SET_PLDS(KER, true, MD, false, true);                    \
+  SET_PLDS(KER, false, MD, true, true); SET_PLDS(KER, false, MD, true, false)
+    SET_PLDS4(1, 0); SET_PLDS4(1, 1); SET_PLDS4(2, 0); SET_PLDS4(2, 1);
+#undef SET_PLDS4
+#undef SET_PLDS
     *plan = P.release();
     return 0;
   } catch (const HipError &e) {
@@ -614,8 +1028,10 @@ int stereo_trws_plan_reset(stereo_trws_plan *P, char *err, size_t errcap) {
   try {
     STEREO_HIP_CHECK(hipMemset(P->d_msg.p, 0, sizeof(double) * (size_t)P->E * P->K));
     STEREO_HIP_CHECK(hipMemset(P->d_x.p, 0, sizeof(int32_t) * P->N));
+    STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * P->N));
+    STEREO_HIP_CHECK(hipMemset(P->d_ctl.p, 0, sizeof(int32_t) * 2));
     STEREO_HIP_CHECK(hipDeviceSynchronize());
-    P->iterations = 0; P->energy = 0; P->lb = 0;
+    P->iterations = 0; P->energy = 0; P->lb = 0; P->epoch = 0; P->fwd_pending = false;
     return 0;
   } catch (const HipError &e) {
     return fail(e.msg, err, errcap);
@@ -632,16 +1048,28 @@ int stereo_trws_plan_iterate(stereo_trws_plan *P, int iters, double max_relgap, 
   try {
     const DevParams p = make_params(P);
     for (int it = 0; it < iters; ++it) {
-      if (P->kernel == 1) {
-        if (P->mode == 0) launch_iteration<1, 0>(P, p, s); else launch_iteration<1, 1>(P, p, s);
+      if (P->persistent) {
+        if (P->kernel == 1) {
+          if (P->mode == 0) persistent_iteration<1, 0>(P, p, s); else persistent_iteration<1, 1>(P, p, s);
+        } else {
+          if (P->mode == 0) persistent_iteration<2, 0>(P, p, s); else persistent_iteration<2, 1>(P, p, s);
+        }
       } else {
-        if (P->mode == 0) launch_iteration<2, 0>(P, p, s); else launch_iteration<2, 1>(P, p, s);
+        if (P->kernel == 1) {
+          if (P->mode == 0) launch_iteration<1, 0>(P, p, s); else launch_iteration<1, 1>(P, p, s);
+        } else {
+          if (P->mode == 0) launch_iteration<2, 0>(P, p, s); else launch_iteration<2, 1>(P, p, s);
+        }
       }
       STEREO_HIP_CHECK(hipMemcpyAsync(P->h_lb.p, P->d_lbterms.p, sizeof(double) * P->g.lb_terms,
                                       hipMemcpyDeviceToHost, s));
       STEREO_HIP_CHECK(hipMemcpyAsync(P->h_en.p, P->d_eterms.p, sizeof(double) * P->N,
                                       hipMemcpyDeviceToHost, s));
+      int32_t ctl[2] = {0, 0};
+      if (P->persistent)
+        STEREO_HIP_CHECK(hipMemcpyAsync(ctl, P->d_ctl.p, sizeof(ctl), hipMemcpyDeviceToHost, s));
       STEREO_HIP_CHECK(hipStreamSynchronize(s));
+      if (ctl[1]) return fail("stereo_trws: a persistent sweep gave up waiting on a dependency flag", err, errcap);
       if (P->time_sweeps) {
         float ms = 0;
         STEREO_HIP_CHECK(hipEventElapsedTime(&ms, P->ev0, P->ev1));
@@ -697,6 +1125,15 @@ int stereo_trws_plan_stats(stereo_trws_plan *P, double *sweep_ms, int64_t *sweep
   if (sweep_launches) *sweep_launches = P->sweep_launches;
   if (reset) { P->sweep_ms = 0; P->sweep_launches = 0; }
   P->time_sweeps = true;
+  return 0;
+}
+
+int stereo_trws_plan_counters(stereo_trws_plan *P, int64_t *serial_messages, int reset) {
+  if (!P) return 1;
+  unsigned long long v = 0;
+  if (hipMemcpy(&v, P->d_fallbacks.p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  if (serial_messages) *serial_messages = (int64_t)v;
+  if (reset && hipMemset(P->d_fallbacks.p, 0, sizeof(v)) != hipSuccess) return 1;
   return 0;
 }
 

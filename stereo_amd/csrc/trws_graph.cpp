@@ -165,6 +165,46 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
     for (int32_t k = g.bptr[r]; k < g.bptr[r + 1]; ++k) g.lb_pos_edge[g.bidx[k]] = (int32_t)pos++;
   }
   g.lb_terms = pos;
+  // ---- persistent sweep schedules
+  for (int d = 0; d < 2; ++d) {
+    TrwsGraph::Sweep &S = g.sweep[d];
+    // incoming / outgoing lists of this direction, by rank
+    const std::vector<int32_t> &iptr = d == 0 ? g.bptr : g.fptr, &iidx = d == 0 ? g.bidx : g.fidx;
+    const std::vector<int32_t> &optr = d == 0 ? g.fptr : g.bptr, &oidx = d == 0 ? g.fidx : g.bidx;
+    S.run_ptr.clear(); S.dep_ptr.assign(N + 1, 0); S.dep_rank.clear(); S.in_slot.assign(E, -1);
+    std::vector<int32_t> deps_of(N, 0);
+    std::vector<std::vector<int32_t>> tmp_deps;  // filled per rank in processing order
+    tmp_deps.resize(N);
+    for (int64_t p = 0; p < N; ++p) {
+      const int32_t r = d == 0 ? (int32_t)p : (int32_t)(N - 1 - p);
+      const int32_t pred = d == 0 ? r - 1 : r + 1;  // rank processed just before
+      bool chained = false;
+      std::vector<int32_t> &deps = tmp_deps[r];
+      for (int32_t k = iptr[r]; k < iptr[r + 1]; ++k) {
+        const int32_t e = iidx[k];
+        const int32_t other = g.rank[d == 0 ? g.tail[e] : g.head[e]];
+        if (p > 0 && other == pred) {
+          chained = true;
+          for (int32_t w = optr[pred]; w < optr[pred + 1] && w - optr[pred] < TrwsGraph::kMaxSlots; ++w)
+            if (oidx[w] == e) S.in_slot[k] = (int8_t)(w - optr[pred]);
+        } else if (std::find(deps.begin(), deps.end(), other) == deps.end()) {
+          deps.push_back(other);
+        }
+      }
+      if (!chained) {
+        S.run_ptr.push_back((int32_t)p);
+        // a new run starts here: nothing is handed over in LDS
+        for (int32_t k = iptr[r]; k < iptr[r + 1]; ++k) S.in_slot[k] = -1;
+      }
+    }
+    S.run_ptr.push_back((int32_t)N);
+    int64_t dp = 0;
+    for (int64_t r = 0; r < N; ++r) {
+      S.dep_ptr[r] = (int32_t)dp;
+      for (int32_t x : tmp_deps[r]) { S.dep_rank.push_back(x); ++dp; }
+    }
+    S.dep_ptr[N] = (int32_t)dp;
+  }
   return true;
 }
 

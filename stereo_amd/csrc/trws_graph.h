@@ -34,6 +34,22 @@ struct TrwsGraph {
   std::vector<int32_t> lb_pos_node;  // per rank
   std::vector<int32_t> lb_pos_edge;  // per edge
   int64_t lb_terms = 0;
+
+  // Schedule of the persistent dataflow sweeps.  Processing position p is rank p
+  // in the forward sweep and rank N-1-p in the backward sweep.  A "run" is a
+  // maximal stretch of consecutive positions in which every node has its
+  // predecessor among its incoming neighbours (a grid row, the border chain):
+  // one workgroup walks a run sequentially, hands the messages for the next
+  // node over in LDS and waits on completion flags only for `dep_rank`.
+  struct Sweep {
+    std::vector<int32_t> run_ptr;   // R+1 offsets into processing positions
+    std::vector<int32_t> dep_ptr;   // N+1, indexed by rank
+    std::vector<int32_t> dep_rank;  // ranks whose flag must be set first
+    // aligned with the node's INCOMING list (bidx forward / fidx backward):
+    // slot of that edge in the predecessor's outgoing list, or -1
+    std::vector<int8_t> in_slot;
+  } sweep[2];
+  static constexpr int kMaxSlots = 4;
 };
 
 // conn: 2 x E zero-based (column major: conn[2e] = tail, conn[2e+1] = head).

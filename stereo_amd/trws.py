@@ -169,6 +169,11 @@ class TrwsPlan:
         _lib.check(rc, err)
         return dict(rank=rank, levels=lv.value, max_level_nodes=mx.value)
 
+    def serial_messages(self, reset=False):
+        n = C.c_int64()
+        _lib.lib().stereo_trws_plan_counters(self._h, C.byref(n), C.c_int(int(reset)))
+        return n.value
+
     def stats(self, reset=False):
         ms, n = C.c_double(), C.c_int64()
         _lib.lib().stereo_trws_plan_stats(self._h, C.byref(ms), C.byref(n), C.c_int(int(reset)))
