@@ -102,12 +102,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    plan.iterate(args.warmup)
+    NEVER = -1e300  # (E-LB)/E < max_relgap can fire with max_relgap = 0 once E ~ LB; time exactly K steps
+    plan.iterate(args.warmup, max_relgap=NEVER)
     plan.stats(reset=True)
     plan.serial_messages(reset=True)
     barrier()
     t0 = time.perf_counter()
-    plan.iterate(args.steps)  # returns after the last iteration's scalars reached the host
+    done, _ = plan.iterate(args.steps, max_relgap=NEVER)  # returns after the last scalars reached the host
+    assert done == args.steps, (done, args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:

@@ -70,6 +70,9 @@ struct DevParams {
   int N;
   unsigned long long *fallbacks;  // messages that needed the serial envelope (diagnostics)
   int certificate;                // 0: always run the serial envelope
+  unsigned long long *prof;       // optional: 8 phase-cycle accumulators (development)
+  const int32_t *desc[2];         // packed node descriptors of the fast kernel
+  int prof_run;
 };
 
 // ---- agent-scope (sc1) accesses: data handed between workgroups inside one launch
@@ -95,6 +98,42 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 }
 // wave-uniform predicate -> scalar branch
 #define UNI(c) (__builtin_amdgcn_ballot_w64(c) != 0)
+
+// ---- DPP wave reductions (gfx9 row_bcast forms): ~20 VALU instead of 12 ds_bpermute.
+// The combined value ends up in lane 63 and is broadcast with v_readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+}
+#define DPP_REDUCE_STEPS(STEP) \
+  STEP(0xB1, 0xF) STEP(0x4E, 0xF) STEP(0x141, 0xF) STEP(0x140, 0xF) STEP(0x142, 0xA) STEP(0x143, 0xC)
+__device__ __forceinline__ double wave_min_dpp(double v) {
+#define STEP(C, M) { const double o = dpp_f64<C, M>(v); v = o < v ? o : v; }
+  DPP_REDUCE_STEPS(STEP)
+#undef STEP
+  return readlane_f64(v, 63);
+}
+__device__ __forceinline__ double wave_max_dpp(double v) {
+#define STEP(C, M) { const double o = dpp_f64<C, M>(v); v = o > v ? o : v; }
+  DPP_REDUCE_STEPS(STEP)
+#undef STEP
+  return readlane_f64(v, 63);
+}
+// lexicographic (value, index) minimum -> index of the FIRST minimum, uniform
+__device__ __forceinline__ int wave_argmin_dpp(double v, int i) {
+#define STEP(C, M) { const double ov = dpp_f64<C, M>(v); const int oi = dpp_i32<C, M>(i); \
+                     if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; } }
+  DPP_REDUCE_STEPS(STEP)
+#undef STEP
+  return __builtin_amdgcn_readlane(i, 63);
+}
 
 
 __device__ __forceinline__ double wave_min(double v) {
@@ -573,6 +612,13 @@ __global__ __launch_bounds__(kBlock) void trws_persistent_kernel(DevParams p, in
     __syncthreads();
     if (run >= p.nruns[D]) break;
     const int p0 = p.run_ptr[D][run], p1 = p.run_ptr[D][run + 1];
+    long long tprev = p.prof ? (long long)__builtin_readcyclecounter() : 0;
+#define PROF(slot)                                                                 \
+  if (p.prof && tid == 0 && run == 0) {                                            \
+    const long long tn = (long long)__builtin_readcyclecounter();                  \
+    atomicAdd(p.prof + (slot), (unsigned long long)(tn - tprev));                  \
+    tprev = tn;                                                                    \
+  }
     for (int pos = p0; pos < p1; ++pos) {
       const int r = BACKWARD ? N - 1 - pos : pos;
       const int node = p.order[r];
@@ -593,6 +639,7 @@ __global__ __launch_bounds__(kBlock) void trws_persistent_kernel(DevParams p, in
         }
       }
       if (__syncthreads_or(gave_up)) return;  // bounded spin: the host reports the failure
+      PROF(0)
       // ---- primal of the previous iteration (needs the outgoing messages before the update)
       if (PRIMAL) {
         double bestv = __builtin_huge_val();
@@ -634,6 +681,7 @@ __global__ __launch_bounds__(kBlock) void trws_persistent_kernel(DevParams p, in
           p.eterms[r] = Dbs[bi];
         }
         __syncthreads();
+        PROF(1)
       }
       if (UPDATE) {
         // ---- Di = D + outgoing-list messages (from the previous sweep) + incoming ones
@@ -659,6 +707,7 @@ __global__ __launch_bounds__(kBlock) void trws_persistent_kernel(DevParams p, in
           if (tid == 0) p.lbterms[p.lb_pos_node[r]] = vmin;
         }
         __syncthreads();  // Di complete, previous hand-over consumed
+        PROF(2)
         const double gamma = p.gamma[r];
         for (int i = o0 + wave; i < o1; i += kWavesPerBlock) {
           const int e = oidx[i];
@@ -667,14 +716,354 @@ __global__ __launch_bounds__(kBlock) void trws_persistent_kernel(DevParams p, in
               p, e, Di, gamma, scratch, sl < kMaxSlots ? hand + sl * Kp : nullptr, lane);
           if (BACKWARD && lane == 0) p.lbterms[p.lb_pos_edge[e]] = v;
         }
+        PROF(3)
       }
       // ---- publish: every storing wave drains, then one lane raises the flag
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) st_sc1(p.done + r, epoch);
+      PROF(4)
     }
+#undef PROF
   }
 }
+
+// ---- fast persistent sweep: K <= 64, <= 4 edges per list, <= 2 foreign dependencies ----
+// Same dataflow schedule as trws_persistent_kernel, restructured so that in
+// steady state a node visit touches no memory on its critical path:
+//  * lane = label; every wave keeps D, the outgoing-list messages and the
+//    incoming messages of the node in registers and forms Di redundantly, so the
+//    only workgroup traffic is the LDS hand-over of the new messages;
+//  * a packed 128-byte descriptor per processing position replaces the chains of
+//    dependent index loads; descriptor, unary and previous-sweep messages of the
+//    NEXT node are fetched while the current node's messages are computed, and
+//    so are the foreign incoming messages once their flags are seen raised;
+//  * a node's completion flag is raised in the middle of the next visit, when
+//    its write-through stores have long drained, so no store latency is exposed.
+struct NodeDesc {
+  int node, rank, nout, nin, ndep, md, lbn;
+  int e[8], slot[8], dep[4], lbe[8], xn[8];
+};
+#define RLI(v, i) __builtin_amdgcn_readlane((v), (i))
+__device__ __forceinline__ NodeDesc decode_desc(int w) {
+  NodeDesc d;
+  d.node = RLI(w, 0); d.rank = RLI(w, 1);
+  const int f = RLI(w, 2);
+  d.nout = f & 15; d.nin = (f >> 4) & 15; d.ndep = (f >> 8) & 15; d.md = (f >> 16) & 255;
+  d.lbn = RLI(w, 3);
+  d.e[0] = RLI(w, 4); d.e[1] = RLI(w, 5); d.e[2] = RLI(w, 6); d.e[3] = RLI(w, 7);
+  d.e[4] = RLI(w, 8); d.e[5] = RLI(w, 9); d.e[6] = RLI(w, 10); d.e[7] = RLI(w, 11);
+  d.slot[0] = RLI(w, 12); d.slot[1] = RLI(w, 13); d.slot[2] = RLI(w, 14); d.slot[3] = RLI(w, 15);
+  d.slot[4] = RLI(w, 16); d.slot[5] = RLI(w, 17); d.slot[6] = RLI(w, 18); d.slot[7] = RLI(w, 19);
+  d.dep[0] = RLI(w, 20); d.dep[1] = RLI(w, 21); d.dep[2] = RLI(w, 22); d.dep[3] = RLI(w, 23);
+  d.lbe[0] = RLI(w, 24); d.lbe[1] = RLI(w, 25); d.lbe[2] = RLI(w, 26); d.lbe[3] = RLI(w, 27);
+  d.lbe[4] = RLI(w, 28); d.lbe[5] = RLI(w, 29); d.lbe[6] = RLI(w, 30); d.lbe[7] = RLI(w, 31);
+  d.xn[0] = RLI(w, 32); d.xn[1] = RLI(w, 33); d.xn[2] = RLI(w, 34); d.xn[3] = RLI(w, 35);
+  d.xn[4] = RLI(w, 36); d.xn[5] = RLI(w, 37); d.xn[6] = RLI(w, 38); d.xn[7] = RLI(w, 39);
+  return d;
+}
+
+// bounded wait for one completion flag; returns false if the launch must give up
+__device__ __forceinline__ bool wait_flag(const DevParams &p, int rank, int epoch) {
+  const int32_t *flag = p.done + rank;
+  int spins = 0;
+  while (ld_sc1(flag) < epoch) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > kSpinLimit || ((spins & 1023) == 0 && ld_sc1(p.abort_flag))) {
+      st_sc1(p.abort_flag, 1);
+      return false;
+    }
+  }
+  return true;
+}
+
+// Message update with everything in registers (K <= 64): h = gamma*Di - old message,
+// qsrc / t = source / destination positions, perm = ascending order of the sources
+// (only touched by the serial fallback).  Returns the normalised message in `out`.
+template <int KERNEL>
+__device__ __forceinline__ double message_regs(const DevParams &p, int K, double alpha, double h,
+                                               double qsrc, double t, const uint16_t *perm,
+                                               double &outmsg, int lane) {
+  const double inf = __builtin_huge_val();
+  const bool act = lane < K;
+  const double hmin = wave_min_dpp(h);  // inactive lanes hold +inf
+  double out, vmin;
+  if (UNI(alpha == 0)) {
+    out = hmin; vmin = hmin;  // typeStereoLinear.h:390-396
+  } else {
+    const double vtrunc = hmin + alpha * p.lambda;
+    bool need_serial = true;
+    out = vtrunc;
+    if (KERNEL == 1 && p.certificate) {
+      // Fast path (DESIGN.md "message certificate").  Only "useful" sources, those with
+      // h < vTrunc, can produce a value below the truncation level: cost >= h for every
+      // other source.  Min-plus over the useful sources is therefore the plain min-plus
+      // result; the certificate demands (i) every pair of cones with distinct apex positions
+      // of which at least one is useful is delta-separated from tangency (|u_i-u_j| > delta
+      // and |v_i-v_j| > delta with u = h - alpha q, v = h + alpha q), so each comparison
+      // the reference's serial envelope construction makes on a useful cone is decided as
+      // in real arithmetic, and (ii) at every destination whose minimum beats vTrunc the
+      // minimum is delta-separated from the next larger cost and from vTrunc, so rounding
+      // in the envelope's breakpoints cannot pick another value.  Otherwise: serial path.
+      const double aq = alpha * qsrc;
+      const double ui = h - aq, vi = h + aq;
+      const double mag = wave_max_dpp(act ? fabs(h) + fabs(aq) + alpha * fabs(t) : 0.0);
+      const double delta = 1e-9 * (mag + fabs(alpha * p.lambda));
+      const bool useful = act && h < vtrunc;
+      unsigned long long mask = __builtin_amdgcn_ballot_w64(useful);
+      double m1 = inf, m2 = inf;
+      bool bad = !(delta < inf);
+      while (mask) {
+        const int j = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const double hj = readlane_f64(h, j), qj = readlane_f64(qsrc, j);
+        const double uj = readlane_f64(ui, j), vj = readlane_f64(vi, j);
+        const double c = pair_cost<1>(alpha, t - qj, hj);
+        if (c < m1) { m2 = m1; m1 = c; } else if (c > m1 && c < m2) { m2 = c; }
+        const bool near = (fabs(ui - uj) <= delta) || (fabs(vi - vj) <= delta);
+        bad = bad || (near && qsrc != qj);
+      }
+      bad = bad || (m1 < vtrunc && !(m2 - m1 > delta && vtrunc - m1 > delta));
+      need_serial = UNI(act && bad);
+      out = m1 < vtrunc ? m1 : vtrunc;
+      if (need_serial && lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
+    }
+    if (need_serial) {
+      const int idx = act ? perm[lane] : lane;
+      const double hs = __shfl(h, idx, kWave), qs = __shfl(qsrc, idx, kWave);
+      double sh, sq, zz;
+      const int maxtop = build_envelope_regs<KERNEL>(K, alpha, hs, qs, sh, sq, zz, lane);
+      double ch = 0, cq = 0;
+      bool walking = true;
+      for (int j = 0; j <= maxtop; ++j) {
+        const double shj = readlane_f64(sh, j), sqj = readlane_f64(sq, j), zj1 = readlane_f64(zz, j);
+        if (walking) { ch = shj; cq = sqj; walking = zj1 < t; }
+      }
+      const double c = pair_cost<KERNEL>(alpha, t - cq, ch);
+      out = c < vtrunc ? c : vtrunc;
+    }
+    vmin = wave_min_dpp(act ? out : inf);
+  }
+  outmsg = out - vmin;
+  return vmin;
+}
+
+template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
+__global__ __launch_bounds__(kBlock) void trws_fast_kernel(DevParams p, int epoch) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double *hand = lds;                      // 2 x 8 x 64 doubles: new messages for the next node of the run
+  int *s_run = (int *)(lds + 16 * kWave);
+  const int K = p.K;
+  const double inf = __builtin_huge_val();
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  constexpr int D = BACKWARD ? 1 : 0;
+  constexpr int DW = TrwsGraph::kDescWords;
+  const int32_t *desc = p.desc[D];
+  const bool act = lane < K;
+  const double posk = (SHARED && act) ? p.pos[lane] : 0.0;
+
+  // previous-sweep (static) data of a node: unary, outgoing-list messages, edge weights, positions
+  auto load_static = [&](const NodeDesc &d, double &Dk_, double (&m_)[8], double (&a_)[8],
+                         double (&qv_)[8], double (&qpv_)[8]) {
+    if (act) Dk_ = p.unary[(size_t)d.node * K + lane];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < d.nout + d.nin) {
+        const bool is_out = j < d.nout;
+        if (is_out && act) m_[j] = p.msg[(size_t)d.e[j] * K + lane];
+        if ((is_out && UPDATE) || (!is_out && PRIMAL)) {
+          a_[j] = p.alpha[d.e[j]];
+          if (!SHARED && act) {
+            qv_[j] = p.q[(size_t)d.e[j] * K + lane];
+            qpv_[j] = p.qprim[(size_t)d.e[j] * K + lane];
+          }
+        }
+      }
+    }
+  };
+
+  for (;;) {
+    if (tid == 0) *s_run = atomicAdd(p.ticket, 1);
+    __syncthreads();
+    const int run = __builtin_amdgcn_readfirstlane(*s_run);
+    __syncthreads();
+    if (run >= p.nruns[D]) break;
+    const int p0 = p.run_ptr[D][run], p1 = p.run_ptr[D][run + 1];
+
+    NodeDesc cur = decode_desc(desc[(size_t)p0 * DW + lane]);
+    int nw = p0 + 1 < p1 ? desc[(size_t)(p0 + 1) * DW + lane] : 0;
+    double Dk = 0, m[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double qv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, qpv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    load_static(cur, Dk, m, a, qv, qpv);
+    bool pre_ok = false;   // foreign incoming data of `cur` already sits in m[] / px[]
+    int px[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int xprev = 0, prev_rank = -1, rbuf = 0;
+    long long tprev = p.prof ? (long long)__builtin_readcyclecounter() : 0;
+    unsigned long long pacc[5] = {0, 0, 0, 0, 0}, nblock = 0;
+#define PROF(slot)                                                                 \
+  if (p.prof) {                                                                    \
+    const long long tn = (long long)__builtin_readcyclecounter();                  \
+    pacc[slot] += (unsigned long long)(tn - tprev);                                \
+    tprev = tn;                                                                    \
+  }
+
+    for (int pos = p0; pos < p1; ++pos) {
+      const bool has_next = pos + 1 < p1;
+      const int ntot = cur.nout + cur.nin;
+      double prim_e = 0, node_vmin = 0;
+      // ---- incoming messages: LDS hand-over, prefetched registers, or (rarely) a blocking fetch
+      if (!pre_ok) {
+        if (cur.ndep > 0) ++nblock;
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (ok && j < cur.ndep) ok = wait_flag(p, cur.dep[j], epoch);
+        if (!ok) return;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (j >= cur.nout && j < ntot && cur.slot[j] < 0) {
+            if (UPDATE && act) m[j] = ld_sc1(p.msg + (size_t)cur.e[j] * K + lane);
+            if (PRIMAL) px[j] = ld_sc1(p.x + cur.xn[j]);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (UPDATE && j >= cur.nout && j < ntot && cur.slot[j] >= 0) m[j] = hand[(rbuf * 8 + cur.slot[j]) * kWave + lane];
+      PROF(0)
+      // ---- primal of the previous iteration (minimize.cpp:223-264), every wave redundantly
+      if (PRIMAL) {
+        double db = Dk;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (j >= cur.nout && j < ntot) {
+            const int ks = cur.slot[j] >= 0 ? xprev : __builtin_amdgcn_readfirstlane(px[j]);
+            const int md = (cur.md >> j) & 1;
+            double d;
+            if (SHARED) {
+              const double pks = readlane_f64(posk, ks);
+              d = md == 0 ? pks - posk : posk - pks;
+            } else {
+              d = md == 0 ? readlane_f64(qpv[j], ks) - qv[j] : qpv[j] - readlane_f64(qv[j], ks);
+            }
+            const double v = KERNEL == 1 ? fabs(d) : d * d;
+            db += a[j] * (v < p.lambda ? v : p.lambda);
+          }
+        }
+        double di = db;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < cur.nout) di += m[j];
+        const int bi = wave_argmin_dpp(act ? di : inf, act ? lane : 0x7fffffff);
+        xprev = bi;
+        prim_e = readlane_f64(db, bi);
+      }
+      PROF(1)
+      double Di = 0;
+      if (UPDATE) {
+        Di = Dk;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < ntot) Di += m[j];
+        if (BACKWARD) {
+          node_vmin = wave_min_dpp(act ? Di : inf);
+          Di -= node_vmin;
+        }
+      }
+      PROF(2)
+      // ---- raise the flag of the previous node.  Its write-through stores were issued a
+      // whole message computation ago; every wave drains, then one lane stores the flag.
+      // (Measured: raising it here costs the drain on the critical path of this row but
+      // lets the row below start earlier, which wins on grids.)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        if (prev_rank >= 0) st_sc1(p.done + prev_rank, epoch);
+        // this node's scalars go out only now, so that the drain above never waits for them
+        if (PRIMAL) { st_sc1(p.x + cur.node, xprev); p.eterms[cur.rank] = prim_e; }
+        if (UPDATE && BACKWARD) p.lbterms[cur.lbn] = node_vmin;
+      }
+      // ---- prefetch for the next node
+      NodeDesc nx = cur;
+      int nnw = 0;
+      double nDk = 0, nm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, na[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      double nqv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nqpv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      bool npre_ok = false;
+      int npx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (has_next) {
+        nx = decode_desc(nw);
+        int fl[4] = {epoch, epoch, epoch, epoch};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < nx.ndep) fl[j] = ld_sc1(p.done + nx.dep[j]);
+        if (pos + 2 < p1) nnw = desc[(size_t)(pos + 2) * DW + lane];
+        load_static(nx, nDk, nm, na, nqv, nqpv);
+        npre_ok = UNI(fl[0] >= epoch && fl[1] >= epoch && fl[2] >= epoch && fl[3] >= epoch);
+        if (npre_ok) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (j >= nx.nout && j < nx.nout + nx.nin && nx.slot[j] < 0) {
+              if (UPDATE && act) nm[j] = ld_sc1(p.msg + (size_t)nx.e[j] * K + lane);
+              if (PRIMAL) npx[j] = ld_sc1(p.x + nx.xn[j]);
+            }
+          }
+        }
+      }
+      PROF(3)
+      // ---- messages of outgoing edges wave, wave + 4
+      double newm[2] = {0, 0}, newv[2] = {0, 0};
+      if (UPDATE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if ((j & 3) == wave && j < cur.nout) {
+            const double gamma = (double)1 / (double)(cur.nout > cur.nin ? cur.nout : cur.nin);
+            const double h = act ? gamma * Di - m[j] : inf;
+            const bool src_is_qprim = ((BACKWARD ? 1 : 0) == ((cur.md >> j) & 1));
+            const double qsrc = SHARED ? posk : (src_is_qprim ? qpv[j] : qv[j]);
+            const double qdst = SHARED ? posk : (src_is_qprim ? qv[j] : qpv[j]);
+            const uint16_t *perm =
+                SHARED ? p.perm_pos : (src_is_qprim ? p.perm_qp : p.perm_q) + (size_t)cur.e[j] * K;
+            newv[j >> 2] = message_regs<KERNEL>(p, K, a[j], h, qsrc, qdst, perm, newm[j >> 2], lane);
+          }
+        }
+      }
+      PROF(4)
+      // ---- stores: write-through to HBM for other workgroups, LDS for the next node of the run
+      if (UPDATE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if ((j & 3) == wave && j < cur.nout) {
+            if (act) {
+              st_sc1(p.msg + (size_t)cur.e[j] * K + lane, newm[j >> 2]);
+              hand[((rbuf ^ 1) * 8 + j) * kWave + lane] = newm[j >> 2];
+            }
+            if (BACKWARD && lane == 0) p.lbterms[cur.lbe[j]] = newv[j >> 2];
+          }
+        }
+      }
+      __syncthreads();  // hand-over complete
+      rbuf ^= 1;
+      prev_rank = cur.rank;
+      cur = nx; nw = nnw; Dk = nDk; pre_ok = npre_ok;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        m[j] = nm[j]; a[j] = na[j]; qv[j] = nqv[j]; qpv[j] = nqpv[j]; px[j] = npx[j];
+      }
+    }
+    // ---- flag of the last node of the run
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (prev_rank >= 0 && tid == 0) st_sc1(p.done + prev_rank, epoch);
+    if (p.prof && tid == 0 && (p.prof_run < 0 || run == p.prof_run)) {
+      for (int i = 0; i < 5; ++i) atomicAdd(p.prof + i, pacc[i]);
+      atomicAdd(p.prof + 5, nblock);
+      atomicAdd(p.prof + 6, (unsigned long long)(p1 - p0));
+    }
+#undef PROF
+  }
+}
+#undef RLI
 
 // Ascending sort permutation of each K-vector (ties: lower index first), one
 // wave per vector, bitonic network in LDS.  Replaces the per-edge std::sort of
@@ -730,7 +1119,9 @@ struct stereo_trws_plan {
   // persistent sweep schedule
   DevBuf<int32_t> d_run_ptr[2], d_dep_ptr[2], d_dep_rank[2], d_done, d_ctl;  // d_ctl: [ticket, abort]
   DevBuf<int8_t> d_in_slot[2];
-  DevBuf<unsigned long long> d_fallbacks;
+  DevBuf<int32_t> d_desc[2];
+  bool fast = false;
+  DevBuf<unsigned long long> d_fallbacks, d_prof;
   bool certificate = true;
   int epoch = 0;
   bool persistent = true;
@@ -782,6 +1173,10 @@ DevParams make_params(stereo_trws_plan *P) {
   }
   p.done = P->d_done.p; p.ticket = P->d_ctl.p; p.abort_flag = P->d_ctl.p + 1; p.N = (int)P->N;
   p.fallbacks = P->d_fallbacks.p; p.certificate = P->certificate ? 1 : 0;
+  p.prof = P->d_prof.p;
+  p.desc[0] = P->d_desc[0].p; p.desc[1] = P->d_desc[1].p;
+  p.prof_run = -1;
+  if (const char *pr = std::getenv("STEREO_HIP_TRWS_PROF_RUN")) p.prof_run = std::atoi(pr);
   return p;
 }
 
@@ -793,6 +1188,25 @@ void launch_persistent(stereo_trws_plan *P, const DevParams &p, int what, hipStr
   const int epoch = ++P->epoch;
   STEREO_HIP_CHECK(hipMemsetAsync(P->d_ctl.p, 0, sizeof(int32_t), s));  // ticket = 0
   const dim3 grid(P->grid_blocks), block(kBlock);
+  if (P->fast) {
+    const size_t flds = sizeof(double) * (16 * kWave + 2);
+    const bool sh = P->pos != nullptr;
+#define FAST(BW, PR, UP)                                                                          \
+  do {                                                                                            \
+    if (sh) hipLaunchKernelGGL((trws_fast_kernel<KERNEL, BW, PR, UP, true>), grid, block, flds, s, p, epoch); \
+    else hipLaunchKernelGGL((trws_fast_kernel<KERNEL, BW, PR, UP, false>), grid, block, flds, s, p, epoch);   \
+  } while (0)
+    switch (what) {
+      case 0: FAST(false, false, true); break;
+      case 1: FAST(true, false, true); break;
+      case 2: FAST(false, true, true); break;
+      default: FAST(false, true, false); break;
+    }
+#undef FAST
+    STEREO_HIP_CHECK(hipGetLastError());
+    if (what != 3) P->sweep_launches += 1;
+    return;
+  }
   switch (what) {
     case 0: hipLaunchKernelGGL((trws_persistent_kernel<KERNEL, false, MODE, false, true>), grid, block, lds, s, p, epoch); break;
     case 1: hipLaunchKernelGGL((trws_persistent_kernel<KERNEL, true, MODE, false, true>), grid, block, lds, s, p, epoch); break;
@@ -920,12 +1334,16 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
       P->d_dep_ptr[d].upload(S.dep_ptr.data(), S.dep_ptr.size());
       P->d_dep_rank[d].upload(S.dep_rank.data(), S.dep_rank.size());
       P->d_in_slot[d].upload(S.in_slot.data(), S.in_slot.size());
+      if (g.fast_ok) P->d_desc[d].upload(S.desc.data(), S.desc.size());
     }
+    P->fast = g.fast_ok && K <= kWave && message_mode == STEREO_TRWS_MESSAGES_EXACT;
+    if (const char *f = std::getenv("STEREO_HIP_TRWS_FAST")) P->fast = P->fast && std::string(f) != "0";
     P->d_done.alloc(N);
     P->d_ctl.alloc(2);
     P->d_fallbacks.alloc(1);
     STEREO_HIP_CHECK(hipMemset(P->d_fallbacks.p, 0, sizeof(unsigned long long)));
     if (const char *c = std::getenv("STEREO_HIP_TRWS_CERTIFICATE")) P->certificate = std::string(c) != "0";
+    if (std::getenv("STEREO_HIP_TRWS_PROF")) { P->d_prof.alloc(8); STEREO_HIP_CHECK(hipMemset(P->d_prof.p, 0, 64)); }
     STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * N));
     STEREO_HIP_CHECK(hipMemset(P->d_ctl.p, 0, sizeof(int32_t) * 2));
     if (const char *sc = std::getenv("STEREO_HIP_TRWS_SCHEDULE")) P->persistent = std::string(sc) != "levels";
@@ -974,7 +1392,15 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
   }
 }
 
-void stereo_trws_plan_destroy(stereo_trws_plan *plan) { delete plan; }
+void stereo_trws_plan_destroy(stereo_trws_plan *plan) {
+  if (plan && plan->d_prof.p) {
+    unsigned long long v[8];
+    if (hipMemcpy(v, plan->d_prof.p, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess)
+      std::fprintf(stderr, "[stereo_hip prof] all runs, cycles: in %llu primal %llu Di %llu flag+prefetch %llu messages %llu | blocking steps %llu of %llu\n",
+                   v[0], v[1], v[2], v[3], v[4], v[5], v[6]);
+  }
+  delete plan;
+}
 
 int stereo_trws_plan_upload(stereo_trws_plan *P, const double *unary, const double *q,
                             const double *qprim, const double *positions, const double *alphas,

@@ -205,6 +205,48 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
     }
     S.dep_ptr[N] = (int32_t)dp;
   }
+  // ---- descriptors of the fast kernel (layout: trws.hip NodeDesc)
+  g.fast_ok = true;
+  for (int64_t r = 0; r < N && g.fast_ok; ++r) {
+    if ((g.fptr[r + 1] - g.fptr[r]) + (g.bptr[r + 1] - g.bptr[r]) > 8) g.fast_ok = false;
+    for (int d = 0; d < 2; ++d)
+      if (g.sweep[d].dep_ptr[r + 1] - g.sweep[d].dep_ptr[r] > 4) g.fast_ok = false;
+  }
+  if (g.fast_ok) {
+    constexpr int W = TrwsGraph::kDescWords;
+    for (int d = 0; d < 2; ++d) {
+      TrwsGraph::Sweep &S = g.sweep[d];
+      const std::vector<int32_t> &iptr = d == 0 ? g.bptr : g.fptr, &iidx = d == 0 ? g.bidx : g.fidx;
+      const std::vector<int32_t> &optr = d == 0 ? g.fptr : g.bptr, &oidx = d == 0 ? g.fidx : g.bidx;
+      S.desc.assign((size_t)N * W, 0);
+      for (int64_t p = 0; p < N; ++p) {
+        const int32_t r = d == 0 ? (int32_t)p : (int32_t)(N - 1 - p);
+        int32_t *D = &S.desc[(size_t)p * W];
+        const int nout = optr[r + 1] - optr[r], nin = iptr[r + 1] - iptr[r];
+        const int nd = S.dep_ptr[r + 1] - S.dep_ptr[r];
+        uint32_t md = 0;
+        for (int k = 0; k < 8; ++k) {
+          int32_t e = 0, slot = -1, lbe = 0, xn = 0;
+          if (k < nout) {
+            e = oidx[optr[r] + k];
+            lbe = g.lb_pos_edge[e];
+          } else if (k < nout + nin) {
+            const int32_t ik = iptr[r] + (k - nout);
+            e = iidx[ik];
+            slot = S.in_slot[ik];
+            xn = d == 0 ? g.tail[e] : g.head[e];  // the other endpoint: its label feeds the primal
+          }
+          if (k < nout + nin && g.mdir[e]) md |= 1u << k;
+          D[4 + k] = e; D[12 + k] = slot; D[24 + k] = lbe; D[32 + k] = xn;
+        }
+        D[0] = g.order[r];
+        D[1] = r;
+        D[2] = (int32_t)((uint32_t)nout | ((uint32_t)nin << 4) | ((uint32_t)nd << 8) | (md << 16));
+        D[3] = g.lb_pos_node[r];
+        for (int k = 0; k < 4; ++k) D[20 + k] = k < nd ? S.dep_rank[S.dep_ptr[r] + k] : 0;
+      }
+    }
+  }
   return true;
 }
 

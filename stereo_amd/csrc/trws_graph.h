@@ -48,8 +48,14 @@ struct TrwsGraph {
     // aligned with the node's INCOMING list (bidx forward / fidx backward):
     // slot of that edge in the predecessor's outgoing list, or -1
     std::vector<int8_t> in_slot;
+    // Packed per-position descriptors for the fast kernel (kDescWords int32 each,
+    // layout in trws.hip: NodeDesc); empty unless fast_ok.
+    std::vector<int32_t> desc;
   } sweep[2];
-  static constexpr int kMaxSlots = 4;
+  static constexpr int kDescWords = 64;
+  // every node has <= 8 incident edges and <= 4 foreign dependencies per direction
+  bool fast_ok = false;
+  static constexpr int kMaxSlots = 8;
 };
 
 // conn: 2 x E zero-based (column major: conn[2e] = tail, conn[2e+1] = head).
