@@ -176,3 +176,26 @@ def add_column(kernel, q, qprim, alpha, lam, ksource, dest, dirn, mdir, impl="br
     fn(C.c_int(kernel), C.c_int(q.shape[0]), pq, pqp, C.c_double(alpha), C.c_double(lam),
        C.c_int(int(ksource)), d.ctypes.data_as(_dp), C.c_int(dirn), C.c_int(mdir))
     return d
+
+
+# --------------------------------------------------------------------- QPBO
+
+def ref_rd(U0, U1, E00, E01, E10, E11, conn, improve=False, stage=0, seed=None):
+    """The REFERENCE QPBO library behind the restated rd_mex gateway (oracle/_ref).
+    conn (E,2) zero based.  stage 1 stops after Solve() (strong persistency only)."""
+    L = ref_qpbo()
+    if L is None:
+        raise RuntimeError("oracle/_ref/libref_qpbo.so not available")
+    U0, p0 = _d(U0); U1, p1 = _d(U1)
+    E00, a = _d(E00); E01, b = _d(E01); E10, c_ = _d(E10); E11, d = _d(E11)
+    cc, pc = _conn(conn)
+    N, E = U0.shape[0], cc.shape[0]
+    if seed is not None:
+        L.ref_srand(C.c_uint(seed))
+    lab = np.zeros(N)
+    en, lb, nu = C.c_double(), C.c_double(), C.c_double()
+    rc = L.ref_rd_stage(p0, p1, a, b, c_, d, pc, C.c_int64(N), C.c_int64(E), C.c_int(int(improve)),
+                        C.c_int(stage), lab.ctypes.data_as(_dp), C.byref(en), C.byref(lb), C.byref(nu))
+    if rc:
+        raise RuntimeError("ref_rd failed")
+    return lab, en.value, lb.value, nu.value

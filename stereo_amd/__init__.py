@@ -7,5 +7,6 @@ the reference wrappers; arrays use MATLAB shapes (K x N, 2 x E, ...).
 """
 from ._lib import StereoHipError, device_count, LIB_PATH  # noqa: F401
 from .trws import trws, TrwsPlan  # noqa: F401
+from .rd import rd  # noqa: F401
 
-__all__ = ["trws", "TrwsPlan", "StereoHipError", "device_count", "LIB_PATH"]
+__all__ = ["trws", "rd", "TrwsPlan", "StereoHipError", "device_count", "LIB_PATH"]

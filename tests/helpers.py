@@ -54,3 +54,43 @@ def trws_problem(seed, H, W, K, kind="general", integer=False, zero_alpha_frac=0
         alphas[alphas == 0] = 1
     alphas[rng.random(E) < zero_alpha_frac] = 0.0
     return dict(unary=unary, conn=conn, q=q, qprim=qprim, alphas=alphas)
+
+
+def fusion_problem(seed, H, W, kernel=1, tol=8.0, integer=False, unary_scale=40.0, weight=1.0,
+                   nonsub_boost=0.0):
+    """One binary fusion move on an H x W grid: current = noisy fronto-parallel planes,
+    proposal = one slanted plane.  Terms follow dispmap_super.m:236-262 (via oracle.terms).
+    Returns dict(U0, U1, E00, E01, E10, E11, conn (E,2))."""
+    rng = np.random.default_rng(seed)
+    N = H * W
+    conn = grid_conn(H, W)
+    pts = terms.get_points(H, W)
+    cur = np.zeros((4, N)); cur[2] = 1.0
+    cur[3] = -(np.round(rng.uniform(0, 30, N) / 6) * 6 + rng.normal(size=N) * 0.3)
+    prop = random_planes(rng, N, 1, spread=30.0, slant=0.15)[0]
+    wts = np.full(conn.shape[0], weight)
+    E00, E01, E10, E11 = terms.all_pairwise_costs(kernel, wts, tol, cur, prop, conn[:, 0], conn[:, 1], pts)
+    U0 = rng.uniform(0, unary_scale, N)
+    U1 = rng.uniform(0, unary_scale, N)
+    if nonsub_boost:
+        k = rng.random(conn.shape[0]) < 0.2
+        E00 = E00 + nonsub_boost * k
+        E11 = E11 + nonsub_boost * k
+    if integer:
+        U0, U1 = np.round(U0 / 4), np.round(U1 / 4)
+        E00, E01, E10, E11 = (np.round(x) for x in (E00, E01, E10, E11))
+    return dict(U0=U0, U1=U1, E00=E00, E01=E01, E10=E10, E11=E11, conn=conn)
+
+
+def glass_problem(seed, H, W, field=3.0, integer=True):
+    """Frustrated +-J couplings with a weak random field: roof duality leaves part of the
+    grid unlabelled (exercises weak persistency and Improve)."""
+    rng = np.random.default_rng(seed)
+    conn = grid_conn(H, W)
+    E, N = conn.shape[0], H * W
+    J = rng.normal(size=E) * 2
+    U1 = rng.normal(size=N) * field
+    if integer:
+        J, U1 = np.round(J * 2), np.round(U1 * 2)
+    z = np.zeros(E)
+    return dict(U0=np.zeros(N), U1=U1, E00=z.copy(), E01=J.copy(), E10=J.copy(), E11=z.copy(), conn=conn)
