@@ -138,6 +138,51 @@ int stereo_rd(const double *U0, const double *U1, const double *E00, const doubl
               int64_t E, int improve, double *labelling, double *energy,
               double *lower_bound, double *num_unlabelled, char *err, size_t errcap);
 
+/* ---- term builders and cost volume ------------------------------------- *
+ * Device versions of the MATLAB array math between the images and the two
+ * solvers.  Pixels are numbered column-major, id = col*H + row (dispmap_super.m:281-282);
+ * points(:,id) = [col+1; row+1] (:275-278); planes are 4-vectors [a b c d],
+ * disparity = -(a*x + b*y + d)/c (:318-328).  d_step != 0 applies the
+ * dispmap_globalstereo rescaling (d - d_min)/d_step (dispmap_globalstereo.m:336-345).
+ */
+
+/* dispmap_super.m:236-262 all_pairwise_costs (+ :226-235 pairwise_cost).
+ * conn 2 x E zero based [ind1; ind2]; points 2 x N; assignment / proposal 4 x N;
+ * proposal == NULL computes E00 only (update_energy, :263-274).  Planes with c == 0
+ * fail with "Infinite disparity" (:323-325). */
+int stereo_pairwise_terms(int kernel, int64_t N, int64_t E, const uint32_t *conn, const double *points,
+                          const double *assignment, const double *proposal, const double *weights,
+                          double tol, double d_min, double d_step, double *E00, double *E01,
+                          double *E10, double *E11, char *err, size_t errcap);
+
+/* dispmap_super.m:177-183: q(k,e), qprim(k,e) of K proposals (4 x N x K) -> K x E each. */
+int stereo_trws_positions(int64_t N, int64_t E, int K, const uint32_t *conn, const double *points,
+                          const double *proposals, double d_min, double d_step, double *q,
+                          double *qprim, char *err, size_t errcap);
+
+/* dispmap_ncc.m:116-198 compute_ncc.  im0 = reference image, im1 = the image that is
+ * shifted; both H x W x 3 column major doubles.  layout 0: H x W x D (MATLAB, self.ncc);
+ * layout 1: D x (H*W), label fastest -- what TRW-S consumes as `unary` after
+ * unary_weight*(1 - ncc). */
+int stereo_ncc_volume(const double *im0, const double *im1, int H, int W, const double *disparities,
+                      int D, int patchsize, int layout, double *ncc, char *err, size_t errcap);
+
+/* dispmap_ncc.m:107-115 unary_cost = unary_weight*(1 - sample_ncc_from_disp(...)) (:222-276). */
+int stereo_ncc_unary(const double *ncc, int H, int W, int D, int layout, const double *disparities,
+                     double unary_weight, const double *assignment, double *U, char *err,
+                     size_t errcap);
+
+/* dispmap_ncc.m:208-221 best_disp_from_ncc (winner takes all + parabola vertex), H x W. */
+int stereo_ncc_best_disp(const double *ncc, int H, int W, int D, int layout, const double *disparities,
+                         double *best, char *err, size_t errcap);
+
+/* dispmap_globalstereo.m:355-375 unary_cost with ephoto (:405) and the 'linear' branch of
+ * vgg_interp2 (imrender/vgg/vgg_interp2.cxx:245-322, oobv = -1000).  P2 = self.P(:,:,2),
+ * 4 x 3 column major (already permuted, :43). */
+int stereo_globalstereo_unary(const double *im0, const double *im1, int H, int W, int C,
+                              const double *P2, double d_min, double d_step, double col_thresh,
+                              const double *assignment, double *U, char *err, size_t errcap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,7 +148,7 @@ def compute_ncc(im0, im1, disparities, patchsize=2):
     out = np.zeros((H, W, len(disparities)))
     for i, d in enumerate(disparities):
         bnd = np.zeros((H, W))
-        bnd[:, int(round(d + 1)) - 1:] = 1
+        bnd[:, int(np.floor(d + 1 + 0.5)) - 1:] = 1   # MATLAB round(): half away from zero
         tr = _shift_image(im1, d)
         T = [tr[:, :, c] for c in range(3)]
         boxT = [box(x) for x in T]
@@ -272,3 +272,30 @@ def vgg_interp2_linear(A, X, Y, oobv):
                 elif yy == h:
                     out[i] = A[h - 1, w - 1]
     return out
+
+
+def globalstereo_rescale(disps, d_min, d_step):
+    """dispmap_globalstereo.m:336-345: disparity map in units of the search range."""
+    return (disps - d_min) / d_step
+
+
+def globalstereo_unary_cost(im0, im1, P2, d_min, d_step, col_thresh, assignment, points):
+    """dispmap_globalstereo.m:355-375 + ephoto (:405).  im0/im1 (H, W, C) doubles, P2 the
+    4 x 3 matrix self.P(:,:,2) (already permuted, :43), assignment (4, N) -> (N,)."""
+    im0 = np.asarray(im0, np.float64)
+    im1 = np.asarray(im1, np.float64)
+    H, W, Cn = im0.shape
+    dhat = globalstereo_rescale(disparity_from_assignment(assignment, points), d_min, d_step)
+    disp = d_step * (dhat + d_min)                       # sic: exact only for d_min = 0
+    X = points[0]
+    Y = points[1]
+    T = [(X * P2[0, k] + Y * P2[1, k]) + (1.0 * P2[2, k] + disp * P2[3, k]) for k in range(3)]
+    Nrm = 1.0 / T[2]
+    T0 = T[0] * Nrm
+    T1 = T[1] * Nrm
+    R = im0.transpose(1, 0, 2).reshape(H * W, Cn)         # column-major pixels
+    M = vgg_interp2_linear(im1, T0, T1, -1000.0) - R
+    ssd = np.zeros(H * W)
+    for c in range(Cn):
+        ssd = ssd + M[:, c] ** 2
+    return np.log(2.0) - np.log(np.exp(ssd * (-1.0 / (col_thresh * Cn))) + 1.0)

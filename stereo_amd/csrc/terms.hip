@@ -1,0 +1,408 @@
+// Cost-volume and term-builder kernels (MI355X / gfx950) + their C ABI.
+//
+// Device versions of the MATLAB array math that feeds the two solvers:
+//   dispmap_super.m:318-328   plane -> disparity
+//   dispmap_super.m:226-262   truncated |p-q|^k pairwise terms (E00, E01, E10, E11)
+//   dispmap_super.m:177-183   q / qprim of K proposals for TRW-S
+//   dispmap_ncc.m:116-198     5x5xRGB normalised cross-correlation volume
+//   dispmap_ncc.m:107-115,222-276  parabola sampling of the volume -> NCC unary
+//   dispmap_ncc.m:208-221     winner-takes-all initial disparity
+//   dispmap_globalstereo.m:336-345,355-375,405 + imrender/vgg/vgg_interp2.cxx:245-322
+//                             photo-consistency unary (warp, bilinear gather, ephoto)
+// All are independent per pixel / per edge: one thread each, coalesced along the
+// column-major pixel index (MATLAB layout), images served from L2.  HBM-bound
+// streaming kernels; no contraction (-ffp-contract=off) so that + - * / match numpy.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/stereo_hip.h"
+#include "common.h"
+
+namespace stereo {
+namespace {
+
+constexpr int kTB = 256;
+
+__device__ __forceinline__ double plane_disp(const double *pl, double x, double y) {
+  // -(sum(assignment(1:2,:).*points) + assignment(4,:)) ./ assignment(3,:)
+  const double s = pl[0] * x + pl[1] * y;
+  return -(s + pl[3]) / pl[2];
+}
+
+__device__ __forceinline__ double pair_term(int kernel, double w, double p, double q, double tol) {
+  const double d = p - q;
+  const double v = kernel == 1 ? fabs(d) : d * d;
+  return w * (v < tol ? v : tol);
+}
+
+__global__ __launch_bounds__(kTB) void pairwise_terms_kernel(int kernel, int64_t E, const uint32_t *conn,
+                                                            const double *points, const double *cur,
+                                                            const double *prop, const double *w, double tol,
+                                                            double d_min, double d_step, double *E00,
+                                                            double *E01, double *E10, double *E11) {
+  const int64_t e = (int64_t)blockIdx.x * kTB + threadIdx.x;
+  if (e >= E) return;
+  const uint32_t i1 = conn[2 * e], i2 = conn[2 * e + 1];
+  const double x = points[2 * (size_t)i2], y = points[2 * (size_t)i2 + 1];
+  double q = plane_disp(cur + 4 * (size_t)i2, x, y), qp = plane_disp(cur + 4 * (size_t)i1, x, y);
+  if (d_step != 0) { q = (q - d_min) / d_step; qp = (qp - d_min) / d_step; }
+  const double we = w[e];
+  E00[e] = pair_term(kernel, we, q, qp, tol);
+  if (prop) {
+    double nq = plane_disp(prop + 4 * (size_t)i2, x, y), nqp = plane_disp(prop + 4 * (size_t)i1, x, y);
+    if (d_step != 0) { nq = (nq - d_min) / d_step; nqp = (nqp - d_min) / d_step; }
+    E11[e] = pair_term(kernel, we, nq, nqp, tol);
+    E10[e] = pair_term(kernel, we, q, nqp, tol);   // dispmap_super.m:256
+    E01[e] = pair_term(kernel, we, nq, qp, tol);   // dispmap_super.m:259
+  }
+}
+
+__global__ __launch_bounds__(kTB) void trws_positions_kernel(int64_t E, int K, int64_t N, const uint32_t *conn,
+                                                            const double *points, const double *props,
+                                                            double d_min, double d_step, double *q,
+                                                            double *qprim) {
+  const int64_t t = (int64_t)blockIdx.x * kTB + threadIdx.x;
+  if (t >= E * K) return;
+  const int64_t e = t / K;
+  const int k = (int)(t % K);
+  const uint32_t i1 = conn[2 * e], i2 = conn[2 * e + 1];
+  const double x = points[2 * (size_t)i2], y = points[2 * (size_t)i2 + 1];
+  const double *P = props + (size_t)k * 4 * N;
+  double a = plane_disp(P + 4 * (size_t)i2, x, y), b = plane_disp(P + 4 * (size_t)i1, x, y);
+  if (d_step != 0) { a = (a - d_min) / d_step; b = (b - d_min) / d_step; }
+  q[t] = a;       // K x E column major: label fastest
+  qprim[t] = b;
+}
+
+// ---- NCC volume -----------------------------------------------------------
+
+struct NccParams {
+  int H, W, D, r;
+  const double *im0, *im1;  // H x W x 3 column major
+  const double *disp;       // D
+  double *out;
+  int layout;               // 0: H x W x D (MATLAB), 1: D x N label fastest
+};
+
+// right image shifted by d (dispmap_ncc.m:145-154), zero outside the filled columns
+__device__ __forceinline__ double shifted(const NccParams &p, int row, int col, int ch, double d, int c0, int n,
+                                          double step) {
+  if (row < 0 || row >= p.H || col < 0 || col >= p.W) return 0.0;  // conv2 'same' zero padding
+  if (col + 1 < c0) return 0.0;
+  const int i = col + 1 - c0;
+  const double X = n > 1 ? 1.0 + i * step : 1.0;  // linspace(1, W-d, n)
+  int x0 = (int)floor(X);
+  if (x0 < 1) x0 = 1;
+  if (p.W > 1 && x0 > p.W - 1) x0 = p.W - 1;
+  const double t = X - x0;
+  const double *plane = p.im1 + (size_t)ch * p.H * p.W;
+  const double left = plane[(size_t)(x0 - 1) * p.H + row];
+  if (t == 0) return left;
+  const int xr = x0 < p.W - 1 ? x0 : p.W - 1;
+  const double right = plane[(size_t)xr * p.H + row];
+  return left * (1 - t) + right * t;
+}
+
+__device__ __forceinline__ double ref_px(const NccParams &p, int row, int col, int ch) {
+  if (row < 0 || row >= p.H || col < 0 || col >= p.W) return 0.0;
+  return p.im0[(size_t)ch * p.H * p.W + (size_t)col * p.H + row];
+}
+
+__global__ __launch_bounds__(kTB) void ncc_volume_kernel(NccParams p) {
+  const int64_t t = (int64_t)blockIdx.x * kTB + threadIdx.x;
+  const int64_t Npx = (int64_t)p.H * p.W;
+  if (t >= Npx * p.D) return;
+  const int di = (int)(t / Npx);
+  const int64_t px = t % Npx;
+  const int row = (int)(px % p.H), col = (int)(px / p.H);
+  const double d = p.disp[di];
+  const int c0 = (int)ceil(d + 1);
+  const int n = p.W - c0 + 1;
+  const double step = n > 1 ? ((p.W - d) - 1.0) / (n - 1) : 0.0;
+  const int r = p.r;
+  const double npatch = (double)((2 * r + 1) * (2 * r + 1));
+  const double mscale = 1.0 / npatch / 3.0;
+  double bL[3] = {0, 0, 0}, bT[3] = {0, 0, 0}, bLL[3] = {0, 0, 0}, bTT[3] = {0, 0, 0}, bLT[3] = {0, 0, 0};
+  for (int dx = -r; dx <= r; ++dx)
+    for (int dy = -r; dy <= r; ++dy)
+      for (int ch = 0; ch < 3; ++ch) {
+        const double L = ref_px(p, row + dy, col + dx, ch);
+        const double T = shifted(p, row + dy, col + dx, ch, d, c0, n, step);
+        bL[ch] += L; bT[ch] += T; bLL[ch] += L * L; bTT[ch] += T * T; bLT[ch] += L * T;
+      }
+  const double meanL = (bL[0] * mscale + bL[1] * mscale) + bL[2] * mscale;
+  const double meanT = (bT[0] * mscale + bT[1] * mscale) + bT[2] * mscale;
+  const double t1L = (bLL[0] + bLL[1]) + bLL[2];
+  const double t2L = (meanL * bL[0] + meanL * bL[1]) + meanL * bL[2];
+  const double varL = t1L - 2 * t2L + npatch * 3 * meanL * meanL;
+  const double u1 = (bTT[0] + bTT[1]) + bTT[2];
+  const double u2 = (meanT * bT[0] + meanT * bT[1]) + meanT * bT[2];
+  const double varT = u1 - 2 * u2 + npatch * 3 * meanT * meanT;
+  const double c1 = (bLT[0] + bLT[1]) + bLT[2];
+  const double c2 = (meanL * bT[0] + meanL * bT[1]) + meanL * bT[2];
+  const double c3 = (meanT * bL[0] + meanT * bL[1]) + meanT * bL[2];
+  const double num = c1 - c2 - c3 + npatch * 3 * meanT * meanL;
+  // sqrt of a negative variance is imaginary in MATLAB; real(num/normL/normT) follows
+  // (dispmap_ncc.m:141,171,188-192): one imaginary norm -> 0, both -> -num/(sL*sT)
+  double val;
+  const double sL = sqrt(fabs(varL)), sT = sqrt(fabs(varT));
+  if (varL >= 0 && varT >= 0) val = num / sL / sT;
+  else if (varL < 0 && varT < 0) val = -(num / sL / sT);
+  else val = 0.0;
+  if (!isfinite(val)) val = 0.0;
+  const int cmask = (int)floor(d + 1 + 0.5);  // bnd_im(:, round(d+1):end) = 1, MATLAB round()
+  if (col + 1 < cmask) val = 0.0;
+  if (p.layout == 0) p.out[(size_t)di * Npx + px] = val;
+  else p.out[(size_t)px * p.D + di] = val;
+}
+
+// ---- NCC sampling (dispmap_ncc.m:222-276) -----------------------------------
+
+__device__ __forceinline__ double vol(const double *ncc, int64_t Npx, int D, int layout, int64_t px, int k) {
+  return layout == 0 ? ncc[(size_t)k * Npx + px] : ncc[(size_t)px * D + k];
+}
+
+__device__ __forceinline__ void lagrange(const double *ncc, int64_t Npx, int D, int layout, int64_t px,
+                                         const double *dv, int t2 /*1-based*/, double y2, bool ok, double &r,
+                                         double &pp, double &q, double &d2) {
+  const int t1 = ok ? t2 - 1 : t2, t3 = ok ? t2 + 1 : t2;
+  const double d1 = dv[t1 - 1], d3 = dv[t3 - 1];
+  d2 = dv[t2 - 1];
+  const double y1 = vol(ncc, Npx, D, layout, px, t1 - 1), y3 = vol(ncc, Npx, D, layout, px, t3 - 1);
+  const double a = y1 / (d1 - d2) / (d1 - d3);
+  const double b = y2 / (d2 - d1) / (d2 - d3);
+  const double c = y3 / (d3 - d1) / (d3 - d2);
+  r = a + b + c;
+  pp = -(a * (d2 + d3) + b * (d1 + d3) + c * (d1 + d2));
+  q = a * d2 * d3 + b * d1 * d3 + c * d1 * d2;
+}
+
+__global__ __launch_bounds__(kTB) void ncc_unary_kernel(const double *ncc, int H, int W, int D, int layout,
+                                                       const double *dv, double dmin, double dmax,
+                                                       double unary_weight, const double *assign, double *U) {
+  const int64_t px = (int64_t)blockIdx.x * kTB + threadIdx.x;
+  const int64_t Npx = (int64_t)H * W;
+  if (px >= Npx) return;
+  const double x = (double)(px / H + 1), y = (double)(px % H + 1);
+  const double disp = plane_disp(assign + 4 * (size_t)px, x, y);
+  int t2 = 1;
+  double smallest = fabs(disp - dv[0]), y2 = 1.0;
+  for (int i = 0; i < D; ++i) {
+    const double nd = fabs(disp - dv[i]);
+    if (nd <= smallest) { t2 = i + 1; y2 = vol(ncc, Npx, D, layout, px, i); smallest = nd; }
+  }
+  const bool ok = t2 < D && t2 > 1;
+  double r, pp, q, d2;
+  lagrange(ncc, Npx, D, layout, px, dv, t2, y2, ok, r, pp, q, d2);
+  double v = r * (disp * disp) + pp * disp + q;
+  if (t2 == 1) v = vol(ncc, Npx, D, layout, px, 0);
+  if (t2 == D) v = vol(ncc, Npx, D, layout, px, D - 1);
+  if (!(disp <= dmax && disp >= dmin)) v = -1e6;
+  U[px] = unary_weight * (1 - v);
+}
+
+__global__ __launch_bounds__(kTB) void ncc_best_disp_kernel(const double *ncc, int H, int W, int D, int layout,
+                                                           const double *dv, double *best) {
+  const int64_t px = (int64_t)blockIdx.x * kTB + threadIdx.x;
+  const int64_t Npx = (int64_t)H * W;
+  if (px >= Npx) return;
+  int t2 = 1;
+  double y2 = vol(ncc, Npx, D, layout, px, 0);
+  for (int i = 1; i < D; ++i) {
+    const double v = vol(ncc, Npx, D, layout, px, i);
+    if (v > y2) { y2 = v; t2 = i + 1; }  // max(...,[],3): first maximum
+  }
+  const bool ok = t2 < D && t2 > 1;
+  double r, pp, q, d2;
+  lagrange(ncc, Npx, D, layout, px, dv, t2, y2, ok, r, pp, q, d2);
+  best[px] = ok ? -pp / r / 2 : d2;
+}
+
+// ---- globalstereo unary -------------------------------------------------------
+
+__global__ __launch_bounds__(kTB) void globalstereo_unary_kernel(const double *im0, const double *im1, int H,
+                                                                int W, int C, const double *P2 /*4x3 col major*/,
+                                                                double d_min, double d_step, double col_thresh,
+                                                                const double *assign, double *U) {
+  const int64_t px = (int64_t)blockIdx.x * kTB + threadIdx.x;
+  const int64_t Npx = (int64_t)H * W;
+  if (px >= Npx) return;
+  const double x = (double)(px / H + 1), y = (double)(px % H + 1);
+  const double dhat = (plane_disp(assign + 4 * (size_t)px, x, y) - d_min) / d_step;
+  const double disp = d_step * (dhat + d_min);  // dispmap_globalstereo.m:356 (sic)
+  double T[3];
+  for (int k = 0; k < 3; ++k)
+    T[k] = (x * P2[4 * k] + y * P2[4 * k + 1]) + (1.0 * P2[4 * k + 2] + disp * P2[4 * k + 3]);
+  const double Nn = 1.0 / T[2];
+  const double X = T[0] * Nn, Y = T[1] * Nn;
+  const double oobv = -1000.0, dw = (double)W, dh = (double)H;
+  double ssd = 0;
+  for (int c = 0; c < C; ++c) {
+    const double *A = im1 + (size_t)c * Npx;
+    double o = oobv;
+    if (X >= 1 && Y >= 1) {  // vgg_interp2.cxx:260-317
+      if (X < dw) {
+        if (Y < dh) {
+          const int xi = (int)X, yi = (int)Y;
+          const double u = X - xi, v = Y - yi;
+          const size_t k = (size_t)H * (xi - 1) + yi - 1;
+          o = A[k] + (A[k + H] - A[k]) * u;
+          o += ((A[k + 1] - o) + (A[k + H + 1] - A[k + 1]) * u) * v;
+        } else if (Y == dh) {
+          const int xi = (int)X;
+          const double u = X - xi;
+          const size_t k = (size_t)H * xi - 1;
+          o = A[k] + (A[k + H] - A[k]) * u;
+        }
+      } else if (X == dw) {
+        if (Y < dh) {
+          const int yi = (int)Y;
+          const double v = Y - yi;
+          const size_t k = (size_t)H * (W - 1) + yi - 1;
+          o = A[k] + (A[k + 1] - A[k]) * v;
+        } else if (Y == dh) {
+          o = A[(size_t)H * W - 1];
+        }
+      }
+    }
+    const double m = o - im0[(size_t)c * Npx + px];
+    ssd = ssd + m * m;
+  }
+  U[px] = log(2.0) - log(exp(ssd * (-1.0 / (col_thresh * C))) + 1.0);
+}
+
+template <class F>
+int guarded(const char *what, char *err, size_t errcap, F f) {
+  if (stereo_hip_device_count() < 1)
+    return fail(std::string(what) + ": no HIP device available (the HIP path has no CPU fallback)", err, errcap);
+  try {
+    f();
+    STEREO_HIP_CHECK(hipGetLastError());
+    STEREO_HIP_CHECK(hipDeviceSynchronize());
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  } catch (const std::exception &e) {
+    return fail(std::string(what) + ": " + e.what(), err, errcap);
+  }
+}
+
+inline unsigned blocks(int64_t n) { return (unsigned)((n + kTB - 1) / kTB); }
+
+void check_planes(const double *pl, int64_t M) {
+  for (int64_t i = 0; i < M; ++i)
+    if (pl[4 * i + 2] == 0) throw std::runtime_error("Infinite disparity");  // dispmap_super.m:323-325
+}
+
+template <class T>
+void download(T *dst, const DevBuf<T> &b, size_t n) {
+  STEREO_HIP_CHECK(hipMemcpy(dst, b.p, n * sizeof(T), hipMemcpyDeviceToHost));
+}
+
+}  // namespace
+}  // namespace stereo
+
+using namespace stereo;
+
+extern "C" {
+
+int stereo_pairwise_terms(int kernel, int64_t N, int64_t E, const uint32_t *conn, const double *points,
+                          const double *assignment, const double *proposal, const double *weights, double tol,
+                          double d_min, double d_step, double *E00, double *E01, double *E10, double *E11,
+                          char *err, size_t errcap) {
+  if (kernel != 1 && kernel != 2) return fail("Unkown kernel type", err, errcap);  // dispmap_super.m:233
+  if (!conn || !points || !assignment || !weights || !E00 || (proposal && (!E01 || !E10 || !E11)))
+    return fail("stereo_pairwise_terms: NULL argument", err, errcap);
+  return guarded("stereo_pairwise_terms", err, errcap, [&] {
+    check_planes(assignment, N);
+    if (proposal) check_planes(proposal, N);
+    DevBuf<uint32_t> dc; DevBuf<double> dp, da, dpr, dw, o0, o1, o2, o3;
+    dc.upload(conn, 2 * E); dp.upload(points, 2 * N); da.upload(assignment, 4 * N); dw.upload(weights, E);
+    if (proposal) dpr.upload(proposal, 4 * N);
+    o0.alloc(E); o1.alloc(E); o2.alloc(E); o3.alloc(E);
+    hipLaunchKernelGGL(pairwise_terms_kernel, dim3(blocks(E)), dim3(kTB), 0, 0, kernel, E, dc.p, dp.p, da.p,
+                       proposal ? dpr.p : nullptr, dw.p, tol, d_min, d_step, o0.p, o1.p, o2.p, o3.p);
+    download(E00, o0, E);
+    if (proposal) { download(E01, o1, E); download(E10, o2, E); download(E11, o3, E); }
+  });
+}
+
+int stereo_trws_positions(int64_t N, int64_t E, int K, const uint32_t *conn, const double *points,
+                          const double *proposals, double d_min, double d_step, double *q, double *qprim,
+                          char *err, size_t errcap) {
+  if (!conn || !points || !proposals || !q || !qprim || K < 1)
+    return fail("stereo_trws_positions: bad argument", err, errcap);
+  return guarded("stereo_trws_positions", err, errcap, [&] {
+    check_planes(proposals, N * K);
+    DevBuf<uint32_t> dc; DevBuf<double> dp, dpr, oq, oqp;
+    dc.upload(conn, 2 * E); dp.upload(points, 2 * N); dpr.upload(proposals, (size_t)4 * N * K);
+    oq.alloc((size_t)E * K); oqp.alloc((size_t)E * K);
+    hipLaunchKernelGGL(trws_positions_kernel, dim3(blocks(E * K)), dim3(kTB), 0, 0, E, K, N, dc.p, dp.p, dpr.p,
+                       d_min, d_step, oq.p, oqp.p);
+    download(q, oq, (size_t)E * K); download(qprim, oqp, (size_t)E * K);
+  });
+}
+
+int stereo_ncc_volume(const double *im0, const double *im1, int H, int W, const double *disparities, int D,
+                      int patchsize, int layout, double *ncc, char *err, size_t errcap) {
+  if (!im0 || !im1 || !disparities || !ncc || H < 1 || W < 1 || D < 1 || patchsize < 0 || (layout != 0 && layout != 1))
+    return fail("stereo_ncc_volume: bad argument", err, errcap);
+  return guarded("stereo_ncc_volume", err, errcap, [&] {
+    const size_t npx = (size_t)H * W;
+    DevBuf<double> d0, d1, dd, out;
+    d0.upload(im0, npx * 3); d1.upload(im1, npx * 3); dd.upload(disparities, D); out.alloc(npx * D);
+    NccParams p{H, W, D, patchsize, d0.p, d1.p, dd.p, out.p, layout};
+    hipLaunchKernelGGL(ncc_volume_kernel, dim3(blocks((int64_t)npx * D)), dim3(kTB), 0, 0, p);
+    download(ncc, out, npx * D);
+  });
+}
+
+int stereo_ncc_unary(const double *ncc, int H, int W, int D, int layout, const double *disparities,
+                     double unary_weight, const double *assignment, double *U, char *err, size_t errcap) {
+  if (!ncc || !disparities || !assignment || !U || D < 1) return fail("stereo_ncc_unary: bad argument", err, errcap);
+  return guarded("stereo_ncc_unary", err, errcap, [&] {
+    const size_t npx = (size_t)H * W;
+    check_planes(assignment, npx);
+    double dmin = disparities[0], dmax = disparities[0];
+    for (int i = 1; i < D; ++i) { dmin = std::min(dmin, disparities[i]); dmax = std::max(dmax, disparities[i]); }
+    DevBuf<double> dn, dd, da, out;
+    dn.upload(ncc, npx * D); dd.upload(disparities, D); da.upload(assignment, 4 * npx); out.alloc(npx);
+    hipLaunchKernelGGL(ncc_unary_kernel, dim3(blocks(npx)), dim3(kTB), 0, 0, dn.p, H, W, D, layout, dd.p, dmin,
+                       dmax, unary_weight, da.p, out.p);
+    download(U, out, npx);
+  });
+}
+
+int stereo_ncc_best_disp(const double *ncc, int H, int W, int D, int layout, const double *disparities,
+                         double *best, char *err, size_t errcap) {
+  if (!ncc || !disparities || !best || D < 1) return fail("stereo_ncc_best_disp: bad argument", err, errcap);
+  return guarded("stereo_ncc_best_disp", err, errcap, [&] {
+    const size_t npx = (size_t)H * W;
+    DevBuf<double> dn, dd, out;
+    dn.upload(ncc, npx * D); dd.upload(disparities, D); out.alloc(npx);
+    hipLaunchKernelGGL(ncc_best_disp_kernel, dim3(blocks(npx)), dim3(kTB), 0, 0, dn.p, H, W, D, layout, dd.p, out.p);
+    download(best, out, npx);
+  });
+}
+
+int stereo_globalstereo_unary(const double *im0, const double *im1, int H, int W, int C, const double *P2,
+                              double d_min, double d_step, double col_thresh, const double *assignment,
+                              double *U, char *err, size_t errcap) {
+  if (!im0 || !im1 || !P2 || !assignment || !U || C < 1) return fail("stereo_globalstereo_unary: bad argument", err, errcap);
+  return guarded("stereo_globalstereo_unary", err, errcap, [&] {
+    const size_t npx = (size_t)H * W;
+    check_planes(assignment, npx);
+    DevBuf<double> d0, d1, dP, da, out;
+    d0.upload(im0, npx * C); d1.upload(im1, npx * C); dP.upload(P2, 12); da.upload(assignment, 4 * npx);
+    out.alloc(npx);
+    hipLaunchKernelGGL(globalstereo_unary_kernel, dim3(blocks(npx)), dim3(kTB), 0, 0, d0.p, d1.p, H, W, C, dP.p,
+                       d_min, d_step, col_thresh, da.p, out.p);
+    download(U, out, npx);
+  });
+}
+
+}  // extern "C"
