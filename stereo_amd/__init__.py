@@ -8,5 +8,6 @@ the reference wrappers; arrays use MATLAB shapes (K x N, 2 x E, ...).
 from ._lib import StereoHipError, device_count, LIB_PATH  # noqa: F401
 from .trws import trws, TrwsPlan  # noqa: F401
 from .rd import rd  # noqa: F401
+from .dispmap import dispmap_super, dispmap_ncc, dispmap_globalstereo  # noqa: F401
 
-__all__ = ["trws", "rd", "TrwsPlan", "StereoHipError", "device_count", "LIB_PATH"]
+__all__ = ["trws", "rd", "dispmap_super", "dispmap_ncc", "dispmap_globalstereo", "TrwsPlan", "StereoHipError", "device_count", "LIB_PATH"]

@@ -1,0 +1,283 @@
+"""Host-side mirror of the reference's problem classes (dispmap_super.m,
+dispmap_ncc.m, dispmap_globalstereo.m): same method names, argument meaning and
+error behaviour, every array operation and both solvers running on the GPU through
+the C ABI.  Planes are 4 x N arrays, images H x W x C doubles.
+
+Not mirrored (out of scope for the hot path): proposal generators
+(generate_new_plane_RANSAC, segpln), mean-shift segmentation (edge weights enter as an
+array or a segment-label image), figures.
+"""
+import numpy as np
+
+from . import terms as T
+from ._lib import StereoHipError
+from .rd import rd
+from .trws import trws
+
+
+class dispmap_super:
+    """dispmap_super.m.  Subclasses provide unary_cost()."""
+
+    def __init__(self, images, kernel):
+        self.images = [np.asarray(im, dtype=np.float64) for im in images]
+        self.sz = self.images[0].shape[:2]
+        self.maxiter = 1000          # dispmap_super.m:9
+        self._max_relgap = 1e-4      # dispmap_super.m:10
+        self._improve = False        # dispmap_super.m:13
+        self._assignment = None
+        self.stored_energy = np.inf
+        self._kernel = kernel
+        self.neighborhood = T.construct_neighborhood(*self.sz)          # zero based 2 x E
+        self.points = T.get_points(*self.sz)
+        self.smooth_weights = np.ones(self.neighborhood.shape[1])       # dispmap_super.m:35
+        self.d_min, self.d_step = 0.0, 0.0                              # rescaling only in globalstereo
+
+    # ---- properties with the reference's setters (dispmap_super.m:39-56)
+    @property
+    def max_relgap(self):
+        return self._max_relgap
+
+    @max_relgap.setter
+    def max_relgap(self, v):
+        if v < 0:
+            raise StereoHipError("Maximum relative gap must be non-negative")
+        self._max_relgap = v
+
+    @property
+    def improve(self):
+        return self._improve
+
+    @improve.setter
+    def improve(self, v):
+        self._improve = bool(v)
+
+    @property
+    def assignment(self):
+        return self._assignment
+
+    @assignment.setter
+    def assignment(self, a):
+        self._assignment = np.asfortranarray(a, dtype=np.float64)
+        self.update_energy()
+
+    @property
+    def smoothness_kernel(self):
+        return self._kernel
+
+    @smoothness_kernel.setter
+    def smoothness_kernel(self, k):
+        self._kernel = k
+        self.update_energy()
+
+    def energy(self):
+        return self.stored_energy
+
+    # ---- terms
+    def unary_cost(self, assignment):
+        raise StereoHipError("Overload unary_cost")
+
+    def disparitymap_from_assignment(self, assignment, points=None):
+        pts = self.points if points is None else points
+        if np.any(assignment[2] == 0):
+            raise StereoHipError("Infinite disparity")
+        d = -((assignment[0] * pts[0] + assignment[1] * pts[1]) + assignment[3]) / assignment[2]
+        if self.d_step != 0:
+            d = (d - self.d_min) / self.d_step
+        return d
+
+    def all_pairwise_costs(self, assignment, proposal=None):
+        return T.pairwise_terms(self._kernel, self.neighborhood, self.points, assignment, proposal,
+                                self.smooth_weights, self.tol, self.d_min, self.d_step)
+
+    def update_energy(self):
+        """dispmap_super.m:263-274"""
+        if self._assignment is None or not hasattr(self, "tol"):
+            self.stored_energy = np.inf
+            return
+        U = self.unary_cost(self._assignment)
+        P = self.all_pairwise_costs(self._assignment)
+        self.stored_energy = float(np.sum(U) + np.sum(P))
+
+    # ---- moves
+    def binary_fusion(self, proposal):
+        """dispmap_super.m:61-84"""
+        proposal = np.asfortranarray(proposal, dtype=np.float64)
+        if proposal.shape != self._assignment.shape:
+            raise StereoHipError("Binary fusion: Proposals is of wrong size")
+        E00, E01, E10, E11 = self.all_pairwise_costs(self._assignment, proposal)
+        U0 = self.unary_cost(self._assignment)
+        U1 = self.unary_cost(proposal)
+        labelling, e, lb, num_unlabelled = rd(U0, U1, E00, E01, E10, E11, self.neighborhood + 1,
+                                              {"improve": self._improve})
+        a = self._assignment.copy(order="F")
+        take = labelling == 1
+        a[:, take] = proposal[:, take]
+        self.assignment = a
+        return e, lb, num_unlabelled
+
+    def binary_fuse_until_convergence(self, proposal_cell, rng=None):
+        """dispmap_super.m:85-152, including its quirks (the loop variable is bumped inside the
+        body, so ids(2) is fused first).  `rng` supplies the random revisit order (MATLAB's
+        randi stream cannot be reproduced): a numpy Generator or an explicit id list."""
+        if not isinstance(proposal_cell, (list, tuple)):
+            raise StereoHipError("Input proposals should be given in cell array.")
+        n = len(proposal_cell)
+        number_of_random_ids = self.maxiter * 5
+        if rng is None or isinstance(rng, np.random.Generator):
+            rng = rng or np.random.default_rng()
+            rand_ids = rng.integers(1, n + 1, number_of_random_ids)
+        else:
+            rand_ids = np.asarray(rng, dtype=np.int64)
+        ids = np.concatenate([np.arange(1, n + 1), rand_ids])
+        ids[:-1][np.diff(ids) == 0] = 0         # ids([diff(ids) == 0]) = 0 zeroes the FIRST of a repeated pair
+        ids = ids[(ids >= 1) & (ids <= n)]
+        E = [self.energy()]
+        visited = np.zeros(n, dtype=bool)
+        for it in range(1, self.maxiter + 1):
+            if it > number_of_random_ids:
+                ids = np.concatenate([ids, ids])
+            it1 = it + 1                          # iter = iter + 1 inside the for body
+            if it1 > len(ids):
+                break
+            pid = ids[it1 - 1]
+            if visited[pid - 1]:
+                continue
+            self.binary_fusion(proposal_cell[pid - 1])
+            E.append(self.energy())
+            if E[-2] != E[-1]:
+                visited[:] = False
+            else:
+                visited[pid - 1] = True
+            if visited.all():
+                break
+        return len(E)
+
+    def simultaneous_fusion(self, proposal_cell):
+        """dispmap_super.m:153-198"""
+        if not isinstance(proposal_cell, (list, tuple)):
+            raise StereoHipError("Input proposals should be given in cell array.")
+        props = [np.asfortranarray(p, dtype=np.float64) for p in proposal_cell] + [self._assignment]
+        unary = np.stack([self.unary_cost(p) for p in props], axis=0)             # K x N
+        q, qprim = T.trws_positions(self.neighborhood, self.points, props, self.d_min, self.d_step)
+        L, e, lb, iterations = trws(np.int32(self._kernel), unary, self.neighborhood + 1, q, qprim,
+                                    self.smooth_weights.reshape(-1), self.tol,
+                                    {"maxiter": self.maxiter, "max_relgap": self._max_relgap})
+        a = np.zeros_like(props[0])
+        for i, p in enumerate(props):
+            a[:, L == i + 1] = p[:, L == i + 1]
+        self.assignment = a
+        return e, lb, iterations
+
+    def current_dispmap(self):
+        return self.disparitymap_from_assignment(self._assignment).reshape(self.sz[1], self.sz[0]).T
+
+    def set_disparity(self, disp):
+        a = np.zeros((4, self.sz[0] * self.sz[1]))
+        a[2] = 1
+        a[3] = -np.asarray(disp, np.float64).T.reshape(-1)   # column-major (:)
+        self.assignment = a
+
+
+class dispmap_ncc(dispmap_super):
+    """dispmap_ncc.m"""
+
+    def __init__(self, images, disparities, kernel, unary_weight, tol):
+        super().__init__(images, kernel)
+        self.disparities = np.asarray(disparities, dtype=np.float64).reshape(-1)
+        self._unary_weight = unary_weight
+        self._tol = tol
+        self.ncc = T.ncc_volume(self.images[0], self.images[1], self.disparities, 2)   # compute_ncc(self, 2)
+        self.init_solution()
+
+    @property
+    def tol(self):
+        return self._tol
+
+    @tol.setter
+    def tol(self, v):
+        if v < 0:
+            raise StereoHipError("Tolerance weight must be positive")
+        self._tol = v
+        self.update_energy()
+
+    @property
+    def unary_weight(self):
+        return self._unary_weight
+
+    @unary_weight.setter
+    def unary_weight(self, v):
+        if v < 0:
+            raise StereoHipError("Unary weight must be positive")
+        self._unary_weight = v
+        self.update_energy()
+
+    def unary_cost(self, assignment):
+        return T.ncc_unary(self.ncc, self.disparities, self._unary_weight, assignment)
+
+    def best_disp_from_ncc(self):
+        return T.ncc_best_disp(self.ncc, self.disparities)
+
+    def init_solution(self):
+        self.set_disparity(self.best_disp_from_ncc())
+
+    restart = init_solution
+
+
+class dispmap_globalstereo(dispmap_super):
+    """dispmap_globalstereo.m with the constants of ojw_default_options('cvpr08')
+    (imrender/ojw/ojw_default_options.m:58-80) as defaults.  The mean-shift segmentation of
+    preprocess() (:391) is out of scope: pass `segment` (H x W labels) or `smooth_weights`."""
+
+    def __init__(self, images, P, disp_range, disparity_factor, options=None, segment=None,
+                 smooth_weights=None, start_disparity=None, rng=None):
+        opt = dict(smoothness_kernel=1, disp_thresh=0.02, col_thresh=30.0, lambda_l=9.0, lambda_h=108.0,
+                   connect=4, improve=1)
+        opt.update(options or {})
+        super().__init__(images, opt["smoothness_kernel"])
+        self.options = opt
+        P = np.asarray(P, dtype=np.float64)
+        if np.max(np.abs(P[:, :, 0].T.reshape(-1)[[0, 1, 2, 3, 4, 5, 8]] - np.array([1, 0, 0, 0, 1, 0, 1.0]))) > 1e-12:
+            raise StereoHipError("First image must be reference image")
+        self.P2 = np.asfortranarray(P[:, :, 1].T)          # self.P = permute(P, [2 1 3]); a = 2
+        disps = np.arange(disp_range[0] * disparity_factor, disp_range[1] * disparity_factor + 1)[::-1]
+        self.d_min = float(disps[-1])
+        self.d_step = float(disps[0] - self.d_min)
+        self._tol = opt["disp_thresh"]
+        self._improve = opt["improve"] > 0
+        nin = len(self.images)
+        if smooth_weights is not None:
+            self.smooth_weights = np.asarray(smooth_weights, np.float64).reshape(-1)
+        elif segment is not None:
+            seg = np.asarray(segment).T.reshape(-1)
+            same = seg[self.neighborhood[0]] == seg[self.neighborhood[1]]
+            ew = same * opt["lambda_h"] + (~same) * opt["lambda_l"]                   # :400-402
+            self.smooth_weights = ew * (nin / ((opt["connect"] == 8) + 1))            # :403
+        if self._kernel == 2:                                                          # :410-413
+            self.smooth_weights = self.smooth_weights / self._tol
+            self._tol = self._tol ** 2
+        H, W = self.sz
+        if start_disparity is None:
+            rng = rng or np.random.default_rng()
+            start_disparity = rng.random((H, W)) * self.d_step + self.d_min          # :56
+        self.start_disparity = np.asarray(start_disparity, np.float64)
+        self.init_solution()
+
+    @property
+    def tol(self):
+        return self._tol
+
+    @tol.setter
+    def tol(self, v):
+        if v < 0:
+            raise StereoHipError("Tolerance weight must be positive")
+        self._tol = v
+        self.update_energy()
+
+    def unary_cost(self, assignment):
+        return T.globalstereo_unary(self.images[0], self.images[1], self.P2, self.d_min, self.d_step,
+                                    self.options["col_thresh"], assignment)
+
+    def init_solution(self):
+        self.set_disparity(self.start_disparity)
+
+    restart = init_solution
