@@ -199,3 +199,20 @@ def ref_rd(U0, U1, E00, E01, E10, E11, conn, improve=False, stage=0, seed=None):
     if rc:
         raise RuntimeError("ref_rd failed")
     return lab, en.value, lb.value, nu.value
+
+
+def rd(U0, U1, E00, E01, E10, E11, conn, improve=False, stage=0, seed=None):
+    """This repo's restatement (oracle/qpbo_oracle.c); same interface as ref_rd."""
+    U0, p0 = _d(U0); U1, p1 = _d(U1)
+    E00, a = _d(E00); E01, b = _d(E01); E10, c_ = _d(E10); E11, d = _d(E11)
+    cc, pc = _conn(conn)
+    N, E = U0.shape[0], cc.shape[0]
+    if seed is not None:
+        C.CDLL(None).srand(C.c_uint(seed))
+    lab = np.zeros(N)
+    en, lb, nu = C.c_double(), C.c_double(), C.c_double()
+    rc = lib().oracle_rd(p0, p1, a, b, c_, d, pc, C.c_int64(N), C.c_int64(E), C.c_int(int(improve)),
+                         C.c_int(stage), lab.ctypes.data_as(_dp), C.byref(en), C.byref(lb), C.byref(nu))
+    if rc:
+        raise RuntimeError("oracle_rd failed rc=%d" % rc)
+    return lab, en.value, lb.value, nu.value
