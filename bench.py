@@ -61,18 +61,10 @@ def main():
     ap.add_argument("--message-mode", choices=["exact", "minplus"], default="exact")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+    from stereo_amd import dist as D
+    rank, local_rank, world, dist = D.init("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    torch.cuda.set_device(local_rank)
 
     import stereo_amd
     from stereo_amd import _lib
@@ -97,10 +89,7 @@ def main():
     plan.stats(reset=True)  # enables per-iteration sweep timing with HIP events
 
     def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        D.barrier(dist, dev)
 
     NEVER = -1e300  # (E-LB)/E < max_relgap can fire with max_relgap = 0 once E ~ LB; time exactly K steps
     plan.iterate(args.warmup, max_relgap=NEVER)
@@ -112,10 +101,8 @@ def main():
     assert done == args.steps, (done, args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # every rank ran `steps` iterations on its own image pair: whole-job rate = all units / slowest rank
+    rate, dt = D.throughput(dist, args.steps, dt, dev)
     sweep_ms, sweep_launches = plan.stats()
     serial_msgs = plan.serial_messages()
     _, energy, lb, iters = plan.result(want_labels=False)
@@ -131,7 +118,7 @@ def main():
         achieved = bytes_per_launch / avg_launch_s / 1e9
         out = {
             "metric": "TRW-S fusion iterations/sec, 450x375x60 labels",
-            "value": world * args.steps / dt,
+            "value": rate,
             "unit": "iterations/s",
             "n_gpus": world,
             "steps": args.steps,
