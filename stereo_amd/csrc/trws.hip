@@ -741,7 +741,7 @@ __global__ __launch_bounds__(kBlock) void trws_persistent_kernel(DevParams p, in
 //  * a node's completion flag is raised in the middle of the next visit, when
 //    its write-through stores have long drained, so no store latency is exposed.
 struct NodeDesc {
-  int node, rank, nout, nin, ndep, md, lbn;
+  int node, rank, nout, nin, ndep, md, lbn, urgent;
   int e[8], slot[8], dep[4], lbe[8], xn[8];
 };
 #define RLI(v, i) __builtin_amdgcn_readlane((v), (i))
@@ -760,6 +760,7 @@ __device__ __forceinline__ NodeDesc decode_desc(int w) {
   d.lbe[4] = RLI(w, 28); d.lbe[5] = RLI(w, 29); d.lbe[6] = RLI(w, 30); d.lbe[7] = RLI(w, 31);
   d.xn[0] = RLI(w, 32); d.xn[1] = RLI(w, 33); d.xn[2] = RLI(w, 34); d.xn[3] = RLI(w, 35);
   d.xn[4] = RLI(w, 36); d.xn[5] = RLI(w, 37); d.xn[6] = RLI(w, 38); d.xn[7] = RLI(w, 39);
+  d.urgent = RLI(w, 40);
   return d;
 }
 
@@ -976,13 +977,18 @@ __global__ __launch_bounds__(kBlock) void trws_fast_kernel(DevParams p, int epoc
       // whole message computation ago; every wave drains, then one lane stores the flag.
       // (Measured: raising it here costs the drain on the critical path of this row but
       // lets the row below start earlier, which wins on grids.)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) {
-        if (prev_rank >= 0) st_sc1(p.done + prev_rank, epoch);
-        // this node's scalars go out only now, so that the drain above never waits for them
-        if (PRIMAL) { st_sc1(p.x + cur.node, xprev); p.eterms[cur.rank] = prim_e; }
-        if (UPDATE && BACKWARD) p.lbterms[cur.lbn] = node_vmin;
+      // Runs nobody can be waiting on ("lazy", see trws_graph.cpp) raise it at the end of the
+      // visit instead, where the drain is free.
+      const bool urgent = cur.urgent != 0;
+      if (urgent) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+          if (prev_rank >= 0) st_sc1(p.done + prev_rank, epoch);
+          // this node's scalars go out only now, so that the drain above never waits for them
+          if (PRIMAL) { st_sc1(p.x + cur.node, xprev); p.eterms[cur.rank] = prim_e; }
+          if (UPDATE && BACKWARD) p.lbterms[cur.lbn] = node_vmin;
+        }
       }
       // ---- prefetch for the next node
       NodeDesc nx = cur;
@@ -1030,6 +1036,13 @@ __global__ __launch_bounds__(kBlock) void trws_fast_kernel(DevParams p, int epoc
       }
       PROF(4)
       // ---- stores: write-through to HBM for other workgroups, LDS for the next node of the run
+      if (!urgent) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // older stores and prefetches: long done
+        if (tid == 0) {
+          if (PRIMAL) { st_sc1(p.x + cur.node, xprev); p.eterms[cur.rank] = prim_e; }
+          if (UPDATE && BACKWARD) p.lbterms[cur.lbn] = node_vmin;
+        }
+      }
       if (UPDATE) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -1043,6 +1056,7 @@ __global__ __launch_bounds__(kBlock) void trws_fast_kernel(DevParams p, int epoc
         }
       }
       __syncthreads();  // hand-over complete
+      if (!urgent && prev_rank >= 0 && tid == 0) st_sc1(p.done + prev_rank, epoch);
       rbuf ^= 1;
       prev_rank = cur.rank;
       cur = nx; nw = nnw; Dk = nDk; pre_ok = npre_ok;

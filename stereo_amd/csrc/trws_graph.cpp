@@ -245,6 +245,22 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
         D[3] = g.lb_pos_node[r];
         for (int k = 0; k < 4; ++k) D[20 + k] = k < nd ? S.dep_rank[S.dep_ptr[r] + k] : 0;
       }
+      // Completion flags are raised either in the middle of the next visit (costs a store
+      // drain on that run's critical path, but the dependent run can follow closely) or
+      // lazily at its end (free).  A run is "lazy" if the next run cannot start before this
+      // one has finished anyway: its first node waits for this run's last node.
+      const int64_t R = (int64_t)S.run_ptr.size() - 1;
+      for (int64_t k = 0; k < R; ++k) {
+        bool lazy = k == R - 1;
+        if (!lazy) {
+          const int64_t plast = S.run_ptr[k + 1] - 1, pnext = S.run_ptr[k + 1];
+          const int32_t rlast = d == 0 ? (int32_t)plast : (int32_t)(N - 1 - plast);
+          const int32_t rnext = d == 0 ? (int32_t)pnext : (int32_t)(N - 1 - pnext);
+          for (int32_t q = S.dep_ptr[rnext]; q < S.dep_ptr[rnext + 1]; ++q)
+            if (S.dep_rank[q] == rlast) lazy = true;
+        }
+        for (int64_t p = S.run_ptr[k]; p < S.run_ptr[k + 1]; ++p) S.desc[(size_t)p * W + 40] = lazy ? 0 : 1;
+      }
     }
   }
   return true;
