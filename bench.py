@@ -116,6 +116,12 @@ def main():
         bytes_per_launch = bytes_pair / launches_per_iter
         avg_launch_s = (sweep_ms * 1e-3) / max(sweep_launches, 1)
         achieved = bytes_per_launch / avg_launch_s / 1e9
+        # HBM traffic per launch from the committed PMC passes of this same workload (profiles/),
+        # corrected as MI355X_MICROARCH.md prescribes; null if the workload differs from them
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_trws_teddy60_pmc_hbm.json")
+        if (H, W, K) == (375, 450, 60) and os.path.exists(pmc):
+            traffic = json.load(open(pmc))["per_launch"]["hbm_bytes_corrected"]
         out = {
             "metric": "TRW-S fusion iterations/sec, 450x375x60 labels",
             "value": rate,
@@ -135,7 +141,7 @@ def main():
                        "parallelism": "independent image pair per GPU" if world > 1 else "1 GPU"},
             "serial_envelope_messages": serial_msgs, "final_energy": energy, "final_lower_bound": lb, "iterations_done": iters,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "trws_sweep_kernel", "bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches_per_iter},
         }
