@@ -73,6 +73,8 @@ struct DevParams {
   unsigned long long *prof;       // optional: 8 phase-cycle accumulators (development)
   const int32_t *desc[2];         // packed node descriptors of the fast kernel
   int prof_run;
+  int debug;  // development switches (timing experiments only)
+  unsigned long long *timeline;  // optional [2][nruns][2] wall-clock stamps (development)
 };
 
 // ---- agent-scope (sc1) accesses: data handed between workgroups inside one launch
@@ -690,8 +692,8 @@ __global__ __launch_bounds__(kBlock) void trws_persistent_kernel(DevParams p, in
           double acc = p.unary[(size_t)node * K + k];
           for (int i = o0; i < o1; ++i) acc += p.msg[(size_t)oidx[i] * K + k];
           for (int i = i0; i < i1; ++i) {
-            const int sl = in_slot[i];
-            acc += sl >= 0 ? hand[sl * Kp + k] : ld_sc1(p.msg + (size_t)iidx[i] * K + k);
+            const int sl = in_slot[i];  // 0..7: previous visit (LDS); 8..15: two visits back -> HBM
+            acc += (sl >= 0 && sl < 8) ? hand[sl * Kp + k] : ld_sc1(p.msg + (size_t)iidx[i] * K + k);
           }
           Di[k] = acc;
           vloc = acc < vloc ? acc : vloc;
@@ -814,15 +816,24 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
       unsigned long long mask = __builtin_amdgcn_ballot_w64(useful);
       double m1 = inf, m2 = inf;
       bool bad = !(delta < inf);
+      // two sources per trip: their chains are independent, which roughly doubles the issue
+      // rate of a single wave; a source visited twice (odd count) changes nothing
       while (mask) {
-        const int j = __builtin_ctzll(mask);
+        const int j0 = __builtin_ctzll(mask);
         mask &= mask - 1;
-        const double hj = readlane_f64(h, j), qj = readlane_f64(qsrc, j);
-        const double uj = readlane_f64(ui, j), vj = readlane_f64(vi, j);
-        const double c = pair_cost<1>(alpha, t - qj, hj);
-        if (c < m1) { m2 = m1; m1 = c; } else if (c > m1 && c < m2) { m2 = c; }
-        const bool near = (fabs(ui - uj) <= delta) || (fabs(vi - vj) <= delta);
-        bad = bad || (near && qsrc != qj);
+        const int j1 = mask ? __builtin_ctzll(mask) : j0;
+        mask &= mask - 1;
+        const double hj0 = readlane_f64(h, j0), qj0 = readlane_f64(qsrc, j0);
+        const double hj1 = readlane_f64(h, j1), qj1 = readlane_f64(qsrc, j1);
+        const double uj0 = readlane_f64(ui, j0), vj0 = readlane_f64(vi, j0);
+        const double uj1 = readlane_f64(ui, j1), vj1 = readlane_f64(vi, j1);
+        const double c0 = pair_cost<1>(alpha, t - qj0, hj0);
+        const double c1 = pair_cost<1>(alpha, t - qj1, hj1);
+        const bool near0 = (fabs(ui - uj0) <= delta) || (fabs(vi - vj0) <= delta);
+        const bool near1 = (fabs(ui - uj1) <= delta) || (fabs(vi - vj1) <= delta);
+        if (c0 < m1) { m2 = m1; m1 = c0; } else if (c0 > m1 && c0 < m2) { m2 = c0; }
+        if (c1 < m1) { m2 = m1; m1 = c1; } else if (c1 > m1 && c1 < m2) { m2 = c1; }
+        bad = bad || (near0 && qsrc != qj0) || (near1 && qsrc != qj1);
       }
       bad = bad || (m1 < vtrunc && !(m2 - m1 > delta && vtrunc - m1 > delta));
       need_serial = UNI(act && bad);
@@ -849,11 +860,37 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
   return vmin;
 }
 
+#undef RLI
+
+// ---- pipelined persistent sweep (K <= 64): role-specialised waves ---------------------
+// Same dataflow schedule and arithmetic as trws_fast_kernel, but the global-memory traffic
+// of a visit is taken off the critical path by dedicated waves of the workgroup:
+//   waves 0-7  compute: read the staged node from LDS, form Di, compute outgoing message
+//              `wave` in registers, hand it over in LDS
+//   wave 8     loader:  while node i is computed, decodes the descriptor of node i+1, waits
+//              for its foreign completion flags, fetches unary / messages / weights /
+//              positions / neighbour labels and stages them in LDS
+//   wave 9     storer:  while node i is computed, writes node i-1's new messages and scalars
+//              to HBM (write-through), drains, raises node i-1's completion flag
+//   wave 10    primal:  labelling + energy term of node i (previous iteration's primal pass)
+// One s_barrier per visit.  The compute waves never touch global memory, so no load or
+// store latency is ever exposed on the chain of dependent visits.
+constexpr int kPipeCompute = 8;  // one compute wave per outgoing message (<= 8 per node)
+constexpr int kPipeWaves = kPipeCompute + 3;
+constexpr int kPipeThreads = kPipeWaves * kWave;
+// LDS stage layout (doubles): D[64] m[8][64] qv[8][64] qpv[8][64] | a[8] | ints: desc[64] px[8]
+constexpr int kStD = 0, kStM = 64, kStQ = 64 + 512, kStQP = 64 + 1024, kStA = 64 + 1536;
+constexpr int kStI = kStA + 8;                    // int area starts here (as doubles)
+constexpr int kStageDoubles = kStI + 36;          // 64 + 8 ints = 36 doubles
+constexpr int kScalDoubles = 16;                  // newv[8], node_vmin, prim_e, x (as int)
+
 template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
-__global__ __launch_bounds__(kBlock) void trws_fast_kernel(DevParams p, int epoch) {
+__global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, int epoch) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double *hand = lds;                      // 2 x 8 x 64 doubles: new messages for the next node of the run
-  int *s_run = (int *)(lds + 16 * kWave);
+  double *stage0 = lds;                                   // 2 stages
+  double *hand = lds + 2 * kStageDoubles;                 // ring of 4 x 8 x 64: the last visits' new messages
+  double *scal = hand + 4 * 8 * kWave;                    // 2 x kScalDoubles
+  int *ctl = (int *)(scal + 2 * kScalDoubles);            // [0] run, [1] abort
   const int K = p.K;
   const double inf = __builtin_huge_val();
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -863,221 +900,202 @@ __global__ __launch_bounds__(kBlock) void trws_fast_kernel(DevParams p, int epoc
   const int32_t *desc = p.desc[D];
   const bool act = lane < K;
   const double posk = (SHARED && act) ? p.pos[lane] : 0.0;
-
-  // previous-sweep (static) data of a node: unary, outgoing-list messages, edge weights, positions
-  auto load_static = [&](const NodeDesc &d, double &Dk_, double (&m_)[8], double (&a_)[8],
-                         double (&qv_)[8], double (&qpv_)[8]) {
-    if (act) Dk_ = p.unary[(size_t)d.node * K + lane];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (j < d.nout + d.nin) {
-        const bool is_out = j < d.nout;
-        if (is_out && act) m_[j] = p.msg[(size_t)d.e[j] * K + lane];
-        if ((is_out && UPDATE) || (!is_out && PRIMAL)) {
-          a_[j] = p.alpha[d.e[j]];
-          if (!SHARED && act) {
-            qv_[j] = p.q[(size_t)d.e[j] * K + lane];
-            qpv_[j] = p.qprim[(size_t)d.e[j] * K + lane];
-          }
-        }
-      }
-    }
-  };
+  if (tid == 0) ctl[1] = 0;
+  if ((p.debug & 2) && !BACKWARD) p.prof = nullptr;  // profile backward sweeps only
+  if ((p.debug & 4) && BACKWARD) p.prof = nullptr;   // profile forward sweeps only
 
   for (;;) {
-    if (tid == 0) *s_run = atomicAdd(p.ticket, 1);
+    if (tid == 0) ctl[0] = atomicAdd(p.ticket, 1);
     __syncthreads();
-    const int run = __builtin_amdgcn_readfirstlane(*s_run);
+    const int run = __builtin_amdgcn_readfirstlane(ctl[0]);
     __syncthreads();
     if (run >= p.nruns[D]) break;
     const int p0 = p.run_ptr[D][run], p1 = p.run_ptr[D][run + 1];
+    int xprev = 0, xprev2 = 0;  // primal wave: labels of the previous two nodes of the run
+    if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2] = wall_clock64();
+    unsigned long long busy = 0;
 
-    NodeDesc cur = decode_desc(desc[(size_t)p0 * DW + lane]);
-    int nw = p0 + 1 < p1 ? desc[(size_t)(p0 + 1) * DW + lane] : 0;
-    double Dk = 0, m[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    double qv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, qpv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    load_static(cur, Dk, m, a, qv, qpv);
-    bool pre_ok = false;   // foreign incoming data of `cur` already sits in m[] / px[]
-    int px[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int xprev = 0, prev_rank = -1, rbuf = 0;
-    long long tprev = p.prof ? (long long)__builtin_readcyclecounter() : 0;
-    unsigned long long pacc[5] = {0, 0, 0, 0, 0}, nblock = 0;
-#define PROF(slot)                                                                 \
-  if (p.prof) {                                                                    \
-    const long long tn = (long long)__builtin_readcyclecounter();                  \
-    pacc[slot] += (unsigned long long)(tn - tprev);                                \
-    tprev = tn;                                                                    \
-  }
+    for (int pos = p0 - 1; pos <= p1; ++pos) {
+      const long long tstart = p.prof ? (long long)__builtin_readcyclecounter() : 0;
+      double *st = stage0 + (pos & 1) * kStageDoubles;          // node `pos`
+      double *stn = stage0 + ((pos + 1) & 1) * kStageDoubles;   // node `pos + 1`
+      double *hcur = hand + (pos & 3) * 8 * kWave, *hprev = hand + ((pos - 1) & 3) * 8 * kWave;
+      double *hprev2 = hand + ((pos - 2) & 3) * 8 * kWave;
+      double *sc = scal + (pos & 1) * kScalDoubles;
+      const bool have_node = pos >= p0 && pos < p1;
 
-    for (int pos = p0; pos < p1; ++pos) {
-      const bool has_next = pos + 1 < p1;
-      const int ntot = cur.nout + cur.nin;
-      double prim_e = 0, node_vmin = 0;
-      // ---- incoming messages: LDS hand-over, prefetched registers, or (rarely) a blocking fetch
-      if (!pre_ok) {
-        if (cur.ndep > 0) ++nblock;
-        bool ok = true;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (ok && j < cur.ndep) ok = wait_flag(p, cur.dep[j], epoch);
-        if (!ok) return;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (j >= cur.nout && j < ntot && cur.slot[j] < 0) {
-            if (UPDATE && act) m[j] = ld_sc1(p.msg + (size_t)cur.e[j] * K + lane);
-            if (PRIMAL) px[j] = ld_sc1(p.x + cur.xn[j]);
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (UPDATE && j >= cur.nout && j < ntot && cur.slot[j] >= 0) m[j] = hand[(rbuf * 8 + cur.slot[j]) * kWave + lane];
-      PROF(0)
-      // ---- primal of the previous iteration (minimize.cpp:223-264), every wave redundantly
-      if (PRIMAL) {
-        double db = Dk;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (j >= cur.nout && j < ntot) {
-            const int ks = cur.slot[j] >= 0 ? xprev : __builtin_amdgcn_readfirstlane(px[j]);
-            const int md = (cur.md >> j) & 1;
-            double d;
-            if (SHARED) {
-              const double pks = readlane_f64(posk, ks);
-              d = md == 0 ? pks - posk : posk - pks;
-            } else {
-              d = md == 0 ? readlane_f64(qpv[j], ks) - qv[j] : qpv[j] - readlane_f64(qv[j], ks);
-            }
-            const double v = KERNEL == 1 ? fabs(d) : d * d;
-            db += a[j] * (v < p.lambda ? v : p.lambda);
-          }
-        }
-        double di = db;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (j < cur.nout) di += m[j];
-        const int bi = wave_argmin_dpp(act ? di : inf, act ? lane : 0x7fffffff);
-        xprev = bi;
-        prim_e = readlane_f64(db, bi);
-      }
-      PROF(1)
-      double Di = 0;
-      if (UPDATE) {
-        Di = Dk;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (j < ntot) Di += m[j];
-        if (BACKWARD) {
-          node_vmin = wave_min_dpp(act ? Di : inf);
-          Di -= node_vmin;
-        }
-      }
-      PROF(2)
-      // ---- raise the flag of the previous node.  Its write-through stores were issued a
-      // whole message computation ago; every wave drains, then one lane stores the flag.
-      // (Measured: raising it here costs the drain on the critical path of this row but
-      // lets the row below start earlier, which wins on grids.)
-      // Runs nobody can be waiting on ("lazy", see trws_graph.cpp) raise it at the end of the
-      // visit instead, where the drain is free.
-      const bool urgent = cur.urgent != 0;
-      if (urgent) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-          if (prev_rank >= 0) st_sc1(p.done + prev_rank, epoch);
-          // this node's scalars go out only now, so that the drain above never waits for them
-          if (PRIMAL) { st_sc1(p.x + cur.node, xprev); p.eterms[cur.rank] = prim_e; }
-          if (UPDATE && BACKWARD) p.lbterms[cur.lbn] = node_vmin;
-        }
-      }
-      // ---- prefetch for the next node
-      NodeDesc nx = cur;
-      int nnw = 0;
-      double nDk = 0, nm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, na[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      double nqv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nqpv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      bool npre_ok = false;
-      int npx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (has_next) {
-        nx = decode_desc(nw);
-        int fl[4] = {epoch, epoch, epoch, epoch};
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j < nx.ndep) fl[j] = ld_sc1(p.done + nx.dep[j]);
-        if (pos + 2 < p1) nnw = desc[(size_t)(pos + 2) * DW + lane];
-        load_static(nx, nDk, nm, na, nqv, nqpv);
-        npre_ok = UNI(fl[0] >= epoch && fl[1] >= epoch && fl[2] >= epoch && fl[3] >= epoch);
-        if (npre_ok) {
+      if (wave < kPipeCompute) {
+        // ------------------------------------------------------------ compute
+        if (UPDATE && have_node) {
+          const int *sti = (const int *)(st + kStI);
+          const int f = __builtin_amdgcn_readfirstlane(sti[2]);
+          const int nout = f & 15, nin = (f >> 4) & 15, md = (f >> 16) & 255, ntot = nout + nin;
+          double Di = act ? st[kStD + lane] : 0.0;
+          double mown = 0;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            if (j >= nx.nout && j < nx.nout + nx.nin && nx.slot[j] < 0) {
-              if (UPDATE && act) nm[j] = ld_sc1(p.msg + (size_t)nx.e[j] * K + lane);
-              if (PRIMAL) npx[j] = ld_sc1(p.x + nx.xn[j]);
+            if (j < ntot) {
+              double v;
+              const int sl = j >= nout ? __builtin_amdgcn_readfirstlane(sti[12 + j]) : -1;
+              if (sl >= 8) v = hprev2[(sl - 8) * kWave + lane];
+              else if (sl >= 0) v = hprev[sl * kWave + lane];
+              else v = st[kStM + j * kWave + lane];
+              Di += v;
+              if (j == wave && j < nout) mown = v;
+            }
+          }
+          double node_vmin = 0;
+          if (BACKWARD) {
+            node_vmin = wave_min_dpp(act ? Di : inf);
+            Di -= node_vmin;
+            if (tid == 0) sc[8] = node_vmin;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (j == wave && j < nout) {
+              const double gamma = (double)1 / (double)(nout > nin ? nout : nin);
+              const double h = act ? gamma * Di - mown : inf;
+              const bool src_is_qprim = ((BACKWARD ? 1 : 0) == ((md >> j) & 1));
+              double qsrc = posk, qdst = posk;
+              const uint16_t *perm = p.perm_pos;
+              if (!SHARED) {
+                const double a_ = act ? st[kStQ + j * kWave + lane] : 0.0;
+                const double b_ = act ? st[kStQP + j * kWave + lane] : 0.0;
+                qsrc = src_is_qprim ? b_ : a_;
+                qdst = src_is_qprim ? a_ : b_;
+                const int e = __builtin_amdgcn_readfirstlane(sti[4 + j]);
+                perm = (src_is_qprim ? p.perm_qp : p.perm_q) + (size_t)e * K;
+              }
+              const double alpha = st[kStA + j];
+              double newm = 0;
+              const double v = message_regs<KERNEL>(p, K, alpha, h, qsrc, qdst, perm, newm, lane);
+              if (act) hcur[j * kWave + lane] = newm;
+              if (BACKWARD && lane == 0) sc[j] = v;
             }
           }
         }
-      }
-      PROF(3)
-      // ---- messages of outgoing edges wave, wave + 4
-      double newm[2] = {0, 0}, newv[2] = {0, 0};
-      if (UPDATE) {
+      } else if (wave == kPipeCompute) {
+        // ------------------------------------------------------------ loader: stage node pos + 1
+        if (pos + 1 >= p0 && pos + 1 < p1) {
+          const int w = desc[(size_t)(pos + 1) * DW + lane];
+          const NodeDesc nx = decode_desc(w);
+          int *stni = (int *)(stn + kStI);
+          stni[lane] = w;
+          const int ntot = nx.nout + nx.nin;
+          // everything that does not depend on other workgroups is requested first ...
+          double dk = 0, mv[8], qv[8], qpv[8];
+          if (act) dk = p.unary[(size_t)nx.node * K + lane];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if ((j & 3) == wave && j < cur.nout) {
-            const double gamma = (double)1 / (double)(cur.nout > cur.nin ? cur.nout : cur.nin);
-            const double h = act ? gamma * Di - m[j] : inf;
-            const bool src_is_qprim = ((BACKWARD ? 1 : 0) == ((cur.md >> j) & 1));
-            const double qsrc = SHARED ? posk : (src_is_qprim ? qpv[j] : qv[j]);
-            const double qdst = SHARED ? posk : (src_is_qprim ? qv[j] : qpv[j]);
-            const uint16_t *perm =
-                SHARED ? p.perm_pos : (src_is_qprim ? p.perm_qp : p.perm_q) + (size_t)cur.e[j] * K;
-            newv[j >> 2] = message_regs<KERNEL>(p, K, a[j], h, qsrc, qdst, perm, newm[j >> 2], lane);
-          }
-        }
-      }
-      PROF(4)
-      // ---- stores: write-through to HBM for other workgroups, LDS for the next node of the run
-      if (!urgent) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // older stores and prefetches: long done
-        if (tid == 0) {
-          if (PRIMAL) { st_sc1(p.x + cur.node, xprev); p.eterms[cur.rank] = prim_e; }
-          if (UPDATE && BACKWARD) p.lbterms[cur.lbn] = node_vmin;
-        }
-      }
-      if (UPDATE) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if ((j & 3) == wave && j < cur.nout) {
-            if (act) {
-              st_sc1(p.msg + (size_t)cur.e[j] * K + lane, newm[j >> 2]);
-              hand[((rbuf ^ 1) * 8 + j) * kWave + lane] = newm[j >> 2];
+          for (int j = 0; j < 8; ++j) {
+            mv[j] = 0; qv[j] = 0; qpv[j] = 0;
+            if (j < ntot && act) {
+              const size_t off = (size_t)nx.e[j] * K + lane;
+              if (j < nx.nout && (UPDATE || PRIMAL)) mv[j] = p.msg[off];
+              if (!SHARED) { qv[j] = p.q[off]; qpv[j] = p.qprim[off]; }
             }
-            if (BACKWARD && lane == 0) p.lbterms[cur.lbe[j]] = newv[j >> 2];
           }
+          double av = 0;
+          int pxv = 0, xn = 0, sl = 0;
+          if (lane < ntot) {
+            int ej = 0;  // lane j fetches the scalars of edge j
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (lane == j) { ej = nx.e[j]; xn = nx.xn[j]; sl = nx.slot[j]; }
+            av = p.alpha[ej];
+          }
+          // ... then the completion flags of the foreign neighbours, then their data
+          bool ok = true;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (ok && j < nx.ndep) ok = wait_flag(p, nx.dep[j], epoch);
+          if (!ok && lane == 0) ctl[1] = 1;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (UPDATE && j >= nx.nout && j < ntot && nx.slot[j] < 0 && act)
+              mv[j] = ld_sc1(p.msg + (size_t)nx.e[j] * K + lane);
+          if (PRIMAL && lane < ntot && lane >= nx.nout && sl < 0) pxv = ld_sc1(p.x + xn);
+          if (act) stn[kStD + lane] = dk;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (j < ntot && act) {
+              stn[kStM + j * kWave + lane] = mv[j];
+              if (!SHARED) { stn[kStQ + j * kWave + lane] = qv[j]; stn[kStQP + j * kWave + lane] = qpv[j]; }
+            }
+          }
+          if (lane < 8) { stn[kStA + lane] = av; stni[64 + lane] = pxv; }
+        }
+      } else if (wave == kPipeCompute + 1) {
+        // ------------------------------------------------------------ storer: node pos - 1
+        if (pos - 1 >= p0) {
+          const NodeDesc pd = decode_desc(desc[(size_t)(pos - 1) * DW + lane]);
+          const double *scp = scal + ((pos + 1) & 1) * kScalDoubles;  // parity of pos - 1
+          if (UPDATE) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              if (j < pd.nout) {
+                if (act) st_sc1(p.msg + (size_t)pd.e[j] * K + lane, hprev[j * kWave + lane]);
+                if (BACKWARD && lane == 0) p.lbterms[pd.lbe[j]] = scp[j];
+              }
+            }
+            if (BACKWARD && lane == 0) p.lbterms[pd.lbn] = scp[8];
+          }
+          if (PRIMAL && lane == 0) {
+            st_sc1(p.x + pd.node, ((const int *)(scp + 10))[0]);
+            p.eterms[pd.rank] = scp[9];
+          }
+          if (!(p.debug & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) st_sc1(p.done + pd.rank, epoch);
+        }
+      } else {
+        // ------------------------------------------------------------ primal of node pos
+        if (PRIMAL && have_node) {
+          const int *sti = (const int *)(st + kStI);
+          const int f = __builtin_amdgcn_readfirstlane(sti[2]);
+          const int nout = f & 15, nin = (f >> 4) & 15, md = (f >> 16) & 255, ntot = nout + nin;
+          double db = act ? st[kStD + lane] : 0.0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (j >= nout && j < ntot) {
+              const int sl = __builtin_amdgcn_readfirstlane(sti[12 + j]);
+              const int ks = sl >= 8 ? xprev2 : sl >= 0 ? xprev : __builtin_amdgcn_readfirstlane(sti[64 + j]);
+              const int mdj = (md >> j) & 1;
+              double d;
+              if (SHARED) {
+                const double pks = readlane_f64(posk, ks);
+                d = mdj == 0 ? pks - posk : posk - pks;
+              } else {
+                const double qvj = act ? st[kStQ + j * kWave + lane] : 0.0;
+                const double qpj = act ? st[kStQP + j * kWave + lane] : 0.0;
+                d = mdj == 0 ? readlane_f64(qpj, ks) - qvj : qpj - readlane_f64(qvj, ks);
+              }
+              const double v = KERNEL == 1 ? fabs(d) : d * d;
+              db += st[kStA + j] * (v < p.lambda ? v : p.lambda);
+            }
+          }
+          double di = db;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j < nout) di += st[kStM + j * kWave + lane];
+          const int bi = wave_argmin_dpp(act ? di : inf, act ? lane : 0x7fffffff);
+          xprev2 = xprev; xprev = bi;
+          const double eb = readlane_f64(db, bi);
+          if (lane == 0) { sc[9] = eb; ((int *)(sc + 10))[0] = bi; }
         }
       }
-      __syncthreads();  // hand-over complete
-      if (!urgent && prev_rank >= 0 && tid == 0) st_sc1(p.done + prev_rank, epoch);
-      rbuf ^= 1;
-      prev_rank = cur.rank;
-      cur = nx; nw = nnw; Dk = nDk; pre_ok = npre_ok;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        m[j] = nm[j]; a[j] = na[j]; qv[j] = nqv[j]; qpv[j] = nqpv[j]; px[j] = npx[j];
-      }
+      if (p.prof) busy += (unsigned long long)((long long)__builtin_readcyclecounter() - tstart);
+      __syncthreads();
+      if (ctl[1]) return;  // a dependency wait gave up (bounded spin); host reports it
     }
-    // ---- flag of the last node of the run
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (prev_rank >= 0 && tid == 0) st_sc1(p.done + prev_rank, epoch);
-    if (p.prof && tid == 0 && (p.prof_run < 0 || run == p.prof_run)) {
-      for (int i = 0; i < 5; ++i) atomicAdd(p.prof + i, pacc[i]);
-      atomicAdd(p.prof + 5, nblock);
-      atomicAdd(p.prof + 6, (unsigned long long)(p1 - p0));
+    if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2 + 1] = wall_clock64();
+    if (p.prof && lane == 0 && (p.prof_run < 0 || run == p.prof_run)) {
+      // busy cycles before the barrier per role: compute (wave 0), loader, storer, primal; steps
+      const int slot = wave == 0 ? 0 : wave == kPipeCompute ? 1 : wave == kPipeCompute + 1 ? 2 : wave == kPipeCompute + 2 ? 3 : -1;
+      if (slot >= 0) atomicAdd(p.prof + slot, busy);
+      if (wave == 0) atomicAdd(p.prof + 6, (unsigned long long)(p1 - p0));
     }
-#undef PROF
   }
 }
-#undef RLI
+
 
 // Ascending sort permutation of each K-vector (ties: lower index first), one
 // wave per vector, bitonic network in LDS.  Replaces the per-edge std::sort of
@@ -1135,7 +1153,7 @@ struct stereo_trws_plan {
   DevBuf<int8_t> d_in_slot[2];
   DevBuf<int32_t> d_desc[2];
   bool fast = false;
-  DevBuf<unsigned long long> d_fallbacks, d_prof;
+  DevBuf<unsigned long long> d_fallbacks, d_prof, d_timeline;
   bool certificate = true;
   int epoch = 0;
   bool persistent = true;
@@ -1188,8 +1206,11 @@ DevParams make_params(stereo_trws_plan *P) {
   p.done = P->d_done.p; p.ticket = P->d_ctl.p; p.abort_flag = P->d_ctl.p + 1; p.N = (int)P->N;
   p.fallbacks = P->d_fallbacks.p; p.certificate = P->certificate ? 1 : 0;
   p.prof = P->d_prof.p;
+  p.timeline = P->d_timeline.p;
   p.desc[0] = P->d_desc[0].p; p.desc[1] = P->d_desc[1].p;
   p.prof_run = -1;
+  p.debug = 0;
+  if (const char *dbg = std::getenv("STEREO_HIP_TRWS_DEBUG")) p.debug = std::atoi(dbg);
   if (const char *pr = std::getenv("STEREO_HIP_TRWS_PROF_RUN")) p.prof_run = std::atoi(pr);
   return p;
 }
@@ -1203,20 +1224,21 @@ void launch_persistent(stereo_trws_plan *P, const DevParams &p, int what, hipStr
   STEREO_HIP_CHECK(hipMemsetAsync(P->d_ctl.p, 0, sizeof(int32_t), s));  // ticket = 0
   const dim3 grid(P->grid_blocks), block(kBlock);
   if (P->fast) {
-    const size_t flds = sizeof(double) * (16 * kWave + 2);
+    const size_t plds = sizeof(double) * (2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + 2);
     const bool sh = P->pos != nullptr;
-#define FAST(BW, PR, UP)                                                                          \
+    const dim3 pblock(kPipeThreads);
+#define PIPE(BW, PR, UP)                                                                          \
   do {                                                                                            \
-    if (sh) hipLaunchKernelGGL((trws_fast_kernel<KERNEL, BW, PR, UP, true>), grid, block, flds, s, p, epoch); \
-    else hipLaunchKernelGGL((trws_fast_kernel<KERNEL, BW, PR, UP, false>), grid, block, flds, s, p, epoch);   \
+    if (sh) hipLaunchKernelGGL((trws_pipe_kernel<KERNEL, BW, PR, UP, true>), grid, pblock, plds, s, p, epoch); \
+    else hipLaunchKernelGGL((trws_pipe_kernel<KERNEL, BW, PR, UP, false>), grid, pblock, plds, s, p, epoch);   \
   } while (0)
     switch (what) {
-      case 0: FAST(false, false, true); break;
-      case 1: FAST(true, false, true); break;
-      case 2: FAST(false, true, true); break;
-      default: FAST(false, true, false); break;
+      case 0: PIPE(false, false, true); break;
+      case 1: PIPE(true, false, true); break;
+      case 2: PIPE(false, true, true); break;
+      default: PIPE(false, true, false); break;
     }
-#undef FAST
+#undef PIPE
     STEREO_HIP_CHECK(hipGetLastError());
     if (what != 3) P->sweep_launches += 1;
     return;
@@ -1358,6 +1380,7 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
     STEREO_HIP_CHECK(hipMemset(P->d_fallbacks.p, 0, sizeof(unsigned long long)));
     if (const char *c = std::getenv("STEREO_HIP_TRWS_CERTIFICATE")) P->certificate = std::string(c) != "0";
     if (std::getenv("STEREO_HIP_TRWS_PROF")) { P->d_prof.alloc(8); STEREO_HIP_CHECK(hipMemset(P->d_prof.p, 0, 64)); }
+    if (std::getenv("STEREO_HIP_TRWS_TIMELINE")) P->d_timeline.alloc(4 * g.sweep[0].run_ptr.size());
     STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * N));
     STEREO_HIP_CHECK(hipMemset(P->d_ctl.p, 0, sizeof(int32_t) * 2));
     if (const char *sc = std::getenv("STEREO_HIP_TRWS_SCHEDULE")) P->persistent = std::string(sc) != "levels";
@@ -1407,10 +1430,23 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
 }
 
 void stereo_trws_plan_destroy(stereo_trws_plan *plan) {
+  if (plan && plan->d_timeline.p) {
+    const size_t R = plan->g.sweep[0].run_ptr.size() - 1;
+    std::vector<unsigned long long> t(4 * (R + 1));
+    if (hipMemcpy(t.data(), plan->d_timeline.p, sizeof(unsigned long long) * 4 * R, hipMemcpyDeviceToHost) == hipSuccess) {
+      for (int d = 0; d < 2; ++d) {
+        const unsigned long long t0 = t[(size_t)d * R * 2];
+        std::fprintf(stderr, "[stereo_hip timeline] dir %d (us since run 0 start): ", d);
+        for (size_t r = 0; r < R; r += (r < 8 ? 1 : R / 12 + 1))
+          std::fprintf(stderr, "run%zu[%.0f..%.0f] ", r, (t[(d * R + r) * 2] - t0) / 100.0, (t[(d * R + r) * 2 + 1] - t0) / 100.0);
+        std::fprintf(stderr, "last[%.0f..%.0f]\n", (t[(d * R + R - 1) * 2] - t0) / 100.0, (t[(d * R + R - 1) * 2 + 1] - t0) / 100.0);
+      }
+    }
+  }
   if (plan && plan->d_prof.p) {
     unsigned long long v[8];
     if (hipMemcpy(v, plan->d_prof.p, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess)
-      std::fprintf(stderr, "[stereo_hip prof] all runs, cycles: in %llu primal %llu Di %llu flag+prefetch %llu messages %llu | blocking steps %llu of %llu\n",
+      std::fprintf(stderr, "[stereo_hip prof] cycles: p0 %llu p1 %llu p2 %llu p3 %llu p4 %llu | p5 %llu steps %llu\n",
                    v[0], v[1], v[2], v[3], v[4], v[5], v[6]);
   }
   delete plan;

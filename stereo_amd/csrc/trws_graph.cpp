@@ -175,26 +175,32 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
     std::vector<int32_t> deps_of(N, 0);
     std::vector<std::vector<int32_t>> tmp_deps;  // filled per rank in processing order
     tmp_deps.resize(N);
+    int64_t run_start = 0;
     for (int64_t p = 0; p < N; ++p) {
       const int32_t r = d == 0 ? (int32_t)p : (int32_t)(N - 1 - p);
-      const int32_t pred = d == 0 ? r - 1 : r + 1;  // rank processed just before
+      // ranks visited one and two steps earlier (hand-over through LDS is kept for two visits)
+      const int32_t near1 = d == 0 ? r - 1 : r + 1, near2 = d == 0 ? r - 2 : r + 2;
       bool chained = false;
       std::vector<int32_t> &deps = tmp_deps[r];
+      // pass 1: does this node hang on one of the last two visits of the current run?
+      for (int32_t k = iptr[r]; k < iptr[r + 1]; ++k) {
+        const int32_t other = g.rank[d == 0 ? g.tail[iidx[k]] : g.head[iidx[k]]];
+        if ((p - 1 >= run_start && other == near1) || (p - 2 >= run_start && other == near2)) chained = true;
+      }
+      if (!chained) { S.run_ptr.push_back((int32_t)p); run_start = p; }
       for (int32_t k = iptr[r]; k < iptr[r + 1]; ++k) {
         const int32_t e = iidx[k];
         const int32_t other = g.rank[d == 0 ? g.tail[e] : g.head[e]];
-        if (p > 0 && other == pred) {
-          chained = true;
-          for (int32_t w = optr[pred]; w < optr[pred + 1] && w - optr[pred] < TrwsGraph::kMaxSlots; ++w)
-            if (oidx[w] == e) S.in_slot[k] = (int8_t)(w - optr[pred]);
+        int dist = 0;
+        if (p - 1 >= run_start && other == near1) dist = 1;
+        else if (p - 2 >= run_start && other == near2) dist = 2;
+        if (dist) {
+          // slot of the edge in that node's outgoing list; in_slot = slot + 8 * (dist - 1)
+          for (int32_t w = optr[other]; w < optr[other + 1] && w - optr[other] < TrwsGraph::kMaxSlots; ++w)
+            if (oidx[w] == e) S.in_slot[k] = (int8_t)((w - optr[other]) + 8 * (dist - 1));
         } else if (std::find(deps.begin(), deps.end(), other) == deps.end()) {
           deps.push_back(other);
         }
-      }
-      if (!chained) {
-        S.run_ptr.push_back((int32_t)p);
-        // a new run starts here: nothing is handed over in LDS
-        for (int32_t k = iptr[r]; k < iptr[r + 1]; ++k) S.in_slot[k] = -1;
       }
     }
     S.run_ptr.push_back((int32_t)N);
