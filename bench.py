@@ -142,7 +142,7 @@ def main():
             "serial_envelope_messages": serial_msgs, "final_energy": energy, "final_lower_bound": lb, "iterations_done": iters,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "trws_sweep_kernel", "bytes_per_launch": bytes_per_launch,
+                         "kernel": "trws_pipe_kernel (one persistent launch per sweep)", "bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches_per_iter},
         }
         if not args.no_cpu_baseline:
