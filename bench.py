@@ -156,6 +156,32 @@ def main():
                                    "kind": "port",
                                    "sample": "%d iterations of the same %dx%dx%d volume, oracle/trws_oracle.c "
                                              "(envelope messages), setup excluded" % (ci, W, H, K)}
+        if world == 1 and not args.no_cpu_baseline:
+            # secondary figure: QPBO binary fusion moves/s on a Teddy-sized move (host arrays in,
+            # labels out -- PCIe inclusive), next to the reference QPBO library where it travelled
+            try:
+                from helpers import fusion_problem
+                from stereo_amd.rd import RdPlan
+                fp = fusion_problem(5, H, W, kernel=1, tol=8.0)
+                fargs = (fp["U0"], fp["U1"], fp["E00"], fp["E01"], fp["E10"], fp["E11"])
+                rp = RdPlan(N, fp["conn"].T)
+                rp.solve(*fargs)
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    flab, fen, flb, fnu = rp.solve(*fargs)
+                tf = (time.perf_counter() - t1) / 10
+                extra = {"moves_per_s": 1.0 / tf, "ms_per_move": tf * 1e3, "grid": "%dx%d" % (W, H),
+                         "energy": fen, "lower_bound": flb, "unlabelled": fnu, "includes": "H2D of the six term arrays + D2H of labels"}
+                from oracle import pyoracle
+                if pyoracle.have_ref_qpbo():
+                    t1 = time.perf_counter()
+                    rlab, ren, rlb, rnu = pyoracle.ref_rd(*fargs, fp["conn"])
+                    tr_ = time.perf_counter() - t1
+                    extra["cpu_reference"] = {"moves_per_s": 1.0 / tr_, "kind": "reference", "cores": 1,
+                                              "labels_equal": bool(np.array_equal(rlab, flab))}
+                out["binary_fusion"] = extra
+            except Exception as exc:  # the headline number must not depend on the secondary one
+                out["binary_fusion"] = {"error": str(exc)}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -138,6 +138,24 @@ int stereo_rd(const double *U0, const double *U1, const double *E00, const doubl
               int64_t E, int improve, double *labelling, double *energy,
               double *lower_bound, double *num_unlabelled, char *err, size_t errcap);
 
+/* Device-resident form of stereo_rd for repeated fusion moves on one connectivity
+ * (dispmap_super.m:61-84 is called once per proposal): edge grouping, the doubled-graph
+ * slot layout and all device buffers are set up once; a move uploads (or binds) the six term
+ * arrays, rebuilds capacities on the device and solves. */
+typedef struct stereo_rd_plan stereo_rd_plan;
+int stereo_rd_plan_create(int64_t N, int64_t E, const uint32_t *conn, stereo_rd_plan **plan, char *err,
+                          size_t errcap);
+void stereo_rd_plan_destroy(stereo_rd_plan *plan);
+int stereo_rd_plan_solve(stereo_rd_plan *plan, const double *U0, const double *U1, const double *E00,
+                         const double *E01, const double *E10, const double *E11, int improve,
+                         double *labelling, double *energy, double *lower_bound,
+                         double *num_unlabelled, char *err, size_t errcap);
+/* the same with the six term arrays already in HBM (e.g. written by the term-builder kernels) */
+int stereo_rd_plan_solve_device(stereo_rd_plan *plan, const double *d_U0, const double *d_U1,
+                                const double *d_E00, const double *d_E01, const double *d_E10,
+                                const double *d_E11, int improve, double *labelling, double *energy,
+                                double *lower_bound, double *num_unlabelled, char *err, size_t errcap);
+
 /* ---- term builders and cost volume ------------------------------------- *
  * Device versions of the MATLAB array math between the images and the two
  * solvers.  Pixels are numbered column-major, id = col*H + row (dispmap_super.m:281-282);

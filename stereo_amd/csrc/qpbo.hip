@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -106,36 +107,122 @@ __global__ __launch_bounds__(kQB) void qpbo_gather_relabel_kernel(QpboDev g) {
   g.h2[v] = hv;
 }
 
-__global__ __launch_bounds__(kQB) void qpbo_bfs_init_kernel(QpboDev g, int32_t *frontier) {
-  const int v = blockIdx.x * kQB + threadIdx.x;
-  if (v >= g.n) return;
-  if (g.snk[v] > 0) {
-    g.h[v] = 1;
-    frontier[atomicAdd(g.counters + 1, 1)] = v;
-  } else {
-    g.h[v] = g.n;
-  }
-}
-
-__global__ __launch_bounds__(kQB) void qpbo_bfs_step_kernel(QpboDev g, const int32_t *frontier, int count,
-                                                           int32_t *next, int level) {
-  const int t = blockIdx.x * kQB + threadIdx.x;
-  if (t >= count) return;
-  const int w = frontier[t];
-  const int a0 = g.aptr[w], a1 = g.aptr[w + 1];
-  for (int a = a0; a < a1; ++a) {
-    // arc head[a] -> w is rev[a]: it must be residual for head[a] to reach the sink through w
-    if (g.r[g.rev[a]] > 0) {
-      const int v = g.head[a];
-      if (atomicCAS(g.h + v, g.n, level + 1) == g.n) next[atomicAdd(g.counters + 1, 1)] = v;
-    }
-  }
-}
-
 __global__ __launch_bounds__(kQB) void qpbo_count_active_kernel(QpboDev g) {
   const int v = blockIdx.x * kQB + threadIdx.x;
   if (v >= g.n) return;
   if (g.ex[v] > 0 && g.h[v] < g.n) atomicAdd(g.counters, 1);
+}
+
+
+// ---- device-side construction for the plan API ------------------------------------------
+// The doubled graph has a fixed slot layout per neighbour pair (one outgoing arc at each of
+// i, j, i', j'); only heads, reverse links and capacities depend on whether the summed table
+// is submodular, so a fusion move re-builds the whole network with two streaming kernels.
+struct RdPlanDev {
+  int N, npairs;
+  const int32_t *pair_i, *pair_j, *pe_ptr, *pe_edge;  // pe_edge: edge id * 2 + transposed bit
+  const int32_t *slots;                                // 4 per pair: out of i, j, i', j'
+  const int32_t *aptr;                                 // CSR by doubled node
+  const int32_t *slot_pair;                            // per slot: pair * 2 + role (0 = i side, 1 = j side)
+  const double *U0, *U1, *E00, *E01, *E10, *E11;
+  int32_t *head, *rev;
+  double *r, *ci, *cjs, *konst, *ex, *snk, *trv, *u0;
+};
+
+__global__ __launch_bounds__(kQB) void rd_pairs_kernel(RdPlanDev d) {
+  const int k = blockIdx.x * kQB + threadIdx.x;
+  if (k >= d.npairs) return;
+  double A = 0, B = 0, C = 0, D = 0;
+  for (int q = d.pe_ptr[k]; q < d.pe_ptr[k + 1]; ++q) {
+    const int e = d.pe_edge[q] >> 1, tr = d.pe_edge[q] & 1;
+    A += d.E00[e]; D += d.E11[e];
+    if (tr) { B += d.E10[e]; C += d.E01[e]; } else { B += d.E01[e]; C += d.E10[e]; }
+  }
+  const bool sub = B + C >= A + D;  // QPBO.cpp:434
+  double a = sub ? A : B, b = sub ? B : A, c = sub ? C : D, dd = sub ? D : C;
+  double ci = dd - a, cj, cij, cji;   // QPBO.h:760-807
+  b -= a; c -= dd;
+  if (b < 0) { ci += -b; cj = b; cji = b + c; cij = 0; }
+  else if (c < 0) { ci += c; cj = -c; cij = b + c; cji = 0; }
+  else { cj = 0; cij = b; cji = c; }
+  d.ci[k] = ci;
+  d.cjs[k] = sub ? cj : -cj;
+  d.konst[k] = sub ? A : B + cj;
+  const int i = d.pair_i[k], j = d.pair_j[k], N = d.N;
+  const int si = d.slots[4 * k], sj = d.slots[4 * k + 1], sim = d.slots[4 * k + 2], sjm = d.slots[4 * k + 3];
+  if (sub) {  // i->j (cij), j->i (cji), j'->i' (cij), i'->j' (cji)
+    d.head[si] = j; d.rev[si] = sj; d.r[si] = cij;
+    d.head[sj] = i; d.rev[sj] = si; d.r[sj] = cji;
+    d.head[sjm] = i + N; d.rev[sjm] = sim; d.r[sjm] = cij;
+    d.head[sim] = j + N; d.rev[sim] = sjm; d.r[sim] = cji;
+  } else {    // i->j' (cij), j'->i (cji), j->i' (cij), i'->j (cji)
+    d.head[si] = j + N; d.rev[si] = sjm; d.r[si] = cij;
+    d.head[sjm] = i; d.rev[sjm] = si; d.r[sjm] = cji;
+    d.head[sj] = i + N; d.rev[sj] = sim; d.r[sj] = cij;
+    d.head[sim] = j; d.rev[sim] = sj; d.r[sim] = cji;
+  }
+}
+
+__global__ __launch_bounds__(kQB) void rd_nodes_kernel(RdPlanDev d) {
+  const int v = blockIdx.x * kQB + threadIdx.x;
+  if (v >= d.N) return;
+  double t = 0;
+  for (int s = d.aptr[v]; s < d.aptr[v + 1]; ++s) {
+    const int pr = d.slot_pair[s];
+    t += (pr & 1) ? d.cjs[pr >> 1] : d.ci[pr >> 1];
+  }
+  t += d.U1[v] - d.U0[v];  // QPBO.h:615-624
+  d.trv[v] = t;
+  d.ex[v] = t > 0 ? t : 0.0; d.snk[v] = t < 0 ? -t : 0.0;
+  d.ex[v + d.N] = t < 0 ? -t : 0.0; d.snk[v + d.N] = t > 0 ? t : 0.0;  // mate: -t (QPBO.cpp:689)
+}
+
+// fixed-shape reduction (same tree for every run): partial[b] = sum of a 2048-element chunk
+__global__ __launch_bounds__(kQB) void det_sum_kernel(const double *x, int64_t n, double *partial) {
+  __shared__ double sh[kQB];
+  const int64_t base = (int64_t)blockIdx.x * (kQB * 8);
+  double acc = 0;
+  for (int k = 0; k < 8; ++k) {
+    const int64_t i = base + (int64_t)k * kQB + threadIdx.x;
+    if (i < n) acc += x[i];
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = kQB / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+// energy of a labelling from the caller's tables: per-node and per-edge terms
+__global__ __launch_bounds__(kQB) void rd_energy_terms_kernel(int64_t N, int64_t E, const uint32_t *conn,
+                                                              const int32_t *h, int n, const double *U0,
+                                                              const double *U1, const double *E00,
+                                                              const double *E01, const double *E10,
+                                                              const double *E11, const int8_t *label,
+                                                              double *terms) {
+  const int64_t t = (int64_t)blockIdx.x * kQB + threadIdx.x;
+  if (t < N) {
+    terms[t] = label[t] == 1 ? U1[t] : U0[t];
+  } else if (t < N + E) {
+    const int64_t e = t - N;
+    const int xi = label[conn[2 * e]] == 1, xj = label[conn[2 * e + 1]] == 1;
+    terms[t] = xi ? (xj ? E11[e] : E10[e]) : (xj ? E01[e] : E00[e]);
+  }
+}
+
+// pull-style exact relabelling: one level per launch, no queues, no host round trip per level
+__global__ __launch_bounds__(kQB) void qpbo_relabel_init_kernel(QpboDev g) {
+  const int v = blockIdx.x * kQB + threadIdx.x;
+  if (v >= g.n) return;
+  g.h[v] = g.snk[v] > 0 ? 1 : g.n;
+}
+__global__ __launch_bounds__(kQB) void qpbo_relabel_level_kernel(QpboDev g, int level, int32_t *changed) {
+  const int v = blockIdx.x * kQB + threadIdx.x;
+  if (v >= g.n || g.h[v] != g.n) return;
+  for (int a = g.aptr[v]; a < g.aptr[v + 1]; ++a)
+    if (g.r[a] > 0 && g.h[g.head[a]] == level) { g.h[v] = level + 1; *changed = 1; return; }
 }
 
 // ---- host-side construction ----------------------------------------------
@@ -265,7 +352,7 @@ namespace {
 struct QpboSolver {
   QpboProblem P;
   int n = 0, m = 0;
-  DevBuf<int32_t> d_aptr, d_head, d_rev, d_h, d_h2, d_front0, d_front1, d_cnt;
+  DevBuf<int32_t> d_aptr, d_head, d_rev, d_h, d_h2, d_cnt, d_flags;
   DevBuf<double> d_r, d_delta, d_ex, d_snk;
   std::vector<double> snk0;
   QpboDev g{};
@@ -286,7 +373,7 @@ struct QpboSolver {
     }
     snk0 = snk;
     d_ex.upload(ex.data(), n); d_snk.upload(snk.data(), n);
-    d_h.alloc(n); d_h2.alloc(n); d_front0.alloc(n); d_front1.alloc(n); d_cnt.alloc(4);
+    d_h.alloc(n); d_h2.alloc(n); d_cnt.alloc(4);
     STEREO_HIP_CHECK(hipMemset(d_cnt.p, 0, sizeof(int32_t) * 4));
     g.n = n; g.m = m; g.aptr = d_aptr.p; g.head = d_head.p; g.rev = d_rev.p; g.r = d_r.p;
     g.delta = d_delta.p; g.ex = d_ex.p; g.snk = d_snk.p; g.h = d_h.p; g.h2 = d_h2.p; g.counters = d_cnt.p;
@@ -295,25 +382,26 @@ struct QpboSolver {
 
   int grid() const { return (n + kQB - 1) / kQB; }
 
-  // exact distances to the sink in the residual graph (frontier BFS); returns #active nodes
+  // exact distances to the sink in the residual graph; returns #active nodes.  Levels are
+  // launched in batches, the host only looks at the "anything changed" words between batches.
   int global_relabel() {
-    int32_t cnt[4] = {0, 0, 0, 0};
-    STEREO_HIP_CHECK(hipMemset(d_cnt.p, 0, sizeof(cnt)));
-    hipLaunchKernelGGL(qpbo_bfs_init_kernel, dim3(grid()), dim3(kQB), 0, 0, g, d_front0.p);
-    int32_t *cur = d_front0.p, *nxt = d_front1.p;
-    for (int level = 1;; ++level) {
-      STEREO_HIP_CHECK(hipMemcpy(cnt, d_cnt.p, sizeof(cnt), hipMemcpyDeviceToHost));
-      const int count = cnt[1];
-      if (count == 0) break;
-      STEREO_HIP_CHECK(hipMemset(d_cnt.p + 1, 0, sizeof(int32_t)));
-      hipLaunchKernelGGL(qpbo_bfs_step_kernel, dim3((count + kQB - 1) / kQB), dim3(kQB), 0, 0, g, cur, count, nxt, level);
-      std::swap(cur, nxt);
+    const int batch = 64;
+    hipLaunchKernelGGL(qpbo_relabel_init_kernel, dim3(grid()), dim3(kQB), 0, 0, g);
+    std::vector<int32_t> flags(batch);
+    if (d_flags.n < (size_t)batch) d_flags.alloc(batch);
+    for (int level = 1;;) {
+      STEREO_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(int32_t) * batch, 0));
+      for (int k = 0; k < batch; ++k, ++level)
+        hipLaunchKernelGGL(qpbo_relabel_level_kernel, dim3(grid()), dim3(kQB), 0, 0, g, level, d_flags.p + k);
+      STEREO_HIP_CHECK(hipMemcpy(flags.data(), d_flags.p, sizeof(int32_t) * batch, hipMemcpyDeviceToHost));
+      if (!flags[batch - 1]) break;  // a level that changes nothing ends the search
     }
-    STEREO_HIP_CHECK(hipMemset(d_cnt.p, 0, sizeof(int32_t)));
+    int32_t cnt = 0;
+    STEREO_HIP_CHECK(hipMemsetAsync(d_cnt.p, 0, sizeof(int32_t), 0));
     hipLaunchKernelGGL(qpbo_count_active_kernel, dim3(grid()), dim3(kQB), 0, 0, g);
-    STEREO_HIP_CHECK(hipMemcpy(cnt, d_cnt.p, sizeof(cnt), hipMemcpyDeviceToHost));
+    STEREO_HIP_CHECK(hipMemcpy(&cnt, d_cnt.p, sizeof(cnt), hipMemcpyDeviceToHost));
     ++relabels;
-    return cnt[0];
+    return cnt;
   }
 
   // AddUnaryTerm(i, 0, INFTY) with INFTY = 1 + max over the two saturation sums of node i
@@ -348,7 +436,7 @@ struct QpboSolver {
 
   void maxflow() {
     int active = global_relabel();
-    const int check_every = 32;
+    int check_every = 8;  // grows: easy instances finish within a few sweeps
     int relabel_every = 256;
     if (const char *e = std::getenv("STEREO_HIP_QPBO_RELABEL_EVERY")) relabel_every = std::max(1, std::atoi(e));
     int since_relabel = 0;
@@ -361,6 +449,7 @@ struct QpboSolver {
       }
       iterations += check_every;
       since_relabel += check_every;
+      if (check_every < 32) check_every *= 2;
       int32_t cnt = 0;
       STEREO_HIP_CHECK(hipMemcpy(&cnt, d_cnt.p, sizeof(cnt), hipMemcpyDeviceToHost));
       active = cnt;
@@ -441,9 +530,16 @@ extern "C" int stereo_rd(const double *U0, const double *U1, const double *E00, 
   try {
     QpboSolver S;
     std::string berr;
+    const bool verbose = std::getenv("STEREO_HIP_QPBO_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     if (!build_problem(U0, U1, E00, E01, E10, E11, conn, N, E, S.P, berr)) return fail(berr, err, errcap);
+    const double t1 = now();
     S.upload();
+    const double t2 = now();
     S.maxflow();
+    const double t3 = now();
+    if (verbose) std::fprintf(stderr, "[stereo_hip qpbo] build %.2f ms, upload %.2f ms, maxflow %.2f ms\n", t1 - t0, t2 - t1, t3 - t2);
     const int n = S.n;
     std::vector<int32_t> h(n);
     std::vector<double> snk(n);
@@ -514,4 +610,226 @@ extern "C" int stereo_rd(const double *U0, const double *U1, const double *E00, 
   } catch (const std::exception &e) {
     return fail(std::string("stereo_rd: ") + e.what(), err, errcap);
   }
+}
+
+// ------------------------------------------------------------------ plan API
+
+struct stereo_rd_plan {
+  int64_t N = 0, E = 0, npairs = 0;
+  std::vector<int32_t> aptr;  // host copy (Improve, weak persistency)
+  DevBuf<int32_t> d_pair_i, d_pair_j, d_pe_ptr, d_pe_edge, d_slots, d_slot_pair;
+  DevBuf<uint32_t> d_conn;
+  DevBuf<double> d_ci, d_cjs, d_konst, d_trv, d_terms, d_partial, d_in[6], d_snk0;
+  DevBuf<int8_t> d_label;
+  QpboSolver S;
+};
+
+namespace {
+
+double det_sum(const double *x, int64_t n, DevBuf<double> &partial) {
+  if (n <= 0) return 0.0;
+  const int64_t nb = (n + kQB * 8 - 1) / (kQB * 8);
+  if (partial.n < (size_t)nb) partial.alloc(nb);
+  hipLaunchKernelGGL(det_sum_kernel, dim3((unsigned)nb), dim3(kQB), 0, 0, x, n, partial.p);
+  std::vector<double> h(nb);
+  STEREO_HIP_CHECK(hipMemcpy(h.data(), partial.p, sizeof(double) * nb, hipMemcpyDeviceToHost));
+  double s = 0;
+  for (double v : h) s += v;  // fixed order
+  return s;
+}
+
+}  // namespace
+
+extern "C" int stereo_rd_plan_create(int64_t N, int64_t E, const uint32_t *conn, stereo_rd_plan **plan, char *err,
+                                     size_t errcap) {
+  if (!plan) return fail("stereo_rd_plan_create: plan is NULL", err, errcap);
+  *plan = nullptr;
+  if (N <= 0 || (E > 0 && !conn)) return fail("stereo_rd_plan_create: bad argument", err, errcap);
+  if (2 * N >= INT32_MAX / 2 || E >= INT32_MAX / 4) return fail("stereo_rd: problem too large for 32-bit ids", err, errcap);
+  if (stereo_hip_device_count() < 1)
+    return fail("stereo_rd: no HIP device available (the HIP path has no CPU fallback)", err, errcap);
+  try {
+    std::unique_ptr<stereo_rd_plan> P(new stereo_rd_plan);
+    P->N = N; P->E = E;
+    std::vector<int64_t> order(E);
+    std::iota(order.begin(), order.end(), 0);
+    for (int64_t e = 0; e < E; ++e) {
+      const uint32_t a = conn[2 * e], b = conn[2 * e + 1];
+      if (a >= (uint64_t)N || b >= (uint64_t)N) return fail("connectivity index out of range", err, errcap);
+      if (a == b) return fail("stereo_rd: self loops are not supported", err, errcap);
+    }
+    auto key = [&](int64_t e) {
+      const uint32_t a = conn[2 * e], b = conn[2 * e + 1];
+      return ((uint64_t)std::min(a, b) << 32) | std::max(a, b);
+    };
+    std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return key(x) < key(y); });
+    std::vector<int32_t> pi, pj, pe_ptr, pe_edge(E);
+    for (int64_t k = 0; k < E; ++k) {
+      const int64_t e = order[k];
+      const uint32_t a = conn[2 * e], b = conn[2 * e + 1];
+      const int32_t lo = (int32_t)std::min(a, b), hi = (int32_t)std::max(a, b);
+      if (pi.empty() || pi.back() != lo || pj.back() != hi) { pi.push_back(lo); pj.push_back(hi); pe_ptr.push_back((int32_t)k); }
+      pe_edge[k] = (int32_t)(e * 2 + ((int32_t)a == lo ? 0 : 1));
+    }
+    pe_ptr.push_back((int32_t)E);
+    const int64_t np = (int64_t)pi.size(), n = 2 * N, m = 4 * np;
+    P->npairs = np;
+    // slot layout: every pair owns one outgoing arc at i, j, i', j'; arcs grouped by tail in pair order
+    std::vector<int32_t> aptr(n + 1, 0);
+    for (int64_t k = 0; k < np; ++k) { ++aptr[pi[k] + 1]; ++aptr[pj[k] + 1]; ++aptr[pi[k] + N + 1]; ++aptr[pj[k] + N + 1]; }
+    for (int64_t v = 0; v < n; ++v) aptr[v + 1] += aptr[v];
+    std::vector<int32_t> fill(aptr.begin(), aptr.end() - 1), slots(4 * np), slot_pair(m, 0);
+    for (int64_t k = 0; k < np; ++k) {
+      const int32_t i = pi[k], j = pj[k];
+      slots[4 * k] = fill[i]++; slots[4 * k + 1] = fill[j]++;
+      slots[4 * k + 2] = fill[i + N]++; slots[4 * k + 3] = fill[j + N]++;
+      slot_pair[slots[4 * k]] = (int32_t)(2 * k); slot_pair[slots[4 * k + 1]] = (int32_t)(2 * k + 1);
+      slot_pair[slots[4 * k + 2]] = (int32_t)(2 * k); slot_pair[slots[4 * k + 3]] = (int32_t)(2 * k + 1);
+    }
+    P->aptr = aptr;
+    P->d_pair_i.upload(pi.data(), np); P->d_pair_j.upload(pj.data(), np);
+    P->d_pe_ptr.upload(pe_ptr.data(), pe_ptr.size()); P->d_pe_edge.upload(pe_edge.data(), E);
+    P->d_slots.upload(slots.data(), slots.size()); P->d_slot_pair.upload(slot_pair.data(), slot_pair.size());
+    P->d_conn.upload(conn, 2 * E);
+    P->d_ci.alloc(np); P->d_cjs.alloc(np); P->d_konst.alloc(np); P->d_trv.alloc(N);
+    P->d_terms.alloc(N + E); P->d_label.alloc(N); P->d_snk0.alloc(n);
+    QpboSolver &S = P->S;
+    S.P.N = N; S.P.aptr = aptr;
+    S.n = (int)n; S.m = (int)m;
+    S.d_aptr.upload(aptr.data(), aptr.size());
+    S.d_head.alloc(m); S.d_rev.alloc(m); S.d_r.alloc(m); S.d_delta.alloc(std::max<int64_t>(m, 1));
+    S.d_ex.alloc(n); S.d_snk.alloc(n); S.d_h.alloc(n); S.d_h2.alloc(n); S.d_cnt.alloc(4);
+    S.g.n = (int)n; S.g.m = (int)m; S.g.aptr = S.d_aptr.p; S.g.head = S.d_head.p; S.g.rev = S.d_rev.p;
+    S.g.r = S.d_r.p; S.g.delta = S.d_delta.p; S.g.ex = S.d_ex.p; S.g.snk = S.d_snk.p; S.g.h = S.d_h.p;
+    S.g.h2 = S.d_h2.p; S.g.counters = S.d_cnt.p;
+    STEREO_HIP_CHECK(hipDeviceSynchronize());
+    *plan = P.release();
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  } catch (const std::exception &e) {
+    return fail(std::string("stereo_rd_plan_create: ") + e.what(), err, errcap);
+  }
+}
+
+extern "C" void stereo_rd_plan_destroy(stereo_rd_plan *plan) { delete plan; }
+
+// inputs: six DEVICE arrays (U0, U1 of length N; E00, E01, E10, E11 of length E)
+static int rd_plan_solve_device(stereo_rd_plan *P, const double *const in[6], int improve, double *labelling,
+                                double *energy, double *lower_bound, double *num_unlabelled, char *err,
+                                size_t errcap) {
+  try {
+    QpboSolver &S = P->S;
+    const int64_t N = P->N, E = P->E, np = P->npairs;
+    const int n = S.n;
+    RdPlanDev d{};
+    d.N = (int)N; d.npairs = (int)np; d.pair_i = P->d_pair_i.p; d.pair_j = P->d_pair_j.p;
+    d.pe_ptr = P->d_pe_ptr.p; d.pe_edge = P->d_pe_edge.p; d.slots = P->d_slots.p; d.aptr = S.d_aptr.p;
+    d.slot_pair = P->d_slot_pair.p;
+    d.U0 = in[0]; d.U1 = in[1]; d.E00 = in[2]; d.E01 = in[3]; d.E10 = in[4]; d.E11 = in[5];
+    d.head = S.d_head.p; d.rev = S.d_rev.p; d.r = S.d_r.p; d.ci = P->d_ci.p; d.cjs = P->d_cjs.p;
+    d.konst = P->d_konst.p; d.ex = S.d_ex.p; d.snk = S.d_snk.p; d.trv = P->d_trv.p;
+    // the two kernels may leave the sweep state of a previous move behind: restore the buffers
+    S.g.h = S.d_h.p; S.g.h2 = S.d_h2.p;
+    STEREO_HIP_CHECK(hipMemsetAsync(S.d_delta.p, 0, sizeof(double) * std::max(S.m, 1), 0));
+    if (np > 0) hipLaunchKernelGGL(rd_pairs_kernel, dim3((unsigned)((np + kQB - 1) / kQB)), dim3(kQB), 0, 0, d);
+    hipLaunchKernelGGL(rd_nodes_kernel, dim3((unsigned)((N + kQB - 1) / kQB)), dim3(kQB), 0, 0, d);
+    STEREO_HIP_CHECK(hipMemcpyAsync(P->d_snk0.p, S.d_snk.p, sizeof(double) * n, hipMemcpyDeviceToDevice, 0));
+    // constant of the normal form and sum_i min(0, tr_i): fixed-shape reductions
+    const double konst = det_sum(P->d_konst.p, np, P->d_partial) + det_sum(in[0], N, P->d_partial);
+    const double cap_in = det_sum(P->d_snk0.p, n, P->d_partial);
+    // sum_i min(0, tr_i) = -(sink capacity of the unprimed half)
+    const double neg = -det_sum(P->d_snk0.p, N, P->d_partial);
+    S.iterations = 0; S.relabels = 0;
+    S.maxflow();
+    std::vector<int32_t> h(n);
+    STEREO_HIP_CHECK(hipMemcpy(h.data(), S.g.h, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    const double left = det_sum(S.d_snk.p, n, P->d_partial);
+    *lower_bound = konst + neg + (cap_in - left) / 2;
+    std::vector<int> label(N);
+    double unl = 0;
+    for (int64_t i = 0; i < N; ++i) {
+      const int li = h[i] < n ? 1 : 0, lm = h[i + N] < n ? 1 : 0;
+      label[i] = li == lm ? -1 : li;
+      if (label[i] < 0) unl += 1;
+    }
+    if (unl > 0) {
+      // rare: pull the residual network to the host for the two-pass DFS / Improve bookkeeping
+      S.P.head.resize(S.m); S.P.rev.resize(S.m);
+      std::vector<double> r(S.m);
+      STEREO_HIP_CHECK(hipMemcpy(S.P.head.data(), S.d_head.p, sizeof(int32_t) * S.m, hipMemcpyDeviceToHost));
+      STEREO_HIP_CHECK(hipMemcpy(S.P.rev.data(), S.d_rev.p, sizeof(int32_t) * S.m, hipMemcpyDeviceToHost));
+      STEREO_HIP_CHECK(hipMemcpy(r.data(), S.d_r.p, sizeof(double) * S.m, hipMemcpyDeviceToHost));
+      weak_persistencies(S.P, r, label);
+      unl = 0;
+      for (int64_t i = 0; i < N; ++i) if (label[i] < 0) unl += 1;
+    }
+    *num_unlabelled = unl;
+    if (std::getenv("STEREO_HIP_QPBO_VERBOSE"))
+      std::fprintf(stderr, "[stereo_hip qpbo plan] n=%d arcs=%d iterations=%lld global_relabels=%lld unlabelled=%g\n", S.n,
+                   S.m, (long long)S.iterations, (long long)S.relabels, unl);
+    if (improve && unl > 0) {
+      std::vector<int32_t> perm(N);
+      for (int64_t i = 0; i < N; ++i) perm[i] = (int32_t)i;
+      for (int64_t i = 0; i < N - 1; ++i) {  // QPBO_extra.cpp:13-27
+        int64_t j = i + (int64_t)((rand() / (1.0 + (double)RAND_MAX)) * (double)(N - i));
+        if (j > N - 1) j = N - 1;
+        std::swap(perm[i], perm[j]);
+      }
+      for (int64_t pidx = 0; pidx < N; ++pidx) {
+        const int32_t i = perm[pidx];
+        if ((h[i] < n) != (h[i + N] < n)) continue;
+        S.fix_to_zero(i);
+        S.maxflow();
+        STEREO_HIP_CHECK(hipMemcpy(h.data(), S.g.h, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+      }
+      for (int64_t i = 0; i < N; ++i) {
+        const int li = h[i] < n ? 1 : 0, lm = h[i + N] < n ? 1 : 0;
+        label[i] = li == lm ? 0 : li;
+      }
+    }
+    std::vector<int8_t> l8(N);
+    for (int64_t i = 0; i < N; ++i) { l8[i] = (int8_t)label[i]; labelling[i] = label[i]; }
+    P->d_label.upload(l8.data(), N);
+    hipLaunchKernelGGL(rd_energy_terms_kernel, dim3((unsigned)((N + E + kQB - 1) / kQB)), dim3(kQB), 0, 0, N, E,
+                       P->d_conn.p, S.g.h, n, in[0], in[1], in[2], in[3], in[4], in[5], P->d_label.p, P->d_terms.p);
+    *energy = det_sum(P->d_terms.p, N + E, P->d_partial);
+    STEREO_HIP_CHECK(hipGetLastError());
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  } catch (const std::exception &e) {
+    return fail(std::string("stereo_rd: ") + e.what(), err, errcap);
+  }
+}
+
+extern "C" int stereo_rd_plan_solve(stereo_rd_plan *P, const double *U0, const double *U1, const double *E00,
+                                    const double *E01, const double *E10, const double *E11, int improve,
+                                    double *labelling, double *energy, double *lower_bound,
+                                    double *num_unlabelled, char *err, size_t errcap) {
+  if (!P || !U0 || !U1 || !labelling || !energy || !lower_bound || !num_unlabelled ||
+      (P->E > 0 && (!E00 || !E01 || !E10 || !E11)))
+    return fail("stereo_rd_plan_solve: NULL argument", err, errcap);
+  try {
+    const double *src[6] = {U0, U1, E00, E01, E10, E11};
+    const double *in[6];
+    for (int k = 0; k < 6; ++k) {
+      P->d_in[k].upload(src[k], k < 2 ? P->N : P->E);
+      in[k] = P->d_in[k].p;
+    }
+    return rd_plan_solve_device(P, in, improve, labelling, energy, lower_bound, num_unlabelled, err, errcap);
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+extern "C" int stereo_rd_plan_solve_device(stereo_rd_plan *P, const double *d_U0, const double *d_U1,
+                                           const double *d_E00, const double *d_E01, const double *d_E10,
+                                           const double *d_E11, int improve, double *labelling, double *energy,
+                                           double *lower_bound, double *num_unlabelled, char *err,
+                                           size_t errcap) {
+  if (!P || !d_U0 || !d_U1 || !labelling || !energy || !lower_bound || !num_unlabelled)
+    return fail("stereo_rd_plan_solve_device: NULL argument", err, errcap);
+  const double *in[6] = {d_U0, d_U1, d_E00, d_E01, d_E10, d_E11};
+  return rd_plan_solve_device(P, in, improve, labelling, energy, lower_bound, num_unlabelled, err, errcap);
 }

@@ -11,7 +11,7 @@ import numpy as np
 
 from . import terms as T
 from ._lib import StereoHipError
-from .rd import rd
+from .rd import RdPlan, rd  # noqa: F401
 from .trws import trws
 
 
@@ -31,6 +31,7 @@ class dispmap_super:
         self.points = T.get_points(*self.sz)
         self.smooth_weights = np.ones(self.neighborhood.shape[1])       # dispmap_super.m:35
         self.d_min, self.d_step = 0.0, 0.0                              # rescaling only in globalstereo
+        self._rd_plan = None                                            # device-resident QPBO, built lazily
 
     # ---- properties with the reference's setters (dispmap_super.m:39-56)
     @property
@@ -107,8 +108,9 @@ class dispmap_super:
         E00, E01, E10, E11 = self.all_pairwise_costs(self._assignment, proposal)
         U0 = self.unary_cost(self._assignment)
         U1 = self.unary_cost(proposal)
-        labelling, e, lb, num_unlabelled = rd(U0, U1, E00, E01, E10, E11, self.neighborhood + 1,
-                                              {"improve": self._improve})
+        if self._rd_plan is None:      # same solver as rd(...), graph layout kept across moves
+            self._rd_plan = RdPlan(self.sz[0] * self.sz[1], self.neighborhood)
+        labelling, e, lb, num_unlabelled = self._rd_plan.solve(U0, U1, E00, E01, E10, E11, self._improve)
         a = self._assignment.copy(order="F")
         take = labelling == 1
         a[:, take] = proposal[:, take]

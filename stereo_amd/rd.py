@@ -49,3 +49,46 @@ def rd(U0, U1, E00, E01, E10, E11, connectivity, options=None):
                               C.byref(nu), err, C.c_size_t(len(err)))
     _lib.check(rc, err)
     return lab, en.value, lb.value, nu.value
+
+
+class RdPlan:
+    """Device-resident roof-duality solver for one connectivity (stereo_rd_plan_*): repeated
+    binary fusions on one image reuse the doubled-graph layout and all device buffers."""
+
+    def __init__(self, N, connectivity0):
+        c = np.asarray(connectivity0)
+        if c.ndim != 2 or c.shape[0] != 2:
+            raise StereoHipError("connectivity must be 2 x E")
+        self._conn = np.asfortranarray(c, dtype=np.uint32)
+        self.N, self.E = int(N), int(self._conn.shape[1])
+        self._h = C.c_void_p()
+        err = _lib.errbuf()
+        L = _lib.lib()
+        L.stereo_rd_plan_destroy.restype = None
+        rc = L.stereo_rd_plan_create(C.c_int64(self.N), C.c_int64(self.E), _p(self._conn, C.c_uint32),
+                                     C.byref(self._h), err, C.c_size_t(len(err)))
+        _lib.check(rc, err)
+
+    def close(self):
+        if self._h:
+            _lib.lib().stereo_rd_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve(self, U0, U1, E00, E01, E10, E11, improve=False):
+        U0, U1, E00, E01, E10, E11 = map(_v, (U0, U1, E00, E01, E10, E11))
+        assert U0.shape[0] == self.N and U1.shape[0] == self.N
+        assert E00.shape[0] == E01.shape[0] == E10.shape[0] == E11.shape[0] == self.E
+        lab = np.zeros(self.N)
+        en, lb, nu = C.c_double(), C.c_double(), C.c_double()
+        err = _lib.errbuf()
+        rc = _lib.lib().stereo_rd_plan_solve(self._h, _p(U0), _p(U1), _p(E00), _p(E01), _p(E10), _p(E11),
+                                             C.c_int(int(bool(improve))), _p(lab), C.byref(en), C.byref(lb),
+                                             C.byref(nu), err, C.c_size_t(len(err)))
+        _lib.check(rc, err)
+        return lab, en.value, lb.value, nu.value

@@ -130,3 +130,27 @@ def test_rd_golden_vectors(hip):
         lab_i, en2, _, _ = hip.rd(*args, p["conn"].T + 1, {"improve": True})
         assert np.array_equal(lab_i, improved), name
         assert _rel(en2, en_i) < 1e-9, name
+
+
+def test_plan_equals_stateless_and_reference(hip, oracle):
+    """stereo_rd_plan_* (capacities built on the device, buffers reused across moves) must give
+    what stereo_rd gives, move after move, including after a move that left nodes unlabelled."""
+    import ctypes
+    from stereo_amd.rd import RdPlan
+    libc = ctypes.CDLL(None)
+    H, W = 20, 24
+    probs = [fusion_problem(301, H, W), glass_problem(302, H, W, 3.0, True), fusion_problem(303, H, W, nonsub_boost=5.0),
+             glass_problem(304, H, W, 3.0, False), fusion_problem(305, H, W, kernel=2, tol=20.0)]
+    plan = RdPlan(H * W, probs[0]["conn"].T)
+    for k, p in enumerate(probs):
+        args = (p["U0"], p["U1"], p["E00"], p["E01"], p["E10"], p["E11"])
+        for improve in (False, True):
+            libc.srand(k)
+            a = hip.rd(*args, p["conn"].T + 1, {"improve": improve})
+            libc.srand(k)
+            b = plan.solve(*args, improve=improve)
+            assert np.array_equal(a[0], b[0]), (k, improve)
+            assert a[3] == b[3] and _rel(a[1], b[1]) < 1e-12 and _rel(a[2], b[2]) < 1e-12, (k, improve)
+            if oracle.have_ref_qpbo() and improve:
+                r = oracle.ref_rd(*args, p["conn"], improve=True, seed=k)
+                assert np.array_equal(r[0], b[0]), k

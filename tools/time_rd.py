@@ -14,3 +14,12 @@ t = time.time(); lab, en, lb, nu = stereo_amd.rd(*args, p["conn"].T + 1, {}); tg
 t = time.time(); ref = po.ref_rd(*args, p["conn"]); tr = time.time() - t
 print("gpu %.4fs ref %.4fs labels equal %s en %.6f/%.6f lb %.6f/%.6f unl %g/%g" % (
     tg, tr, np.array_equal(lab, ref[0]), en, ref[1], lb, ref[2], nu, ref[3]))
+
+from stereo_amd.rd import RdPlan
+plan = RdPlan(H * W, p["conn"].T)
+plan.solve(*args)
+t = time.time()
+for _ in range(5):
+    labp, enp, lbp, nup = plan.solve(*args)
+tp = (time.time() - t) / 5
+print("plan %.4fs per move (%.1f moves/s), labels equal %s" % (tp, 1 / tp, np.array_equal(labp, ref[0])))
