@@ -786,7 +786,7 @@ __device__ __forceinline__ bool wait_flag(const DevParams &p, int rank, int epoc
 template <int KERNEL>
 __device__ __forceinline__ double message_regs(const DevParams &p, int K, double alpha, double h,
                                                double qsrc, double t, const uint16_t *perm,
-                                               double &outmsg, int lane) {
+                                               double &outmsg, int lane, double *hq = nullptr) {
   const double inf = __builtin_huge_val();
   const bool act = lane < K;
   const double hmin = wave_min_dpp(h);  // inactive lanes hold +inf
@@ -816,25 +816,40 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
       unsigned long long mask = __builtin_amdgcn_ballot_w64(useful);
       double m1 = inf, m2 = inf;
       bool bad = !(delta < inf);
-      // two sources per trip: their chains are independent, which roughly doubles the issue
-      // rate of a single wave; a source visited twice (odd count) changes nothing
+      // The sources are broadcast from a per-wave LDS table (one ds_read_b128 per source instead of
+      // eight v_readlane); two sources per trip keep two independent dependency chains in flight.
+      // m1 / m2 = smallest and second smallest DISTINCT cost seen so far.
+      if (hq) {
+        hq[2 * lane] = h; hq[2 * lane + 1] = qsrc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+#define STEREO_SRC(J, HJ, QJ)                                                       \
+  double HJ, QJ;                                                                     \
+  if (hq) { HJ = hq[2 * (J)]; QJ = hq[2 * (J) + 1]; }                                \
+  else { HJ = readlane_f64(h, (J)); QJ = readlane_f64(qsrc, (J)); }
+#define STEREO_ACC(HJ, QJ)                                                           \
+  {                                                                                  \
+    const double c = pair_cost<1>(alpha, t - QJ, HJ);                                \
+    const double lo = fmin(m1, c), hi = fmax(m1, c);                                 \
+    m2 = hi > lo ? fmin(m2, hi) : m2;                                                \
+    m1 = lo;                                                                         \
+    const double aqj = alpha * QJ;                                                   \
+    const bool near = (fabs(ui - (HJ - aqj)) <= delta) || (fabs(vi - (HJ + aqj)) <= delta); \
+    bad = bad || (near && qsrc != QJ);                                               \
+  }
       while (mask) {
         const int j0 = __builtin_ctzll(mask);
         mask &= mask - 1;
-        const int j1 = mask ? __builtin_ctzll(mask) : j0;
+        const int j1 = mask ? __builtin_ctzll(mask) : j0;  // a source visited twice changes nothing
         mask &= mask - 1;
-        const double hj0 = readlane_f64(h, j0), qj0 = readlane_f64(qsrc, j0);
-        const double hj1 = readlane_f64(h, j1), qj1 = readlane_f64(qsrc, j1);
-        const double uj0 = readlane_f64(ui, j0), vj0 = readlane_f64(vi, j0);
-        const double uj1 = readlane_f64(ui, j1), vj1 = readlane_f64(vi, j1);
-        const double c0 = pair_cost<1>(alpha, t - qj0, hj0);
-        const double c1 = pair_cost<1>(alpha, t - qj1, hj1);
-        const bool near0 = (fabs(ui - uj0) <= delta) || (fabs(vi - vj0) <= delta);
-        const bool near1 = (fabs(ui - uj1) <= delta) || (fabs(vi - vj1) <= delta);
-        if (c0 < m1) { m2 = m1; m1 = c0; } else if (c0 > m1 && c0 < m2) { m2 = c0; }
-        if (c1 < m1) { m2 = m1; m1 = c1; } else if (c1 > m1 && c1 < m2) { m2 = c1; }
-        bad = bad || (near0 && qsrc != qj0) || (near1 && qsrc != qj1);
+        STEREO_SRC(j0, hj0, qj0)
+        STEREO_SRC(j1, hj1, qj1)
+        STEREO_ACC(hj0, qj0)
+        STEREO_ACC(hj1, qj1)
       }
+#undef STEREO_SRC
+#undef STEREO_ACC
       bad = bad || (m1 < vtrunc && !(m2 - m1 > delta && vtrunc - m1 > delta));
       need_serial = UNI(act && bad);
       out = m1 < vtrunc ? m1 : vtrunc;
@@ -890,7 +905,8 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
   double *stage0 = lds;                                   // 2 stages
   double *hand = lds + 2 * kStageDoubles;                 // ring of 4 x 8 x 64: the last visits' new messages
   double *scal = hand + 4 * 8 * kWave;                    // 2 x kScalDoubles
-  int *ctl = (int *)(scal + 2 * kScalDoubles);            // [0] run, [1] abort
+  double *hqtab = scal + 2 * kScalDoubles;                // per compute wave: 64 x (h, q)
+  int *ctl = (int *)(hqtab + kPipeCompute * 2 * kWave);   // [0] run, [1] abort
   const int K = p.K;
   const double inf = __builtin_huge_val();
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -968,7 +984,8 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
               }
               const double alpha = st[kStA + j];
               double newm = 0;
-              const double v = message_regs<KERNEL>(p, K, alpha, h, qsrc, qdst, perm, newm, lane);
+              const double v = message_regs<KERNEL>(p, K, alpha, h, qsrc, qdst, perm, newm, lane,
+                                                    hqtab + wave * 2 * kWave);
               if (act) hcur[j * kWave + lane] = newm;
               if (BACKWARD && lane == 0) sc[j] = v;
             }
@@ -1224,7 +1241,7 @@ void launch_persistent(stereo_trws_plan *P, const DevParams &p, int what, hipStr
   STEREO_HIP_CHECK(hipMemsetAsync(P->d_ctl.p, 0, sizeof(int32_t), s));  // ticket = 0
   const dim3 grid(P->grid_blocks), block(kBlock);
   if (P->fast) {
-    const size_t plds = sizeof(double) * (2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + 2);
+    const size_t plds = sizeof(double) * (2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * 2 * kWave + 2);
     const bool sh = P->pos != nullptr;
     const dim3 pblock(kPipeThreads);
 #define PIPE(BW, PR, UP)                                                                          \
