@@ -928,6 +928,8 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
     if (run >= p.nruns[D]) break;
     const int p0 = p.run_ptr[D][run], p1 = p.run_ptr[D][run + 1];
     int xprev = 0, xprev2 = 0;  // primal wave: labels of the previous two nodes of the run
+    int wnext = 0;              // loader: raw descriptor word of the node after next (prefetched)
+    if (wave == kPipeCompute) wnext = desc[(size_t)p0 * DW + lane];
     if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2] = wall_clock64();
     unsigned long long busy = 0;
 
@@ -946,13 +948,15 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
           const int *sti = (const int *)(st + kStI);
           const int f = __builtin_amdgcn_readfirstlane(sti[2]);
           const int nout = f & 15, nin = (f >> 4) & 15, md = (f >> 16) & 255, ntot = nout + nin;
+          const unsigned slA = (unsigned)__builtin_amdgcn_readfirstlane(sti[41]);
+          const unsigned slB = (unsigned)__builtin_amdgcn_readfirstlane(sti[42]);
           double Di = act ? st[kStD + lane] : 0.0;
           double mown = 0;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             if (j < ntot) {
               double v;
-              const int sl = j >= nout ? __builtin_amdgcn_readfirstlane(sti[12 + j]) : -1;
+              const int sl = j >= nout ? (int)(signed char)(((j < 4 ? slA : slB) >> (8 * (j & 3))) & 255) : -1;
               if (sl >= 8) v = hprev2[(sl - 8) * kWave + lane];
               else if (sl >= 0) v = hprev[sl * kWave + lane];
               else v = st[kStM + j * kWave + lane];
@@ -994,7 +998,8 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
       } else if (wave == kPipeCompute) {
         // ------------------------------------------------------------ loader: stage node pos + 1
         if (pos + 1 >= p0 && pos + 1 < p1) {
-          const int w = desc[(size_t)(pos + 1) * DW + lane];
+          const int w = wnext;
+          if (pos + 2 < p1) wnext = desc[(size_t)(pos + 2) * DW + lane];
           const NodeDesc nx = decode_desc(w);
           int *stni = (int *)(stn + kStI);
           stni[lane] = w;

@@ -250,6 +250,10 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
         D[2] = (int32_t)((uint32_t)nout | ((uint32_t)nin << 4) | ((uint32_t)nd << 8) | (md << 16));
         D[3] = g.lb_pos_node[r];
         for (int k = 0; k < 4; ++k) D[20 + k] = k < nd ? S.dep_rank[S.dep_ptr[r] + k] : 0;
+        // slots once more, one byte each (0xff = none), for the compute waves: words 41, 42
+        uint32_t pk[2] = {0, 0};
+        for (int k = 0; k < 8; ++k) pk[k >> 2] |= (uint32_t)(uint8_t)(int8_t)D[12 + k] << (8 * (k & 3));
+        D[41] = (int32_t)pk[0]; D[42] = (int32_t)pk[1];
       }
       // Completion flags are raised either in the middle of the next visit (costs a store
       // drain on that run's critical path, but the dependent run can follow closely) or
