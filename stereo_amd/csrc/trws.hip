@@ -1026,11 +1026,23 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
             av = p.alpha[ej];
           }
           // ... then the completion flags of the foreign neighbours, then their data
-          bool ok = true;
+          // (all flags are polled together: lane j watches dependency j)
+          if (nx.ndep > 0) {
+            int myrank = nx.dep[0];
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (ok && j < nx.ndep) ok = wait_flag(p, nx.dep[j], epoch);
-          if (!ok && lane == 0) ctl[1] = 1;
+            for (int j = 1; j < 4; ++j)
+              if (lane == j) myrank = nx.dep[j];
+            const bool watching = lane < nx.ndep;
+            int spins = 0;
+            bool ok = true;
+            for (;;) {
+              const int v = watching ? ld_sc1(p.done + myrank) : epoch;
+              if (!UNI(v < epoch)) break;
+              __builtin_amdgcn_s_sleep(1);
+              if (++spins > kSpinLimit || ((spins & 1023) == 0 && ld_sc1(p.abort_flag))) { ok = false; break; }
+            }
+            if (!ok && lane == 0) { st_sc1(p.abort_flag, 1); ctl[1] = 1; }
+          }
 #pragma unroll
           for (int j = 0; j < 8; ++j)
             if (UPDATE && j >= nx.nout && j < ntot && nx.slot[j] < 0 && act)
@@ -1070,7 +1082,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
         }
       } else {
         // ------------------------------------------------------------ primal of node pos
-        if (PRIMAL && have_node) {
+        if (PRIMAL && have_node && !(p.debug & 8)) {
           const int *sti = (const int *)(st + kStI);
           const int f = __builtin_amdgcn_readfirstlane(sti[2]);
           const int nout = f & 15, nin = (f >> 4) & 15, md = (f >> 16) & 255, ntot = nout + nin;
