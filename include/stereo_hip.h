@@ -113,6 +113,12 @@ int stereo_trws_plan_stats(stereo_trws_plan *plan, double *sweep_ms, int64_t *sw
  * construction and the serial construction was run instead. */
 int stereo_trws_plan_counters(stereo_trws_plan *plan, int64_t *serial_messages, int reset);
 
+/* Diagnostics: which sweep implementation the plan's current inputs select.
+ * 0 level-synchronous launches, 1 generic persistent kernel, 2 pipelined kernel (K <= 64),
+ * 3 wide pipelined kernel (64 < K <= 256, shared strictly ascending positions).
+ * All give identical results.  Negative on a NULL plan. */
+int stereo_trws_plan_path(stereo_trws_plan *plan);
+
 /* Host-only graph analysis behind stereo_trws_plan_create (no device needed):
  * node order of SetAutomaticOrdering (ordering.cpp:7-157), edge orientation and
  * per-node forward/backward edge lists of CompleteGraphConstruction

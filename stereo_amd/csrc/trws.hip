@@ -75,6 +75,7 @@ struct DevParams {
   int prof_run;
   int debug;  // development switches (timing experiments only)
   unsigned long long *timeline;  // optional [2][nruns][2] wall-clock stamps (development)
+  int window;  // wide kernel: sources within lambda of a destination lie within +-window indices
 };
 
 // ---- agent-scope (sc1) accesses: data handed between workgroups inside one launch
@@ -1131,6 +1132,485 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
 }
 
 
+// ---- wide-label pipelined sweep: 64 < K <= 256, shared strictly ascending positions -------
+// The regime of the large grids (3000x2000x256): per message K^2 pair costs are too many, so
+//  * min-plus only looks at the sources inside the truncation window of each destination
+//    (a source farther than lambda costs >= vTrunc exactly, by monotone rounding);
+//  * the certificate's tangency test ("no two u = h - alpha q, nor two v = h + alpha q, within
+//    delta") is done by sorting u and v in LDS and looking at neighbours -- conservative (all
+//    pairs, not only those with a useful cone), O(K log^2 K) instead of O(K^2);
+//  * a message is spread over several waves: `chunks` waves for the windowed min-plus (lane =
+//    one of 64 destinations), one wave per sort.  12 compute waves synchronise among
+//    themselves with an LDS counter; loader / storer / primal waves as in trws_pipe_kernel
+//    meet them once per visit at the hardware barrier.
+// If the certificate fails (or kernel 2), one wave runs the reference's serial envelope
+// construction in LDS for that message.
+constexpr int kWideCompute = 12;
+constexpr int kWideWaves = kWideCompute + 3;
+constexpr int kWideThreads = kWideWaves * kWave;
+constexpr int kWS = 264;  // LDS row stride in doubles (>= 256 + 2, multiple of 8)
+constexpr int kWStI = kWS + 8 * kWS + 8;            // int area of a stage (in doubles)
+constexpr int kWStage = kWStI + 36;
+// stage: D[kWS] m[8][kWS] a[8] | ints desc[64] px[8]
+
+struct WidePtrs {
+  double *stage0, *hand, *Di, *H, *outb, *sortb, *pos, *part, *scal;
+  int *ipart, *ctl;
+};
+__device__ __forceinline__ WidePtrs wide_carve(double *lds) {
+  WidePtrs w;
+  w.stage0 = lds;                       // 2 * kWStage
+  w.hand = w.stage0 + 2 * kWStage;      // 3 * 8 * kWS
+  w.Di = w.hand + 3 * 8 * kWS;          // kWS
+  w.H = w.Di + kWS;                     // 8 * kWS
+  w.outb = w.H + 8 * kWS;               // 8 * kWS
+  w.sortb = w.outb + 8 * kWS;           // 16 * kWS (u_j, v_j per message)
+  w.pos = w.sortb + 16 * kWS;           // kWS
+  w.part = w.pos + kWS;                 // 128: hmin[8][4] vmin[8][4] mag[8][4] dmin[4]
+  w.scal = w.part + 128;                // 2 * kScalDoubles
+  w.ipart = (int *)(w.scal + 2 * kScalDoubles);  // bad[8], barrier counter, ...
+  w.ctl = w.ipart + 16;
+  return w;
+}
+constexpr int kWideLdsDoubles = 2 * kWStage + 3 * 8 * kWS + kWS + 8 * kWS * 2 + 16 * kWS + kWS + 128 + 2 * kScalDoubles + 16;
+static_assert(kWideLdsDoubles * 8 <= 160 * 1024, "wide kernel LDS");
+
+// software barrier among the compute waves (monotone LDS counter)
+__device__ __forceinline__ void compute_barrier(int *counter, int &phase, int lane, int *abort_word) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  ++phase;
+  if (lane == 0) {
+    __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    int spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < phase * kWideCompute) {
+      __builtin_amdgcn_s_sleep(0);
+      if (++spins > kSpinLimit) { *abort_word = 1; break; }  // bounded: never hang the device
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Bitonic sort of 64 * R keys held in registers by one wave: key i = c * 64 + lane lives in
+// r[c] of `lane`.  Exchanges across >= 64 positions are register-to-register, the others lane
+// shuffles.  Keys only (the certificate needs the gaps, not the permutation).
+template <int R>
+__device__ __forceinline__ void wave_sort_regs(double (&r)[R], int lane) {
+#pragma unroll
+  for (int size = 2; size <= 64 * R; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      if (stride >= 64) {
+        const int m = stride >> 6;
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+          if ((c & m) == 0) {
+            const bool up = ((c * 64) & size) == 0;
+            const double a = r[c], b = r[c | m];
+            const double lo = fmin(a, b), hi = fmax(a, b);
+            r[c] = up ? lo : hi;
+            r[c | m] = up ? hi : lo;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+          const double o = __shfl_xor(r[c], stride, kWave);
+          const bool up = (((c * 64) | lane) & size) == 0;
+          const bool keep_min = ((lane & stride) == 0) == up;
+          r[c] = keep_min ? fmin(r[c], o) : fmax(r[c], o);
+        }
+      }
+    }
+  }
+}
+
+// true if two neighbours of the sorted keys (first K of them) are within delta
+template <int R>
+__device__ __forceinline__ bool sorted_gap_within(const double (&r)[R], int K, double delta, int lane) {
+  bool bad = false;
+#pragma unroll
+  for (int c = 0; c < R; ++c) {
+    double nxt = __shfl_down(r[c], 1, kWave);
+    if (c + 1 < R) { const double first = readlane_f64(r[c + 1], 0); nxt = lane == kWave - 1 ? first : nxt; }
+    const int i = c * 64 + lane;
+    const bool have = i + 1 < K && (c + 1 < R || lane < kWave - 1);
+    bad = bad || (have && !(nxt - r[c] > delta));
+  }
+  return bad;
+}
+
+template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE>
+__global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, int epoch) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const WidePtrs L = wide_carve(lds);
+  const int K = p.K;
+  const int C = (K + kWave - 1) / kWave;  // 64-label chunks
+  const double inf = __builtin_huge_val();
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  constexpr int D = BACKWARD ? 1 : 0;
+  constexpr int DW = TrwsGraph::kDescWords;
+  const int32_t *desc = p.desc[D];
+  for (int k = tid; k < kWS; k += kWideThreads) L.pos[k] = k < K ? p.pos[k] : inf;
+  if (tid == 0) { L.ctl[1] = 0; L.ipart[8] = 0; }
+  int cphase = 0;  // compute-barrier phase counter (compute waves only)
+  // development profile (STEREO_HIP_TRWS_PROF): cycles of wave 0 per phase [0..7], busy cycles of
+  // loader / storer / primal [8..10], hardware-barrier wait of wave 0 [11], visits [12]
+  unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pbusy = 0, pwait = 0, pvis = 0;
+#define WSTAMP(i) do { if (p.prof) { const long long now_ = (long long)__builtin_readcyclecounter(); pacc[i] += (unsigned long long)(now_ - tmark); tmark = now_; } } while (0)
+  __syncthreads();
+
+  for (;;) {
+    if (tid == 0) L.ctl[0] = atomicAdd(p.ticket, 1);
+    __syncthreads();
+    const int run = __builtin_amdgcn_readfirstlane(L.ctl[0]);
+    __syncthreads();
+    if (run >= p.nruns[D]) break;
+    const int p0 = p.run_ptr[D][run], p1 = p.run_ptr[D][run + 1];
+    int xprev = 0, xprev2 = 0;
+    int wnext = 0;
+    if (wave == kWideCompute) wnext = desc[(size_t)p0 * DW + lane];
+
+    for (int pos = p0 - 1; pos <= p1; ++pos) {
+      double *st = L.stage0 + (pos & 1) * kWStage;
+      double *stn = L.stage0 + ((pos + 1) & 1) * kWStage;
+      const int hb = ((pos % 3) + 3) % 3, hb1 = (((pos - 1) % 3) + 3) % 3, hb2 = (((pos - 2) % 3) + 3) % 3;
+      double *hcur = L.hand + hb * 8 * kWS, *hprev = L.hand + hb1 * 8 * kWS, *hprev2 = L.hand + hb2 * 8 * kWS;
+      double *sc = L.scal + (pos & 1) * kScalDoubles;
+      const bool have_node = pos >= p0 && pos < p1;
+      long long tmark = p.prof ? (long long)__builtin_readcyclecounter() : 0;
+      const long long tvisit = tmark;
+
+      if (wave < kWideCompute) {
+        // ======================================================== compute waves
+        if (UPDATE && have_node) {
+          const int *sti = (const int *)(st + kWStI);
+          const int f = __builtin_amdgcn_readfirstlane(sti[2]);
+          const int nout = f & 15, nin = (f >> 4) & 15, ntot = nout + nin;
+          const unsigned slA = (unsigned)__builtin_amdgcn_readfirstlane(sti[41]);
+          const unsigned slB = (unsigned)__builtin_amdgcn_readfirstlane(sti[42]);
+          // ---- P1: Di = D + messages in list order, one chunk per wave
+          if (wave < C) {
+            const int k = wave * kWave + lane;
+            double di = inf;
+            if (k < K) {
+              di = st[k];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                if (j < ntot) {
+                  const int sl = j >= nout ? (int)(signed char)(((j < 4 ? slA : slB) >> (8 * (j & 3))) & 255) : -1;
+                  di += sl >= 8 ? hprev2[(sl - 8) * kWS + k] : sl >= 0 ? hprev[sl * kWS + k] : st[kWS + j * kWS + k];
+                }
+              }
+              L.Di[k] = di;
+            }
+            if (BACKWARD) {
+              const double m = wave_min_dpp(di);
+              if (lane == 0) L.part[96 + wave] = m;
+            }
+          }
+          WSTAMP(0);
+          compute_barrier(L.ipart + 8, cphase, lane, L.ctl + 1);
+          WSTAMP(1);
+          // ---- P2: H_j = gamma * Di - m_j for every outgoing edge, partial minima
+          double node_vmin = 0;
+          if (BACKWARD) {
+            node_vmin = L.part[96];
+            for (int c = 1; c < C; ++c) { const double o = L.part[96 + c]; node_vmin = o < node_vmin ? o : node_vmin; }
+            if (tid == 0) sc[8] = node_vmin;
+          }
+          const double gamma = (double)1 / (double)(nout > nin ? nout : nin);
+          for (int t = wave; t < nout * 4; t += kWideCompute) {
+            const int j = t >> 2, c = t & 3, k = c * kWave + lane;
+            if (c >= C) continue;
+            double h = inf, mg = 0;
+            if (k < K) {
+              const double di = BACKWARD ? L.Di[k] - node_vmin : L.Di[k];
+              h = gamma * di - st[kWS + j * kWS + k];
+              L.H[j * kWS + k] = h;
+              const double aq = st[kWS + 8 * kWS + j] * L.pos[k];
+              mg = fabs(h) + 2 * fabs(aq);
+            }
+            const double hm = wave_min_dpp(h), mm = wave_max_dpp(mg);
+            if (lane == 0) { L.part[j * 4 + c] = hm; L.part[64 + j * 4 + c] = mm; }
+          }
+          if (wave < 8 && lane == 0) L.ipart[wave] = 0;  // bad flags
+          WSTAMP(2);
+          compute_barrier(L.ipart + 8, cphase, lane, L.ctl + 1);
+          WSTAMP(3);
+          // ---- P3: per message two sorts (certificate) and `C` windowed min-plus tasks
+          const int T = (KERNEL == 1 && p.certificate) ? 6 * nout : 0;
+          for (int tt = wave; tt < T; tt += kWideCompute) {
+            const bool is_sort = tt < 2 * nout;
+            const int j = is_sort ? tt >> 1 : (tt - 2 * nout) >> 2;
+            if (!is_sort && ((tt - 2 * nout) & 3) >= C) continue;
+            const double alpha = st[kWS + 8 * kWS + j];
+            double hmin = L.part[j * 4], mag = L.part[64 + j * 4];
+            for (int c = 1; c < C; ++c) {
+              const double a = L.part[j * 4 + c], b = L.part[64 + j * 4 + c];
+              hmin = a < hmin ? a : hmin; mag = b > mag ? b : mag;
+            }
+            const double vtrunc = hmin + alpha * p.lambda;
+            const double delta = 1e-9 * (mag + fabs(alpha * p.lambda));
+            if (UNI(alpha == 0)) continue;  // constant message, handled in P4
+            if (is_sort) {
+              if (p.debug & 16) continue;
+              const double sgn = (tt & 1) ? 1.0 : -1.0;
+              bool bad = !(delta < inf);
+              if (K <= 128) {
+                double r[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                  const int k = c * kWave + lane;
+                  r[c] = k < K ? L.H[j * kWS + k] + sgn * (alpha * L.pos[k]) : inf;
+                }
+                wave_sort_regs<2>(r, lane);
+                bad = bad || sorted_gap_within<2>(r, K, delta, lane);
+              } else {
+                double r[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                  const int k = c * kWave + lane;
+                  r[c] = k < K ? L.H[j * kWS + k] + sgn * (alpha * L.pos[k]) : inf;
+                }
+                wave_sort_regs<4>(r, lane);
+                bad = bad || sorted_gap_within<4>(r, K, delta, lane);
+              }
+              if (UNI(bad) && lane == 0) L.ipart[j] = 1;
+            } else {
+              const int c = (tt - 2 * nout) & 3, k = c * kWave + lane;
+              double m1 = inf, m2 = inf, out = vtrunc;
+              bool bad = false;
+              if (k < K) {
+                const double tk = L.pos[k];
+                const int lo = k - p.window > 0 ? k - p.window : 0, hi = k + p.window < K - 1 ? k + p.window : K - 1;
+                for (int i = lo; i <= ((p.debug & 32) ? lo : hi); ++i) {
+                  const double cst = pair_cost<1>(alpha, tk - L.pos[i], L.H[j * kWS + i]);
+                  const double lo_ = fmin(m1, cst), hi_ = fmax(m1, cst);
+                  m2 = hi_ > lo_ ? fmin(m2, hi_) : m2;
+                  m1 = lo_;
+                }
+                bad = m1 < vtrunc && !(m2 - m1 > delta && vtrunc - m1 > delta);
+                out = m1 < vtrunc ? m1 : vtrunc;
+                L.outb[j * kWS + k] = out;
+              }
+              const double vm = wave_min_dpp(k < K ? out : inf);
+              if (lane == 0) L.part[32 + j * 4 + c] = vm;
+              if (UNI(bad) && lane == 0) L.ipart[j] = 1;
+            }
+          }
+          WSTAMP(4);
+          compute_barrier(L.ipart + 8, cphase, lane, L.ctl + 1);
+          WSTAMP(5);
+          // ---- P4: normalise and hand over; serial envelope where the certificate failed
+          for (int t = wave; t < nout * 4; t += kWideCompute) {
+            const int j = t >> 2, c = t & 3, k = c * kWave + lane;
+            if (c >= C) continue;
+            const double alpha = st[kWS + 8 * kWS + j];
+            double hmin = L.part[j * 4];
+            for (int cc = 1; cc < C; ++cc) { const double a = L.part[j * 4 + cc]; hmin = a < hmin ? a : hmin; }
+            const bool constant = alpha == 0;
+            const bool serial = !constant && (KERNEL != 1 || !p.certificate || L.ipart[j] != 0);
+            if (constant) {
+              // typeStereoLinear.h:390-396: message = min H everywhere, normalised to zero
+              if (k < K) hcur[j * kWS + k] = hmin - hmin;
+              if (BACKWARD && c == 0 && lane == 0) sc[j] = hmin;
+            } else if (!serial) {
+              double vmin = L.part[32 + j * 4];
+              for (int cc = 1; cc < C; ++cc) { const double a = L.part[32 + j * 4 + cc]; vmin = a < vmin ? a : vmin; }
+              if (k < K) hcur[j * kWS + k] = L.outb[j * kWS + k] - vmin;
+              if (BACKWARD && c == 0 && lane == 0) sc[j] = vmin;
+            } else if (c == 0) {
+              // one wave, whole message: the reference's serial construction in LDS
+              if (lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
+              const double vtrunc = hmin + alpha * p.lambda;
+              double *sh = L.sortb + (2 * j) * kWS, *sq = L.sortb + (2 * j + 1) * kWS, *z = L.outb + j * kWS;
+              if (lane == 0) build_envelope<KERNEL>(K, alpha, L.H + j * kWS, L.pos, sh, sq, z);
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              double vloc = inf, ov[4] = {0, 0, 0, 0};
+#pragma unroll
+              for (int cc = 0; cc < 4; ++cc) {
+                const int kk = cc * kWave + lane;
+                if (cc < C && kk < K) {
+                  const double tk = L.pos[kk];
+                  int jj = 0;
+                  while (z[jj + 1] < tk) ++jj;
+                  const double cst = pair_cost<KERNEL>(alpha, tk - sq[jj], sh[jj]);
+                  ov[cc] = cst < vtrunc ? cst : vtrunc;
+                  vloc = ov[cc] < vloc ? ov[cc] : vloc;
+                }
+              }
+              const double vmin = wave_min_dpp(vloc);
+#pragma unroll
+              for (int cc = 0; cc < 4; ++cc) {
+                const int kk = cc * kWave + lane;
+                if (cc < C && kk < K) hcur[j * kWS + kk] = ov[cc] - vmin;
+              }
+              if (BACKWARD && lane == 0) sc[j] = vmin;
+            }
+          }
+        }
+      } else if (wave == kWideCompute) {
+        // ======================================================== loader: stage node pos + 1
+        if (pos + 1 >= p0 && pos + 1 < p1) {
+          const int w = wnext;
+          if (pos + 2 < p1) wnext = desc[(size_t)(pos + 2) * DW + lane];
+          const NodeDesc nx = decode_desc(w);
+          int *stni = (int *)(stn + kWStI);
+          stni[lane] = w;
+          const int ntot = nx.nout + nx.nin;
+          // all requests go out before anything is consumed (registers first, LDS at the end)
+          double dk[4], mv[8][4];
+          bool okc[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            okc[c] = c < C && c * kWave + lane < K;
+            dk[c] = okc[c] ? p.unary[(size_t)nx.node * K + c * kWave + lane] : 0.0;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              mv[j][c] = 0;
+              if (j < nx.nout && (UPDATE || PRIMAL) && okc[c]) mv[j][c] = p.msg[(size_t)nx.e[j] * K + c * kWave + lane];
+            }
+          }
+          double av = 0;
+          int pxv = 0, xn = 0, sl = 0;
+          if (lane < ntot) {
+            int ej = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (lane == j) { ej = nx.e[j]; xn = nx.xn[j]; sl = nx.slot[j]; }
+            av = p.alpha[ej];
+          }
+          if (nx.ndep > 0) {
+            int myrank = nx.dep[0];
+#pragma unroll
+            for (int j = 1; j < 4; ++j)
+              if (lane == j) myrank = nx.dep[j];
+            const bool watching = lane < nx.ndep;
+            int spins = 0;
+            bool ok = true;
+            for (;;) {
+              const int v = watching ? ld_sc1(p.done + myrank) : epoch;
+              if (!UNI(v < epoch)) break;
+              __builtin_amdgcn_s_sleep(1);
+              if (++spins > kSpinLimit || ((spins & 1023) == 0 && ld_sc1(p.abort_flag))) { ok = false; break; }
+            }
+            if (!ok && lane == 0) { st_sc1(p.abort_flag, 1); L.ctl[1] = 1; }
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (UPDATE && j >= nx.nout && j < ntot && nx.slot[j] < 0) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                if (okc[c]) mv[j][c] = ld_sc1(p.msg + (size_t)nx.e[j] * K + c * kWave + lane);
+            }
+          }
+          if (PRIMAL && lane < ntot && lane >= nx.nout && sl < 0) pxv = ld_sc1(p.x + xn);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (okc[c]) {
+              stn[c * kWave + lane] = dk[c];
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if (j < ntot) stn[kWS + j * kWS + c * kWave + lane] = mv[j][c];
+            }
+          }
+          if (lane < 8) { stn[kWS + 8 * kWS + lane] = av; stni[64 + lane] = pxv; }
+        }
+      } else if (wave == kWideCompute + 1) {
+        // ======================================================== storer: node pos - 1
+        if (pos - 1 >= p0) {
+          const NodeDesc pd = decode_desc(desc[(size_t)(pos - 1) * DW + lane]);
+          const double *scp = L.scal + ((pos + 1) & 1) * kScalDoubles;
+          if (UPDATE) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              if (j < pd.nout) {
+                for (int c = 0; c < C; ++c) {
+                  const int k = c * kWave + lane;
+                  if (k < K) st_sc1(p.msg + (size_t)pd.e[j] * K + k, hprev[j * kWS + k]);
+                }
+                if (BACKWARD && lane == 0) p.lbterms[pd.lbe[j]] = scp[j];
+              }
+            }
+            if (BACKWARD && lane == 0) p.lbterms[pd.lbn] = scp[8];
+          }
+          if (PRIMAL && lane == 0) {
+            st_sc1(p.x + pd.node, ((const int *)(scp + 10))[0]);
+            p.eterms[pd.rank] = scp[9];
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) st_sc1(p.done + pd.rank, epoch);
+        }
+      } else {
+        // ======================================================== primal of node pos
+        if (PRIMAL && have_node) {
+          const int *sti = (const int *)(st + kWStI);
+          const int f = __builtin_amdgcn_readfirstlane(sti[2]);
+          const int nout = f & 15, nin = (f >> 4) & 15, md = (f >> 16) & 255, ntot = nout + nin;
+          double bestv = inf, bestdb = 0;
+          int besti = 0x7fffffff;
+          for (int c = 0; c < C; ++c) {
+            const int k = c * kWave + lane;
+            if (k < K) {
+              const double pk = L.pos[k];
+              double db = st[k];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                if (j >= nout && j < ntot) {
+                  const int sl = __builtin_amdgcn_readfirstlane(sti[12 + j]);
+                  const int ks = sl >= 8 ? xprev2 : sl >= 0 ? xprev : __builtin_amdgcn_readfirstlane(sti[64 + j]);
+                  const double pks = L.pos[ks];
+                  const double d = ((md >> j) & 1) == 0 ? pks - pk : pk - pks;
+                  const double v = KERNEL == 1 ? fabs(d) : d * d;
+                  db += st[kWS + 8 * kWS + j] * (v < p.lambda ? v : p.lambda);
+                }
+              }
+              double di = db;
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if (j < nout) di += st[kWS + j * kWS + k];
+              if (di < bestv) { bestv = di; besti = k; bestdb = db; }  // ascending k per lane: first minimum
+            }
+          }
+          const int bi = wave_argmin_dpp(bestv, besti);
+          // the lane that owns label bi holds its DiBackward value
+          const int owner = bi & (kWave - 1);
+          const double eb = readlane_f64(bestdb, owner);
+          xprev2 = xprev; xprev = bi;
+          if (lane == 0) { sc[9] = eb; ((int *)(sc + 10))[0] = bi; }
+        }
+      }
+      if (p.prof) {
+        const long long now_ = (long long)__builtin_readcyclecounter();
+        if (wave == 0) { pacc[6] += (unsigned long long)(now_ - tmark); pvis += have_node ? 1 : 0; }
+        pbusy += (unsigned long long)(now_ - tvisit);
+        tmark = now_;
+      }
+      __syncthreads();
+      if (p.prof && wave == 0) pwait += (unsigned long long)((long long)__builtin_readcyclecounter() - tmark);
+      if (L.ctl[1]) {
+        if (tid == 0) st_sc1(p.abort_flag, 1);
+        return;
+      }
+    }
+  }
+#undef WSTAMP
+  if (p.prof && lane == 0) {
+    if (wave == 0) {
+      for (int i = 0; i < 7; ++i) atomicAdd(p.prof + i, pacc[i]);
+      atomicAdd(p.prof + 11, pwait);
+      atomicAdd(p.prof + 12, pvis);
+    }
+    if (wave >= kWideCompute) atomicAdd(p.prof + 8 + (wave - kWideCompute), pbusy);
+  }
+}
+
 // Ascending sort permutation of each K-vector (ties: lower index first), one
 // wave per vector, bitonic network in LDS.  Replaces the per-edge std::sort of
 // trws_mex.cpp:84-119 (which re-sorts after every push_back).
@@ -1187,6 +1667,9 @@ struct stereo_trws_plan {
   DevBuf<int8_t> d_in_slot[2];
   DevBuf<int32_t> d_desc[2];
   bool fast = false;
+  bool wide = false;  // 64 < K <= 256 with shared strictly ascending positions: trws_wide_kernel
+  bool wide_allowed = false;
+  int window = 0;
   DevBuf<unsigned long long> d_fallbacks, d_prof, d_timeline;
   bool certificate = true;
   int epoch = 0;
@@ -1243,6 +1726,7 @@ DevParams make_params(stereo_trws_plan *P) {
   p.timeline = P->d_timeline.p;
   p.desc[0] = P->d_desc[0].p; p.desc[1] = P->d_desc[1].p;
   p.prof_run = -1;
+  p.window = P->window;
   p.debug = 0;
   if (const char *dbg = std::getenv("STEREO_HIP_TRWS_DEBUG")) p.debug = std::atoi(dbg);
   if (const char *pr = std::getenv("STEREO_HIP_TRWS_PROF_RUN")) p.prof_run = std::atoi(pr);
@@ -1257,6 +1741,19 @@ void launch_persistent(stereo_trws_plan *P, const DevParams &p, int what, hipStr
   const int epoch = ++P->epoch;
   STEREO_HIP_CHECK(hipMemsetAsync(P->d_ctl.p, 0, sizeof(int32_t), s));  // ticket = 0
   const dim3 grid(P->grid_blocks), block(kBlock);
+  if (P->wide) {
+    const size_t wlds = sizeof(double) * kWideLdsDoubles;
+    const dim3 wgrid(std::min(P->grid_blocks, 256)), wblock(kWideThreads);
+    switch (what) {
+      case 0: hipLaunchKernelGGL((trws_wide_kernel<KERNEL, false, false, true>), wgrid, wblock, wlds, s, p, epoch); break;
+      case 1: hipLaunchKernelGGL((trws_wide_kernel<KERNEL, true, false, true>), wgrid, wblock, wlds, s, p, epoch); break;
+      case 2: hipLaunchKernelGGL((trws_wide_kernel<KERNEL, false, true, true>), wgrid, wblock, wlds, s, p, epoch); break;
+      default: hipLaunchKernelGGL((trws_wide_kernel<KERNEL, false, true, false>), wgrid, wblock, wlds, s, p, epoch); break;
+    }
+    STEREO_HIP_CHECK(hipGetLastError());
+    if (what != 3) P->sweep_launches += 1;
+    return;
+  }
   if (P->fast) {
     const size_t plds = sizeof(double) * (2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * 2 * kWave + 2);
     const bool sh = P->pos != nullptr;
@@ -1345,6 +1842,28 @@ void finish_inputs(stereo_trws_plan *P) {
     run_argsort(P->qprim, P->d_perm_qp.p, P->K, P->E, nullptr);
   }
   STEREO_HIP_CHECK(hipDeviceSynchronize());
+  // wide-label kernel: shared positions that are finite and strictly ascending
+  P->wide = false;
+  if (P->wide_allowed && P->pos && P->lambda >= 0) {
+    std::vector<double> hp(P->K);
+    STEREO_HIP_CHECK(hipMemcpy(hp.data(), P->pos, sizeof(double) * P->K, hipMemcpyDeviceToHost));
+    bool asc = std::isfinite(hp[0]);
+    for (int k = 1; k < P->K && asc; ++k) asc = std::isfinite(hp[k]) && hp[k] > hp[k - 1];
+    if (asc) {
+      // a source farther than lambda from a destination (squared distance for kernel 2)
+      // costs >= vTrunc, so min-plus only needs the sources within +-window indices
+      int w = 0;
+      for (int k = 0, lo = 0; k < P->K; ++k) {
+        for (;; ++lo) {
+          const double d = hp[k] - hp[lo];
+          if ((P->kernel == 1 ? d : d * d) <= P->lambda) break;
+        }
+        w = std::max(w, k - lo);
+      }
+      P->window = w;
+      P->wide = true;
+    }
+  }
   P->have_inputs = true;
 }
 
@@ -1407,13 +1926,17 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
       if (g.fast_ok) P->d_desc[d].upload(S.desc.data(), S.desc.size());
     }
     P->fast = g.fast_ok && K <= kWave && message_mode == STEREO_TRWS_MESSAGES_EXACT;
-    if (const char *f = std::getenv("STEREO_HIP_TRWS_FAST")) P->fast = P->fast && std::string(f) != "0";
+    P->wide_allowed = g.fast_ok && K > kWave && K <= 256 && message_mode == STEREO_TRWS_MESSAGES_EXACT;
+    if (const char *f = std::getenv("STEREO_HIP_TRWS_FAST")) {
+      P->fast = P->fast && std::string(f) != "0";
+      P->wide_allowed = P->wide_allowed && std::string(f) != "0";
+    }
     P->d_done.alloc(N);
     P->d_ctl.alloc(2);
     P->d_fallbacks.alloc(1);
     STEREO_HIP_CHECK(hipMemset(P->d_fallbacks.p, 0, sizeof(unsigned long long)));
     if (const char *c = std::getenv("STEREO_HIP_TRWS_CERTIFICATE")) P->certificate = std::string(c) != "0";
-    if (std::getenv("STEREO_HIP_TRWS_PROF")) { P->d_prof.alloc(8); STEREO_HIP_CHECK(hipMemset(P->d_prof.p, 0, 64)); }
+    if (std::getenv("STEREO_HIP_TRWS_PROF")) { P->d_prof.alloc(16); STEREO_HIP_CHECK(hipMemset(P->d_prof.p, 0, 128)); }
     if (std::getenv("STEREO_HIP_TRWS_TIMELINE")) P->d_timeline.alloc(4 * g.sweep[0].run_ptr.size());
     STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * N));
     STEREO_HIP_CHECK(hipMemset(P->d_ctl.p, 0, sizeof(int32_t) * 2));
@@ -1454,6 +1977,16 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
     SET_PLDS4(1, 0); SET_PLDS4(1, 1); SET_PLDS4(2, 0); SET_PLDS4(2, 1);
 #undef SET_PLDS4
 #undef SET_PLDS
+    if (P->wide_allowed) {
+      const int wlds = (int)(sizeof(double) * kWideLdsDoubles);
+#define SET_WLDS(KER)                                                                              \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_wide_kernel<KER, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wlds)); \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_wide_kernel<KER, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wlds));  \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_wide_kernel<KER, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wlds));  \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_wide_kernel<KER, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, wlds))
+      SET_WLDS(1); SET_WLDS(2);
+#undef SET_WLDS
+    }
     *plan = P.release();
     return 0;
   } catch (const HipError &e) {
@@ -1478,10 +2011,16 @@ void stereo_trws_plan_destroy(stereo_trws_plan *plan) {
     }
   }
   if (plan && plan->d_prof.p) {
-    unsigned long long v[8];
-    if (hipMemcpy(v, plan->d_prof.p, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess)
+    unsigned long long v[16];
+    if (hipMemcpy(v, plan->d_prof.p, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess) {
       std::fprintf(stderr, "[stereo_hip prof] cycles: p0 %llu p1 %llu p2 %llu p3 %llu p4 %llu | p5 %llu steps %llu\n",
                    v[0], v[1], v[2], v[3], v[4], v[5], v[6]);
+      if (plan->wide && v[12])
+        std::fprintf(stderr, "[stereo_hip prof wide] per visit: P1 %.0f b %.0f P2 %.0f b %.0f P3 %.0f b %.0f P4 %.0f | loader %.0f storer %.0f primal %.0f | hw barrier wait %.0f | visits %llu\n",
+                     (double)v[0] / v[12], (double)v[1] / v[12], (double)v[2] / v[12], (double)v[3] / v[12], (double)v[4] / v[12],
+                     (double)v[5] / v[12], (double)v[6] / v[12], (double)v[8] / v[12], (double)v[9] / v[12], (double)v[10] / v[12],
+                     (double)v[11] / v[12], v[12]);
+    }
   }
   delete plan;
 }
@@ -1645,6 +2184,12 @@ int stereo_trws_plan_counters(stereo_trws_plan *P, int64_t *serial_messages, int
   if (serial_messages) *serial_messages = (int64_t)v;
   if (reset && hipMemset(P->d_fallbacks.p, 0, sizeof(v)) != hipSuccess) return 1;
   return 0;
+}
+
+int stereo_trws_plan_path(stereo_trws_plan *P) {
+  if (!P) return -1;
+  if (!P->persistent) return 0;
+  return P->wide ? 3 : P->fast ? 2 : 1;
 }
 
 int stereo_trws(int kernel, const double *unary, const uint32_t *conn, const double *q,

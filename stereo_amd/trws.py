@@ -169,6 +169,10 @@ class TrwsPlan:
         _lib.check(rc, err)
         return dict(rank=rank, levels=lv.value, max_level_nodes=mx.value)
 
+    def path(self):
+        """0 levels, 1 generic persistent, 2 pipelined (K <= 64), 3 wide pipelined."""
+        return int(_lib.lib().stereo_trws_plan_path(self._h))
+
     def serial_messages(self, reset=False):
         n = C.c_int64()
         _lib.lib().stereo_trws_plan_counters(self._h, C.byref(n), C.c_int(int(reset)))
