@@ -61,6 +61,7 @@ struct DevParams {
   int32_t *x;
   // persistent dataflow sweeps
   const int32_t *run_ptr[2];
+  const int32_t *run_order[2];  // ticket -> run (nullptr: identity)
   int nruns[2];
   const int32_t *dep_ptr[2], *dep_rank[2];
   const int8_t *in_slot[2];
@@ -609,7 +610,7 @@ __global__ __launch_bounds__(kBlock) void trws_persistent_kernel(DevParams p, in
   const int8_t *in_slot = p.in_slot[D];
   const int N = p.N;
   for (;;) {
-    if (tid == 0) *s_run = atomicAdd(p.ticket, 1);
+    if (tid == 0) { const int t_ = atomicAdd(p.ticket, 1); *s_run = (p.run_order[BACKWARD ? 1 : 0] && t_ < p.nruns[BACKWARD ? 1 : 0]) ? p.run_order[BACKWARD ? 1 : 0][t_] : t_; }
     __syncthreads();
     const int run = *s_run;
     __syncthreads();
@@ -922,7 +923,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
   if ((p.debug & 4) && BACKWARD) p.prof = nullptr;   // profile forward sweeps only
 
   for (;;) {
-    if (tid == 0) ctl[0] = atomicAdd(p.ticket, 1);
+    if (tid == 0) { const int t_ = atomicAdd(p.ticket, 1); ctl[0] = (p.run_order[D] && t_ < p.nruns[D]) ? p.run_order[D][t_] : t_; }
     __syncthreads();
     const int run = __builtin_amdgcn_readfirstlane(ctl[0]);
     __syncthreads();
@@ -1133,111 +1134,145 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
 
 
 // ---- wide-label pipelined sweep: 64 < K <= 256, shared strictly ascending positions -------
-// The regime of the large grids (3000x2000x256): per message K^2 pair costs are too many, so
+// The regime of the large grids (3000x2000x256).  A lane holds four labels (k = c * 64 + lane).
+// Per message K^2 pair costs are too many, so
 //  * min-plus only looks at the sources inside the truncation window of each destination
 //    (a source farther than lambda costs >= vTrunc exactly, by monotone rounding);
 //  * the certificate's tangency test ("no two u = h - alpha q, nor two v = h + alpha q, within
-//    delta") is done by sorting u and v in LDS and looking at neighbours -- conservative (all
-//    pairs, not only those with a useful cone), O(K log^2 K) instead of O(K^2);
-//  * a message is spread over several waves: `chunks` waves for the windowed min-plus (lane =
-//    one of 64 destinations), one wave per sort.  12 compute waves synchronise among
-//    themselves with an LDS counter; loader / storer / primal waves as in trws_pipe_kernel
-//    meet them once per visit at the hardware barrier.
-// If the certificate fails (or kernel 2), one wave runs the reference's serial envelope
-// construction in LDS for that message.
+//    delta") is a closest-pair test by bucketing -- conservative (all pairs, not only those
+//    with a useful cone), O(K) instead of O(K^2).
+// Three compute waves per outgoing message, each forming Di and H = gamma Di - m itself (cheap,
+// and no barrier between them): wave 3j does the windowed min-plus, waves 3j+1 / 3j+2 the u / v
+// closest-pair tests and post their verdicts in LDS; wave 3j waits for the two verdicts,
+// normalises and hands over.  Loader / storer / primal waves as in trws_pipe_kernel; one
+// hardware barrier per visit.  Nodes with more than four outgoing messages take a second round
+// (message j + 4 on the same waves).  If the certificate fails, wave 3j runs the reference's
+// serial envelope construction in LDS (one at a time per workgroup: shared scratch, rare).
+// Kernel 1 (truncated linear) only; kernel 2 has no certificate and stays on the generic kernel.
 constexpr int kWideCompute = 12;
 constexpr int kWideWaves = kWideCompute + 3;
 constexpr int kWideThreads = kWideWaves * kWave;
-constexpr int kWS = 264;  // LDS row stride in doubles (>= 256 + 2, multiple of 8)
+constexpr int kWS = 260;    // LDS row stride in doubles (>= 256 + 1 breakpoints, multiple of 4)
+constexpr int kWPad = 16;   // min-plus source table is padded by this many (+inf, 0) entries on both sides
+constexpr int kWScr = 2 * (256 + 2 * kWPad);  // per compute wave scratch: (h, q) source table | 256 keys + 516 ints
+constexpr int kWBuckets = 512;
 constexpr int kWStI = kWS + 8 * kWS + 8;            // int area of a stage (in doubles)
 constexpr int kWStage = kWStI + 36;
 // stage: D[kWS] m[8][kWS] a[8] | ints desc[64] px[8]
 
 struct WidePtrs {
-  double *stage0, *hand, *Di, *H, *outb, *sortb, *pos, *part, *scal;
-  int *ipart, *ctl;
+  double *stage0, *hand, *scr, *fb, *pos, *scal;
+  int *dring, *flags, *ctl;
 };
 __device__ __forceinline__ WidePtrs wide_carve(double *lds) {
   WidePtrs w;
-  w.stage0 = lds;                       // 2 * kWStage
-  w.hand = w.stage0 + 2 * kWStage;      // 3 * 8 * kWS
-  w.Di = w.hand + 3 * 8 * kWS;          // kWS
-  w.H = w.Di + kWS;                     // 8 * kWS
-  w.outb = w.H + 8 * kWS;               // 8 * kWS
-  w.sortb = w.outb + 8 * kWS;           // 16 * kWS (u_j, v_j per message)
-  w.pos = w.sortb + 16 * kWS;           // kWS
-  w.part = w.pos + kWS;                 // 128: hmin[8][4] vmin[8][4] mag[8][4] dmin[4]
-  w.scal = w.part + 128;                // 2 * kScalDoubles
-  w.ipart = (int *)(w.scal + 2 * kScalDoubles);  // bad[8], barrier counter, ...
-  w.ctl = w.ipart + 16;
+  w.stage0 = lds;                            // 2 * kWStage
+  w.hand = w.stage0 + 2 * kWStage;           // 3 * 8 * kWS : new messages of the last three visits
+  w.scr = w.hand + 3 * 8 * kWS;              // kWideCompute * kWScr
+  w.fb = w.scr + kWideCompute * kWScr;       // 4 * kWS : sources, stack, breakpoints of the serial construction
+  w.pos = w.fb + 4 * kWS;                    // kWS
+  w.scal = w.pos + kWS;                      // 2 * kScalDoubles
+  w.dring = (int *)(w.scal + 2 * kScalDoubles);  // 3 * 64 descriptor words (for the storer)
+  w.flags = w.dring + 3 * 64;                // [8][2] verdicts of the closest-pair waves
+  w.ctl = w.flags + 16;                      // [0] run, [1] abort, [2] lock of the serial scratch
   return w;
 }
-constexpr int kWideLdsDoubles = 2 * kWStage + 3 * 8 * kWS + kWS + 8 * kWS * 2 + 16 * kWS + kWS + 128 + 2 * kScalDoubles + 16;
+constexpr int kWideLdsDoubles = 2 * kWStage + 3 * 8 * kWS + kWideCompute * kWScr + 4 * kWS + kWS + 2 * kScalDoubles + 96 + 8 + 2;
 static_assert(kWideLdsDoubles * 8 <= 160 * 1024, "wide kernel LDS");
 
-// software barrier among the compute waves (monotone LDS counter)
-__device__ __forceinline__ void compute_barrier(int *counter, int &phase, int lane, int *abort_word) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  ++phase;
-  if (lane == 0) {
-    __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    int spins = 0;
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < phase * kWideCompute) {
-      __builtin_amdgcn_s_sleep(0);
-      if (++spins > kSpinLimit) { *abort_word = 1; break; }  // bounded: never hang the device
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// inclusive prefix sum over the wave (Hillis-Steele inside rows of 16, then row broadcasts)
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+  return v;
 }
 
-// Bitonic sort of 64 * R keys held in registers by one wave: key i = c * 64 + lane lives in
-// r[c] of `lane`.  Exchanges across >= 64 positions are register-to-register, the others lane
-// shuffles.  Keys only (the certificate needs the gaps, not the permutation).
-template <int R>
-__device__ __forceinline__ void wave_sort_regs(double (&r)[R], int lane) {
+// True if two of the first K keys (key i = c * 64 + lane lives in r[c] of `lane`) are within
+// delta of each other.  mn <= every key <= mn + span.  One wave, no sort: counting sort into
+// 512 equal-width buckets (LDS counters), then every key is compared with the rest of its
+// bucket and the whole next bucket.  Buckets are wider than 2 delta, so keys two or more
+// buckets apart cannot be near.  Conservative `true` on degenerate key distributions.
+// scr: 256 doubles + 516 ints.
+__device__ __forceinline__ bool keys_within(const double (&r)[4], int K, int C, double delta, double mn,
+                                            double span, double *scr, int lane) {
+  const double inf = __builtin_huge_val();
+  double *sorted = scr;
+  int *cnt = (int *)(scr + 256);  // counters, afterwards start[0 .. kWBuckets + 1]
+  if (!(span > (2.0 * kWBuckets) * delta) || !(span < inf)) return true;
+  const double scale = (double)kWBuckets / span;
+  ((int4 *)cnt)[2 * lane] = make_int4(0, 0, 0, 0);
+  ((int4 *)cnt)[2 * lane + 1] = make_int4(0, 0, 0, 0);
+  WSYNC();
+  int b[4], rank[4];
 #pragma unroll
-  for (int size = 2; size <= 64 * R; size <<= 1) {
-#pragma unroll
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      if (stride >= 64) {
-        const int m = stride >> 6;
-#pragma unroll
-        for (int c = 0; c < R; ++c) {
-          if ((c & m) == 0) {
-            const bool up = ((c * 64) & size) == 0;
-            const double a = r[c], b = r[c | m];
-            const double lo = fmin(a, b), hi = fmax(a, b);
-            r[c] = up ? lo : hi;
-            r[c | m] = up ? hi : lo;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < R; ++c) {
-          const double o = __shfl_xor(r[c], stride, kWave);
-          const bool up = (((c * 64) | lane) & size) == 0;
-          const bool keep_min = ((lane & stride) == 0) == up;
-          r[c] = keep_min ? fmin(r[c], o) : fmax(r[c], o);
-        }
-      }
+  for (int c = 0; c < 4; ++c) {
+    b[c] = 0; rank[c] = 0;
+    if (c < C && c * kWave + lane < K) {
+      const int bb = (int)((r[c] - mn) * scale);
+      b[c] = bb > kWBuckets - 1 ? kWBuckets - 1 : bb < 0 ? 0 : bb;
+      rank[c] = __hip_atomic_fetch_add(cnt + b[c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
   }
-}
-
-// true if two neighbours of the sorted keys (first K of them) are within delta
-template <int R>
-__device__ __forceinline__ bool sorted_gap_within(const double (&r)[R], int K, double delta, int lane) {
+  WSYNC();
+  const int4 c0 = ((int4 *)cnt)[2 * lane], c1 = ((int4 *)cnt)[2 * lane + 1];  // buckets 8 lane .. 8 lane + 7
+  const int tot = c0.x + c0.y + c0.z + c0.w + c1.x + c1.y + c1.z + c1.w;
+  const int incl = wave_incl_scan_i32(tot);
+  int e = incl - tot;
+  int4 s0, s1;
+  s0.x = e; e += c0.x; s0.y = e; e += c0.y; s0.z = e; e += c0.z; s0.w = e; e += c0.w;
+  s1.x = e; e += c1.x; s1.y = e; e += c1.y; s1.z = e; e += c1.z; s1.w = e;
+  ((int4 *)cnt)[2 * lane] = s0;
+  ((int4 *)cnt)[2 * lane + 1] = s1;
+  if (lane == kWave - 1) { cnt[kWBuckets] = incl; cnt[kWBuckets + 1] = incl; }
+  WSYNC();
+  int st4[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) st4[c] = cnt[b[c]];  // unconditional: one LDS round trip for all four
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (c < C && c * kWave + lane < K) sorted[st4[c] + rank[c]] = r[c];
+  WSYNC();
+  double u[4];
+  int len[4], bq[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) u[c] = sorted[c * kWave + lane];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int bb = (c < C && c * kWave + lane < K) ? (int)((u[c] - mn) * scale) : 0;
+    bq[c] = bb > kWBuckets - 1 ? kWBuckets - 1 : bb < 0 ? 0 : bb;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) len[c] = cnt[bq[c] + 2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int q = c * kWave + lane;
+    len[c] = (c < C && q < K) ? len[c] - q : 0;  // keys q+1 .. q+len-1 share the bucket or the next one
+  }
   bool bad = false;
+  for (int i = 1;; ++i) {
+    bool any = false;
+    double o[4];
 #pragma unroll
-  for (int c = 0; c < R; ++c) {
-    double nxt = __shfl_down(r[c], 1, kWave);
-    if (c + 1 < R) { const double first = readlane_f64(r[c + 1], 0); nxt = lane == kWave - 1 ? first : nxt; }
-    const int i = c * 64 + lane;
-    const bool have = i + 1 < K && (c + 1 < R || lane < kWave - 1);
-    bad = bad || (have && !(nxt - r[c] > delta));
+    for (int c = 0; c < 4; ++c) {  // unconditional reads first: one LDS round trip per step
+      const int q = c * kWave + lane + i;
+      o[c] = sorted[q < 256 ? q : 255];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool on = i < len[c];
+      any = any || on;
+      bad = bad || (on && !(fabs(o[c] - u[c]) > delta));
+    }
+    if (!UNI(any)) break;
+    if (i >= 24) { bad = true; break; }  // crowded buckets: give up, serial path decides
   }
-  return bad;
+  return UNI(bad);
 }
 
 template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE>
@@ -1253,16 +1288,25 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
   constexpr int DW = TrwsGraph::kDescWords;
   const int32_t *desc = p.desc[D];
   for (int k = tid; k < kWS; k += kWideThreads) L.pos[k] = k < K ? p.pos[k] : inf;
-  if (tid == 0) { L.ctl[1] = 0; L.ipart[8] = 0; }
-  int cphase = 0;  // compute-barrier phase counter (compute waves only)
-  // development profile (STEREO_HIP_TRWS_PROF): cycles of wave 0 per phase [0..7], busy cycles of
-  // loader / storer / primal [8..10], hardware-barrier wait of wave 0 [11], visits [12]
-  unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pbusy = 0, pwait = 0, pvis = 0;
+  if (wave < kWideCompute && wave % 3 == 0 && lane < 2 * kWPad) {
+    // padding of the min-plus source tables, never overwritten afterwards
+    double2 *tab = (double2 *)(L.scr + wave * kWScr);
+    tab[lane < kWPad ? lane : K + lane] = make_double2(inf, 0.0);
+  }
+  if (tid < 16) L.flags[tid] = -1;
+  if (tid == 0) { L.ctl[1] = 0; L.ctl[2] = 0; }
+  double posr[4];  // this lane's four label positions
+#pragma unroll
+  for (int c = 0; c < 4; ++c) posr[c] = c * kWave + lane < K ? p.pos[c * kWave + lane] : inf;
+  const double pos_first = p.pos[0], pos_last = p.pos[K - 1];
+  // development profile (STEREO_HIP_TRWS_PROF): cycles of wave 0 per phase [0..15], busy cycles of
+  // loader / storer / primal [16..18], hardware-barrier wait of wave 0 [19], visits [20]
+  unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pbusy = 0, pwait = 0, pvis = 0;
 #define WSTAMP(i) do { if (p.prof) { const long long now_ = (long long)__builtin_readcyclecounter(); pacc[i] += (unsigned long long)(now_ - tmark); tmark = now_; } } while (0)
   __syncthreads();
 
   for (;;) {
-    if (tid == 0) L.ctl[0] = atomicAdd(p.ticket, 1);
+    if (tid == 0) { const int t_ = atomicAdd(p.ticket, 1); L.ctl[0] = (p.run_order[D] && t_ < p.nruns[D]) ? p.run_order[D][t_] : t_; }
     __syncthreads();
     const int run = __builtin_amdgcn_readfirstlane(L.ctl[0]);
     __syncthreads();
@@ -1271,6 +1315,7 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
     int xprev = 0, xprev2 = 0;
     int wnext = 0;
     if (wave == kWideCompute) wnext = desc[(size_t)p0 * DW + lane];
+    if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2] = wall_clock64();
 
     for (int pos = p0 - 1; pos <= p1; ++pos) {
       double *st = L.stage0 + (pos & 1) * kWStage;
@@ -1284,171 +1329,203 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
 
       if (wave < kWideCompute) {
         // ======================================================== compute waves
+        const int j0 = wave / 3, role = wave - 3 * j0;  // role 0: min-plus, 1: u test, 2: v test
         if (UPDATE && have_node) {
           const int *sti = (const int *)(st + kWStI);
           const int f = __builtin_amdgcn_readfirstlane(sti[2]);
           const int nout = f & 15, nin = (f >> 4) & 15, ntot = nout + nin;
-          const unsigned slA = (unsigned)__builtin_amdgcn_readfirstlane(sti[41]);
-          const unsigned slB = (unsigned)__builtin_amdgcn_readfirstlane(sti[42]);
-          // ---- P1: Di = D + messages in list order, one chunk per wave
-          if (wave < C) {
-            const int k = wave * kWave + lane;
-            double di = inf;
-            if (k < K) {
-              di = st[k];
+          const bool fast_msg = KERNEL == 1 && p.certificate != 0;
+          const bool working = j0 < nout && (role == 0 || fast_msg);
+          if (working || (BACKWARD && wave == 0)) {
+            const unsigned slA = (unsigned)__builtin_amdgcn_readfirstlane(sti[41]);
+            const unsigned slB = (unsigned)__builtin_amdgcn_readfirstlane(sti[42]);
+            // Di = D + messages in list order (from the ring where the neighbour was one of
+            // the last two visits of this run); every working wave forms it itself
+            // (reads are unconditional -- rows are padded to 256 -- and masked afterwards, so that
+            // all of them are in flight together)
+            double di[4];
+            bool valid[4];
 #pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                if (j < ntot) {
-                  const int sl = j >= nout ? (int)(signed char)(((j < 4 ? slA : slB) >> (8 * (j & 3))) & 255) : -1;
-                  di += sl >= 8 ? hprev2[(sl - 8) * kWS + k] : sl >= 0 ? hprev[sl * kWS + k] : st[kWS + j * kWS + k];
-                }
+            for (int c = 0; c < 4; ++c) { valid[c] = c * kWave + lane < K; di[c] = st[c * kWave + lane]; }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+              if (jj < ntot) {
+                const int sl = jj >= nout ? (int)(signed char)(((jj < 4 ? slA : slB) >> (8 * (jj & 3))) & 255) : -1;
+                const double *src = sl >= 8 ? hprev2 + (sl - 8) * kWS : sl >= 0 ? hprev + sl * kWS : st + kWS + jj * kWS;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) di[c] += src[c * kWave + lane];
               }
-              L.Di[k] = di;
             }
-            if (BACKWARD) {
-              const double m = wave_min_dpp(di);
-              if (lane == 0) L.part[96 + wave] = m;
-            }
-          }
-          WSTAMP(0);
-          compute_barrier(L.ipart + 8, cphase, lane, L.ctl + 1);
-          WSTAMP(1);
-          // ---- P2: H_j = gamma * Di - m_j for every outgoing edge, partial minima
-          double node_vmin = 0;
-          if (BACKWARD) {
-            node_vmin = L.part[96];
-            for (int c = 1; c < C; ++c) { const double o = L.part[96 + c]; node_vmin = o < node_vmin ? o : node_vmin; }
-            if (tid == 0) sc[8] = node_vmin;
-          }
-          const double gamma = (double)1 / (double)(nout > nin ? nout : nin);
-          for (int t = wave; t < nout * 4; t += kWideCompute) {
-            const int j = t >> 2, c = t & 3, k = c * kWave + lane;
-            if (c >= C) continue;
-            double h = inf, mg = 0;
-            if (k < K) {
-              const double di = BACKWARD ? L.Di[k] - node_vmin : L.Di[k];
-              h = gamma * di - st[kWS + j * kWS + k];
-              L.H[j * kWS + k] = h;
-              const double aq = st[kWS + 8 * kWS + j] * L.pos[k];
-              mg = fabs(h) + 2 * fabs(aq);
-            }
-            const double hm = wave_min_dpp(h), mm = wave_max_dpp(mg);
-            if (lane == 0) { L.part[j * 4 + c] = hm; L.part[64 + j * 4 + c] = mm; }
-          }
-          if (wave < 8 && lane == 0) L.ipart[wave] = 0;  // bad flags
-          WSTAMP(2);
-          compute_barrier(L.ipart + 8, cphase, lane, L.ctl + 1);
-          WSTAMP(3);
-          // ---- P3: per message two sorts (certificate) and `C` windowed min-plus tasks
-          const int T = (KERNEL == 1 && p.certificate) ? 6 * nout : 0;
-          for (int tt = wave; tt < T; tt += kWideCompute) {
-            const bool is_sort = tt < 2 * nout;
-            const int j = is_sort ? tt >> 1 : (tt - 2 * nout) >> 2;
-            if (!is_sort && ((tt - 2 * nout) & 3) >= C) continue;
-            const double alpha = st[kWS + 8 * kWS + j];
-            double hmin = L.part[j * 4], mag = L.part[64 + j * 4];
-            for (int c = 1; c < C; ++c) {
-              const double a = L.part[j * 4 + c], b = L.part[64 + j * 4 + c];
-              hmin = a < hmin ? a : hmin; mag = b > mag ? b : mag;
-            }
-            const double vtrunc = hmin + alpha * p.lambda;
-            const double delta = 1e-9 * (mag + fabs(alpha * p.lambda));
-            if (UNI(alpha == 0)) continue;  // constant message, handled in P4
-            if (is_sort) {
-              if (p.debug & 16) continue;
-              const double sgn = (tt & 1) ? 1.0 : -1.0;
-              bool bad = !(delta < inf);
-              if (K <= 128) {
-                double r[2];
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                  const int k = c * kWave + lane;
-                  r[c] = k < K ? L.H[j * kWS + k] + sgn * (alpha * L.pos[k]) : inf;
+            for (int c = 0; c < 4; ++c) di[c] = valid[c] ? di[c] : inf;
+            if (BACKWARD) {
+              const double dm = fmin(fmin(di[0], di[1]), fmin(di[2], di[3]));
+              const double node_vmin = wave_min_dpp(dm);
+              if (wave == 0 && lane == 0) sc[8] = node_vmin;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) di[c] -= node_vmin;
+            }
+            WSTAMP(0);
+            for (int j = j0; working && j < nout; j += 4) {
+              const double gamma = (double)1 / (double)(nout > nin ? nout : nin);
+              const double alpha = st[kWS + 8 * kWS + j];
+              double h[4], hlo = inf, hhi = -inf;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) h[c] = gamma * di[c] - st[kWS + j * kWS + c * kWave + lane];
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                hlo = fmin(hlo, valid[c] ? h[c] : inf); hhi = fmax(hhi, valid[c] ? h[c] : -inf);
+                h[c] = valid[c] ? h[c] : inf;
+              }
+              const double hmin = wave_min_dpp(hlo), hmax = wave_max_dpp(hhi);
+              const double vtrunc = hmin + alpha * p.lambda;
+              const double ap0 = alpha * pos_first, ap1 = alpha * pos_last;
+              const double aplo = fmin(ap0, ap1), aphi = fmax(ap0, ap1);
+              const double mag = fmax(fabs(hmin), fabs(hmax)) + 2 * fmax(fabs(ap0), fabs(ap1));
+              const double delta = 1e-9 * (mag + fabs(alpha * p.lambda));
+              const bool constant = UNI(alpha == 0);
+              double *scr = L.scr + wave * kWScr;
+              WSTAMP(1);
+              if (role != 0) {
+                // ---- tangency: no two u = h - alpha q (role 1) / v = h + alpha q (role 2) within delta
+                if (!constant) {
+                  const double sgn = role == 2 ? 1.0 : -1.0;
+                  double r[4];
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) r[c] = h[c] + sgn * (alpha * posr[c]);
+                  const double mn = role == 2 ? hmin + aplo : hmin - aphi;
+                  const double mx = role == 2 ? hmax + aphi : hmax - aplo;
+                  bool bad = !(delta < inf) || (p.debug & 16);
+                  if (!bad) bad = keys_within(r, K, C, delta, mn, mx - mn, scr, lane);
+                  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                  if (lane == 0)
+                    __hip_atomic_store(L.flags + 2 * j + (role - 1), (pos << 1) | (bad ? 1 : 0), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                wave_sort_regs<2>(r, lane);
-                bad = bad || sorted_gap_within<2>(r, K, delta, lane);
+                WSTAMP(2);
               } else {
-                double r[4];
+                double out[4] = {0, 0, 0, 0}, vmin = 0;
+                if (constant) {
+                  // typeStereoLinear.h:390-396: message = min H everywhere, normalised to zero
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) out[c] = hmin;
+                  vmin = hmin;
+                } else {
+                  // source table: (h, q) pairs at index kWPad + k, (+inf, 0) padding on both sides
+                  double2 *tab = (double2 *)scr + kWPad;
+#pragma unroll
+                  for (int c = 0; c < 4; ++c)
+                    if (valid[c]) tab[c * kWave + lane] = make_double2(h[c], posr[c]);
+                  WSYNC();
+                  bool serial = !fast_msg;
+                  if (fast_msg) {
+                    // ---- windowed min-plus: smallest and second smallest cost per destination
+                    // (equal costs from two sources count as a zero margin: serial path decides)
+                    double m1[4] = {inf, inf, inf, inf}, m2[4] = {inf, inf, inf, inf};
+                    const int w = (p.debug & 32) ? 0 : p.window;
+                    if (w <= kWPad) {
+                      for (int d = -w; d <= w; ++d) {
+                        double2 sv[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) sv[c] = tab[c * kWave + lane + d];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                          const double cst = pair_cost<1>(alpha, posr[c] - sv[c].y, sv[c].x);
+                          const double lo_ = fmin(m1[c], cst), hi_ = fmax(m1[c], cst);
+                          m2[c] = fmin(m2[c], hi_);
+                          m1[c] = lo_;
+                        }
+                      }
+                    } else {
+                      for (int d = -w; d <= w; ++d) {
+                        double2 sv[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                          const int i = c * kWave + lane + d;
+                          sv[c] = tab[i < 0 ? 0 : i > K - 1 ? K - 1 : i];
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                          const int i = c * kWave + lane + d;
+                          double cst = pair_cost<1>(alpha, posr[c] - sv[c].y, sv[c].x);
+                          cst = (i >= 0 && i < K) ? cst : inf;
+                          const double lo_ = fmin(m1[c], cst), hi_ = fmax(m1[c], cst);
+                          m2[c] = fmin(m2[c], hi_);
+                          m1[c] = lo_;
+                        }
+                      }
+                    }
+                    bool bad = false;
+                    double vloc = inf;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                      if (valid[c]) {
+                        bad = bad || (m1[c] < vtrunc && !(m2[c] - m1[c] > delta && vtrunc - m1[c] > delta));
+                        out[c] = m1[c] < vtrunc ? m1[c] : vtrunc;
+                        vloc = fmin(vloc, out[c]);
+                      }
+                    }
+                    vmin = wave_min_dpp(vloc);
+                    serial = UNI(bad);
+                    WSTAMP(3);
+                    // the verdicts of the two closest-pair waves of this message
+                    {
+                      int spins = 0;
+                      for (;;) {
+                        const int v = lane < 2 ? __hip_atomic_load(L.flags + 2 * j + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : (pos << 1);
+                        const bool ready = (v >> 1) == pos;
+                        if (!UNI(!ready)) { serial = serial || UNI((v & 1) != 0); break; }
+                        __builtin_amdgcn_s_sleep(0);
+                        if (++spins > kSpinLimit) { if (lane == 0) L.ctl[1] = 1; break; }  // bounded
+                      }
+                      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
+                    WSTAMP(4);
+                  }
+                  if (serial) {
+                    // the reference's serial construction in LDS; the stack lives in a scratch
+                    // shared by the workgroup (rare path): take its lock
+                    if (lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
+                    if (lane == 0) {
+                      int spins = 0;
+                      while (__hip_atomic_exchange(L.ctl + 2, 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > kSpinLimit) { L.ctl[1] = 1; break; }
+                      }
+                    }
+                    WSYNC();
+                    double *sh = L.fb, *sq = L.fb + kWS, *z = L.fb + 2 * kWS, *Hs = L.fb + 3 * kWS;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                      if (valid[c]) Hs[c * kWave + lane] = h[c];
+                    WSYNC();
+                    if (lane == 0) build_envelope<KERNEL>(K, alpha, Hs, L.pos, sh, sq, z);
+                    WSYNC();
+                    double vloc = inf;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                      const int k = c * kWave + lane;
+                      if (c < C && k < K) {
+                        int jj = 0;
+                        while (z[jj + 1] < posr[c]) ++jj;
+                        const double cst = pair_cost<KERNEL>(alpha, posr[c] - sq[jj], sh[jj]);
+                        out[c] = cst < vtrunc ? cst : vtrunc;
+                        vloc = fmin(vloc, out[c]);
+                      }
+                    }
+                    WSYNC();
+                    if (lane == 0) __hip_atomic_store(L.ctl + 2, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    vmin = wave_min_dpp(vloc);
+                  }
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                   const int k = c * kWave + lane;
-                  r[c] = k < K ? L.H[j * kWS + k] + sgn * (alpha * L.pos[k]) : inf;
+                  if (c < C && k < K) hcur[j * kWS + k] = out[c] - vmin;
                 }
-                wave_sort_regs<4>(r, lane);
-                bad = bad || sorted_gap_within<4>(r, K, delta, lane);
+                if (BACKWARD && lane == 0) sc[j] = vmin;
+                WSTAMP(5);
               }
-              if (UNI(bad) && lane == 0) L.ipart[j] = 1;
-            } else {
-              const int c = (tt - 2 * nout) & 3, k = c * kWave + lane;
-              double m1 = inf, m2 = inf, out = vtrunc;
-              bool bad = false;
-              if (k < K) {
-                const double tk = L.pos[k];
-                const int lo = k - p.window > 0 ? k - p.window : 0, hi = k + p.window < K - 1 ? k + p.window : K - 1;
-                for (int i = lo; i <= ((p.debug & 32) ? lo : hi); ++i) {
-                  const double cst = pair_cost<1>(alpha, tk - L.pos[i], L.H[j * kWS + i]);
-                  const double lo_ = fmin(m1, cst), hi_ = fmax(m1, cst);
-                  m2 = hi_ > lo_ ? fmin(m2, hi_) : m2;
-                  m1 = lo_;
-                }
-                bad = m1 < vtrunc && !(m2 - m1 > delta && vtrunc - m1 > delta);
-                out = m1 < vtrunc ? m1 : vtrunc;
-                L.outb[j * kWS + k] = out;
-              }
-              const double vm = wave_min_dpp(k < K ? out : inf);
-              if (lane == 0) L.part[32 + j * 4 + c] = vm;
-              if (UNI(bad) && lane == 0) L.ipart[j] = 1;
-            }
-          }
-          WSTAMP(4);
-          compute_barrier(L.ipart + 8, cphase, lane, L.ctl + 1);
-          WSTAMP(5);
-          // ---- P4: normalise and hand over; serial envelope where the certificate failed
-          for (int t = wave; t < nout * 4; t += kWideCompute) {
-            const int j = t >> 2, c = t & 3, k = c * kWave + lane;
-            if (c >= C) continue;
-            const double alpha = st[kWS + 8 * kWS + j];
-            double hmin = L.part[j * 4];
-            for (int cc = 1; cc < C; ++cc) { const double a = L.part[j * 4 + cc]; hmin = a < hmin ? a : hmin; }
-            const bool constant = alpha == 0;
-            const bool serial = !constant && (KERNEL != 1 || !p.certificate || L.ipart[j] != 0);
-            if (constant) {
-              // typeStereoLinear.h:390-396: message = min H everywhere, normalised to zero
-              if (k < K) hcur[j * kWS + k] = hmin - hmin;
-              if (BACKWARD && c == 0 && lane == 0) sc[j] = hmin;
-            } else if (!serial) {
-              double vmin = L.part[32 + j * 4];
-              for (int cc = 1; cc < C; ++cc) { const double a = L.part[32 + j * 4 + cc]; vmin = a < vmin ? a : vmin; }
-              if (k < K) hcur[j * kWS + k] = L.outb[j * kWS + k] - vmin;
-              if (BACKWARD && c == 0 && lane == 0) sc[j] = vmin;
-            } else if (c == 0) {
-              // one wave, whole message: the reference's serial construction in LDS
-              if (lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
-              const double vtrunc = hmin + alpha * p.lambda;
-              double *sh = L.sortb + (2 * j) * kWS, *sq = L.sortb + (2 * j + 1) * kWS, *z = L.outb + j * kWS;
-              if (lane == 0) build_envelope<KERNEL>(K, alpha, L.H + j * kWS, L.pos, sh, sq, z);
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-              __builtin_amdgcn_wave_barrier();
-              double vloc = inf, ov[4] = {0, 0, 0, 0};
-#pragma unroll
-              for (int cc = 0; cc < 4; ++cc) {
-                const int kk = cc * kWave + lane;
-                if (cc < C && kk < K) {
-                  const double tk = L.pos[kk];
-                  int jj = 0;
-                  while (z[jj + 1] < tk) ++jj;
-                  const double cst = pair_cost<KERNEL>(alpha, tk - sq[jj], sh[jj]);
-                  ov[cc] = cst < vtrunc ? cst : vtrunc;
-                  vloc = ov[cc] < vloc ? ov[cc] : vloc;
-                }
-              }
-              const double vmin = wave_min_dpp(vloc);
-#pragma unroll
-              for (int cc = 0; cc < 4; ++cc) {
-                const int kk = cc * kWave + lane;
-                if (cc < C && kk < K) hcur[j * kWS + kk] = ov[cc] - vmin;
-              }
-              if (BACKWARD && lane == 0) sc[j] = vmin;
             }
           }
         }
@@ -1460,6 +1537,7 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
           const NodeDesc nx = decode_desc(w);
           int *stni = (int *)(stn + kWStI);
           stni[lane] = w;
+          L.dring[((pos + 1) % 3) * 64 + lane] = w;
           const int ntot = nx.nout + nx.nin;
           // all requests go out before anything is consumed (registers first, LDS at the end)
           double dk[4], mv[8][4];
@@ -1525,15 +1603,16 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
       } else if (wave == kWideCompute + 1) {
         // ======================================================== storer: node pos - 1
         if (pos - 1 >= p0) {
-          const NodeDesc pd = decode_desc(desc[(size_t)(pos - 1) * DW + lane]);
+          const NodeDesc pd = decode_desc(L.dring[((pos - 1) % 3) * 64 + lane]);
           const double *scp = L.scal + ((pos + 1) & 1) * kScalDoubles;
           if (UPDATE) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               if (j < pd.nout) {
-                for (int c = 0; c < C; ++c) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
                   const int k = c * kWave + lane;
-                  if (k < K) st_sc1(p.msg + (size_t)pd.e[j] * K + k, hprev[j * kWS + k]);
+                  if (c < C && k < K) st_sc1(p.msg + (size_t)pd.e[j] * K + k, hprev[j * kWS + k]);
                 }
                 if (BACKWARD && lane == 0) p.lbterms[pd.lbe[j]] = scp[j];
               }
@@ -1553,42 +1632,57 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
           const int *sti = (const int *)(st + kWStI);
           const int f = __builtin_amdgcn_readfirstlane(sti[2]);
           const int nout = f & 15, nin = (f >> 4) & 15, md = (f >> 16) & 255, ntot = nout + nin;
-          double bestv = inf, bestdb = 0;
-          int besti = 0x7fffffff;
-          for (int c = 0; c < C; ++c) {
-            const int k = c * kWave + lane;
-            if (k < K) {
-              const double pk = L.pos[k];
-              double db = st[k];
+          double db[4], di[4];
 #pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                if (j >= nout && j < ntot) {
-                  const int sl = __builtin_amdgcn_readfirstlane(sti[12 + j]);
-                  const int ks = sl >= 8 ? xprev2 : sl >= 0 ? xprev : __builtin_amdgcn_readfirstlane(sti[64 + j]);
-                  const double pks = L.pos[ks];
-                  const double d = ((md >> j) & 1) == 0 ? pks - pk : pk - pks;
+          for (int c = 0; c < 4; ++c) {
+            const int k = c * kWave + lane;
+            db[c] = (c < C && k < K) ? st[k] : inf;
+          }
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            if (jj >= nout && jj < ntot) {
+              const int sl = __builtin_amdgcn_readfirstlane(sti[12 + jj]);
+              const int ks = sl >= 8 ? xprev2 : sl >= 0 ? xprev : __builtin_amdgcn_readfirstlane(sti[64 + jj]);
+              const double pks = L.pos[ks], aj = st[kWS + 8 * kWS + jj];
+              const bool fwd = ((md >> jj) & 1) == 0;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                if (c < C) {
+                  const double d = fwd ? pks - posr[c] : posr[c] - pks;
                   const double v = KERNEL == 1 ? fabs(d) : d * d;
-                  db += st[kWS + 8 * kWS + j] * (v < p.lambda ? v : p.lambda);
+                  db[c] += aj * (v < p.lambda ? v : p.lambda);
                 }
               }
-              double di = db;
-#pragma unroll
-              for (int j = 0; j < 8; ++j)
-                if (j < nout) di += st[kWS + j * kWS + k];
-              if (di < bestv) { bestv = di; besti = k; bestdb = db; }  // ascending k per lane: first minimum
             }
           }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) di[c] = db[c];
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            if (jj < nout) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const int k = c * kWave + lane;
+                if (c < C && k < K) di[c] += st[kWS + jj * kWS + k];
+              }
+            }
+          }
+          double bestv = inf, bestdb = 0;
+          int besti = 0x7fffffff;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {  // ascending k per lane: strict '<' keeps the first minimum
+            const int k = c * kWave + lane;
+            if (c < C && k < K && di[c] < bestv) { bestv = di[c]; besti = k; bestdb = db[c]; }
+          }
           const int bi = wave_argmin_dpp(bestv, besti);
-          // the lane that owns label bi holds its DiBackward value
-          const int owner = bi & (kWave - 1);
-          const double eb = readlane_f64(bestdb, owner);
+          const double eb = readlane_f64(bestdb, bi & (kWave - 1));  // the lane owning label bi
           xprev2 = xprev; xprev = bi;
           if (lane == 0) { sc[9] = eb; ((int *)(sc + 10))[0] = bi; }
         }
       }
       if (p.prof) {
         const long long now_ = (long long)__builtin_readcyclecounter();
-        if (wave == 0) { pacc[6] += (unsigned long long)(now_ - tmark); pvis += have_node ? 1 : 0; }
+        if (wave == 0) pvis += have_node ? 1 : 0;
         pbusy += (unsigned long long)(now_ - tvisit);
         tmark = now_;
       }
@@ -1599,17 +1693,20 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
         return;
       }
     }
+    if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2 + 1] = wall_clock64();
   }
 #undef WSTAMP
   if (p.prof && lane == 0) {
     if (wave == 0) {
-      for (int i = 0; i < 7; ++i) atomicAdd(p.prof + i, pacc[i]);
-      atomicAdd(p.prof + 11, pwait);
-      atomicAdd(p.prof + 12, pvis);
+      for (int i = 0; i < 16; ++i) atomicAdd(p.prof + i, pacc[i]);
+      atomicAdd(p.prof + 19, pwait);
+      atomicAdd(p.prof + 20, pvis);
     }
-    if (wave >= kWideCompute) atomicAdd(p.prof + 8 + (wave - kWideCompute), pbusy);
+    if (wave >= kWideCompute) atomicAdd(p.prof + 16 + (wave - kWideCompute), pbusy);
+    if (wave == 1) for (int i = 0; i < 3; ++i) atomicAdd(p.prof + 8 + i, pacc[i]);  // a closest-pair wave
   }
 }
+#undef WSYNC
 
 // Ascending sort permutation of each K-vector (ties: lower index first), one
 // wave per vector, bitonic network in LDS.  Replaces the per-edge std::sort of
@@ -1663,6 +1760,7 @@ struct stereo_trws_plan {
   DevBuf<uint8_t> d_mdir;
   DevBuf<double> d_gamma, d_msg, d_lbterms, d_eterms;
   // persistent sweep schedule
+  DevBuf<int32_t> d_run_order[2];
   DevBuf<int32_t> d_run_ptr[2], d_dep_ptr[2], d_dep_rank[2], d_done, d_ctl;  // d_ctl: [ticket, abort]
   DevBuf<int8_t> d_in_slot[2];
   DevBuf<int32_t> d_desc[2];
@@ -1717,6 +1815,7 @@ DevParams make_params(stereo_trws_plan *P) {
   p.lbterms = P->d_lbterms.p; p.eterms = P->d_eterms.p; p.x = P->d_x.p;
   for (int d = 0; d < 2; ++d) {
     p.run_ptr[d] = P->d_run_ptr[d].p; p.nruns[d] = (int)P->g.sweep[d].run_ptr.size() - 1;
+    p.run_order[d] = P->d_run_order[d].p;
     p.dep_ptr[d] = P->d_dep_ptr[d].p; p.dep_rank[d] = P->d_dep_rank[d].p;
     p.in_slot[d] = P->d_in_slot[d].p;
   }
@@ -1745,10 +1844,10 @@ void launch_persistent(stereo_trws_plan *P, const DevParams &p, int what, hipStr
     const size_t wlds = sizeof(double) * kWideLdsDoubles;
     const dim3 wgrid(std::min(P->grid_blocks, 256)), wblock(kWideThreads);
     switch (what) {
-      case 0: hipLaunchKernelGGL((trws_wide_kernel<KERNEL, false, false, true>), wgrid, wblock, wlds, s, p, epoch); break;
-      case 1: hipLaunchKernelGGL((trws_wide_kernel<KERNEL, true, false, true>), wgrid, wblock, wlds, s, p, epoch); break;
-      case 2: hipLaunchKernelGGL((trws_wide_kernel<KERNEL, false, true, true>), wgrid, wblock, wlds, s, p, epoch); break;
-      default: hipLaunchKernelGGL((trws_wide_kernel<KERNEL, false, true, false>), wgrid, wblock, wlds, s, p, epoch); break;
+      case 0: hipLaunchKernelGGL((trws_wide_kernel<1, false, false, true>), wgrid, wblock, wlds, s, p, epoch); break;
+      case 1: hipLaunchKernelGGL((trws_wide_kernel<1, true, false, true>), wgrid, wblock, wlds, s, p, epoch); break;
+      case 2: hipLaunchKernelGGL((trws_wide_kernel<1, false, true, true>), wgrid, wblock, wlds, s, p, epoch); break;
+      default: hipLaunchKernelGGL((trws_wide_kernel<1, false, true, false>), wgrid, wblock, wlds, s, p, epoch); break;
     }
     STEREO_HIP_CHECK(hipGetLastError());
     if (what != 3) P->sweep_launches += 1;
@@ -1903,7 +2002,11 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
     std::unique_ptr<stereo_trws_plan> P(new stereo_trws_plan);
     P->kernel = kernel; P->K = K; P->Kp = (K + 1) & ~1; P->mode = message_mode; P->N = N; P->E = E;
     std::string gerr;
-    if (!build_trws_graph(N, E, conn, P->g, gerr)) return fail(gerr, err, errcap);
+    // workgroups that stay resident: runs beyond that are cut / dispensed by dependency level
+    const bool wide_candidate = kernel == 1 && K > kWave && K <= 256 && message_mode == STEREO_TRWS_MESSAGES_EXACT;
+    const int64_t per_cu = std::min<int64_t>(std::max<int64_t>(1, (int64_t)(160 * 1024) / (int64_t)persistent_lds_bytes(P->Kp)), 4);
+    const int64_t capacity = wide_candidate ? 256 : 256 * per_cu;
+    if (!build_trws_graph(N, E, conn, P->g, gerr, capacity)) return fail(gerr, err, errcap);
     const TrwsGraph &g = P->g;
     if (sweep_lds_bytes(P->Kp) > 160 * 1024) return fail("stereo_trws: K too large for LDS", err, errcap);
     P->d_tail.upload(g.tail.data(), g.tail.size());
@@ -1920,13 +2023,14 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
     for (int d = 0; d < 2; ++d) {
       const TrwsGraph::Sweep &S = g.sweep[d];
       P->d_run_ptr[d].upload(S.run_ptr.data(), S.run_ptr.size());
+      if (!S.run_order.empty()) P->d_run_order[d].upload(S.run_order.data(), S.run_order.size());
       P->d_dep_ptr[d].upload(S.dep_ptr.data(), S.dep_ptr.size());
       P->d_dep_rank[d].upload(S.dep_rank.data(), S.dep_rank.size());
       P->d_in_slot[d].upload(S.in_slot.data(), S.in_slot.size());
       if (g.fast_ok) P->d_desc[d].upload(S.desc.data(), S.desc.size());
     }
     P->fast = g.fast_ok && K <= kWave && message_mode == STEREO_TRWS_MESSAGES_EXACT;
-    P->wide_allowed = g.fast_ok && K > kWave && K <= 256 && message_mode == STEREO_TRWS_MESSAGES_EXACT;
+    P->wide_allowed = g.fast_ok && kernel == 1 && K > kWave && K <= 256 && message_mode == STEREO_TRWS_MESSAGES_EXACT;
     if (const char *f = std::getenv("STEREO_HIP_TRWS_FAST")) {
       P->fast = P->fast && std::string(f) != "0";
       P->wide_allowed = P->wide_allowed && std::string(f) != "0";
@@ -1936,7 +2040,7 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
     P->d_fallbacks.alloc(1);
     STEREO_HIP_CHECK(hipMemset(P->d_fallbacks.p, 0, sizeof(unsigned long long)));
     if (const char *c = std::getenv("STEREO_HIP_TRWS_CERTIFICATE")) P->certificate = std::string(c) != "0";
-    if (std::getenv("STEREO_HIP_TRWS_PROF")) { P->d_prof.alloc(16); STEREO_HIP_CHECK(hipMemset(P->d_prof.p, 0, 128)); }
+    if (std::getenv("STEREO_HIP_TRWS_PROF")) { P->d_prof.alloc(32); STEREO_HIP_CHECK(hipMemset(P->d_prof.p, 0, 256)); }
     if (std::getenv("STEREO_HIP_TRWS_TIMELINE")) P->d_timeline.alloc(4 * g.sweep[0].run_ptr.size());
     STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * N));
     STEREO_HIP_CHECK(hipMemset(P->d_ctl.p, 0, sizeof(int32_t) * 2));
@@ -1944,8 +2048,6 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
     {
       // one workgroup per concurrently active run, capped by what stays resident
       const int64_t runs = std::max<int64_t>((int64_t)g.sweep[0].run_ptr.size() - 1, 1);
-      const int64_t by_lds = std::max<int64_t>(1, (int64_t)(160 * 1024) / (int64_t)persistent_lds_bytes(P->Kp));
-      const int64_t per_cu = std::min<int64_t>(by_lds, 4);
       P->grid_blocks = (int)std::min<int64_t>(runs, 256 * per_cu);
     }
     P->d_msg.alloc((size_t)E * K);
@@ -1984,7 +2086,7 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
   STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_wide_kernel<KER, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wlds));  \
   STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_wide_kernel<KER, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wlds));  \
   STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_wide_kernel<KER, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, wlds))
-      SET_WLDS(1); SET_WLDS(2);
+      SET_WLDS(1);
 #undef SET_WLDS
     }
     *plan = P.release();
@@ -2011,15 +2113,17 @@ void stereo_trws_plan_destroy(stereo_trws_plan *plan) {
     }
   }
   if (plan && plan->d_prof.p) {
-    unsigned long long v[16];
+    unsigned long long v[32];
     if (hipMemcpy(v, plan->d_prof.p, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess) {
-      std::fprintf(stderr, "[stereo_hip prof] cycles: p0 %llu p1 %llu p2 %llu p3 %llu p4 %llu | p5 %llu steps %llu\n",
-                   v[0], v[1], v[2], v[3], v[4], v[5], v[6]);
-      if (plan->wide && v[12])
-        std::fprintf(stderr, "[stereo_hip prof wide] per visit: P1 %.0f b %.0f P2 %.0f b %.0f P3 %.0f b %.0f P4 %.0f | loader %.0f storer %.0f primal %.0f | hw barrier wait %.0f | visits %llu\n",
-                     (double)v[0] / v[12], (double)v[1] / v[12], (double)v[2] / v[12], (double)v[3] / v[12], (double)v[4] / v[12],
-                     (double)v[5] / v[12], (double)v[6] / v[12], (double)v[8] / v[12], (double)v[9] / v[12], (double)v[10] / v[12],
-                     (double)v[11] / v[12], v[12]);
+      if (!plan->wide)
+        std::fprintf(stderr, "[stereo_hip prof] cycles: p0 %llu p1 %llu p2 %llu p3 %llu p4 %llu | p5 %llu steps %llu\n",
+                     v[0], v[1], v[2], v[3], v[4], v[5], v[6]);
+      if (plan->wide && v[20]) {
+        std::fprintf(stderr, "[stereo_hip prof wide] cycles per visit of wave 0:");
+        for (int i = 0; i < 16; ++i) std::fprintf(stderr, " [%d] %.0f", i, (double)v[i] / v[20]);
+        std::fprintf(stderr, " | loader %.0f storer %.0f primal %.0f | hw barrier wait %.0f | visits %llu\n",
+                     (double)v[16] / v[20], (double)v[17] / v[20], (double)v[18] / v[20], (double)v[19] / v[20], v[20]);
+      }
     }
   }
   delete plan;

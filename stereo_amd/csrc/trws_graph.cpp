@@ -52,7 +52,7 @@ class Boundary {
 }  // namespace
 
 bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
-                      std::string &err) {
+                      std::string &err, int64_t max_resident_runs) {
   if (N <= 0 || E < 0) { err = "build_trws_graph: empty problem"; return false; }
   if (N >= INT32_MAX || E >= INT32_MAX) { err = "build_trws_graph: more than 2^31 nodes/edges"; return false; }
   g = TrwsGraph();
@@ -166,15 +166,22 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
   }
   g.lb_terms = pos;
   // ---- persistent sweep schedules
-  for (int d = 0; d < 2; ++d) {
+  // cut == false: a run ends only where the node does not hang on one of the two previous
+  // visits.  cut == true (used when there are more runs than resident workgroups): a run also
+  // ends in front of a node whose dependency level jumps (it will wait long for a foreign
+  // node -- e.g. the last node of a grid row waits for the border chain -- and would pin a
+  // workgroup meanwhile), and runs are dispensed by the level of their first node.
+  auto build_runs = [&](int d, bool cut) {
     TrwsGraph::Sweep &S = g.sweep[d];
     // incoming / outgoing lists of this direction, by rank
     const std::vector<int32_t> &iptr = d == 0 ? g.bptr : g.fptr, &iidx = d == 0 ? g.bidx : g.fidx;
     const std::vector<int32_t> &optr = d == 0 ? g.fptr : g.bptr, &oidx = d == 0 ? g.fidx : g.bidx;
     S.run_ptr.clear(); S.dep_ptr.assign(N + 1, 0); S.dep_rank.clear(); S.in_slot.assign(E, -1);
-    std::vector<int32_t> deps_of(N, 0);
+    S.run_order.clear();
     std::vector<std::vector<int32_t>> tmp_deps;  // filled per rank in processing order
     tmp_deps.resize(N);
+    std::vector<int32_t> lev(N, 0);  // dependency level within this sweep direction
+    constexpr int32_t kJump = 8;
     int64_t run_start = 0;
     for (int64_t p = 0; p < N; ++p) {
       const int32_t r = d == 0 ? (int32_t)p : (int32_t)(N - 1 - p);
@@ -183,10 +190,14 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
       bool chained = false;
       std::vector<int32_t> &deps = tmp_deps[r];
       // pass 1: does this node hang on one of the last two visits of the current run?
+      int32_t lv = 0;
       for (int32_t k = iptr[r]; k < iptr[r + 1]; ++k) {
         const int32_t other = g.rank[d == 0 ? g.tail[iidx[k]] : g.head[iidx[k]]];
         if ((p - 1 >= run_start && other == near1) || (p - 2 >= run_start && other == near2)) chained = true;
+        lv = std::max(lv, lev[other] + 1);
       }
+      lev[r] = lv;
+      if (cut && chained && p >= 1 && lv > lev[near1] + kJump) chained = false;
       if (!chained) { S.run_ptr.push_back((int32_t)p); run_start = p; }
       for (int32_t k = iptr[r]; k < iptr[r + 1]; ++k) {
         const int32_t e = iidx[k];
@@ -210,6 +221,39 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
       for (int32_t x : tmp_deps[r]) { S.dep_rank.push_back(x); ++dp; }
     }
     S.dep_ptr[N] = (int32_t)dp;
+    if (!cut) return;
+    // dispense runs by the level of their first node; keep the order only if every foreign
+    // dependency then lies in a run dispensed earlier (otherwise workgroups could all be
+    // waiting for a run nobody has picked up yet)
+    const int64_t R = (int64_t)S.run_ptr.size() - 1;
+    std::vector<int32_t> order(R);
+    for (int64_t k = 0; k < R; ++k) order[k] = (int32_t)k;
+    auto first_lev = [&](int32_t k) { const int64_t p = S.run_ptr[k]; return lev[d == 0 ? p : N - 1 - p]; };
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return first_lev(x) < first_lev(y); });
+    std::vector<int32_t> ticket_of_run(R), run_of_pos(N);
+    for (int64_t t = 0; t < R; ++t) ticket_of_run[order[t]] = (int32_t)t;
+    for (int64_t k = 0; k < R; ++k)
+      for (int64_t p = S.run_ptr[k]; p < S.run_ptr[k + 1]; ++p) run_of_pos[p] = (int32_t)k;
+    bool safe = true;
+    for (int64_t r = 0; r < N && safe; ++r) {
+      const int32_t mine = run_of_pos[d == 0 ? r : N - 1 - r];
+      for (int32_t x : tmp_deps[r]) {
+        const int32_t theirs = run_of_pos[d == 0 ? x : N - 1 - x];
+        if (theirs != mine && ticket_of_run[theirs] > ticket_of_run[mine]) { safe = false; break; }
+      }
+    }
+    if (safe) S.run_order = order;
+  };
+  for (int d = 0; d < 2; ++d) {
+    build_runs(d, false);
+    if (max_resident_runs > 0 && (int64_t)g.sweep[d].run_ptr.size() - 1 > max_resident_runs) {
+      build_runs(d, true);
+      // a cut turns the hand-over from the previous visit into a foreign dependency; the fast
+      // kernels take at most four per node
+      bool ok = true;
+      for (int64_t r = 0; r < N && ok; ++r) ok = g.sweep[d].dep_ptr[r + 1] - g.sweep[d].dep_ptr[r] <= 4;
+      if (!ok) build_runs(d, false);
+    }
   }
   // ---- descriptors of the fast kernel (layout: trws.hip NodeDesc)
   g.fast_ok = true;

@@ -43,6 +43,8 @@ struct TrwsGraph {
   // node over in LDS and waits on completion flags only for `dep_rank`.
   struct Sweep {
     std::vector<int32_t> run_ptr;   // R+1 offsets into processing positions
+    // order in which workgroups pick runs up (ticket -> run); empty = 0, 1, 2, ...
+    std::vector<int32_t> run_order;
     std::vector<int32_t> dep_ptr;   // N+1, indexed by rank
     std::vector<int32_t> dep_rank;  // ranks whose flag must be set first
     // aligned with the node's INCOMING list (bidx forward / fidx backward):
@@ -60,7 +62,9 @@ struct TrwsGraph {
 
 // conn: 2 x E zero-based (column major: conn[2e] = tail, conn[2e+1] = head).
 // Returns false and sets `err` on invalid input.
+// max_resident_runs > 0: if a sweep has more runs than that, cut runs in front of nodes that
+// wait long for a foreign node and dispense them in dependency-level order (see trws_graph.cpp).
 bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
-                      std::string &err);
+                      std::string &err, int64_t max_resident_runs = 0);
 
 }  // namespace stereo
