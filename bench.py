@@ -39,6 +39,27 @@ def synthetic_volume(H, W, K, seed):
     return np.ascontiguousarray(cost.transpose(1, 0, 2).reshape(H * W, K))  # node id = col*H + row
 
 
+def synthetic_volume_device(H, W, K, seed, dev):
+    """The same construction on the device (torch RNG), for volumes too large to build on the host
+    in reasonable time (3000 x 2000 x 256: 12 GB)."""
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    cols = torch.arange(W, device=dev, dtype=torch.float64)[:, None]
+    rows = torch.arange(H, device=dev, dtype=torch.float64)[None, :]
+    truth = (0.25 * K + 0.5 * K * (cols / W) + 0.1 * K * torch.sin(rows / 37.0)).clamp(0, K - 1)
+    mask = ((torch.div(rows, 60, rounding_mode="floor") + torch.div(cols, 75, rounding_mode="floor")) % 2) == 0
+    truth = torch.where(mask, truth * 0.6, truth).reshape(H * W, 1)  # node id = col*H + row
+    out = torch.empty(H * W, K, dtype=torch.float64, device=dev)
+    lab = torch.arange(K, device=dev, dtype=torch.float64)[None, :]
+    step = max(1, (1 << 26) // K)
+    for a in range(0, H * W, step):
+        b = min(H * W, a + step)
+        out[a:b] = torch.clamp((lab - truth[a:b]).abs() / 4.0, max=1.0) * 30.0
+        out[a:b] += torch.rand(b - a, K, generator=g, device=dev, dtype=torch.float64) * 10.0
+    return out
+
+
 def algorithmic_bytes_per_sweep_pair(info_deg, K):
     """per node and sweep read D (K) + every incident message,
     write the outgoing ones; 8-byte reals.  info_deg = (nf, nb) arrays by node."""
@@ -76,11 +97,11 @@ def main():
     N = H * W
     conn = grid_conn(H, W)
     E = conn.shape[0]
-    unary = synthetic_volume(H, W, K, seed=1 + rank)
+    dev = torch.device("cuda", local_rank)
+    big = N * K > (1 << 28)
+    d_unary = synthetic_volume_device(H, W, K, 1 + rank, dev) if big else torch.from_numpy(synthetic_volume(H, W, K, seed=1 + rank)).to(dev)
     plan = TrwsPlan(1, K, N, conn.T, message_mode=0 if args.message_mode == "exact" else 1)
     # inputs live in HBM as torch tensors (plumbing only) and are bound, not copied
-    dev = torch.device("cuda", local_rank)
-    d_unary = torch.from_numpy(unary).to(dev)
     d_alpha = torch.ones(E, dtype=torch.float64, device=dev)
     d_pos = torch.arange(K, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
@@ -142,13 +163,15 @@ def main():
             "serial_envelope_messages": serial_msgs, "final_energy": energy, "final_lower_bound": lb, "iterations_done": iters,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "trws_pipe_kernel (one persistent launch per sweep)", "bytes_per_launch": bytes_per_launch,
+                         "kernel": {3: "trws_wide_kernel", 2: "trws_pipe_kernel", 1: "trws_persistent_kernel", 0: "trws_sweep_kernel (per level)"}[plan.path()]
+                                   + " (one persistent launch per sweep)", "bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches_per_iter},
         }
         if not args.no_cpu_baseline:
             from oracle import pyoracle
             q = np.tile(np.arange(K, dtype=np.float64), (E, 1))
             ci = max(args.cpu_iters, 1)
+            unary = d_unary.cpu().numpy()
             r = pyoracle.trws(1, unary, conn, q, q, np.ones(E), 8.0, maxiter=ci, max_relgap=-1e300,
                               mode=1, want_trace=True)
             secs = float(r[4][-1, 2])

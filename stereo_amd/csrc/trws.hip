@@ -1144,13 +1144,15 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
 // Three compute waves per outgoing message, each forming Di and H = gamma Di - m itself (cheap,
 // and no barrier between them): wave 3j does the windowed min-plus, waves 3j+1 / 3j+2 the u / v
 // closest-pair tests and post their verdicts in LDS; wave 3j waits for the two verdicts,
-// normalises and hands over.  Loader / storer / primal waves as in trws_pipe_kernel; one
+// normalises and hands over.  Loader / storer / primal waves as in trws_pipe_kernel (the loader is
+// split in two: data nobody else writes, and data behind completion flags, so that the two HBM
+// round trips of a visit overlap); one
 // hardware barrier per visit.  Nodes with more than four outgoing messages take a second round
 // (message j + 4 on the same waves).  If the certificate fails, wave 3j runs the reference's
 // serial envelope construction in LDS (one at a time per workgroup: shared scratch, rare).
 // Kernel 1 (truncated linear) only; kernel 2 has no certificate and stays on the generic kernel.
 constexpr int kWideCompute = 12;
-constexpr int kWideWaves = kWideCompute + 3;
+constexpr int kWideWaves = kWideCompute + 4;  // + loader (own data), loader (foreign data), storer, primal
 constexpr int kWideThreads = kWideWaves * kWave;
 constexpr int kWS = 260;    // LDS row stride in doubles (>= 256 + 1 breakpoints, multiple of 4)
 constexpr int kWPad = 16;   // min-plus source table is padded by this many (+inf, 0) entries on both sides
@@ -1312,22 +1314,36 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
     __syncthreads();
     if (run >= p.nruns[D]) break;
     const int p0 = p.run_ptr[D][run], p1 = p.run_ptr[D][run + 1];
-    int xprev = 0, xprev2 = 0;
-    int wnext = 0;
-    if (wave == kWideCompute) wnext = desc[(size_t)p0 * DW + lane];
     if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2] = wall_clock64();
 
-    for (int pos = p0 - 1; pos <= p1; ++pos) {
-      double *st = L.stage0 + (pos & 1) * kWStage;
-      double *stn = L.stage0 + ((pos + 1) & 1) * kWStage;
-      const int hb = ((pos % 3) + 3) % 3, hb1 = (((pos - 1) % 3) + 3) % 3, hb2 = (((pos - 2) % 3) + 3) % 3;
-      double *hcur = L.hand + hb * 8 * kWS, *hprev = L.hand + hb1 * 8 * kWS, *hprev2 = L.hand + hb2 * 8 * kWS;
-      double *sc = L.scal + (pos & 1) * kScalDoubles;
-      const bool have_node = pos >= p0 && pos < p1;
-      long long tmark = p.prof ? (long long)__builtin_readcyclecounter() : 0;
-      const long long tvisit = tmark;
-
-      if (wave < kWideCompute) {
+    // One visit loop per role (not one loop with a role switch inside): state carried from visit
+    // to visit -- the loader's parked registers -- then occupies registers in that role only.
+#define WIDE_VISITS_BEGIN     for (int pos = p0 - 1; pos <= p1; ++pos) { \
+      double *st = L.stage0 + (pos & 1) * kWStage; \
+      double *stn = L.stage0 + ((pos + 1) & 1) * kWStage; \
+      const int hb = ((pos % 3) + 3) % 3, hb1 = (((pos - 1) % 3) + 3) % 3, hb2 = (((pos - 2) % 3) + 3) % 3; \
+      double *hcur = L.hand + hb * 8 * kWS, *hprev = L.hand + hb1 * 8 * kWS, *hprev2 = L.hand + hb2 * 8 * kWS; \
+      double *sc = L.scal + (pos & 1) * kScalDoubles; \
+      const bool have_node = pos >= p0 && pos < p1; \
+      long long tmark = p.prof ? (long long)__builtin_readcyclecounter() : 0; \
+      const long long tvisit = tmark; \
+      (void)st; (void)stn; (void)hcur; (void)hprev; (void)hprev2; (void)sc; (void)have_node; (void)tvisit;
+#define WIDE_VISITS_END_(BARRIER)       if (p.prof) { \
+        const long long now_ = (long long)__builtin_readcyclecounter(); \
+        if (wave == 0) pvis += have_node ? 1 : 0; \
+        pbusy += (unsigned long long)(now_ - tvisit); \
+        tmark = now_; \
+      } \
+      BARRIER; \
+      if (p.prof && wave == 0) pwait += (unsigned long long)((long long)__builtin_readcyclecounter() - tmark); \
+      if (L.ctl[1]) { \
+        if (tid == 0) st_sc1(p.abort_flag, 1); \
+        return; \
+      } \
+    }
+#define WIDE_VISITS_END WIDE_VISITS_END_(__syncthreads())
+    if (wave < kWideCompute) {
+      WIDE_VISITS_BEGIN
         // ======================================================== compute waves
         const int j0 = wave / 3, role = wave - 3 * j0;  // role 0: min-plus, 1: u test, 2: v test
         if (UPDATE && have_node) {
@@ -1529,8 +1545,11 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
             }
           }
         }
-      } else if (wave == kWideCompute) {
-        // ======================================================== loader: stage node pos + 1
+      WIDE_VISITS_END
+    } else if (wave == kWideCompute) {
+      int wnext = desc[(size_t)p0 * DW + lane];
+      WIDE_VISITS_BEGIN
+        // ======================================================== loader A: node pos + 1, own data
         if (pos + 1 >= p0 && pos + 1 < p1) {
           const int w = wnext;
           if (pos + 2 < p1) wnext = desc[(size_t)(pos + 2) * DW + lane];
@@ -1556,13 +1575,40 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
             }
           }
           double av = 0;
-          int pxv = 0, xn = 0, sl = 0;
           if (lane < ntot) {
             int ej = 0;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-              if (lane == j) { ej = nx.e[j]; xn = nx.xn[j]; sl = nx.slot[j]; }
+              if (lane == j) ej = nx.e[j];
             av = p.alpha[ej];
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (okc[c]) {
+              stn[c * kWave + lane] = dk[c];
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if (j < nx.nout) stn[kWS + j * kWS + c * kWave + lane] = mv[j][c];
+            }
+          }
+          if (lane < 8) stn[kWS + 8 * kWS + lane] = av;
+        }
+      WIDE_VISITS_END
+    } else if (wave == kWideCompute + 1) {
+      int wnext = desc[(size_t)p0 * DW + lane];
+      WIDE_VISITS_BEGIN
+        // ======================================================== loader B: node pos + 1, data behind flags
+        if (pos + 1 >= p0 && pos + 1 < p1) {
+          const int w = wnext;
+          if (pos + 2 < p1) wnext = desc[(size_t)(pos + 2) * DW + lane];
+          const NodeDesc nx = decode_desc(w);
+          int *stni = (int *)(stn + kWStI);
+          const int ntot = nx.nout + nx.nin;
+          int pxv = 0, xn = 0, sl = 0;
+          if (lane < ntot) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (lane == j) { xn = nx.xn[j]; sl = nx.slot[j]; }
           }
           if (nx.ndep > 0) {
             int myrank = nx.dep[0];
@@ -1580,27 +1626,30 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
             }
             if (!ok && lane == 0) { st_sc1(p.abort_flag, 1); L.ctl[1] = 1; }
           }
+          double mv[8][4];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              mv[j][c] = 0;
+              if (UPDATE && j >= nx.nout && j < ntot && nx.slot[j] < 0 && c < C && c * kWave + lane < K)
+                mv[j][c] = ld_sc1(p.msg + (size_t)nx.e[j] * K + c * kWave + lane);
+            }
+          }
+          if (PRIMAL && lane < ntot && lane >= nx.nout && sl < 0) pxv = ld_sc1(p.x + xn);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             if (UPDATE && j >= nx.nout && j < ntot && nx.slot[j] < 0) {
 #pragma unroll
               for (int c = 0; c < 4; ++c)
-                if (okc[c]) mv[j][c] = ld_sc1(p.msg + (size_t)nx.e[j] * K + c * kWave + lane);
+                if (c < C && c * kWave + lane < K) stn[kWS + j * kWS + c * kWave + lane] = mv[j][c];
             }
           }
-          if (PRIMAL && lane < ntot && lane >= nx.nout && sl < 0) pxv = ld_sc1(p.x + xn);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (okc[c]) {
-              stn[c * kWave + lane] = dk[c];
-#pragma unroll
-              for (int j = 0; j < 8; ++j)
-                if (j < ntot) stn[kWS + j * kWS + c * kWave + lane] = mv[j][c];
-            }
-          }
-          if (lane < 8) { stn[kWS + 8 * kWS + lane] = av; stni[64 + lane] = pxv; }
+          if (lane < 8) stni[64 + lane] = pxv;
         }
-      } else if (wave == kWideCompute + 1) {
+      WIDE_VISITS_END
+    } else if (wave == kWideCompute + 2) {
+      WIDE_VISITS_BEGIN
         // ======================================================== storer: node pos - 1
         if (pos - 1 >= p0) {
           const NodeDesc pd = decode_desc(L.dring[((pos - 1) % 3) * 64 + lane]);
@@ -1626,7 +1675,10 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0) st_sc1(p.done + pd.rank, epoch);
         }
-      } else {
+      WIDE_VISITS_END
+    } else {
+      int xprev = 0, xprev2 = 0;
+      WIDE_VISITS_BEGIN
         // ======================================================== primal of node pos
         if (PRIMAL && have_node) {
           const int *sti = (const int *)(st + kWStI);
@@ -1679,28 +1731,19 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
           xprev2 = xprev; xprev = bi;
           if (lane == 0) { sc[9] = eb; ((int *)(sc + 10))[0] = bi; }
         }
-      }
-      if (p.prof) {
-        const long long now_ = (long long)__builtin_readcyclecounter();
-        if (wave == 0) pvis += have_node ? 1 : 0;
-        pbusy += (unsigned long long)(now_ - tvisit);
-        tmark = now_;
-      }
-      __syncthreads();
-      if (p.prof && wave == 0) pwait += (unsigned long long)((long long)__builtin_readcyclecounter() - tmark);
-      if (L.ctl[1]) {
-        if (tid == 0) st_sc1(p.abort_flag, 1);
-        return;
-      }
+            WIDE_VISITS_END
     }
+#undef WIDE_VISITS_BEGIN
+#undef WIDE_VISITS_END
+#undef WIDE_VISITS_END_
     if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2 + 1] = wall_clock64();
   }
 #undef WSTAMP
   if (p.prof && lane == 0) {
     if (wave == 0) {
       for (int i = 0; i < 16; ++i) atomicAdd(p.prof + i, pacc[i]);
-      atomicAdd(p.prof + 19, pwait);
-      atomicAdd(p.prof + 20, pvis);
+      atomicAdd(p.prof + 21, pwait);
+      atomicAdd(p.prof + 22, pvis);
     }
     if (wave >= kWideCompute) atomicAdd(p.prof + 16 + (wave - kWideCompute), pbusy);
     if (wave == 1) for (int i = 0; i < 3; ++i) atomicAdd(p.prof + 8 + i, pacc[i]);  // a closest-pair wave
@@ -2118,11 +2161,12 @@ void stereo_trws_plan_destroy(stereo_trws_plan *plan) {
       if (!plan->wide)
         std::fprintf(stderr, "[stereo_hip prof] cycles: p0 %llu p1 %llu p2 %llu p3 %llu p4 %llu | p5 %llu steps %llu\n",
                      v[0], v[1], v[2], v[3], v[4], v[5], v[6]);
-      if (plan->wide && v[20]) {
+      if (plan->wide && v[22]) {
         std::fprintf(stderr, "[stereo_hip prof wide] cycles per visit of wave 0:");
-        for (int i = 0; i < 16; ++i) std::fprintf(stderr, " [%d] %.0f", i, (double)v[i] / v[20]);
-        std::fprintf(stderr, " | loader %.0f storer %.0f primal %.0f | hw barrier wait %.0f | visits %llu\n",
-                     (double)v[16] / v[20], (double)v[17] / v[20], (double)v[18] / v[20], (double)v[19] / v[20], v[20]);
+        for (int i = 0; i < 16; ++i) std::fprintf(stderr, " [%d] %.0f", i, (double)v[i] / v[22]);
+        std::fprintf(stderr, " | loader A %.0f B %.0f storer %.0f primal %.0f | hw barrier wait %.0f | visits %llu\n",
+                     (double)v[16] / v[22], (double)v[17] / v[22], (double)v[18] / v[22], (double)v[19] / v[22],
+                     (double)v[21] / v[22], v[22]);
       }
     }
   }
