@@ -114,6 +114,184 @@ __global__ __launch_bounds__(kQB) void qpbo_count_active_kernel(QpboDev g) {
 }
 
 
+// ---- the whole max-flow in ONE launch -------------------------------------------------------
+// The multi-launch loop above is launch bound (a Teddy move is ~800 launches of a few
+// microseconds of work each).  This kernel runs the same synchronous rounds -- push | barrier |
+// gather + relabel | barrier -- and the level-synchronous global relabelling between grid-wide
+// barriers: one workgroup of 1024 threads per CU, all resident (cooperative launch), nodes
+// in a grid-stride loop.  Everything one workgroup writes and another reads inside the launch
+// (heights, residuals, pushed amounts) goes through agent-scope (sc1) accesses -- the XCDs' L2s are
+// not coherent for plain accesses inside a launch -- so the barrier itself needs no cache
+// write-back / invalidate: __syncthreads drains the stores, one atomic counter does the rest.
+// Same arithmetic in the same per-node order as the kernels above, so results are reproducible.
+constexpr int kMB = 1024;
+// ctl words: [0] barrier counter, [1] abort, [2..4] "changed" slots, [5..7] active-count slots,
+// [8] rounds done, [9] global relabels done
+struct QpboCtl { enum { kBar = 0, kAbort = 1, kChanged = 2, kActive = 5, kRounds = 8, kRelabels = 9, kWords = 16 }; };
+constexpr int kGridSpinLimit = 1 << 24;
+__device__ __forceinline__ int ldc(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stc(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ldc(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stc(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ bool grid_sync(int32_t *ctl, unsigned &gen) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ++gen;
+    __hip_atomic_fetch_add(ctl + QpboCtl::kBar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int target = (int)(gen * gridDim.x);
+    int spins = 0;
+    while (__hip_atomic_load(ctl + QpboCtl::kBar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > kGridSpinLimit) {  // bounded: never hang the device
+        __hip_atomic_store(ctl + QpboCtl::kAbort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  return __hip_atomic_load(ctl + QpboCtl::kAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+}
+
+__global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *ctl, int relabel_every, int max_rounds) {
+  __shared__ int s_red;
+  unsigned gen = 0;
+  const int n = g.n;
+  const int first = blockIdx.x * kMB + threadIdx.x, stride = gridDim.x * kMB;
+  int32_t *h = g.h, *h2 = g.h2;
+  int slot = 0;  // rotating flag slot: written in phase k, read after its barrier, cleared one phase later
+  auto ld = [&](int w) { return __hip_atomic_load(ctl + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto clear_next = [&](int base) {
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+      __hip_atomic_store(ctl + base + (slot + 1) % 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // exact distances to the sink in the residual graph (frontier BFS, pull), then #active nodes
+  auto global_relabel = [&](int &active) -> bool {
+    for (int v = first; v < n; v += stride) stc(h + v, g.snk[v] > 0 ? 1 : n);
+    if (!grid_sync(ctl, gen)) return false;
+    for (int level = 1;; ++level) {
+      slot = (slot + 1) % 3;
+      clear_next(QpboCtl::kChanged);
+      bool changed = false;
+      for (int v = first; v < n; v += stride) {
+        if (ldc(h + v) != n) continue;
+        for (int a = g.aptr[v]; a < g.aptr[v + 1]; ++a)
+          if (ldc(g.r + a) > 0 && ldc(h + g.head[a]) == level) { stc(h + v, level + 1); changed = true; break; }
+      }
+      if (__syncthreads_or(changed) && threadIdx.x == 0)
+        __hip_atomic_store(ctl + QpboCtl::kChanged + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!grid_sync(ctl, gen)) return false;
+      if (!ld(QpboCtl::kChanged + slot)) break;
+    }
+    slot = (slot + 1) % 3;
+    clear_next(QpboCtl::kActive);
+    int cnt = 0;
+    for (int v = first; v < n; v += stride) cnt += (g.ex[v] > 0 && ldc(h + v) < n) ? 1 : 0;
+    cnt = __syncthreads_count(cnt > 0 ? 1 : 0) > 0 ? cnt : 0;
+    if (threadIdx.x == 0) s_red = 0;
+    __syncthreads();
+    if (cnt) atomicAdd(&s_red, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_red)
+      __hip_atomic_fetch_add(ctl + QpboCtl::kActive + slot, s_red, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!grid_sync(ctl, gen)) return false;
+    active = ld(QpboCtl::kActive + slot);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctl[QpboCtl::kRelabels] += 1; ctl[10] += (int)gen; ctl[11 + (ctl[QpboCtl::kRelabels] - 1 < 4 ? ctl[QpboCtl::kRelabels] - 1 : 4)] = (int)gen; }
+    return true;
+  };
+
+  int active = 0;
+  if (!global_relabel(active)) return;
+  int rounds = 0, since_relabel = 0, interval = relabel_every < 8 ? relabel_every : 8, stagnant = 0, last_active = active;
+  while (active > 0 && rounds < max_rounds) {
+    // ---- push (old heights; a pair of arcs is only modified by the endpoint that is higher)
+    for (int v = first; v < n; v += stride) {
+      double e = g.ex[v];
+      const int hv = ldc(h + v);
+      if (!(e > 0) || hv >= n) continue;
+      if (hv == 1) {
+        const double sk = g.snk[v];
+        if (sk > 0) {
+          const double d = e < sk ? e : sk;
+          g.snk[v] = sk - d;
+          e -= d;
+        }
+      }
+      const int a0 = g.aptr[v], a1 = g.aptr[v + 1];
+      for (int a = a0; a < a1 && e > 0; ++a) {
+        const double ra = ldc(g.r + a);
+        if (ra > 0 && hv == ldc(h + g.head[a]) + 1) {
+          const double d = e < ra ? e : ra;
+          const int b = g.rev[a];
+          stc(g.r + a, ra - d);
+          stc(g.r + b, ldc(g.r + b) + d);
+          stc(g.delta + a, d);
+          e -= d;
+        }
+      }
+      g.ex[v] = e;
+    }
+    if (!grid_sync(ctl, gen)) return;
+    // ---- gather the pushed flow in the node's own arc order, relabel from the post-push residual graph
+    slot = (slot + 1) % 3;
+    clear_next(QpboCtl::kActive);
+    int cnt = 0;
+    for (int v = first; v < n; v += stride) {
+      double e = g.ex[v];
+      const int a0 = g.aptr[v], a1 = g.aptr[v + 1];
+      for (int a = a0; a < a1; ++a) {
+        const int b = g.rev[a];
+        const double d = ldc(g.delta + b);
+        if (d != 0) { e += d; stc(g.delta + b, 0.0); }
+      }
+      g.ex[v] = e;
+      int hv = ldc(h + v);
+      if (e > 0 && hv < n) {
+        int hmin = n;
+        if (g.snk[v] > 0) hmin = 0;
+        for (int a = a0; a < a1; ++a)
+          if (ldc(g.r + a) > 0) {
+            const int hw = ldc(h + g.head[a]);
+            hmin = hw < hmin ? hw : hmin;
+          }
+        if (hmin + 1 > hv) hv = hmin + 1 < n ? hmin + 1 : n;
+        if (hv < n) ++cnt;
+      }
+      stc(h2 + v, hv);
+    }
+    if (threadIdx.x == 0) s_red = 0;
+    __syncthreads();
+    if (cnt) atomicAdd(&s_red, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_red)
+      __hip_atomic_fetch_add(ctl + QpboCtl::kActive + slot, s_red, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!grid_sync(ctl, gen)) return;
+    active = ld(QpboCtl::kActive + slot);
+    if (g.counters && blockIdx.x == 0 && threadIdx.x == 0 && rounds < 1024) g.counters[16 + rounds] = active;
+    { int32_t *t = h; h = h2; h2 = t; }
+    ++rounds; ++since_relabel;
+    // Excess that cannot reach the sink any more only climbs one level per round; an exact
+    // relabelling retires it at once.  Early relabels are cheap (few BFS levels) and usually
+    // end the solve after a handful of rounds, so the interval starts small and doubles.
+    stagnant = active >= last_active ? stagnant + 1 : 0;  // no progress: what is left is probably cut off
+    last_active = active;
+    if (active > 0 && (since_relabel >= interval || (stagnant >= 2 && since_relabel >= 4))) {
+      if (!global_relabel(active)) return;
+      since_relabel = 0; stagnant = 0; last_active = active;
+      interval = interval * 2 < relabel_every ? interval * 2 : relabel_every;
+    }
+  }
+  // heights may be stale lower bounds: one exact BFS defines T; leave it in g.h
+  if (!global_relabel(active)) return;
+  if (h != g.h) {
+    for (int v = first; v < n; v += stride) g.h[v] = ldc(h + v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ctl[QpboCtl::kRounds] += rounds;
+    if (rounds >= max_rounds && active > 0) ctl[QpboCtl::kAbort] = 2;
+  }
+}
+
 // ---- device-side construction for the plan API ------------------------------------------
 // The doubled graph has a fixed slot layout per neighbour pair (one outgoing arc at each of
 // i, j, i', j'); only heads, reverse links and capacities depend on whether the summed table
@@ -352,7 +530,7 @@ namespace {
 struct QpboSolver {
   QpboProblem P;
   int n = 0, m = 0;
-  DevBuf<int32_t> d_aptr, d_head, d_rev, d_h, d_h2, d_cnt, d_flags;
+  DevBuf<int32_t> d_aptr, d_head, d_rev, d_h, d_h2, d_cnt, d_flags, d_ctl;
   DevBuf<double> d_r, d_delta, d_ex, d_snk;
   std::vector<double> snk0;
   QpboDev g{};
@@ -373,8 +551,8 @@ struct QpboSolver {
     }
     snk0 = snk;
     d_ex.upload(ex.data(), n); d_snk.upload(snk.data(), n);
-    d_h.alloc(n); d_h2.alloc(n); d_cnt.alloc(4);
-    STEREO_HIP_CHECK(hipMemset(d_cnt.p, 0, sizeof(int32_t) * 4));
+    d_h.alloc(n); d_h2.alloc(n); d_cnt.alloc(2048);
+    STEREO_HIP_CHECK(hipMemset(d_cnt.p, 0, sizeof(int32_t) * 2048));
     g.n = n; g.m = m; g.aptr = d_aptr.p; g.head = d_head.p; g.rev = d_rev.p; g.r = d_r.p;
     g.delta = d_delta.p; g.ex = d_ex.p; g.snk = d_snk.p; g.h = d_h.p; g.h2 = d_h2.p; g.counters = d_cnt.p;
     STEREO_HIP_CHECK(hipDeviceSynchronize());
@@ -434,8 +612,40 @@ struct QpboSolver {
     STEREO_HIP_CHECK(hipMemcpy(d_snk.p + im, &nsn1, sizeof(double), hipMemcpyHostToDevice));
   }
 
+  // One cooperative launch runs the whole max-flow (qpbo_maxflow_kernel); the multi-launch loop
+  // is kept behind STEREO_HIP_QPBO_PERSISTENT=0 for comparison.
   void maxflow() {
+    static const bool persistent = [] { const char *e = std::getenv("STEREO_HIP_QPBO_PERSISTENT"); return !(e && std::string(e) == "0"); }();
+    if (!persistent) { maxflow_launches(); return; }
+    int relabel_every = 256;
+    if (const char *e = std::getenv("STEREO_HIP_QPBO_RELABEL_EVERY")) relabel_every = std::max(1, std::atoi(e));
+    if (d_ctl.n < (size_t)QpboCtl::kWords) d_ctl.alloc(QpboCtl::kWords);
+    STEREO_HIP_CHECK(hipMemsetAsync(d_ctl.p, 0, sizeof(int32_t) * QpboCtl::kWords, 0));
+    int dev = 0, cus = 0, per_cu = 0;
+    STEREO_HIP_CHECK(hipGetDevice(&dev));
+    STEREO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    STEREO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qpbo_maxflow_kernel, kMB, 0));
+    if (per_cu < 1) throw HipError{"qpbo_maxflow_kernel does not fit on a CU"};
+    int blocks = std::min(cus * std::min(per_cu, 2), (n + kMB - 1) / kMB);
+    blocks = std::max(blocks, 1);
+    QpboDev gg = g;
+    int32_t *ctl = d_ctl.p;
+    int max_rounds = 1 << 21;
+    void *args[] = {&gg, &ctl, &relabel_every, &max_rounds};
+    STEREO_HIP_CHECK(hipLaunchCooperativeKernel((const void *)qpbo_maxflow_kernel, dim3(blocks), dim3(kMB), args, 0, 0));
+    int32_t host_ctl[QpboCtl::kWords];
+    STEREO_HIP_CHECK(hipMemcpy(host_ctl, d_ctl.p, sizeof(host_ctl), hipMemcpyDeviceToHost));
+    if (host_ctl[QpboCtl::kAbort] == 1) throw HipError{"stereo_rd: grid barrier gave up (device-side spin bound)"};
+    if (host_ctl[QpboCtl::kAbort] == 2) throw HipError{"stereo_rd: push-relabel did not converge within the round bound"};
+    if (std::getenv("STEREO_HIP_QPBO_VERBOSE")) std::fprintf(stderr, "[stereo_hip qpbo] barrier generations at the end of relabels: %d %d %d %d %d\n", host_ctl[11], host_ctl[12], host_ctl[13], host_ctl[14], host_ctl[15]);
+    if (std::getenv("STEREO_HIP_QPBO_VERBOSE")) { std::vector<int32_t> tr(1040); (void)hipMemcpy(tr.data(), d_cnt.p, sizeof(int32_t) * 1040, hipMemcpyDeviceToHost); std::fprintf(stderr, "[stereo_hip qpbo] active per round:"); for (int i = 0; i < host_ctl[QpboCtl::kRounds] && i < 1024; i += (i < 32 ? 1 : 8)) std::fprintf(stderr, " %d", tr[16 + i]); std::fprintf(stderr, "\n"); }
+    iterations += host_ctl[QpboCtl::kRounds];
+    relabels += host_ctl[QpboCtl::kRelabels];
+  }
+
+  void maxflow_launches() {
     int active = global_relabel();
+
     int check_every = 8;  // grows: easy instances finish within a few sweeps
     int relabel_every = 256;
     if (const char *e = std::getenv("STEREO_HIP_QPBO_RELABEL_EVERY")) relabel_every = std::max(1, std::atoi(e));
@@ -698,7 +908,7 @@ extern "C" int stereo_rd_plan_create(int64_t N, int64_t E, const uint32_t *conn,
     S.n = (int)n; S.m = (int)m;
     S.d_aptr.upload(aptr.data(), aptr.size());
     S.d_head.alloc(m); S.d_rev.alloc(m); S.d_r.alloc(m); S.d_delta.alloc(std::max<int64_t>(m, 1));
-    S.d_ex.alloc(n); S.d_snk.alloc(n); S.d_h.alloc(n); S.d_h2.alloc(n); S.d_cnt.alloc(4);
+    S.d_ex.alloc(n); S.d_snk.alloc(n); S.d_h.alloc(n); S.d_h2.alloc(n); S.d_cnt.alloc(2048);
     S.g.n = (int)n; S.g.m = (int)m; S.g.aptr = S.d_aptr.p; S.g.head = S.d_head.p; S.g.rev = S.d_rev.p;
     S.g.r = S.d_r.p; S.g.delta = S.d_delta.p; S.g.ex = S.d_ex.p; S.g.snk = S.d_snk.p; S.g.h = S.d_h.p;
     S.g.h2 = S.d_h2.p; S.g.counters = S.d_cnt.p;
@@ -741,7 +951,15 @@ static int rd_plan_solve_device(stereo_rd_plan *P, const double *const in[6], in
     // sum_i min(0, tr_i) = -(sink capacity of the unprimed half)
     const double neg = -det_sum(P->d_snk0.p, N, P->d_partial);
     S.iterations = 0; S.relabels = 0;
+    const bool verbose = std::getenv("STEREO_HIP_QPBO_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    if (verbose) STEREO_HIP_CHECK(hipDeviceSynchronize());
+    const double tm0 = now();
     S.maxflow();
+    if (verbose) {
+      STEREO_HIP_CHECK(hipDeviceSynchronize());
+      std::fprintf(stderr, "[stereo_hip qpbo plan] maxflow %.3f ms\n", now() - tm0);
+    }
     std::vector<int32_t> h(n);
     STEREO_HIP_CHECK(hipMemcpy(h.data(), S.g.h, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
     const double left = det_sum(S.d_snk.p, n, P->d_partial);
