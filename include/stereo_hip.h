@@ -207,6 +207,36 @@ int stereo_globalstereo_unary(const double *im0, const double *im1, int H, int W
                               const double *P2, double d_min, double d_step, double col_thresh,
                               const double *assignment, double *U, char *err, size_t errcap);
 
+/* ---- device-resident fusion moves --------------------------------------- *
+ * The state of one dispmap object kept in HBM across moves: connectivity, weights, points,
+ * the current assignment (dispmap_super.m properties :5-24), its unary and the unary source of
+ * the subclass.  A binary fusion move (dispmap_super.m:61-84 binary_fusion followed by
+ * :263-274 update_energy) then uploads only the proposal (4 x N) and returns four scalars:
+ * pairwise terms, both unaries, QPBO (stereo_rd_plan), the scatter of the accepted planes and
+ * the new energy all run on the device.  d_step != 0: dispmap_globalstereo rescaling. */
+typedef struct stereo_fusion stereo_fusion;
+int stereo_fusion_create(int H, int W, int kernel, double tol, int64_t E, const uint32_t *conn,
+                         const double *weights, double d_min, double d_step, stereo_fusion **ctx,
+                         char *err, size_t errcap);
+void stereo_fusion_destroy(stereo_fusion *ctx);
+/* unary source: dispmap_ncc.m:107-115 (ncc: H x W x D, MATLAB layout) ... */
+int stereo_fusion_unary_ncc(stereo_fusion *ctx, const double *ncc, int D, const double *disparities,
+                            double unary_weight, char *err, size_t errcap);
+/* ... or dispmap_globalstereo.m:355-375 (images H x W x C, P2 4 x 3 as in stereo_globalstereo_unary) */
+int stereo_fusion_unary_globalstereo(stereo_fusion *ctx, const double *im0, const double *im1, int C,
+                                     const double *P2, double col_thresh, char *err, size_t errcap);
+/* set.assignment + update_energy (dispmap_super.m:57-60, :263-274); energy may be NULL */
+int stereo_fusion_set_assignment(stereo_fusion *ctx, const double *assignment, double *energy, char *err,
+                                 size_t errcap);
+/* current assignment (4 x N, may be NULL) and stored energy (may be NULL) */
+int stereo_fusion_get_assignment(stereo_fusion *ctx, double *assignment, double *energy, char *err,
+                                 size_t errcap);
+/* one binary fusion move; energy = stored energy after the move, the other three are the outputs
+ * of rd.m for this move (any may be NULL) */
+int stereo_fusion_binary(stereo_fusion *ctx, const double *proposal, int improve, double *energy,
+                         double *rd_energy, double *lower_bound, double *num_unlabelled, char *err,
+                         size_t errcap);
+
 #ifdef __cplusplus
 }
 #endif

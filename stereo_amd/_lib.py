@@ -30,6 +30,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.stereo_hip_last_error.restype = C.c_char_p
         L.stereo_trws_plan_destroy.restype = None
+        L.stereo_rd_plan_destroy.restype = None
+        L.stereo_fusion_destroy.restype = None
         _lib = L
     return _lib
 

@@ -14,7 +14,12 @@
 // streaming kernels; no contraction (-ffp-contract=off) so that + - * / match numpy.
 #include <hip/hip_runtime.h>
 
+#include <memory>
+
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -275,6 +280,36 @@ __global__ __launch_bounds__(kTB) void globalstereo_unary_kernel(const double *i
   U[px] = log(2.0) - log(exp(ssd * (-1.0 / (col_thresh * C))) + 1.0);
 }
 
+// ---- device-resident fusion moves (stereo_fusion_*) -----------------------------------------
+// dispmap_super.m:78-82: assignment(:, labelling == 1) = proposal(:, labelling == 1); the cached
+// unary of the current assignment follows (the unary is a per-pixel function of the pixel's plane).
+__global__ __launch_bounds__(kTB) void fusion_scatter_kernel(int64_t N, const uint8_t *take, const double *prop,
+                                                            const double *U1, double *cur, double *Ucur) {
+  const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
+  if (i >= N || !take[i]) return;
+  cur[4 * i] = prop[4 * i]; cur[4 * i + 1] = prop[4 * i + 1];
+  cur[4 * i + 2] = prop[4 * i + 2]; cur[4 * i + 3] = prop[4 * i + 3];
+  Ucur[i] = U1[i];
+}
+
+// fixed-shape reduction (same tree for every run): partial[b] = sum of a 2048-element chunk
+__global__ __launch_bounds__(kTB) void fusion_sum_kernel(const double *x, int64_t n, double *partial) {
+  __shared__ double sh[kTB];
+  const int64_t base = (int64_t)blockIdx.x * (kTB * 8);
+  double acc = 0;
+  for (int k = 0; k < 8; ++k) {
+    const int64_t i = base + (int64_t)k * kTB + threadIdx.x;
+    if (i < n) acc += x[i];
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s2 = kTB / 2; s2 > 0; s2 >>= 1) {
+    if ((int)threadIdx.x < s2) sh[threadIdx.x] += sh[threadIdx.x + s2];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
 template <class F>
 int guarded(const char *what, char *err, size_t errcap, F f) {
   if (stereo_hip_device_count() < 1)
@@ -402,6 +437,183 @@ int stereo_globalstereo_unary(const double *im0, const double *im1, int H, int W
     hipLaunchKernelGGL(globalstereo_unary_kernel, dim3(blocks(npx)), dim3(kTB), 0, 0, d0.p, d1.p, H, W, C, dP.p,
                        d_min, d_step, col_thresh, da.p, out.p);
     download(U, out, npx);
+  });
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- fusion context
+
+struct stereo_fusion {
+  int H = 0, W = 0, kernel = 1;
+  int64_t N = 0, E = 0;
+  double tol = 0, d_min = 0, d_step = 0;
+  DevBuf<uint32_t> conn;
+  DevBuf<double> points, weights, cur, prop, Ucur, U1, E00, E01, E10, E11, partial;
+  DevBuf<uint8_t> take;
+  stereo_rd_plan *rd = nullptr;
+  // unary source: 1 = NCC volume (dispmap_ncc.m), 2 = photo-consistency (dispmap_globalstereo.m)
+  int unary_kind = 0;
+  DevBuf<double> ncc, disparities, im0, im1, P2;
+  int D = 0, C = 0;
+  double unary_weight = 0, dmin = 0, dmax = 0, col_thresh = 0;
+  bool have_assignment = false;
+  double energy = 0;
+  std::vector<double> h_lab;
+  std::vector<uint8_t> h_take;
+  ~stereo_fusion() { if (rd) stereo_rd_plan_destroy(rd); }
+};
+
+namespace {
+
+double fusion_sum(stereo_fusion *F, const double *x, int64_t n) {
+  if (n <= 0) return 0;
+  const int64_t nb = (n + kTB * 8 - 1) / (kTB * 8);
+  if ((int64_t)F->partial.n < nb) F->partial.alloc(nb);
+  hipLaunchKernelGGL(fusion_sum_kernel, dim3((unsigned)nb), dim3(kTB), 0, 0, x, n, F->partial.p);
+  std::vector<double> h(nb);
+  STEREO_HIP_CHECK(hipMemcpy(h.data(), F->partial.p, sizeof(double) * nb, hipMemcpyDeviceToHost));
+  double t = 0;
+  for (int64_t i = 0; i < nb; ++i) t += h[i];
+  return t;
+}
+
+void fusion_unary(stereo_fusion *F, const double *d_planes, double *d_out) {
+  if (F->unary_kind == 1) {
+    hipLaunchKernelGGL(ncc_unary_kernel, dim3(blocks(F->N)), dim3(kTB), 0, 0, F->ncc.p, F->H, F->W, F->D, 0,
+                       F->disparities.p, F->dmin, F->dmax, F->unary_weight, d_planes, d_out);
+  } else if (F->unary_kind == 2) {
+    hipLaunchKernelGGL(globalstereo_unary_kernel, dim3(blocks(F->N)), dim3(kTB), 0, 0, F->im0.p, F->im1.p, F->H,
+                       F->W, F->C, F->P2.p, F->d_min, F->d_step, F->col_thresh, d_planes, d_out);
+  } else {
+    throw std::runtime_error("Overload unary_cost");  // dispmap_super.m:200-203
+  }
+}
+
+// dispmap_super.m:263-274 update_energy on the resident assignment
+void fusion_update_energy(stereo_fusion *F) {
+  hipLaunchKernelGGL(pairwise_terms_kernel, dim3(blocks(F->E)), dim3(kTB), 0, 0, F->kernel, F->E, F->conn.p,
+                     F->points.p, F->cur.p, (const double *)nullptr, F->weights.p, F->tol, F->d_min, F->d_step,
+                     F->E00.p, F->E01.p, F->E10.p, F->E11.p);
+  F->energy = fusion_sum(F, F->Ucur.p, F->N) + fusion_sum(F, F->E00.p, F->E);
+}
+
+}  // namespace
+
+extern "C" {
+
+int stereo_fusion_create(int H, int W, int kernel, double tol, int64_t E, const uint32_t *conn,
+                         const double *weights, double d_min, double d_step, stereo_fusion **ctx, char *err,
+                         size_t errcap) {
+  if (!ctx) return fail("stereo_fusion_create: ctx is NULL", err, errcap);
+  *ctx = nullptr;
+  if (kernel != 1 && kernel != 2) return fail("Unkown kernel type", err, errcap);  // dispmap_super.m:233
+  if (H < 1 || W < 1 || E < 0 || (E > 0 && (!conn || !weights))) return fail("stereo_fusion_create: bad argument", err, errcap);
+  std::unique_ptr<stereo_fusion> F(new stereo_fusion);
+  const int rc = guarded("stereo_fusion_create", err, errcap, [&] {
+    F->H = H; F->W = W; F->kernel = kernel; F->tol = tol; F->E = E; F->N = (int64_t)H * W;
+    F->d_min = d_min; F->d_step = d_step;
+    const int64_t N = F->N;
+    std::vector<double> pts(2 * N);
+    for (int64_t i = 0; i < N; ++i) { pts[2 * i] = (double)(i / H + 1); pts[2 * i + 1] = (double)(i % H + 1); }  // :275-278
+    F->conn.upload(conn, 2 * E); F->weights.upload(weights, E); F->points.upload(pts.data(), 2 * N);
+    F->cur.alloc(4 * N); F->prop.alloc(4 * N); F->Ucur.alloc(N); F->U1.alloc(N); F->take.alloc(N);
+    F->E00.alloc(std::max<int64_t>(E, 1)); F->E01.alloc(std::max<int64_t>(E, 1));
+    F->E10.alloc(std::max<int64_t>(E, 1)); F->E11.alloc(std::max<int64_t>(E, 1));
+    F->h_lab.resize(N); F->h_take.resize(N);
+    char e2[256] = {0};
+    if (stereo_rd_plan_create(N, E, conn, &F->rd, e2, sizeof(e2)) != 0) throw std::runtime_error(e2);
+  });
+  if (rc == 0) *ctx = F.release();
+  return rc;
+}
+
+void stereo_fusion_destroy(stereo_fusion *ctx) { delete ctx; }
+
+int stereo_fusion_unary_ncc(stereo_fusion *F, const double *ncc, int D, const double *disparities,
+                            double unary_weight, char *err, size_t errcap) {
+  if (!F || !ncc || !disparities || D < 1) return fail("stereo_fusion_unary_ncc: bad argument", err, errcap);
+  return guarded("stereo_fusion_unary_ncc", err, errcap, [&] {
+    F->ncc.upload(ncc, (size_t)F->N * D); F->disparities.upload(disparities, D);
+    F->D = D; F->unary_weight = unary_weight; F->unary_kind = 1;
+    F->dmin = F->dmax = disparities[0];
+    for (int i = 1; i < D; ++i) { F->dmin = std::min(F->dmin, disparities[i]); F->dmax = std::max(F->dmax, disparities[i]); }
+    F->have_assignment = false;
+  });
+}
+
+int stereo_fusion_unary_globalstereo(stereo_fusion *F, const double *im0, const double *im1, int C,
+                                     const double *P2, double col_thresh, char *err, size_t errcap) {
+  if (!F || !im0 || !im1 || !P2 || C < 1) return fail("stereo_fusion_unary_globalstereo: bad argument", err, errcap);
+  return guarded("stereo_fusion_unary_globalstereo", err, errcap, [&] {
+    F->im0.upload(im0, (size_t)F->N * C); F->im1.upload(im1, (size_t)F->N * C); F->P2.upload(P2, 12);
+    F->C = C; F->col_thresh = col_thresh; F->unary_kind = 2;
+    F->have_assignment = false;
+  });
+}
+
+int stereo_fusion_set_assignment(stereo_fusion *F, const double *assignment, double *energy, char *err,
+                                 size_t errcap) {
+  if (!F || !assignment) return fail("stereo_fusion_set_assignment: bad argument", err, errcap);
+  return guarded("stereo_fusion_set_assignment", err, errcap, [&] {
+    check_planes(assignment, F->N);
+    F->cur.upload(assignment, 4 * F->N);
+    fusion_unary(F, F->cur.p, F->Ucur.p);
+    fusion_update_energy(F);
+    F->have_assignment = true;
+    if (energy) *energy = F->energy;
+  });
+}
+
+int stereo_fusion_get_assignment(stereo_fusion *F, double *assignment, double *energy, char *err, size_t errcap) {
+  if (!F) return fail("stereo_fusion_get_assignment: bad argument", err, errcap);
+  if (!F->have_assignment) return fail("stereo_fusion: no assignment set", err, errcap);
+  return guarded("stereo_fusion_get_assignment", err, errcap, [&] {
+    if (assignment) download(assignment, F->cur, 4 * F->N);
+    if (energy) *energy = F->energy;
+  });
+}
+
+int stereo_fusion_binary(stereo_fusion *F, const double *proposal, int improve, double *energy,
+                         double *rd_energy, double *lower_bound, double *num_unlabelled, char *err,
+                         size_t errcap) {
+  if (!F || !proposal) return fail("stereo_fusion_binary: bad argument", err, errcap);
+  if (!F->have_assignment) return fail("stereo_fusion: no assignment set", err, errcap);
+  return guarded("stereo_fusion_binary", err, errcap, [&] {
+    const int64_t N = F->N, E = F->E;
+    const bool verbose = std::getenv("STEREO_HIP_FUSION_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t[6];
+    t[0] = now();
+    check_planes(proposal, N);
+    F->prop.upload(proposal, 4 * N);
+    hipLaunchKernelGGL(pairwise_terms_kernel, dim3(blocks(E)), dim3(kTB), 0, 0, F->kernel, E, F->conn.p, F->points.p,
+                       F->cur.p, F->prop.p, F->weights.p, F->tol, F->d_min, F->d_step, F->E00.p, F->E01.p,
+                       F->E10.p, F->E11.p);
+    fusion_unary(F, F->prop.p, F->U1.p);
+    if (verbose) STEREO_HIP_CHECK(hipDeviceSynchronize());
+    t[1] = now();
+    double e = 0, lb = 0, unl = 0;
+    char e2[256] = {0};
+    if (stereo_rd_plan_solve_device(F->rd, F->Ucur.p, F->U1.p, F->E00.p, F->E01.p, F->E10.p, F->E11.p, improve,
+                                    F->h_lab.data(), &e, &lb, &unl, e2, sizeof(e2)) != 0)
+      throw std::runtime_error(e2);
+    t[2] = now();
+    for (int64_t i = 0; i < N; ++i) F->h_take[i] = F->h_lab[i] == 1 ? 1 : 0;
+    F->take.upload(F->h_take.data(), N);
+    hipLaunchKernelGGL(fusion_scatter_kernel, dim3(blocks(N)), dim3(kTB), 0, 0, N, F->take.p, F->prop.p, F->U1.p,
+                       F->cur.p, F->Ucur.p);
+    if (verbose) STEREO_HIP_CHECK(hipDeviceSynchronize());
+    t[3] = now();
+    fusion_update_energy(F);
+    t[4] = now();
+    if (verbose)
+      std::fprintf(stderr, "[stereo_hip fusion] upload+terms %.2f ms, qpbo %.2f ms, scatter %.2f ms, energy %.2f ms\n",
+                   t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3]);
+    if (energy) *energy = F->energy;
+    if (rd_energy) *rd_energy = e;
+    if (lower_bound) *lower_bound = lb;
+    if (num_unlabelled) *num_unlabelled = unl;
   });
 }
 

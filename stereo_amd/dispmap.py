@@ -11,6 +11,7 @@ import numpy as np
 
 from . import terms as T
 from ._lib import StereoHipError
+from .fusion import FusionContext
 from .rd import RdPlan, rd  # noqa: F401
 from .trws import trws
 
@@ -29,9 +30,22 @@ class dispmap_super:
         self._kernel = kernel
         self.neighborhood = T.construct_neighborhood(*self.sz)          # zero based 2 x E
         self.points = T.get_points(*self.sz)
-        self.smooth_weights = np.ones(self.neighborhood.shape[1])       # dispmap_super.m:35
+        self._smooth_weights = np.ones(self.neighborhood.shape[1])      # dispmap_super.m:35
         self.d_min, self.d_step = 0.0, 0.0                              # rescaling only in globalstereo
         self._rd_plan = None                                            # device-resident QPBO, built lazily
+        self._ctx = None              # device-resident object state (stereo_fusion_*), built lazily
+        self._ctx_has_assignment = False   # the context holds the current assignment
+        self._host_stale = False           # ... and the host copy is older than the context's
+
+    @property
+    def smooth_weights(self):
+        return self._smooth_weights
+
+    @smooth_weights.setter
+    def smooth_weights(self, w):
+        self._smooth_weights = np.asarray(w, np.float64).reshape(-1)
+        if getattr(self, "_ctx", None) is not None:
+            self._invalidate_ctx()
 
     # ---- properties with the reference's setters (dispmap_super.m:39-56)
     @property
@@ -54,12 +68,40 @@ class dispmap_super:
 
     @property
     def assignment(self):
+        if self._host_stale:          # moves ran on the device: fetch the planes on demand
+            self._assignment, _ = self._ctx.get_assignment()
+            self._host_stale = False
         return self._assignment
 
     @assignment.setter
     def assignment(self, a):
         self._assignment = np.asfortranarray(a, dtype=np.float64)
+        self._host_stale = False
+        self._ctx_has_assignment = False
         self.update_energy()
+
+    # ---- device-resident state
+    def _attach_unary(self, ctx):
+        """Subclasses hand their unary source to the context; False = no device unary."""
+        return False
+
+    def _invalidate_ctx(self):
+        """A parameter the context has baked in (tol, weights, kernel, unary source) changed."""
+        if self._host_stale:
+            self._assignment, _ = self._ctx.get_assignment()
+            self._host_stale = False
+        self._ctx = None
+        self._ctx_has_assignment = False
+
+    def _context(self):
+        if self._ctx is None:
+            ctx = FusionContext(self.sz[0], self.sz[1], self._kernel, self.tol, self.neighborhood,
+                                self.smooth_weights, self.d_min, self.d_step)
+            if not self._attach_unary(ctx):
+                return None
+            self._ctx = ctx
+            self._ctx_has_assignment = False
+        return self._ctx
 
     @property
     def smoothness_kernel(self):
@@ -68,6 +110,7 @@ class dispmap_super:
     @smoothness_kernel.setter
     def smoothness_kernel(self, k):
         self._kernel = k
+        self._invalidate_ctx()
         self.update_energy()
 
     def energy(self):
@@ -95,6 +138,11 @@ class dispmap_super:
         if self._assignment is None or not hasattr(self, "tol"):
             self.stored_energy = np.inf
             return
+        ctx = self._context()
+        if ctx is not None:           # unary, E00 and both sums on the device
+            self.stored_energy = ctx.set_assignment(self.assignment)
+            self._ctx_has_assignment = True
+            return
         U = self.unary_cost(self._assignment)
         P = self.all_pairwise_costs(self._assignment)
         self.stored_energy = float(np.sum(U) + np.sum(P))
@@ -105,6 +153,15 @@ class dispmap_super:
         proposal = np.asfortranarray(proposal, dtype=np.float64)
         if proposal.shape != self._assignment.shape:
             raise StereoHipError("Binary fusion: Proposals is of wrong size")
+        ctx = self._context()
+        if ctx is not None:
+            # device-resident move: only the proposal goes up, four scalars come back
+            if not self._ctx_has_assignment:
+                ctx.set_assignment(self._assignment)
+                self._ctx_has_assignment = True
+            self.stored_energy, e, lb, num_unlabelled = ctx.binary(proposal, self._improve)
+            self._host_stale = True
+            return e, lb, num_unlabelled
         E00, E01, E10, E11 = self.all_pairwise_costs(self._assignment, proposal)
         U0 = self.unary_cost(self._assignment)
         U1 = self.unary_cost(proposal)
@@ -158,7 +215,7 @@ class dispmap_super:
         """dispmap_super.m:153-198"""
         if not isinstance(proposal_cell, (list, tuple)):
             raise StereoHipError("Input proposals should be given in cell array.")
-        props = [np.asfortranarray(p, dtype=np.float64) for p in proposal_cell] + [self._assignment]
+        props = [np.asfortranarray(p, dtype=np.float64) for p in proposal_cell] + [self.assignment]
         unary = np.stack([self.unary_cost(p) for p in props], axis=0)             # K x N
         q, qprim = T.trws_positions(self.neighborhood, self.points, props, self.d_min, self.d_step)
         L, e, lb, iterations = trws(np.int32(self._kernel), unary, self.neighborhood + 1, q, qprim,
@@ -171,7 +228,7 @@ class dispmap_super:
         return e, lb, iterations
 
     def current_dispmap(self):
-        return self.disparitymap_from_assignment(self._assignment).reshape(self.sz[1], self.sz[0]).T
+        return self.disparitymap_from_assignment(self.assignment).reshape(self.sz[1], self.sz[0]).T
 
     def set_disparity(self, disp):
         a = np.zeros((4, self.sz[0] * self.sz[1]))
@@ -200,6 +257,7 @@ class dispmap_ncc(dispmap_super):
         if v < 0:
             raise StereoHipError("Tolerance weight must be positive")
         self._tol = v
+        self._invalidate_ctx()
         self.update_energy()
 
     @property
@@ -211,10 +269,15 @@ class dispmap_ncc(dispmap_super):
         if v < 0:
             raise StereoHipError("Unary weight must be positive")
         self._unary_weight = v
+        self._invalidate_ctx()
         self.update_energy()
 
     def unary_cost(self, assignment):
         return T.ncc_unary(self.ncc, self.disparities, self._unary_weight, assignment)
+
+    def _attach_unary(self, ctx):
+        ctx.unary_ncc(self.ncc, self.disparities, self._unary_weight)
+        return True
 
     def best_disp_from_ncc(self):
         return T.ncc_best_disp(self.ncc, self.disparities)
@@ -273,11 +336,16 @@ class dispmap_globalstereo(dispmap_super):
         if v < 0:
             raise StereoHipError("Tolerance weight must be positive")
         self._tol = v
+        self._invalidate_ctx()
         self.update_energy()
 
     def unary_cost(self, assignment):
         return T.globalstereo_unary(self.images[0], self.images[1], self.P2, self.d_min, self.d_step,
                                     self.options["col_thresh"], assignment)
+
+    def _attach_unary(self, ctx):
+        ctx.unary_globalstereo(self.images[0], self.images[1], self.P2, self.options["col_thresh"])
+        return True
 
     def init_solution(self):
         self.set_disparity(self.start_disparity)

@@ -1,0 +1,70 @@
+"""Device-resident fusion moves (``stereo_fusion_*``): the state of one dispmap object --
+connectivity, weights, current assignment, the unary source -- stays in HBM; a binary
+fusion move uploads the proposal and returns four scalars."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import StereoHipError  # noqa: F401
+
+
+def _f(a):
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+def _p(a, t=C.c_double):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+class FusionContext:
+    def __init__(self, H, W, kernel, tol, conn0, weights, d_min=0.0, d_step=0.0):
+        conn = np.asfortranarray(np.asarray(conn0), dtype=np.uint32)
+        if conn.ndim != 2 or conn.shape[0] != 2:
+            raise StereoHipError("connectivity must be 2 x E")
+        w = _f(np.asarray(weights, np.float64).reshape(-1))
+        self.N, self.E = H * W, conn.shape[1]
+        self._h = C.c_void_p()
+        err = _lib.errbuf()
+        rc = _lib.lib().stereo_fusion_create(C.c_int(H), C.c_int(W), C.c_int(int(kernel)), C.c_double(tol),
+                                            C.c_int64(self.E), _p(conn, C.c_uint32), _p(w), C.c_double(d_min),
+                                            C.c_double(d_step), C.byref(self._h), err, C.c_size_t(len(err)))
+        _lib.check(rc, err)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib().stereo_fusion_destroy(h)
+            self._h = None
+
+    def _call(self, fn, *args):
+        err = _lib.errbuf()
+        _lib.check(fn(self._h, *args, err, C.c_size_t(len(err))), err)
+
+    def unary_ncc(self, ncc, disparities, unary_weight):
+        ncc, d = _f(ncc), _f(np.asarray(disparities, np.float64).reshape(-1))
+        self._call(_lib.lib().stereo_fusion_unary_ncc, _p(ncc), C.c_int(d.shape[0]), _p(d), C.c_double(unary_weight))
+
+    def unary_globalstereo(self, im0, im1, P2, col_thresh):
+        im0, im1 = _f(im0), _f(im1)
+        Cn = 1 if im0.ndim == 2 else im0.shape[2]
+        self._call(_lib.lib().stereo_fusion_unary_globalstereo, _p(im0), _p(im1), C.c_int(Cn),
+                   _p(_f(np.asarray(P2, np.float64))), C.c_double(col_thresh))
+
+    def set_assignment(self, assignment):
+        e = C.c_double()
+        self._call(_lib.lib().stereo_fusion_set_assignment, _p(_f(assignment)), C.byref(e))
+        return e.value
+
+    def get_assignment(self):
+        a = np.zeros((4, self.N), order="F")
+        e = C.c_double()
+        self._call(_lib.lib().stereo_fusion_get_assignment, _p(a), C.byref(e))
+        return a, e.value
+
+    def binary(self, proposal, improve=False):
+        """-> (stored energy after the move, rd energy, rd lower bound, num_unlabelled)"""
+        e, re_, lb, nu = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        self._call(_lib.lib().stereo_fusion_binary, _p(_f(proposal)), C.c_int(int(bool(improve))), C.byref(e),
+                   C.byref(re_), C.byref(lb), C.byref(nu))
+        return e.value, re_.value, lb.value, nu.value
