@@ -152,6 +152,10 @@ typedef struct stereo_rd_plan stereo_rd_plan;
 int stereo_rd_plan_create(int64_t N, int64_t E, const uint32_t *conn, stereo_rd_plan **plan, char *err,
                           size_t errcap);
 void stereo_rd_plan_destroy(stereo_rd_plan *plan);
+/* Optional hint: the N nodes are the pixels of an H x W image numbered col*H + row
+ * (dispmap_super.m:281-282).  Only the internal work partition changes (image patches instead of
+ * index ranges per workgroup: fewer grid-wide barriers), never a result. */
+int stereo_rd_plan_set_grid(stereo_rd_plan *plan, int H, int W, char *err, size_t errcap);
 int stereo_rd_plan_solve(stereo_rd_plan *plan, const double *U0, const double *U1, const double *E00,
                          const double *E01, const double *E10, const double *E11, int improve,
                          double *labelling, double *energy, double *lower_bound,

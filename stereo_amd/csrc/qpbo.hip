@@ -50,6 +50,11 @@ struct QpboDev {
   double *r, *delta, *ex, *snk;
   int32_t *h, *h2;
   int32_t *counters;  // [0] active nodes, [1] frontier size (next), [2] changed flag
+  // tiling for the block-local relabelling: tile T owns positions [T * 1024, (T + 1) * 1024);
+  // perm[pos] = node or -1, pos_of[node] = pos.  A tile holds nodes that are close in the graph
+  // (a 16 x 32 pixel patch and its mates when the grid shape is known).
+  const int32_t *perm, *pos_of;
+  int ntiles;
 };
 
 __global__ __launch_bounds__(kQB) void qpbo_push_kernel(QpboDev g) {
@@ -155,6 +160,7 @@ __device__ __forceinline__ bool grid_sync(int32_t *ctl, unsigned &gen) {
 
 __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *ctl, int relabel_every, int max_rounds) {
   __shared__ int s_red;
+  __shared__ int s_h[kMB];
   unsigned gen = 0;
   const int n = g.n;
   const int first = blockIdx.x * kMB + threadIdx.x, stride = gridDim.x * kMB;
@@ -165,20 +171,63 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     if (blockIdx.x == 0 && threadIdx.x == 0)
       __hip_atomic_store(ctl + base + (slot + 1) % 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  // exact distances to the sink in the residual graph (frontier BFS, pull), then #active nodes
+  // Exact distances to the sink in the residual graph, then #active nodes.  Label correcting
+  // instead of one grid barrier per BFS level: every workgroup relaxes h[v] = min(h[v], h[w] + 1)
+  // over the residual arcs of its tile (heights in LDS, arc status in registers) until nothing
+  // changes inside the tile, then the tiles exchange their boundary heights at a grid barrier;
+  // done when no tile changed.  The fixpoint is the BFS distance whatever the schedule, so the
+  // result is deterministic, and a front crosses a whole tile per barrier instead of one level.
   auto global_relabel = [&](int &active) -> bool {
+    constexpr int kArcRegs = 8;
     for (int v = first; v < n; v += stride) stc(h + v, g.snk[v] > 0 ? 1 : n);
+    // residuals do not change during the relabelling: after this invalidate plain loads of r see
+    // what the (write-through, sc1) pushes stored
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (!grid_sync(ctl, gen)) return false;
-    for (int level = 1;; ++level) {
+    for (;;) {
       slot = (slot + 1) % 3;
       clear_next(QpboCtl::kChanged);
-      bool changed = false;
-      for (int v = first; v < n; v += stride) {
-        if (ldc(h + v) != n) continue;
-        for (int a = g.aptr[v]; a < g.aptr[v + 1]; ++a)
-          if (ldc(g.r + a) > 0 && ldc(h + g.head[a]) == level) { stc(h + v, level + 1); changed = true; break; }
+      bool any_changed = false;
+      for (int T = blockIdx.x; T < g.ntiles; T += gridDim.x) {
+        const int v = g.perm[T * kMB + threadIdx.x];
+        int my = n, winfo[kArcRegs], exth[kArcRegs], a0 = 0, a1 = 0;
+        if (v >= 0) {
+          my = ldc(h + v);
+          a0 = g.aptr[v]; a1 = g.aptr[v + 1];
+        }
+        s_h[threadIdx.x] = my;
+#pragma unroll
+        for (int k = 0; k < kArcRegs; ++k) {
+          winfo[k] = -1; exth[k] = n;
+          if (a0 + k < a1 && g.r[a0 + k] > 0) {
+            const int w = g.head[a0 + k], pw = g.pos_of[w];
+            if (pw / kMB == T) winfo[k] = pw % kMB;
+            else { winfo[k] = -2; exth[k] = ldc(h + w); }
+          }
+        }
+        __syncthreads();
+        const int start = my;
+        bool ch;
+        do {
+          int best = my;
+#pragma unroll
+          for (int k = 0; k < kArcRegs; ++k) {
+            const int hw = winfo[k] >= 0 ? s_h[winfo[k]] : exth[k];
+            best = (winfo[k] != -1 && hw + 1 < best) ? hw + 1 : best;
+          }
+          for (int a = a0 + kArcRegs; a < a1; ++a) {  // nodes of higher degree: the rest from memory
+            if (!(g.r[a] > 0)) continue;
+            const int w = g.head[a], pw = g.pos_of[w];
+            const int hw = pw / kMB == T ? s_h[pw % kMB] : ldc(h + w);
+            best = hw + 1 < best ? hw + 1 : best;
+          }
+          ch = best < my;
+          if (ch) { my = best; s_h[threadIdx.x] = my; }  // heights only decrease: racing readers are harmless
+        } while (__syncthreads_or(ch));
+        if (my < start) { stc(h + v, my); any_changed = true; }
+        __syncthreads();
       }
-      if (__syncthreads_or(changed) && threadIdx.x == 0)
+      if (__syncthreads_or(any_changed) && threadIdx.x == 0)
         __hip_atomic_store(ctl + QpboCtl::kChanged + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (!grid_sync(ctl, gen)) return false;
       if (!ld(QpboCtl::kChanged + slot)) break;
@@ -530,7 +579,7 @@ namespace {
 struct QpboSolver {
   QpboProblem P;
   int n = 0, m = 0;
-  DevBuf<int32_t> d_aptr, d_head, d_rev, d_h, d_h2, d_cnt, d_flags, d_ctl;
+  DevBuf<int32_t> d_aptr, d_head, d_rev, d_h, d_h2, d_cnt, d_flags, d_ctl, d_perm, d_posof;
   DevBuf<double> d_r, d_delta, d_ex, d_snk;
   std::vector<double> snk0;
   QpboDev g{};
@@ -555,10 +604,39 @@ struct QpboSolver {
     STEREO_HIP_CHECK(hipMemset(d_cnt.p, 0, sizeof(int32_t) * 2048));
     g.n = n; g.m = m; g.aptr = d_aptr.p; g.head = d_head.p; g.rev = d_rev.p; g.r = d_r.p;
     g.delta = d_delta.p; g.ex = d_ex.p; g.snk = d_snk.p; g.h = d_h.p; g.h2 = d_h2.p; g.counters = d_cnt.p;
+    set_tiling(P.N, 0, 0);
     STEREO_HIP_CHECK(hipDeviceSynchronize());
   }
 
   int grid() const { return (n + kQB - 1) / kQB; }
+
+  // Tiles of the block-local relabelling.  With the grid shape (pixels numbered col * H + row):
+  // a 16 column x 32 row patch and its mates; otherwise 512 consecutive nodes and their mates.
+  void set_tiling(int64_t Nn, int H, int W) {
+    const int half = kMB / 2;
+    std::vector<int32_t> perm, posof(2 * Nn, -1);
+    if (H > 0 && W > 0 && (int64_t)H * W == Nn) {
+      const int tw = 16, th = half / tw, tc = (W + tw - 1) / tw, tr = (H + th - 1) / th;
+      perm.assign((size_t)tc * tr * kMB, -1);
+      for (int64_t v = 0; v < Nn; ++v) {
+        const int col = (int)(v / H), row = (int)(v % H);
+        const int64_t T = (int64_t)(col / tw) * tr + row / th;
+        const int sl = (col % tw) * th + row % th;
+        perm[T * kMB + sl] = (int32_t)v; perm[T * kMB + half + sl] = (int32_t)(v + Nn);
+      }
+    } else {
+      const int64_t nt = (Nn + half - 1) / half;
+      perm.assign((size_t)nt * kMB, -1);
+      for (int64_t v = 0; v < Nn; ++v) {
+        perm[(v / half) * kMB + v % half] = (int32_t)v;
+        perm[(v / half) * kMB + half + v % half] = (int32_t)(v + Nn);
+      }
+    }
+    for (size_t q = 0; q < perm.size(); ++q)
+      if (perm[q] >= 0) posof[perm[q]] = (int32_t)q;
+    d_perm.upload(perm.data(), perm.size()); d_posof.upload(posof.data(), posof.size());
+    g.perm = d_perm.p; g.pos_of = d_posof.p; g.ntiles = (int)(perm.size() / kMB);
+  }
 
   // exact distances to the sink in the residual graph; returns #active nodes.  Levels are
   // launched in batches, the host only looks at the "anything changed" words between batches.
@@ -626,7 +704,7 @@ struct QpboSolver {
     STEREO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     STEREO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qpbo_maxflow_kernel, kMB, 0));
     if (per_cu < 1) throw HipError{"qpbo_maxflow_kernel does not fit on a CU"};
-    int blocks = std::min(cus * std::min(per_cu, 2), (n + kMB - 1) / kMB);
+    int blocks = std::min(cus * std::min(per_cu, 2), std::max(g.ntiles, 1));
     blocks = std::max(blocks, 1);
     QpboDev gg = g;
     int32_t *ctl = d_ctl.p;
@@ -912,6 +990,7 @@ extern "C" int stereo_rd_plan_create(int64_t N, int64_t E, const uint32_t *conn,
     S.g.n = (int)n; S.g.m = (int)m; S.g.aptr = S.d_aptr.p; S.g.head = S.d_head.p; S.g.rev = S.d_rev.p;
     S.g.r = S.d_r.p; S.g.delta = S.d_delta.p; S.g.ex = S.d_ex.p; S.g.snk = S.d_snk.p; S.g.h = S.d_h.p;
     S.g.h2 = S.d_h2.p; S.g.counters = S.d_cnt.p;
+    S.set_tiling(N, 0, 0);
     STEREO_HIP_CHECK(hipDeviceSynchronize());
     *plan = P.release();
     return 0;
@@ -1018,6 +1097,18 @@ static int rd_plan_solve_device(stereo_rd_plan *P, const double *const in[6], in
     return fail(e.msg, err, errcap);
   } catch (const std::exception &e) {
     return fail(std::string("stereo_rd: ") + e.what(), err, errcap);
+  }
+}
+
+extern "C" int stereo_rd_plan_set_grid(stereo_rd_plan *P, int H, int W, char *err, size_t errcap) {
+  if (!P) return fail("stereo_rd_plan_set_grid: NULL plan", err, errcap);
+  if (H < 1 || W < 1 || (int64_t)H * W != P->N) return fail("stereo_rd_plan_set_grid: H * W must equal N", err, errcap);
+  try {
+    P->S.set_tiling(P->N, H, W);
+    STEREO_HIP_CHECK(hipDeviceSynchronize());
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
   }
 }
 

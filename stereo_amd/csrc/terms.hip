@@ -523,6 +523,7 @@ int stereo_fusion_create(int H, int W, int kernel, double tol, int64_t E, const 
     F->h_lab.resize(N); F->h_take.resize(N);
     char e2[256] = {0};
     if (stereo_rd_plan_create(N, E, conn, &F->rd, e2, sizeof(e2)) != 0) throw std::runtime_error(e2);
+    if (stereo_rd_plan_set_grid(F->rd, H, W, e2, sizeof(e2)) != 0) throw std::runtime_error(e2);
   });
   if (rc == 0) *ctx = F.release();
   return rc;
