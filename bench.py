@@ -60,6 +60,20 @@ def synthetic_volume_device(H, W, K, seed, dev):
     return out
 
 
+def synthetic_pair(H, W, D, seed=0):
+    """A smooth random texture and its warp by a planted disparity field: an image pair for the
+    NCC cost volume (dispmap_ncc) of the end-to-end fusion figure."""
+    rng = np.random.default_rng(seed)
+    tex = rng.uniform(0, 255, size=(H, W + D, 3))
+    for _ in range(3):
+        tex = (tex + np.roll(tex, 1, 0) + np.roll(tex, 1, 1)) / 3
+    disp = (0.15 * D + 0.5 * D * (np.arange(W)[None, :] / W) + 0.08 * D * np.sin(np.arange(H)[:, None] / 40.0)).astype(int)
+    im0 = tex[:, :W]
+    cols = np.clip(np.arange(W)[None, :] + disp, 0, W + D - 1)
+    im1 = np.stack([np.take_along_axis(tex[:, :, c], cols, 1) for c in range(3)], axis=2)
+    return im0, im1
+
+
 def algorithmic_bytes_per_sweep_pair(info_deg, K):
     """per node and sweep read D (K) + every incident message,
     write the outgoing ones; 8-byte reals.  info_deg = (nf, nb) arrays by node."""
@@ -187,7 +201,7 @@ def main():
                 from stereo_amd.rd import RdPlan
                 fp = fusion_problem(5, H, W, kernel=1, tol=8.0)
                 fargs = (fp["U0"], fp["U1"], fp["E00"], fp["E01"], fp["E10"], fp["E11"])
-                rp = RdPlan(N, fp["conn"].T)
+                rp = RdPlan(N, fp["conn"].T, grid=(H, W))
                 rp.solve(*fargs)
                 t1 = time.perf_counter()
                 for _ in range(10):
@@ -202,6 +216,20 @@ def main():
                     tr_ = time.perf_counter() - t1
                     extra["cpu_reference"] = {"moves_per_s": 1.0 / tr_, "kind": "reference", "cores": 1,
                                               "labels_equal": bool(np.array_equal(rlab, flab))}
+                # whole fusion moves through the mirrored class (dispmap_super.m:61-84 + update_energy):
+                # NCC volume, assignment and all terms resident in HBM, one proposal uploaded per move
+                im0, im1 = synthetic_pair(H, W, K)
+                dm = stereo_amd.dispmap_ncc([im0, im1], np.arange(K, dtype=np.float64), 1, 40.0, 8.0)
+                planes = [np.stack([np.zeros(N), np.zeros(N), np.ones(N), np.full(N, -float(d))])
+                          for d in np.linspace(2, K - 3, 9)]
+                dm.binary_fusion(planes[0])
+                t1 = time.perf_counter()
+                for pl in planes[1:]:
+                    dm.binary_fusion(pl)
+                tm = (time.perf_counter() - t1) / (len(planes) - 1)
+                extra["end_to_end"] = {"moves_per_s": 1.0 / tm, "ms_per_move": tm * 1e3, "energy": dm.energy(),
+                                       "what": "dispmap_ncc.binary_fusion on a synthetic %dx%d pair, %d fronto-parallel "
+                                               "proposals: pairwise terms + unaries + QPBO + scatter + energy on the device" % (W, H, len(planes) - 1)}
                 out["binary_fusion"] = extra
             except Exception as exc:  # the headline number must not depend on the secondary one
                 out["binary_fusion"] = {"error": str(exc)}

@@ -693,7 +693,8 @@ struct QpboSolver {
   // One cooperative launch runs the whole max-flow (qpbo_maxflow_kernel); the multi-launch loop
   // is kept behind STEREO_HIP_QPBO_PERSISTENT=0 for comparison.
   void maxflow() {
-    static const bool persistent = [] { const char *e = std::getenv("STEREO_HIP_QPBO_PERSISTENT"); return !(e && std::string(e) == "0"); }();
+    const char *pe = std::getenv("STEREO_HIP_QPBO_PERSISTENT");
+    const bool persistent = !(pe && std::string(pe) == "0");
     if (!persistent) { maxflow_launches(); return; }
     int relabel_every = 256;
     if (const char *e = std::getenv("STEREO_HIP_QPBO_RELABEL_EVERY")) relabel_every = std::max(1, std::atoi(e));

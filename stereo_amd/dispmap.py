@@ -166,7 +166,7 @@ class dispmap_super:
         U0 = self.unary_cost(self._assignment)
         U1 = self.unary_cost(proposal)
         if self._rd_plan is None:      # same solver as rd(...), graph layout kept across moves
-            self._rd_plan = RdPlan(self.sz[0] * self.sz[1], self.neighborhood)
+            self._rd_plan = RdPlan(self.sz[0] * self.sz[1], self.neighborhood, grid=self.sz)
         labelling, e, lb, num_unlabelled = self._rd_plan.solve(U0, U1, E00, E01, E10, E11, self._improve)
         a = self._assignment.copy(order="F")
         take = labelling == 1

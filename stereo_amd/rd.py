@@ -55,7 +55,9 @@ class RdPlan:
     """Device-resident roof-duality solver for one connectivity (stereo_rd_plan_*): repeated
     binary fusions on one image reuse the doubled-graph layout and all device buffers."""
 
-    def __init__(self, N, connectivity0):
+    def __init__(self, N, connectivity0, grid=None):
+        """grid = (H, W): the nodes are the pixels of an H x W image numbered col*H + row (a work
+        partition hint, stereo_rd_plan_set_grid; results do not depend on it)."""
         c = np.asarray(connectivity0)
         if c.ndim != 2 or c.shape[0] != 2:
             raise StereoHipError("connectivity must be 2 x E")
@@ -68,6 +70,10 @@ class RdPlan:
         rc = L.stereo_rd_plan_create(C.c_int64(self.N), C.c_int64(self.E), _p(self._conn, C.c_uint32),
                                      C.byref(self._h), err, C.c_size_t(len(err)))
         _lib.check(rc, err)
+        if grid is not None:
+            rc = L.stereo_rd_plan_set_grid(self._h, C.c_int(int(grid[0])), C.c_int(int(grid[1])), err,
+                                           C.c_size_t(len(err)))
+            _lib.check(rc, err)
 
     def close(self):
         if self._h:
