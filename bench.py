@@ -154,9 +154,10 @@ def main():
         # HBM traffic per launch from the committed PMC passes of this same workload (profiles/),
         # corrected as MI355X_MICROARCH.md prescribes; null if the workload differs from them
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_trws_teddy60_pmc_hbm.json")
-        if (H, W, K) == (375, 450, 60) and os.path.exists(pmc):
-            traffic = json.load(open(pmc))["per_launch"]["hbm_bytes_corrected"]
+        pmc = {(375, 450, 60): "r01_trws_teddy60_pmc_hbm.json",
+               (1000, 1500, 256): "r01_trws_wide256_1500x1000_pmc_hbm.json"}.get((H, W, K))
+        if pmc and os.path.exists(os.path.join(ROOT, "profiles", pmc)):
+            traffic = json.load(open(os.path.join(ROOT, "profiles", pmc)))["per_launch"]["hbm_bytes_corrected"]
         out = {
             "metric": "TRW-S fusion iterations/sec, 450x375x60 labels",
             "value": rate,
