@@ -16,7 +16,7 @@ def init(backend=None):
     """Returns (rank, local_rank, world, dist_or_None).  Rendezvous on 127.0.0.1 unless
     MASTER_ADDR says otherwise."""
     rank, local_rank, world = env_rank()
-    if world <= 1:
+    if world <= 1 and not os.environ.get("STEREO_AMD_FORCE_DIST"):  # (forcing: exercise RCCL on a 1-GPU box)
         return rank, local_rank, world, None
     import torch
     import torch.distributed as dist
