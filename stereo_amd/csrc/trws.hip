@@ -952,6 +952,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
           const int nout = f & 15, nin = (f >> 4) & 15, md = (f >> 16) & 255, ntot = nout + nin;
           const unsigned slA = (unsigned)__builtin_amdgcn_readfirstlane(sti[41]);
           const unsigned slB = (unsigned)__builtin_amdgcn_readfirstlane(sti[42]);
+          if (wave < nout || (BACKWARD && wave == 0)) {  // waves without a message stay out of the way
           double Di = act ? st[kStD + lane] : 0.0;
           double mown = 0;
 #pragma unroll
@@ -995,6 +996,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
               if (act) hcur[j * kWave + lane] = newm;
               if (BACKWARD && lane == 0) sc[j] = v;
             }
+          }
           }
         }
       } else if (wave == kPipeCompute) {
