@@ -77,6 +77,7 @@ struct DevParams {
   int debug;  // development switches (timing experiments only)
   unsigned long long *timeline;  // optional [2][nruns][2] wall-clock stamps (development)
   int window;  // wide kernel: sources within lambda of a destination lie within +-window indices
+  double uniform_step;  // wide kernel: != 0 if pos[k+d] - pos[k] == d * step exactly for |d| <= window <= 16
 };
 
 // ---- agent-scope (sc1) accesses: data handed between workgroups inside one launch
@@ -1165,8 +1166,8 @@ constexpr int kWStage = kWStI + 36;
 // stage: D[kWS] m[8][kWS] a[8] | ints desc[64] px[8]
 
 struct WidePtrs {
-  double *stage0, *hand, *scr, *fb, *pos, *scal;
-  int *dring, *flags, *ctl;
+  double *stage0, *hand, *scr, *fb, *pos, *scal, *msc;
+  int *dring, *flags, *hflag, *ctl;
 };
 __device__ __forceinline__ WidePtrs wide_carve(double *lds) {
   WidePtrs w;
@@ -1176,12 +1177,14 @@ __device__ __forceinline__ WidePtrs wide_carve(double *lds) {
   w.fb = w.scr + kWideCompute * kWScr;       // 4 * kWS : sources, stack, breakpoints of the serial construction
   w.pos = w.fb + 4 * kWS;                    // kWS
   w.scal = w.pos + kWS;                      // 2 * kScalDoubles
-  w.dring = (int *)(w.scal + 2 * kScalDoubles);  // 3 * 64 descriptor words (for the storer)
+  w.msc = w.scal + 2 * kScalDoubles;         // [8][2]: hmin, hmax of H_j for the closest-pair waves
+  w.dring = (int *)(w.msc + 16);             // 3 * 64 descriptor words (for the storer)
   w.flags = w.dring + 3 * 64;                // [8][2] verdicts of the closest-pair waves
-  w.ctl = w.flags + 16;                      // [0] run, [1] abort, [2] lock of the serial scratch
+  w.hflag = w.flags + 16;                    // [8] "H_j is in the min-plus wave's table" (visit token)
+  w.ctl = w.hflag + 8;                       // [0] run, [1] abort, [2] lock of the serial scratch
   return w;
 }
-constexpr int kWideLdsDoubles = 2 * kWStage + 3 * 8 * kWS + kWideCompute * kWScr + 4 * kWS + kWS + 2 * kScalDoubles + 96 + 8 + 2;
+constexpr int kWideLdsDoubles = 2 * kWStage + 3 * 8 * kWS + kWideCompute * kWScr + 4 * kWS + kWS + 2 * kScalDoubles + 16 + 96 + 8 + 4 + 2;
 static_assert(kWideLdsDoubles * 8 <= 160 * 1024, "wide kernel LDS");
 
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
@@ -1292,12 +1295,17 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
   constexpr int DW = TrwsGraph::kDescWords;
   const int32_t *desc = p.desc[D];
   for (int k = tid; k < kWS; k += kWideThreads) L.pos[k] = k < K ? p.pos[k] : inf;
+  // positions on an exact arithmetic progression (checked on the host: pos[k+d] - pos[k] == d * step
+  // bit for bit): the min-plus source table then holds h only and alpha |d step| is formed once per d
+  const double ustep = p.uniform_step;
+  const bool uniform = ustep != 0;
   if (wave < kWideCompute && wave % 3 == 0 && lane < 2 * kWPad) {
     // padding of the min-plus source tables, never overwritten afterwards
-    double2 *tab = (double2 *)(L.scr + wave * kWScr);
-    tab[lane < kWPad ? lane : K + lane] = make_double2(inf, 0.0);
+    if (uniform) (L.scr + wave * kWScr)[lane < kWPad ? lane : K + lane] = inf;
+    else ((double2 *)(L.scr + wave * kWScr))[lane < kWPad ? lane : K + lane] = make_double2(inf, 0.0);
   }
   if (tid < 16) L.flags[tid] = -1;
+  if (tid < 8) L.hflag[tid] = -1;
   if (tid == 0) { L.ctl[1] = 0; L.ctl[2] = 0; }
   double posr[4];  // this lane's four label positions
 #pragma unroll
@@ -1355,16 +1363,19 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
           const bool fast_msg = KERNEL == 1 && p.certificate != 0;
           const bool working = j0 < nout && (role == 0 || fast_msg);
           if (working || (BACKWARD && wave == 0)) {
+            bool valid[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) valid[c] = c * kWave + lane < K;
+            double di[4] = {inf, inf, inf, inf};
+            if (role == 0) {
             const unsigned slA = (unsigned)__builtin_amdgcn_readfirstlane(sti[41]);
             const unsigned slB = (unsigned)__builtin_amdgcn_readfirstlane(sti[42]);
             // Di = D + messages in list order (from the ring where the neighbour was one of
-            // the last two visits of this run); every working wave forms it itself
+            // the last two visits of this run), formed by the min-plus wave of each message
             // (reads are unconditional -- rows are padded to 256 -- and masked afterwards, so that
             // all of them are in flight together)
-            double di[4];
-            bool valid[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { valid[c] = c * kWave + lane < K; di[c] = st[c * kWave + lane]; }
+            for (int c = 0; c < 4; ++c) di[c] = st[c * kWave + lane];
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
               if (jj < ntot) {
@@ -1383,25 +1394,57 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
 #pragma unroll
               for (int c = 0; c < 4; ++c) di[c] -= node_vmin;
             }
+            }
             WSTAMP(0);
             for (int j = j0; working && j < nout; j += 4) {
               const double gamma = (double)1 / (double)(nout > nin ? nout : nin);
               const double alpha = st[kWS + 8 * kWS + j];
-              double h[4], hlo = inf, hhi = -inf;
+              const bool constant = UNI(alpha == 0);
+              double h[4] = {inf, inf, inf, inf}, hmin = 0, hmax = 0;
+              double2 *mtab = (double2 *)(L.scr + (wave - role) * kWScr) + kWPad;  // the min-plus wave's (h, q) table
+              double *htab = L.scr + (wave - role) * kWScr + kWPad;                // ... or h only (uniform positions)
+              if (role == 0) {
+                double hlo = inf, hhi = -inf;
 #pragma unroll
-              for (int c = 0; c < 4; ++c) h[c] = gamma * di[c] - st[kWS + j * kWS + c * kWave + lane];
+                for (int c = 0; c < 4; ++c) h[c] = gamma * di[c] - st[kWS + j * kWS + c * kWave + lane];
 #pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                hlo = fmin(hlo, valid[c] ? h[c] : inf); hhi = fmax(hhi, valid[c] ? h[c] : -inf);
-                h[c] = valid[c] ? h[c] : inf;
+                for (int c = 0; c < 4; ++c) {
+                  hlo = fmin(hlo, valid[c] ? h[c] : inf); hhi = fmax(hhi, valid[c] ? h[c] : -inf);
+                  h[c] = valid[c] ? h[c] : inf;
+                }
+                hmin = wave_min_dpp(hlo); hmax = wave_max_dpp(hhi);
+                if (fast_msg && !constant) {
+                  // publish H_j for the two closest-pair waves (and as this wave's source table)
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) {
+                    if (valid[c]) {
+                      if (uniform) htab[c * kWave + lane] = h[c];
+                      else mtab[c * kWave + lane] = make_double2(h[c], posr[c]);
+                    }
+                  }
+                  if (lane == 0) { L.msc[2 * j] = hmin; L.msc[2 * j + 1] = hmax; }
+                  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                  if (lane == 0) __hip_atomic_store(L.hflag + j, pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+              } else if (!constant) {
+                int spins = 0;
+                while (__hip_atomic_load(L.hflag + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != pos) {
+                  __builtin_amdgcn_s_sleep(0);
+                  if (++spins > kSpinLimit) { if (lane == 0) L.ctl[1] = 1; break; }  // bounded
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                double hv[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) hv[c] = uniform ? htab[c * kWave + lane] : mtab[c * kWave + lane].x;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) h[c] = valid[c] ? hv[c] : inf;
+                hmin = L.msc[2 * j]; hmax = L.msc[2 * j + 1];
               }
-              const double hmin = wave_min_dpp(hlo), hmax = wave_max_dpp(hhi);
               const double vtrunc = hmin + alpha * p.lambda;
               const double ap0 = alpha * pos_first, ap1 = alpha * pos_last;
               const double aplo = fmin(ap0, ap1), aphi = fmax(ap0, ap1);
               const double mag = fmax(fabs(hmin), fabs(hmax)) + 2 * fmax(fabs(ap0), fabs(ap1));
               const double delta = 1e-9 * (mag + fabs(alpha * p.lambda));
-              const bool constant = UNI(alpha == 0);
               double *scr = L.scr + wave * kWScr;
               WSTAMP(1);
               if (role != 0) {
@@ -1430,10 +1473,8 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
                   vmin = hmin;
                 } else {
                   // source table: (h, q) pairs at index kWPad + k, (+inf, 0) padding on both sides
-                  double2 *tab = (double2 *)scr + kWPad;
-#pragma unroll
-                  for (int c = 0; c < 4; ++c)
-                    if (valid[c]) tab[c * kWave + lane] = make_double2(h[c], posr[c]);
+                  // (written above, when H_j was published)
+                  double2 *tab = mtab;
                   WSYNC();
                   bool serial = !fast_msg;
                   if (fast_msg) {
@@ -1441,7 +1482,21 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
                     // (equal costs from two sources count as a zero margin: serial path decides)
                     double m1[4] = {inf, inf, inf, inf}, m2[4] = {inf, inf, inf, inf};
                     const int w = (p.debug & 32) ? 0 : p.window;
-                    if (w <= kWPad) {
+                    if (uniform && w <= kWPad) {
+                      for (int d = -w; d <= w; ++d) {
+                        const double ad = alpha * fabs((double)d * ustep);  // == alpha |t - q| exactly
+                        double hs[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) hs[c] = htab[c * kWave + lane + d];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                          const double cst = ad + hs[c];
+                          const double lo_ = fmin(m1[c], cst), hi_ = fmax(m1[c], cst);
+                          m2[c] = fmin(m2[c], hi_);
+                          m1[c] = lo_;
+                        }
+                      }
+                    } else if (w <= kWPad) {
                       for (int d = -w; d <= w; ++d) {
                         double2 sv[4];
 #pragma unroll
@@ -1813,6 +1868,7 @@ struct stereo_trws_plan {
   bool wide = false;  // 64 < K <= 256 with shared strictly ascending positions: trws_wide_kernel
   bool wide_allowed = false;
   int window = 0;
+  double uniform_step = 0;
   DevBuf<unsigned long long> d_fallbacks, d_prof, d_timeline;
   bool certificate = true;
   int epoch = 0;
@@ -1871,6 +1927,7 @@ DevParams make_params(stereo_trws_plan *P) {
   p.desc[0] = P->d_desc[0].p; p.desc[1] = P->d_desc[1].p;
   p.prof_run = -1;
   p.window = P->window;
+  p.uniform_step = P->uniform_step;
   p.debug = 0;
   if (const char *dbg = std::getenv("STEREO_HIP_TRWS_DEBUG")) p.debug = std::atoi(dbg);
   if (const char *pr = std::getenv("STEREO_HIP_TRWS_PROF_RUN")) p.prof_run = std::atoi(pr);
@@ -1987,7 +2044,7 @@ void finish_inputs(stereo_trws_plan *P) {
   }
   STEREO_HIP_CHECK(hipDeviceSynchronize());
   // wide-label kernel: shared positions that are finite and strictly ascending
-  P->wide = false;
+  P->wide = false; P->uniform_step = 0;
   if (P->wide_allowed && P->pos && P->lambda >= 0) {
     std::vector<double> hp(P->K);
     STEREO_HIP_CHECK(hipMemcpy(hp.data(), P->pos, sizeof(double) * P->K, hipMemcpyDeviceToHost));
@@ -2006,6 +2063,15 @@ void finish_inputs(stereo_trws_plan *P) {
       }
       P->window = w;
       P->wide = true;
+      // exact arithmetic progression inside the window?  (then alpha |t - q| = alpha |d step| bit for bit)
+      P->uniform_step = 0;
+      if (w <= 16 && P->K > 1) {
+        const double step = hp[1] - hp[0];
+        bool uni = step > 0;
+        for (int d = 1; d <= w && uni; ++d)
+          for (int k = 0; k + d < P->K && uni; ++k) uni = (hp[k + d] - hp[k]) == (double)d * step;
+        if (uni) P->uniform_step = step;
+      }
     }
   }
   P->have_inputs = true;
