@@ -836,23 +836,27 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
       // The sources are broadcast from a per-wave LDS table (one ds_read_b128 per source instead of
       // eight v_readlane); two sources per trip keep two independent dependency chains in flight.
       // m1 / m2 = smallest and second smallest DISTINCT cost seen so far.
+      // table entry of a source: (h, q, u, v) -- the tangency test then needs no arithmetic on the source
       if (hq) {
-        hq[2 * lane] = h; hq[2 * lane + 1] = qsrc;
+        hq[4 * lane] = h; hq[4 * lane + 1] = qsrc; hq[4 * lane + 2] = ui; hq[4 * lane + 3] = vi;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
-#define STEREO_SRC(J, HJ, QJ)                                                       \
-  double HJ, QJ;                                                                     \
-  if (hq) { HJ = hq[2 * (J)]; QJ = hq[2 * (J) + 1]; }                                \
-  else { HJ = readlane_f64(h, (J)); QJ = readlane_f64(qsrc, (J)); }
+#define STEREO_SRC(J, HJ, QJ)                                                        \
+  double HJ, QJ, HJ##u, HJ##v;                                                       \
+  if (hq) { HJ = hq[4 * (J)]; QJ = hq[4 * (J) + 1]; HJ##u = hq[4 * (J) + 2]; HJ##v = hq[4 * (J) + 3]; } \
+  else {                                                                             \
+    HJ = readlane_f64(h, (J)); QJ = readlane_f64(qsrc, (J));                         \
+    const double aqj_ = alpha * QJ;                                                  \
+    HJ##u = HJ - aqj_; HJ##v = HJ + aqj_;                                            \
+  }
 #define STEREO_ACC(HJ, QJ)                                                           \
   {                                                                                  \
     const double c = pair_cost<1>(alpha, t - QJ, HJ);                                \
-    const double lo = min_raw(m1, c), hi = max_raw(m1, c);                                 \
-    m2 = hi > lo ? min_raw(m2, hi) : m2;                                                \
+    const double lo = min_raw(m1, c), hi = max_raw(m1, c);                           \
+    m2 = hi > lo ? min_raw(m2, hi) : m2;                                             \
     m1 = lo;                                                                         \
-    const double aqj = alpha * QJ;                                                   \
-    const bool near = (fabs(ui - (HJ - aqj)) <= delta) || (fabs(vi - (HJ + aqj)) <= delta); \
+    const bool near = (fabs(ui - HJ##u) <= delta) || (fabs(vi - HJ##v) <= delta);    \
     bad = bad || (near && qsrc != QJ);                                               \
   }
       while (mask) {
@@ -922,8 +926,8 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
   double *stage0 = lds;                                   // 2 stages
   double *hand = lds + 2 * kStageDoubles;                 // ring of 4 x 8 x 64: the last visits' new messages
   double *scal = hand + 4 * 8 * kWave;                    // 2 x kScalDoubles
-  double *hqtab = scal + 2 * kScalDoubles;                // per compute wave: 64 x (h, q)
-  int *ctl = (int *)(hqtab + kPipeCompute * 2 * kWave);   // [0] run, [1] abort
+  double *hqtab = scal + 2 * kScalDoubles;                // per compute wave: 64 x (h, q, u, v)
+  int *ctl = (int *)(hqtab + kPipeCompute * 4 * kWave);   // [0] run, [1] abort
   const int K = p.K;
   const double inf = __builtin_huge_val();
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -1007,7 +1011,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
               const double alpha = st[kStA + j];
               double newm = 0;
               const double v = message_regs<KERNEL>(p, K, alpha, h, qsrc, qdst, perm, newm, lane,
-                                                    hqtab + wave * 2 * kWave);
+                                                    hqtab + wave * 4 * kWave);
               if (act) hcur[j * kWave + lane] = newm;
               if (BACKWARD && lane == 0) sc[j] = v;
             }
@@ -1970,7 +1974,7 @@ void launch_persistent(stereo_trws_plan *P, const DevParams &p, int what, hipStr
     return;
   }
   if (P->fast) {
-    const size_t plds = sizeof(double) * (2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * 2 * kWave + 2);
+    const size_t plds = sizeof(double) * (2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * 4 * kWave + 2);
     const bool sh = P->pos != nullptr;
     const dim3 pblock(kPipeThreads);
 #define PIPE(BW, PR, UP)                                                                          \
