@@ -240,6 +240,13 @@ int stereo_fusion_get_assignment(stereo_fusion *ctx, double *assignment, double 
 int stereo_fusion_binary(stereo_fusion *ctx, const double *proposal, int improve, double *energy,
                          double *rd_energy, double *lower_bound, double *num_unlabelled, char *err,
                          size_t errcap);
+/* one simultaneous fusion (dispmap_super.m:153-198): the K proposals (4 x N x K) and the current
+ * assignment (appended as label K+1, :160) compete per pixel; unary K x N, q / qprim K x E, TRW-S
+ * (stereo_trws_plan, options maxiter / max_relgap as in trws.m) and the scatter of the winning
+ * planes run on the device.  energy = stored energy afterwards; the other three are trws.m's. */
+int stereo_fusion_simultaneous(stereo_fusion *ctx, const double *proposals, int K, double maxiter,
+                               double max_relgap, double *energy, double *trws_energy,
+                               double *lower_bound, double *iterations, char *err, size_t errcap);
 
 #ifdef __cplusplus
 }

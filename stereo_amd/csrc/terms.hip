@@ -292,6 +292,26 @@ __global__ __launch_bounds__(kTB) void fusion_scatter_kernel(int64_t N, const ui
   Ucur[i] = U1[i];
 }
 
+// unary of proposal k into the K x N (label fastest) layout TRW-S consumes
+__global__ __launch_bounds__(kTB) void fusion_interleave_kernel(int64_t N, int K, int k, const double *Uk,
+                                                               double *unary) {
+  const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
+  if (i < N) unary[i * K + k] = Uk[i];
+}
+
+// dispmap_super.m:189-195: every pixel takes the plane of the proposal TRW-S chose for it;
+// its unary follows from the K x N table
+__global__ __launch_bounds__(kTB) void fusion_select_kernel(int64_t N, int K, const int32_t *label,
+                                                           const double *props, const double *unary,
+                                                           double *cur, double *Ucur) {
+  const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
+  if (i >= N) return;
+  const int k = label[i];
+  const double *P = props + (size_t)k * 4 * N + 4 * i;
+  cur[4 * i] = P[0]; cur[4 * i + 1] = P[1]; cur[4 * i + 2] = P[2]; cur[4 * i + 3] = P[3];
+  Ucur[i] = unary[i * K + k];
+}
+
 // fixed-shape reduction (same tree for every run): partial[b] = sum of a 2048-element chunk
 __global__ __launch_bounds__(kTB) void fusion_sum_kernel(const double *x, int64_t n, double *partial) {
   __shared__ double sh[kTB];
@@ -452,6 +472,12 @@ struct stereo_fusion {
   DevBuf<double> points, weights, cur, prop, Ucur, U1, E00, E01, E10, E11, partial;
   DevBuf<uint8_t> take;
   stereo_rd_plan *rd = nullptr;
+  stereo_trws_plan *trws = nullptr;  // simultaneous fusion: plan of the last label count
+  int trws_K = 0;
+  DevBuf<double> props, unaryK, qK, qpK;
+  DevBuf<int32_t> labels;
+  std::vector<uint32_t> h_conn;
+  std::vector<int32_t> h_label;
   // unary source: 1 = NCC volume (dispmap_ncc.m), 2 = photo-consistency (dispmap_globalstereo.m)
   int unary_kind = 0;
   DevBuf<double> ncc, disparities, im0, im1, P2;
@@ -461,7 +487,10 @@ struct stereo_fusion {
   double energy = 0;
   std::vector<double> h_lab;
   std::vector<uint8_t> h_take;
-  ~stereo_fusion() { if (rd) stereo_rd_plan_destroy(rd); }
+  ~stereo_fusion() {
+    if (rd) stereo_rd_plan_destroy(rd);
+    if (trws) stereo_trws_plan_destroy(trws);
+  }
 };
 
 namespace {
@@ -517,6 +546,7 @@ int stereo_fusion_create(int H, int W, int kernel, double tol, int64_t E, const 
     std::vector<double> pts(2 * N);
     for (int64_t i = 0; i < N; ++i) { pts[2 * i] = (double)(i / H + 1); pts[2 * i + 1] = (double)(i % H + 1); }  // :275-278
     F->conn.upload(conn, 2 * E); F->weights.upload(weights, E); F->points.upload(pts.data(), 2 * N);
+    F->h_conn.assign(conn, conn + 2 * E);
     F->cur.alloc(4 * N); F->prop.alloc(4 * N); F->Ucur.alloc(N); F->U1.alloc(N); F->take.alloc(N);
     F->E00.alloc(std::max<int64_t>(E, 1)); F->E01.alloc(std::max<int64_t>(E, 1));
     F->E10.alloc(std::max<int64_t>(E, 1)); F->E11.alloc(std::max<int64_t>(E, 1));
@@ -615,6 +645,62 @@ int stereo_fusion_binary(stereo_fusion *F, const double *proposal, int improve, 
     if (rd_energy) *rd_energy = e;
     if (lower_bound) *lower_bound = lb;
     if (num_unlabelled) *num_unlabelled = unl;
+  });
+}
+
+int stereo_fusion_simultaneous(stereo_fusion *F, const double *proposals, int K, double maxiter,
+                               double max_relgap, double *energy, double *trws_energy, double *lower_bound,
+                               double *iterations, char *err, size_t errcap) {
+  if (!F || !proposals || K < 1) return fail("stereo_fusion_simultaneous: bad argument", err, errcap);
+  if (!F->have_assignment) return fail("stereo_fusion: no assignment set", err, errcap);
+  return guarded("stereo_fusion_simultaneous", err, errcap, [&] {
+    const int64_t N = F->N, E = F->E;
+    const int Kt = K + 1;  // proposals{end+1} = self.assignment (dispmap_super.m:160)
+    check_planes(proposals, N * K);
+    char e2[256] = {0};
+    if (!F->trws || F->trws_K != Kt) {
+      if (F->trws) { stereo_trws_plan_destroy(F->trws); F->trws = nullptr; }
+      if (stereo_trws_plan_create(F->kernel, Kt, N, E, F->h_conn.data(), STEREO_TRWS_MESSAGES_EXACT, &F->trws, e2,
+                                  sizeof(e2)) != 0)
+        throw std::runtime_error(e2);
+      F->trws_K = Kt;
+      F->props.alloc((size_t)4 * N * Kt); F->unaryK.alloc((size_t)N * Kt);
+      F->qK.alloc((size_t)std::max<int64_t>(E, 1) * Kt); F->qpK.alloc((size_t)std::max<int64_t>(E, 1) * Kt);
+      F->labels.alloc(N); F->h_label.resize(N);
+    }
+    STEREO_HIP_CHECK(hipMemcpy(F->props.p, proposals, sizeof(double) * 4 * N * K, hipMemcpyHostToDevice));
+    STEREO_HIP_CHECK(hipMemcpy(F->props.p + (size_t)4 * N * K, F->cur.p, sizeof(double) * 4 * N, hipMemcpyDeviceToDevice));
+    // unary (K x N, dispmap_super.m:164-172) and positions (:177-183) on the device
+    for (int k = 0; k < Kt; ++k) {
+      if (k < K) fusion_unary(F, F->props.p + (size_t)k * 4 * N, F->U1.p);
+      hipLaunchKernelGGL(fusion_interleave_kernel, dim3(blocks(N)), dim3(kTB), 0, 0, N, Kt, k,
+                         k < K ? F->U1.p : F->Ucur.p, F->unaryK.p);
+    }
+    if (E > 0)
+      hipLaunchKernelGGL(trws_positions_kernel, dim3(blocks(E * Kt)), dim3(kTB), 0, 0, E, Kt, N, F->conn.p, F->points.p,
+                         F->props.p, F->d_min, F->d_step, F->qK.p, F->qpK.p);
+    STEREO_HIP_CHECK(hipDeviceSynchronize());
+    if (stereo_trws_plan_bind_device(F->trws, F->unaryK.p, F->qK.p, F->qpK.p, nullptr, F->weights.p, F->tol, e2,
+                                     sizeof(e2)) != 0 ||
+        stereo_trws_plan_reset(F->trws, e2, sizeof(e2)) != 0)
+      throw std::runtime_error(e2);
+    // Minimize_TRW_S runs at least one iteration and stops at iter >= iterMax (minimize.cpp:100-112)
+    int iters = maxiter >= 1 ? (maxiter > 2e9 ? 2000000000 : (int)maxiter) : 1;
+    int done = 0, stopped = 0;
+    if (stereo_trws_plan_iterate(F->trws, iters, max_relgap, nullptr, &done, &stopped, e2, sizeof(e2)) != 0)
+      throw std::runtime_error(e2);
+    double te = 0, tlb = 0, tit = 0;
+    if (stereo_trws_plan_result(F->trws, F->h_lab.data(), &te, &tlb, &tit, e2, sizeof(e2)) != 0)
+      throw std::runtime_error(e2);
+    for (int64_t i = 0; i < N; ++i) F->h_label[i] = (int32_t)F->h_lab[i] - 1;
+    F->labels.upload(F->h_label.data(), N);
+    hipLaunchKernelGGL(fusion_select_kernel, dim3(blocks(N)), dim3(kTB), 0, 0, N, Kt, F->labels.p, F->props.p,
+                       F->unaryK.p, F->cur.p, F->Ucur.p);
+    fusion_update_energy(F);
+    if (energy) *energy = F->energy;
+    if (trws_energy) *trws_energy = te;
+    if (lower_bound) *lower_bound = tlb;
+    if (iterations) *iterations = tit;
   });
 }
 

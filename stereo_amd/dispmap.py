@@ -215,6 +215,15 @@ class dispmap_super:
         """dispmap_super.m:153-198"""
         if not isinstance(proposal_cell, (list, tuple)):
             raise StereoHipError("Input proposals should be given in cell array.")
+        ctx = self._context()
+        if ctx is not None:
+            # device-resident: proposals go up, unary / positions / TRW-S / scatter stay in HBM
+            if not self._ctx_has_assignment:
+                ctx.set_assignment(self._assignment)
+                self._ctx_has_assignment = True
+            self.stored_energy, e, lb, iterations = ctx.simultaneous(proposal_cell, self.maxiter, self._max_relgap)
+            self._host_stale = True
+            return e, lb, iterations
         props = [np.asfortranarray(p, dtype=np.float64) for p in proposal_cell] + [self.assignment]
         unary = np.stack([self.unary_cost(p) for p in props], axis=0)             # K x N
         q, qprim = T.trws_positions(self.neighborhood, self.points, props, self.d_min, self.d_step)

@@ -68,3 +68,12 @@ class FusionContext:
         self._call(_lib.lib().stereo_fusion_binary, _p(_f(proposal)), C.c_int(int(bool(improve))), C.byref(e),
                    C.byref(re_), C.byref(lb), C.byref(nu))
         return e.value, re_.value, lb.value, nu.value
+
+    def simultaneous(self, proposals, maxiter=1000, max_relgap=0.0):
+        """proposals: list of 4 x N plane arrays (the current assignment is appended on the device).
+        -> (stored energy afterwards, trws energy, lower bound, iterations)"""
+        stack = np.asfortranarray(np.stack([np.asarray(P, np.float64) for P in proposals], axis=2))  # 4 x N x K
+        e, te, lb, it = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        self._call(_lib.lib().stereo_fusion_simultaneous, _p(stack), C.c_int(len(proposals)), C.c_double(maxiter),
+                   C.c_double(max_relgap), C.byref(e), C.byref(te), C.byref(lb), C.byref(it))
+        return e.value, te.value, lb.value, it.value

@@ -80,3 +80,38 @@ def test_context_api_and_errors(hip):
         ctx.binary(bad)
     with pytest.raises(hip.StereoHipError, match="Unkown kernel type"):
         FusionContext(H, W, 3, 2.0, conn, np.ones(conn.shape[1]))
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_context_simultaneous_equals_stateless(kernel, hip):
+    """stereo_fusion_simultaneous (unary K x N, q / qprim, TRW-S and the scatter on the device) vs
+    the same fusion assembled from the stateless entry points: identical planes, TRW-S energy,
+    bound and iteration count; stored energy to 1e-12."""
+    from stereo_amd import terms as T
+    im0, im1 = _crop()
+    disps = np.arange(0, 24.0)
+    tol = 8.0 if kernel == 1 else 30.0
+    dm = hip.dispmap_ncc([im0, im1], disps, kernel, 40.0, tol)
+    dm.maxiter, dm.max_relgap = 12, 1e-6
+    N = im0.shape[0] * im0.shape[1]
+    props = [ot.fronto_parallel(d, N) for d in (2.0, 7.0, 12.0, 18.0)] + [
+        np.stack([np.full(N, 0.05), np.full(N, -0.02), np.ones(N), np.full(N, -8.0)])]
+    a0 = dm.assignment.copy(order="F")
+    allp = props + [a0]
+    unary = np.stack([dm.unary_cost(p) for p in allp], axis=0)
+    q, qp = T.trws_positions(dm.neighborhood, dm.points, allp)
+    L, e, lb, it = hip.trws(np.int32(kernel), unary, dm.neighborhood + 1, q, qp, dm.smooth_weights, tol,
+                            {"maxiter": 12, "max_relgap": 1e-6})
+    want = np.zeros_like(a0)
+    for k, p in enumerate(allp):
+        want[:, L == k + 1] = p[:, L == k + 1]
+    e2, lb2, it2 = dm.simultaneous_fusion(props)
+    assert np.array_equal(dm.assignment, want)
+    assert e2 == e and lb2 == lb and it2 == it
+    U = dm.unary_cost(want)
+    P = T.pairwise_terms(kernel, dm.neighborhood, dm.points, want, None, dm.smooth_weights, tol)
+    en = float(U.sum() + P.sum())
+    assert abs(dm.energy() - en) <= 1e-12 * abs(en)
+    # a binary move after it still works on the resident state
+    dm.binary_fusion(props[0])
+    assert np.isfinite(dm.energy())

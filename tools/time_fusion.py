@@ -35,3 +35,13 @@ for p in props[:3]:
     dm.binary_fusion(p)
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
+
+# simultaneous fusion (dispmap_super.m:153-198) of 7 proposals + current, 20 TRW-S iterations
+dm.maxiter, dm.max_relgap = 20, 0.0
+sp = [ot.fronto_parallel(float(d), N) for d in (4, 12, 20, 28, 36, 44, 52)]
+dm.simultaneous_fusion(sp)
+t = time.time()
+e, lb, it = dm.simultaneous_fusion(sp)
+dt = time.time() - t
+print("simultaneous_fusion K=%d: %.3f s for %d iterations (%.1f it/s incl. unary/positions/scatter), energy %.3f lb %.3f" % (
+    len(sp) + 1, dt, it, it / dt, e, lb))
