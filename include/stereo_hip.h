@@ -152,6 +152,8 @@ typedef struct stereo_rd_plan stereo_rd_plan;
 int stereo_rd_plan_create(int64_t N, int64_t E, const uint32_t *conn, stereo_rd_plan **plan, char *err,
                           size_t errcap);
 void stereo_rd_plan_destroy(stereo_rd_plan *plan);
+/* Device pointer to the labels of the last solve: N int8 in {-1, 0, 1} (valid until the next solve). */
+const int8_t *stereo_rd_plan_device_labels(stereo_rd_plan *plan);
 /* Optional hint: the N nodes are the pixels of an H x W image numbered col*H + row
  * (dispmap_super.m:281-282).  Only the internal work partition changes (image patches instead of
  * index ranges per workgroup: fewer grid-wide barriers), never a result. */
@@ -160,7 +162,8 @@ int stereo_rd_plan_solve(stereo_rd_plan *plan, const double *U0, const double *U
                          const double *E01, const double *E10, const double *E11, int improve,
                          double *labelling, double *energy, double *lower_bound,
                          double *num_unlabelled, char *err, size_t errcap);
-/* the same with the six term arrays already in HBM (e.g. written by the term-builder kernels) */
+/* the same with the six term arrays already in HBM (e.g. written by the term-builder kernels);
+ * labelling may be NULL: the labels then stay on the device (stereo_rd_plan_device_labels) */
 int stereo_rd_plan_solve_device(stereo_rd_plan *plan, const double *d_U0, const double *d_U1,
                                 const double *d_E00, const double *d_E01, const double *d_E10,
                                 const double *d_E11, int improve, double *labelling, double *energy,

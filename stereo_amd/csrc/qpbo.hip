@@ -445,6 +445,18 @@ __global__ __launch_bounds__(kQB) void rd_nodes_kernel(RdPlanDev d) {
   d.ex[v + d.N] = t < 0 ? -t : 0.0; d.snk[v + d.N] = t > 0 ? t : 0.0;  // mate: -t (QPBO.cpp:689)
 }
 
+// strong persistency on the device (QPBO.cpp:840-844): x_i = 1 iff i reaches the sink, 0 iff its
+// mate does, -1 if both or neither; counts the -1s
+__global__ __launch_bounds__(kQB) void rd_labels_kernel(int64_t N, int n, const int32_t *h, int8_t *label,
+                                                       int32_t *unlabelled) {
+  const int64_t i = (int64_t)blockIdx.x * kQB + threadIdx.x;
+  if (i >= N) return;
+  const int li = h[i] < n ? 1 : 0, lm = h[i + N] < n ? 1 : 0;
+  const int l = li == lm ? -1 : li;
+  label[i] = (int8_t)l;
+  if (l < 0) atomicAdd(unlabelled, 1);
+}
+
 // fixed-shape reduction (same tree for every run): partial[b] = sum of a 2048-element chunk
 __global__ __launch_bounds__(kQB) void det_sum_kernel(const double *x, int64_t n, double *partial) {
   __shared__ double sh[kQB];
@@ -1081,19 +1093,25 @@ static int rd_plan_solve_device(stereo_rd_plan *P, const double *const in[6], in
       STEREO_HIP_CHECK(hipDeviceSynchronize());
       std::fprintf(stderr, "[stereo_hip qpbo plan] maxflow %.3f ms\n", now() - tm0);
     }
-    std::vector<int32_t> h(n);
-    STEREO_HIP_CHECK(hipMemcpy(h.data(), S.g.h, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
     const double left = det_sum(S.d_snk.p, n, P->d_partial);
     *lower_bound = konst + neg + (cap_in - left) / 2;
-    std::vector<int> label(N);
-    double unl = 0;
-    for (int64_t i = 0; i < N; ++i) {
-      const int li = h[i] < n ? 1 : 0, lm = h[i + N] < n ? 1 : 0;
-      label[i] = li == lm ? -1 : li;
-      if (label[i] < 0) unl += 1;
-    }
+    // labels on the device; the host only sees the number of unlabelled nodes
+    if ((int64_t)P->d_label.n < N) P->d_label.alloc(N);
+    STEREO_HIP_CHECK(hipMemsetAsync(S.d_cnt.p + 3, 0, sizeof(int32_t), 0));
+    hipLaunchKernelGGL(rd_labels_kernel, dim3((unsigned)((N + kQB - 1) / kQB)), dim3(kQB), 0, 0, N, n, S.g.h,
+                       P->d_label.p, S.d_cnt.p + 3);
+    int32_t unl32 = 0;
+    STEREO_HIP_CHECK(hipMemcpy(&unl32, S.d_cnt.p + 3, sizeof(unl32), hipMemcpyDeviceToHost));
+    double unl = unl32;
     if (unl > 0) {
-      // rare: pull the residual network to the host for the two-pass DFS / Improve bookkeeping
+      // rare: heights and the residual network go to the host for the two-pass DFS / Improve
+      std::vector<int32_t> h(n);
+      STEREO_HIP_CHECK(hipMemcpy(h.data(), S.g.h, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+      std::vector<int> label(N);
+      for (int64_t i = 0; i < N; ++i) {
+        const int li = h[i] < n ? 1 : 0, lm = h[i + N] < n ? 1 : 0;
+        label[i] = li == lm ? -1 : li;
+      }
       S.P.head.resize(S.m); S.P.rev.resize(S.m);
       std::vector<double> r(S.m);
       STEREO_HIP_CHECK(hipMemcpy(S.P.head.data(), S.d_head.p, sizeof(int32_t) * S.m, hipMemcpyDeviceToHost));
@@ -1102,34 +1120,40 @@ static int rd_plan_solve_device(stereo_rd_plan *P, const double *const in[6], in
       weak_persistencies(S.P, r, label);
       unl = 0;
       for (int64_t i = 0; i < N; ++i) if (label[i] < 0) unl += 1;
+      *num_unlabelled = unl;  // rd_mex.cpp:83-88: counted before Improve
+      if (improve && unl > 0) {
+        std::vector<int32_t> perm(N);
+        for (int64_t i = 0; i < N; ++i) perm[i] = (int32_t)i;
+        for (int64_t i = 0; i < N - 1; ++i) {  // QPBO_extra.cpp:13-27
+          int64_t j = i + (int64_t)((rand() / (1.0 + (double)RAND_MAX)) * (double)(N - i));
+          if (j > N - 1) j = N - 1;
+          std::swap(perm[i], perm[j]);
+        }
+        for (int64_t pidx = 0; pidx < N; ++pidx) {
+          const int32_t i = perm[pidx];
+          if ((h[i] < n) != (h[i + N] < n)) continue;
+          S.fix_to_zero(i);
+          S.maxflow();
+          STEREO_HIP_CHECK(hipMemcpy(h.data(), S.g.h, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+        }
+        for (int64_t i = 0; i < N; ++i) {
+          const int li = h[i] < n ? 1 : 0, lm = h[i + N] < n ? 1 : 0;
+          label[i] = li == lm ? 0 : li;
+        }
+      }
+      std::vector<int8_t> l8(N);
+      for (int64_t i = 0; i < N; ++i) l8[i] = (int8_t)label[i];
+      P->d_label.upload(l8.data(), N);
     }
     *num_unlabelled = unl;
     if (std::getenv("STEREO_HIP_QPBO_VERBOSE"))
       std::fprintf(stderr, "[stereo_hip qpbo plan] n=%d arcs=%d iterations=%lld global_relabels=%lld unlabelled=%g\n", S.n,
                    S.m, (long long)S.iterations, (long long)S.relabels, unl);
-    if (improve && unl > 0) {
-      std::vector<int32_t> perm(N);
-      for (int64_t i = 0; i < N; ++i) perm[i] = (int32_t)i;
-      for (int64_t i = 0; i < N - 1; ++i) {  // QPBO_extra.cpp:13-27
-        int64_t j = i + (int64_t)((rand() / (1.0 + (double)RAND_MAX)) * (double)(N - i));
-        if (j > N - 1) j = N - 1;
-        std::swap(perm[i], perm[j]);
-      }
-      for (int64_t pidx = 0; pidx < N; ++pidx) {
-        const int32_t i = perm[pidx];
-        if ((h[i] < n) != (h[i + N] < n)) continue;
-        S.fix_to_zero(i);
-        S.maxflow();
-        STEREO_HIP_CHECK(hipMemcpy(h.data(), S.g.h, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-      }
-      for (int64_t i = 0; i < N; ++i) {
-        const int li = h[i] < n ? 1 : 0, lm = h[i + N] < n ? 1 : 0;
-        label[i] = li == lm ? 0 : li;
-      }
+    if (labelling) {
+      std::vector<int8_t> l8(N);
+      STEREO_HIP_CHECK(hipMemcpy(l8.data(), P->d_label.p, N, hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < N; ++i) labelling[i] = l8[i];
     }
-    std::vector<int8_t> l8(N);
-    for (int64_t i = 0; i < N; ++i) { l8[i] = (int8_t)label[i]; labelling[i] = label[i]; }
-    P->d_label.upload(l8.data(), N);
     hipLaunchKernelGGL(rd_energy_terms_kernel, dim3((unsigned)((N + E + kQB - 1) / kQB)), dim3(kQB), 0, 0, N, E,
                        P->d_conn.p, S.g.h, n, in[0], in[1], in[2], in[3], in[4], in[5], P->d_label.p, P->d_terms.p);
     *energy = det_sum(P->d_terms.p, N + E, P->d_partial);
@@ -1141,6 +1165,8 @@ static int rd_plan_solve_device(stereo_rd_plan *P, const double *const in[6], in
     return fail(std::string("stereo_rd: ") + e.what(), err, errcap);
   }
 }
+
+extern "C" const int8_t *stereo_rd_plan_device_labels(stereo_rd_plan *P) { return P ? P->d_label.p : nullptr; }
 
 extern "C" int stereo_rd_plan_set_grid(stereo_rd_plan *P, int H, int W, char *err, size_t errcap) {
   if (!P) return fail("stereo_rd_plan_set_grid: NULL plan", err, errcap);
@@ -1179,7 +1205,7 @@ extern "C" int stereo_rd_plan_solve_device(stereo_rd_plan *P, const double *d_U0
                                            const double *d_E11, int improve, double *labelling, double *energy,
                                            double *lower_bound, double *num_unlabelled, char *err,
                                            size_t errcap) {
-  if (!P || !d_U0 || !d_U1 || !labelling || !energy || !lower_bound || !num_unlabelled)
+  if (!P || !d_U0 || !d_U1 || !energy || !lower_bound || !num_unlabelled)
     return fail("stereo_rd_plan_solve_device: NULL argument", err, errcap);
   const double *in[6] = {d_U0, d_U1, d_E00, d_E01, d_E10, d_E11};
   return rd_plan_solve_device(P, in, improve, labelling, energy, lower_bound, num_unlabelled, err, errcap);

@@ -283,10 +283,10 @@ __global__ __launch_bounds__(kTB) void globalstereo_unary_kernel(const double *i
 // ---- device-resident fusion moves (stereo_fusion_*) -----------------------------------------
 // dispmap_super.m:78-82: assignment(:, labelling == 1) = proposal(:, labelling == 1); the cached
 // unary of the current assignment follows (the unary is a per-pixel function of the pixel's plane).
-__global__ __launch_bounds__(kTB) void fusion_scatter_kernel(int64_t N, const uint8_t *take, const double *prop,
+__global__ __launch_bounds__(kTB) void fusion_scatter_kernel(int64_t N, const int8_t *label, const double *prop,
                                                             const double *U1, double *cur, double *Ucur) {
   const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
-  if (i >= N || !take[i]) return;
+  if (i >= N || label[i] != 1) return;
   cur[4 * i] = prop[4 * i]; cur[4 * i + 1] = prop[4 * i + 1];
   cur[4 * i + 2] = prop[4 * i + 2]; cur[4 * i + 3] = prop[4 * i + 3];
   Ucur[i] = U1[i];
@@ -627,13 +627,11 @@ int stereo_fusion_binary(stereo_fusion *F, const double *proposal, int improve, 
     double e = 0, lb = 0, unl = 0;
     char e2[256] = {0};
     if (stereo_rd_plan_solve_device(F->rd, F->Ucur.p, F->U1.p, F->E00.p, F->E01.p, F->E10.p, F->E11.p, improve,
-                                    F->h_lab.data(), &e, &lb, &unl, e2, sizeof(e2)) != 0)
+                                    nullptr, &e, &lb, &unl, e2, sizeof(e2)) != 0)  // labels stay on the device
       throw std::runtime_error(e2);
     t[2] = now();
-    for (int64_t i = 0; i < N; ++i) F->h_take[i] = F->h_lab[i] == 1 ? 1 : 0;
-    F->take.upload(F->h_take.data(), N);
-    hipLaunchKernelGGL(fusion_scatter_kernel, dim3(blocks(N)), dim3(kTB), 0, 0, N, F->take.p, F->prop.p, F->U1.p,
-                       F->cur.p, F->Ucur.p);
+    hipLaunchKernelGGL(fusion_scatter_kernel, dim3(blocks(N)), dim3(kTB), 0, 0, N, stereo_rd_plan_device_labels(F->rd),
+                       F->prop.p, F->U1.p, F->cur.p, F->Ucur.p);
     if (verbose) STEREO_HIP_CHECK(hipDeviceSynchronize());
     t[3] = now();
     fusion_update_energy(F);
