@@ -78,6 +78,8 @@ struct DevParams {
   unsigned long long *timeline;  // optional [2][nruns][2] wall-clock stamps (development)
   int window;  // wide kernel: sources within lambda of a destination lie within +-window indices
   double uniform_step;  // wide kernel: != 0 if pos[k+d] - pos[k] == d * step exactly for |d| <= window <= 16
+  int win_ok;  // shared strictly ascending positions and window <= 16: windowed min-plus allowed
+  double pos_first, pos_last;  // ... their two ends
 };
 
 // ---- agent-scope (sc1) accesses: data handed between workgroups inside one launch
@@ -797,13 +799,43 @@ __device__ __forceinline__ bool wait_flag(const DevParams &p, int rank, int epoc
   return true;
 }
 
+// ---- lane exchange lane ^ S without an address register where the hardware offers one
+template <int S>
+__device__ __forceinline__ unsigned xor_lane_u32(unsigned v) {
+  if (S == 1) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+  if (S == 2) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  if (S == 8) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false);  // row_ror:8
+  if (S == 4 || S == 16) return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (S << 10));    // bit mode: xor S
+  return (unsigned)__shfl_xor((int)v, S, kWave);
+}
+// Bitonic sort of two independent sets of 64 unsigned keys (one key of each per lane), ascending by lane.
+template <int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_step2(unsigned &a, unsigned &b, int lane) {
+  const unsigned oa = xor_lane_u32<STRIDE>(a), ob = xor_lane_u32<STRIDE>(b);
+  const bool keep_min = ((lane & STRIDE) == 0) == ((lane & SIZE) == 0);
+  a = keep_min ? (a < oa ? a : oa) : (a > oa ? a : oa);
+  b = keep_min ? (b < ob ? b : ob) : (b > ob ? b : ob);
+}
+__device__ __forceinline__ void wave_sort2(unsigned &a, unsigned &b, int lane) {
+  bitonic_step2<2, 1>(a, b, lane);
+  bitonic_step2<4, 2>(a, b, lane); bitonic_step2<4, 1>(a, b, lane);
+  bitonic_step2<8, 4>(a, b, lane); bitonic_step2<8, 2>(a, b, lane); bitonic_step2<8, 1>(a, b, lane);
+  bitonic_step2<16, 8>(a, b, lane); bitonic_step2<16, 4>(a, b, lane); bitonic_step2<16, 2>(a, b, lane);
+  bitonic_step2<16, 1>(a, b, lane);
+  bitonic_step2<32, 16>(a, b, lane); bitonic_step2<32, 8>(a, b, lane); bitonic_step2<32, 4>(a, b, lane);
+  bitonic_step2<32, 2>(a, b, lane); bitonic_step2<32, 1>(a, b, lane);
+  bitonic_step2<64, 32>(a, b, lane); bitonic_step2<64, 16>(a, b, lane); bitonic_step2<64, 8>(a, b, lane);
+  bitonic_step2<64, 4>(a, b, lane); bitonic_step2<64, 2>(a, b, lane); bitonic_step2<64, 1>(a, b, lane);
+}
+
 // Message update with everything in registers (K <= 64): h = gamma*Di - old message,
 // qsrc / t = source / destination positions, perm = ascending order of the sources
 // (only touched by the serial fallback).  Returns the normalised message in `out`.
 template <int KERNEL>
 __device__ __forceinline__ double message_regs(const DevParams &p, int K, double alpha, double h,
                                                double qsrc, double t, const uint16_t *perm,
-                                               double &outmsg, int lane, double *hq = nullptr) {
+                                               double &outmsg, int lane, double *hq = nullptr,
+                                               int window = -1) {
   const double inf = __builtin_huge_val();
   const bool act = lane < K;
   const double hmin = wave_min_dpp(h);  // inactive lanes hold +inf
@@ -859,6 +891,37 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
     const bool near = (fabs(ui - HJ##u) <= delta) || (fabs(vi - HJ##v) <= delta);    \
     bad = bad || (near && qsrc != QJ);                                               \
   }
+      if (window >= 0 && __builtin_popcountll(mask) > ((p.debug >> 12) ? (p.debug >> 12) : 32)) {
+        // Flat h (the zig-zag rows: gamma = 1/6 .. 1/8 makes almost every source useful) on shared
+        // strictly ascending positions.  The pair loop below would be K^2; instead
+        //  * tangency for ALL pairs by sorting u and v (conservative superset of the useful pairs):
+        //    keys quantised to 32 bits over a range that certainly contains them, "within delta"
+        //    tested as "within delta / resolution + 2 units";
+        //  * min-plus only over the sources inside the truncation window of each destination (a source
+        //    farther than lambda costs >= vTrunc exactly); the table is padded with +inf entries.
+        const double hmax = wave_max_dpp(act ? h : -inf);
+        const double ap0 = alpha * p.pos_first, ap1 = alpha * p.pos_last;
+        const double aplo = min_raw(ap0, ap1), aphi = max_raw(ap0, ap1);
+        const double span = (hmax - hmin) + (aphi - aplo);  // >= max u - min u and >= max v - min v
+        const double scale = 4294967040.0 / span;           // (2^32 - 256) / span
+        bad = bad || !(span < inf) || !(span > 0) || !(delta * scale < 1e9);
+        unsigned ku = 0xFFFFFFFFu, kv = 0xFFFFFFFFu;
+        if (act && !bad) {
+          ku = (unsigned)((ui - (hmin - aphi)) * scale);
+          kv = (unsigned)((vi - (hmin + aplo)) * scale);
+        }
+        wave_sort2(ku, kv, lane);
+        const unsigned un = (unsigned)__shfl_down((int)ku, 1, kWave), vn = (unsigned)__shfl_down((int)kv, 1, kWave);
+        const unsigned thr = bad ? 0u : (unsigned)(delta * scale) + 2u;
+        bad = bad || (lane + 1 < K && (un - ku <= thr || vn - kv <= thr));
+        for (int d = -window; d <= window; ++d) {
+          const double hj = hq[4 * (lane + d)], qj = hq[4 * (lane + d) + 1];
+          const double c = pair_cost<1>(alpha, t - qj, hj);
+          const double lo = min_raw(m1, c), hi = max_raw(m1, c);
+          m2 = hi > lo ? min_raw(m2, hi) : m2;
+          m1 = lo;
+        }
+      } else {
       while (mask) {
         const int j0 = __builtin_ctzll(mask);
         mask &= mask - 1;
@@ -868,6 +931,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
         STEREO_SRC(j1, hj1, qj1)
         STEREO_ACC(hj0, qj0)
         STEREO_ACC(hj1, qj1)
+      }
       }
 #undef STEREO_SRC
 #undef STEREO_ACC
@@ -919,6 +983,8 @@ constexpr int kStD = 0, kStM = 64, kStQ = 64 + 512, kStQP = 64 + 1024, kStA = 64
 constexpr int kStI = kStA + 8;                    // int area starts here (as doubles)
 constexpr int kStageDoubles = kStI + 36;          // 64 + 8 ints = 36 doubles
 constexpr int kScalDoubles = 16;                  // newv[8], node_vmin, prim_e, x (as int)
+constexpr int kPipePad = 16;                      // source tables are padded by this many (+inf) entries on both sides
+constexpr int kPipeTab = 4 * (kWave + 2 * kPipePad);  // doubles per compute wave: (h, q, u, v) x 96
 
 template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
 __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, int epoch) {
@@ -927,7 +993,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
   double *hand = lds + 2 * kStageDoubles;                 // ring of 4 x 8 x 64: the last visits' new messages
   double *scal = hand + 4 * 8 * kWave;                    // 2 x kScalDoubles
   double *hqtab = scal + 2 * kScalDoubles;                // per compute wave: 64 x (h, q, u, v)
-  int *ctl = (int *)(hqtab + kPipeCompute * 4 * kWave);   // [0] run, [1] abort
+  int *ctl = (int *)(hqtab + kPipeCompute * kPipeTab);    // [0] run, [1] abort
   const int K = p.K;
   const double inf = __builtin_huge_val();
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -938,6 +1004,11 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
   const bool act = lane < K;
   const double posk = (SHARED && act) ? p.pos[lane] : 0.0;
   if (tid == 0) ctl[1] = 0;
+  if (wave < kPipeCompute && lane < 2 * kPipePad) {
+    // padding of the source tables (entries -16 .. -1 and 64 .. 79): never overwritten afterwards
+    double *e = hqtab + wave * kPipeTab + 4 * (lane < kPipePad ? lane : kWave + lane);
+    e[0] = inf; e[1] = 0; e[2] = 0; e[3] = 0;
+  }
   if ((p.debug & 2) && !BACKWARD) p.prof = nullptr;  // profile backward sweeps only
   if ((p.debug & 4) && BACKWARD) p.prof = nullptr;   // profile forward sweeps only
 
@@ -1011,7 +1082,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
               const double alpha = st[kStA + j];
               double newm = 0;
               const double v = message_regs<KERNEL>(p, K, alpha, h, qsrc, qdst, perm, newm, lane,
-                                                    hqtab + wave * 4 * kWave);
+                                                    hqtab + wave * kPipeTab + 4 * kPipePad, (SHARED && p.win_ok) ? p.window : -1);
               if (act) hcur[j * kWave + lane] = newm;
               if (BACKWARD && lane == 0) sc[j] = v;
             }
@@ -1885,6 +1956,8 @@ struct stereo_trws_plan {
   bool fast = false;
   bool wide = false;  // 64 < K <= 256 with shared strictly ascending positions: trws_wide_kernel
   bool wide_allowed = false;
+  bool pos_ascending = false;  // shared positions finite and strictly ascending
+  double pos_first = 0, pos_last = 0;
   int window = 0;
   double uniform_step = 0;
   DevBuf<unsigned long long> d_fallbacks, d_prof, d_timeline;
@@ -1946,8 +2019,10 @@ DevParams make_params(stereo_trws_plan *P) {
   p.prof_run = -1;
   p.window = P->window;
   p.uniform_step = P->uniform_step;
+  p.pos_first = P->pos_first; p.pos_last = P->pos_last;
   p.debug = 0;
   if (const char *dbg = std::getenv("STEREO_HIP_TRWS_DEBUG")) p.debug = std::atoi(dbg);
+  p.win_ok = (P->pos_ascending && P->window <= 16 && !(p.debug & 256)) ? 1 : 0;
   if (const char *pr = std::getenv("STEREO_HIP_TRWS_PROF_RUN")) p.prof_run = std::atoi(pr);
   return p;
 }
@@ -1974,7 +2049,7 @@ void launch_persistent(stereo_trws_plan *P, const DevParams &p, int what, hipStr
     return;
   }
   if (P->fast) {
-    const size_t plds = sizeof(double) * (2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * 4 * kWave + 2);
+    const size_t plds = sizeof(double) * (2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * kPipeTab + 2);
     const bool sh = P->pos != nullptr;
     const dim3 pblock(kPipeThreads);
 #define PIPE(BW, PR, UP)                                                                          \
@@ -2061,9 +2136,10 @@ void finish_inputs(stereo_trws_plan *P) {
     run_argsort(P->qprim, P->d_perm_qp.p, P->K, P->E, nullptr);
   }
   STEREO_HIP_CHECK(hipDeviceSynchronize());
-  // wide-label kernel: shared positions that are finite and strictly ascending
-  P->wide = false; P->uniform_step = 0;
-  if (P->wide_allowed && P->pos && P->lambda >= 0) {
+  // shared positions that are finite and strictly ascending: truncation window in index steps
+  // (windowed min-plus of the pipelined kernel's flat-h path; the wide-label kernel requires it)
+  P->wide = false; P->uniform_step = 0; P->pos_ascending = false; P->window = 0;
+  if (P->pos && P->lambda >= 0) {
     std::vector<double> hp(P->K);
     STEREO_HIP_CHECK(hipMemcpy(hp.data(), P->pos, sizeof(double) * P->K, hipMemcpyDeviceToHost));
     bool asc = std::isfinite(hp[0]);
@@ -2080,7 +2156,9 @@ void finish_inputs(stereo_trws_plan *P) {
         w = std::max(w, k - lo);
       }
       P->window = w;
-      P->wide = true;
+      P->pos_ascending = true;
+      P->pos_first = hp[0]; P->pos_last = hp[P->K - 1];
+      P->wide = P->wide_allowed;
       // exact arithmetic progression inside the window?  (then alpha |t - q| = alpha |d step| bit for bit)
       P->uniform_step = 0;
       if (w <= 16 && P->K > 1) {
