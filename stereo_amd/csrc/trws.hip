@@ -976,7 +976,8 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
 // One s_barrier per visit.  The compute waves never touch global memory, so no load or
 // store latency is ever exposed on the chain of dependent visits.
 constexpr int kPipeCompute = 8;  // one compute wave per outgoing message (<= 8 per node)
-constexpr int kPipeWaves = kPipeCompute + 3;
+constexpr int kPipeWaves = kPipeCompute + 4;  // loader, storer, (idle), primal: the primal wave lands on SIMD 3,
+                                              // which otherwise hosts one compute wave only
 constexpr int kPipeThreads = kPipeWaves * kWave;
 // LDS stage layout (doubles): D[64] m[8][64] qv[8][64] qpv[8][64] | a[8] | ints: desc[64] px[8]
 constexpr int kStD = 0, kStM = 64, kStQ = 64 + 512, kStQP = 64 + 1024, kStA = 64 + 1536;
@@ -1174,7 +1175,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
           if (!(p.debug & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0) st_sc1(p.done + pd.rank, epoch);
         }
-      } else {
+      } else if (wave == kPipeCompute + 3) {
         // ------------------------------------------------------------ primal of node pos
         if (PRIMAL && have_node && !(p.debug & 8)) {
           const int *sti = (const int *)(st + kStI);
@@ -1217,7 +1218,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
     if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2 + 1] = wall_clock64();
     if (p.prof && lane == 0 && (p.prof_run < 0 || run == p.prof_run)) {
       // busy cycles before the barrier per role: compute (wave 0), loader, storer, primal; steps
-      const int slot = wave == 0 ? 0 : wave == kPipeCompute ? 1 : wave == kPipeCompute + 1 ? 2 : wave == kPipeCompute + 2 ? 3 : -1;
+      const int slot = wave == 0 ? 0 : wave == kPipeCompute ? 1 : wave == kPipeCompute + 1 ? 2 : wave == kPipeCompute + 3 ? 3 : -1;
       if (slot >= 0) atomicAdd(p.prof + slot, busy);
       if (wave == 0) atomicAdd(p.prof + 6, (unsigned long long)(p1 - p0));
     }
