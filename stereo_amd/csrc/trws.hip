@@ -74,7 +74,8 @@ struct DevParams {
   unsigned long long *prof;       // optional: 8 phase-cycle accumulators (development)
   const int32_t *desc[2];         // packed node descriptors of the fast kernel
   int prof_run;
-  int debug;  // development switches (timing experiments only)
+  int debug;  // development switches: 2 / 4 profile backward / forward sweeps only, 256 no windowed paths
+              // (none of them changes a result)
   unsigned long long *timeline;  // optional [2][nruns][2] wall-clock stamps (development)
   int window;  // wide kernel: sources within lambda of a destination lie within +-window indices
   double uniform_step;  // wide kernel: != 0 if pos[k+d] - pos[k] == d * step exactly for |d| <= window <= 16
@@ -891,7 +892,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
     const bool near = (fabs(ui - HJ##u) <= delta) || (fabs(vi - HJ##v) <= delta);    \
     bad = bad || (near && qsrc != QJ);                                               \
   }
-      if (window >= 0 && __builtin_popcountll(mask) > ((p.debug >> 12) ? (p.debug >> 12) : 32)) {
+      if (window >= 0 && __builtin_popcountll(mask) > 32) {
         // Flat h (the zig-zag rows: gamma = 1/6 .. 1/8 makes almost every source useful) on shared
         // strictly ascending positions.  The pair loop below would be K^2; instead
         //  * tangency for ALL pairs by sorting u and v (conservative superset of the useful pairs):
@@ -1172,12 +1173,12 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
             st_sc1(p.x + pd.node, ((const int *)(scp + 10))[0]);
             p.eterms[pd.rank] = scp[9];
           }
-          if (!(p.debug & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0) st_sc1(p.done + pd.rank, epoch);
         }
       } else if (wave == kPipeCompute + 3) {
         // ------------------------------------------------------------ primal of node pos
-        if (PRIMAL && have_node && !(p.debug & 8)) {
+        if (PRIMAL && have_node) {
           const int *sti = (const int *)(st + kStI);
           const int f = __builtin_amdgcn_readfirstlane(sti[2]);
           const int nout = f & 15, nin = (f >> 4) & 15, md = (f >> 16) & 255, ntot = nout + nin;
@@ -1546,7 +1547,7 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
                   for (int c = 0; c < 4; ++c) r[c] = h[c] + sgn * (alpha * posr[c]);
                   const double mn = role == 2 ? hmin + aplo : hmin - aphi;
                   const double mx = role == 2 ? hmax + aphi : hmax - aplo;
-                  bool bad = !(delta < inf) || (p.debug & 16);
+                  bool bad = !(delta < inf);
                   if (!bad) bad = keys_within(r, K, C, delta, mn, mx - mn, scr, lane);
                   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                   if (lane == 0)
@@ -1571,7 +1572,7 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
                     // ---- windowed min-plus: smallest and second smallest cost per destination
                     // (equal costs from two sources count as a zero margin: serial path decides)
                     double m1[4] = {inf, inf, inf, inf}, m2[4] = {inf, inf, inf, inf};
-                    const int w = (p.debug & 32) ? 0 : p.window;
+                    const int w = p.window;
                     if (uniform && w <= kWPad) {
                       for (int d = -w; d <= w; ++d) {
                         const double ad = alpha * fabs((double)d * ustep);  // == alpha |t - q| exactly
