@@ -182,7 +182,7 @@ def main():
                                    + " (one persistent launch per sweep)", "bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches_per_iter},
         }
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:  # reported baseline: rank 0 at N=1 only
             from oracle import pyoracle
             q = np.tile(np.arange(K, dtype=np.float64), (E, 1))
             ci = max(args.cpu_iters, 1)
