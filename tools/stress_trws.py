@@ -1,0 +1,46 @@
+"""Development tool: randomised parity stress of the TRW-S kernels against the CPU oracle
+(sizes, label counts, kernels, shared / per-edge positions, integer ties drawn at random)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import stereo_amd
+from stereo_amd.trws import TrwsPlan
+from helpers import trws_problem
+from oracle import pyoracle as po
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t0, n, bad = time.time(), 0, 0
+while time.time() - t0 < budget:
+    H, W = int(rng.integers(1, 70)), int(rng.integers(2, 70))
+    K = int(rng.choice([2, 3, 5, 8, 16, 31, 60, 64, 65, 100, 200, 256]))
+    if K > 64 and H * W > 1500:
+        H, W = min(H, 30), min(W, 40)
+    kernel = int(rng.choice([1, 1, 1, 2]))
+    shared = bool(rng.integers(0, 2))
+    integer = bool(rng.integers(0, 4) == 0)
+    tol = float(rng.choice([0.0, 1.5, 3.0, 8.0, 40.0]))
+    iters = int(rng.integers(1, 6))
+    seed = int(rng.integers(0, 1 << 30))
+    p = trws_problem(seed, H, W, K, kind="fronto" if shared else "general", integer=integer)
+    if shared:
+        pos = np.cumsum(rng.uniform(0.05, 2.0, size=K)) if rng.integers(0, 2) else np.arange(K, dtype=np.float64)
+        q = np.tile(pos, (p["conn"].shape[0], 1)); qp = q
+    else:
+        q, qp = p["q"], p["qprim"]
+    ref = po.trws(kernel, p["unary"], p["conn"], q, qp, p["alphas"], tol, iters, -1e300, mode=1)
+    plan = TrwsPlan(kernel, K, H * W, p["conn"].T)
+    if shared:
+        plan.upload(p["unary"].T, p["alphas"], tol, positions=pos)
+    else:
+        plan.upload(p["unary"].T, p["alphas"], tol, q=q.T, qprim=qp.T)
+    plan.iterate(iters, max_relgap=-1e300)
+    got = plan.result()
+    ok = np.array_equal(got[0], ref[0]) and got[1] == ref[1] and got[2] == ref[2]
+    n += 1
+    if not ok:
+        bad += 1
+        print("MISMATCH", dict(seed=seed, H=H, W=W, K=K, kernel=kernel, shared=shared, integer=integer, tol=tol, iters=iters, path=plan.path()))
+print("stress: %d problems, %d mismatches, %.0f s" % (n, bad, time.time() - t0))
+sys.exit(1 if bad else 0)
