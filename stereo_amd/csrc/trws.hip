@@ -1979,12 +1979,20 @@ struct stereo_trws_plan {
   double energy = 0, lb = 0;
   int64_t iterations = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // the lower-bound terms of an iteration go to the host on their own stream while the next
+  // launch (forward sweep + primal) runs, and are summed there meanwhile
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_bwd = nullptr, ev_lb = nullptr;
+  bool lb_in_flight = false;
   double sweep_ms = 0;
   int64_t sweep_launches = 0;
   bool time_sweeps = false;
   ~stereo_trws_plan() {
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    if (ev_bwd) (void)hipEventDestroy(ev_bwd);
+    if (ev_lb) (void)hipEventDestroy(ev_lb);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
   }
 };
 
@@ -2085,6 +2093,13 @@ void persistent_iteration(stereo_trws_plan *P, const DevParams &p, hipStream_t s
   if (P->time_sweeps) STEREO_HIP_CHECK(hipEventRecord(P->ev0, s));
   if (!P->fwd_pending) launch_persistent<KERNEL, MODE>(P, p, 0, s);
   launch_persistent<KERNEL, MODE>(P, p, 1, s);
+  // the backward sweep's lower-bound terms travel while the next launch runs
+  STEREO_HIP_CHECK(hipEventRecord(P->ev_bwd, s));
+  STEREO_HIP_CHECK(hipStreamWaitEvent(P->copy_stream, P->ev_bwd, 0));
+  STEREO_HIP_CHECK(hipMemcpyAsync(P->h_lb.p, P->d_lbterms.p, sizeof(double) * P->g.lb_terms, hipMemcpyDeviceToHost,
+                                  P->copy_stream));
+  STEREO_HIP_CHECK(hipEventRecord(P->ev_lb, P->copy_stream));
+  P->lb_in_flight = true;
   // forward sweep of the NEXT iteration fused with this iteration's primal
   launch_persistent<KERNEL, MODE>(P, p, 2, s);
   P->fwd_pending = true;
@@ -2268,6 +2283,9 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
     STEREO_HIP_CHECK(hipMemset(P->d_x.p, 0, sizeof(int32_t) * N));
     STEREO_HIP_CHECK(hipEventCreate(&P->ev0));
     STEREO_HIP_CHECK(hipEventCreate(&P->ev1));
+    STEREO_HIP_CHECK(hipEventCreateWithFlags(&P->ev_bwd, hipEventDisableTiming));
+    STEREO_HIP_CHECK(hipEventCreateWithFlags(&P->ev_lb, hipEventDisableTiming));
+    STEREO_HIP_CHECK(hipStreamCreateWithFlags(&P->copy_stream, hipStreamNonBlocking));
     STEREO_HIP_CHECK(hipDeviceSynchronize());
     // every sweep kernel may need more than the default 64 KiB of dynamic LDS
     const int lds = (int)sweep_lds_bytes(P->Kp);
@@ -2424,13 +2442,20 @@ int stereo_trws_plan_iterate(stereo_trws_plan *P, int iters, double max_relgap, 
           if (P->mode == 0) launch_iteration<2, 0>(P, p, s); else launch_iteration<2, 1>(P, p, s);
         }
       }
-      STEREO_HIP_CHECK(hipMemcpyAsync(P->h_lb.p, P->d_lbterms.p, sizeof(double) * P->g.lb_terms,
-                                      hipMemcpyDeviceToHost, s));
+      if (!P->lb_in_flight)
+        STEREO_HIP_CHECK(hipMemcpyAsync(P->h_lb.p, P->d_lbterms.p, sizeof(double) * P->g.lb_terms,
+                                        hipMemcpyDeviceToHost, s));
       STEREO_HIP_CHECK(hipMemcpyAsync(P->h_en.p, P->d_eterms.p, sizeof(double) * P->N,
                                       hipMemcpyDeviceToHost, s));
       int32_t ctl[2] = {0, 0};
       if (P->persistent)
         STEREO_HIP_CHECK(hipMemcpyAsync(ctl, P->d_ctl.p, sizeof(ctl), hipMemcpyDeviceToHost, s));
+      // sums in the reference's order (minimize.cpp:82,92 and :260): sequential, bit exact
+      double lb = 0, en = 0;
+      if (P->lb_in_flight) {  // summed while the forward sweep + primal launch is still running
+        STEREO_HIP_CHECK(hipEventSynchronize(P->ev_lb));
+        for (int64_t i = 0; i < P->g.lb_terms; ++i) lb += P->h_lb.p[i];
+      }
       STEREO_HIP_CHECK(hipStreamSynchronize(s));
       if (ctl[1]) return fail("stereo_trws: a persistent sweep gave up waiting on a dependency flag", err, errcap);
       if (P->time_sweeps) {
@@ -2438,9 +2463,9 @@ int stereo_trws_plan_iterate(stereo_trws_plan *P, int iters, double max_relgap, 
         STEREO_HIP_CHECK(hipEventElapsedTime(&ms, P->ev0, P->ev1));
         P->sweep_ms += ms;
       }
-      // sums in the reference's order (minimize.cpp:82,92 and :260): sequential, bit exact
-      double lb = 0, en = 0;
-      for (int64_t i = 0; i < P->g.lb_terms; ++i) lb += P->h_lb.p[i];
+      if (!P->lb_in_flight)
+        for (int64_t i = 0; i < P->g.lb_terms; ++i) lb += P->h_lb.p[i];
+      P->lb_in_flight = false;
       for (int64_t i = 0; i < P->N; ++i) en += P->h_en.p[i];
       P->lb = lb; P->energy = en; P->iterations += 1;
       if (done_iters) *done_iters += 1;
