@@ -9,9 +9,13 @@
 // Layout in HBM (all label-fastest, exactly MATLAB's K x N / K x E column major):
 //   unary [N][K]   messages [E][K]   q,qprim [E][K] (or one shared positions[K])
 //   perm_q, perm_qp [E][K] uint16: ascending sort permutation of q(:,e), qprim(:,e)
-// Work decomposition: the reference node order induces a dependency DAG; nodes
-// of one DAG level are independent.  One workgroup (4 waves) per node, one wave
-// per outgoing message, lane = label.
+// Work decomposition: the reference node order induces a dependency DAG.  One persistent
+// launch per sweep walks it as a dataflow: workgroups draw "runs" (a grid row, the border
+// chain) from a ticket counter and hand messages over in LDS inside a run, through HBM +
+// completion flags between runs.  Four implementations, identical results
+// (stereo_trws_plan_path): trws_pipe_kernel (K <= 64, role-specialised waves),
+// trws_wide_kernel (64 < K <= 256, shared ascending positions), trws_persistent_kernel
+// (everything else), trws_sweep_kernel (one launch per DAG level; kept for comparison).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -72,7 +76,7 @@ struct DevParams {
   unsigned long long *fallbacks;  // messages that needed the serial envelope (diagnostics)
   int certificate;                // 0: always run the serial envelope
   unsigned long long *prof;       // optional: 8 phase-cycle accumulators (development)
-  const int32_t *desc[2];         // packed node descriptors of the fast kernel
+  const int32_t *desc[2];         // packed node descriptors of the pipelined kernels
   int prof_run;
   int debug;  // development switches: 2 / 4 profile backward / forward sweeps only, 256 no windowed paths
               // (none of them changes a result)
@@ -964,7 +968,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
 #undef RLI
 
 // ---- pipelined persistent sweep (K <= 64): role-specialised waves ---------------------
-// Same dataflow schedule and arithmetic as trws_fast_kernel, but the global-memory traffic
+// Same dataflow schedule and arithmetic as trws_persistent_kernel, but the global-memory traffic
 // of a visit is taken off the critical path by dedicated waves of the workgroup:
 //   waves 0-7  compute: read the staged node from LDS, form Di, compute outgoing message
 //              `wave` in registers, hand it over in LDS
@@ -973,7 +977,8 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
 //              positions / neighbour labels and stages them in LDS
 //   wave 9     storer:  while node i is computed, writes node i-1's new messages and scalars
 //              to HBM (write-through), drains, raises node i-1's completion flag
-//   wave 10    primal:  labelling + energy term of node i (previous iteration's primal pass)
+//   wave 11    primal:  labelling + energy term of node i (previous iteration's primal pass);
+//              wave 10 idles so that the primal wave shares a SIMD with one compute wave only
 // One s_barrier per visit.  The compute waves never touch global memory, so no load or
 // store latency is ever exposed on the chain of dependent visits.
 constexpr int kPipeCompute = 8;  // one compute wave per outgoing message (<= 8 per node)
