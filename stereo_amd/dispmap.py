@@ -296,6 +296,36 @@ class dispmap_ncc(dispmap_super):
 
     restart = init_solution
 
+    # ---- proposals (dispmap_ncc.m:48-92).  Host side: a few dozen points and 3 x 3 SVDs per
+    # proposal; MATLAB's svd is outside the reference tree, so this mirrors the arithmetic with
+    # numpy's (parity unpinned -- proposals are inputs of the parity-tested path, not outputs).
+    def generate_new_plane_RANSAC(self, x, y, r):
+        """dispmap_ncc.m:48-66: plane fitted to the winner-takes-all disparities within radius r
+        of pixel (x, y) (1-based, x = column), repeated for every pixel."""
+        pts = self.points
+        best = np.asarray(self.best_disp_from_ncc()).T.reshape(-1)      # column-major pixel order
+        ids = np.sqrt((pts[0] - x) ** 2 + (pts[1] - y) ** 2) < r
+        p = self.fit_plane_to_points(np.vstack([pts[:, ids], best[ids]]))
+        return np.asfortranarray(np.repeat(p.reshape(4, 1), self.sz[0] * self.sz[1], axis=1))
+
+    def fit_plane_to_points(self, points):
+        """dispmap_ncc.m:67-92: total least squares (kernel 2) or 20 rounds of iteratively
+        reweighted least squares (kernel 1) through the SVD of the centred points."""
+        points = np.asarray(points, np.float64)
+        c = points.mean(axis=1, keepdims=True)
+        cost = -(points - c).T                                             # n x 3
+        p = np.zeros(4)
+        if self._kernel == 1:
+            w = np.ones((cost.shape[0], 1))
+            for _ in range(20):
+                v = np.linalg.svd(w * cost, full_matrices=False)[2][-1]
+                p[:3] = v
+                w = np.sqrt(np.abs(cost @ v)).reshape(-1, 1)
+        elif self._kernel == 2:
+            p[:3] = np.linalg.svd(cost, full_matrices=False)[2][-1]
+        p[3] = -(p[:3] @ points[:3].mean(axis=1))
+        return p / p[2]
+
 
 class dispmap_globalstereo(dispmap_super):
     """dispmap_globalstereo.m with the constants of ojw_default_options('cvpr08')
