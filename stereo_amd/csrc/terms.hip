@@ -654,6 +654,9 @@ int stereo_fusion_simultaneous(stereo_fusion *F, const double *proposals, int K,
   return guarded("stereo_fusion_simultaneous", err, errcap, [&] {
     const int64_t N = F->N, E = F->E;
     const int Kt = K + 1;  // proposals{end+1} = self.assignment (dispmap_super.m:160)
+    const bool verbose = std::getenv("STEREO_HIP_FUSION_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     check_planes(proposals, N * K);
     char e2[256] = {0};
     if (!F->trws || F->trws_K != Kt) {
@@ -678,15 +681,18 @@ int stereo_fusion_simultaneous(stereo_fusion *F, const double *proposals, int K,
       hipLaunchKernelGGL(trws_positions_kernel, dim3(blocks(E * Kt)), dim3(kTB), 0, 0, E, Kt, N, F->conn.p, F->points.p,
                          F->props.p, F->d_min, F->d_step, F->qK.p, F->qpK.p);
     STEREO_HIP_CHECK(hipDeviceSynchronize());
+    const double t1 = now();
     if (stereo_trws_plan_bind_device(F->trws, F->unaryK.p, F->qK.p, F->qpK.p, nullptr, F->weights.p, F->tol, e2,
                                      sizeof(e2)) != 0 ||
         stereo_trws_plan_reset(F->trws, e2, sizeof(e2)) != 0)
       throw std::runtime_error(e2);
+    const double t2 = now();
     // Minimize_TRW_S runs at least one iteration and stops at iter >= iterMax (minimize.cpp:100-112)
     int iters = maxiter >= 1 ? (maxiter > 2e9 ? 2000000000 : (int)maxiter) : 1;
     int done = 0, stopped = 0;
     if (stereo_trws_plan_iterate(F->trws, iters, max_relgap, nullptr, &done, &stopped, e2, sizeof(e2)) != 0)
       throw std::runtime_error(e2);
+    const double t3 = now();
     double te = 0, tlb = 0, tit = 0;
     if (stereo_trws_plan_result(F->trws, F->h_lab.data(), &te, &tlb, &tit, e2, sizeof(e2)) != 0)
       throw std::runtime_error(e2);
@@ -696,6 +702,12 @@ int stereo_fusion_simultaneous(stereo_fusion *F, const double *proposals, int K,
                        F->unaryK.p, F->cur.p, F->Ucur.p);
     fusion_update_energy(F);
     if (energy) *energy = F->energy;
+    if (verbose) {
+      int64_t serial = 0;
+      (void)stereo_trws_plan_counters(F->trws, &serial, 1);
+      std::fprintf(stderr, "[stereo_hip fusion] simultaneous K=%d: plan + unary + positions %.1f ms, bind (argsort) %.1f ms, %d iterations %.1f ms (path %d, %lld serial-envelope messages), scatter + energy %.1f ms\n",
+                   Kt, t1 - t0, t2 - t1, done, t3 - t2, stereo_trws_plan_path(F->trws), (long long)serial, now() - t3);
+    }
     if (trws_energy) *trws_energy = te;
     if (lower_bound) *lower_bound = tlb;
     if (iterations) *iterations = tit;

@@ -453,7 +453,107 @@ __device__ double update_message(const DevParams &p, int e, const double *Di, do
     vmin = hmin;
   } else {
     const double vtrunc = hmin + alpha * p.lambda;
-    if (MODE == STEREO_TRWS_MESSAGES_EXACT) {
+    bool certified = false;
+    if (MODE == STEREO_TRWS_MESSAGES_EXACT && KERNEL == 1 && p.certificate && K <= 2 * kWave) {
+      // Certified fast path for 64 < K <= 128 (two labels per lane), as in the register path:
+      // min-plus over the useful sources (h < vTrunc) and the tangency / margin certificate
+      // (DESIGN.md "message certificate"); the serial construction below only runs if it fails.
+      // A / B hold the sources in ascending position order; a lane owns cones and destinations
+      // lane and lane + 64.  The list of useful sources is compacted into `sh` (free until then).
+      int *ul = (int *)sh;
+      int nu = 0;
+      double ck_h[2], ck_q[2], ck_u[2], ck_v[2], tt[2], m1[2] = {inf, inf}, m2[2] = {inf, inf};
+      double mag = 0;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int k = lane + it * kWave;
+        const bool on = k < K;
+        ck_h[it] = on ? A[k] : inf; ck_q[it] = on ? B[k] : 0.0; tt[it] = on ? dst[k] : 0.0;
+        const double aq = alpha * ck_q[it];
+        ck_u[it] = ck_h[it] - aq; ck_v[it] = ck_h[it] + aq;
+        if (on) {
+          const double mg = fabs(ck_h[it]) + fabs(aq) + alpha * fabs(tt[it]);
+          mag = mg > mag ? mg : mag;
+        }
+        const bool useful = on && ck_h[it] < vtrunc;
+        const unsigned long long um = __builtin_amdgcn_ballot_w64(useful);
+        if (useful) ul[nu + __builtin_popcountll(um & ((1ull << lane) - 1))] = k;
+        nu += __builtin_popcountll(um);
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(mag, off, kWave);
+        mag = o > mag ? o : mag;
+      }
+      double delta = 1e-9 * (mag + fabs(alpha * p.lambda));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      bool bad = false;
+      bool rel[2] = {true, true};  // cones that take part in the tangency test
+      for (int attempt = 0;; ++attempt) {
+        bad = !(delta < inf);
+        vmin = inf;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) { m1[it] = inf; m2[it] = inf; }
+        for (int jj = 0; jj < nu; ++jj) {
+          const int j = ul[jj];
+          const double hj = A[j], qj = B[j];
+          const double aqj = alpha * qj;
+          const double uj = hj - aqj, vj = hj + aqj;
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const double c = pair_cost<1>(alpha, tt[it] - qj, hj);
+            const double lo = min_raw(m1[it], c), hi = max_raw(m1[it], c);
+            m2[it] = hi > lo ? min_raw(m2[it], hi) : m2[it];
+            m1[it] = lo;
+            const bool near = (fabs(ck_u[it] - uj) <= delta) || (fabs(ck_v[it] - vj) <= delta);
+            bad = bad || (near && ck_q[it] != qj && rel[it] && lane + it * kWave < K);
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          if (lane + it * kWave < K) {
+            bad = bad || (m1[it] < vtrunc && !(m2[it] - m1[it] > delta && vtrunc - m1[it] > delta));
+            outv[it] = m1[it] < vtrunc ? m1[it] : vtrunc;
+            vmin = outv[it] < vmin ? outv[it] : vmin;
+          }
+        }
+        if (!UNI(bad) || attempt == 1) break;
+        // Second look: a cone whose apex lies above vTrunc by more than alpha times the whole position
+        // range cannot touch a useful cone (every useful cone dominates it with that margin wherever
+        // they meet), so it neither counts for the magnitude behind delta nor for the tangency test.
+        // Out-of-range plane proposals (unary ~ 4e7, dispmap_ncc.m:245) would otherwise inflate delta.
+        double qabs = 0;
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+          if (lane + it * kWave < K) qabs = max_raw(qabs, max_raw(fabs(ck_q[it]), fabs(tt[it])));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) qabs = max_raw(qabs, __shfl_xor(qabs, off, kWave));
+        const double hbig = vtrunc + 2.000002 * fabs(alpha) * qabs;
+        double mag2 = 0;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          rel[it] = ck_h[it] <= hbig;
+          if (lane + it * kWave < K)
+            mag2 = max_raw(mag2, (rel[it] ? fabs(ck_h[it]) : 0.0) + fabs(alpha * ck_q[it]) + alpha * fabs(tt[it]));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mag2 = max_raw(mag2, __shfl_xor(mag2, off, kWave));
+        mag2 = max_raw(mag2, fabs(vtrunc));
+        const double delta2 = 1e-9 * (mag2 + fabs(alpha * p.lambda));
+        if (!(delta2 < delta)) break;
+        delta = delta2;
+      }
+      certified = !UNI(bad);
+      if (!certified) {
+        vmin = inf;
+        if (lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
+        __builtin_amdgcn_wave_barrier();  // everyone is done with the list in `sh`
+      }
+    }
+    if (certified) {
+      // outv / vmin are set
+    } else if (MODE == STEREO_TRWS_MESSAGES_EXACT) {
       if (lane == 0) build_envelope<KERNEL>(K, alpha, A, B, sh, sq, z);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -833,6 +933,45 @@ __device__ __forceinline__ void wave_sort2(unsigned &a, unsigned &b, int lane) {
   bitonic_step2<64, 4>(a, b, lane); bitonic_step2<64, 2>(a, b, lane); bitonic_step2<64, 1>(a, b, lane);
 }
 
+// Second look at a message whose certificate failed (cold path, kept out of line so that it costs the
+// hot path no registers).  A cone whose apex lies above vTrunc by more than alpha times the whole
+// position range cannot touch a useful cone -- every useful cone dominates it with that margin
+// wherever they meet -- so it neither counts for the magnitude behind delta nor for the tangency
+// test.  Out-of-range plane proposals (unary ~ 4e7, dispmap_ncc.m:245) would otherwise inflate delta
+// and send almost every message of such a fusion to the serial construction.  Returns "still bad";
+// m1 = min-plus value over the useful sources.
+__device__ __attribute__((noinline)) bool message_second_look(double lambda, int K, double alpha, double h,
+                                                              double qsrc, double t, double vtrunc,
+                                                              double delta, int lane, double &m1_out) {
+  const double inf = __builtin_huge_val();
+  const bool act = lane < K;
+  const double aq = alpha * qsrc;
+  const double qabs = wave_max_dpp(act ? max_raw(fabs(qsrc), fabs(t)) : 0.0);
+  const bool rel = act && h <= vtrunc + 2.000002 * fabs(alpha) * qabs;
+  const double mag2 = max_raw(wave_max_dpp(act ? (rel ? fabs(h) : 0.0) + fabs(aq) + alpha * fabs(t) : 0.0), fabs(vtrunc));
+  const double delta2 = 1e-9 * (mag2 + fabs(alpha * lambda));
+  if (!(delta2 < delta)) return true;
+  const double ui = h - aq, vi = h + aq;
+  unsigned long long mask = __builtin_amdgcn_ballot_w64(act && h < vtrunc);
+  double m1 = inf, m2 = inf;
+  bool bad = false;
+  while (mask) {
+    const int j = __builtin_ctzll(mask);
+    mask &= mask - 1;
+    const double hj = readlane_f64(h, j), qj = readlane_f64(qsrc, j);
+    const double c = pair_cost<1>(alpha, t - qj, hj);
+    const double lo = min_raw(m1, c), hi = max_raw(m1, c);
+    m2 = hi > lo ? min_raw(m2, hi) : m2;
+    m1 = lo;
+    const double aqj = alpha * qj;
+    const bool near = (fabs(ui - (hj - aqj)) <= delta2) || (fabs(vi - (hj + aqj)) <= delta2);
+    bad = bad || (near && qsrc != qj && rel);
+  }
+  bad = bad || (m1 < vtrunc && !(m2 - m1 > delta2 && vtrunc - m1 > delta2));
+  m1_out = m1;
+  return UNI(act && bad);
+}
+
 // Message update with everything in registers (K <= 64): h = gamma*Di - old message,
 // qsrc / t = source / destination positions, perm = ascending order of the sources
 // (only touched by the serial fallback).  Returns the normalised message in `out`.
@@ -942,6 +1081,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
 #undef STEREO_ACC
       bad = bad || (m1 < vtrunc && !(m2 - m1 > delta && vtrunc - m1 > delta));
       need_serial = UNI(act && bad);
+      if (need_serial) need_serial = message_second_look(p.lambda, K, alpha, h, qsrc, t, vtrunc, delta, lane, m1);
       out = m1 < vtrunc ? m1 : vtrunc;
       if (need_serial && lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
     }

@@ -24,6 +24,10 @@ while time.time() - t0 < budget:
     iters = int(rng.integers(1, 6))
     seed = int(rng.integers(0, 1 << 30))
     p = trws_problem(seed, H, W, K, kind="fronto" if shared else "general", integer=integer)
+    if rng.integers(0, 3) == 0:
+        # out-of-range plane proposals give unaries of 4e7 (dispmap_ncc.m:245): some labels of some pixels
+        huge = rng.random(p["unary"].shape) < 0.1
+        p["unary"] = np.where(huge, 4e7 + p["unary"], p["unary"])
     if shared:
         pos = np.cumsum(rng.uniform(0.05, 2.0, size=K)) if rng.integers(0, 2) else np.arange(K, dtype=np.float64)
         q = np.tile(pos, (p["conn"].shape[0], 1)); qp = q
