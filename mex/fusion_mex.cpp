@@ -7,7 +7,7 @@
 //        fusion_mex('unary_ncc', h, ncc HxWxD, disparities, unary_weight)            % dispmap_ncc
 //        fusion_mex('unary_globalstereo', h, im0, im1, P2 4x3, col_thresh)            % dispmap_globalstereo
 //   e  = fusion_mex('set_assignment', h, assignment 4xN)                             % set.assignment + update_energy
-//   [a, e] = fusion_mex('get_assignment', h)
+//   [a, e] = fusion_mex('get_assignment', h, N)
 //   [e, rd_e, lb, unl] = fusion_mex('binary', h, proposal 4xN, improve)
 //   [e, trws_e, lb, it] = fusion_mex('simultaneous', h, proposals 4xNxK, maxiter, max_relgap)
 //        fusion_mex('destroy', h)
