@@ -152,6 +152,13 @@ __device__ __forceinline__ double wave_max_dpp(double v) {
 #undef STEP
   return readlane_f64(v, 63);
 }
+// minimum of `a` and maximum of `b` over the wave in one interleaved pass (two independent chains)
+__device__ __forceinline__ void wave_min_max_dpp(double &a, double &b) {
+#define STEP(C, M) { const double oa = dpp_f64<C, M>(a), ob = dpp_f64<C, M>(b); a = min_raw(oa, a); b = max_raw(ob, b); }
+  DPP_REDUCE_STEPS(STEP)
+#undef STEP
+  a = readlane_f64(a, 63); b = readlane_f64(b, 63);
+}
 // lexicographic (value, index) minimum -> index of the FIRST minimum, uniform
 __device__ __forceinline__ int wave_argmin_dpp(double v, int i) {
 #define STEP(C, M) { const double ov = dpp_f64<C, M>(v); const int oi = dpp_i32<C, M>(i); \
@@ -982,7 +989,10 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
                                                int window = -1) {
   const double inf = __builtin_huge_val();
   const bool act = lane < K;
-  const double hmin = wave_min_dpp(h);  // inactive lanes hold +inf
+  // hmin and the magnitude behind delta in one interleaved reduction
+  const double aq = alpha * qsrc;
+  double hmin = h, mag = act ? fabs(h) + fabs(aq) + alpha * fabs(t) : 0.0;  // inactive lanes hold h = +inf
+  wave_min_max_dpp(hmin, mag);
   double out, vmin;
   if (UNI(alpha == 0)) {
     out = hmin; vmin = hmin;  // typeStereoLinear.h:390-396
@@ -1001,9 +1011,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
       // in real arithmetic, and (ii) at every destination whose minimum beats vTrunc the
       // minimum is delta-separated from the next larger cost and from vTrunc, so rounding
       // in the envelope's breakpoints cannot pick another value.  Otherwise: serial path.
-      const double aq = alpha * qsrc;
       const double ui = h - aq, vi = h + aq;
-      const double mag = wave_max_dpp(act ? fabs(h) + fabs(aq) + alpha * fabs(t) : 0.0);
       const double delta = 1e-9 * (mag + fabs(alpha * p.lambda));
       const bool useful = act && h < vtrunc;
       unsigned long long mask = __builtin_amdgcn_ballot_w64(useful);
