@@ -115,7 +115,8 @@ int stereo_trws_plan_counters(stereo_trws_plan *plan, int64_t *serial_messages, 
 
 /* Diagnostics: which sweep implementation the plan's current inputs select.
  * 0 level-synchronous launches, 1 generic persistent kernel, 2 pipelined kernel (K <= 64),
- * 3 wide pipelined kernel (64 < K <= 256, shared strictly ascending positions).
+ * 3 wide pipelined kernel (64 < K <= 256, shared strictly ascending positions),
+ * 4 two-labels-per-lane pipelined kernel (64 < K <= 128, linear kernel, any positions).
  * All give identical results.  Negative on a NULL plan. */
 int stereo_trws_plan_path(stereo_trws_plan *plan);
 

@@ -78,7 +78,8 @@ def test_wide_kernel_matches_oracle(case, hip, oracle):
 
 
 def test_wide_kernel_needs_ascending_positions(hip, oracle):
-    """Descending or repeated positions fall back to the generic kernel, same results."""
+    """Descending or repeated positions cannot use the windowed wide kernel: they run on the
+    two-labels-per-lane pipelined kernel (K <= 128), same results."""
     from stereo_amd.trws import TrwsPlan
     K, H, W = 90, 6, 7
     p = trws_problem(44, H, W, K, kind="fronto")
@@ -88,7 +89,7 @@ def test_wide_kernel_needs_ascending_positions(hip, oracle):
         lab_o, en_o, lb_o, _ = oracle.trws(1, p["unary"], p["conn"], q, q, p["alphas"], 4.0, 3, -1e300, mode=1)
         plan = TrwsPlan(1, K, H * W, p["conn"].T)
         plan.upload(p["unary"].T, p["alphas"], 4.0, positions=pos)
-        assert plan.path() == 1
+        assert plan.path() == 4
         plan.iterate(3, max_relgap=-1e300)
         lab, en, lb, _ = plan.result()
         assert np.array_equal(lab, lab_o) and en == en_o and lb == lb_o
