@@ -136,3 +136,37 @@ def test_more_rows_than_resident_workgroups(H, W, K, hip, oracle):
     plan.iterate(3, max_relgap=-1e300)
     lab, en, lb, it = plan.result()
     assert np.array_equal(lab, lab_o) and en == en_o and lb == lb_o and it == it_o
+
+
+PIPE2 = [
+    # seed, H, W, K, integer, huge, tol, maxiter
+    (71, 8, 9, 65, False, False, 2.0, 4),
+    (72, 7, 8, 100, False, False, 3.0, 4),
+    (73, 6, 7, 128, False, False, 2.5, 3),
+    (74, 9, 8, 96, True, False, 3.0, 5),        # integer costs and positions: ties -> serial construction
+    (75, 8, 8, 79, False, True, 8.0, 4),        # out-of-range proposals: unaries of 4e7 among normal ones
+    (76, 1, 11, 90, False, False, 2.0, 4),      # a chain
+]
+
+
+@pytest.mark.parametrize("case", PIPE2, ids=[str(c[0]) for c in PIPE2])
+def test_two_labels_per_lane_kernel_matches_oracle(case, hip, oracle):
+    """64 < K <= 128 with per-edge positions (a simultaneous fusion of many proposals): the
+    two-labels-per-lane pipelined kernel against the oracle, bit exact."""
+    from stereo_amd.trws import TrwsPlan
+    seed, H, W, K, integer, huge, tol, maxiter = case
+    p = trws_problem(seed, H, W, K, kind="general", integer=integer)
+    if huge:
+        rng = np.random.default_rng(seed)
+        p["unary"] = np.where(rng.random(p["unary"].shape) < 0.15, 4e7 + p["unary"], p["unary"])
+    lab_o, en_o, lb_o, it_o = oracle.trws(1, p["unary"], p["conn"], p["q"], p["qprim"], p["alphas"], tol,
+                                          maxiter, -1e300, mode=1)
+    plan = TrwsPlan(1, K, H * W, p["conn"].T)
+    plan.upload(p["unary"].T, p["alphas"], tol, q=p["q"].T, qprim=p["qprim"].T)
+    assert plan.path() == 4
+    plan.iterate(maxiter, max_relgap=-1e300)
+    lab, en, lb, it = plan.result()
+    assert it == it_o and np.array_equal(lab, lab_o) and en == en_o and lb == lb_o
+    if not integer:
+        E = p["conn"].shape[0]
+        assert plan.serial_messages() < 0.2 * (2 * E * maxiter + E)
