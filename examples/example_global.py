@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""example_global.m on the GPU: dispmap_globalstereo (photo-consistency unary, truncated linear
+smoothness with segment-dependent weights, QPBO with Improve) and a sweep of binary fusions over
+piecewise-planar proposals.
+
+    python examples/example_global.py [im_left.png im_right.png] [--size H W]
+
+Out of scope here: the reference's SegPln proposals come from a mean-shift
+segmentation + plane fits and its edge weights from the same segmentation; this script uses its own
+deterministic stand-ins -- block-wise random planes at several block sizes, and "same segment" =
+small colour difference across the edge.  Without images a synthetic textured pair is used.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def piecewise_planar(H, W, cell, rng, d_lo, d_hi):
+    """One proposal, 4 x N (pixel id = col * H + row): a random plane [a b 1 -d] per cell x cell block."""
+    rows, cols = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    by, bx = rows // cell, cols // cell
+    nb = (by.max() + 1, bx.max() + 1)
+    a = rng.normal(0, 0.3, nb)[by, bx]
+    b = rng.normal(0, 0.3, nb)[by, bx]
+    d0 = rng.uniform(d_lo, d_hi, nb)[by, bx]
+    x, y = cols + 1.0, rows + 1.0
+    cx, cy = (bx + 0.5) * cell, (by + 0.5) * cell
+    # disparity d0 at the block centre: -(a x + b y + p4) = d0 + a (cx - x) + b (cy - y)
+    p4 = -(d0 + a * cx + b * cy)
+    planes = np.stack([a, b, np.ones_like(a), p4])                     # 4 x H x W
+    return np.asfortranarray(planes.transpose(0, 2, 1).reshape(4, H * W))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("images", nargs="*")
+    ap.add_argument("--size", type=int, nargs=2, default=[375, 450])
+    args = ap.parse_args()
+    import stereo_amd
+    from stereo_amd import terms as T
+    if len(args.images) == 2:
+        from PIL import Image
+        images = [np.asarray(Image.open(f).convert("RGB"), dtype=np.float64) for f in args.images]
+    else:
+        from bench import synthetic_pair
+        images = list(synthetic_pair(args.size[0], args.size[1], 60))
+    H, W = images[0].shape[:2]
+    P = np.tile(np.hstack([np.eye(3), np.zeros((3, 1))])[:, :, None], (1, 1, 2))   # example_global.m:17-18
+    P[0, 3, 1] = -0.25
+    disp_range, disparity_factor = (0, 59), 4
+    # edge weights: lambda_h inside a "segment" (small colour difference), lambda_l across
+    conn = T.construct_neighborhood(H, W)
+    img = images[0].transpose(1, 0, 2).reshape(H * W, -1)
+    same = np.abs(img[conn[0]] - img[conn[1]]).sum(axis=1) < 30.0
+    weights = np.where(same, 108.0, 9.0) * 2.0                                      # dispmap_globalstereo.m:400-403
+    rng = np.random.default_rng(0)
+    t0 = time.time()
+    dm = stereo_amd.dispmap_globalstereo(images, P, disp_range, disparity_factor, smooth_weights=weights, rng=rng)
+    print("object + random start: %.2f s, energy %.6f" % (time.time() - t0, dm.energy()))
+    d_lo, d_hi = dm.d_min, dm.d_min + dm.d_step
+    proposals = [piecewise_planar(H, W, cell, rng, d_lo, d_hi) for cell in (8, 12, 16, 24, 32, 48, 64) for _ in range(2)]
+    t0 = time.time()
+    for k, p in enumerate(proposals):
+        e, lb, unl = dm.binary_fusion(p)
+    dt = time.time() - t0
+    print("binary fusion of %d piecewise-planar proposals: %.3f s (%.1f moves/s), energy %.6f, last move: %d unlabelled" % (
+        len(proposals), dt, len(proposals) / dt, dm.energy(), int(unl)))
+
+
+if __name__ == "__main__":
+    main()

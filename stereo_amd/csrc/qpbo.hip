@@ -158,16 +158,20 @@ __device__ __forceinline__ bool grid_sync(int32_t *ctl, unsigned &gen) {
   return __hip_atomic_load(ctl + QpboCtl::kAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
 }
 
-__global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *ctl, int relabel_every, int max_rounds) {
+__global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *ctl, int relabel_every, int max_rounds,
+                                                            int tiled, int switch_at) {
+  extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // tile state of the tiled rounds
   __shared__ int s_red;
   __shared__ int s_h[kMB];
   unsigned gen = 0;
   const int n = g.n;
   const int first = blockIdx.x * kMB + threadIdx.x, stride = gridDim.x * kMB;
   int32_t *h = g.h, *h2 = g.h2;
-  int slot = 0;  // rotating flag slot: written in phase k, read after its barrier, cleared one phase later
+  // rotating flag slots, one ring per flag family: written in phase k of that family, read after its
+  // barrier, cleared one phase (of the same family) later
+  int slotA = 0, slotC = 0;
   auto ld = [&](int w) { return __hip_atomic_load(ctl + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  auto clear_next = [&](int base) {
+  auto clear_next = [&](int base, int slot) {
     if (blockIdx.x == 0 && threadIdx.x == 0)
       __hip_atomic_store(ctl + base + (slot + 1) % 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
@@ -179,14 +183,16 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
   // result is deterministic, and a front crosses a whole tile per barrier instead of one level.
   auto global_relabel = [&](int &active) -> bool {
     constexpr int kArcRegs = 8;
-    for (int v = first; v < n; v += stride) stc(h + v, g.snk[v] > 0 ? 1 : n);
+    const long long t_in = wall_clock64();
+    const unsigned gen_in = gen;
+    for (int v = first; v < n; v += stride) stc(h + v, ldc(g.snk + v) > 0 ? 1 : n);
     // residuals do not change during the relabelling: after this invalidate plain loads of r see
     // what the (write-through, sc1) pushes stored
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (!grid_sync(ctl, gen)) return false;
     for (;;) {
-      slot = (slot + 1) % 3;
-      clear_next(QpboCtl::kChanged);
+      slotC = (slotC + 1) % 3;
+      clear_next(QpboCtl::kChanged, slotC);
       bool any_changed = false;
       for (int T = blockIdx.x; T < g.ntiles; T += gridDim.x) {
         const int v = g.perm[T * kMB + threadIdx.x];
@@ -228,31 +234,36 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         __syncthreads();
       }
       if (__syncthreads_or(any_changed) && threadIdx.x == 0)
-        __hip_atomic_store(ctl + QpboCtl::kChanged + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ctl + QpboCtl::kChanged + slotC, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (!grid_sync(ctl, gen)) return false;
-      if (!ld(QpboCtl::kChanged + slot)) break;
+      if (!ld(QpboCtl::kChanged + slotC)) break;
     }
-    slot = (slot + 1) % 3;
-    clear_next(QpboCtl::kActive);
+    slotA = (slotA + 1) % 3;
+    clear_next(QpboCtl::kActive, slotA);
     int cnt = 0;
-    for (int v = first; v < n; v += stride) cnt += (g.ex[v] > 0 && ldc(h + v) < n) ? 1 : 0;
+    for (int v = first; v < n; v += stride) cnt += (ldc(g.ex + v) > 0 && ldc(h + v) < n) ? 1 : 0;
     cnt = __syncthreads_count(cnt > 0 ? 1 : 0) > 0 ? cnt : 0;
     if (threadIdx.x == 0) s_red = 0;
     __syncthreads();
     if (cnt) atomicAdd(&s_red, cnt);
     __syncthreads();
     if (threadIdx.x == 0 && s_red)
-      __hip_atomic_fetch_add(ctl + QpboCtl::kActive + slot, s_red, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(ctl + QpboCtl::kActive + slotA, s_red, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!grid_sync(ctl, gen)) return false;
-    active = ld(QpboCtl::kActive + slot);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { ctl[QpboCtl::kRelabels] += 1; ctl[10] += (int)gen; ctl[11 + (ctl[QpboCtl::kRelabels] - 1 < 4 ? ctl[QpboCtl::kRelabels] - 1 : 4)] = (int)gen; }
+    active = ld(QpboCtl::kActive + slotA);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // statistics: #relabels, their barriers and time (10 ns ticks)
+      ctl[QpboCtl::kRelabels] += 1;
+      ctl[11] += (int)(wall_clock64() - t_in);
+      ctl[12] += (int)(gen - gen_in);
+    }
     return true;
   };
 
   int active = 0;
   if (!global_relabel(active)) return;
   int rounds = 0, since_relabel = 0, interval = relabel_every < 8 ? relabel_every : 8, stagnant = 0, last_active = active;
-  while (active > 0 && rounds < max_rounds) {
+
+  while (active > 0 && rounds < max_rounds && (tiled <= 0 || rounds < switch_at)) {
     // ---- push (old heights; a pair of arcs is only modified by the endpoint that is higher)
     for (int v = first; v < n; v += stride) {
       double e = g.ex[v];
@@ -305,8 +316,8 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     }
     if (!grid_sync(ctl, gen)) return;
     // ---- gather the pushed flow in the node's own arc order, relabel from the post-push residual graph
-    slot = (slot + 1) % 3;
-    clear_next(QpboCtl::kActive);
+    slotA = (slotA + 1) % 3;
+    clear_next(QpboCtl::kActive, slotA);
     int cnt = 0;
     for (int v = first; v < n; v += stride) {
       double e = g.ex[v];
@@ -354,9 +365,9 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     if (cnt) atomicAdd(&s_red, cnt);
     __syncthreads();
     if (threadIdx.x == 0 && s_red)
-      __hip_atomic_fetch_add(ctl + QpboCtl::kActive + slot, s_red, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(ctl + QpboCtl::kActive + slotA, s_red, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!grid_sync(ctl, gen)) return;
-    active = ld(QpboCtl::kActive + slot);
+    active = ld(QpboCtl::kActive + slotA);
     if (g.counters && blockIdx.x == 0 && threadIdx.x == 0 && rounds < 1024) g.counters[16 + rounds] = active;
     { int32_t *t = h; h = h2; h2 = t; }
     ++rounds; ++since_relabel;
@@ -371,8 +382,190 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
       interval = interval * 2 < relabel_every ? interval * 2 : relabel_every;
     }
   }
+  // ---- tiled rounds (every node has at most four arcs: the 4-connected grid) ------------------
+  // One round per grid barrier moves excess one hop; on instances with strong smoothness the flow
+  // has to travel hundreds of pixels.  Here a workgroup takes its tile (a 16 x 32 pixel patch and
+  // its mates: excess, heights, sink capacities and the residuals of the tile's own arcs) into
+  // LDS and runs up to `tiled` synchronous push / gather + relabel rounds there between two grid
+  // barriers.  Arcs that leave the tile are pushed on in the first local round only, when both
+  // endpoints see the heights of the last barrier (so still only the higher endpoint of an arc pair
+  // pushes); the amount goes into delta[parity][arc] and the owner of the reverse arc takes it in
+  // at the start of its next round.  Same per-node arithmetic order in every run: deterministic.
+  bool exact = false;
+  if (tiled > 0 && active > 0 && rounds < max_rounds) {
+    const long long t_tiled = wall_clock64();
+    const int rounds_in = rounds;
+    // hand-over from the plain rounds: heights into g.h, excess and sink capacities written through
+    // (from here on the workgroup that owns a node's tile reads and writes them)
+    for (int v = first; v < n; v += stride) {
+      if (h != g.h) stc(g.h + v, ldc(h + v));
+      stc(g.ex + v, g.ex[v]); stc(g.snk + v, g.snk[v]);
+    }
+    h = g.h; h2 = g.h2;
+    if (!grid_sync(ctl, gen)) return;
+    double *s_ex = dyn_lds, *s_snk = dyn_lds + kMB, *s_r = dyn_lds + 2 * kMB, *s_d = dyn_lds + 6 * kMB;
+    int G = 0;  // global round number: pushes of round G land in delta buffer G & 1
+    // L local rounds (L == 0: only take in what was pushed across tile borders); counts the active
+    // nodes and one more per workgroup that pushed across a border (that flow is still in transit)
+    auto tile_round = [&](int L) -> bool {
+      ++G;
+      double *dout = g.delta + (size_t)(G & 1) * g.m, *din = g.delta + (size_t)((G + 1) & 1) * g.m;
+      slotA = (slotA + 1) % 3;
+      clear_next(QpboCtl::kActive, slotA);
+      int cnt = 0;
+      bool crossed = false;
+      for (int T = blockIdx.x; T < g.ntiles; T += gridDim.x) {
+        const int v = g.perm[T * kMB + threadIdx.x];
+        const bool valid = v >= 0;
+        int loc[4] = {-1, -1, -1, -1}, rvk[4] = {0, 0, 0, 0}, exth[4] = {n, n, n, n}, a0 = 0, deg = 0;
+        double e = 0;
+        int hv = n;
+        if (valid) {
+          e = ldc(g.ex + v); hv = ldc(h + v);
+          a0 = g.aptr[v]; deg = g.aptr[v + 1] - a0;
+          s_snk[threadIdx.x] = ldc(g.snk + v);
+          double rk[4], din_k[4];
+          int rvs[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            rk[k] = 0; din_k[k] = 0; rvs[k] = 0;
+            if (k < deg) {
+              const int a = a0 + k, w = g.head[a], pw = g.pos_of[w];
+              rvs[k] = g.rev[a];
+              rvk[k] = rvs[k] - g.aptr[w];
+              rk[k] = ldc(g.r + a);
+              if (pw / kMB == T) loc[k] = pw % kMB;
+              else { exth[k] = ldc(h + w); din_k[k] = ldc(din + rvs[k]); }
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (k < deg && din_k[k] != 0) {  // flow that arrived over this arc's reverse during the last round
+              e += din_k[k]; rk[k] += din_k[k];
+              stc(din + rvs[k], 0.0);
+            }
+            s_r[threadIdx.x * 4 + k] = rk[k];
+            s_d[threadIdx.x * 4 + k] = 0;
+          }
+        } else {
+          s_snk[threadIdx.x] = 0;
+        }
+        s_ex[threadIdx.x] = e;
+        s_h[threadIdx.x] = hv;
+        const int h0 = hv;  // height at the barrier
+        __syncthreads();
+        for (int l = 0; l < L; ++l) {
+          // push (a pair of arcs is only modified by the endpoint that is higher)
+          if (valid) {
+            e = s_ex[threadIdx.x]; hv = s_h[threadIdx.x];
+            if (e > 0 && hv < n) {
+              if (hv == 1) {
+                const double sk = s_snk[threadIdx.x];
+                if (sk > 0) {
+                  const double d = e < sk ? e : sk;
+                  s_snk[threadIdx.x] = sk - d;
+                  e -= d;
+                }
+              }
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                if (k < deg && e > 0) {
+                  const double ra = s_r[threadIdx.x * 4 + k];
+                  if (ra > 0) {
+                    const bool local = loc[k] >= 0;
+                    const int hw = local ? s_h[loc[k]] : exth[k];
+                    if ((local || l == 0) && hv == hw + 1) {
+                      const double d = e < ra ? e : ra;
+                      s_r[threadIdx.x * 4 + k] = ra - d;
+                      if (local) s_d[loc[k] * 4 + rvk[k]] = d;
+                      else { stc(dout + a0 + k, d); crossed = true; }
+                      e -= d;
+                    }
+                  }
+                }
+              }
+              s_ex[threadIdx.x] = e;
+            }
+          }
+          __syncthreads();
+          // gather in the node's own arc order, relabel from the post-push residual graph
+          int newh = n;
+          if (valid) {
+            e = s_ex[threadIdx.x];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (k < deg) {
+                const double d = s_d[threadIdx.x * 4 + k];
+                if (d != 0) { e += d; s_r[threadIdx.x * 4 + k] += d; s_d[threadIdx.x * 4 + k] = 0; }
+              }
+            }
+            s_ex[threadIdx.x] = e;
+            hv = s_h[threadIdx.x];
+            newh = hv;
+            if (e > 0 && hv < n) {
+              int hmin = s_snk[threadIdx.x] > 0 ? 0 : n;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                // outside heights are lower bounds.  An outside neighbour that stood exactly one above
+                // this node at the barrier may have pushed to it in this round; the residual that gives
+                // this node's arc arrives with the next round, so the arc counts as open until then.
+                if (k < deg && (s_r[threadIdx.x * 4 + k] > 0 || (loc[k] < 0 && exth[k] == h0 + 1))) {
+                  const int hw = loc[k] >= 0 ? s_h[loc[k]] : exth[k];
+                  hmin = hw < hmin ? hw : hmin;
+                }
+              }
+              if (hmin + 1 > hv) newh = hmin + 1 < n ? hmin + 1 : n;
+            }
+          }
+          __syncthreads();  // every old height has been read
+          if (valid) s_h[threadIdx.x] = newh;
+          if (!__syncthreads_or(valid && s_ex[threadIdx.x] > 0 && newh < n)) break;
+        }
+        if (valid) {
+          stc(g.ex + v, s_ex[threadIdx.x]); stc(g.snk + v, s_snk[threadIdx.x]);  // read by other workgroups in the relabelling
+          const int hnew = s_h[threadIdx.x];
+          stc(h + v, hnew);
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (k < deg) stc(g.r + a0 + k, s_r[threadIdx.x * 4 + k]);
+          if (s_ex[threadIdx.x] > 0 && hnew < n) ++cnt;
+        }
+        __syncthreads();  // the tile buffers are reused
+      }
+      if (threadIdx.x == 0) s_red = 0;
+      __syncthreads();
+      if (cnt) atomicAdd(&s_red, cnt);
+      if (crossed) atomicOr(&s_red, 1 << 30);
+      __syncthreads();
+      if (threadIdx.x == 0 && s_red)
+        __hip_atomic_fetch_add(ctl + QpboCtl::kActive + slotA, (s_red & ((1 << 30) - 1)) + (s_red >> 30), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+      if (!grid_sync(ctl, gen)) return false;
+      active = ld(QpboCtl::kActive + slotA);
+      return true;
+    };
+    do {
+      while (active > 0 && rounds < max_rounds) {
+        if (!tile_round(tiled)) return;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && g.counters && rounds < 1024) g.counters[16 + rounds] = active;
+        ++rounds; ++since_relabel;
+        stagnant = active >= last_active ? stagnant + 1 : 0;
+        last_active = active;
+        if (active > 0 && (since_relabel >= interval || (stagnant >= 2 && since_relabel >= 4))) {
+          if (!tile_round(0)) return;  // nothing in transit while the residual graph is searched
+          if (!global_relabel(active)) return;
+          since_relabel = 0; stagnant = 0; last_active = active;
+          interval = interval * 2 < relabel_every ? interval * 2 : relabel_every;
+        }
+      }
+      if (!global_relabel(active)) return;  // exact heights: anything left over is cut off
+    } while (active > 0 && rounds < max_rounds);
+    exact = true;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctl[13] += (int)(wall_clock64() - t_tiled); ctl[14] += rounds - rounds_in; }
+  }
+
   // heights may be stale lower bounds: one exact BFS defines T; leave it in g.h
-  if (!global_relabel(active)) return;
+  if (!exact && !global_relabel(active)) return;
   if (h != g.h) {
     for (int v = first; v < n; v += stride) g.h[v] = ldc(h + v);
   }
@@ -637,6 +830,7 @@ struct QpboSolver {
   std::vector<double> snk0;
   QpboDev g{};
   int64_t iterations = 0, relabels = 0;
+  int max_degree = 0;  // arcs per doubled node (4 on the 4-connected grid)
 
   void upload() {
     n = (int)(2 * P.N); m = (int)P.head.size();
@@ -644,8 +838,10 @@ struct QpboSolver {
     d_head.upload(P.head.data(), P.head.size());
     d_rev.upload(P.rev.data(), P.rev.size());
     d_r.upload(P.cap.data(), P.cap.size());
-    d_delta.alloc(std::max(m, 1));
-    STEREO_HIP_CHECK(hipMemset(d_delta.p, 0, sizeof(double) * std::max(m, 1)));
+    d_delta.alloc((size_t)2 * std::max(m, 1));
+    STEREO_HIP_CHECK(hipMemset(d_delta.p, 0, sizeof(double) * 2 * std::max(m, 1)));
+    max_degree = 0;
+    for (int v = 0; v < n; ++v) max_degree = std::max(max_degree, (int)(P.aptr[v + 1] - P.aptr[v]));
     std::vector<double> ex(n), snk(n);
     for (int v = 0; v < n; ++v) {  // QPBO_maxflow.cpp:135-150: tr_cap > 0 source arc, < 0 sink arc
       ex[v] = P.tr[v] > 0 ? P.tr[v] : 0.0;
@@ -756,20 +952,29 @@ struct QpboSolver {
     int dev = 0, cus = 0, per_cu = 0;
     STEREO_HIP_CHECK(hipGetDevice(&dev));
     STEREO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    STEREO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qpbo_maxflow_kernel, kMB, 0));
+    STEREO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qpbo_maxflow_kernel, kMB, sizeof(double) * 10 * kMB));
     if (per_cu < 1) throw HipError{"qpbo_maxflow_kernel does not fit on a CU"};
     int blocks = std::min(cus * std::min(per_cu, 2), std::max(g.ntiles, 1));
     blocks = std::max(blocks, 1);
     QpboDev gg = g;
     int32_t *ctl = d_ctl.p;
     int max_rounds = 1 << 21;
-    void *args[] = {&gg, &ctl, &relabel_every, &max_rounds};
-    STEREO_HIP_CHECK(hipLaunchCooperativeKernel((const void *)qpbo_maxflow_kernel, dim3(blocks), dim3(kMB), args, 0, 0));
+    // tiled rounds: every node has at most four arcs and the pushed-amount buffer has two halves
+    int tiled = (max_degree <= 4 && d_delta.n >= (size_t)2 * std::max(m, 1)) ? 16 : 0;
+    if (const char *e = std::getenv("STEREO_HIP_QPBO_TILED")) tiled = tiled ? std::max(0, std::atoi(e)) : 0;
+    const size_t dyn = tiled ? sizeof(double) * 10 * kMB : 0;
+    if (tiled) STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)qpbo_maxflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    int switch_at = 16;  // plain rounds first: most moves end within a dozen of them
+    if (const char *e = std::getenv("STEREO_HIP_QPBO_SWITCH")) switch_at = std::max(0, std::atoi(e));
+    void *args[] = {&gg, &ctl, &relabel_every, &max_rounds, &tiled, &switch_at};
+    STEREO_HIP_CHECK(hipLaunchCooperativeKernel((const void *)qpbo_maxflow_kernel, dim3(blocks), dim3(kMB), args, dyn, 0));
     int32_t host_ctl[QpboCtl::kWords];
     STEREO_HIP_CHECK(hipMemcpy(host_ctl, d_ctl.p, sizeof(host_ctl), hipMemcpyDeviceToHost));
     if (host_ctl[QpboCtl::kAbort] == 1) throw HipError{"stereo_rd: grid barrier gave up (device-side spin bound)"};
     if (host_ctl[QpboCtl::kAbort] == 2) throw HipError{"stereo_rd: push-relabel did not converge within the round bound"};
-    if (std::getenv("STEREO_HIP_QPBO_VERBOSE")) std::fprintf(stderr, "[stereo_hip qpbo] barrier generations at the end of relabels: %d %d %d %d %d\n", host_ctl[11], host_ctl[12], host_ctl[13], host_ctl[14], host_ctl[15]);
+    if (std::getenv("STEREO_HIP_QPBO_VERBOSE"))
+      std::fprintf(stderr, "[stereo_hip qpbo] relabels: %.3f ms, %d barriers; tiled section: %.3f ms, %d rounds\n", host_ctl[11] * 1e-5,
+                   host_ctl[12], host_ctl[13] * 1e-5, host_ctl[14]);
     if (std::getenv("STEREO_HIP_QPBO_VERBOSE")) { std::vector<int32_t> tr(1040); (void)hipMemcpy(tr.data(), d_cnt.p, sizeof(int32_t) * 1040, hipMemcpyDeviceToHost); std::fprintf(stderr, "[stereo_hip qpbo] active per round:"); for (int i = 0; i < host_ctl[QpboCtl::kRounds] && i < 1024; i += (i < 32 ? 1 : 8)) std::fprintf(stderr, " %d", tr[16 + i]); std::fprintf(stderr, "\n"); }
     iterations += host_ctl[QpboCtl::kRounds];
     relabels += host_ctl[QpboCtl::kRelabels];
@@ -1039,7 +1244,9 @@ extern "C" int stereo_rd_plan_create(int64_t N, int64_t E, const uint32_t *conn,
     S.P.N = N; S.P.aptr = aptr;
     S.n = (int)n; S.m = (int)m;
     S.d_aptr.upload(aptr.data(), aptr.size());
-    S.d_head.alloc(m); S.d_rev.alloc(m); S.d_r.alloc(m); S.d_delta.alloc(std::max<int64_t>(m, 1));
+    S.max_degree = 0;
+    for (size_t v = 0; v + 1 < aptr.size(); ++v) S.max_degree = std::max(S.max_degree, (int)(aptr[v + 1] - aptr[v]));
+    S.d_head.alloc(m); S.d_rev.alloc(m); S.d_r.alloc(m); S.d_delta.alloc((size_t)2 * std::max<int64_t>(m, 1));
     S.d_ex.alloc(n); S.d_snk.alloc(n); S.d_h.alloc(n); S.d_h2.alloc(n); S.d_cnt.alloc(2048);
     S.g.n = (int)n; S.g.m = (int)m; S.g.aptr = S.d_aptr.p; S.g.head = S.d_head.p; S.g.rev = S.d_rev.p;
     S.g.r = S.d_r.p; S.g.delta = S.d_delta.p; S.g.ex = S.d_ex.p; S.g.snk = S.d_snk.p; S.g.h = S.d_h.p;
@@ -1074,7 +1281,7 @@ static int rd_plan_solve_device(stereo_rd_plan *P, const double *const in[6], in
     d.konst = P->d_konst.p; d.ex = S.d_ex.p; d.snk = S.d_snk.p; d.trv = P->d_trv.p;
     // the two kernels may leave the sweep state of a previous move behind: restore the buffers
     S.g.h = S.d_h.p; S.g.h2 = S.d_h2.p;
-    STEREO_HIP_CHECK(hipMemsetAsync(S.d_delta.p, 0, sizeof(double) * std::max(S.m, 1), 0));
+    STEREO_HIP_CHECK(hipMemsetAsync(S.d_delta.p, 0, sizeof(double) * 2 * std::max(S.m, 1), 0));
     if (np > 0) hipLaunchKernelGGL(rd_pairs_kernel, dim3((unsigned)((np + kQB - 1) / kQB)), dim3(kQB), 0, 0, d);
     hipLaunchKernelGGL(rd_nodes_kernel, dim3((unsigned)((N + kQB - 1) / kQB)), dim3(kQB), 0, 0, d);
     STEREO_HIP_CHECK(hipMemcpyAsync(P->d_snk0.p, S.d_snk.p, sizeof(double) * n, hipMemcpyDeviceToDevice, 0));
