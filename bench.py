@@ -178,7 +178,7 @@ def main():
             "serial_envelope_messages": serial_msgs, "final_energy": energy, "final_lower_bound": lb, "iterations_done": iters,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": {3: "trws_wide_kernel", 2: "trws_pipe_kernel", 1: "trws_persistent_kernel", 0: "trws_sweep_kernel (per level)"}[plan.path()]
+                         "kernel": {4: "trws_pipe2_kernel", 3: "trws_wide_kernel", 2: "trws_pipe_kernel", 1: "trws_persistent_kernel", 0: "trws_sweep_kernel (per level)"}[plan.path()]
                                    + " (one persistent launch per sweep)", "bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches_per_iter},
         }

@@ -84,6 +84,7 @@ struct DevParams {
   int window;  // wide kernel: sources within lambda of a destination lie within +-window indices
   double uniform_step;  // wide kernel: != 0 if pos[k+d] - pos[k] == d * step exactly for |d| <= window <= 16
   int win_ok;  // shared strictly ascending positions and window <= 16: windowed min-plus allowed
+  double pos_gap;  // smallest distance of two neighbouring shared positions (ascending case)
   double pos_first, pos_last;  // ... their two ends
 };
 
@@ -325,6 +326,78 @@ __device__ __forceinline__ int build_envelope_regs(int K, double alpha, double h
   return maxtop;
 }
 
+// Certified fast path of the truncated QUADRATIC message (typeStereoQuadratic.h:329-501), K <= 64,
+// lane = source and destination label.  The reference builds the lower envelope of the parabolas
+// alpha (t - q_s)^2 + h_s as the lower convex hull of the points (q_s, g_s = h_s + alpha q_s^2) --
+// its breakpoint s = (g_k - g_j) / (2 alpha (q_k - q_j)) is the hull slope over 2 alpha -- by a
+// monotone-chain scan, then picks for destination t the stack slot with z[slot] < t <= z[slot+1].
+// Suppose that at t the smallest cost c_j(t) is separated from every other source's cost by more
+// than delta.  Since c_s(t) - c_j(t) = 2 alpha (q_s - q_j) (sigma(j,s) - t), every exact slope from
+// j to a later source exceeds t + delta / (2 alpha Q) and every slope from an earlier source to j is
+// below t - delta / (2 alpha Q) (Q = span of the source positions).  If the rounding error of any
+// computed breakpoint that involves j (<= ~1e-14 G / (alpha gap), G >= |g|, gap = distance from
+// a useful source to the nearest other source) is smaller than that margin, then (i) j is pushed
+// when its turn comes (no near-duplicate position: gap > 1e-8 regime), (ii) no later source pops it
+// (its breakpoint against j stays above j's own), and (iii) j's two breakpoints on the final stack
+// bracket t; breakpoints increase strictly along the stack by construction (a push requires
+// s > z[top]), so the walk stops at j: the reference returns exactly alpha (t-q_j)^2 + h_j, the
+// plain min-plus value.  Sources with h >= vTrunc cost >= vTrunc everywhere: they are covered by
+// the margin to vTrunc.  Destinations whose minimum is >= vTrunc return vTrunc whatever is picked.
+// Returns "needs the serial construction"; m1 = min-plus value over the useful sources.
+__device__ __forceinline__ bool message_quad_fast(double lambda, int K, double alpha, double h, double qsrc,
+                                                  double t, double vtrunc, int lane, const double *hq,
+                                                  double &m1_out, int window = -1, double shared_gap = 0) {
+  const double inf = __builtin_huge_val();
+  const bool act = lane < K;
+  double scale = act ? fabs(h) + alpha * qsrc * qsrc + alpha * t * t : 0.0;  // >= |g| and >= cost / 4
+  scale = wave_max_dpp(scale);
+  double qlo = act ? qsrc : inf, qhi = act ? qsrc : -inf;
+  wave_min_max_dpp(qlo, qhi);  // smallest and largest source position
+  const double delta = 1e-9 * (scale + fabs(alpha * lambda) + fabs(vtrunc));
+  unsigned long long mask = __builtin_amdgcn_ballot_w64(act && h < vtrunc);
+  double m1 = inf, m2 = inf;
+  // `gap` must not become a wave-uniform constant: this compiler (AMD clang 22, gfx950) then merges it
+  // with the uniform `shared_gap` in scalar registers and emits s_mov_b64 with a 64-bit literal, which
+  // the encoder truncates to its low half (+inf -> 0.0).  build.sh greps the ISA for that pattern.
+  double gap = inf;
+  asm volatile("" : "+v"(gap));
+  if (window >= 0 && __builtin_popcountll(mask) > 2 * window + 1) {
+    // shared strictly ascending positions (padded table): a source more than `window` indices away
+    // lies farther than sqrt(lambda (1 + 1e-9)) and costs >= vTrunc bit for bit (alpha > 0; the two
+    // roundings of alpha d d lose less than the 1e-9), so it is covered by the margin to vTrunc
+    for (int d = -window; d <= window; ++d) {
+      const double hj = hq[4 * (lane + d)], qj = hq[4 * (lane + d) + 1];
+      const double c = pair_cost<2>(alpha, t - qj, hj);
+      const double lo = min_raw(m1, c), hi = max_raw(m1, c);
+      m2 = min_raw(m2, hi);
+      m1 = lo;
+    }
+    gap = shared_gap;
+    mask = 0;
+  }
+  while (mask) {
+    const int j = __builtin_ctzll(mask);
+    mask &= mask - 1;
+    double hj, qj;
+    if (hq) { hj = hq[4 * j]; qj = hq[4 * j + 1]; }
+    else { hj = readlane_f64(h, j); qj = readlane_f64(qsrc, j); }
+    const double c = pair_cost<2>(alpha, t - qj, hj);
+    const double lo = min_raw(m1, c), hi = max_raw(m1, c);
+    m2 = min_raw(m2, hi);  // second smallest, equal costs of two sources count
+    m1 = lo;
+    const double dq = fabs(qsrc - qj);
+    gap = lane != j ? min_raw(gap, dq) : gap;
+  }
+  gap = wave_min_dpp(act ? gap : inf);
+  bool bad = !(delta < inf) || !(alpha > 0) || !(gap > 4e-8);
+  // breakpoint error <= ~7 eps G / (alpha gap) must stay below the slope margin delta / (2 alpha Q):
+  // delta gap > 1.6e-15 G Q, tested with a factor 60 in hand
+  bad = bad || !(1e-13 * scale * (qhi - qlo) < delta * gap);
+  bad = bad || (m1 < vtrunc && !(m2 - m1 > delta && vtrunc - m1 > delta));
+  m1_out = m1;
+  return UNI(act && bad);
+}
+
 // One message update by one wave (typeStereo*.h UpdateMessage).  Di lives in
 // LDS.  Returns vMin (identical in all lanes).  SC1: the new message is stored
 // write-through at agent scope (it is consumed by another workgroup inside the
@@ -399,6 +472,12 @@ __device__ double update_message(const DevParams &p, int e, const double *Di, do
         }
         bad = bad || (m1 < vtrunc && !(m2 - m1 > delta));
         need_serial = UNI(lane < K && bad);
+        out = m1 < vtrunc ? m1 : vtrunc;
+        if (need_serial && lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
+      }
+      if (KERNEL == 2 && p.certificate) {
+        double m1;
+        need_serial = message_quad_fast(p.lambda, K, alpha, h, qsrc, t, vtrunc, lane, nullptr, m1);
         out = m1 < vtrunc ? m1 : vtrunc;
         if (need_serial && lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
       }
@@ -1093,6 +1172,17 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
       out = m1 < vtrunc ? m1 : vtrunc;
       if (need_serial && lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
     }
+    if (KERNEL == 2 && p.certificate) {
+      if (hq) {
+        hq[4 * lane] = h; hq[4 * lane + 1] = qsrc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      double m1;
+      need_serial = message_quad_fast(p.lambda, K, alpha, h, qsrc, t, vtrunc, lane, hq, m1, hq ? window : -1, p.pos_gap);
+      out = m1 < vtrunc ? m1 : vtrunc;
+      if (need_serial && lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
+    }
     if (need_serial) {
       const int idx = act ? perm[lane] : lane;
       const double hs = __shfl(h, idx, kWave), qs = __shfl(qsrc, idx, kWave);
@@ -1778,7 +1868,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, i
 // hardware barrier per visit.  Nodes with more than four outgoing messages take a second round
 // (message j + 4 on the same waves).  If the certificate fails, wave 3j runs the reference's
 // serial envelope construction in LDS (one at a time per workgroup: shared scratch, rare).
-// Kernel 1 (truncated linear) only; kernel 2 has no certificate and stays on the generic kernel.
+// Kernel 1 (truncated linear) only; kernel 2 above K = 64 stays on the generic kernel.
 constexpr int kWideCompute = 12;
 constexpr int kWideWaves = kWideCompute + 4;  // + loader (own data), loader (foreign data), storer, primal
 constexpr int kWideThreads = kWideWaves * kWave;
@@ -2494,7 +2584,7 @@ struct stereo_trws_plan {
   bool fast2 = false; // 64 < K <= 128, linear kernel, any positions: trws_pipe2_kernel (when not wide)
   bool wide_allowed = false;
   bool pos_ascending = false;  // shared positions finite and strictly ascending
-  double pos_first = 0, pos_last = 0;
+  double pos_first = 0, pos_last = 0, pos_gap = 0;
   int window = 0;
   double uniform_step = 0;
   DevBuf<unsigned long long> d_fallbacks, d_prof, d_timeline;
@@ -2568,6 +2658,7 @@ DevParams make_params(stereo_trws_plan *P) {
   p.debug = 0;
   if (const char *dbg = std::getenv("STEREO_HIP_TRWS_DEBUG")) p.debug = std::atoi(dbg);
   p.win_ok = (P->pos_ascending && P->window <= 16 && !(p.debug & 256)) ? 1 : 0;
+  p.pos_gap = P->pos_gap;
   if (const char *pr = std::getenv("STEREO_HIP_TRWS_PROF_RUN")) p.prof_run = std::atoi(pr);
   return p;
 }
@@ -2723,13 +2814,15 @@ void finish_inputs(stereo_trws_plan *P) {
       for (int k = 0, lo = 0; k < P->K; ++k) {
         for (;; ++lo) {
           const double d = hp[k] - hp[lo];
-          if ((P->kernel == 1 ? d : d * d) <= P->lambda) break;
+          if ((P->kernel == 1 ? d : d * d) <= (P->kernel == 1 ? P->lambda : P->lambda * (1 + 1e-9))) break;
         }
         w = std::max(w, k - lo);
       }
       P->window = w;
       P->pos_ascending = true;
       P->pos_first = hp[0]; P->pos_last = hp[P->K - 1];
+      P->pos_gap = std::numeric_limits<double>::infinity();
+      for (int k = 1; k < P->K; ++k) P->pos_gap = std::min(P->pos_gap, hp[k] - hp[k - 1]);
       P->wide = P->wide_allowed;
       // exact arithmetic progression inside the window?  (then alpha |t - q| = alpha |d step| bit for bit)
       P->uniform_step = 0;

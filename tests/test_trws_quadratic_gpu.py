@@ -1,0 +1,107 @@
+"""-m gpu parity tests of the certified fast path of the truncated QUADRATIC message
+(typeStereoQuadratic.h:329-501; DESIGN.md 4.3 "quadratic certificate") against the CPU oracle,
+which runs the reference's serial envelope construction.  Bar: labels, energy, lower bound and
+iteration count bit exact; and the fast path must actually carry the generic instances.
+"""
+import numpy as np
+import pytest
+
+from helpers import trws_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_shared(hip, oracle, seed, H, W, K, pos, tol, maxiter, integer=False, alpha_scale=1.0):
+    from stereo_amd.trws import TrwsPlan
+    p = trws_problem(seed, H, W, K, kind="fronto", integer=integer, alpha_scale=alpha_scale)
+    E = p["conn"].shape[0]
+    q = np.tile(pos, (E, 1))
+    ref = oracle.trws(2, p["unary"], p["conn"], q, q, p["alphas"], tol, maxiter, -1e300, mode=1)
+    plan = TrwsPlan(2, K, H * W, p["conn"].T)
+    plan.upload(p["unary"].T, p["alphas"], tol, positions=pos)
+    assert plan.path() == 2
+    plan.iterate(maxiter, max_relgap=-1e300)
+    lab, en, lb, it = plan.result()
+    assert it == ref[3]
+    assert np.array_equal(lab, ref[0]), "labels differ at %d nodes" % int((lab != ref[0]).sum())
+    assert en == ref[1] and lb == ref[2]
+    return plan.serial_messages(), 2 * E * maxiter + E
+
+
+SHARED = [
+    # seed, H, W, K, positions, tol (= lambda, squared units), maxiter
+    (71, 9, 11, 16, "grid", 64.0, 4),      # window covers every label: useful-source loop
+    (72, 10, 12, 60, "grid", 64.0, 4),     # window 8 < K: windowed loop on flat messages
+    (73, 10, 12, 60, "grid", 8.0, 4),      # window 2
+    (74, 8, 9, 64, "half", 9.0, 4),        # spacing 0.5, negative positions
+    (75, 9, 10, 33, "irregular", 6.0, 4),
+    (76, 8, 8, 48, "offset", 16.0, 3),     # positions around 1e3: g = h + alpha q^2 is large, the margin scales with it
+    (77, 7, 9, 20, "grid", 0.0, 3),        # lambda = 0
+    (78, 6, 7, 40, "grid", 1e9, 3),        # no truncation
+]
+
+
+def _positions(kind, K, rng):
+    if kind == "grid":
+        return np.arange(K, dtype=np.float64)
+    if kind == "half":
+        return np.arange(K, dtype=np.float64) * 0.5 - 7.0
+    if kind == "offset":
+        return 1000.0 + np.arange(K, dtype=np.float64)
+    return np.cumsum(rng.uniform(0.05, 2.0, size=K))
+
+
+@pytest.mark.parametrize("case", SHARED, ids=[str(c[0]) for c in SHARED])
+def test_quadratic_shared_positions(case, hip, oracle):
+    seed, H, W, K, pk, tol, maxiter = case
+    pos = _positions(pk, K, np.random.default_rng(seed + 1000))
+    serial, total = _run_shared(hip, oracle, seed, H, W, K, pos, tol, maxiter)
+    if 0 < tol < 1e6:
+        assert serial < 0.2 * total, (serial, total)
+
+
+def test_quadratic_integer_ties_fall_back(hip, oracle):
+    # integer unaries / weights on the integer grid: equal costs at many destinations -> the margin
+    # fails and the serial construction decides, same bits
+    serial, total = _run_shared(hip, oracle, 81, 9, 10, 24, np.arange(24.0), 9.0, 5, integer=True)
+    assert serial > 0
+
+
+def test_quadratic_near_duplicate_positions_fall_back(hip, oracle):
+    # two positions 5e-9 apart: the reference's `q_k - q_j < 1e-8` branch; never certified
+    pos = np.arange(12.0)
+    pos[7] = pos[6] + 5e-9
+    serial, total = _run_shared(hip, oracle, 82, 7, 8, 12, pos, 9.0, 4)
+    assert serial > 0.5 * total
+
+
+@pytest.mark.parametrize("seed,H,W,K,tol", [(91, 12, 14, 8, 3.0), (92, 20, 30, 16, 3.0), (93, 9, 11, 15, 0.5),
+                                             (94, 8, 9, 40, 2.0)])
+def test_quadratic_per_edge_positions(seed, H, W, K, tol, hip, oracle):
+    # general planes: q != qprim, per-edge positions in arbitrary order (the simultaneous_fusion case)
+    from stereo_amd.trws import TrwsPlan
+    p = trws_problem(seed, H, W, K, kind="general")
+    maxiter = 4
+    ref = oracle.trws(2, p["unary"], p["conn"], p["q"], p["qprim"], p["alphas"], tol, maxiter, -1e300, mode=1)
+    plan = TrwsPlan(2, K, H * W, p["conn"].T)
+    plan.upload(p["unary"].T, p["alphas"], tol, q=p["q"].T, qprim=p["qprim"].T)
+    plan.iterate(maxiter, max_relgap=-1e300)
+    lab, en, lb, it = plan.result()
+    assert np.array_equal(lab, ref[0]) and en == ref[1] and lb == ref[2] and it == ref[3]
+    E = p["conn"].shape[0]
+    assert plan.serial_messages() < 0.5 * (2 * E * maxiter + E)
+
+
+def test_quadratic_certificate_off_gives_the_same_bits(hip, monkeypatch):
+    from stereo_amd.trws import TrwsPlan
+    p = trws_problem(95, 14, 15, 30, kind="fronto")
+    pos = np.arange(30.0)
+    out = []
+    for cert in ("1", "0"):
+        monkeypatch.setenv("STEREO_HIP_TRWS_CERTIFICATE", cert)
+        plan = TrwsPlan(2, 30, 14 * 15, p["conn"].T)
+        plan.upload(p["unary"].T, p["alphas"], 9.0, positions=pos)
+        plan.iterate(5, max_relgap=-1e300)
+        out.append(plan.result() + (plan.serial_messages(),))
+    a, b = out
+    assert np.array_equal(a[0], b[0]) and a[1:4] == b[1:4]  # (fallbacks are only counted with the certificate on)

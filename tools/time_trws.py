@@ -1,0 +1,31 @@
+"""Development tool: time TRW-S iterations of a synthetic volume for a given kernel / size.
+usage: time_trws.py [kernel=1] [H=375] [W=450] [K=60] [tol=8] [iters=10]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from bench import synthetic_volume
+from helpers import grid_conn
+from stereo_amd.trws import TrwsPlan
+a = sys.argv[1:]
+kernel = int(a[0]) if len(a) > 0 else 1
+H = int(a[1]) if len(a) > 1 else 375
+W = int(a[2]) if len(a) > 2 else 450
+K = int(a[3]) if len(a) > 3 else 60
+tol = float(a[4]) if len(a) > 4 else 8.0
+iters = int(a[5]) if len(a) > 5 else 10
+dev = torch.device("cuda", 0)
+conn = grid_conn(H, W); E = conn.shape[0]; N = H * W
+d_unary = torch.from_numpy(synthetic_volume(H, W, K, seed=1)).to(dev)
+plan = TrwsPlan(kernel, K, N, conn.T)
+d_alpha = torch.ones(E, dtype=torch.float64, device=dev)
+d_pos = torch.arange(K, dtype=torch.float64, device=dev)
+plan.bind_device(d_unary.data_ptr(), d_alpha.data_ptr(), tol, d_positions=d_pos.data_ptr(), keepalive=(d_unary, d_alpha, d_pos))
+plan.iterate(2, max_relgap=-1e300)
+plan.serial_messages(reset=True)
+torch.cuda.synchronize(); t = time.perf_counter()
+plan.iterate(iters, max_relgap=-1e300)
+dt = (time.perf_counter() - t) / iters
+_, en, lb, it = plan.result(want_labels=False)
+print("kernel %d %dx%dx%d tol %g: path %d, %.2f ms/iter (%.1f it/s), serial messages %d, energy %.6f lb %.6f" % (
+    kernel, W, H, K, tol, plan.path(), dt * 1e3, 1 / dt, plan.serial_messages(), en, lb))
