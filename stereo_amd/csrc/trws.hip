@@ -637,6 +637,71 @@ __device__ double update_message(const DevParams &p, int e, const double *Di, do
         __builtin_amdgcn_wave_barrier();  // everyone is done with the list in `sh`
       }
     }
+    if (MODE == STEREO_TRWS_MESSAGES_EXACT && KERNEL == 2 && p.certificate && K <= 4 * kWave) {
+      // Quadratic kernel, 64 < K <= 256 (up to four labels per lane): plain min-plus over the useful
+      // sources with the destination-margin certificate of message_quad_fast.  A / B
+      // hold the sources in ascending position order, so the smallest distance between two source
+      // positions is the smallest gap of two neighbours (all sources: more than the proof needs).
+      constexpr int NI = 4;
+      int *ul = (int *)sh;
+      int nu = 0;
+      double tt[NI], m1[NI], m2[NI];
+      double scale = 0, qlo = inf, qhi = -inf, gap = inf;
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        const int k = lane + it * kWave;
+        const bool on = k < K;
+        const double hk = on ? A[k] : inf, qk = on ? B[k] : 0.0;
+        tt[it] = on ? dst[k] : 0.0;
+        m1[it] = inf; m2[it] = inf;
+        if (on) {
+          scale = max_raw(scale, fabs(hk) + alpha * qk * qk + alpha * tt[it] * tt[it]);
+          qlo = min_raw(qlo, qk); qhi = max_raw(qhi, qk);
+          if (k + 1 < K) gap = min_raw(gap, B[k + 1] - qk);
+        }
+        const bool useful = on && hk < vtrunc;
+        const unsigned long long um = __builtin_amdgcn_ballot_w64(useful);
+        if (useful) ul[nu + __builtin_popcountll(um & ((1ull << lane) - 1))] = k;
+        nu += __builtin_popcountll(um);
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        scale = max_raw(scale, __shfl_xor(scale, off, kWave));
+        qlo = min_raw(qlo, __shfl_xor(qlo, off, kWave));
+        qhi = max_raw(qhi, __shfl_xor(qhi, off, kWave));
+        gap = min_raw(gap, __shfl_xor(gap, off, kWave));
+      }
+      const double delta = 1e-9 * (scale + fabs(alpha * p.lambda) + fabs(vtrunc));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int jj = 0; jj < nu; ++jj) {
+        const int j = ul[jj];
+        const double hj = A[j], qj = B[j];
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+          const double c = pair_cost<2>(alpha, tt[it] - qj, hj);
+          const double lo = min_raw(m1[it], c), hi = max_raw(m1[it], c);
+          m2[it] = min_raw(m2[it], hi);
+          m1[it] = lo;
+        }
+      }
+      bool bad = !(delta < inf) || !(alpha > 0) || !(gap > 4e-8) || !(1e-13 * scale * (qhi - qlo) < delta * gap);
+      vmin = inf;
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        if (lane + it * kWave < K) {
+          bad = bad || (m1[it] < vtrunc && !(m2[it] - m1[it] > delta && vtrunc - m1[it] > delta));
+          outv[it] = m1[it] < vtrunc ? m1[it] : vtrunc;
+          vmin = outv[it] < vmin ? outv[it] : vmin;
+        }
+      }
+      certified = !UNI(bad);
+      if (!certified) {
+        vmin = inf;
+        if (lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
+        __builtin_amdgcn_wave_barrier();  // everyone is done with the list in `sh`
+      }
+    }
     if (certified) {
       // outv / vmin are set
     } else if (MODE == STEREO_TRWS_MESSAGES_EXACT) {

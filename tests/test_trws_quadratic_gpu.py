@@ -19,7 +19,7 @@ def _run_shared(hip, oracle, seed, H, W, K, pos, tol, maxiter, integer=False, al
     ref = oracle.trws(2, p["unary"], p["conn"], q, q, p["alphas"], tol, maxiter, -1e300, mode=1)
     plan = TrwsPlan(2, K, H * W, p["conn"].T)
     plan.upload(p["unary"].T, p["alphas"], tol, positions=pos)
-    assert plan.path() == 2
+    assert plan.path() == (2 if K <= 64 else 1)
     plan.iterate(maxiter, max_relgap=-1e300)
     lab, en, lb, it = plan.result()
     assert it == ref[3]
@@ -38,6 +38,9 @@ SHARED = [
     (76, 8, 8, 48, "offset", 16.0, 3),     # positions around 1e3: g = h + alpha q^2 is large, the margin scales with it
     (77, 7, 9, 20, "grid", 0.0, 3),        # lambda = 0
     (78, 6, 7, 40, "grid", 1e9, 3),        # no truncation
+    (79, 7, 8, 100, "grid", 64.0, 3),      # K > 64: generic kernel, up to four labels per lane
+    (80, 6, 7, 256, "irregular", 30.0, 3),
+    (83, 5, 6, 200, "half", 16.0, 3),
 ]
 
 
@@ -76,7 +79,7 @@ def test_quadratic_near_duplicate_positions_fall_back(hip, oracle):
 
 
 @pytest.mark.parametrize("seed,H,W,K,tol", [(91, 12, 14, 8, 3.0), (92, 20, 30, 16, 3.0), (93, 9, 11, 15, 0.5),
-                                             (94, 8, 9, 40, 2.0)])
+                                             (94, 8, 9, 40, 2.0), (96, 6, 7, 130, 30.0)])
 def test_quadratic_per_edge_positions(seed, H, W, K, tol, hip, oracle):
     # general planes: q != qprim, per-edge positions in arbitrary order (the simultaneous_fusion case)
     from stereo_amd.trws import TrwsPlan
@@ -89,7 +92,8 @@ def test_quadratic_per_edge_positions(seed, H, W, K, tol, hip, oracle):
     lab, en, lb, it = plan.result()
     assert np.array_equal(lab, ref[0]) and en == ref[1] and lb == ref[2] and it == ref[3]
     E = p["conn"].shape[0]
-    assert plan.serial_messages() < 0.5 * (2 * E * maxiter + E)
+    if K <= 64:  # (130 random planes: positions closer than the certificate's gap bound allows)
+        assert plan.serial_messages() < 0.5 * (2 * E * maxiter + E)
 
 
 def test_quadratic_certificate_off_gives_the_same_bits(hip, monkeypatch):
