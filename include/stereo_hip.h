@@ -132,6 +132,21 @@ int stereo_trws_analyze(int64_t N, int64_t E, const uint32_t *conn, int64_t *ran
                         int64_t *fwd_idx, int64_t *bwd_ptr, int64_t *bwd_idx, int64_t *level,
                         char *err, size_t errcap);
 
+/* Host-only inspection of the dataflow schedule the descriptor-driven sweep kernels walk
+ * (trws_graph.h "chain schedule"; no reference counterpart -- the reference is serial,
+ * minimize.cpp:36-95).  direction 0 = forward sweep, 1 = backward.  max_resident_runs as
+ * passed by stereo_trws_plan_create (0 = unlimited).  Outputs (any may be NULL):
+ * rank_at (N): rank visited at schedule position p; run_ptr (N+1 entries provided, *nruns+1
+ * used): offsets of the runs in schedule positions; ticket_run (N provided, *nruns used):
+ * run picked up with ticket t; pred_rank (N, by rank): rank visited just before in the same
+ * run whose messages are handed over in LDS, or -1; dep_ptr (N+1) / dep_rank (4N provided):
+ * foreign ranks a node waits for (completion flags).  Returns non-zero if the graph is not
+ * eligible for those kernels. */
+int stereo_trws_schedule(int64_t N, int64_t E, const uint32_t *conn, int64_t max_resident_runs,
+                         int direction, int64_t *rank_at, int64_t *run_ptr, int64_t *nruns,
+                         int64_t *ticket_run, int64_t *pred_rank, int64_t *dep_ptr,
+                         int64_t *dep_rank, char *err, size_t errcap);
+
 /* ---- QPBO roof-duality binary fusion ---------------------------------- *
  * Replaces cpp/rd_mex.cpp:14-100 mexFunction:
  *   [labelling, energy, lower_bound, num_unlabelled] =

@@ -2640,7 +2640,7 @@ struct stereo_trws_plan {
   DevBuf<uint8_t> d_mdir;
   DevBuf<double> d_gamma, d_msg, d_lbterms, d_eterms;
   // persistent sweep schedule
-  DevBuf<int32_t> d_run_order[2];
+  DevBuf<int32_t> d_run_order[2], d_chain_run_ptr[2], d_chain_run_order[2];
   DevBuf<int32_t> d_run_ptr[2], d_dep_ptr[2], d_dep_rank[2], d_done, d_ctl;  // d_ctl: [ticket, abort]
   DevBuf<int8_t> d_in_slot[2];
   DevBuf<int32_t> d_desc[2];
@@ -2705,9 +2705,17 @@ DevParams make_params(stereo_trws_plan *P) {
   p.fptr = P->d_fptr.p; p.fidx = P->d_fidx.p; p.bptr = P->d_bptr.p; p.bidx = P->d_bidx.p;
   p.gamma = P->d_gamma.p; p.lb_pos_node = P->d_lbn.p; p.lb_pos_edge = P->d_lbe.p;
   p.lbterms = P->d_lbterms.p; p.eterms = P->d_eterms.p; p.x = P->d_x.p;
+  // the descriptor-driven kernels walk the chain schedule (trws_graph.h), the generic ones the
+  // rank-contiguous runs
+  const bool chain = P->g.fast_ok && (P->wide || P->fast2 || P->fast);
   for (int d = 0; d < 2; ++d) {
-    p.run_ptr[d] = P->d_run_ptr[d].p; p.nruns[d] = (int)P->g.sweep[d].run_ptr.size() - 1;
-    p.run_order[d] = P->d_run_order[d].p;
+    if (chain) {
+      p.run_ptr[d] = P->d_chain_run_ptr[d].p; p.nruns[d] = (int)P->g.sweep[d].chain_run_ptr.size() - 1;
+      p.run_order[d] = P->d_chain_run_order[d].p;
+    } else {
+      p.run_ptr[d] = P->d_run_ptr[d].p; p.nruns[d] = (int)P->g.sweep[d].run_ptr.size() - 1;
+      p.run_order[d] = P->d_run_order[d].p;
+    }
     p.dep_ptr[d] = P->d_dep_ptr[d].p; p.dep_rank[d] = P->d_dep_rank[d].p;
     p.in_slot[d] = P->d_in_slot[d].p;
   }
@@ -2964,7 +2972,11 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
       P->d_dep_ptr[d].upload(S.dep_ptr.data(), S.dep_ptr.size());
       P->d_dep_rank[d].upload(S.dep_rank.data(), S.dep_rank.size());
       P->d_in_slot[d].upload(S.in_slot.data(), S.in_slot.size());
-      if (g.fast_ok) P->d_desc[d].upload(S.desc.data(), S.desc.size());
+      if (g.fast_ok) {
+        P->d_desc[d].upload(S.desc.data(), S.desc.size());
+        P->d_chain_run_ptr[d].upload(S.chain_run_ptr.data(), S.chain_run_ptr.size());
+        if (!S.chain_run_order.empty()) P->d_chain_run_order[d].upload(S.chain_run_order.data(), S.chain_run_order.size());
+      }
     }
     P->fast = g.fast_ok && K <= kWave && message_mode == STEREO_TRWS_MESSAGES_EXACT;
     P->wide_allowed = g.fast_ok && kernel == 1 && K > kWave && K <= 256 && message_mode == STEREO_TRWS_MESSAGES_EXACT;
@@ -2980,13 +2992,16 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
     STEREO_HIP_CHECK(hipMemset(P->d_fallbacks.p, 0, sizeof(unsigned long long)));
     if (const char *c = std::getenv("STEREO_HIP_TRWS_CERTIFICATE")) P->certificate = std::string(c) != "0";
     if (std::getenv("STEREO_HIP_TRWS_PROF")) { P->d_prof.alloc(32); STEREO_HIP_CHECK(hipMemset(P->d_prof.p, 0, 256)); }
-    if (std::getenv("STEREO_HIP_TRWS_TIMELINE")) P->d_timeline.alloc(4 * g.sweep[0].run_ptr.size());
+    if (std::getenv("STEREO_HIP_TRWS_TIMELINE"))
+      P->d_timeline.alloc(4 * std::max({g.sweep[0].run_ptr.size(), g.sweep[0].chain_run_ptr.size(), g.sweep[1].chain_run_ptr.size()}) + 4);
     STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * N));
     STEREO_HIP_CHECK(hipMemset(P->d_ctl.p, 0, sizeof(int32_t) * 2));
     if (const char *sc = std::getenv("STEREO_HIP_TRWS_SCHEDULE")) P->persistent = std::string(sc) != "levels";
     {
       // one workgroup per concurrently active run, capped by what stays resident
-      const int64_t runs = std::max<int64_t>((int64_t)g.sweep[0].run_ptr.size() - 1, 1);
+      int64_t runs = std::max<int64_t>((int64_t)g.sweep[0].run_ptr.size() - 1, 1);
+      if (g.fast_ok)
+        runs = std::max<int64_t>({runs, (int64_t)g.sweep[0].chain_run_ptr.size() - 1, (int64_t)g.sweep[1].chain_run_ptr.size() - 1});
       P->grid_blocks = (int)std::min<int64_t>(runs, 256 * per_cu);
     }
     P->d_msg.alloc((size_t)E * K);
@@ -3052,7 +3067,8 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
 
 void stereo_trws_plan_destroy(stereo_trws_plan *plan) {
   if (plan && plan->d_timeline.p) {
-    const size_t R = plan->g.sweep[0].run_ptr.size() - 1;
+    const bool chain = plan->g.fast_ok && (plan->wide || plan->fast2 || plan->fast);
+    const size_t R = (chain ? plan->g.sweep[0].chain_run_ptr.size() : plan->g.sweep[0].run_ptr.size()) - 1;
     std::vector<unsigned long long> t(4 * (R + 1));
     if (hipMemcpy(t.data(), plan->d_timeline.p, sizeof(unsigned long long) * 4 * R, hipMemcpyDeviceToHost) == hipSuccess) {
       for (int d = 0; d < 2; ++d) {

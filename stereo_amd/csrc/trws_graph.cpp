@@ -268,12 +268,104 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
       TrwsGraph::Sweep &S = g.sweep[d];
       const std::vector<int32_t> &iptr = d == 0 ? g.bptr : g.fptr, &iidx = d == 0 ? g.bidx : g.fidx;
       const std::vector<int32_t> &optr = d == 0 ? g.fptr : g.bptr, &oidx = d == 0 ? g.fidx : g.bidx;
-      S.desc.assign((size_t)N * W, 0);
+      auto position = [&](int32_t r) -> int64_t { return d == 0 ? (int64_t)r : N - 1 - (int64_t)r; };
+      auto other_end = [&](int32_t e_in) -> int32_t { return g.rank[d == 0 ? g.tail[e_in] : g.head[e_in]]; };
+      // ---- chain schedule: a node extends the run of the node visited two steps or one step
+      // earlier if it depends on it and that node is still the last one of its run; two steps
+      // first, which is what separates two interleaved rows (s0 s1 s2 s3 ...: s3 hangs on s1 AND
+      // on s2, s4 only on s2) into the runs s0 s1 s3 s5 ... and s2 s4 s6 ...
+      std::vector<int32_t> lev(N, 0), run_of(N, -1), pred(N, -1), run_tail, first_lev;
+      std::vector<std::vector<int32_t>> runs;
+      const bool cut = max_resident_runs > 0 && (int64_t)S.run_ptr.size() - 1 > max_resident_runs;
+      constexpr int32_t kJump = 8;
       for (int64_t p = 0; p < N; ++p) {
         const int32_t r = d == 0 ? (int32_t)p : (int32_t)(N - 1 - p);
+        int32_t lv = 0, best = -1;
+        for (int32_t k = iptr[r]; k < iptr[r + 1]; ++k) {
+          const int32_t o = other_end(iidx[k]);
+          lv = std::max(lv, lev[o] + 1);
+          const int64_t back = p - position(o);
+          if ((back != 1 && back != 2) || run_tail[run_of[o]] != o) continue;
+          if (best < 0 || position(o) < position(best)) best = o;
+        }
+        lev[r] = lv;
+        if (cut && best >= 0 && lv > lev[best] + kJump) best = -1;
+        if (best >= 0) {
+          run_of[r] = run_of[best]; runs[run_of[r]].push_back(r); run_tail[run_of[r]] = r; pred[r] = best;
+        } else {
+          run_of[r] = (int32_t)runs.size(); runs.push_back({r}); run_tail.push_back(r); first_lev.push_back(lv);
+        }
+      }
+      const int64_t R = (int64_t)runs.size();
+      // foreign dependencies per rank (everything but the predecessor in the run)
+      std::vector<std::vector<int32_t>> deps(N);
+      bool ok = true;
+      for (int64_t r = 0; r < N && ok; ++r) {
+        for (int32_t k = iptr[r]; k < iptr[r + 1]; ++k) {
+          const int32_t o = other_end(iidx[k]);
+          if (o != pred[r] && std::find(deps[r].begin(), deps[r].end(), o) == deps[r].end()) deps[r].push_back(o);
+        }
+        ok = deps[r].size() <= 4;
+      }
+      // ticket order.  Runs are numbered by the position of their first node; a dependency can
+      // then live in a run with a LARGER number (the two interleaved rows need each other).  That
+      // is harmless while every run has its own resident workgroup.  With fewer workgroups than
+      // runs it must be shown that waiting never blocks the dispenser: accepted if a run only
+      // looks ahead to the very next ticket and that one looks ahead to nobody (the smallest
+      // unfinished ticket and its successor are always held, so both make progress).
+      std::vector<int32_t> order(R), ticket_of_run(R);
+      for (int64_t k = 0; k < R; ++k) order[k] = (int32_t)k;
+      if (cut) std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return first_lev[x] < first_lev[y]; });
+      auto look_ahead_ok = [&]() {
+        for (int64_t t = 0; t < R; ++t) ticket_of_run[order[t]] = (int32_t)t;
+        std::vector<int32_t> ahead(R, 0);  // per ticket: farthest ticket it waits for, minus its own
+        for (int64_t r = 0; r < N; ++r)
+          for (int32_t x : deps[r]) {
+            const int32_t mine = ticket_of_run[run_of[r]], theirs = ticket_of_run[run_of[x]];
+            ahead[mine] = std::max(ahead[mine], theirs - mine);
+          }
+        for (int64_t t = 0; t < R; ++t)
+          if (ahead[t] > 1 || (ahead[t] == 1 && t + 1 < R && ahead[t + 1] > 0)) return false;
+        return true;
+      };
+      if (ok && max_resident_runs > 0 && R > max_resident_runs && !look_ahead_ok()) {
+        if (cut) {  // try creation order before giving up
+          for (int64_t k = 0; k < R; ++k) order[k] = (int32_t)k;
+          ok = look_ahead_ok();
+        } else {
+          ok = false;
+        }
+      }
+      S.chain_rank.clear(); S.chain_run_ptr.clear(); S.chain_run_order.clear();
+      std::vector<int32_t> pred2(N, -1);  // rank visited two steps earlier in the same run (rank-contiguous fallback only)
+      if (ok) {
+        for (int64_t k = 0; k < R; ++k) {
+          S.chain_run_ptr.push_back((int32_t)S.chain_rank.size());
+          for (int32_t r : runs[k]) S.chain_rank.push_back(r);
+        }
+        S.chain_run_ptr.push_back((int32_t)S.chain_rank.size());
+        bool identity = true;
+        for (int64_t k = 0; k < R; ++k) identity = identity && order[k] == (int32_t)k;
+        if (!identity) S.chain_run_order = order;
+      } else {
+        // fall back to the rank-contiguous runs of build_runs (hand-over from one or two visits back)
+        S.chain_rank.resize(N);
+        for (int64_t p = 0; p < N; ++p) S.chain_rank[p] = d == 0 ? (int32_t)p : (int32_t)(N - 1 - p);
+        S.chain_run_ptr = S.run_ptr; S.chain_run_order = S.run_order;
+        for (int64_t r = 0; r < N; ++r) { deps[r].assign(S.dep_rank.begin() + S.dep_ptr[r], S.dep_rank.begin() + S.dep_ptr[r + 1]); pred[r] = -1; }
+        for (size_t k = 0; k + 1 < S.chain_run_ptr.size(); ++k)
+          for (int64_t p = S.chain_run_ptr[k]; p < S.chain_run_ptr[k + 1]; ++p) {
+            if (p - 1 >= S.chain_run_ptr[k]) pred[S.chain_rank[p]] = S.chain_rank[p - 1];
+            if (p - 2 >= S.chain_run_ptr[k]) pred2[S.chain_rank[p]] = S.chain_rank[p - 2];
+          }
+      }
+      // ---- descriptors, in schedule order
+      S.desc.assign((size_t)N * W, 0);
+      for (int64_t p = 0; p < N; ++p) {
+        const int32_t r = S.chain_rank[p];
         int32_t *D = &S.desc[(size_t)p * W];
         const int nout = optr[r + 1] - optr[r], nin = iptr[r + 1] - iptr[r];
-        const int nd = S.dep_ptr[r + 1] - S.dep_ptr[r];
+        const int nd = (int)deps[r].size();
         uint32_t md = 0;
         for (int k = 0; k < 8; ++k) {
           int32_t e = 0, slot = -1, lbe = 0, xn = 0;
@@ -283,7 +375,12 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
           } else if (k < nout + nin) {
             const int32_t ik = iptr[r] + (k - nout);
             e = iidx[ik];
-            slot = S.in_slot[ik];
+            // slot of the edge in the outgoing list of the node visited one (0..7) or two (8..15) steps earlier
+            const int32_t o = other_end(e);
+            const int dist = (pred[r] >= 0 && o == pred[r]) ? 1 : (pred2[r] >= 0 && o == pred2[r]) ? 2 : 0;
+            if (dist)
+              for (int32_t w = optr[o]; w < optr[o + 1] && w - optr[o] < TrwsGraph::kMaxSlots; ++w)
+                if (oidx[w] == e) slot = (w - optr[o]) + 8 * (dist - 1);
             xn = d == 0 ? g.tail[e] : g.head[e];  // the other endpoint: its label feeds the primal
           }
           if (k < nout + nin && g.mdir[e]) md |= 1u << k;
@@ -293,7 +390,7 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
         D[1] = r;
         D[2] = (int32_t)((uint32_t)nout | ((uint32_t)nin << 4) | ((uint32_t)nd << 8) | (md << 16));
         D[3] = g.lb_pos_node[r];
-        for (int k = 0; k < 4; ++k) D[20 + k] = k < nd ? S.dep_rank[S.dep_ptr[r] + k] : 0;
+        for (int k = 0; k < 4; ++k) D[20 + k] = k < nd ? deps[r][k] : 0;
         // slots once more, one byte each (0xff = none), for the compute waves: words 41, 42
         uint32_t pk[2] = {0, 0};
         for (int k = 0; k < 8; ++k) pk[k >> 2] |= (uint32_t)(uint8_t)(int8_t)D[12 + k] << (8 * (k & 3));
@@ -301,20 +398,20 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
       }
       // Completion flags are raised either in the middle of the next visit (costs a store
       // drain on that run's critical path, but the dependent run can follow closely) or
-      // lazily at its end (free).  A run is "lazy" if the next run cannot start before this
-      // one has finished anyway: its first node waits for this run's last node.
-      const int64_t R = (int64_t)S.run_ptr.size() - 1;
-      for (int64_t k = 0; k < R; ++k) {
-        bool lazy = k == R - 1;
-        if (!lazy) {
-          const int64_t plast = S.run_ptr[k + 1] - 1, pnext = S.run_ptr[k + 1];
-          const int32_t rlast = d == 0 ? (int32_t)plast : (int32_t)(N - 1 - plast);
-          const int32_t rnext = d == 0 ? (int32_t)pnext : (int32_t)(N - 1 - pnext);
-          for (int32_t q = S.dep_ptr[rnext]; q < S.dep_ptr[rnext + 1]; ++q)
-            if (S.dep_rank[q] == rlast) lazy = true;
+      // lazily at its end (free).  A run is "lazy" if nobody else reads its flags before it
+      // has finished anyway: no node of another run depends on any node but its last.
+      const int64_t RR = (int64_t)S.chain_run_ptr.size() - 1;
+      std::vector<int32_t> run_at(N);
+      for (int64_t k = 0; k < RR; ++k)
+        for (int64_t p = S.chain_run_ptr[k]; p < S.chain_run_ptr[k + 1]; ++p) run_at[S.chain_rank[p]] = (int32_t)k;
+      std::vector<uint8_t> eager(RR, 0);
+      for (int64_t r = 0; r < N; ++r)
+        for (int32_t x : deps[r]) {
+          const int32_t kx = run_at[x];
+          if (x != S.chain_rank[S.chain_run_ptr[kx + 1] - 1]) eager[kx] = 1;
         }
-        for (int64_t p = S.run_ptr[k]; p < S.run_ptr[k + 1]; ++p) S.desc[(size_t)p * W + 40] = lazy ? 0 : 1;
-      }
+      for (int64_t k = 0; k < RR; ++k)
+        for (int64_t p = S.chain_run_ptr[k]; p < S.chain_run_ptr[k + 1]; ++p) S.desc[(size_t)p * W + 40] = eager[k];
     }
   }
   return true;
@@ -350,5 +447,40 @@ extern "C" int stereo_trws_analyze(int64_t N, int64_t E, const uint32_t *conn, i
     if (head) head[e] = g.head[e];
     if (mdir) mdir[e] = g.mdir[e];
   }
+  return 0;
+}
+
+extern "C" int stereo_trws_schedule(int64_t N, int64_t E, const uint32_t *conn, int64_t max_resident_runs,
+                                    int direction, int64_t *rank_at, int64_t *run_ptr, int64_t *nruns,
+                                    int64_t *ticket_run, int64_t *pred_rank, int64_t *dep_ptr,
+                                    int64_t *dep_rank, char *err, size_t errcap) {
+  stereo::TrwsGraph g;
+  std::string gerr;
+  if (!conn && E > 0) return stereo::fail("stereo_trws_schedule: NULL connectivity", err, errcap);
+  if (direction != 0 && direction != 1) return stereo::fail("stereo_trws_schedule: direction must be 0 or 1", err, errcap);
+  if (!stereo::build_trws_graph(N, E, conn, g, gerr, max_resident_runs)) return stereo::fail(gerr, err, errcap);
+  if (!g.fast_ok) return stereo::fail("stereo_trws_schedule: graph not eligible for the descriptor-driven kernels", err, errcap);
+  const stereo::TrwsGraph::Sweep &S = g.sweep[direction];
+  constexpr int W = stereo::TrwsGraph::kDescWords;
+  const int64_t R = (int64_t)S.chain_run_ptr.size() - 1;
+  if (nruns) *nruns = R;
+  for (int64_t p = 0; p < N; ++p) if (rank_at) rank_at[p] = S.chain_rank[p];
+  for (int64_t k = 0; k <= R; ++k) if (run_ptr) run_ptr[k] = S.chain_run_ptr[k];
+  for (int64_t t = 0; t < R; ++t) if (ticket_run) ticket_run[t] = S.chain_run_order.empty() ? t : S.chain_run_order[t];
+  // predecessor and dependencies as the kernels see them: from the descriptors
+  int64_t dp = 0;
+  std::vector<int64_t> pos_of(N);
+  for (int64_t p = 0; p < N; ++p) pos_of[S.chain_rank[p]] = p;
+  for (int64_t r = 0; r < N; ++r) {
+    const int32_t *D = &S.desc[(size_t)pos_of[r] * W];
+    const int nout = D[2] & 15, nin = (D[2] >> 4) & 15, nd = (D[2] >> 8) & 15;
+    int64_t pr = -1;
+    for (int k = nout; k < nout + nin; ++k)
+      if (D[12 + k] >= 0 && D[12 + k] < 8) pr = g.rank[D[32 + k]];
+    if (pred_rank) pred_rank[r] = pr;
+    if (dep_ptr) dep_ptr[r] = dp;
+    for (int k = 0; k < nd; ++k, ++dp) if (dep_rank) dep_rank[dp] = D[20 + k];
+  }
+  if (dep_ptr) dep_ptr[N] = dp;
   return 0;
 }

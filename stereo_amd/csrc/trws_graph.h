@@ -50,9 +50,17 @@ struct TrwsGraph {
     // aligned with the node's INCOMING list (bidx forward / fidx backward):
     // slot of that edge in the predecessor's outgoing list, or -1
     std::vector<int8_t> in_slot;
-    // Packed per-position descriptors for the fast kernel (kDescWords int32 each,
-    // layout in trws.hip: NodeDesc); empty unless fast_ok.
+    // Packed per-position descriptors for the fast kernels (kDescWords int32 each,
+    // layout in trws.hip: NodeDesc); empty unless fast_ok.  They are laid out in the order of
+    // the CHAIN schedule below, which is what the descriptor-driven kernels walk.
     std::vector<int32_t> desc;
+    // Chain schedule of the fast kernels: a run is a path of the dependency DAG (every node
+    // hangs on the node visited just before it), not necessarily a stretch of consecutive
+    // ranks -- the reference order interleaves the ranks of the last two grid rows, which a
+    // rank-contiguous run would walk as ONE serial chain of 2W visits.  chain_rank maps a
+    // schedule position to the rank visited there; chain_run_ptr / chain_run_order are the
+    // counterparts of run_ptr / run_order over schedule positions.
+    std::vector<int32_t> chain_rank, chain_run_ptr, chain_run_order;
   } sweep[2];
   static constexpr int kDescWords = 64;
   // every node has <= 8 incident edges and <= 4 foreign dependencies per direction

@@ -205,3 +205,83 @@ def analyze(N, connectivity0):
                                         P(out["level"]), err, C.c_size_t(len(err)))
     _lib.check(rc, err)
     return out
+
+
+def schedule(N, connectivity0, direction, max_resident_runs=0):
+    """Host-only inspection of the chain schedule of the descriptor-driven sweep kernels
+    (stereo_trws_schedule); connectivity zero based.  Returns dict(rank_at, run_ptr,
+    ticket_run, pred_rank, dep_ptr, dep_rank)."""
+    c = np.asarray(connectivity0)
+    if c.ndim != 2 or c.shape[0] != 2:
+        raise StereoHipError("connectivity must be 2 x E")
+    c = np.asfortranarray(c, dtype=np.uint32)
+    E = c.shape[1]
+    i64 = lambda n: np.zeros(n, np.int64)
+    rank_at, run_ptr, ticket_run, pred, dep_ptr, dep_rank = i64(N), i64(N + 1), i64(N), i64(N), i64(N + 1), i64(4 * N)
+    nruns = C.c_int64(0)
+    err = _lib.errbuf()
+    P = lambda a: _ptr(a, C.c_int64)
+    rc = _lib.lib().stereo_trws_schedule(C.c_int64(N), C.c_int64(E), _ptr(c, C.c_uint32),
+                                         C.c_int64(max_resident_runs), C.c_int(direction), P(rank_at),
+                                         P(run_ptr), C.byref(nruns), P(ticket_run), P(pred), P(dep_ptr),
+                                         P(dep_rank), err, C.c_size_t(len(err)))
+    _lib.check(rc, err)
+    R = nruns.value
+    return dict(rank_at=rank_at, run_ptr=run_ptr[:R + 1], ticket_run=ticket_run[:R], pred_rank=pred,
+                dep_ptr=dep_ptr, dep_rank=dep_rank[:dep_ptr[N]])
+
+
+def simulate_schedule(sched, workgroups, visit=1.0, handover=0.0):
+    """Discrete simulation of the dataflow sweep on `workgroups` resident workgroups that take
+    run tickets in order: a visit costs `visit`, a message from another run arrives `handover`
+    after its node finished.  Returns (makespan, finished_all).  Deadlock -> finished_all False."""
+    import heapq
+    rank_at, run_ptr, ticket_run = sched["rank_at"], sched["run_ptr"], sched["ticket_run"]
+    dep_ptr, dep_rank = sched["dep_ptr"], sched["dep_rank"]
+    N = len(rank_at)
+    R = len(ticket_run)
+    done_t = np.full(N, -1.0)          # completion time by rank
+    waiting = {}                       # rank -> list of runs blocked on it
+    cur = [int(run_ptr[k]) for k in range(R)]   # next schedule position of each run
+    run_time = [0.0] * R               # local clock of each held run
+    next_ticket = 0
+    free_at = []                       # min-heap of times at which a workgroup becomes free
+    events = []                        # (time, run) runs ready to try advancing
+    for _ in range(min(int(workgroups), R)):
+        heapq.heappush(free_at, 0.0)
+    finished = 0
+
+    def start_next():
+        nonlocal next_ticket
+        while free_at and next_ticket < R:
+            t0 = heapq.heappop(free_at)
+            k = int(ticket_run[next_ticket]); next_ticket += 1
+            run_time[k] = t0
+            heapq.heappush(events, (t0, k))
+
+    start_next()
+    while events:
+        t, k = heapq.heappop(events)
+        blocked = False
+        while cur[k] < run_ptr[k + 1]:
+            r = int(rank_at[cur[k]])
+            ready = run_time[k]
+            for x in dep_rank[dep_ptr[r]:dep_ptr[r + 1]]:
+                x = int(x)
+                if done_t[x] < 0:
+                    waiting.setdefault(x, []).append(k)
+                    blocked = True
+                    break
+                ready = max(ready, done_t[x] + handover)
+            if blocked:
+                break
+            run_time[k] = ready + visit
+            done_t[r] = run_time[k]
+            for kk in waiting.pop(r, []):
+                heapq.heappush(events, (run_time[k], kk))
+            cur[k] += 1
+        if not blocked:
+            finished += 1
+            heapq.heappush(free_at, run_time[k])
+            start_next()
+    return float(done_t.max()), finished == R

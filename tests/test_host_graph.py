@@ -81,3 +81,69 @@ def test_fit_plane_to_points_recovers_a_plane():
         assert np.allclose(p, [-0.3, 0.2, 1.0, -7.0], atol=1e-9)
     # (the reference's IRLS weight is w = sqrt(|residual|), dispmap_ncc.m:82 -- it grows with the
     #  residual; the mirror keeps that, so no robustness claim is tested here)
+
+
+# ---- chain schedule of the descriptor-driven sweep kernels (host only) ----------------------
+
+def _check_schedule(H, W, capacity):
+    from stereo_amd.trws import analyze, schedule, simulate_schedule
+    conn = grid_conn(H, W)
+    N = H * W
+    a = analyze(N, conn.T)
+    rank = a["rank"]
+    # dependency lists by rank, straight from the oriented edges
+    tail_r, head_r = rank[a["tail"]], rank[a["head"]]
+    levels = int(a["level"].max()) + 1
+    out = {}
+    for d in (0, 1):
+        s = schedule(N, conn.T, d, capacity)
+        R = len(s["ticket_run"])
+        assert sorted(s["rank_at"].tolist()) == list(range(N))            # every node visited once
+        assert sorted(s["ticket_run"].tolist()) == list(range(R))         # every run dispensed once
+        pos_of = np.empty(N, np.int64); pos_of[s["rank_at"]] = np.arange(N)
+        run_of_pos = np.repeat(np.arange(R), np.diff(s["run_ptr"]))
+        need = [set() for _ in range(N)]
+        src, dst = (tail_r, head_r) if d == 0 else (head_r, tail_r)
+        for x, y in zip(src.tolist(), dst.tolist()):
+            need[y].add(x)
+        for r in range(N):
+            deps = set(s["dep_rank"][s["dep_ptr"][r]:s["dep_ptr"][r + 1]].tolist())
+            pr = int(s["pred_rank"][r])
+            if pr >= 0:
+                # the LDS hand-over comes from the node visited just before in the same run
+                assert pos_of[pr] == pos_of[r] - 1 and run_of_pos[pos_of[pr]] == run_of_pos[pos_of[r]]
+                deps.add(pr)
+            assert deps == need[r], (r, deps, need[r])
+            assert len(s["dep_rank"][s["dep_ptr"][r]:s["dep_ptr"][r + 1]]) <= 4
+        # dataflow simulation: with every run resident the sweep takes exactly the DAG depth; with
+        # `capacity` workgroups taking tickets in order it still completes (no deadlock)
+        mk, ok = simulate_schedule(s, 10 ** 9)
+        assert ok and mk == levels
+        if capacity:
+            mk2, ok2 = simulate_schedule(s, capacity)
+            assert ok2, "schedule deadlocks with %d resident workgroups" % capacity
+            out[d] = mk2 / levels
+    return out
+
+
+def test_chain_schedule_small_grids():
+    for H, W in [(2, 2), (3, 3), (5, 5), (6, 8), (7, 9), (12, 14), (1, 9), (9, 1), (2, 7)]:
+        _check_schedule(H, W, 0)
+        _check_schedule(H, W, 2)
+        _check_schedule(H, W, 3)
+
+
+def test_chain_schedule_splits_the_interleaved_rows():
+    from stereo_amd.trws import schedule
+    H, W = 30, 40
+    conn = grid_conn(H, W)
+    for d in (0, 1):
+        s = schedule(H * W, conn.T, d, 0)
+        lens = np.sort(np.diff(s["run_ptr"]))
+        # border chain + top row is the one long run; no other run is longer than a grid row
+        assert lens[-1] == 2 * H + 2 * W - 4 and lens[-2] <= W
+
+
+def test_chain_schedule_more_rows_than_workgroups():
+    slow = _check_schedule(120, 90, 16)
+    assert max(slow.values()) < 8.0
