@@ -1,5 +1,6 @@
 """Development tool: time TRW-S iterations of a synthetic volume for a given kernel / size.
-usage: time_trws.py [kernel=1] [H=375] [W=450] [K=60] [tol=8] [iters=10]"""
+usage: time_trws.py [kernel=1] [H=375] [W=450] [K=60] [tol=8] [iters=10] [general=0]
+general=1: per-edge positions q != qprim (label k + jitter), as a fusion of K plane proposals has them."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -14,13 +15,20 @@ W = int(a[2]) if len(a) > 2 else 450
 K = int(a[3]) if len(a) > 3 else 60
 tol = float(a[4]) if len(a) > 4 else 8.0
 iters = int(a[5]) if len(a) > 5 else 10
+general = int(a[6]) if len(a) > 6 else 0
 dev = torch.device("cuda", 0)
 conn = grid_conn(H, W); E = conn.shape[0]; N = H * W
 d_unary = torch.from_numpy(synthetic_volume(H, W, K, seed=1)).to(dev)
 plan = TrwsPlan(kernel, K, N, conn.T)
 d_alpha = torch.ones(E, dtype=torch.float64, device=dev)
 d_pos = torch.arange(K, dtype=torch.float64, device=dev)
-plan.bind_device(d_unary.data_ptr(), d_alpha.data_ptr(), tol, d_positions=d_pos.data_ptr(), keepalive=(d_unary, d_alpha, d_pos))
+if general:
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    d_q = torch.arange(K, dtype=torch.float64, device=dev)[None, :] + 0.25 * torch.rand(E, K, dtype=torch.float64, device=dev, generator=g)
+    d_qp = torch.arange(K, dtype=torch.float64, device=dev)[None, :] + 0.25 * torch.rand(E, K, dtype=torch.float64, device=dev, generator=g)
+    plan.bind_device(d_unary.data_ptr(), d_alpha.data_ptr(), tol, d_q=d_q.data_ptr(), d_qprim=d_qp.data_ptr(), keepalive=(d_unary, d_alpha, d_q, d_qp))
+else:
+    plan.bind_device(d_unary.data_ptr(), d_alpha.data_ptr(), tol, d_positions=d_pos.data_ptr(), keepalive=(d_unary, d_alpha, d_pos))
 plan.iterate(2, max_relgap=-1e300)
 plan.serial_messages(reset=True)
 torch.cuda.synchronize(); t = time.perf_counter()
