@@ -328,7 +328,11 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
           if (ahead[t] > 1 || (ahead[t] == 1 && t + 1 < R && ahead[t + 1] > 0)) return false;
         return true;
       };
-      if (ok && max_resident_runs > 0 && R > max_resident_runs && !look_ahead_ok()) {
+      // (checked whenever there are more runs than CUs: one workgroup per CU is all that is certain
+      // to be resident, whatever max_resident_runs the caller derived from its kernel's LDS use)
+      constexpr int64_t kCertainlyResident = 256;
+      const int64_t resident = max_resident_runs > 0 ? std::min(max_resident_runs, kCertainlyResident) : 0;
+      if (ok && resident > 0 && R > resident && !look_ahead_ok()) {
         if (cut) {  // try creation order before giving up
           for (int64_t k = 0; k < R; ++k) order[k] = (int32_t)k;
           ok = look_ahead_ok();
