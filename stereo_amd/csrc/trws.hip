@@ -22,7 +22,10 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <limits>
+#include <memory>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <vector>
@@ -2634,7 +2637,7 @@ using namespace stereo;
 struct stereo_trws_plan {
   int kernel = 1, K = 0, Kp = 0, mode = 0, device = 0;
   int64_t N = 0, E = 0;
-  TrwsGraph g;
+  std::shared_ptr<const TrwsGraph> graph;  // host-side analysis; shared with the cache of the last connectivity
   // device copies of the graph
   DevBuf<int32_t> d_tail, d_order, d_fptr, d_fidx, d_bptr, d_bidx, d_lbn, d_lbe, d_levels, d_x;
   DevBuf<uint8_t> d_mdir;
@@ -2707,13 +2710,13 @@ DevParams make_params(stereo_trws_plan *P) {
   p.lbterms = P->d_lbterms.p; p.eterms = P->d_eterms.p; p.x = P->d_x.p;
   // the descriptor-driven kernels walk the chain schedule (trws_graph.h), the generic ones the
   // rank-contiguous runs
-  const bool chain = P->g.fast_ok && (P->wide || P->fast2 || P->fast);
+  const bool chain = P->graph->fast_ok && (P->wide || P->fast2 || P->fast);
   for (int d = 0; d < 2; ++d) {
     if (chain) {
-      p.run_ptr[d] = P->d_chain_run_ptr[d].p; p.nruns[d] = (int)P->g.sweep[d].chain_run_ptr.size() - 1;
+      p.run_ptr[d] = P->d_chain_run_ptr[d].p; p.nruns[d] = (int)P->graph->sweep[d].chain_run_ptr.size() - 1;
       p.run_order[d] = P->d_chain_run_order[d].p;
     } else {
-      p.run_ptr[d] = P->d_run_ptr[d].p; p.nruns[d] = (int)P->g.sweep[d].run_ptr.size() - 1;
+      p.run_ptr[d] = P->d_run_ptr[d].p; p.nruns[d] = (int)P->graph->sweep[d].run_ptr.size() - 1;
       p.run_order[d] = P->d_run_order[d].p;
     }
     p.dep_ptr[d] = P->d_dep_ptr[d].p; p.dep_rank[d] = P->d_dep_rank[d].p;
@@ -2815,7 +2818,7 @@ void persistent_iteration(stereo_trws_plan *P, const DevParams &p, hipStream_t s
   // the backward sweep's lower-bound terms travel while the next launch runs
   STEREO_HIP_CHECK(hipEventRecord(P->ev_bwd, s));
   STEREO_HIP_CHECK(hipStreamWaitEvent(P->copy_stream, P->ev_bwd, 0));
-  STEREO_HIP_CHECK(hipMemcpyAsync(P->h_lb.p, P->d_lbterms.p, sizeof(double) * P->g.lb_terms, hipMemcpyDeviceToHost,
+  STEREO_HIP_CHECK(hipMemcpyAsync(P->h_lb.p, P->d_lbterms.p, sizeof(double) * P->graph->lb_terms, hipMemcpyDeviceToHost,
                                   P->copy_stream));
   STEREO_HIP_CHECK(hipEventRecord(P->ev_lb, P->copy_stream));
   P->lb_in_flight = true;
@@ -2827,7 +2830,7 @@ void persistent_iteration(stereo_trws_plan *P, const DevParams &p, hipStream_t s
 
 template <int KERNEL, int MODE>
 void launch_iteration(stereo_trws_plan *P, const DevParams &p, hipStream_t s) {
-  const TrwsGraph &g = P->g;
+  const TrwsGraph &g = *P->graph;
   const int L = (int)g.level_ptr.size() - 1;
   const size_t lds = sweep_lds_bytes(P->Kp), plds = primal_lds_bytes(P->Kp);
   if (P->time_sweeps) STEREO_HIP_CHECK(hipEventRecord(P->ev0, s));
@@ -2951,8 +2954,29 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
     const bool wide_candidate = kernel == 1 && K > kWave && K <= 256 && message_mode == STEREO_TRWS_MESSAGES_EXACT;
     const int64_t per_cu = std::min<int64_t>(std::max<int64_t>(1, (int64_t)(160 * 1024) / (int64_t)persistent_lds_bytes(P->Kp)), 4);
     const int64_t capacity = wide_candidate ? 256 : 256 * per_cu;
-    if (!build_trws_graph(N, E, conn, P->g, gerr, capacity)) return fail(gerr, err, errcap);
-    const TrwsGraph &g = P->g;
+    // The analysis depends on the connectivity only (ordering, lists, schedules: 0.2-0.6 s at Teddy
+    // size); consecutive plans for the same image grid -- every trws() call of a fusion loop --
+    // share the last one.
+    {
+      static std::mutex cache_mutex;
+      static struct { int64_t N = -1, E = -1, capacity = -1; std::vector<uint32_t> conn; std::shared_ptr<const TrwsGraph> g; } cache;
+      std::lock_guard<std::mutex> lock(cache_mutex);
+      const bool hit = cache.g && cache.N == N && cache.E == E && cache.capacity == capacity &&
+                       std::memcmp(cache.conn.data(), conn, sizeof(uint32_t) * 2 * (size_t)E) == 0;
+      if (hit) {
+        P->graph = cache.g;
+      } else {
+        auto fresh = std::make_shared<TrwsGraph>();
+        if (!build_trws_graph(N, E, conn, *fresh, gerr, capacity)) return fail(gerr, err, errcap);
+        P->graph = fresh;
+        if (N <= (1 << 20)) {  // (the descriptors of a 3000 x 2000 grid are 3 GB: not worth keeping)
+          cache.N = N; cache.E = E; cache.capacity = capacity; cache.conn.assign(conn, conn + 2 * (size_t)E); cache.g = fresh;
+        } else {
+          cache.g.reset(); cache.conn.clear(); cache.N = -1;
+        }
+      }
+    }
+    const TrwsGraph &g = *P->graph;
     if (sweep_lds_bytes(P->Kp) > 160 * 1024) return fail("stereo_trws: K too large for LDS", err, errcap);
     P->d_tail.upload(g.tail.data(), g.tail.size());
     P->d_order.upload(g.order.data(), g.order.size());
@@ -3067,8 +3091,8 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
 
 void stereo_trws_plan_destroy(stereo_trws_plan *plan) {
   if (plan && plan->d_timeline.p) {
-    const bool chain = plan->g.fast_ok && (plan->wide || plan->fast2 || plan->fast);
-    const size_t R = (chain ? plan->g.sweep[0].chain_run_ptr.size() : plan->g.sweep[0].run_ptr.size()) - 1;
+    const bool chain = plan->graph->fast_ok && (plan->wide || plan->fast2 || plan->fast);
+    const size_t R = (chain ? plan->graph->sweep[0].chain_run_ptr.size() : plan->graph->sweep[0].run_ptr.size()) - 1;
     std::vector<unsigned long long> t(4 * (R + 1));
     if (hipMemcpy(t.data(), plan->d_timeline.p, sizeof(unsigned long long) * 4 * R, hipMemcpyDeviceToHost) == hipSuccess) {
       for (int d = 0; d < 2; ++d) {
@@ -3184,7 +3208,7 @@ int stereo_trws_plan_iterate(stereo_trws_plan *P, int iters, double max_relgap, 
         }
       }
       if (!P->lb_in_flight)
-        STEREO_HIP_CHECK(hipMemcpyAsync(P->h_lb.p, P->d_lbterms.p, sizeof(double) * P->g.lb_terms,
+        STEREO_HIP_CHECK(hipMemcpyAsync(P->h_lb.p, P->d_lbterms.p, sizeof(double) * P->graph->lb_terms,
                                         hipMemcpyDeviceToHost, s));
       STEREO_HIP_CHECK(hipMemcpyAsync(P->h_en.p, P->d_eterms.p, sizeof(double) * P->N,
                                       hipMemcpyDeviceToHost, s));
@@ -3195,7 +3219,7 @@ int stereo_trws_plan_iterate(stereo_trws_plan *P, int iters, double max_relgap, 
       double lb = 0, en = 0;
       if (P->lb_in_flight) {  // summed while the forward sweep + primal launch is still running
         STEREO_HIP_CHECK(hipEventSynchronize(P->ev_lb));
-        for (int64_t i = 0; i < P->g.lb_terms; ++i) lb += P->h_lb.p[i];
+        for (int64_t i = 0; i < P->graph->lb_terms; ++i) lb += P->h_lb.p[i];
       }
       STEREO_HIP_CHECK(hipStreamSynchronize(s));
       if (ctl[1]) return fail("stereo_trws: a persistent sweep gave up waiting on a dependency flag", err, errcap);
@@ -3205,7 +3229,7 @@ int stereo_trws_plan_iterate(stereo_trws_plan *P, int iters, double max_relgap, 
         P->sweep_ms += ms;
       }
       if (!P->lb_in_flight)
-        for (int64_t i = 0; i < P->g.lb_terms; ++i) lb += P->h_lb.p[i];
+        for (int64_t i = 0; i < P->graph->lb_terms; ++i) lb += P->h_lb.p[i];
       P->lb_in_flight = false;
       for (int64_t i = 0; i < P->N; ++i) en += P->h_en.p[i];
       P->lb = lb; P->energy = en; P->iterations += 1;
@@ -3242,9 +3266,9 @@ int stereo_trws_plan_result(stereo_trws_plan *P, double *labelling, double *ener
 int stereo_trws_plan_info(stereo_trws_plan *P, int64_t *rank, int64_t *levels,
                           int64_t *max_level_nodes, char *err, size_t errcap) {
   if (!P) return fail("stereo_trws_plan_info: NULL plan", err, errcap);
-  if (rank) for (int64_t i = 0; i < P->N; ++i) rank[i] = P->g.rank[i];
-  if (levels) *levels = (int64_t)P->g.level_ptr.size() - 1;
-  if (max_level_nodes) *max_level_nodes = P->g.max_level_nodes;
+  if (rank) for (int64_t i = 0; i < P->N; ++i) rank[i] = P->graph->rank[i];
+  if (levels) *levels = (int64_t)P->graph->level_ptr.size() - 1;
+  if (max_level_nodes) *max_level_nodes = P->graph->max_level_nodes;
   return 0;
 }
 
