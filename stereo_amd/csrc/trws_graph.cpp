@@ -5,8 +5,12 @@
 #include "common.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
 #include <queue>
+#include <thread>
 
 namespace stereo {
 namespace {
@@ -51,8 +55,10 @@ class Boundary {
 
 }  // namespace
 
+#define TICK(name) do { if (std::getenv("STEREO_HIP_GRAPH_VERBOSE")) { auto now_ = std::chrono::steady_clock::now(); std::fprintf(stderr, "[graph] -> %s: %.1f ms\n", name, std::chrono::duration<double, std::milli>(now_ - tick_).count()); tick_ = now_; } } while (0)
 bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
                       std::string &err, int64_t max_resident_runs) {
+  auto tick_ = std::chrono::steady_clock::now();
   if (N <= 0 || E < 0) { err = "build_trws_graph: empty problem"; return false; }
   if (N >= INT32_MAX || E >= INT32_MAX) { err = "build_trws_graph: more than 2^31 nodes/edges"; return false; }
   g = TrwsGraph();
@@ -70,6 +76,7 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
     nextB[e] = firstB[b]; firstB[b] = (int32_t)e;
     ++deg[a]; ++deg[b];
   }
+  TICK("0");
   // ---- SetAutomaticOrdering
   g.order.resize(N); g.rank.assign(N, -1);
   {
@@ -107,6 +114,7 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
       }
     }
   }
+  TICK("1");
   // ---- CompleteGraphConstruction: orient low -> high rank, rebuild lists
   std::fill(firstB.begin(), firstB.end(), -1);
   for (int64_t r = 0; r < N; ++r) {
@@ -126,6 +134,7 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
       }
     }
   }
+  TICK("2");
   // ---- flatten to CSR by rank, gamma, levels, lower-bound term positions
   g.fptr.assign(N + 1, 0); g.bptr.assign(N + 1, 0);
   g.fidx.resize(E); g.bidx.resize(E); g.gamma.resize(N);
@@ -165,6 +174,7 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
     for (int32_t k = g.bptr[r]; k < g.bptr[r + 1]; ++k) g.lb_pos_edge[g.bidx[k]] = (int32_t)pos++;
   }
   g.lb_terms = pos;
+  TICK("3");
   // ---- persistent sweep schedules
   // cut == false: a run ends only where the node does not hang on one of the two previous
   // visits.  cut == true (used when there are more runs than resident workgroups): a run also
@@ -255,6 +265,7 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
       if (!ok) build_runs(d, false);
     }
   }
+  TICK("4");
   // ---- descriptors of the fast kernel (layout: trws.hip NodeDesc)
   g.fast_ok = true;
   for (int64_t r = 0; r < N && g.fast_ok; ++r) {
@@ -264,7 +275,8 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
   }
   if (g.fast_ok) {
     constexpr int W = TrwsGraph::kDescWords;
-    for (int d = 0; d < 2; ++d) {
+    // the two sweep directions are independent of each other: one host thread each
+    auto build_direction = [&](int d) {
       TrwsGraph::Sweep &S = g.sweep[d];
       const std::vector<int32_t> &iptr = d == 0 ? g.bptr : g.fptr, &iidx = d == 0 ? g.bidx : g.fidx;
       const std::vector<int32_t> &optr = d == 0 ? g.fptr : g.bptr, &oidx = d == 0 ? g.fidx : g.bidx;
@@ -274,8 +286,7 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
       // earlier if it depends on it and that node is still the last one of its run; two steps
       // first, which is what separates two interleaved rows (s0 s1 s2 s3 ...: s3 hangs on s1 AND
       // on s2, s4 only on s2) into the runs s0 s1 s3 s5 ... and s2 s4 s6 ...
-      std::vector<int32_t> lev(N, 0), run_of(N, -1), pred(N, -1), run_tail, first_lev;
-      std::vector<std::vector<int32_t>> runs;
+      std::vector<int32_t> lev(N, 0), run_of(N, -1), pred(N, -1), next_of(N, -1), run_tail, run_head, first_lev;
       const bool cut = max_resident_runs > 0 && (int64_t)S.run_ptr.size() - 1 > max_resident_runs;
       constexpr int32_t kJump = 8;
       for (int64_t p = 0; p < N; ++p) {
@@ -291,14 +302,23 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
         lev[r] = lv;
         if (cut && best >= 0 && lv > lev[best] + kJump) best = -1;
         if (best >= 0) {
-          run_of[r] = run_of[best]; runs[run_of[r]].push_back(r); run_tail[run_of[r]] = r; pred[r] = best;
+          run_of[r] = run_of[best]; next_of[best] = r; run_tail[run_of[r]] = r; pred[r] = best;
         } else {
-          run_of[r] = (int32_t)runs.size(); runs.push_back({r}); run_tail.push_back(r); first_lev.push_back(lv);
+          run_of[r] = (int32_t)run_head.size(); run_head.push_back(r); run_tail.push_back(r); first_lev.push_back(lv);
         }
       }
-      const int64_t R = (int64_t)runs.size();
+      const int64_t R = (int64_t)run_head.size();
       // foreign dependencies per rank (everything but the predecessor in the run)
-      std::vector<std::vector<int32_t>> deps(N);
+      struct Deps {  // at most kMaxSlots incoming edges per node in this branch (fast_ok)
+        int32_t v[TrwsGraph::kMaxSlots]; int32_t n = 0;
+        const int32_t *begin() const { return v; }
+        const int32_t *end() const { return v + n; }
+        size_t size() const { return (size_t)n; }
+        int32_t operator[](int k) const { return v[k]; }
+        void push_back(int32_t x) { v[n++] = x; }
+        void assign(const int32_t *a, const int32_t *b) { n = 0; for (; a != b; ++a) v[n++] = *a; }
+      };
+      std::vector<Deps> deps(N);
       bool ok = true;
       for (int64_t r = 0; r < N && ok; ++r) {
         for (int32_t k = iptr[r]; k < iptr[r + 1]; ++k) {
@@ -345,7 +365,7 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
       if (ok) {
         for (int64_t k = 0; k < R; ++k) {
           S.chain_run_ptr.push_back((int32_t)S.chain_rank.size());
-          for (int32_t r : runs[k]) S.chain_rank.push_back(r);
+          for (int32_t r = run_head[k]; r >= 0; r = next_of[r]) S.chain_rank.push_back(r);
         }
         S.chain_run_ptr.push_back((int32_t)S.chain_rank.size());
         bool identity = true;
@@ -356,7 +376,7 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
         S.chain_rank.resize(N);
         for (int64_t p = 0; p < N; ++p) S.chain_rank[p] = d == 0 ? (int32_t)p : (int32_t)(N - 1 - p);
         S.chain_run_ptr = S.run_ptr; S.chain_run_order = S.run_order;
-        for (int64_t r = 0; r < N; ++r) { deps[r].assign(S.dep_rank.begin() + S.dep_ptr[r], S.dep_rank.begin() + S.dep_ptr[r + 1]); pred[r] = -1; }
+        for (int64_t r = 0; r < N; ++r) { deps[r].assign(S.dep_rank.data() + S.dep_ptr[r], S.dep_rank.data() + S.dep_ptr[r + 1]); pred[r] = -1; }
         for (size_t k = 0; k + 1 < S.chain_run_ptr.size(); ++k)
           for (int64_t p = S.chain_run_ptr[k]; p < S.chain_run_ptr[k + 1]; ++p) {
             if (p - 1 >= S.chain_run_ptr[k]) pred[S.chain_rank[p]] = S.chain_rank[p - 1];
@@ -416,8 +436,12 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
         }
       for (int64_t k = 0; k < RR; ++k)
         for (int64_t p = S.chain_run_ptr[k]; p < S.chain_run_ptr[k + 1]; ++p) S.desc[(size_t)p * W + 40] = eager[k];
-    }
+    };
+    std::thread backward([&] { build_direction(1); });
+    build_direction(0);
+    backward.join();
   }
+  TICK("end");
   return true;
 }
 
