@@ -123,3 +123,38 @@ def test_teddy_size_properties(hip):
     plan.iterate(4, max_relgap=-1e300)
     lab2, en2, lb2, _ = plan.result()
     assert np.array_equal(lab1, lab2) and en1 == en2 and lb1 == lb2
+
+
+@pytest.mark.parametrize("kernel,K,general", [(1, 60, False), (2, 16, True)])
+def test_teddy_size_matches_oracle(kernel, K, general, hip, oracle):
+    """Full 450x375 grid, two iterations, bit for bit against the CPU oracle: more grid rows than
+    resident workgroups, the chain schedule with its two mutually dependent interleaved rows,
+    the border chain of 1646 serial visits."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synthetic_volume
+    from helpers import grid_conn
+    from stereo_amd.trws import TrwsPlan
+    H, W = 375, 450
+    conn = grid_conn(H, W)
+    E = conn.shape[0]
+    unary = synthetic_volume(H, W, K, 7)
+    rng = np.random.default_rng(17)
+    alphas = rng.uniform(0.5, 2.0, size=E)
+    tol = 8.0 if kernel == 1 else 9.0
+    plan = TrwsPlan(kernel, K, H * W, conn.T)
+    if general:
+        q = np.arange(K, dtype=np.float64)[None, :] + 0.25 * rng.random((E, K))
+        qp = np.arange(K, dtype=np.float64)[None, :] + 0.25 * rng.random((E, K))
+        plan.upload(unary.T, alphas, tol, q=q.T, qprim=qp.T)
+    else:
+        pos = np.arange(K, dtype=np.float64)
+        q = qp = np.tile(pos, (E, 1))
+        plan.upload(unary.T, alphas, tol, positions=pos)
+    ref = oracle.trws(kernel, unary, conn, q, qp, alphas, tol, 2, -1e300, mode=1)
+    plan.iterate(2, max_relgap=-1e300)
+    lab, en, lb, it = plan.result()
+    assert plan.path() == 2
+    assert np.array_equal(lab, ref[0]), "labels differ at %d nodes" % int((lab != ref[0]).sum())
+    assert en == ref[1] and lb == ref[2] and it == ref[3]
