@@ -1307,6 +1307,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
   double *scal = hand + 4 * 8 * kWave;                    // 2 x kScalDoubles
   double *hqtab = scal + 2 * kScalDoubles;                // per compute wave: 64 x (h, q, u, v)
   int *ctl = (int *)(hqtab + kPipeCompute * kPipeTab);    // [0] run, [1] abort
+  int *dring = ctl + 4;                                   // the last three descriptors (the storer's comes from here, not from HBM)
   const int K = p.K;
   const double inf = __builtin_huge_val();
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -1410,6 +1411,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
           const NodeDesc nx = decode_desc(w);
           int *stni = (int *)(stn + kStI);
           stni[lane] = w;
+          dring[((pos + 1) % 3) * kWave + lane] = w;
           const int ntot = nx.nout + nx.nin;
           // everything that does not depend on other workgroups is requested first ...
           double dk = 0, mv[8], qv[8], qpv[8];
@@ -1468,7 +1470,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
       } else if (wave == kPipeCompute + 1) {
         // ------------------------------------------------------------ storer: node pos - 1
         if (pos - 1 >= p0) {
-          const NodeDesc pd = decode_desc(desc[(size_t)(pos - 1) * DW + lane]);
+          const NodeDesc pd = decode_desc(dring[((pos - 1) % 3) * kWave + lane]);
           const double *scp = scal + ((pos + 1) & 1) * kScalDoubles;  // parity of pos - 1
           if (UPDATE) {
 #pragma unroll
@@ -2781,7 +2783,7 @@ void launch_persistent(stereo_trws_plan *P, const DevParams &p, int what, hipStr
     return;
   }
   if (P->fast) {
-    const size_t plds = sizeof(double) * (2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * kPipeTab + 2);
+    const size_t plds = sizeof(double) * (2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * kPipeTab + 2 + 3 * kWave / 2);
     const bool sh = P->pos != nullptr;
     const dim3 pblock(kPipeThreads);
 #define PIPE(BW, PR, UP)                                                                          \
