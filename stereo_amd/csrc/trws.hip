@@ -12,10 +12,14 @@
 // Work decomposition: the reference node order induces a dependency DAG.  One persistent
 // launch per sweep walks it as a dataflow: workgroups draw "runs" (a grid row, the border
 // chain) from a ticket counter and hand messages over in LDS inside a run, through HBM +
-// completion flags between runs.  Four implementations, identical results
-// (stereo_trws_plan_path): trws_pipe_kernel (K <= 64, role-specialised waves),
-// trws_wide_kernel (64 < K <= 256, shared ascending positions), trws_persistent_kernel
-// (everything else), trws_sweep_kernel (one launch per DAG level; kept for comparison).
+// completion flags between runs.  Five implementations, identical results
+// (stereo_trws_plan_path): trws_pipe_kernel (K <= 64, role-specialised waves, both smoothness
+// kernels), trws_pipe2_kernel (64 < K <= 128, two labels per lane, linear kernel),
+// trws_wide_kernel (64 < K <= 256, shared ascending positions, linear kernel),
+// trws_persistent_kernel (everything else), trws_sweep_kernel (one launch per DAG level; kept
+// for comparison).  The three descriptor-driven kernels walk the chain schedule of
+// trws_graph.h; messages take a certified min-plus fast path and fall back to
+// the reference's serial envelope construction when the certificate fails.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -26,7 +30,6 @@
 #include <limits>
 #include <memory>
 #include <mutex>
-#include <memory>
 #include <string>
 #include <vector>
 
