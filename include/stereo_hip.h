@@ -31,6 +31,11 @@ int stereo_hip_abi_version(void);
 int stereo_hip_device_count(void);
 /* Selects the device used by subsequent calls of this thread (default 0). */
 int stereo_hip_set_device(int device);
+/* Creates the HIP context of the current device and launches one empty kernel, so that the
+ * runtime's one-time initialisation happens now.  Optional; it matters to callers that seed libc
+ * rand() for QPBO Improve (QPBO_extra.cpp:13-27 draws its permutation from it): the runtime
+ * consumes rand() values during that initialisation.  Returns 0, or non-zero without a device. */
+int stereo_hip_warm_up(void);
 /* Last error message of the calling thread ("" if none). */
 const char *stereo_hip_last_error(void);
 

@@ -27,12 +27,23 @@ def lib():
             raise StereoHipError(
                 "%s not found: build it with stereo_amd/csrc/build.sh "
                 "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        # PyTorch-ROCm ships its own libamdhip64; a process must not end up with two HIP runtimes
+        # (torch then reports "No HIP GPUs are available").  Loading torch first makes this
+        # library resolve to the same runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.stereo_hip_last_error.restype = C.c_char_p
         L.stereo_trws_plan_destroy.restype = None
         L.stereo_rd_plan_destroy.restype = None
         L.stereo_fusion_destroy.restype = None
         _lib = L
+        # one-time runtime initialisation now, not inside the first solver call: it consumes libc
+        # rand() values, which QPBO Improve draws its permutation from (see stereo_hip_warm_up)
+        if L.stereo_hip_device_count() > 0:
+            L.stereo_hip_warm_up()
     return _lib
 
 

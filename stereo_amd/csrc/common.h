@@ -1,5 +1,6 @@
 // Shared helpers of libstereo_hip.so (error reporting, HIP checks).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -53,6 +54,10 @@ struct DevBuf {
     if (count == 0) count = 1;
     STEREO_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
     n = count;
+    // development aid: STEREO_HIP_POISON=<byte> fills every fresh allocation, so that a read of
+    // memory nobody wrote shows up as a changed result instead of depending on what was there
+    static const char *poison = std::getenv("STEREO_HIP_POISON");
+    if (poison) STEREO_HIP_CHECK(hipMemset(p, std::atoi(poison), count * sizeof(T)));
   }
   void upload(const T *src, size_t count, hipStream_t s = nullptr) {
     if (count > n || !p) alloc(count);

@@ -159,7 +159,7 @@ __device__ __forceinline__ bool grid_sync(int32_t *ctl, unsigned &gen) {
 }
 
 __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *ctl, int relabel_every, int max_rounds,
-                                                            int tiled, int switch_at) {
+                                                            int tiled, int switch_at, int incremental) {
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // tile state of the tiled rounds
   __shared__ int s_red;
   __shared__ int s_h[kMB];
@@ -181,11 +181,21 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
   // changes inside the tile, then the tiles exchange their boundary heights at a grid barrier;
   // done when no tile changed.  The fixpoint is the BFS distance whatever the schedule, so the
   // result is deterministic, and a front crosses a whole tile per barrier instead of one level.
+  int relabels_done = 0;
   auto global_relabel = [&](int &active) -> bool {
     constexpr int kArcRegs = 8;
     const long long t_in = wall_clock64();
     const unsigned gen_in = gen;
-    for (int v = first; v < n; v += stride) stc(h + v, ldc(g.snk + v) > 0 ? 1 : n);
+    // (`warm`: the heights are the exact distances of a flow that was maximal before a unary term
+    // changed -- Improve.  Kept as the starting point of the label correction they stay a valid
+    // labelling (every residual arc still sees at most one level down once the relaxation has
+    // converged, sink arcs are re-seeded), which is all the push phase needs; far fewer passes.)
+    const bool warm = incremental != 0 && relabels_done == 0;
+    ++relabels_done;
+    for (int v = first; v < n; v += stride) {
+      const int old_h = warm ? ldc(h + v) : n;
+      stc(h + v, ldc(g.snk + v) > 0 ? 1 : (old_h < n ? old_h : n));
+    }
     // residuals do not change during the relabelling: after this invalidate plain loads of r see
     // what the (write-through, sc1) pushes stored
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -575,6 +585,30 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
   }
 }
 
+// ---- Improve (QPBO_extra.cpp:1151-1233) helpers: the loop over the rand() permutation stays on the
+// host, but what it needs per step -- the next node of the permutation that is still not strongly
+// labelled, and the large unary term that fixes it -- is computed where the data lives.
+__global__ void qpbo_next_ambiguous_kernel(const int32_t *perm, int from, int N, int n, const int32_t *h, int32_t *out) {
+  const int j = from + blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  const int i = perm[j];
+  if ((h[i] < n) == (h[i + N] < n)) atomicMin(out, j);  // both or neither side reaches the sink
+}
+
+// AddUnaryTerm(i, 0, INFTY) with INFTY = max(-t_i + sum of outgoing residuals, t_i + sum of incoming) + 1
+// evaluated on node i (QPBO_extra.cpp:241-254, :1177-1187), same summation order as the reference
+__global__ void qpbo_fix_to_zero_kernel(QpboDev g, int i, int N) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const int im = i + N;
+  const double tcap = g.ex[i] - g.snk[i];
+  double c1 = -tcap, c2 = tcap;
+  for (int a = g.aptr[i]; a < g.aptr[i + 1]; ++a) { c1 += g.r[a]; c2 += g.r[g.rev[a]]; }
+  const double INFTY = (c1 > c2 ? c1 : c2) + 1;
+  const double t0 = g.ex[i] - g.snk[i] + INFTY, t1 = g.ex[im] - g.snk[im] - INFTY;
+  g.ex[i] = t0 > 0 ? t0 : 0; g.snk[i] = t0 < 0 ? -t0 : 0;
+  g.ex[im] = t1 > 0 ? t1 : 0; g.snk[im] = t1 < 0 ? -t1 : 0;
+}
+
 // ---- device-side construction for the plan API ------------------------------------------
 // The doubled graph has a fixed slot layout per neighbour pair (one outgoing arc at each of
 // i, j, i', j'); only heads, reverse links and capacities depend on whether the summed table
@@ -913,35 +947,36 @@ struct QpboSolver {
   // (QPBO_extra.cpp:241-254, :1185-1199), applied to the push-relabel state: more source
   // capacity at i, more sink capacity at its mate.
   void fix_to_zero(int i) {
-    const int im = i + (int)P.N;
-    double ex2[2], sn2[2];
-    STEREO_HIP_CHECK(hipMemcpy(&ex2[0], d_ex.p + i, sizeof(double), hipMemcpyDeviceToHost));
-    STEREO_HIP_CHECK(hipMemcpy(&ex2[1], d_ex.p + im, sizeof(double), hipMemcpyDeviceToHost));
-    STEREO_HIP_CHECK(hipMemcpy(&sn2[0], d_snk.p + i, sizeof(double), hipMemcpyDeviceToHost));
-    STEREO_HIP_CHECK(hipMemcpy(&sn2[1], d_snk.p + im, sizeof(double), hipMemcpyDeviceToHost));
-    const int a0 = P.aptr[i], a1 = P.aptr[i + 1];
-    std::vector<double> rr(std::max(a1 - a0, 1));
-    const double tcap = ex2[0] - sn2[0];
-    double c1 = -tcap, c2 = tcap;
-    for (int a = a0; a < a1; ++a) {
-      double ra, rb;
-      STEREO_HIP_CHECK(hipMemcpy(&ra, d_r.p + a, sizeof(double), hipMemcpyDeviceToHost));
-      STEREO_HIP_CHECK(hipMemcpy(&rb, d_r.p + P.rev[a], sizeof(double), hipMemcpyDeviceToHost));
-      c1 += ra; c2 += rb;
+    hipLaunchKernelGGL(qpbo_fix_to_zero_kernel, dim3(1), dim3(64), 0, 0, g, i, (int)P.N);
+    STEREO_HIP_CHECK(hipGetLastError());
+  }
+
+  // The Improve loop over a permutation of the nodes (QPBO_extra.cpp:1190-1200): every node that is
+  // not strongly labelled when its turn comes is fixed to 0 and the flow is maximised again.
+  // `h` returns the final heights.
+  void improve(const std::vector<int32_t> &perm, std::vector<int32_t> &h) {
+    const int N = (int)P.N;
+    DevBuf<int32_t> d_perm, d_next;
+    d_perm.upload(perm.data(), perm.size());
+    d_next.alloc(1);
+    for (int from = 0; from < N;) {
+      int32_t next = N;
+      STEREO_HIP_CHECK(hipMemcpyAsync(d_next.p, &next, sizeof(next), hipMemcpyHostToDevice, 0));
+      hipLaunchKernelGGL(qpbo_next_ambiguous_kernel, dim3((unsigned)((N - from + 255) / 256)), dim3(256), 0, 0,
+                         d_perm.p, from, N, n, g.h, d_next.p);
+      STEREO_HIP_CHECK(hipMemcpy(&next, d_next.p, sizeof(next), hipMemcpyDeviceToHost));
+      if (next >= N) break;
+      fix_to_zero(perm[next]);
+      maxflow(true);
+      from = next + 1;
     }
-    const double INFTY = (c1 > c2 ? c1 : c2) + 1;
-    double t0 = ex2[0] - sn2[0] + INFTY, t1 = ex2[1] - sn2[1] - INFTY;
-    const double nex0 = t0 > 0 ? t0 : 0, nsn0 = t0 < 0 ? -t0 : 0;
-    const double nex1 = t1 > 0 ? t1 : 0, nsn1 = t1 < 0 ? -t1 : 0;
-    STEREO_HIP_CHECK(hipMemcpy(d_ex.p + i, &nex0, sizeof(double), hipMemcpyHostToDevice));
-    STEREO_HIP_CHECK(hipMemcpy(d_snk.p + i, &nsn0, sizeof(double), hipMemcpyHostToDevice));
-    STEREO_HIP_CHECK(hipMemcpy(d_ex.p + im, &nex1, sizeof(double), hipMemcpyHostToDevice));
-    STEREO_HIP_CHECK(hipMemcpy(d_snk.p + im, &nsn1, sizeof(double), hipMemcpyHostToDevice));
+    h.resize(n);
+    STEREO_HIP_CHECK(hipMemcpy(h.data(), g.h, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
   }
 
   // One cooperative launch runs the whole max-flow (qpbo_maxflow_kernel); the multi-launch loop
   // is kept behind STEREO_HIP_QPBO_PERSISTENT=0 for comparison.
-  void maxflow() {
+  void maxflow(bool warm = false) {
     const char *pe = std::getenv("STEREO_HIP_QPBO_PERSISTENT");
     const bool persistent = !(pe && std::string(pe) == "0");
     if (!persistent) { maxflow_launches(); return; }
@@ -966,7 +1001,9 @@ struct QpboSolver {
     if (tiled) STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)qpbo_maxflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     int switch_at = 16;  // plain rounds first: most moves end within a dozen of them
     if (const char *e = std::getenv("STEREO_HIP_QPBO_SWITCH")) switch_at = std::max(0, std::atoi(e));
-    void *args[] = {&gg, &ctl, &relabel_every, &max_rounds, &tiled, &switch_at};
+    int incremental = warm ? 1 : 0;
+    if (const char *e = std::getenv("STEREO_HIP_QPBO_WARM")) incremental = incremental && std::atoi(e) != 0;
+    void *args[] = {&gg, &ctl, &relabel_every, &max_rounds, &tiled, &switch_at, &incremental};
     STEREO_HIP_CHECK(hipLaunchCooperativeKernel((const void *)qpbo_maxflow_kernel, dim3(blocks), dim3(kMB), args, dyn, 0));
     int32_t host_ctl[QpboCtl::kWords];
     STEREO_HIP_CHECK(hipMemcpy(host_ctl, d_ctl.p, sizeof(host_ctl), hipMemcpyDeviceToHost));
@@ -1064,6 +1101,21 @@ void weak_persistencies(const QpboProblem &P, const std::vector<double> &r, std:
     }
 }
 
+// The permutation of QPBO::Improve (QPBO_extra.cpp:13-27), drawn from libc rand() like the
+// reference's.  Note for callers that seed rand() to reproduce the reference: the HIP runtime draws
+// from the same generator during its one-time initialisation (measured), so initialise it first
+// (stereo_hip_warm_up; the Python package does so when it loads the library).
+std::vector<int32_t> improve_permutation(int64_t N) {
+  std::vector<int32_t> perm((size_t)N);
+  for (int64_t i = 0; i < N; ++i) perm[i] = (int32_t)i;
+  for (int64_t i = 0; i < N - 1; ++i) {
+    int64_t j = i + (int64_t)((rand() / (1.0 + (double)RAND_MAX)) * (double)(N - i));
+    if (j > N - 1) j = N - 1;
+    std::swap(perm[i], perm[j]);
+  }
+  return perm;
+}
+
 }  // namespace
 
 extern "C" int stereo_rd(const double *U0, const double *U1, const double *E00, const double *E01,
@@ -1121,23 +1173,8 @@ extern "C" int stereo_rd(const double *U0, const double *U1, const double *E00, 
       // QPBO::Improve() (QPBO_extra.cpp:1151-1233) from user labels 0: visit the nodes in a
       // rand() permutation (QPBO_extra.cpp:13-27); a node that is still not strongly labelled
       // is fixed to 0 by a large unary term and the flow is re-maximised incrementally.
-      std::vector<int32_t> perm(N);
-      for (int64_t i = 0; i < N; ++i) perm[i] = (int32_t)i;
-      for (int64_t i = 0; i < N - 1; ++i) {
-        int64_t j = i + (int64_t)((rand() / (1.0 + (double)RAND_MAX)) * (double)(N - i));
-        if (j > N - 1) j = N - 1;
-        std::swap(perm[i], perm[j]);
-      }
       // only nodes without a strong label can ever need fixing; strong labels persist
-      for (int64_t pidx = 0; pidx < N; ++pidx) {
-        const int32_t i = perm[pidx];
-        if (h[i] < n || h[i + N] < n) {
-          if ((h[i] < n) != (h[i + N] < n)) continue;  // strongly labelled
-        }
-        S.fix_to_zero(i);
-        S.maxflow();
-        STEREO_HIP_CHECK(hipMemcpy(h.data(), S.g.h, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-      }
+      S.improve(improve_permutation(N), h);
       for (int64_t i = 0; i < N; ++i) {
         const int li = h[i] < n ? 1 : 0, lm = h[i + N] < n ? 1 : 0;
         label[i] = li == lm ? 0 : li;  // QPBO_extra.cpp:1210-1219: ambiguous -> user label (0)
@@ -1329,20 +1366,7 @@ static int rd_plan_solve_device(stereo_rd_plan *P, const double *const in[6], in
       for (int64_t i = 0; i < N; ++i) if (label[i] < 0) unl += 1;
       *num_unlabelled = unl;  // rd_mex.cpp:83-88: counted before Improve
       if (improve && unl > 0) {
-        std::vector<int32_t> perm(N);
-        for (int64_t i = 0; i < N; ++i) perm[i] = (int32_t)i;
-        for (int64_t i = 0; i < N - 1; ++i) {  // QPBO_extra.cpp:13-27
-          int64_t j = i + (int64_t)((rand() / (1.0 + (double)RAND_MAX)) * (double)(N - i));
-          if (j > N - 1) j = N - 1;
-          std::swap(perm[i], perm[j]);
-        }
-        for (int64_t pidx = 0; pidx < N; ++pidx) {
-          const int32_t i = perm[pidx];
-          if ((h[i] < n) != (h[i + N] < n)) continue;
-          S.fix_to_zero(i);
-          S.maxflow();
-          STEREO_HIP_CHECK(hipMemcpy(h.data(), S.g.h, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-        }
+        S.improve(improve_permutation(N), h);
         for (int64_t i = 0; i < N; ++i) {
           const int li = h[i] < n ? 1 : 0, lm = h[i + N] < n ? 1 : 0;
           label[i] = li == lm ? 0 : li;

@@ -2931,6 +2931,22 @@ int stereo_hip_device_count(void) {
   return n;
 }
 
+__global__ void warm_up_kernel() {}
+
+int stereo_hip_warm_up(void) {
+  if (stereo_hip_device_count() < 1) return 1;
+  if (hipFree(nullptr) != hipSuccess) return 1;
+  hipLaunchKernelGGL(warm_up_kernel, dim3(1), dim3(64), 0, 0);
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  // every runtime service the QPBO path uses (cooperative launch, occupancy query, function
+  // attributes, the Improve kernels) once, on a frustrated triangle that stays unlabelled
+  const double U[3] = {0, 0, 0}, same[3] = {1, 1, 1}, diff[3] = {0, 0, 0};
+  const uint32_t conn[6] = {0, 1, 1, 2, 2, 0};
+  double lab[3], en = 0, lb = 0, nu = 0;
+  char err[256];
+  return stereo_rd(U, U, same, diff, diff, same, conn, 3, 3, 1, lab, &en, &lb, &nu, err, sizeof(err));
+}
+
 int stereo_hip_set_device(int device) {
   if (hipSetDevice(device) != hipSuccess) {
     last_error() = "hipSetDevice failed";
