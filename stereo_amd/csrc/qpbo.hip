@@ -984,10 +984,19 @@ struct QpboSolver {
     if (const char *e = std::getenv("STEREO_HIP_QPBO_RELABEL_EVERY")) relabel_every = std::max(1, std::atoi(e));
     if (d_ctl.n < (size_t)QpboCtl::kWords) d_ctl.alloc(QpboCtl::kWords);
     STEREO_HIP_CHECK(hipMemsetAsync(d_ctl.p, 0, sizeof(int32_t) * QpboCtl::kWords, 0));
-    int dev = 0, cus = 0, per_cu = 0;
+    // (device properties and the occupancy of the kernel are asked once per process and device:
+    // an Improve pass calls this function hundreds of times)
+    static int cached_dev = -1, cached_cus = 0, cached_per_cu = 0;
+    int dev = 0;
     STEREO_HIP_CHECK(hipGetDevice(&dev));
-    STEREO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    STEREO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qpbo_maxflow_kernel, kMB, sizeof(double) * 10 * kMB));
+    if (dev != cached_dev) {
+      int c = 0, pc = 0;
+      STEREO_HIP_CHECK(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
+      STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)qpbo_maxflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 10 * kMB)));
+      STEREO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, qpbo_maxflow_kernel, kMB, sizeof(double) * 10 * kMB));
+      cached_cus = c; cached_per_cu = pc; cached_dev = dev;
+    }
+    const int cus = cached_cus, per_cu = cached_per_cu;
     if (per_cu < 1) throw HipError{"qpbo_maxflow_kernel does not fit on a CU"};
     int blocks = std::min(cus * std::min(per_cu, 2), std::max(g.ntiles, 1));
     blocks = std::max(blocks, 1);
@@ -998,7 +1007,6 @@ struct QpboSolver {
     int tiled = (max_degree <= 4 && d_delta.n >= (size_t)2 * std::max(m, 1)) ? 16 : 0;
     if (const char *e = std::getenv("STEREO_HIP_QPBO_TILED")) tiled = tiled ? std::max(0, std::atoi(e)) : 0;
     const size_t dyn = tiled ? sizeof(double) * 10 * kMB : 0;
-    if (tiled) STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)qpbo_maxflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     int switch_at = 16;  // plain rounds first: most moves end within a dozen of them
     if (const char *e = std::getenv("STEREO_HIP_QPBO_SWITCH")) switch_at = std::max(0, std::atoi(e));
     int incremental = warm ? 1 : 0;
