@@ -88,6 +88,10 @@ int stereo_trws_plan_bind_device(stereo_trws_plan *plan, const double *d_unary,
                                  const double *d_q, const double *d_qprim,
                                  const double *d_positions, const double *d_alphas,
                                  double tol, char *err, size_t errcap);
+/* Both calls start a NEW minimisation: if the plan has iterated before, they imply
+ * stereo_trws_plan_reset (an iterate call runs the forward sweep of the following iteration ahead
+ * of time, so messages computed from the old inputs cannot be continued with new ones). */
+
 /* Zero all messages (MRFEnergy.cpp:115-133) and the iteration counter. */
 int stereo_trws_plan_reset(stereo_trws_plan *plan, char *err, size_t errcap);
 /* Runs up to `iters` further iterations of Minimize_TRW_S (minimize.cpp:31-113):
@@ -124,6 +128,73 @@ int stereo_trws_plan_counters(stereo_trws_plan *plan, int64_t *serial_messages, 
  * 4 two-labels-per-lane pipelined kernel (64 < K <= 128, linear kernel, any positions).
  * All give identical results.  Negative on a NULL plan. */
 int stereo_trws_plan_path(stereo_trws_plan *plan);
+
+/* ---- row strips: one image tiled across the GPUs of a node ------------------------------ *
+ * No reference counterpart (the reference is one serial sweep, minimize.cpp:36-95); what is
+ * sharded is exactly that sweep under the order of ordering.cpp:42-152, and the labels are the
+ * ones a single plan returns, bit for bit.  `owner[i]` names the strip that visits node i; strips
+ * form a chain (an edge joins nodes of one strip or of strips g, g+1) -- for an image, bands of
+ * rows.  One plan per strip, normally one process and one GPU each; every strip keeps the index
+ * space of the whole problem (same array offsets everywhere) but only touches its own nodes, the
+ * edges at them and the boundary row of each neighbour.  A boundary node's new messages, its
+ * completion flag and its label are written by the visiting workgroup straight into the
+ * neighbouring strip's arrays (peer stores over xGMI + flag; nothing is staged through the host
+ * and there is no collective on the data path).  Energy and lower bound come back as per-strip
+ * partial sums (each in the reference's summation order restricted to the strip); the caller adds
+ * them in strip order -- the only cross-strip reduction, two doubles per iteration -- so they
+ * agree with the single-plan values to rounding (1e-12 relative), not bit for bit.
+ *
+ * max_workgroups > 0 caps the strip's launch (strips that share one GPU must all be resident
+ * together).  share_analysis_with: another strip's plan of the same problem in this process
+ * (owner may then be NULL), so the host-side analysis is done once. */
+int stereo_trws_plan_create_strip(int kernel, int K, int64_t N, int64_t E, const uint32_t *conn,
+                                  int message_mode, const int32_t *owner, int nstrips, int strip,
+                                  int max_workgroups, stereo_trws_plan *share_analysis_with,
+                                  stereo_trws_plan **plan, char *err, size_t errcap);
+/* Neighbour in the same process (which: 0 = strip - 1, 1 = strip + 1); enables peer access if the
+ * two plans live on different devices. */
+int stereo_trws_plan_connect(stereo_trws_plan *plan, int which, stereo_trws_plan *peer, char *err,
+                             size_t errcap);
+/* Neighbour in another process: export writes STEREO_TRWS_IPC_BYTES bytes of HIP IPC handles
+ * (messages, flags, labels) that the neighbour passes to ipc_connect after exchanging them over
+ * any channel (bench.py: torch.distributed all_gather). */
+#define STEREO_TRWS_IPC_BYTES 256
+int stereo_trws_plan_ipc_export(stereo_trws_plan *plan, void *handles, size_t cap, char *err,
+                                size_t errcap);
+int stereo_trws_plan_ipc_connect(stereo_trws_plan *plan, int which, const void *handles, char *err,
+                                 size_t errcap);
+/* One iteration of a strip in three steps, so that all strips of a process can be in flight
+ * together and the caller can reduce the partial sums across processes:
+ *   issue   launches forward sweep (first iteration only), backward sweep and the primal pass
+ *           fused with the next forward sweep, without waiting (stream NULL = the plan's own);
+ *   collect waits and returns this strip's partial lower bound and energy;
+ *   commit  records the reduced totals (what stereo_trws_plan_result reports) and counts the
+ *           iteration.  The stop test (E-LB)/E < max_relgap of minimize.cpp:105 is the caller's. */
+int stereo_trws_plan_issue(stereo_trws_plan *plan, void *stream, char *err, size_t errcap);
+/* The same for n <= 16 strips that share ONE device (logical strips; a process that owns several
+ * bands): each sweep is a single launch whose workgroups are divided among the strips, so all of
+ * them are resident together (separate launches on separate streams may be serialised by the
+ * runtime, and strips wait for each other in both directions).  Collect / commit per plan. */
+int stereo_trws_plans_issue(stereo_trws_plan *const *plans, int n, void *stream, char *err, size_t errcap);
+int stereo_trws_plan_collect(stereo_trws_plan *plan, double *lower_bound_part, double *energy_part,
+                             char *err, size_t errcap);
+int stereo_trws_plan_commit(stereo_trws_plan *plan, double lower_bound, double energy, char *err,
+                            size_t errcap);
+/* Diagnostics (any output may be NULL). */
+int stereo_trws_plan_strip_info(stereo_trws_plan *plan, int *nstrips, int *strip, int64_t *own_nodes,
+                                int64_t *runs_forward, int64_t *runs_backward, int *needs_previous,
+                                int *needs_next);
+/* Development aid: completion flags (N, by rank: epoch of the last completed visit) and
+ * [ticket, abort] of the plan's last launch. */
+int stereo_trws_plan_debug_flags(stereo_trws_plan *plan, int32_t *done, int32_t *ctl);
+/* stereo_trws_schedule with strips: additionally run_strip (N provided, *nruns used) = strip of
+ * every run, remote (N, by rank) = descriptor word 43 (bits 0-7: outgoing message k is written
+ * to a neighbour, 8-15: which one, 16 / 17: flag and label also raised at strip - 1 / + 1). */
+int stereo_trws_schedule_strips(int64_t N, int64_t E, const uint32_t *conn, int64_t max_resident_runs,
+                                int direction, const int32_t *owner, int nstrips, int64_t *rank_at,
+                                int64_t *run_ptr, int64_t *nruns, int64_t *ticket_run,
+                                int64_t *pred_rank, int64_t *dep_ptr, int64_t *dep_rank,
+                                int64_t *run_strip, int64_t *remote, char *err, size_t errcap);
 
 /* Host-only graph analysis behind stereo_trws_plan_create (no device needed):
  * node order of SetAutomaticOrdering (ordering.cpp:7-157), edge orientation and

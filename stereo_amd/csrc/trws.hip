@@ -92,21 +92,34 @@ struct DevParams {
   int win_ok;  // shared strictly ascending positions and window <= 16: windowed min-plus allowed
   double pos_gap;  // smallest distance of two neighbouring shared positions (ascending case)
   double pos_first, pos_last;  // ... their two ends
+  // Row strips (one plan per strip, normally one per GPU): a plan dispenses only its own runs and
+  // writes what the neighbouring strips read -- messages on edges that cross the boundary, the
+  // completion flag and the label of a boundary node -- straight into THEIR arrays (same index
+  // space on every strip; over xGMI when the neighbour is another GPU).  [0] previous, [1] next strip.
+  int ntickets[2];
+  double *peer_msg[2];
+  int32_t *peer_done[2], *peer_x[2];
 };
 
-// ---- agent-scope (sc1) accesses: data handed between workgroups inside one launch
-// never sits in a per-CU L1 or a non-coherent L2 (cdna_hip_programming.md G16, R1/R2).
+// ---- hand-over accesses (sc0 sc1): data handed between workgroups inside one launch never sits
+// in a per-CU L1 or a non-coherent L2 (cdna_hip_programming.md G16, R1/R2).  System scope, not
+// agent scope: with row strips the other workgroup may run on the neighbouring GPU and write into
+// this GPU's memory over xGMI; on one GPU both scopes cost the same (measured: 68.6 vs 68.6
+// iterations/s at 450x375x60, 132.2 vs 132.2 ms at 1500x1000x256).
+#ifndef STEREO_HANDOVER_SCOPE
+#define STEREO_HANDOVER_SCOPE __HIP_MEMORY_SCOPE_SYSTEM
+#endif
 __device__ __forceinline__ double ld_sc1(const double *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, STEREO_HANDOVER_SCOPE);
 }
 __device__ __forceinline__ void st_sc1(double *p, double v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, STEREO_HANDOVER_SCOPE);
 }
 __device__ __forceinline__ int ld_sc1(const int32_t *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, STEREO_HANDOVER_SCOPE);
 }
 __device__ __forceinline__ void st_sc1(int32_t *p, int v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, STEREO_HANDOVER_SCOPE);
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
@@ -889,7 +902,7 @@ __global__ __launch_bounds__(kBlock) void trws_persistent_kernel(DevParams p, in
   const int8_t *in_slot = p.in_slot[D];
   const int N = p.N;
   for (;;) {
-    if (tid == 0) { const int t_ = atomicAdd(p.ticket, 1); *s_run = (p.run_order[BACKWARD ? 1 : 0] && t_ < p.nruns[BACKWARD ? 1 : 0]) ? p.run_order[BACKWARD ? 1 : 0][t_] : t_; }
+    if (tid == 0) { const int t_ = atomicAdd(p.ticket, 1); *s_run = t_ < p.ntickets[BACKWARD ? 1 : 0] ? (p.run_order[BACKWARD ? 1 : 0] ? p.run_order[BACKWARD ? 1 : 0][t_] : t_) : p.nruns[BACKWARD ? 1 : 0]; }
     __syncthreads();
     const int run = *s_run;
     __syncthreads();
@@ -1024,7 +1037,7 @@ __global__ __launch_bounds__(kBlock) void trws_persistent_kernel(DevParams p, in
 //  * a node's completion flag is raised in the middle of the next visit, when
 //    its write-through stores have long drained, so no store latency is exposed.
 struct NodeDesc {
-  int node, rank, nout, nin, ndep, md, lbn, urgent;
+  int node, rank, nout, nin, ndep, md, lbn, urgent, remote, epos;
   int e[8], slot[8], dep[4], lbe[8], xn[8];
 };
 #define RLI(v, i) __builtin_amdgcn_readlane((v), (i))
@@ -1044,6 +1057,7 @@ __device__ __forceinline__ NodeDesc decode_desc(int w) {
   d.xn[0] = RLI(w, 32); d.xn[1] = RLI(w, 33); d.xn[2] = RLI(w, 34); d.xn[3] = RLI(w, 35);
   d.xn[4] = RLI(w, 36); d.xn[5] = RLI(w, 37); d.xn[6] = RLI(w, 38); d.xn[7] = RLI(w, 39);
   d.urgent = RLI(w, 40);
+  d.remote = RLI(w, kDescRemote); d.epos = RLI(w, kDescEpos);
   return d;
 }
 
@@ -1303,7 +1317,7 @@ constexpr int kPipePad = 16;                      // source tables are padded by
 constexpr int kPipeTab = 4 * (kWave + 2 * kPipePad);  // doubles per compute wave: (h, q, u, v) x 96
 
 template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
-__global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, int epoch) {
+__device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double *stage0 = lds;                                   // 2 stages
   double *hand = lds + 2 * kStageDoubles;                 // ring of 4 x 8 x 64: the last visits' new messages
@@ -1330,7 +1344,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
   if ((p.debug & 4) && BACKWARD) p.prof = nullptr;   // profile forward sweeps only
 
   for (;;) {
-    if (tid == 0) { const int t_ = atomicAdd(p.ticket, 1); ctl[0] = (p.run_order[D] && t_ < p.nruns[D]) ? p.run_order[D][t_] : t_; }
+    if (tid == 0) { const int t_ = atomicAdd(p.ticket, 1); ctl[0] = t_ < p.ntickets[D] ? (p.run_order[D] ? p.run_order[D][t_] : t_) : p.nruns[D]; }
     __syncthreads();
     const int run = __builtin_amdgcn_readfirstlane(ctl[0]);
     __syncthreads();
@@ -1479,18 +1493,26 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               if (j < pd.nout) {
-                if (act) st_sc1(p.msg + (size_t)pd.e[j] * K + lane, hprev[j * kWave + lane]);
+                double *mb = ((pd.remote >> j) & 1) ? p.peer_msg[(pd.remote >> (8 + j)) & 1] : p.msg;
+                if (act) st_sc1(mb + (size_t)pd.e[j] * K + lane, hprev[j * kWave + lane]);
                 if (BACKWARD && lane == 0) p.lbterms[pd.lbe[j]] = scp[j];
               }
             }
             if (BACKWARD && lane == 0) p.lbterms[pd.lbn] = scp[8];
           }
           if (PRIMAL && lane == 0) {
-            st_sc1(p.x + pd.node, ((const int *)(scp + 10))[0]);
-            p.eterms[pd.rank] = scp[9];
+            const int xi = ((const int *)(scp + 10))[0];
+            st_sc1(p.x + pd.node, xi);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_x[0] + pd.node, xi);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_x[1] + pd.node, xi);
+            p.eterms[pd.epos] = scp[9];
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0) st_sc1(p.done + pd.rank, epoch);
+          if (lane == 0) {
+            st_sc1(p.done + pd.rank, epoch);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_done[0] + pd.rank, epoch);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_done[1] + pd.rank, epoch);
+          }
         }
       } else if (wave == kPipeCompute + 3) {
         // ------------------------------------------------------------ primal of node pos
@@ -1542,6 +1564,30 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
   }
 }
 
+template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
+__global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, int epoch) {
+  pipe_body<KERNEL, BACKWARD, PRIMAL, UPDATE, SHARED>(p, epoch);
+}
+
+// Several strips of one problem in ONE launch (row strips that share a device: logical strips, or
+// a process that owns more than one band): workgroup b works for strip s with first[s] <= b <
+// first[s + 1], on that strip's parameters.  One launch, so that all of them are resident
+// together whatever the runtime does with streams (strips wait for each other in both directions).
+constexpr int kMaxGroup = 16;
+struct GroupArgs {
+  const DevParams *pp;
+  int n;
+  int first[kMaxGroup + 1];
+};
+__device__ __forceinline__ int group_strip(const GroupArgs &ga) {
+  int s = 0;
+  for (int i = 1; i < ga.n; ++i) s = (int)blockIdx.x >= ga.first[i] ? i : s;
+  return s;
+}
+template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
+__global__ __launch_bounds__(kPipeThreads) void trws_pipe_group_kernel(GroupArgs ga, int epoch) {
+  pipe_body<KERNEL, BACKWARD, PRIMAL, UPDATE, SHARED>(ga.pp[group_strip(ga)], epoch);
+}
 
 // ---- pipelined persistent sweep for 64 < K <= 128 (two labels per lane), linear kernel -------
 // The same role-specialised structure as trws_pipe_kernel -- eight compute waves (one message each),
@@ -1584,7 +1630,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, i
   if (tid == 0) ctl[1] = 0;
 
   for (;;) {
-    if (tid == 0) { const int t_ = atomicAdd(p.ticket, 1); ctl[0] = (p.run_order[D] && t_ < p.nruns[D]) ? p.run_order[D][t_] : t_; }
+    if (tid == 0) { const int t_ = atomicAdd(p.ticket, 1); ctl[0] = t_ < p.ntickets[D] ? (p.run_order[D] ? p.run_order[D][t_] : t_) : p.nruns[D]; }
     __syncthreads();
     const int run = __builtin_amdgcn_readfirstlane(ctl[0]);
     __syncthreads();
@@ -1848,20 +1894,28 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, i
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               if (j < pd.nout) {
+                double *mb = ((pd.remote >> j) & 1) ? p.peer_msg[(pd.remote >> (8 + j)) & 1] : p.msg;
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
-                  if (act[c]) st_sc1(p.msg + (size_t)pd.e[j] * K + kk[c], hprev[j * k2W + kk[c]]);
+                  if (act[c]) st_sc1(mb + (size_t)pd.e[j] * K + kk[c], hprev[j * k2W + kk[c]]);
                 if (BACKWARD && lane == 0) p.lbterms[pd.lbe[j]] = scp[j];
               }
             }
             if (BACKWARD && lane == 0) p.lbterms[pd.lbn] = scp[8];
           }
           if (PRIMAL && lane == 0) {
-            st_sc1(p.x + pd.node, ((const int *)(scp + 10))[0]);
-            p.eterms[pd.rank] = scp[9];
+            const int xi = ((const int *)(scp + 10))[0];
+            st_sc1(p.x + pd.node, xi);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_x[0] + pd.node, xi);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_x[1] + pd.node, xi);
+            p.eterms[pd.epos] = scp[9];
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0) st_sc1(p.done + pd.rank, epoch);
+          if (lane == 0) {
+            st_sc1(p.done + pd.rank, epoch);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_done[0] + pd.rank, epoch);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_done[1] + pd.rank, epoch);
+          }
         }
       } else if (wave == kPipeCompute + 3) {
         // ------------------------------------------------------------ primal of node pos
@@ -2071,7 +2125,7 @@ __device__ __forceinline__ bool keys_within(const double (&r)[4], int K, int C, 
 }
 
 template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE>
-__global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, int epoch) {
+__device__ __forceinline__ void wide_body(DevParams p, int epoch) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const WidePtrs L = wide_carve(lds);
   const int K = p.K;
@@ -2106,7 +2160,7 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
   __syncthreads();
 
   for (;;) {
-    if (tid == 0) { const int t_ = atomicAdd(p.ticket, 1); L.ctl[0] = (p.run_order[D] && t_ < p.nruns[D]) ? p.run_order[D][t_] : t_; }
+    if (tid == 0) { const int t_ = atomicAdd(p.ticket, 1); L.ctl[0] = t_ < p.ntickets[D] ? (p.run_order[D] ? p.run_order[D][t_] : t_) : p.nruns[D]; }
     __syncthreads();
     const int run = __builtin_amdgcn_readfirstlane(L.ctl[0]);
     __syncthreads();
@@ -2503,10 +2557,11 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               if (j < pd.nout) {
+                double *mb = ((pd.remote >> j) & 1) ? p.peer_msg[(pd.remote >> (8 + j)) & 1] : p.msg;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                   const int k = c * kWave + lane;
-                  if (c < C && k < K) st_sc1(p.msg + (size_t)pd.e[j] * K + k, hprev[j * kWS + k]);
+                  if (c < C && k < K) st_sc1(mb + (size_t)pd.e[j] * K + k, hprev[j * kWS + k]);
                 }
                 if (BACKWARD && lane == 0) p.lbterms[pd.lbe[j]] = scp[j];
               }
@@ -2514,11 +2569,18 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
             if (BACKWARD && lane == 0) p.lbterms[pd.lbn] = scp[8];
           }
           if (PRIMAL && lane == 0) {
-            st_sc1(p.x + pd.node, ((const int *)(scp + 10))[0]);
-            p.eterms[pd.rank] = scp[9];
+            const int xi = ((const int *)(scp + 10))[0];
+            st_sc1(p.x + pd.node, xi);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_x[0] + pd.node, xi);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_x[1] + pd.node, xi);
+            p.eterms[pd.epos] = scp[9];
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0) st_sc1(p.done + pd.rank, epoch);
+          if (lane == 0) {
+            st_sc1(p.done + pd.rank, epoch);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_done[0] + pd.rank, epoch);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_done[1] + pd.rank, epoch);
+          }
         }
       WIDE_VISITS_END
     } else {
@@ -2593,6 +2655,14 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, in
     if (wave >= kWideCompute) atomicAdd(p.prof + 16 + (wave - kWideCompute), pbusy);
     if (wave == 1) for (int i = 0; i < 3; ++i) atomicAdd(p.prof + 8 + i, pacc[i]);  // a closest-pair wave
   }
+}
+template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE>
+__global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, int epoch) {
+  wide_body<KERNEL, BACKWARD, PRIMAL, UPDATE>(p, epoch);
+}
+template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE>
+__global__ __launch_bounds__(kWideThreads) void trws_wide_group_kernel(GroupArgs ga, int epoch) {
+  wide_body<KERNEL, BACKWARD, PRIMAL, UPDATE>(ga.pp[group_strip(ga)], epoch);
 }
 #undef WSYNC
 
@@ -2673,7 +2743,9 @@ struct stereo_trws_plan {
   double lambda = 0;
   bool have_inputs = false;
   PinnedBuf<double> h_lb, h_en;
-  PinnedBuf<int32_t> h_x;
+  PinnedBuf<int32_t> h_x, h_ctl;
+  hipStream_t issue_stream = nullptr;
+  stereo_trws_plan *timed_by = nullptr;  // first plan of the group launch this plan was issued in
   double energy = 0, lb = 0;
   int64_t iterations = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -2685,7 +2757,25 @@ struct stereo_trws_plan {
   double sweep_ms = 0;
   int64_t sweep_launches = 0;
   bool time_sweeps = false;
+  // row strips (one plan per strip; see DevParams)
+  int nstrips = 1, strip = 0;
+  DevBuf<int32_t> d_tickets[2];
+  int ntickets[2] = {0, 0};
+  int64_t n_lb = 0, n_en = 0;  // lower-bound / energy terms this plan writes (strip-local with strips)
+  double *peer_msg[2] = {nullptr, nullptr};
+  int32_t *peer_done[2] = {nullptr, nullptr}, *peer_x[2] = {nullptr, nullptr};
+  bool need_peer[2] = {false, false};
+  void *ipc_mapped[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  DevBuf<DevParams> d_group;         // parameters of the strips launched together with this one (first plan of a group)
+  PinnedBuf<DevParams> h_group;
+  hipStream_t own_stream = nullptr;  // strips launch concurrently: never on the NULL stream
+  bool issued = false;
+  int cus = 256;
   ~stereo_trws_plan() {
+    for (int w = 0; w < 2; ++w)
+      for (int k = 0; k < 3; ++k)
+        if (ipc_mapped[w][k]) (void)hipIpcCloseMemHandle(ipc_mapped[w][k]);
+    if (own_stream) (void)hipStreamDestroy(own_stream);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (ev_bwd) (void)hipEventDestroy(ev_bwd);
@@ -2727,6 +2817,11 @@ DevParams make_params(stereo_trws_plan *P) {
     p.dep_ptr[d] = P->d_dep_ptr[d].p; p.dep_rank[d] = P->d_dep_rank[d].p;
     p.in_slot[d] = P->d_in_slot[d].p;
   }
+  for (int d = 0; d < 2; ++d) {
+    p.ntickets[d] = P->nstrips > 1 ? P->ntickets[d] : p.nruns[d];
+    if (P->nstrips > 1) p.run_order[d] = P->d_tickets[d].p;
+    p.peer_msg[d] = P->peer_msg[d]; p.peer_done[d] = P->peer_done[d]; p.peer_x[d] = P->peer_x[d];
+  }
   p.done = P->d_done.p; p.ticket = P->d_ctl.p; p.abort_flag = P->d_ctl.p + 1; p.N = (int)P->N;
   p.fallbacks = P->d_fallbacks.p; p.certificate = P->certificate ? 1 : 0;
   p.prof = P->d_prof.p;
@@ -2754,7 +2849,7 @@ void launch_persistent(stereo_trws_plan *P, const DevParams &p, int what, hipStr
   const dim3 grid(P->grid_blocks), block(kBlock);
   if (P->wide) {
     const size_t wlds = sizeof(double) * kWideLdsDoubles;
-    const dim3 wgrid(std::min(P->grid_blocks, 256)), wblock(kWideThreads);
+    const dim3 wgrid(std::min(P->grid_blocks, P->cus)), wblock(kWideThreads);
     switch (what) {
       case 0: hipLaunchKernelGGL((trws_wide_kernel<1, false, false, true>), wgrid, wblock, wlds, s, p, epoch); break;
       case 1: hipLaunchKernelGGL((trws_wide_kernel<1, true, false, true>), wgrid, wblock, wlds, s, p, epoch); break;
@@ -2768,7 +2863,7 @@ void launch_persistent(stereo_trws_plan *P, const DevParams &p, int what, hipStr
   if (P->fast2) {
     const size_t lds2 = sizeof(double) * k2LdsDoubles;
     const bool sh2 = P->pos != nullptr;
-    const dim3 grid2(std::min(P->grid_blocks, 256)), block2(kPipeThreads);
+    const dim3 grid2(std::min(P->grid_blocks, P->cus)), block2(kPipeThreads);
 #define PIPE2(BW, PR, UP)                                                                         \
   do {                                                                                            \
     if (sh2) hipLaunchKernelGGL((trws_pipe2_kernel<BW, PR, UP, true>), grid2, block2, lds2, s, p, epoch);  \
@@ -2823,7 +2918,7 @@ void persistent_iteration(stereo_trws_plan *P, const DevParams &p, hipStream_t s
   // the backward sweep's lower-bound terms travel while the next launch runs
   STEREO_HIP_CHECK(hipEventRecord(P->ev_bwd, s));
   STEREO_HIP_CHECK(hipStreamWaitEvent(P->copy_stream, P->ev_bwd, 0));
-  STEREO_HIP_CHECK(hipMemcpyAsync(P->h_lb.p, P->d_lbterms.p, sizeof(double) * P->graph->lb_terms, hipMemcpyDeviceToHost,
+  STEREO_HIP_CHECK(hipMemcpyAsync(P->h_lb.p, P->d_lbterms.p, sizeof(double) * P->n_lb, hipMemcpyDeviceToHost,
                                   P->copy_stream));
   STEREO_HIP_CHECK(hipEventRecord(P->ev_lb, P->copy_stream));
   P->lb_in_flight = true;
@@ -2868,7 +2963,22 @@ void run_argsort(const double *vals, uint16_t *perm, int K, int64_t count, hipSt
   STEREO_HIP_CHECK(hipGetLastError());
 }
 
+// Zero messages (MRFEnergy.cpp:115-133), labels, flags and every piece of iteration state.
+void reset_state(stereo_trws_plan *P) {
+  STEREO_HIP_CHECK(hipMemset(P->d_msg.p, 0, sizeof(double) * (size_t)P->E * P->K));
+  STEREO_HIP_CHECK(hipMemset(P->d_x.p, 0, sizeof(int32_t) * P->N));
+  STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * P->N));
+  STEREO_HIP_CHECK(hipMemset(P->d_ctl.p, 0, sizeof(int32_t) * 2));
+  STEREO_HIP_CHECK(hipDeviceSynchronize());
+  P->iterations = 0; P->energy = 0; P->lb = 0; P->epoch = 0; P->fwd_pending = false;
+  P->lb_in_flight = false; P->issued = false;
+}
+
 void finish_inputs(stereo_trws_plan *P) {
+  // New inputs start a new minimisation: the forward sweep of the next iteration has usually run
+  // already with the OLD inputs (persistent_iteration fuses it with the primal pass), so the
+  // messages on the device belong to no state the reference could be in with the new ones.
+  if (P->iterations > 0 || P->fwd_pending) reset_state(P);
   if (P->pos) {
     P->d_perm_pos.alloc(P->K);
     run_argsort(P->pos, P->d_perm_pos.p, P->K, 1, nullptr);
@@ -2957,10 +3067,13 @@ int stereo_hip_set_device(int device) {
 
 const char *stereo_hip_last_error(void) { return last_error().c_str(); }
 
-int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint32_t *conn,
-                            int message_mode, stereo_trws_plan **plan, char *err, size_t errcap) {
+static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint32_t *conn, int message_mode,
+                            const int32_t *owner, int nstrips, int strip, int max_blocks,
+                            stereo_trws_plan *share, bool strip_api, stereo_trws_plan **plan, char *err, size_t errcap) {
   if (!plan) return fail("stereo_trws_plan_create: plan is NULL", err, errcap);
   *plan = nullptr;
+  if (nstrips < 1 || strip < 0 || strip >= nstrips) return fail("stereo_trws_plan_create: strip out of range", err, errcap);
+  if (nstrips > 1 && !owner && !share) return fail("stereo_trws_plan_create: strips need an owner per node", err, errcap);
   if (kernel != 1 && kernel != 2) return fail("Unsupported kernel", err, errcap);
   if (K < 1 || K > 8 * kWave) return fail("stereo_trws: K must be in [1, 512]", err, errcap);
   if (message_mode != STEREO_TRWS_MESSAGES_EXACT && message_mode != STEREO_TRWS_MESSAGES_MINPLUS)
@@ -2970,30 +3083,49 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
   try {
     std::unique_ptr<stereo_trws_plan> P(new stereo_trws_plan);
     P->kernel = kernel; P->K = K; P->Kp = (K + 1) & ~1; P->mode = message_mode; P->N = N; P->E = E;
+    P->nstrips = nstrips; P->strip = strip;
     std::string gerr;
-    // workgroups that stay resident: runs beyond that are cut / dispensed by dependency level
+    // Workgroups that stay resident: runs beyond that are cut / dispensed by dependency level.  The
+    // bound comes from the device in use (a partitioned or masked MI355X exposes fewer CUs): one
+    // workgroup per CU is what is certain to be resident, LDS decides how many more fit.
+    STEREO_HIP_CHECK(hipGetDevice(&P->device));
+    {
+      int cus = 0;
+      STEREO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, P->device));
+      P->cus = std::max(cus, 1);
+    }
     const bool wide_candidate = kernel == 1 && K > kWave && K <= 256 && message_mode == STEREO_TRWS_MESSAGES_EXACT;
     const int64_t per_cu = std::min<int64_t>(std::max<int64_t>(1, (int64_t)(160 * 1024) / (int64_t)persistent_lds_bytes(P->Kp)), 4);
-    const int64_t capacity = wide_candidate ? 256 : 256 * per_cu;
+    const int64_t capacity = wide_candidate ? P->cus : P->cus * per_cu;
     // The analysis depends on the connectivity only (ordering, lists, schedules: 0.2-0.6 s at Teddy
     // size); consecutive plans for the same image grid -- every trws() call of a fusion loop --
     // share the last one.
-    {
+    if (share) {
+      // the strips of one process share one analysis (it is the same on every strip)
+      if (!share->graph || share->N != N || share->E != E || share->graph->nstrips != nstrips)
+        return fail("stereo_trws_plan_create: the plan to share the graph analysis with belongs to another problem", err, errcap);
+      P->graph = share->graph;
+    } else {
       static std::mutex cache_mutex;
-      static struct { int64_t N = -1, E = -1, capacity = -1; std::vector<uint32_t> conn; std::shared_ptr<const TrwsGraph> g; } cache;
+      static struct { int64_t N = -1, E = -1, capacity = -1, cus = -1; int nstrips = 1; std::vector<uint32_t> conn; std::vector<int32_t> owner;
+                      std::shared_ptr<const TrwsGraph> g; } cache;
       std::lock_guard<std::mutex> lock(cache_mutex);
-      const bool hit = cache.g && cache.N == N && cache.E == E && cache.capacity == capacity &&
-                       std::memcmp(cache.conn.data(), conn, sizeof(uint32_t) * 2 * (size_t)E) == 0;
+      const bool hit = cache.g && cache.N == N && cache.E == E && cache.capacity == capacity && cache.cus == P->cus &&
+                       cache.nstrips == nstrips &&
+                       std::memcmp(cache.conn.data(), conn, sizeof(uint32_t) * 2 * (size_t)E) == 0 &&
+                       (nstrips == 1 || std::memcmp(cache.owner.data(), owner, sizeof(int32_t) * (size_t)N) == 0);
       if (hit) {
         P->graph = cache.g;
       } else {
         auto fresh = std::make_shared<TrwsGraph>();
-        if (!build_trws_graph(N, E, conn, *fresh, gerr, capacity)) return fail(gerr, err, errcap);
+        if (!build_trws_graph(N, E, conn, *fresh, gerr, capacity, nstrips > 1 ? owner : nullptr, nstrips, P->cus)) return fail(gerr, err, errcap);
         P->graph = fresh;
         if (N <= (1 << 20)) {  // (the descriptors of a 3000 x 2000 grid are 3 GB: not worth keeping)
-          cache.N = N; cache.E = E; cache.capacity = capacity; cache.conn.assign(conn, conn + 2 * (size_t)E); cache.g = fresh;
+          cache.N = N; cache.E = E; cache.capacity = capacity; cache.cus = P->cus; cache.nstrips = nstrips;
+          cache.conn.assign(conn, conn + 2 * (size_t)E); cache.g = fresh;
+          if (nstrips > 1) cache.owner.assign(owner, owner + N); else cache.owner.clear();
         } else {
-          cache.g.reset(); cache.conn.clear(); cache.N = -1;
+          cache.g.reset(); cache.conn.clear(); cache.owner.clear(); cache.N = -1;
         }
       }
     }
@@ -3031,6 +3163,33 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
       P->wide_allowed = P->wide_allowed && std::string(f) != "0";
       P->fast2 = P->fast2 && std::string(f) != "0";
     }
+    if (nstrips > 1) {
+      // a strip walks the chain schedule with one of the descriptor-driven kernels
+      if (!(P->fast || P->wide_allowed || P->fast2))
+        return fail("stereo_trws: row strips need a graph and label count the pipelined kernels take "
+                    "(<= 8 edges per node; K <= 64, or K <= 128 with the linear kernel, or K <= 256 with shared positions)", err, errcap);
+      for (int d = 0; d < 2; ++d) {
+        const TrwsGraph::Sweep &S = g.sweep[d];
+        const int64_t R = (int64_t)S.chain_run_ptr.size() - 1;
+        std::vector<int32_t> mine;
+        for (int64_t t = 0; t < R; ++t) {
+          const int32_t run = S.chain_run_order.empty() ? (int32_t)t : S.chain_run_order[t];
+          if (S.chain_run_strip[run] == strip) mine.push_back(run);
+        }
+        P->ntickets[d] = (int)mine.size();
+        P->d_tickets[d].upload(mine.data(), mine.size());
+        // which neighbours this strip writes to (it must be connected to them before it iterates)
+        for (int64_t q = 0; q < N; ++q) {
+          const uint32_t rem = (uint32_t)S.desc[(size_t)q * TrwsGraph::kDescWords + kDescRemote];
+          if (g.owner[g.order[S.chain_rank[q]]] != strip) continue;
+          if (rem & (1u << 16)) P->need_peer[0] = true;
+          if (rem & (1u << 17)) P->need_peer[1] = true;
+        }
+      }
+    }
+    if (strip_api) STEREO_HIP_CHECK(hipStreamCreateWithFlags(&P->own_stream, hipStreamNonBlocking));
+    P->n_lb = nstrips > 1 ? g.strip_lb_terms[strip] : g.lb_terms;
+    P->n_en = nstrips > 1 ? g.strip_nodes[strip] : N;
     P->d_done.alloc(N);
     P->d_ctl.alloc(2);
     P->d_fallbacks.alloc(1);
@@ -3047,13 +3206,16 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
       int64_t runs = std::max<int64_t>((int64_t)g.sweep[0].run_ptr.size() - 1, 1);
       if (g.fast_ok)
         runs = std::max<int64_t>({runs, (int64_t)g.sweep[0].chain_run_ptr.size() - 1, (int64_t)g.sweep[1].chain_run_ptr.size() - 1});
-      P->grid_blocks = (int)std::min<int64_t>(runs, 256 * per_cu);
+      if (nstrips > 1) runs = std::max<int64_t>({1, (int64_t)P->ntickets[0], (int64_t)P->ntickets[1]});
+      P->grid_blocks = (int)std::min<int64_t>(runs, P->cus * per_cu);
+      if (max_blocks > 0) P->grid_blocks = std::min(P->grid_blocks, max_blocks);
     }
     P->d_msg.alloc((size_t)E * K);
-    P->d_lbterms.alloc(g.lb_terms);
-    P->d_eterms.alloc(N);
+    P->d_lbterms.alloc(P->n_lb);
+    P->d_eterms.alloc(P->n_en);
     P->d_x.alloc(N);
-    P->h_lb.alloc(g.lb_terms); P->h_en.alloc(N); P->h_x.alloc(N);
+    P->h_lb.alloc(P->n_lb); P->h_en.alloc(P->n_en); P->h_x.alloc(N); P->h_ctl.alloc(2);
+    P->h_ctl.p[0] = P->h_ctl.p[1] = 0;
     STEREO_HIP_CHECK(hipMemset(P->d_msg.p, 0, sizeof(double) * (size_t)E * K));
     STEREO_HIP_CHECK(hipMemset(P->d_x.p, 0, sizeof(int32_t) * N));
     STEREO_HIP_CHECK(hipEventCreate(&P->ev0));
@@ -3101,6 +3263,19 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
       SET_WLDS(1);
 #undef SET_WLDS
     }
+    if (strip_api) {
+      const int glds = (int)(sizeof(double) * kWideLdsDoubles);
+#define SET_GW(BW, PR, UP) STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_wide_group_kernel<1, BW, PR, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, glds))
+      SET_GW(false, false, true); SET_GW(true, false, true); SET_GW(false, true, true); SET_GW(false, true, false);
+#undef SET_GW
+      const int gplds = (int)(sizeof(double) * (2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * kPipeTab + 2 + 3 * kWave / 2));
+#define SET_GP(KER, BW, PR, UP)                                                                                                        \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_pipe_group_kernel<KER, BW, PR, UP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gplds)); \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_pipe_group_kernel<KER, BW, PR, UP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gplds))
+      SET_GP(1, false, false, true); SET_GP(1, true, false, true); SET_GP(1, false, true, true); SET_GP(1, false, true, false);
+      SET_GP(2, false, false, true); SET_GP(2, true, false, true); SET_GP(2, false, true, true); SET_GP(2, false, true, false);
+#undef SET_GP
+    }
     *plan = P.release();
     return 0;
   } catch (const HipError &e) {
@@ -3108,6 +3283,19 @@ int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint3
   } catch (const std::exception &e) {
     return fail(std::string("stereo_trws_plan_create: ") + e.what(), err, errcap);
   }
+}
+
+int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint32_t *conn,
+                            int message_mode, stereo_trws_plan **plan, char *err, size_t errcap) {
+  return plan_create_impl(kernel, K, N, E, conn, message_mode, nullptr, 1, 0, 0, nullptr, false, plan, err, errcap);
+}
+
+int stereo_trws_plan_create_strip(int kernel, int K, int64_t N, int64_t E, const uint32_t *conn, int message_mode,
+                                  const int32_t *owner, int nstrips, int strip, int max_workgroups,
+                                  stereo_trws_plan *share_analysis_with, stereo_trws_plan **plan, char *err,
+                                  size_t errcap) {
+  return plan_create_impl(kernel, K, N, E, conn, message_mode, owner, nstrips, strip, max_workgroups,
+                          share_analysis_with, true, plan, err, errcap);
 }
 
 void stereo_trws_plan_destroy(stereo_trws_plan *plan) {
@@ -3193,66 +3381,89 @@ int stereo_trws_plan_bind_device(stereo_trws_plan *P, const double *d_unary, con
 int stereo_trws_plan_reset(stereo_trws_plan *P, char *err, size_t errcap) {
   if (!P) return fail("stereo_trws_plan_reset: NULL plan", err, errcap);
   try {
-    STEREO_HIP_CHECK(hipMemset(P->d_msg.p, 0, sizeof(double) * (size_t)P->E * P->K));
-    STEREO_HIP_CHECK(hipMemset(P->d_x.p, 0, sizeof(int32_t) * P->N));
-    STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * P->N));
-    STEREO_HIP_CHECK(hipMemset(P->d_ctl.p, 0, sizeof(int32_t) * 2));
-    STEREO_HIP_CHECK(hipDeviceSynchronize());
-    P->iterations = 0; P->energy = 0; P->lb = 0; P->epoch = 0; P->fwd_pending = false;
+    reset_state(P);
     return 0;
   } catch (const HipError &e) {
     return fail(e.msg, err, errcap);
   }
 }
 
+// One iteration's launches and device-to-host copies, without waiting for any of them.
+static void issue_iteration(stereo_trws_plan *P, const DevParams &p, hipStream_t s) {
+  if (P->persistent) {
+    if (P->kernel == 1) {
+      if (P->mode == 0) persistent_iteration<1, 0>(P, p, s); else persistent_iteration<1, 1>(P, p, s);
+    } else {
+      if (P->mode == 0) persistent_iteration<2, 0>(P, p, s); else persistent_iteration<2, 1>(P, p, s);
+    }
+  } else {
+    if (P->kernel == 1) {
+      if (P->mode == 0) launch_iteration<1, 0>(P, p, s); else launch_iteration<1, 1>(P, p, s);
+    } else {
+      if (P->mode == 0) launch_iteration<2, 0>(P, p, s); else launch_iteration<2, 1>(P, p, s);
+    }
+  }
+  if (!P->lb_in_flight)
+    STEREO_HIP_CHECK(hipMemcpyAsync(P->h_lb.p, P->d_lbterms.p, sizeof(double) * P->n_lb, hipMemcpyDeviceToHost, s));
+  STEREO_HIP_CHECK(hipMemcpyAsync(P->h_en.p, P->d_eterms.p, sizeof(double) * P->n_en, hipMemcpyDeviceToHost, s));
+  if (P->persistent)
+    STEREO_HIP_CHECK(hipMemcpyAsync(P->h_ctl.p, P->d_ctl.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  P->issued = true;
+}
+
+// Waits for the iteration issued last and sums its lower-bound and energy terms in the
+// reference's order (minimize.cpp:82,92 and :260): sequential, bit exact.  Returns false if a
+// sweep gave up waiting on a dependency flag.
+static bool collect_iteration(stereo_trws_plan *P, hipStream_t s, double *lb_out, double *en_out) {
+  double lb = 0, en = 0;
+  if (P->lb_in_flight) {  // summed while the forward sweep + primal launch is still running
+    STEREO_HIP_CHECK(hipEventSynchronize(P->ev_lb));
+    for (int64_t i = 0; i < P->n_lb; ++i) lb += P->h_lb.p[i];
+  }
+  STEREO_HIP_CHECK(hipStreamSynchronize(s));
+  P->issued = false;
+  if (P->persistent && P->h_ctl.p[1]) return false;
+  if (P->time_sweeps && (!P->timed_by || P->timed_by->time_sweeps)) {
+    float ms = 0;
+    stereo_trws_plan *T = P->timed_by ? P->timed_by : P;
+    STEREO_HIP_CHECK(hipEventElapsedTime(&ms, T->ev0, T->ev1));
+    P->sweep_ms += ms;
+  }
+  if (!P->lb_in_flight)
+    for (int64_t i = 0; i < P->n_lb; ++i) lb += P->h_lb.p[i];
+  P->lb_in_flight = false;
+  for (int64_t i = 0; i < P->n_en; ++i) en += P->h_en.p[i];
+  *lb_out = lb; *en_out = en;
+  return true;
+}
+
+static const char *kGaveUp = "stereo_trws: a persistent sweep gave up waiting on a dependency flag";
+
+static int strip_ready(stereo_trws_plan *P, const char *who, char *err, size_t errcap) {
+  if (!P) return fail(std::string(who) + ": NULL plan", err, errcap);
+  if (!P->have_inputs) return fail(std::string(who) + ": no inputs uploaded/bound", err, errcap);
+  for (int w = 0; w < 2; ++w)
+    if (P->need_peer[w] && !(P->peer_msg[w] && P->peer_done[w] && P->peer_x[w]))
+      return fail(std::string(who) + ": strip is not connected to its " + (w ? "next" : "previous") + " neighbour", err, errcap);
+  return 0;
+}
+
 int stereo_trws_plan_iterate(stereo_trws_plan *P, int iters, double max_relgap, void *stream,
                              int *done_iters, int *stopped, char *err, size_t errcap) {
   if (!P) return fail("stereo_trws_plan_iterate: NULL plan", err, errcap);
   if (!P->have_inputs) return fail("stereo_trws_plan_iterate: no inputs uploaded/bound", err, errcap);
+  if (P->nstrips > 1)
+    return fail("stereo_trws_plan_iterate: a strip iterates through stereo_trws_plan_issue / _collect / _commit "
+                "(its energy and bound are partial sums)", err, errcap);
   if (done_iters) *done_iters = 0;
   if (stopped) *stopped = 0;
   hipStream_t s = (hipStream_t)stream;
   try {
     const DevParams p = make_params(P);
     for (int it = 0; it < iters; ++it) {
-      if (P->persistent) {
-        if (P->kernel == 1) {
-          if (P->mode == 0) persistent_iteration<1, 0>(P, p, s); else persistent_iteration<1, 1>(P, p, s);
-        } else {
-          if (P->mode == 0) persistent_iteration<2, 0>(P, p, s); else persistent_iteration<2, 1>(P, p, s);
-        }
-      } else {
-        if (P->kernel == 1) {
-          if (P->mode == 0) launch_iteration<1, 0>(P, p, s); else launch_iteration<1, 1>(P, p, s);
-        } else {
-          if (P->mode == 0) launch_iteration<2, 0>(P, p, s); else launch_iteration<2, 1>(P, p, s);
-        }
-      }
-      if (!P->lb_in_flight)
-        STEREO_HIP_CHECK(hipMemcpyAsync(P->h_lb.p, P->d_lbterms.p, sizeof(double) * P->graph->lb_terms,
-                                        hipMemcpyDeviceToHost, s));
-      STEREO_HIP_CHECK(hipMemcpyAsync(P->h_en.p, P->d_eterms.p, sizeof(double) * P->N,
-                                      hipMemcpyDeviceToHost, s));
-      int32_t ctl[2] = {0, 0};
-      if (P->persistent)
-        STEREO_HIP_CHECK(hipMemcpyAsync(ctl, P->d_ctl.p, sizeof(ctl), hipMemcpyDeviceToHost, s));
-      // sums in the reference's order (minimize.cpp:82,92 and :260): sequential, bit exact
+      issue_iteration(P, p, s);
       double lb = 0, en = 0;
-      if (P->lb_in_flight) {  // summed while the forward sweep + primal launch is still running
-        STEREO_HIP_CHECK(hipEventSynchronize(P->ev_lb));
-        for (int64_t i = 0; i < P->graph->lb_terms; ++i) lb += P->h_lb.p[i];
-      }
-      STEREO_HIP_CHECK(hipStreamSynchronize(s));
-      if (ctl[1]) return fail("stereo_trws: a persistent sweep gave up waiting on a dependency flag", err, errcap);
-      if (P->time_sweeps) {
-        float ms = 0;
-        STEREO_HIP_CHECK(hipEventElapsedTime(&ms, P->ev0, P->ev1));
-        P->sweep_ms += ms;
-      }
-      if (!P->lb_in_flight)
-        for (int64_t i = 0; i < P->graph->lb_terms; ++i) lb += P->h_lb.p[i];
-      P->lb_in_flight = false;
-      for (int64_t i = 0; i < P->N; ++i) en += P->h_en.p[i];
+      if (!collect_iteration(P, s, &lb, &en)) return fail(kGaveUp, err, errcap);
       P->lb = lb; P->energy = en; P->iterations += 1;
       if (done_iters) *done_iters += 1;
       const double rel_gap = (en - lb) / en;  // minimize.cpp:105
@@ -3265,6 +3476,206 @@ int stereo_trws_plan_iterate(stereo_trws_plan *P, int iters, double max_relgap, 
   } catch (const HipError &e) {
     return fail(e.msg, err, errcap);
   }
+}
+
+// One fused launch for the strips of a group (what: as in launch_persistent).
+static void launch_group(stereo_trws_plan *const *G, int n, int what, hipStream_t s) {
+  stereo_trws_plan *P0 = G[0];
+  GroupArgs ga{};
+  ga.pp = P0->d_group.p; ga.n = n;
+  int total = 0;
+  const int epoch = P0->epoch + 1;
+  for (int i = 0; i < n; ++i) {
+    stereo_trws_plan *P = G[i];
+    ++P->epoch;
+    STEREO_HIP_CHECK(hipMemsetAsync(P->d_ctl.p, 0, sizeof(int32_t), s));  // ticket = 0
+    ga.first[i] = total;
+    total += P0->wide ? std::min(P->grid_blocks, P->cus) : P->grid_blocks;
+    if (what != 3) P->sweep_launches += 1;
+  }
+  ga.first[n] = total;
+  if (P0->wide) {
+    const size_t wlds = sizeof(double) * kWideLdsDoubles;
+    const dim3 grid(total), block(kWideThreads);
+    switch (what) {
+      case 0: hipLaunchKernelGGL((trws_wide_group_kernel<1, false, false, true>), grid, block, wlds, s, ga, epoch); break;
+      case 1: hipLaunchKernelGGL((trws_wide_group_kernel<1, true, false, true>), grid, block, wlds, s, ga, epoch); break;
+      case 2: hipLaunchKernelGGL((trws_wide_group_kernel<1, false, true, true>), grid, block, wlds, s, ga, epoch); break;
+      default: hipLaunchKernelGGL((trws_wide_group_kernel<1, false, true, false>), grid, block, wlds, s, ga, epoch); break;
+    }
+  } else {
+    const size_t plds = sizeof(double) * (2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * kPipeTab + 2 + 3 * kWave / 2);
+    const bool sh = P0->pos != nullptr;
+    const dim3 grid(total), block(kPipeThreads);
+#define GPIPE(KER, BW, PR, UP)                                                                                        \
+  do {                                                                                                                \
+    if (sh) hipLaunchKernelGGL((trws_pipe_group_kernel<KER, BW, PR, UP, true>), grid, block, plds, s, ga, epoch);       \
+    else hipLaunchKernelGGL((trws_pipe_group_kernel<KER, BW, PR, UP, false>), grid, block, plds, s, ga, epoch);         \
+  } while (0)
+#define GPIPE4(KER)                                                                                                   \
+  switch (what) {                                                                                                     \
+    case 0: GPIPE(KER, false, false, true); break;                                                                    \
+    case 1: GPIPE(KER, true, false, true); break;                                                                     \
+    case 2: GPIPE(KER, false, true, true); break;                                                                     \
+    default: GPIPE(KER, false, true, false); break;                                                                   \
+  }
+    if (P0->kernel == 1) { GPIPE4(1) } else { GPIPE4(2) }
+#undef GPIPE4
+#undef GPIPE
+  }
+  STEREO_HIP_CHECK(hipGetLastError());
+}
+
+int stereo_trws_plans_issue(stereo_trws_plan *const *plans, int n, void *stream, char *err, size_t errcap) {
+  if (!plans || n < 1 || n > kMaxGroup) return fail("stereo_trws_plans_issue: need 1 .. 16 plans", err, errcap);
+  for (int i = 0; i < n; ++i) {
+    if (int rc = strip_ready(plans[i], "stereo_trws_plans_issue", err, errcap)) return rc;
+    stereo_trws_plan *P = plans[i], *P0 = plans[0];
+    if (P->issued) return fail("stereo_trws_plans_issue: the previous iteration has not been collected", err, errcap);
+    if (P->device != P0->device || P->graph != P0->graph || P->K != P0->K || P->kernel != P0->kernel ||
+        P->epoch != P0->epoch || P->fwd_pending != P0->fwd_pending || P->wide != P0->wide || P->fast != P0->fast ||
+        (P->pos == nullptr) != (P0->pos == nullptr) || P->mode != P0->mode)
+      return fail("stereo_trws_plans_issue: the plans are not strips of one problem on one device in the same state", err, errcap);
+    if (!P->persistent || !(P->wide || P->fast))
+      return fail("stereo_trws_plans_issue: strips run on the pipelined kernels only (K <= 64, or K <= 256 with shared "
+                  "ascending positions and the linear kernel)", err, errcap);
+  }
+  try {
+    stereo_trws_plan *P0 = plans[0];
+    hipStream_t s = stream ? (hipStream_t)stream : P0->own_stream;
+    if (!s) return fail("stereo_trws_plans_issue: a plain plan needs an explicit stream here", err, errcap);
+    if (P0->d_group.n < (size_t)n) { P0->d_group.alloc(kMaxGroup); P0->h_group.alloc(kMaxGroup); }
+    for (int i = 0; i < n; ++i) P0->h_group.p[i] = make_params(plans[i]);
+    STEREO_HIP_CHECK(hipMemcpyAsync(P0->d_group.p, P0->h_group.p, sizeof(DevParams) * n, hipMemcpyHostToDevice, s));
+    if (P0->time_sweeps) STEREO_HIP_CHECK(hipEventRecord(P0->ev0, s));
+    if (!P0->fwd_pending) launch_group(plans, n, 0, s);
+    launch_group(plans, n, 1, s);
+    // the backward sweep's lower-bound terms travel while the next launch runs
+    STEREO_HIP_CHECK(hipEventRecord(P0->ev_bwd, s));
+    for (int i = 0; i < n; ++i) {
+      stereo_trws_plan *P = plans[i];
+      STEREO_HIP_CHECK(hipStreamWaitEvent(P->copy_stream, P0->ev_bwd, 0));
+      STEREO_HIP_CHECK(hipMemcpyAsync(P->h_lb.p, P->d_lbterms.p, sizeof(double) * P->n_lb, hipMemcpyDeviceToHost, P->copy_stream));
+      STEREO_HIP_CHECK(hipEventRecord(P->ev_lb, P->copy_stream));
+      P->lb_in_flight = true;
+    }
+    launch_group(plans, n, 2, s);  // forward sweep of the NEXT iteration fused with this iteration's primal
+    if (P0->time_sweeps) STEREO_HIP_CHECK(hipEventRecord(P0->ev1, s));
+    for (int i = 0; i < n; ++i) {
+      stereo_trws_plan *P = plans[i];
+      P->fwd_pending = true;
+      STEREO_HIP_CHECK(hipMemcpyAsync(P->h_en.p, P->d_eterms.p, sizeof(double) * P->n_en, hipMemcpyDeviceToHost, s));
+      STEREO_HIP_CHECK(hipMemcpyAsync(P->h_ctl.p, P->d_ctl.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      P->issued = true; P->issue_stream = s; P->timed_by = P0;
+    }
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+int stereo_trws_plan_issue(stereo_trws_plan *P, void *stream, char *err, size_t errcap) {
+  return stereo_trws_plans_issue(&P, 1, stream, err, errcap);
+}
+
+int stereo_trws_plan_collect(stereo_trws_plan *P, double *lb_part, double *energy_part, char *err, size_t errcap) {
+  if (!P) return fail("stereo_trws_plan_collect: NULL plan", err, errcap);
+  if (!P->issued) return fail("stereo_trws_plan_collect: nothing was issued", err, errcap);
+  try {
+    double lb = 0, en = 0;
+    if (!collect_iteration(P, P->issue_stream, &lb, &en)) return fail(kGaveUp, err, errcap);
+    if (lb_part) *lb_part = lb;
+    if (energy_part) *energy_part = en;
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+int stereo_trws_plan_commit(stereo_trws_plan *P, double lower_bound, double energy, char *err, size_t errcap) {
+  if (!P) return fail("stereo_trws_plan_commit: NULL plan", err, errcap);
+  P->lb = lower_bound; P->energy = energy; P->iterations += 1;
+  return 0;
+}
+
+int stereo_trws_plan_connect(stereo_trws_plan *P, int which, stereo_trws_plan *peer, char *err, size_t errcap) {
+  if (!P || !peer || (which != 0 && which != 1)) return fail("stereo_trws_plan_connect: bad argument", err, errcap);
+  if (P->N != peer->N || P->E != peer->E || P->K != peer->K || P->nstrips != peer->nstrips ||
+      peer->strip != P->strip + (which ? 1 : -1))
+    return fail("stereo_trws_plan_connect: the peer is not the neighbouring strip of the same problem", err, errcap);
+  try {
+    if (peer->device != P->device) {  // one process driving several GPUs: map the neighbour's memory
+      int can = 0;
+      STEREO_HIP_CHECK(hipDeviceCanAccessPeer(&can, P->device, peer->device));
+      if (!can) return fail("stereo_trws_plan_connect: no peer access between the two devices", err, errcap);
+      int cur = 0;
+      STEREO_HIP_CHECK(hipGetDevice(&cur));
+      STEREO_HIP_CHECK(hipSetDevice(P->device));
+      const hipError_t e = hipDeviceEnablePeerAccess(peer->device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) STEREO_HIP_CHECK(e);
+      (void)hipGetLastError();
+      STEREO_HIP_CHECK(hipSetDevice(cur));
+    }
+    P->peer_msg[which] = peer->d_msg.p; P->peer_done[which] = peer->d_done.p; P->peer_x[which] = peer->d_x.p;
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+int stereo_trws_plan_ipc_export(stereo_trws_plan *P, void *handles, size_t cap, char *err, size_t errcap) {
+  if (!P || !handles) return fail("stereo_trws_plan_ipc_export: NULL argument", err, errcap);
+  if (cap < STEREO_TRWS_IPC_BYTES) return fail("stereo_trws_plan_ipc_export: buffer smaller than STEREO_TRWS_IPC_BYTES", err, errcap);
+  static_assert(3 * sizeof(hipIpcMemHandle_t) <= STEREO_TRWS_IPC_BYTES, "STEREO_TRWS_IPC_BYTES");
+  try {
+    hipIpcMemHandle_t h[3];
+    STEREO_HIP_CHECK(hipIpcGetMemHandle(&h[0], P->d_msg.p));
+    STEREO_HIP_CHECK(hipIpcGetMemHandle(&h[1], P->d_done.p));
+    STEREO_HIP_CHECK(hipIpcGetMemHandle(&h[2], P->d_x.p));
+    std::memset(handles, 0, STEREO_TRWS_IPC_BYTES);
+    std::memcpy(handles, h, sizeof(h));
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+int stereo_trws_plan_ipc_connect(stereo_trws_plan *P, int which, const void *handles, char *err, size_t errcap) {
+  if (!P || !handles || (which != 0 && which != 1)) return fail("stereo_trws_plan_ipc_connect: bad argument", err, errcap);
+  try {
+    hipIpcMemHandle_t h[3];
+    std::memcpy(h, handles, sizeof(h));
+    void *ptr[3] = {nullptr, nullptr, nullptr};
+    for (int k = 0; k < 3; ++k) {
+      if (P->ipc_mapped[which][k]) { (void)hipIpcCloseMemHandle(P->ipc_mapped[which][k]); P->ipc_mapped[which][k] = nullptr; }
+      STEREO_HIP_CHECK(hipIpcOpenMemHandle(&ptr[k], h[k], hipIpcMemLazyEnablePeerAccess));
+      P->ipc_mapped[which][k] = ptr[k];
+    }
+    P->peer_msg[which] = (double *)ptr[0]; P->peer_done[which] = (int32_t *)ptr[1]; P->peer_x[which] = (int32_t *)ptr[2];
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+int stereo_trws_plan_debug_flags(stereo_trws_plan *P, int32_t *done, int32_t *ctl) {
+  if (!P) return 1;
+  if (done && hipMemcpy(done, P->d_done.p, sizeof(int32_t) * P->N, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  if (ctl && hipMemcpy(ctl, P->d_ctl.p, sizeof(int32_t) * 2, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  return 0;
+}
+
+int stereo_trws_plan_strip_info(stereo_trws_plan *P, int *nstrips, int *strip, int64_t *own_nodes, int64_t *runs_forward,
+                                int64_t *runs_backward, int *needs_previous, int *needs_next) {
+  if (!P) return 1;
+  if (nstrips) *nstrips = P->nstrips;
+  if (strip) *strip = P->strip;
+  if (own_nodes) *own_nodes = P->n_en;
+  if (runs_forward) *runs_forward = P->nstrips > 1 ? P->ntickets[0] : (int64_t)P->graph->sweep[0].chain_run_ptr.size() - 1;
+  if (runs_backward) *runs_backward = P->nstrips > 1 ? P->ntickets[1] : (int64_t)P->graph->sweep[1].chain_run_ptr.size() - 1;
+  if (needs_previous) *needs_previous = P->need_peer[0] ? 1 : 0;
+  if (needs_next) *needs_next = P->need_peer[1] ? 1 : 0;
+  return 0;
 }
 
 int stereo_trws_plan_result(stereo_trws_plan *P, double *labelling, double *energy,

@@ -57,12 +57,22 @@ class Boundary {
 
 #define TICK(name) do { if (std::getenv("STEREO_HIP_GRAPH_VERBOSE")) { auto now_ = std::chrono::steady_clock::now(); std::fprintf(stderr, "[graph] -> %s: %.1f ms\n", name, std::chrono::duration<double, std::milli>(now_ - tick_).count()); tick_ = now_; } } while (0)
 bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
-                      std::string &err, int64_t max_resident_runs) {
+                      std::string &err, int64_t max_resident_runs, const int32_t *owner_in, int nstrips,
+                      int64_t certainly_resident) {
   auto tick_ = std::chrono::steady_clock::now();
   if (N <= 0 || E < 0) { err = "build_trws_graph: empty problem"; return false; }
   if (N >= INT32_MAX || E >= INT32_MAX) { err = "build_trws_graph: more than 2^31 nodes/edges"; return false; }
   g = TrwsGraph();
   g.N = N; g.E = E;
+  if (nstrips < 1) { err = "build_trws_graph: nstrips must be >= 1"; return false; }
+  if (nstrips > 1 && !owner_in) { err = "build_trws_graph: strips need an owner per node"; return false; }
+  g.nstrips = nstrips;
+  if (nstrips > 1) {
+    g.owner.assign(owner_in, owner_in + N);
+    for (int64_t i = 0; i < N; ++i)
+      if (g.owner[i] < 0 || g.owner[i] >= nstrips) { err = "build_trws_graph: owner out of range"; return false; }
+  }
+  const int32_t *own = nstrips > 1 ? g.owner.data() : nullptr;  // per node
   g.tail.resize(E); g.head.resize(E); g.mdir.assign(E, 0);
   std::vector<int32_t> firstF(N, -1), firstB(N, -1), nextF(E), nextB(E);
   std::vector<int32_t> deg(N, 0);
@@ -71,6 +81,7 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
     uint32_t a = conn[2 * e], b = conn[2 * e + 1];
     if (a >= (uint64_t)N || b >= (uint64_t)N) { err = "connectivity index out of range"; return false; }
     if (a == b) { err = "self loops are not supported"; return false; }
+    if (own && std::abs(own[a] - own[b]) > 1) { err = "strips must form a chain: an edge joins strips that are not neighbours"; return false; }
     g.tail[e] = (int32_t)a; g.head[e] = (int32_t)b;
     nextF[e] = firstF[a]; firstF[a] = (int32_t)e;
     nextB[e] = firstB[b]; firstB[b] = (int32_t)e;
@@ -168,12 +179,16 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
     for (int64_t r = 0; r < N; ++r) g.level_ranks[fill[level[r]]++] = (int32_t)r;
   }
   g.lb_pos_node.resize(N); g.lb_pos_edge.assign(E, -1);
-  int64_t pos = 0;
+  g.strip_lb_terms.assign(nstrips, 0); g.strip_nodes.assign(nstrips, 0); g.e_pos.resize(N);
   for (int64_t r = N - 1; r >= 0; --r) {
+    int64_t &pos = g.strip_lb_terms[own ? own[g.order[r]] : 0];  // the node that computes a term owns it
     g.lb_pos_node[r] = (int32_t)pos++;
     for (int32_t k = g.bptr[r]; k < g.bptr[r + 1]; ++k) g.lb_pos_edge[g.bidx[k]] = (int32_t)pos++;
   }
-  g.lb_terms = pos;
+  for (int64_t r = 0; r < N; ++r) g.e_pos[r] = (int32_t)g.strip_nodes[own ? own[g.order[r]] : 0]++;
+  g.lb_terms = 0;
+  for (int64_t v : g.strip_lb_terms) g.lb_terms = std::max(g.lb_terms, v);
+  if (nstrips == 1) g.lb_terms = g.strip_lb_terms[0];
   TICK("3");
   // ---- persistent sweep schedules
   // cut == false: a run ends only where the node does not hang on one of the two previous
@@ -203,7 +218,8 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
       int32_t lv = 0;
       for (int32_t k = iptr[r]; k < iptr[r + 1]; ++k) {
         const int32_t other = g.rank[d == 0 ? g.tail[iidx[k]] : g.head[iidx[k]]];
-        if ((p - 1 >= run_start && other == near1) || (p - 2 >= run_start && other == near2)) chained = true;
+        if (((p - 1 >= run_start && other == near1) || (p - 2 >= run_start && other == near2)) &&
+            (!own || own[g.order[other]] == own[g.order[r]])) chained = true;
         lv = std::max(lv, lev[other] + 1);
       }
       lev[r] = lv;
@@ -215,6 +231,7 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
         int dist = 0;
         if (p - 1 >= run_start && other == near1) dist = 1;
         else if (p - 2 >= run_start && other == near2) dist = 2;
+        if (own && own[g.order[other]] != own[g.order[r]]) dist = 0;
         if (dist) {
           // slot of the edge in that node's outgoing list; in_slot = slot + 8 * (dist - 1)
           for (int32_t w = optr[other]; w < optr[other + 1] && w - optr[other] < TrwsGraph::kMaxSlots; ++w)
@@ -265,6 +282,14 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
       if (!ok) build_runs(d, false);
     }
   }
+  for (int d = 0; d < 2 && own; ++d) {
+    TrwsGraph::Sweep &S = g.sweep[d];
+    S.run_strip.clear();
+    for (size_t k = 0; k + 1 < S.run_ptr.size(); ++k) {
+      const int64_t p = S.run_ptr[k];
+      S.run_strip.push_back(own[g.order[d == 0 ? p : N - 1 - p]]);
+    }
+  }
   TICK("4");
   // ---- descriptors of the fast kernel (layout: trws.hip NodeDesc)
   g.fast_ok = true;
@@ -297,6 +322,7 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
           lv = std::max(lv, lev[o] + 1);
           const int64_t back = p - position(o);
           if ((back != 1 && back != 2) || run_tail[run_of[o]] != o) continue;
+          if (own && own[g.order[o]] != own[g.order[r]]) continue;  // a run stays inside one strip
           if (best < 0 || position(o) < position(best)) best = o;
         }
         lev[r] = lv;
@@ -350,8 +376,7 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
       };
       // (checked whenever there are more runs than CUs: one workgroup per CU is all that is certain
       // to be resident, whatever max_resident_runs the caller derived from its kernel's LDS use)
-      constexpr int64_t kCertainlyResident = 256;
-      const int64_t resident = max_resident_runs > 0 ? std::min(max_resident_runs, kCertainlyResident) : 0;
+      const int64_t resident = max_resident_runs > 0 ? std::min(max_resident_runs, std::max<int64_t>(certainly_resident, 1)) : 0;
       if (ok && resident > 0 && R > resident && !look_ahead_ok()) {
         if (cut) {  // try creation order before giving up
           for (int64_t k = 0; k < R; ++k) order[k] = (int32_t)k;
@@ -415,6 +440,20 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
         D[2] = (int32_t)((uint32_t)nout | ((uint32_t)nin << 4) | ((uint32_t)nd << 8) | (md << 16));
         D[3] = g.lb_pos_node[r];
         for (int k = 0; k < 4; ++k) D[20 + k] = k < nd ? deps[r][k] : 0;
+        // strips: which outgoing messages (and whose copy of the flag / label) live in a neighbour's memory
+        uint32_t remote = 0;
+        if (own) {
+          const int32_t mine = own[g.order[r]];
+          for (int k = 0; k < nout && k < 8; ++k) {
+            const int32_t e = oidx[optr[r] + k];
+            const int32_t theirs = own[d == 0 ? g.head[e] : g.tail[e]];
+            if (theirs == mine) continue;
+            remote |= 1u << k;
+            if (theirs > mine) remote |= (1u << (8 + k)) | (1u << 17); else remote |= 1u << 16;
+          }
+        }
+        D[kDescRemote] = (int32_t)remote;
+        D[kDescEpos] = g.e_pos[r];
         // slots once more, one byte each (0xff = none), for the compute waves: words 41, 42
         uint32_t pk[2] = {0, 0};
         for (int k = 0; k < 8; ++k) pk[k >> 2] |= (uint32_t)(uint8_t)(int8_t)D[12 + k] << (8 * (k & 3));
@@ -436,6 +475,9 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
         }
       for (int64_t k = 0; k < RR; ++k)
         for (int64_t p = S.chain_run_ptr[k]; p < S.chain_run_ptr[k + 1]; ++p) S.desc[(size_t)p * W + 40] = eager[k];
+      S.chain_run_strip.clear();
+      if (own)
+        for (int64_t k = 0; k < RR; ++k) S.chain_run_strip.push_back(own[g.order[S.chain_rank[S.chain_run_ptr[k]]]]);
     };
     std::thread backward([&] { build_direction(1); });
     build_direction(0);
@@ -478,16 +520,17 @@ extern "C" int stereo_trws_analyze(int64_t N, int64_t E, const uint32_t *conn, i
   return 0;
 }
 
-extern "C" int stereo_trws_schedule(int64_t N, int64_t E, const uint32_t *conn, int64_t max_resident_runs,
-                                    int direction, int64_t *rank_at, int64_t *run_ptr, int64_t *nruns,
-                                    int64_t *ticket_run, int64_t *pred_rank, int64_t *dep_ptr,
-                                    int64_t *dep_rank, char *err, size_t errcap) {
+static int schedule_impl(int64_t N, int64_t E, const uint32_t *conn, int64_t max_resident_runs,
+                         int direction, const int32_t *owner, int nstrips, int64_t *rank_at, int64_t *run_ptr,
+                         int64_t *nruns, int64_t *ticket_run, int64_t *pred_rank, int64_t *dep_ptr,
+                         int64_t *dep_rank, int64_t *run_strip, int64_t *remote, const char *who, char *err,
+                         size_t errcap) {
   stereo::TrwsGraph g;
   std::string gerr;
-  if (!conn && E > 0) return stereo::fail("stereo_trws_schedule: NULL connectivity", err, errcap);
-  if (direction != 0 && direction != 1) return stereo::fail("stereo_trws_schedule: direction must be 0 or 1", err, errcap);
-  if (!stereo::build_trws_graph(N, E, conn, g, gerr, max_resident_runs)) return stereo::fail(gerr, err, errcap);
-  if (!g.fast_ok) return stereo::fail("stereo_trws_schedule: graph not eligible for the descriptor-driven kernels", err, errcap);
+  if (!conn && E > 0) return stereo::fail(std::string(who) + ": NULL connectivity", err, errcap);
+  if (direction != 0 && direction != 1) return stereo::fail(std::string(who) + ": direction must be 0 or 1", err, errcap);
+  if (!stereo::build_trws_graph(N, E, conn, g, gerr, max_resident_runs, owner, nstrips)) return stereo::fail(gerr, err, errcap);
+  if (!g.fast_ok) return stereo::fail(std::string(who) + ": graph not eligible for the descriptor-driven kernels", err, errcap);
   const stereo::TrwsGraph::Sweep &S = g.sweep[direction];
   constexpr int W = stereo::TrwsGraph::kDescWords;
   const int64_t R = (int64_t)S.chain_run_ptr.size() - 1;
@@ -495,6 +538,7 @@ extern "C" int stereo_trws_schedule(int64_t N, int64_t E, const uint32_t *conn, 
   for (int64_t p = 0; p < N; ++p) if (rank_at) rank_at[p] = S.chain_rank[p];
   for (int64_t k = 0; k <= R; ++k) if (run_ptr) run_ptr[k] = S.chain_run_ptr[k];
   for (int64_t t = 0; t < R; ++t) if (ticket_run) ticket_run[t] = S.chain_run_order.empty() ? t : S.chain_run_order[t];
+  for (int64_t k = 0; k < R; ++k) if (run_strip) run_strip[k] = S.chain_run_strip.empty() ? 0 : S.chain_run_strip[k];
   // predecessor and dependencies as the kernels see them: from the descriptors
   int64_t dp = 0;
   std::vector<int64_t> pos_of(N);
@@ -506,9 +550,28 @@ extern "C" int stereo_trws_schedule(int64_t N, int64_t E, const uint32_t *conn, 
     for (int k = nout; k < nout + nin; ++k)
       if (D[12 + k] >= 0 && D[12 + k] < 8) pr = g.rank[D[32 + k]];
     if (pred_rank) pred_rank[r] = pr;
+    if (remote) remote[r] = (uint32_t)D[stereo::kDescRemote];
     if (dep_ptr) dep_ptr[r] = dp;
     for (int k = 0; k < nd; ++k, ++dp) if (dep_rank) dep_rank[dp] = D[20 + k];
   }
   if (dep_ptr) dep_ptr[N] = dp;
   return 0;
+}
+
+extern "C" int stereo_trws_schedule(int64_t N, int64_t E, const uint32_t *conn, int64_t max_resident_runs,
+                                    int direction, int64_t *rank_at, int64_t *run_ptr, int64_t *nruns,
+                                    int64_t *ticket_run, int64_t *pred_rank, int64_t *dep_ptr,
+                                    int64_t *dep_rank, char *err, size_t errcap) {
+  return schedule_impl(N, E, conn, max_resident_runs, direction, nullptr, 1, rank_at, run_ptr, nruns, ticket_run,
+                       pred_rank, dep_ptr, dep_rank, nullptr, nullptr, "stereo_trws_schedule", err, errcap);
+}
+
+extern "C" int stereo_trws_schedule_strips(int64_t N, int64_t E, const uint32_t *conn, int64_t max_resident_runs,
+                                           int direction, const int32_t *owner, int nstrips, int64_t *rank_at,
+                                           int64_t *run_ptr, int64_t *nruns, int64_t *ticket_run,
+                                           int64_t *pred_rank, int64_t *dep_ptr, int64_t *dep_rank,
+                                           int64_t *run_strip, int64_t *remote, char *err, size_t errcap) {
+  if (nstrips > 1 && !owner) return stereo::fail("stereo_trws_schedule_strips: NULL owner", err, errcap);
+  return schedule_impl(N, E, conn, max_resident_runs, direction, owner, nstrips, rank_at, run_ptr, nruns, ticket_run,
+                       pred_rank, dep_ptr, dep_rank, run_strip, remote, "stereo_trws_schedule_strips", err, errcap);
 }

@@ -35,6 +35,18 @@ struct TrwsGraph {
   std::vector<int32_t> lb_pos_edge;  // per edge
   int64_t lb_terms = 0;
 
+  // Row strips (multi-GPU): owner[node] = strip that visits the node; empty = one strip.  Strips
+  // form a chain: every edge joins nodes of the same strip or of strips g, g+1.  With strips the
+  // positions above are STRIP-LOCAL (every strip sums its own terms, in the reference's order
+  // restricted to its nodes; the partial sums are combined in strip order), runs never cross a
+  // strip boundary, and the descriptors say which outgoing messages / flags / labels go to the
+  // neighbouring strip's memory.
+  std::vector<int32_t> owner;            // per NODE
+  int nstrips = 1;
+  std::vector<int64_t> strip_lb_terms;   // per strip
+  std::vector<int64_t> strip_nodes;      // per strip
+  std::vector<int32_t> e_pos;            // per rank: position of the node's energy term in its strip
+
   // Schedule of the persistent dataflow sweeps.  Processing position p is rank p
   // in the forward sweep and rank N-1-p in the backward sweep.  A "run" is a
   // maximal stretch of consecutive positions in which every node has its
@@ -61,6 +73,8 @@ struct TrwsGraph {
     // schedule position to the rank visited there; chain_run_ptr / chain_run_order are the
     // counterparts of run_ptr / run_order over schedule positions.
     std::vector<int32_t> chain_rank, chain_run_ptr, chain_run_order;
+    // strip that owns each run of the rank-contiguous / chain schedule (empty with one strip)
+    std::vector<int32_t> run_strip, chain_run_strip;
   } sweep[2];
   static constexpr int kDescWords = 64;
   // every node has <= 8 incident edges and <= 4 foreign dependencies per direction
@@ -72,7 +86,17 @@ struct TrwsGraph {
 // Returns false and sets `err` on invalid input.
 // max_resident_runs > 0: if a sweep has more runs than that, cut runs in front of nodes that
 // wait long for a foreign node and dispense them in dependency-level order (see trws_graph.cpp).
+// owner (N entries, values 0 .. nstrips-1) or nullptr: see TrwsGraph::owner.
+// certainly_resident: workgroups sure to be resident whatever the kernel's LDS use (the CU count).
 bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
-                      std::string &err, int64_t max_resident_runs = 0);
+                      std::string &err, int64_t max_resident_runs = 0,
+                      const int32_t *owner = nullptr, int nstrips = 1, int64_t certainly_resident = 256);
+
+// Descriptor words added for strips (layout of the rest: trws.hip NodeDesc)
+//   word 43: bits 0-7 outgoing message k goes to the neighbouring strip; bits 8-15 which one
+//            (0 = previous strip, 1 = next strip); bit 16 / 17: flag (+ label) also raised in the
+//            previous / next strip's memory
+//   word 44: TrwsGraph::e_pos of the node
+constexpr int kDescRemote = 43, kDescEpos = 44;
 
 }  // namespace stereo

@@ -1,0 +1,157 @@
+"""-m gpu: row-strip TRW-S (the multi-GPU decomposition) as LOGICAL strips on one GPU.
+
+G plans, one per band of rows, run concurrently on one device and hand boundary messages, flags
+and labels to each other exactly as they would across GPUs (the same stores, aimed at the
+neighbour plan's arrays).  Bar: labels bit-identical to the single plan AND to the oracle;
+energy / lower bound are per-strip partial sums added in strip order, so they agree to rounding
+(1e-12 relative, stated in include/stereo_hip.h), and exactly when there is one strip."""
+import numpy as np
+import pytest
+
+from helpers import trws_problem
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-12
+
+
+def _close(a, b):
+    return abs(a - b) <= REL * max(abs(a), abs(b), 1.0)
+
+
+def _run_strips(p, kernel, K, H, W, G, tol, iters, shared_pos=None, wg=None):
+    from stereo_amd.strips import make_strips
+    s = make_strips(kernel, K, H, W, p["conn"].T, G, workgroups_per_strip=wg)
+    if shared_pos is not None:
+        s.upload(p["unary"].T, p["alphas"], tol, positions=shared_pos)
+    else:
+        s.upload(p["unary"].T, p["alphas"], tol, q=p["q"].T, qprim=p["qprim"].T)
+    done, _ = s.iterate(iters, max_relgap=-1e300)
+    assert done == iters
+    r = s.result()
+    path = s.path()
+    infos = [pl.info() for pl in s.plans]
+    s.close()
+    return r, path, infos
+
+
+CASES = [
+    # seed, H, W, K, kernel, kind, integer, tol, iters
+    (101, 60, 70, 16, 1, "general", False, 3.0, 4),   # pipelined kernel, per-edge positions
+    (102, 24, 31, 12, 2, "general", False, 4.0, 4),   # quadratic kernel
+    (103, 18, 22, 9, 1, "general", True, 2.0, 5),     # integer costs: exact ties, serial envelopes
+    (104, 30, 26, 40, 1, "fronto", False, 5.0, 4),    # shared positions, windowed min-plus
+    (105, 9, 40, 8, 1, "general", False, 2.0, 4),     # strips of 2-3 rows
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(c[0]) for c in CASES])
+@pytest.mark.parametrize("G", [2, 4])
+def test_logical_strips_match_single_plan_and_oracle(case, G, hip, oracle):
+    from stereo_amd.trws import TrwsPlan
+    seed, H, W, K, kernel, kind, integer, tol, iters = case
+    p = trws_problem(seed, H, W, K, kind=kind, integer=integer)
+    lab_o, en_o, lb_o, it_o = oracle.trws(kernel, p["unary"], p["conn"], p["q"], p["qprim"], p["alphas"], tol,
+                                          iters, -1e300, mode=1)
+    pos = np.arange(K, dtype=np.float64) if kind == "fronto" else None
+    one = TrwsPlan(kernel, K, H * W, p["conn"].T)
+    if pos is not None:
+        one.upload(p["unary"].T, p["alphas"], tol, positions=pos)
+    else:
+        one.upload(p["unary"].T, p["alphas"], tol, q=p["q"].T, qprim=p["qprim"].T)
+    one.iterate(iters, max_relgap=-1e300)
+    lab1, en1, lb1, _ = one.result()
+    assert np.array_equal(lab1, lab_o) and en1 == en_o and lb1 == lb_o
+    (lab, en, lb, it), path, infos = _run_strips(p, kernel, K, H, W, G, tol, iters, shared_pos=pos)
+    assert path == one.path()
+    assert it == it_o
+    assert sum(i["own_nodes"] for i in infos) == H * W
+    assert np.array_equal(lab, lab_o), "labels differ at %d nodes" % int((lab != lab_o).sum())
+    assert _close(en, en_o) and _close(lb, lb_o), (en, en_o, lb, lb_o)
+
+
+def test_one_strip_is_the_single_plan(hip, oracle):
+    """nstrips = 1 through the strip entry points: the same bits as the plain plan, sums included."""
+    p = trws_problem(106, 14, 15, 10, kind="general")
+    lab_o, en_o, lb_o, _ = oracle.trws(1, p["unary"], p["conn"], p["q"], p["qprim"], p["alphas"], 2.0, 4, -1e300, mode=1)
+    (lab, en, lb, _), _, _ = _run_strips(p, 1, 10, 14, 15, 1, 2.0, 4)
+    assert np.array_equal(lab, lab_o) and en == en_o and lb == lb_o
+
+
+@pytest.mark.parametrize("G", [2, 4])
+def test_wide_kernel_strips_k256(G, hip, oracle):
+    """K = 256 on the wide-label kernel (the 3000 x 2000 x 256 configuration's kernel): strips vs
+    the oracle on a grid the oracle finishes in seconds, and vs the single plan on a larger one."""
+    from stereo_amd.trws import TrwsPlan
+    K = 256
+    pos = np.arange(K, dtype=np.float64)
+    H, W = 12, 14
+    p = trws_problem(107, H, W, K, kind="fronto")
+    lab_o, en_o, lb_o, _ = oracle.trws(1, p["unary"], p["conn"], p["q"], p["qprim"], p["alphas"], 8.0, 2, -1e300, mode=1)
+    (lab, en, lb, _), path, _ = _run_strips(p, 1, K, H, W, G, 8.0, 2, shared_pos=pos)
+    assert path == 3
+    assert np.array_equal(lab, lab_o) and _close(en, en_o) and _close(lb, lb_o)
+    H, W = 64, 72
+    p = trws_problem(108, H, W, K, kind="fronto")
+    one = TrwsPlan(1, K, H * W, p["conn"].T)
+    one.upload(p["unary"].T, p["alphas"], 8.0, positions=pos)
+    one.iterate(3, max_relgap=-1e300)
+    lab1, en1, lb1, _ = one.result()
+    (lab, en, lb, _), path, _ = _run_strips(p, 1, K, H, W, G, 8.0, 3, shared_pos=pos)
+    assert path == 3
+    assert np.array_equal(lab, lab1) and _close(en, en1) and _close(lb, lb1)
+
+
+def test_strips_with_fewer_workgroups_than_runs(hip, oracle):
+    """Each strip has more rows than workgroups: runs wait for tickets inside a strip while the
+    strips wait for each other across the boundary -- no deadlock, same labels."""
+    H, W, K = 90, 8, 6
+    p = trws_problem(109, H, W, K, kind="fronto")
+    pos = np.arange(K, dtype=np.float64)
+    lab_o, en_o, lb_o, _ = oracle.trws(1, p["unary"], p["conn"], p["q"], p["qprim"], p["alphas"], 2.0, 3, -1e300, mode=1)
+    (lab, en, lb, _), _, infos = _run_strips(p, 1, K, H, W, 3, 2.0, 3, shared_pos=pos, wg=4)
+    assert min(i["runs_forward"] for i in infos) > 4
+    assert np.array_equal(lab, lab_o) and _close(en, en_o) and _close(lb, lb_o)
+
+
+def test_unconnected_strip_refuses_to_iterate(hip):
+    from stereo_amd.strips import _StripPlan, row_strip_owner, _conn_f
+    p = trws_problem(110, 8, 9, 5, kind="general")
+    owner = row_strip_owner(8, 9, 2)
+    pl = _StripPlan(1, 5, 72, _conn_f(p["conn"].T), owner, 2, 0, 0, 0, None)
+    pl.upload(p["unary"].T, p["alphas"], 2.0, q=p["q"].T, qprim=p["qprim"].T)
+    with pytest.raises(hip.StereoHipError, match="not connected"):
+        pl.issue()
+    pl.close()
+
+
+def test_new_inputs_restart_the_minimisation(hip, oracle):
+    """upload() after iterate() implies a reset (the look-ahead forward sweep ran on the old
+    inputs): the second problem's result is the oracle's from-scratch result."""
+    from stereo_amd.trws import TrwsPlan
+    p1 = trws_problem(111, 10, 12, 8, kind="general")
+    p2 = trws_problem(112, 10, 12, 8, kind="general")
+    plan = TrwsPlan(1, 8, 120, p1["conn"].T)
+    plan.upload(p1["unary"].T, p1["alphas"], 2.0, q=p1["q"].T, qprim=p1["qprim"].T)
+    plan.iterate(3, max_relgap=-1e300)
+    plan.upload(p2["unary"].T, p2["alphas"], 2.0, q=p2["q"].T, qprim=p2["qprim"].T)
+    plan.iterate(4, max_relgap=-1e300)
+    lab, en, lb, it = plan.result()
+    lab_o, en_o, lb_o, it_o = oracle.trws(1, p2["unary"], p2["conn"], p2["q"], p2["qprim"], p2["alphas"], 2.0, 4,
+                                          -1e300, mode=1)
+    assert it == it_o and np.array_equal(lab, lab_o) and en == en_o and lb == lb_o
+
+
+@pytest.mark.parametrize("shape", [(40, 46, 16), (30, 24, 256)], ids=["k16", "k256"])
+def test_two_processes_hand_over_through_ipc(shape, hip):
+    """One strip per PROCESS: IPC export / open of the neighbour's arrays, flags across processes,
+    all_gather of the partial sums (tools/strips_ipc_check.py; both ranks share the GPU here)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(root, "tools", "strips_ipc_check.py")] + [str(v) for v in shape]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "IPC_STRIPS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
