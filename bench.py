@@ -83,6 +83,77 @@ def algorithmic_bytes_per_sweep_pair(info_deg, K):
     return float(fwd.sum() + bwd.sum())
 
 
+def scale_leg(args, rank, local_rank, world, dist, dev):
+    """Strong scaling of ONE large image (BASELINE.json configs[3]: synthetic 3000 x 2000 x 256-label
+    volume) over the `world` GPUs: rank g owns band g of the rows (stereo_amd.strips), boundary
+    messages / flags / labels go to the neighbour GPU as peer stores over xGMI, energy and bound are
+    reduced as two doubles per iteration.  At world == 1 it is the plain single-GPU plan, so the N=1
+    figure of a scaling run is the single-GPU figure.  Returns the `scale` object (rank 0) or None."""
+    import torch
+    from stereo_amd import dist as D
+    from stereo_amd.trws import TrwsPlan
+    from stereo_amd.strips import TrwsStripRank, row_strip_owner
+    from helpers import grid_conn
+    H, W, K = args.scale_height, args.scale_width, args.scale_labels
+    N = H * W
+    t_setup = time.perf_counter()
+    conn = grid_conn(H, W)
+    E = conn.shape[0]
+    d_unary = synthetic_volume_device(H, W, K, 1, dev)   # the same volume on every rank (same seed)
+    d_alpha = torch.ones(E, dtype=torch.float64, device=dev)
+    d_pos = torch.arange(K, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    if world == 1:
+        solver = TrwsPlan(1, K, N, conn.T)
+        plan = solver
+    else:
+        solver = TrwsStripRank(1, K, H, W, conn.T, rank, world, dist, dev)
+        plan = solver.plan
+    solver.bind_device(d_unary.data_ptr(), d_alpha.data_ptr(), 8.0, d_positions=d_pos.data_ptr(),
+                       keepalive=(d_unary, d_alpha, d_pos))
+    plan.stats(reset=True)
+    setup_s = time.perf_counter() - t_setup
+    NEVER = -1e300
+    solver.iterate(args.scale_warmup, max_relgap=NEVER)
+    plan.stats(reset=True)
+    plan.serial_messages(reset=True)
+    D.barrier(dist, dev)
+    t0 = time.perf_counter()
+    done, _ = solver.iterate(args.scale_steps, max_relgap=NEVER)
+    assert done == args.scale_steps
+    D.barrier(dist, dev)
+    dt = D.max_over_ranks(dist, time.perf_counter() - t0, dev)
+    sweep_ms, launches = plan.stats()
+    serial = D.sum_over_ranks(dist, plan.serial_messages(), dev)
+    if world == 1:
+        lab, energy, lb, _ = solver.result(want_labels=True)
+        crc = int(np.asarray(lab, dtype=np.int64).sum())
+        own_nodes = N
+    else:
+        idx, lab = solver.own_labels()
+        crc = int(D.sum_over_ranks(dist, float(np.asarray(lab, dtype=np.int64).sum()), dev))
+        energy, lb = solver.energy, solver.lb
+        own_nodes = len(idx)
+    # algorithmic bytes of one sweep launch on THIS rank: 13 K R per interior node (SURVEY 8(d)); the
+    # per-node figure with the real degrees is within 0.1 % of it at this size
+    bytes_launch = 13.0 * K * 8.0 * own_nodes
+    avg_launch_s = (sweep_ms * 1e-3) / max(launches, 1)
+    frac = bytes_launch / avg_launch_s / 1e9 / HBM_PEAK_GBS
+    frac_min = -D.max_over_ranks(dist, -frac, dev)
+    frac_max = D.max_over_ranks(dist, frac, dev)
+    if rank != 0:
+        return None
+    return {"workload": "configs[3]: synthetic %dx%dx%d-label cost volume, TRW-S, kernel 1, tol 8, ONE image tiled "
+                        "into %d row strips" % (W, H, K, world),
+            "n_gpus": world, "scaling": "strong", "value": args.scale_steps / dt, "unit": "iterations/s",
+            "ms_per_iteration": dt / args.scale_steps * 1e3, "steps": args.scale_steps, "warmup": args.scale_warmup,
+            "hbm_frac_per_gpu": [frac_min, frac_max], "sweep_launch_ms_rank0": avg_launch_s * 1e3,
+            "serial_envelope_messages": serial, "energy": energy, "lower_bound": lb, "label_sum": crc,
+            "transport": "none (one GPU)" if world == 1 else "peer stores over xGMI into HIP-IPC-mapped neighbour arrays + flag; "
+                         "RCCL all_gather of 2 doubles per iteration",
+            "setup_s": setup_s}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +165,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--message-mode", choices=["exact", "minplus"], default="exact")
+    ap.add_argument("--no-scale", action="store_true", help="skip the 3000x2000x256 strong-scaling leg")
+    ap.add_argument("--scale-height", type=int, default=2000)
+    ap.add_argument("--scale-width", type=int, default=3000)
+    ap.add_argument("--scale-labels", type=int, default=256)
+    ap.add_argument("--scale-steps", type=int, default=3)
+    ap.add_argument("--scale-warmup", type=int, default=1)
     args = ap.parse_args()
 
     import torch
@@ -234,6 +311,18 @@ def main():
                 out["binary_fusion"] = extra
             except Exception as exc:  # the headline number must not depend on the secondary one
                 out["binary_fusion"] = {"error": str(exc)}
+    # second leg: one large image tiled across all ranks (strong scaling); every rank takes part
+    scale = None
+    if not args.no_scale:
+        del plan, d_unary, d_alpha, d_pos
+        torch.cuda.empty_cache()
+        try:
+            scale = scale_leg(args, rank, local_rank, world, dist, dev)
+        except Exception as exc:  # the headline line must not depend on the scaling leg
+            scale = {"error": "%s: %s" % (type(exc).__name__, exc), "n_gpus": world}
+    if rank == 0:
+        if scale is not None:
+            out["scale"] = scale
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

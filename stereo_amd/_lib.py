@@ -42,7 +42,13 @@ def lib():
         _lib = L
         # one-time runtime initialisation now, not inside the first solver call: it consumes libc
         # rand() values, which QPBO Improve draws its permutation from (see stereo_hip_warm_up)
-        if L.stereo_hip_device_count() > 0:
+        # (on the device this rank will use: torchrun exports LOCAL_RANK, and a warm-up on the default
+        # device would leave a HIP context of every rank on GPU 0)
+        ndev = L.stereo_hip_device_count()
+        if ndev > 0:
+            local = os.environ.get("LOCAL_RANK")
+            if local is not None and local.isdigit() and int(local) < ndev:
+                L.stereo_hip_set_device(int(local))
             L.stereo_hip_warm_up()
     return _lib
 

@@ -986,7 +986,9 @@ struct QpboSolver {
     STEREO_HIP_CHECK(hipMemsetAsync(d_ctl.p, 0, sizeof(int32_t) * QpboCtl::kWords, 0));
     // (device properties and the occupancy of the kernel are asked once per process and device:
     // an Improve pass calls this function hundreds of times)
-    static int cached_dev = -1, cached_cus = 0, cached_per_cu = 0;
+    // (thread local: stereo_hip_set_device selects a device per host thread, and two threads
+    // driving different devices must not see each other's half-written entries)
+    static thread_local int cached_dev = -1, cached_cus = 0, cached_per_cu = 0;
     int dev = 0;
     STEREO_HIP_CHECK(hipGetDevice(&dev));
     if (dev != cached_dev) {

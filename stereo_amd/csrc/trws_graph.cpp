@@ -302,6 +302,8 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
     constexpr int W = TrwsGraph::kDescWords;
     // the two sweep directions are independent of each other: one host thread each
     auto build_direction = [&](int d) {
+      auto tick_ = std::chrono::steady_clock::now();
+#define DTICK(name) do { if (d == 0) TICK(name); } while (0)
       TrwsGraph::Sweep &S = g.sweep[d];
       const std::vector<int32_t> &iptr = d == 0 ? g.bptr : g.fptr, &iidx = d == 0 ? g.bidx : g.fidx;
       const std::vector<int32_t> &optr = d == 0 ? g.fptr : g.bptr, &oidx = d == 0 ? g.fidx : g.bidx;
@@ -334,6 +336,7 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
         }
       }
       const int64_t R = (int64_t)run_head.size();
+      DTICK("dir0 chain schedule");
       // foreign dependencies per rank (everything but the predecessor in the run)
       struct Deps {  // at most kMaxSlots incoming edges per node in this branch (fast_ok)
         int32_t v[TrwsGraph::kMaxSlots]; int32_t n = 0;
@@ -353,6 +356,7 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
         }
         ok = deps[r].size() <= 4;
       }
+      DTICK("dir0 dependencies");
       // ticket order.  Runs are numbered by the position of their first node; a dependency can
       // then live in a run with a LARGER number (the two interleaved rows need each other).  That
       // is harmless while every run has its own resident workgroup.  With fewer workgroups than
@@ -408,9 +412,12 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
             if (p - 2 >= S.chain_run_ptr[k]) pred2[S.chain_rank[p]] = S.chain_rank[p - 2];
           }
       }
-      // ---- descriptors, in schedule order
+      DTICK("dir0 tickets");
+      // ---- descriptors, in schedule order (every position is independent of the others: host threads)
       S.desc.assign((size_t)N * W, 0);
-      for (int64_t p = 0; p < N; ++p) {
+      DTICK("dir0 descriptor allocation");
+      auto describe = [&](int64_t pa, int64_t pb) {
+      for (int64_t p = pa; p < pb; ++p) {
         const int32_t r = S.chain_rank[p];
         int32_t *D = &S.desc[(size_t)p * W];
         const int nout = optr[r + 1] - optr[r], nin = iptr[r + 1] - iptr[r];
@@ -459,6 +466,16 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
         for (int k = 0; k < 8; ++k) pk[k >> 2] |= (uint32_t)(uint8_t)(int8_t)D[12 + k] << (8 * (k & 3));
         D[41] = (int32_t)pk[0]; D[42] = (int32_t)pk[1];
       }
+      };
+      {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const int64_t T = std::max<int64_t>(1, std::min<int64_t>({(int64_t)hw / 2, 32, N / 4096 + 1}));
+        std::vector<std::thread> pool;
+        for (int64_t t = 1; t < T; ++t) pool.emplace_back(describe, N * t / T, N * (t + 1) / T);
+        describe(0, N / T);
+        for (auto &th : pool) th.join();
+      }
+      DTICK("dir0 descriptors");
       // Completion flags are raised either in the middle of the next visit (costs a store
       // drain on that run's critical path, but the dependent run can follow closely) or
       // lazily at its end (free).  A run is "lazy" if nobody else reads its flags before it
@@ -479,6 +496,7 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
       if (own)
         for (int64_t k = 0; k < RR; ++k) S.chain_run_strip.push_back(own[g.order[S.chain_rank[S.chain_run_ptr[k]]]]);
     };
+#undef DTICK
     std::thread backward([&] { build_direction(1); });
     build_direction(0);
     backward.join();

@@ -343,7 +343,10 @@ class dispmap_globalstereo(dispmap_super):
         if np.max(np.abs(P[:, :, 0].T.reshape(-1)[[0, 1, 2, 3, 4, 5, 8]] - np.array([1, 0, 0, 0, 1, 0, 1.0]))) > 1e-12:
             raise StereoHipError("First image must be reference image")
         self.P2 = np.asfortranarray(P[:, :, 1].T)          # self.P = permute(P, [2 1 3]); a = 2
-        disps = np.arange(disp_range[0] * disparity_factor, disp_range[1] * disparity_factor + 1)[::-1]
+        # MATLAB colon lo*f : hi*f (dispmap_globalstereo.m:48): lo*f + (0 : floor(hi*f - lo*f)), also
+        # for a fractional span (np.arange(lo*f, hi*f + 1) would append one element then)
+        lo_f, hi_f = disp_range[0] * disparity_factor, disp_range[1] * disparity_factor
+        disps = (lo_f + np.arange(np.floor(hi_f - lo_f + 1e-10) + 1))[::-1]
         self.d_min = float(disps[-1])
         self.d_step = float(disps[0] - self.d_min)
         self._tol = opt["disp_thresh"]

@@ -346,3 +346,112 @@ def schedule_strips(N, connectivity0, direction, owner, nstrips, max_resident_ru
     R = nruns.value
     return dict(rank_at=rank_at, run_ptr=run_ptr[:R + 1], ticket_run=ticket_run[:R], pred_rank=pred,
                 dep_ptr=dep_ptr, dep_rank=dep_rank[:dep_ptr[N]], run_strip=run_strip[:R], remote=remote)
+
+
+def dataflow_reference(sched, analysis_in):
+    """Serial model of one sweep: value[r] = mix(r, values of every incoming neighbour), in the
+    order of the schedule positions.  `analysis_in[r]` = ranks of the incoming neighbours of rank r
+    in this sweep direction.  What a strip-parallel execution must reproduce."""
+    N = len(sched["rank_at"])
+    val = np.zeros(N, dtype=np.uint64)
+    done = np.zeros(N, dtype=bool)
+    # any topological order gives the same values; use dependency order via repeated passes over runs
+    order = _topological(sched, analysis_in)
+    for r in order:
+        val[r] = _mix(r, [val[x] for x in analysis_in[r]])
+        done[r] = True
+    return val
+
+
+def _mix(r, vals):
+    M = (1 << 61) - 1
+    acc = (int(r) * 2654435761 + 12345) % M
+    for v in vals:
+        acc = (acc * 1000003 + int(v)) % M
+    return np.uint64(acc)
+
+
+def _topological(sched, incoming):
+    N = len(sched["rank_at"])
+    indeg = np.array([len(incoming[r]) for r in range(N)])
+    out = [[] for _ in range(N)]
+    for r in range(N):
+        for x in incoming[r]:
+            out[int(x)].append(r)
+    stack = [r for r in range(N) if indeg[r] == 0]
+    order = []
+    while stack:
+        r = stack.pop()
+        order.append(r)
+        for y in out[r]:
+            indeg[y] -= 1
+            if indeg[y] == 0:
+                stack.append(y)
+    if len(order) != N:
+        raise StereoHipError("dependency cycle")
+    return order
+
+
+def simulate_strip(sched, strip, incoming, send, recv, workgroups=4):
+    """Host-side model of ONE strip's sweep launch, with the hand-off protocol of the kernels:
+    `workgroups` resident workgroups draw this strip's runs in ticket order and walk them node by
+    node; a node waits for the flags of its foreign dependencies (`dep_rank`) -- those of another
+    strip arrive through `recv()` -> (rank, value), blocking; after a visit whose descriptor has
+    the notify bit of a neighbour set, `send(neighbour_strip, rank, value)` is called (message
+    first, flag last: here one packet).  Values follow dataflow_reference, taking the predecessor
+    in the run from the 'LDS hand-over' and everything else from flags.  Returns {rank: value} of
+    the strip's nodes; raises if the strip cannot make progress although nothing is in flight."""
+    rank_at, run_ptr, ticket_run = sched["rank_at"], sched["run_ptr"], sched["ticket_run"]
+    dep_ptr, dep_rank, run_strip, remote = sched["dep_ptr"], sched["dep_rank"], sched["run_strip"], sched["remote"]
+    mine = [int(k) for k in ticket_run if run_strip[int(k)] == strip]
+    owner_of_rank = {}
+    for k in range(len(run_strip)):
+        for p in range(int(run_ptr[k]), int(run_ptr[k + 1])):
+            owner_of_rank[int(rank_at[p])] = int(run_strip[k])
+    val = {}            # every value this strip knows (own visits + received)
+    flag = set()        # ranks whose completion flag is visible here
+    expected = set()    # foreign ranks of other strips this strip waits for
+    for k in mine:
+        for p in range(int(run_ptr[k]), int(run_ptr[k + 1])):
+            r = int(rank_at[p])
+            for x in dep_rank[dep_ptr[r]:dep_ptr[r + 1]]:
+                if owner_of_rank[int(x)] != strip:
+                    expected.add(int(x))
+    held, nxt, cur = [], 0, {}
+    result = {}
+    while True:
+        while len(held) < workgroups and nxt < len(mine):
+            k = mine[nxt]; nxt += 1
+            held.append(k); cur[k] = int(run_ptr[k])
+        if not held:
+            break
+        progressed = False
+        for k in list(held):
+            while cur[k] < run_ptr[k + 1]:
+                r = int(rank_at[cur[k]])
+                deps = [int(x) for x in dep_rank[dep_ptr[r]:dep_ptr[r + 1]]]
+                if any(x not in flag for x in deps):
+                    break
+                pred = int(rank_at[cur[k] - 1]) if cur[k] > run_ptr[k] else None
+                for x in incoming[r]:      # everything a visit reads must be here by now
+                    if int(x) not in val:
+                        raise StereoHipError("rank %d visited before the message of rank %d arrived "
+                                             "(pred %s, deps %s)" % (r, int(x), pred, deps))
+                v = _mix(r, [val[int(x)] for x in incoming[r]])
+                val[r] = v; result[r] = v; flag.add(r)
+                rem = int(remote[r])
+                if rem & (1 << 16):
+                    send(strip - 1, r, v)
+                if rem & (1 << 17):
+                    send(strip + 1, r, v)
+                cur[k] += 1
+                progressed = True
+            if cur[k] >= run_ptr[k + 1]:
+                held.remove(k)
+        if progressed:
+            continue
+        if not (expected - flag):
+            raise StereoHipError("strip %d is stuck with nothing left to receive" % strip)
+        r, v = recv()
+        val[int(r)] = v; flag.add(int(r))
+    return result

@@ -94,3 +94,19 @@ def glass_problem(seed, H, W, field=3.0, integer=True):
         J, U1 = np.round(J * 2), np.round(U1 * 2)
     z = np.zeros(E)
     return dict(U0=np.zeros(N), U1=U1, E00=z.copy(), E01=J.copy(), E10=J.copy(), E11=z.copy(), conn=conn)
+
+
+def piecewise_planar(H, W, cell, rng, d_lo, d_hi, slant=0.3):
+    """One proposal, 4 x N (pixel id = col * H + row): a random plane [a b 1 -d] per cell x cell
+    block, disparity d0 in [d_lo, d_hi) at the block centre (the build's deterministic stand-in for
+    the reference's SegPln proposals, dispmap_globalstereo.m:60-201, which need its segmenters)."""
+    rows, cols = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    by, bx = rows // cell, cols // cell
+    nb = (by.max() + 1, bx.max() + 1)
+    a = rng.normal(0, slant, nb)[by, bx]
+    b = rng.normal(0, slant, nb)[by, bx]
+    d0 = rng.uniform(d_lo, d_hi, nb)[by, bx]
+    cx, cy = (bx + 0.5) * cell, (by + 0.5) * cell
+    p4 = -(d0 + a * cx + b * cy)
+    planes = np.stack([a, b, np.ones_like(a), p4])                     # 4 x H x W
+    return np.asfortranarray(planes.transpose(0, 2, 1).reshape(4, H * W))
