@@ -97,8 +97,9 @@ struct DevParams {
   // completion flag and the label of a boundary node -- straight into THEIR arrays (same index
   // space on every strip; over xGMI when the neighbour is another GPU).  [0] previous, [1] next strip.
   int ntickets[2];
-  double *peer_msg[2];
-  int32_t *peer_done[2], *peer_x[2];
+  double *peer_msg0, *peer_msg1;      // (scalars, not arrays: an index computed at run time would put
+  int32_t *peer_done0, *peer_done1;   //  the whole parameter block into scratch memory)
+  int32_t *peer_x0, *peer_x1;
 };
 
 // ---- hand-over accesses (sc0 sc1): data handed between workgroups inside one launch never sits
@@ -1493,7 +1494,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               if (j < pd.nout) {
-                double *mb = ((pd.remote >> j) & 1) ? p.peer_msg[(pd.remote >> (8 + j)) & 1] : p.msg;
+                double *mb = ((pd.remote >> j) & 1) ? (((pd.remote >> (8 + j)) & 1) ? p.peer_msg1 : p.peer_msg0) : p.msg;
                 if (act) st_sc1(mb + (size_t)pd.e[j] * K + lane, hprev[j * kWave + lane]);
                 if (BACKWARD && lane == 0) p.lbterms[pd.lbe[j]] = scp[j];
               }
@@ -1503,15 +1504,15 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           if (PRIMAL && lane == 0) {
             const int xi = ((const int *)(scp + 10))[0];
             st_sc1(p.x + pd.node, xi);
-            if (pd.remote & (1 << 16)) st_sc1(p.peer_x[0] + pd.node, xi);
-            if (pd.remote & (1 << 17)) st_sc1(p.peer_x[1] + pd.node, xi);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_x0 + pd.node, xi);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_x1 + pd.node, xi);
             p.eterms[pd.epos] = scp[9];
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0) {
             st_sc1(p.done + pd.rank, epoch);
-            if (pd.remote & (1 << 16)) st_sc1(p.peer_done[0] + pd.rank, epoch);
-            if (pd.remote & (1 << 17)) st_sc1(p.peer_done[1] + pd.rank, epoch);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_done0 + pd.rank, epoch);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_done1 + pd.rank, epoch);
           }
         }
       } else if (wave == kPipeCompute + 3) {
@@ -1581,7 +1582,8 @@ struct GroupArgs {
 };
 __device__ __forceinline__ int group_strip(const GroupArgs &ga) {
   int s = 0;
-  for (int i = 1; i < ga.n; ++i) s = (int)blockIdx.x >= ga.first[i] ? i : s;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i) s = (i < ga.n && (int)blockIdx.x >= ga.first[i]) ? i : s;  // static indices only
   return s;
 }
 template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
@@ -1894,7 +1896,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, i
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               if (j < pd.nout) {
-                double *mb = ((pd.remote >> j) & 1) ? p.peer_msg[(pd.remote >> (8 + j)) & 1] : p.msg;
+                double *mb = ((pd.remote >> j) & 1) ? (((pd.remote >> (8 + j)) & 1) ? p.peer_msg1 : p.peer_msg0) : p.msg;
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
                   if (act[c]) st_sc1(mb + (size_t)pd.e[j] * K + kk[c], hprev[j * k2W + kk[c]]);
@@ -1906,15 +1908,15 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, i
           if (PRIMAL && lane == 0) {
             const int xi = ((const int *)(scp + 10))[0];
             st_sc1(p.x + pd.node, xi);
-            if (pd.remote & (1 << 16)) st_sc1(p.peer_x[0] + pd.node, xi);
-            if (pd.remote & (1 << 17)) st_sc1(p.peer_x[1] + pd.node, xi);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_x0 + pd.node, xi);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_x1 + pd.node, xi);
             p.eterms[pd.epos] = scp[9];
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0) {
             st_sc1(p.done + pd.rank, epoch);
-            if (pd.remote & (1 << 16)) st_sc1(p.peer_done[0] + pd.rank, epoch);
-            if (pd.remote & (1 << 17)) st_sc1(p.peer_done[1] + pd.rank, epoch);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_done0 + pd.rank, epoch);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_done1 + pd.rank, epoch);
           }
         }
       } else if (wave == kPipeCompute + 3) {
@@ -2557,7 +2559,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               if (j < pd.nout) {
-                double *mb = ((pd.remote >> j) & 1) ? p.peer_msg[(pd.remote >> (8 + j)) & 1] : p.msg;
+                double *mb = ((pd.remote >> j) & 1) ? (((pd.remote >> (8 + j)) & 1) ? p.peer_msg1 : p.peer_msg0) : p.msg;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                   const int k = c * kWave + lane;
@@ -2571,15 +2573,15 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           if (PRIMAL && lane == 0) {
             const int xi = ((const int *)(scp + 10))[0];
             st_sc1(p.x + pd.node, xi);
-            if (pd.remote & (1 << 16)) st_sc1(p.peer_x[0] + pd.node, xi);
-            if (pd.remote & (1 << 17)) st_sc1(p.peer_x[1] + pd.node, xi);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_x0 + pd.node, xi);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_x1 + pd.node, xi);
             p.eterms[pd.epos] = scp[9];
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0) {
             st_sc1(p.done + pd.rank, epoch);
-            if (pd.remote & (1 << 16)) st_sc1(p.peer_done[0] + pd.rank, epoch);
-            if (pd.remote & (1 << 17)) st_sc1(p.peer_done[1] + pd.rank, epoch);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_done0 + pd.rank, epoch);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_done1 + pd.rank, epoch);
           }
         }
       WIDE_VISITS_END
@@ -2820,8 +2822,10 @@ DevParams make_params(stereo_trws_plan *P) {
   for (int d = 0; d < 2; ++d) {
     p.ntickets[d] = P->nstrips > 1 ? P->ntickets[d] : p.nruns[d];
     if (P->nstrips > 1) p.run_order[d] = P->d_tickets[d].p;
-    p.peer_msg[d] = P->peer_msg[d]; p.peer_done[d] = P->peer_done[d]; p.peer_x[d] = P->peer_x[d];
   }
+  p.peer_msg0 = P->peer_msg[0]; p.peer_msg1 = P->peer_msg[1];
+  p.peer_done0 = P->peer_done[0]; p.peer_done1 = P->peer_done[1];
+  p.peer_x0 = P->peer_x[0]; p.peer_x1 = P->peer_x[1];
   p.done = P->d_done.p; p.ticket = P->d_ctl.p; p.abort_flag = P->d_ctl.p + 1; p.N = (int)P->N;
   p.fallbacks = P->d_fallbacks.p; p.certificate = P->certificate ? 1 : 0;
   p.prof = P->d_prof.p;
