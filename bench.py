@@ -1,9 +1,10 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the TRW-S fusion path on MI355X.
 
-Workload at N=1 (BASELINE.json configs[1]): a synthetic Teddy-sized cost volume,
-450 x 375 pixels x 60 fronto-parallel disparity labels (q = qprim = 0..59,
-alphas = 1, tol = 8, kernel 1 -- SURVEY.md 8(d) "Config 2").  A "step" is one
+Workload at N=1 (BASELINE.json configs[1]): the NCC cost volume of a synthetic
+Teddy-sized image pair, 450 x 375 pixels x 60 fronto-parallel disparity labels
+(unary = 40 (1 - ncc), q = qprim = 0..59, alphas = 1, tol = 8, kernel 1 --
+SURVEY.md 8(d) "Config 2").  A "step" is one
 TRW-S iteration (forward sweep, backward sweep with lower bound, primal
 labelling + energy, stop test), exactly what Minimize_TRW_S does per iteration
 (cpp/trw-s/minimize.cpp:31-113).  Inputs are resident in HBM before the timed
@@ -165,6 +166,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--message-mode", choices=["exact", "minplus"], default="exact")
+    ap.add_argument("--volume", choices=["ncc", "noise"], default="ncc",
+                    help="ncc: NCC cost volume of a synthetic image pair (the named workload); noise: planted signal + noise")
     ap.add_argument("--no-scale", action="store_true", help="skip the 3000x2000x256 strong-scaling leg")
     ap.add_argument("--scale-height", type=int, default=2000)
     ap.add_argument("--scale-width", type=int, default=3000)
@@ -190,7 +193,22 @@ def main():
     E = conn.shape[0]
     dev = torch.device("cuda", local_rank)
     big = N * K > (1 << 28)
-    d_unary = synthetic_volume_device(H, W, K, 1 + rank, dev) if big else torch.from_numpy(synthetic_volume(H, W, K, seed=1 + rank)).to(dev)
+    volume = args.volume if not big else "noise"
+    if volume == "ncc":
+        # the named workload: NCC cost volume of an image pair (dispmap_ncc.m:116-198, computed by the
+        # product's own kernel, label fastest) -> unary = unary_weight * (1 - ncc), weight 40
+        # (example_ncc.m:13-16).  The masked columns left of each disparity are flat zeros (:190-191),
+        # so the volume has exact ties like the real Teddy volume and part of the messages take the
+        # reference's serial envelope construction.
+        from stereo_amd import terms as T
+        im0, im1 = synthetic_pair(H, W, K, seed=rank)
+        ncc = T.ncc_volume(im0, im1, np.arange(K, dtype=np.float64), 2, layout=1)     # K x N, label fastest
+        h_unary = np.ascontiguousarray(40.0 * (1.0 - ncc.T))                          # (N, K)
+        d_unary = torch.from_numpy(h_unary).to(dev)
+    elif big:
+        d_unary = synthetic_volume_device(H, W, K, 1 + rank, dev)
+    else:
+        d_unary = torch.from_numpy(synthetic_volume(H, W, K, seed=1 + rank)).to(dev)
     plan = TrwsPlan(1, K, N, conn.T, message_mode=0 if args.message_mode == "exact" else 1)
     # inputs live in HBM as torch tensors (plumbing only) and are bound, not copied
     d_alpha = torch.ones(E, dtype=torch.float64, device=dev)
@@ -248,11 +266,15 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: synthetic %dx%dx%d-label cost volume, TRW-S (trws.m drop-in), "
-                                   "kernel 1, tol 8, alphas 1, fronto-parallel labels" % (W, H, K),
+            "config": {"workload": "configs[1]: %s, %dx%dx%d labels, TRW-S (trws.m drop-in), "
+                                   "kernel 1, tol 8, alphas 1, fronto-parallel labels" % (
+                                       "NCC cost volume (5x5xRGB, unary weight 40) of a synthetic image pair" if volume == "ncc"
+                                       else "synthetic cost volume (planted signal + noise)", W, H, K),
                        "nodes": N, "directed_edges": E, "message_mode": "exact (reference envelope)" if args.message_mode == "exact" else "minplus",
                        "parallelism": "independent image pair per GPU" if world > 1 else "1 GPU"},
-            "serial_envelope_messages": serial_msgs, "final_energy": energy, "final_lower_bound": lb, "iterations_done": iters,
+            "serial_envelope_messages": serial_msgs,
+            "serial_envelope_fraction": serial_msgs / (2.0 * E * max(args.steps, 1)),  # 2E message updates per iteration
+            "final_energy": energy, "final_lower_bound": lb, "iterations_done": iters,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": {4: "trws_pipe2_kernel", 3: "trws_wide_kernel", 2: "trws_pipe_kernel", 1: "trws_persistent_kernel", 0: "trws_sweep_kernel (per level)"}[plan.path()]
@@ -267,6 +289,15 @@ def main():
             r = pyoracle.trws(1, unary, conn, q, q, np.ones(E), 8.0, maxiter=ci, max_relgap=-1e300,
                               mode=1, want_trace=True)
             secs = float(r[4][-1, 2])
+            # "+ final energy vs ref": the same ci iterations from zero messages on the GPU, outside the
+            # timed region, against the oracle run that is being timed anyway
+            plan.reset()
+            plan.iterate(ci, max_relgap=-1e300)
+            g_lab, g_en, g_lb, _ = plan.result(want_labels=True)
+            out["energy_vs_ref"] = {"iterations": ci, "labels_equal": bool(np.array_equal(g_lab, r[0])),
+                                    "energy_equal": bool(g_en == r[1]), "lower_bound_equal": bool(g_lb == r[2]),
+                                    "energy": g_en, "energy_ref": float(r[1]), "lower_bound": g_lb,
+                                    "lower_bound_ref": float(r[2]), "ref": "oracle/trws_oracle.c (envelope messages)"}
             out["cpu_baseline"] = {"value": ci / secs, "unit": "iterations/s", "cores": 1,
                                    "kind": "port",
                                    "sample": "%d iterations of the same %dx%dx%d volume, oracle/trws_oracle.c "

@@ -165,6 +165,182 @@ __global__ __launch_bounds__(kTB) void ncc_volume_kernel(NccParams p) {
   else p.out[(size_t)px * p.D + di] = val;
 }
 
+// ---- NCC volume, integer disparities: staged statistics + separable cross term ---------------
+// With an integer disparity d the shifted image of dispmap_ncc.m:145-154 is a pure shift,
+// imtr(row, col) = im1(row, col - d) (zero for col < d), so the d-independent box sums of im1 and
+// im1^2 serve every slice: box5(imtr)(row, col) = box5(im1)(row, col - d) wherever the 5 x 5 window
+// stays inside the image horizontally (the last `r` columns differ: conv2's zero padding cuts the
+// window of imtr at column W, the one of im1 only at column W + d; they are summed directly).  One
+// pre-pass per image stores per pixel the three per-channel box sums, the mean and the variance term
+// (ncc_stats_kernel: 25 taps x 3 channels in the order of ncc_volume_kernel, d-independent).  What is
+// left per (pixel, d) is the cross term sum_window sum_ch im0 * imtr -- a sliding-window sum with no
+// contraction index shared between outputs (no MFMA) -- computed separably: lane = image row, a wave
+// walks along the columns for one disparity with the five column products of the window in
+// registers, the vertical five-tap sum comes from the neighbouring lanes (DPP wave shifts).  All
+// image and statistics reads are coalesced 512-byte rows served by L2; the volume is written once,
+// coalesced in both layouts (the label-fastest layout through an 8-disparity LDS transpose: 64-byte runs).
+// Association: products (c0 + c1) + c2, then columns left to right, then rows top to bottom; the
+// per-channel 25-tap order of the reference's conv2 is NOT kept for the cross term (agreement with
+// the NumPy restatement to 1e-12 is the bar, tests/test_terms_gpu.py).
+constexpr int kNccRows = 60;    // output rows per wave (64 lanes = 60 + 2 x 2 halo rows)
+constexpr int kNccWaves = 8;    // disparities per workgroup (a 1024-thread workgroup would cap the wave at 128 VGPRs: spills)
+constexpr int kNccCols = 32;    // columns per workgroup
+
+struct NccFast {
+  int H, W, D;
+  const double *im0, *im1;
+  const double *st0, *st1;   // [5][N]: box sums of the three channels, mean, signed norm
+  const double *disp;
+  double *out;
+  int layout;
+};
+
+__global__ __launch_bounds__(kTB) void ncc_stats_kernel(const double *im, int H, int W, int r, double *st) {
+  const int64_t px = (int64_t)blockIdx.x * kTB + threadIdx.x;
+  const int64_t Npx = (int64_t)H * W;
+  if (px >= Npx) return;
+  const int row = (int)(px % H), col = (int)(px / H);
+  const double npatch = (double)((2 * r + 1) * (2 * r + 1));
+  const double mscale = 1.0 / npatch / 3.0;
+  double b[3] = {0, 0, 0}, bb[3] = {0, 0, 0};
+  for (int dx = -r; dx <= r; ++dx)
+    for (int dy = -r; dy <= r; ++dy)
+      for (int ch = 0; ch < 3; ++ch) {
+        const int rr = row + dy, cc = col + dx;
+        const double v = (rr < 0 || rr >= H || cc < 0 || cc >= W) ? 0.0 : im[(size_t)ch * Npx + (size_t)cc * H + rr];
+        b[ch] += v; bb[ch] += v * v;
+      }
+  const double mean = (b[0] * mscale + b[1] * mscale) + b[2] * mscale;
+  const double t1 = (bb[0] + bb[1]) + bb[2];
+  const double t2 = (mean * b[0] + mean * b[1]) + mean * b[2];
+  const double var = t1 - 2 * t2 + npatch * 3 * mean * mean;
+  // the norm with the sign of the variance term: sqrt of a negative one is imaginary in MATLAB
+  // (dispmap_ncc.m:141,171), which the cross kernel resolves from the two signs
+  const double norm = sqrt(fabs(var));
+  st[px] = b[0]; st[Npx + px] = b[1]; st[2 * Npx + px] = b[2]; st[3 * Npx + px] = mean;
+  st[4 * Npx + px] = var < 0 ? -norm : norm;
+}
+
+struct NccCol {  // what one step of the column walk reads: loaded one step ahead
+  double l0, l1, l2, r0, r1, r2;          // the two pixels of the product two columns ahead
+  double bL0, bL1, bL2, meanL, nL;        // statistics of im0 at (row, c)
+  double bT0, bT1, bT2, meanT, nT;        // statistics of im1 at (row, c - d)
+};
+
+__device__ __forceinline__ void ncc_load(const NccFast &p, int64_t Npx, int row_c, int c, int d, NccCol &o) {
+  // unconditional, clamped addresses (masked by the caller): every load of a step is in flight together
+  const int H = p.H, W = p.W;
+  int cp = c + 2; cp = cp < 0 ? 0 : cp > W - 1 ? W - 1 : cp;
+  int cr = c + 2 - d; cr = cr < 0 ? 0 : cr > W - 1 ? W - 1 : cr;
+  const size_t a = (size_t)cp * H + row_c, b = (size_t)cr * H + row_c;
+  o.l0 = p.im0[a]; o.l1 = p.im0[Npx + a]; o.l2 = p.im0[2 * Npx + a];
+  o.r0 = p.im1[b]; o.r1 = p.im1[Npx + b]; o.r2 = p.im1[2 * Npx + b];
+  int cs = c < 0 ? 0 : c > W - 1 ? W - 1 : c;
+  int ct = c - d; ct = ct < 0 ? 0 : ct > W - 1 ? W - 1 : ct;
+  const size_t sa = (size_t)cs * H + row_c, sb = (size_t)ct * H + row_c;
+  o.bL0 = p.st0[sa]; o.bL1 = p.st0[Npx + sa]; o.bL2 = p.st0[2 * Npx + sa]; o.meanL = p.st0[3 * Npx + sa]; o.nL = p.st0[4 * Npx + sa];
+  o.bT0 = p.st1[sb]; o.bT1 = p.st1[Npx + sb]; o.bT2 = p.st1[2 * Npx + sb]; o.meanT = p.st1[3 * Npx + sb]; o.nT = p.st1[4 * Npx + sb];
+}
+
+// Statistics of the shifted image where the 5 x 5 window leaves the image on the right: its columns
+// >= W are zero for imtr but not for im1, so the pre-pass planes do not apply (last two columns only).
+__device__ __forceinline__ void ncc_right_border(const NccFast &p, int64_t Npx, int row, int c, int d,
+                                                           double &bT0, double &bT1, double &bT2, double &meanT,
+                                                           double &nT) {
+  const int H = p.H, W = p.W;
+  double b0 = 0, b1 = 0, b2 = 0, q0 = 0, q1 = 0, q2 = 0;
+  for (int dx = -2; dx <= 2; ++dx)
+    for (int dy = -2; dy <= 2; ++dy) {
+      const int rr = row + dy, cc = c + dx;
+      const bool in = !(rr < 0 || rr >= H || cc < 0 || cc >= W || cc - d < 0);
+      const size_t a = in ? (size_t)(cc - d) * H + rr : 0;
+      const double v0 = in ? p.im1[a] : 0.0, v1 = in ? p.im1[Npx + a] : 0.0, v2 = in ? p.im1[2 * Npx + a] : 0.0;
+      b0 += v0; q0 += v0 * v0; b1 += v1; q1 += v1 * v1; b2 += v2; q2 += v2 * v2;
+    }
+  const double mscale = 1.0 / 25.0 / 3.0;
+  bT0 = b0; bT1 = b1; bT2 = b2;
+  meanT = (b0 * mscale + b1 * mscale) + b2 * mscale;
+  const double u1 = (q0 + q1) + q2;
+  const double u2 = (meanT * b0 + meanT * b1) + meanT * b2;
+  const double varT = u1 - 2 * u2 + 75.0 * meanT * meanT;
+  const double nn = sqrt(fabs(varT));
+  nT = varT < 0 ? -nn : nn;
+}
+
+// value of the lane above (UP) / below in the wave of 64; the lane that falls off the end reads 0
+// (DPP wave_shr:1 / wave_shl:1, bound_ctrl: one VALU move per half instead of a trip through LDS)
+template <bool UP>
+__device__ __forceinline__ double lane_neighbour(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, UP ? 0x138 : 0x130, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, UP ? 0x138 : 0x130, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(kNccWaves * 64, 2) void ncc_cross_kernel(NccFast p) {
+  __shared__ double tr[2][kNccRows][kNccWaves + 1];  // label-fastest transpose, double buffered
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int H = p.H, W = p.W;
+  const int64_t Npx = (int64_t)H * W;
+  const int row0 = blockIdx.x * kNccRows, row = row0 - 2 + lane;
+  const int di = blockIdx.y * kNccWaves + wave;
+  const bool dvalid = di < p.D;
+  const int d = dvalid ? (int)p.disp[di] : 0;
+  const int c_begin = blockIdx.z * kNccCols, c_end = c_begin + kNccCols < W ? c_begin + kNccCols : W;
+  const bool rvalid = row >= 0 && row < H;
+  const int row_c = row < 0 ? 0 : row > H - 1 ? H - 1 : row;
+  const bool outlane = lane >= 2 && lane < 2 + kNccRows && row < H;
+  const double npatch3 = 75.0;
+  auto product = [&](int c, const NccCol &v) -> double {  // sum over the channels of im0(row, c) * imtr(row, c)
+    const double pr = (v.l0 * v.r0 + v.l1 * v.r1) + v.l2 * v.r2;
+    return (rvalid && dvalid && c >= 0 && c < W && c - d >= 0) ? pr : 0.0;
+  };
+  NccCol cur, nxt;
+  double P0, P1, P2, P3;
+  ncc_load(p, Npx, row_c, c_begin - 4, d, cur); P0 = product(c_begin - 2, cur);
+  ncc_load(p, Npx, row_c, c_begin - 3, d, cur); P1 = product(c_begin - 1, cur);
+  ncc_load(p, Npx, row_c, c_begin - 2, d, cur); P2 = product(c_begin, cur);
+  ncc_load(p, Npx, row_c, c_begin - 1, d, cur); P3 = product(c_begin + 1, cur);
+  ncc_load(p, Npx, row_c, c_begin, d, cur);
+  for (int c = c_begin; c < c_end; ++c) {
+    ncc_load(p, Npx, row_c, c + 1, d, nxt);  // the next step's loads travel while this one computes
+    const double P4 = product(c + 2, cur);
+    const double h = (((P0 + P1) + P2) + P3) + P4;
+    const double hm1 = lane_neighbour<true>(h), hp1 = lane_neighbour<false>(h);      // rows - 1, + 1
+    const double hm2 = lane_neighbour<true>(hm1), hp2 = lane_neighbour<false>(hp1);  // rows - 2, + 2
+    const double c1 = (((hm2 + hm1) + h) + hp1) + hp2;
+    P0 = P1; P1 = P2; P2 = P3; P3 = P4;
+    double val = 0.0;
+    const bool live = outlane && dvalid && c >= d;  // columns left of round(d + 1) are masked (dispmap_ncc.m:190-191)
+    double bT0 = cur.bT0, bT1 = cur.bT1, bT2 = cur.bT2, meanT = cur.meanT, nT = cur.nT;
+    if (c + 2 >= W && live) ncc_right_border(p, Npx, row, c, d, bT0, bT1, bT2, meanT, nT);
+    {
+      const double c2 = (cur.meanL * bT0 + cur.meanL * bT1) + cur.meanL * bT2;
+      const double c3 = (meanT * cur.bL0 + meanT * cur.bL1) + meanT * cur.bL2;
+      const double num = c1 - c2 - c3 + npatch3 * meanT * cur.meanL;
+      const double q = num / fabs(cur.nL) / fabs(nT);
+      // real(num / normL / normT) with imaginary norms for negative variance terms (dispmap_ncc.m:188-192)
+      const bool negL = cur.nL < 0, negT = nT < 0;
+      val = negL == negT ? (negL ? -q : q) : 0.0;
+      if (!isfinite(val) || !live) val = 0.0;
+    }
+    if (p.layout == 0) {
+      if (outlane && dvalid) p.out[((size_t)di * W + c) * H + row] = val;
+    } else {
+      double (*buf)[kNccWaves + 1] = tr[(c - c_begin) & 1];
+      if (lane >= 2 && lane < 2 + kNccRows) buf[lane - 2][wave] = val;
+      __syncthreads();
+      const int t = threadIdx.x;
+      if (t < kNccRows * kNccWaves) {
+        const int rr = t / kNccWaves, ww = t % kNccWaves;
+        const int orow = row0 + rr, odi = blockIdx.y * kNccWaves + ww;
+        if (orow < H && odi < p.D) p.out[((size_t)c * H + orow) * p.D + odi] = buf[rr][ww];
+      }
+    }
+    cur = nxt;
+  }
+}
+
 // ---- NCC sampling (dispmap_ncc.m:222-276) -----------------------------------
 
 __device__ __forceinline__ double vol(const double *ncc, int64_t Npx, int D, int layout, int64_t px, int k) {
@@ -188,17 +364,35 @@ __device__ __forceinline__ void lagrange(const double *ncc, int64_t Npx, int D, 
 
 __global__ __launch_bounds__(kTB) void ncc_unary_kernel(const double *ncc, int H, int W, int D, int layout,
                                                        const double *dv, double dmin, double dmax,
-                                                       double unary_weight, const double *assign, double *U) {
+                                                       double unary_weight, const double *assign, double *U,
+                                                       int ascending) {
   const int64_t px = (int64_t)blockIdx.x * kTB + threadIdx.x;
   const int64_t Npx = (int64_t)H * W;
   if (px >= Npx) return;
   const double x = (double)(px / H + 1), y = (double)(px % H + 1);
   const double disp = plane_disp(assign + 4 * (size_t)px, x, y);
+  // nearest sample, ties to the LARGER index (dispmap_ncc.m:230-236: a scan over all slices with
+  // "<="; y2 keeps its initial 1 if no comparison succeeds, i.e. for a NaN disparity)
   int t2 = 1;
   double smallest = fabs(disp - dv[0]), y2 = 1.0;
-  for (int i = 0; i < D; ++i) {
-    const double nd = fabs(disp - dv[i]);
-    if (nd <= smallest) { t2 = i + 1; y2 = vol(ncc, Npx, D, layout, px, i); smallest = nd; }
+  if (ascending) {
+    // strictly ascending samples: |disp - dv[i]| falls, then rises (rounding is monotone), so the
+    // scan's answer is the later of the two samples around disp -- found by bisection -- unless
+    // further samples tie with it after rounding, which the short forward walk covers
+    if (disp == disp) {
+      int lo = 0, hi = D;  // first index with dv[i] > disp
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (dv[mid] > disp) hi = mid; else lo = mid + 1; }
+      int j = lo > 0 ? lo - 1 : 0;
+      double best = fabs(disp - dv[j]);
+      // (an earlier sample can tie with j only after rounding; the scan would still end on j or later)
+      while (j + 1 < D && fabs(disp - dv[j + 1]) <= best) { ++j; best = fabs(disp - dv[j]); }
+      t2 = j + 1; smallest = best; y2 = vol(ncc, Npx, D, layout, px, j);
+    }
+  } else {
+    for (int i = 0; i < D; ++i) {
+      const double nd = fabs(disp - dv[i]);
+      if (nd <= smallest) { t2 = i + 1; y2 = vol(ncc, Npx, D, layout, px, i); smallest = nd; }
+    }
   }
   const bool ok = t2 < D && t2 > 1;
   double r, pp, q, d2;
@@ -358,6 +552,35 @@ void download(T *dst, const DevBuf<T> &b, size_t n) {
   STEREO_HIP_CHECK(hipMemcpy(dst, b.p, n * sizeof(T), hipMemcpyDeviceToHost));
 }
 
+bool strictly_ascending(const double *d, int D) {
+  for (int i = 0; i < D; ++i)
+    if (!(d[i] == d[i]) || (i > 0 && !(d[i] > d[i - 1]))) return false;
+  return true;
+}
+
+// NCC volume on the device: the staged kernels when every disparity is an integer in [0, W) and the
+// patch is 5 x 5 (what dispmap_ncc.m:24 always asks for), the per-tap kernel otherwise.
+void launch_ncc_volume(const double *d_im0, const double *d_im1, int H, int W, const double *h_disp,
+                       const double *d_disp, int D, int patchsize, int layout, double *d_out) {
+  const size_t npx = (size_t)H * W;
+  bool staged = patchsize == 2 && !std::getenv("STEREO_HIP_NCC_NAIVE");
+  for (int i = 0; i < D && staged; ++i) staged = h_disp[i] >= 0 && h_disp[i] < W && h_disp[i] == std::floor(h_disp[i]);
+  if (!staged) {
+    NccParams p{H, W, D, patchsize, d_im0, d_im1, d_disp, d_out, layout};
+    hipLaunchKernelGGL(ncc_volume_kernel, dim3(blocks((int64_t)npx * D)), dim3(kTB), 0, 0, p);
+    return;
+  }
+  DevBuf<double> st0, st1;
+  st0.alloc(5 * npx); st1.alloc(5 * npx);
+  hipLaunchKernelGGL(ncc_stats_kernel, dim3(blocks(npx)), dim3(kTB), 0, 0, d_im0, H, W, patchsize, st0.p);
+  hipLaunchKernelGGL(ncc_stats_kernel, dim3(blocks(npx)), dim3(kTB), 0, 0, d_im1, H, W, patchsize, st1.p);
+  NccFast f{H, W, D, d_im0, d_im1, st0.p, st1.p, d_disp, d_out, layout};
+  const dim3 grid((H + kNccRows - 1) / kNccRows, (D + kNccWaves - 1) / kNccWaves, (W + kNccCols - 1) / kNccCols);
+  hipLaunchKernelGGL(ncc_cross_kernel, grid, dim3(kNccWaves * 64), 0, 0, f);
+  STEREO_HIP_CHECK(hipGetLastError());
+  STEREO_HIP_CHECK(hipDeviceSynchronize());  // st0 / st1 are released on return
+}
+
 }  // namespace
 }  // namespace stereo
 
@@ -410,8 +633,7 @@ int stereo_ncc_volume(const double *im0, const double *im1, int H, int W, const 
     const size_t npx = (size_t)H * W;
     DevBuf<double> d0, d1, dd, out;
     d0.upload(im0, npx * 3); d1.upload(im1, npx * 3); dd.upload(disparities, D); out.alloc(npx * D);
-    NccParams p{H, W, D, patchsize, d0.p, d1.p, dd.p, out.p, layout};
-    hipLaunchKernelGGL(ncc_volume_kernel, dim3(blocks((int64_t)npx * D)), dim3(kTB), 0, 0, p);
+    launch_ncc_volume(d0.p, d1.p, H, W, disparities, dd.p, D, patchsize, layout, out.p);
     download(ncc, out, npx * D);
   });
 }
@@ -427,7 +649,7 @@ int stereo_ncc_unary(const double *ncc, int H, int W, int D, int layout, const d
     DevBuf<double> dn, dd, da, out;
     dn.upload(ncc, npx * D); dd.upload(disparities, D); da.upload(assignment, 4 * npx); out.alloc(npx);
     hipLaunchKernelGGL(ncc_unary_kernel, dim3(blocks(npx)), dim3(kTB), 0, 0, dn.p, H, W, D, layout, dd.p, dmin,
-                       dmax, unary_weight, da.p, out.p);
+                       dmax, unary_weight, da.p, out.p, strictly_ascending(disparities, D) ? 1 : 0);
     download(U, out, npx);
   });
 }
@@ -483,6 +705,7 @@ struct stereo_fusion {
   DevBuf<double> ncc, disparities, im0, im1, P2;
   int D = 0, C = 0;
   double unary_weight = 0, dmin = 0, dmax = 0, col_thresh = 0;
+  bool ascending = false;  // strictly ascending disparities: the sampler bisects instead of scanning
   bool have_assignment = false;
   double energy = 0;
   std::vector<double> h_lab;
@@ -510,7 +733,7 @@ double fusion_sum(stereo_fusion *F, const double *x, int64_t n) {
 void fusion_unary(stereo_fusion *F, const double *d_planes, double *d_out) {
   if (F->unary_kind == 1) {
     hipLaunchKernelGGL(ncc_unary_kernel, dim3(blocks(F->N)), dim3(kTB), 0, 0, F->ncc.p, F->H, F->W, F->D, 0,
-                       F->disparities.p, F->dmin, F->dmax, F->unary_weight, d_planes, d_out);
+                       F->disparities.p, F->dmin, F->dmax, F->unary_weight, d_planes, d_out, F->ascending ? 1 : 0);
   } else if (F->unary_kind == 2) {
     hipLaunchKernelGGL(globalstereo_unary_kernel, dim3(blocks(F->N)), dim3(kTB), 0, 0, F->im0.p, F->im1.p, F->H,
                        F->W, F->C, F->P2.p, F->d_min, F->d_step, F->col_thresh, d_planes, d_out);
@@ -567,6 +790,7 @@ int stereo_fusion_unary_ncc(stereo_fusion *F, const double *ncc, int D, const do
   return guarded("stereo_fusion_unary_ncc", err, errcap, [&] {
     F->ncc.upload(ncc, (size_t)F->N * D); F->disparities.upload(disparities, D);
     F->D = D; F->unary_weight = unary_weight; F->unary_kind = 1;
+    F->ascending = strictly_ascending(disparities, D);
     F->dmin = F->dmax = disparities[0];
     for (int i = 1; i < D; ++i) { F->dmin = std::min(F->dmin, disparities[i]); F->dmax = std::max(F->dmax, disparities[i]); }
     F->have_assignment = false;

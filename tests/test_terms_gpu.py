@@ -124,3 +124,39 @@ def test_globalstereo_unary(hip):
     gray = st.globalstereo_unary(im0[:, :, 0], im1[:, :, 0], P2, d_min, d_step, 30.0, A)
     want_g = ot.globalstereo_unary_cost(im0[:, :, :1], im1[:, :, :1], P2, d_min, d_step, 30.0, A, pts)
     assert np.max(np.abs(gray - want_g)) < 1e-12
+
+
+@pytest.mark.parametrize("shape", [(133, 75, 37), (61, 33, 17), (60, 32, 16), (7, 5, 3)])
+def test_staged_ncc_volume_matches_numpy_and_per_tap_kernel(shape, hip, monkeypatch):
+    """Integer disparities take the staged kernels (statistics pre-pass + separable cross term, several
+    row bands / column segments / disparity groups, ragged at every border); the NumPy restatement
+    and the per-tap kernel (forced by STEREO_HIP_NCC_NAIVE) must agree to 1e-12, both layouts."""
+    from stereo_amd import terms as st
+    H, W, D = shape
+    im0, im1 = _images(11, H, W)
+    disps = np.arange(D, dtype=np.float64)
+    want = ot.compute_ncc(im0, im1, disps)
+    got = st.ncc_volume(im0, im1, disps)
+    lf = st.ncc_volume(im0, im1, disps, layout=1)
+    monkeypatch.setenv("STEREO_HIP_NCC_NAIVE", "1")
+    naive = st.ncc_volume(im0, im1, disps)
+    assert np.max(np.abs(got - want)) < 1e-12
+    assert np.max(np.abs(got - naive)) < 1e-12
+    assert np.array_equal(lf, got.reshape(H * W, D, order="F").T)
+    assert np.max(np.abs(want)) > 0.5
+
+
+def test_sampler_on_unsorted_disparities_scans(hip):
+    """The bisection needs strictly ascending samples; any other order keeps the reference's scan."""
+    from stereo_amd import terms as st
+    H, W = 9, 11
+    rng = np.random.default_rng(4)
+    disps = np.array([3.0, 0.0, 5.0, 1.0, 1.0, 8.0])
+    ncc = rng.uniform(-1, 1, size=(H, W, len(disps)))
+    pts = ot.get_points(H, W)
+    P = np.zeros((4, H * W)); P[2] = 1.0
+    P[3] = -rng.uniform(-1, 9, H * W)
+    P[3, :20] = -np.round(rng.uniform(0, 8, 20))
+    want = ot.ncc_unary_cost(ncc, disps, 40.0, P, pts)
+    got = st.ncc_unary(np.asfortranarray(ncc), disps, 40.0, P)
+    assert np.array_equal(want, got, equal_nan=True)   # (the duplicated sample divides by zero on both sides)
