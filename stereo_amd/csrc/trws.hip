@@ -84,7 +84,8 @@ struct DevParams {
   unsigned long long *prof;       // optional: 8 phase-cycle accumulators (development)
   const int32_t *desc[2];         // packed node descriptors of the pipelined kernels
   int prof_run;
-  int debug;  // development switches: 2 / 4 profile backward / forward sweeps only, 256 no windowed paths
+  int debug;  // development switches: 2 / 4 profile backward / forward sweeps only, 256 no windowed paths,
+              // 512 serial envelopes by the lane-read loop instead of the mask construction
               // (none of them changes a result)
   unsigned long long *timeline;  // optional [2][nruns][2] wall-clock stamps (development)
   int window;  // wide kernel: sources within lambda of a destination lie within +-window indices
@@ -344,6 +345,112 @@ __device__ __forceinline__ int build_envelope_regs(int K, double alpha, double h
     maxtop = top > maxtop ? top : maxtop;
   }
   return maxtop;
+}
+
+// ---- the linear-kernel construction without its inner loop -------------------------------------
+// Every comparison of typeStereoLinear.h:401-460 involves the new cone k and the cone j on top of
+// the stack, nothing else -- so all of them can be evaluated up front for source k against ALL
+// sources j at once (lane j), giving three 64-bit masks per k, and the stack itself shrinks to a
+// bit set over source indices (sources arrive in ascending position order and the stack is a
+// subsequence of them: top = highest set bit, pop = clear it).  One trip per source, no dependent
+// chain of lane reads and scalar branches per pop:
+//   m1[j]: dist + hk <  hj   (j is dominated: pop)           typeStereoLinear.h:417-431
+//   m2[j]: dist + hj <= hk   (k is dominated: drop k)         :432-435
+//   m3[j]: s >= qk or s <= qj ("numerical stability": drop k) :444-449
+// with s = ((hk - hj) + alpha (qk + qj)) / (2 alpha).  The two tests on s are made on the numerator:
+// x -> fl(x / c) is monotone, so s >= qk <=> num >= thi(qk) with thi = the smallest double whose
+// quotient reaches qk, and s <= qj <=> num <= tlo(qj) with tlo the largest one whose quotient stays
+// at or below qj; both thresholds are found per lane by stepping ulp-wise from fl(q c) (a handful of
+// divisions per message instead of one per pair).  Slot contents are recorded per lane exactly as
+// the serial code leaves them (stale breakpoints above `top` included): lane t = slot t holds the
+// source stored there and the pair whose crossing is z[t+1]; values are filled in at the end with
+// one vector division.  Returns false (nothing done) on inputs outside the argument above.
+__device__ __forceinline__ double ulp_up(double x) {    // next double above a finite x
+  long long b = __double_as_longlong(x);
+  b = x > 0 ? b + 1 : x < 0 ? b - 1 : 1;                // +-0 -> smallest positive denormal
+  return __longlong_as_double(b);
+}
+__device__ __forceinline__ double ulp_down(double x) {  // next double below a finite x
+  long long b = __double_as_longlong(x);
+  b = x > 0 ? b - 1 : x < 0 ? b + 1 : (long long)0x8000000000000001ull;
+  return __longlong_as_double(b);
+}
+
+__device__ __forceinline__ bool build_envelope_masks(int K, double alpha, double hs, double qs, double &sh,
+                                                     double &sq, double &zz, int lane, int &maxtop_out) {
+  const double inf = __builtin_huge_val();
+  const bool act = lane < K;
+  const double c = 2 * alpha;
+  bool ok = alpha > 0 && c < inf && (!act || (fabs(hs) < inf && fabs(qs) < inf));
+  // thresholds on the numerator (see above); at most kSteps ulp steps from fl(q c), else give up
+  constexpr int kSteps = 6;
+  double thi = qs * c, tlo = thi;
+  ok = ok && (!act || fabs(thi) < 1e300);
+  if (!UNI(!ok)) {
+    // thi: smallest x with fl(x / c) >= qs
+    bool settled = !act;
+    {
+      const bool above = thi / c >= qs;   // start inside the set: walk down to its edge, else walk up into it
+      for (int i = 0; i < kSteps; ++i) {
+        const double nx = above ? ulp_down(thi) : ulp_up(thi);
+        const bool in = nx / c >= qs;
+        if (above) { if (in && !settled) thi = nx; else settled = true; }
+        else { if (!settled) thi = nx; if (in) settled = true; }
+      }
+      if (above) {  // settled only if the last step left the set
+        settled = settled || !(ulp_down(thi) / c >= qs);
+      }
+    }
+    ok = ok && settled;
+    // tlo: largest x with fl(x / c) <= qs
+    settled = !act;
+    {
+      const bool below = tlo / c <= qs;
+      for (int i = 0; i < kSteps; ++i) {
+        const double nx = below ? ulp_up(tlo) : ulp_down(tlo);
+        const bool in = nx / c <= qs;
+        if (below) { if (in && !settled) tlo = nx; else settled = true; }
+        else { if (!settled) tlo = nx; if (in) settled = true; }
+      }
+      if (below) settled = settled || !(ulp_up(tlo) / c <= qs);
+    }
+    ok = ok && settled;
+  }
+  if (UNI(!ok)) return false;
+  unsigned long long A = 1;      // source 0 is the bottom of the stack
+  int top = 0, maxtop = 0;
+  int src = 0, zk = -1, zj = 0;  // lane t: slot t holds source `src`; z[t+1] = crossing of (zk, zj), inf if zk < 0
+  for (int k = 1; k < K; ++k) {
+    const double hk = readlane_f64(hs, k), qk = readlane_f64(qs, k), thik = readlane_f64(thi, k);
+    const double dist = alpha * fabs(qk - qs);
+    const unsigned long long m1 = __builtin_amdgcn_ballot_w64(dist + hk < hs);
+    const unsigned long long m2 = __builtin_amdgcn_ballot_w64(dist + hs <= hk);
+    const double num = (hk - hs) + alpha * (qk + qs);
+    const unsigned long long m3 = __builtin_amdgcn_ballot_w64(num >= thik || num <= tlo);
+    const unsigned long long B = A & ~m1;
+    if (B == 0) {  // every cone on the stack is dominated: k becomes the bottom (typeStereoLinear.h:419-425)
+      A = 1ull << k;
+      if (lane == 0) { src = k; zk = -1; }
+      top = 0;
+      continue;
+    }
+    const int js = 63 - __builtin_clzll(B);   // the cone k meets: the highest one it does not dominate
+    A &= (2ull << js) - 1;                    // (js < k <= 63)
+    top = __builtin_popcountll(A) - 1;
+    if (((m2 | m3) >> js) & 1) continue;
+    if (lane == top) { zk = k; zj = js; }
+    ++top;
+    if (lane == top) { src = k; zk = -1; }
+    A |= 1ull << k;
+    maxtop = top > maxtop ? top : maxtop;
+  }
+  sh = __shfl(hs, src, kWave); sq = __shfl(qs, src, kWave);
+  const double hk = __shfl(hs, zk < 0 ? 0 : zk, kWave), qk = __shfl(qs, zk < 0 ? 0 : zk, kWave);
+  const double hj = __shfl(hs, zj, kWave), qj = __shfl(qs, zj, kWave);
+  const double s = ((hk - hj) + alpha * (qk + qj)) / (2 * alpha);
+  zz = zk < 0 ? inf : s;
+  maxtop_out = maxtop;
+  return true;
 }
 
 // Certified fast path of the truncated QUADRATIC message (typeStereoQuadratic.h:329-501), K <= 64,
@@ -1165,6 +1272,8 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
     const double vtrunc = hmin + alpha * p.lambda;
     bool need_serial = true;
     out = vtrunc;
+    long long tm0 = p.prof ? (long long)__builtin_readcyclecounter() : 0;  // development profile: slots 8..15
+#define MSTAMP(slot) do { if (p.prof) { const long long n_ = (long long)__builtin_readcyclecounter(); if (lane == 0) { atomicAdd(p.prof + (slot), (unsigned long long)(n_ - tm0)); atomicAdd(p.prof + (slot) + 1, 1ull); } tm0 = n_; } } while (0)
     if (KERNEL == 1 && p.certificate) {
       // Fast path (DESIGN.md "message certificate").  Only "useful" sources, those with
       // h < vTrunc, can produce a value below the truncation level: cost >= h for every
@@ -1254,7 +1363,8 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
 #undef STEREO_ACC
       bad = bad || (m1 < vtrunc && !(m2 - m1 > delta && vtrunc - m1 > delta));
       need_serial = UNI(act && bad);
-      if (need_serial) need_serial = message_second_look(p.lambda, K, alpha, h, qsrc, t, vtrunc, delta, lane, m1);
+      MSTAMP(8);
+      if (need_serial) { need_serial = message_second_look(p.lambda, K, alpha, h, qsrc, t, vtrunc, delta, lane, m1); MSTAMP(10); }
       out = m1 < vtrunc ? m1 : vtrunc;
       if (need_serial && lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
     }
@@ -1273,16 +1383,25 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
       const int idx = act ? perm[lane] : lane;
       const double hs = __shfl(h, idx, kWave), qs = __shfl(qsrc, idx, kWave);
       double sh, sq, zz;
-      const int maxtop = build_envelope_regs<KERNEL>(K, alpha, hs, qs, sh, sq, zz, lane);
-      double ch = 0, cq = 0;
-      bool walking = true;
-      for (int j = 0; j <= maxtop; ++j) {
-        const double shj = readlane_f64(sh, j), sqj = readlane_f64(sq, j), zj1 = readlane_f64(zz, j);
-        if (walking) { ch = shj; cq = sqj; walking = zj1 < t; }
+      int maxtop = 0;
+      bool built = false;
+      if (KERNEL == 1 && !(p.debug & 512)) built = build_envelope_masks(K, alpha, hs, qs, sh, sq, zz, lane, maxtop);
+      if (!built) maxtop = build_envelope_regs<KERNEL>(K, alpha, hs, qs, sh, sq, zz, lane);
+      MSTAMP(12);
+      // the reference walks up the stack while z[j+1] < t (typeStereoLinear.h:462-479): the slot it
+      // stops at is the FIRST one whose upper breakpoint is not below t (stale slots above `top`
+      // included, hence up to the highest slot ever written); found top-down so that the lowest wins
+      int slot = maxtop;
+      for (int j = maxtop - 1; j >= 0; --j) {
+        const double zj1 = readlane_f64(zz, j);
+        slot = !(zj1 < t) ? j : slot;
       }
+      const double ch = __shfl(sh, slot, kWave), cq = __shfl(sq, slot, kWave);
       const double c = pair_cost<KERNEL>(alpha, t - cq, ch);
       out = c < vtrunc ? c : vtrunc;
+      MSTAMP(14);
     }
+#undef MSTAMP
     vmin = wave_min_dpp(act ? out : inf);
   }
   outmsg = out - vmin;
@@ -3323,6 +3442,11 @@ void stereo_trws_plan_destroy(stereo_trws_plan *plan) {
       if (!plan->wide)
         std::fprintf(stderr, "[stereo_hip prof] cycles: p0 %llu p1 %llu p2 %llu p3 %llu p4 %llu | p5 %llu steps %llu\n",
                      v[0], v[1], v[2], v[3], v[4], v[5], v[6]);
+      if (!plan->wide && v[9])
+        std::fprintf(stderr, "[stereo_hip prof messages] certified attempt %.0f cycles x %llu | second look %.0f x %llu | "
+                             "serial construction %.0f x %llu | walk %.0f x %llu\n",
+                     (double)v[8] / v[9], v[9], v[11] ? (double)v[10] / v[11] : 0.0, v[11], v[13] ? (double)v[12] / v[13] : 0.0,
+                     v[13], v[15] ? (double)v[14] / v[15] : 0.0, v[15]);
       if (plan->wide && v[22]) {
         std::fprintf(stderr, "[stereo_hip prof wide] cycles per visit of wave 0:");
         for (int i = 0; i < 16; ++i) std::fprintf(stderr, " [%d] %.0f", i, (double)v[i] / v[22]);

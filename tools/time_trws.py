@@ -1,5 +1,5 @@
 """Development tool: time TRW-S iterations of a synthetic volume for a given kernel / size.
-usage: time_trws.py [kernel=1] [H=375] [W=450] [K=60] [tol=8] [iters=10] [general=0]
+usage: time_trws.py [kernel=1] [H=375] [W=450] [K=60] [tol=8] [iters=10] [general=0] [volume=noise|ncc]
 general=1: per-edge positions q != qprim (label k + jitter), as a fusion of K plane proposals has them."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,9 +16,17 @@ K = int(a[3]) if len(a) > 3 else 60
 tol = float(a[4]) if len(a) > 4 else 8.0
 iters = int(a[5]) if len(a) > 5 else 10
 general = int(a[6]) if len(a) > 6 else 0
+volume = a[7] if len(a) > 7 else "noise"   # "ncc": NCC cost volume of a synthetic pair (bench.py's workload)
 dev = torch.device("cuda", 0)
 conn = grid_conn(H, W); E = conn.shape[0]; N = H * W
-d_unary = torch.from_numpy(synthetic_volume(H, W, K, seed=1)).to(dev)
+if volume == "ncc":
+    from bench import synthetic_pair
+    from stereo_amd import terms as T
+    im0, im1 = synthetic_pair(H, W, K, seed=0)
+    ncc = T.ncc_volume(im0, im1, np.arange(K, dtype=np.float64), 2, layout=1)
+    d_unary = torch.from_numpy(np.ascontiguousarray(40.0 * (1.0 - ncc.T))).to(dev)
+else:
+    d_unary = torch.from_numpy(synthetic_volume(H, W, K, seed=1)).to(dev)
 plan = TrwsPlan(kernel, K, N, conn.T)
 d_alpha = torch.ones(E, dtype=torch.float64, device=dev)
 d_pos = torch.arange(K, dtype=torch.float64, device=dev)
