@@ -249,8 +249,9 @@ def main():
         # HBM traffic per launch from the committed PMC passes of this same workload (profiles/),
         # corrected as MI355X_MICROARCH.md prescribes; null if the workload differs from them
         traffic = None
-        pmc = {(375, 450, 60): "r01_trws_teddy60_pmc_hbm.json",
-               (1000, 1500, 256): "r01_trws_wide256_1500x1000_pmc_hbm.json"}.get((H, W, K))
+        pmc = {(375, 450, 60, "ncc"): "r02_trws_teddy60_ncc_pmc_hbm.json",
+               (375, 450, 60, "noise"): "r01_trws_teddy60_pmc_hbm.json",
+               (1000, 1500, 256, "noise"): "r01_trws_wide256_1500x1000_pmc_hbm.json"}.get((H, W, K, volume))
         if pmc and os.path.exists(os.path.join(ROOT, "profiles", pmc)):
             traffic = json.load(open(os.path.join(ROOT, "profiles", pmc)))["per_launch"]["hbm_bytes_corrected"]
         out = {
