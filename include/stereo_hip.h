@@ -122,6 +122,21 @@ int stereo_trws_plan_stats(stereo_trws_plan *plan, double *sweep_ms, int64_t *sw
  * construction and the serial construction was run instead. */
 int stereo_trws_plan_counters(stereo_trws_plan *plan, int64_t *serial_messages, int reset);
 
+/* Diagnostics / test hook: M independent message updates Edge::UpdateMessage
+ * (typeStereoLinear.h:329-487, typeStereoQuadratic.h:329-501) on the device, one wavefront per
+ * message, through the very routine the pipelined sweep kernel uses (certified min-plus fast
+ * path, second look, serial lower-envelope construction).  Row m of the M x K arrays (K <= 64):
+ * H = gamma[m] * Di - msg_in (:383-387), source positions q_source, destination positions q_dest
+ * (the caller has resolved dir == m_dir, :343-357).  certificate = 0 forces the serial
+ * construction.  shared_positions != NULL tells the routine that every row uses these K strictly
+ * ascending positions for sources and destinations (`window` = index distance beyond which a
+ * source costs >= vTrunc, or -1).  used_serial[m] (may be NULL) = 1 if the serial construction ran. */
+int stereo_trws_messages(int kernel, int K, int64_t M, const double *Di, const double *gamma,
+                         const double *msg_in, const double *q_source, const double *q_dest,
+                         const double *alpha, double lambda, int certificate, int window,
+                         const double *shared_positions, double *msg_out, double *vmin,
+                         int32_t *used_serial, char *err, size_t errcap);
+
 /* Diagnostics: which sweep implementation the plan's current inputs select.
  * 0 level-synchronous launches, 1 generic persistent kernel, 2 pipelined kernel (K <= 64),
  * 3 wide pipelined kernel (64 < K <= 256, shared strictly ascending positions),

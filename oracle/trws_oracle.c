@@ -249,10 +249,19 @@ static int cmp_pair(const void *a, const void *b) {
   int i = ((const pair_t *)a)->i, j = ((const pair_t *)b)->i;
   return (i > j) - (i < j);
 }
+/* sort_oracle.cpp: the reference gateway's own sequence of std::sort calls (trws_mex.cpp:84-97) */
+void oracle_gateway_order(const double *v, int K, int32_t *out);
+/* Ascending order of one position vector as the reference gateway produces it.  Equal values:
+ * index order up to 16 labels (std::sort is an insertion sort there); beyond that whatever the
+ * gateway's repeated std::sort leaves, obtained by running that very sequence -- only when the
+ * vector does hold equal values (the sequence costs K sorts). */
 static void argsort(const double *v, int K, int32_t *out, pair_t *tmp) {
   for (int k = 0; k < K; ++k) { tmp[k].v = v[k]; tmp[k].i = k; }
   qsort(tmp, K, sizeof(pair_t), cmp_pair);
   for (int k = 0; k < K; ++k) out[k] = tmp[k].i;
+  if (K > 16)
+    for (int k = 1; k < K; ++k)
+      if (tmp[k].v == tmp[k - 1].v) { oracle_gateway_order(v, K, out); return; }
 }
 
 /* Lower-envelope message: the reference's O(K) scheme (typeStereoLinear.h:401-479,

@@ -31,6 +31,8 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/stereo_hip.h"
@@ -2823,6 +2825,66 @@ __global__ __launch_bounds__(kWave) void argsort_kernel(const double *vals, uint
   }
 }
 
+// Rows whose ascending order holds two equal values (the order of equal positions needs the
+// reference gateway's own sort sequence, see gateway_order below); one thread per row.
+__global__ __launch_bounds__(kBlock) void equal_values_kernel(const double *vals, const uint16_t *perm, int K,
+                                                             int64_t count, uint8_t *flag) {
+  const int64_t a = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (a >= count) return;
+  const double *v = vals + (size_t)a * K;
+  const uint16_t *pm = perm + (size_t)a * K;
+  bool eq = false;
+  double prev = v[pm[0]];
+  for (int k = 1; k < K; ++k) { const double x = v[pm[k]]; eq = eq || x == prev; prev = x; }
+  flag[a] = eq ? 1 : 0;
+}
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const double *vals, const int64_t *rows, int64_t n, int K,
+                                                            double *out) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t < n * K) out[t] = vals[(size_t)rows[t / K] * K + t % K];
+}
+__global__ __launch_bounds__(kBlock) void scatter_perm_kernel(const uint16_t *in, const int64_t *rows, int64_t n, int K,
+                                                             uint16_t *perm) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t < n * K) perm[(size_t)rows[t / K] * K + t % K] = in[t];
+}
+
+// ---- single message updates (diagnostic entry point stereo_trws_messages) ------------------
+// One wave per message through message_regs -- the routine the pipelined sweep kernel computes
+// its messages with (certified fast path, second look, serial construction), table in LDS as
+// there -- so that the certificate can be attacked with hand-placed near-tangent cones.
+template <int KERNEL>
+__global__ __launch_bounds__(kWave) void trws_messages_kernel(DevParams p, int K, int64_t M, const double *Di,
+                                                             const double *gamma, const double *msg_in,
+                                                             const double *qsrc, const double *qdst,
+                                                             const double *alpha, const uint16_t *perm, int window,
+                                                             double *msg_out, double *vmin, int32_t *serial,
+                                                             unsigned long long *counters) {
+  __shared__ __attribute__((aligned(16))) double tab[kPipeTab];
+  const int lane = threadIdx.x;
+  const bool act = lane < K;
+  if (lane < 2 * kPipePad) {
+    double *e = tab + 4 * (lane < kPipePad ? lane : kWave + lane);
+    e[0] = __builtin_huge_val(); e[1] = 0; e[2] = 0; e[3] = 0;
+  }
+  __syncthreads();
+  for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
+    const size_t o = (size_t)m * K + lane;
+    const double h = act ? gamma[m] * Di[o] - msg_in[o] : __builtin_huge_val();
+    const double qs = act ? qsrc[o] : 0.0, qt = act ? qdst[o] : 0.0;
+    p.fallbacks = counters + blockIdx.x;  // (one counter per workgroup: its messages run one after the other)
+    unsigned long long before = 0;
+    if (lane == 0) before = *p.fallbacks;
+    before = __shfl(before, 0, kWave);
+    double out = 0;
+    const double v = message_regs<KERNEL>(p, K, alpha[m], h, qs, qt, perm + (size_t)m * K, out, lane,
+                                          tab + 4 * kPipePad, window);
+    __threadfence();
+    if (act) msg_out[o] = out;
+    if (lane == 0) { vmin[m] = v; serial[m] = (int32_t)(*p.fallbacks - before); }
+  }
+}
+
 }  // namespace
 }  // namespace stereo
 
@@ -3097,6 +3159,67 @@ void reset_state(stereo_trws_plan *P) {
   P->lb_in_flight = false; P->issued = false;
 }
 
+// The order in which the reference's gateway hands EQUAL positions to the message code.
+// trws_mex.cpp:84-97 pushes one (value, index) pair at a time and calls std::sort on the whole
+// vector after every push, comparing values only (:16-20).  std::sort is not stable: up to 16
+// elements it is an insertion sort (equal values stay in index order -- what argsort_kernel
+// produces), beyond that its introsort may swap equal values.  Equal positions are no corner
+// case: simultaneous_fusion appends the current assignment as a label (dispmap_super.m:158), so
+// wherever a proposal's plane is the current plane two labels coincide exactly.  For such vectors
+// the same sequence of calls is made here, with the std::sort of the toolchain in use -- what a
+// reference built with that toolchain does.
+void gateway_order(const double *v, int K, uint16_t *perm) {
+  typedef std::pair<double, int> Pair;
+  struct Cmp {
+    bool operator()(const Pair &a, const Pair &b) const { return a.first < b.first; }
+  };
+  std::vector<Pair> pr;
+  pr.reserve(K);
+  for (int j = 0; j < K; ++j) {
+    pr.push_back(Pair(v[j], j));
+    std::sort(pr.begin(), pr.end(), Cmp());
+  }
+  for (int j = 0; j < K; ++j) perm[j] = (uint16_t)pr[j].second;
+}
+
+// After argsort_kernel: rows with equal values get the gateway's order (K > 16 only, see above).
+void fix_equal_positions(const double *d_vals, uint16_t *d_perm, int K, int64_t count) {
+  if (K <= 16 || count <= 0) return;
+  DevBuf<uint8_t> d_flag;
+  d_flag.alloc(count);
+  hipLaunchKernelGGL(equal_values_kernel, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, 0, d_vals,
+                     d_perm, K, count, d_flag.p);
+  STEREO_HIP_CHECK(hipGetLastError());
+  std::vector<uint8_t> flag(count);
+  STEREO_HIP_CHECK(hipMemcpy(flag.data(), d_flag.p, count, hipMemcpyDeviceToHost));
+  std::vector<int64_t> rows;
+  for (int64_t a = 0; a < count; ++a)
+    if (flag[a]) rows.push_back(a);
+  const int64_t n = (int64_t)rows.size();
+  if (n == 0) return;
+  DevBuf<int64_t> d_rows;
+  DevBuf<double> d_g;
+  DevBuf<uint16_t> d_p;
+  d_rows.upload(rows.data(), n);
+  d_g.alloc((size_t)n * K); d_p.alloc((size_t)n * K);
+  const unsigned gb = (unsigned)(((int64_t)n * K + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(gb), dim3(kBlock), 0, 0, d_vals, d_rows.p, n, K, d_g.p);
+  STEREO_HIP_CHECK(hipGetLastError());
+  std::vector<double> g((size_t)n * K);
+  STEREO_HIP_CHECK(hipMemcpy(g.data(), d_g.p, sizeof(double) * n * K, hipMemcpyDeviceToHost));
+  std::vector<uint16_t> pm((size_t)n * K);
+  const int64_t T = std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency() / 2, 64, n / 256 + 1}));
+  std::vector<std::thread> pool;
+  auto work = [&](int64_t a, int64_t b) { for (int64_t i = a; i < b; ++i) gateway_order(&g[(size_t)i * K], K, &pm[(size_t)i * K]); };
+  for (int64_t t = 1; t < T; ++t) pool.emplace_back(work, n * t / T, n * (t + 1) / T);
+  work(0, n / T);
+  for (auto &th : pool) th.join();
+  STEREO_HIP_CHECK(hipMemcpy(d_p.p, pm.data(), sizeof(uint16_t) * n * K, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(scatter_perm_kernel, dim3(gb), dim3(kBlock), 0, 0, d_p.p, d_rows.p, n, K, d_perm);
+  STEREO_HIP_CHECK(hipGetLastError());
+  STEREO_HIP_CHECK(hipDeviceSynchronize());
+}
+
 void finish_inputs(stereo_trws_plan *P) {
   // New inputs start a new minimisation: the forward sweep of the next iteration has usually run
   // already with the OLD inputs (persistent_iteration fuses it with the primal pass), so the
@@ -3105,12 +3228,15 @@ void finish_inputs(stereo_trws_plan *P) {
   if (P->pos) {
     P->d_perm_pos.alloc(P->K);
     run_argsort(P->pos, P->d_perm_pos.p, P->K, 1, nullptr);
+    fix_equal_positions(P->pos, P->d_perm_pos.p, P->K, 1);
     P->d_perm_q.release(); P->d_perm_qp.release();
   } else {
     P->d_perm_q.alloc((size_t)P->E * P->K);
     P->d_perm_qp.alloc((size_t)P->E * P->K);
     run_argsort(P->q, P->d_perm_q.p, P->K, P->E, nullptr);
     run_argsort(P->qprim, P->d_perm_qp.p, P->K, P->E, nullptr);
+    fix_equal_positions(P->q, P->d_perm_q.p, P->K, P->E);
+    fix_equal_positions(P->qprim, P->d_perm_qp.p, P->K, P->E);
   }
   STEREO_HIP_CHECK(hipDeviceSynchronize());
   // shared positions that are finite and strictly ascending: truncation window in index steps
@@ -3848,6 +3974,53 @@ int stereo_trws_plan_counters(stereo_trws_plan *P, int64_t *serial_messages, int
   if (serial_messages) *serial_messages = (int64_t)v;
   if (reset && hipMemset(P->d_fallbacks.p, 0, sizeof(v)) != hipSuccess) return 1;
   return 0;
+}
+
+int stereo_trws_messages(int kernel, int K, int64_t M, const double *Di, const double *gamma, const double *msg_in,
+                         const double *q_source, const double *q_dest, const double *alpha, double lambda,
+                         int certificate, int window, const double *shared_positions, double *msg_out,
+                         double *vmin, int32_t *used_serial, char *err, size_t errcap) {
+  if (kernel != 1 && kernel != 2) return fail("Unsupported kernel", err, errcap);
+  if (K < 1 || K > kWave || M < 1) return fail("stereo_trws_messages: K must be in [1, 64], M >= 1", err, errcap);
+  if (!Di || !gamma || !msg_in || !q_source || !q_dest || !alpha || !msg_out || !vmin)
+    return fail("stereo_trws_messages: NULL argument", err, errcap);
+  if (stereo_hip_device_count() < 1) return fail("stereo_trws_messages: no HIP device available", err, errcap);
+  try {
+    const size_t MK = (size_t)M * K;
+    DevBuf<double> dD, dg, dm, dqs, dqd, da, dout, dv;
+    DevBuf<uint16_t> dperm;
+    DevBuf<int32_t> dser;
+    DevBuf<unsigned long long> dfb;
+    dD.upload(Di, MK); dg.upload(gamma, M); dm.upload(msg_in, MK); dqs.upload(q_source, MK); dqd.upload(q_dest, MK);
+    da.upload(alpha, M); dout.alloc(MK); dv.alloc(M); dperm.alloc(MK); dser.alloc(M); dfb.alloc(4096);
+    STEREO_HIP_CHECK(hipMemset(dfb.p, 0, sizeof(unsigned long long) * 4096));
+    run_argsort(dqs.p, dperm.p, K, M, nullptr);
+    fix_equal_positions(dqs.p, dperm.p, K, M);
+    DevParams p{};
+    p.K = K; p.Kp = (K + 1) & ~1; p.kernel = kernel; p.lambda = lambda; p.certificate = certificate ? 1 : 0;
+    p.fallbacks = dfb.p;
+    if (shared_positions) { p.pos_first = shared_positions[0]; p.pos_last = shared_positions[K - 1]; }
+    if (kernel == 2 && shared_positions) {
+      p.pos_gap = std::numeric_limits<double>::infinity();
+      for (int k = 1; k < K; ++k) p.pos_gap = std::min(p.pos_gap, shared_positions[k] - shared_positions[k - 1]);
+    }
+    if (const char *dbg = std::getenv("STEREO_HIP_TRWS_DEBUG")) p.debug = std::atoi(dbg);
+    const unsigned grid = (unsigned)std::min<int64_t>(M, 4096);
+    if (kernel == 1)
+      hipLaunchKernelGGL(trws_messages_kernel<1>, dim3(grid), dim3(kWave), 0, 0, p, K, M, dD.p, dg.p, dm.p, dqs.p, dqd.p,
+                         da.p, dperm.p, shared_positions ? window : -1, dout.p, dv.p, dser.p, dfb.p);
+    else
+      hipLaunchKernelGGL(trws_messages_kernel<2>, dim3(grid), dim3(kWave), 0, 0, p, K, M, dD.p, dg.p, dm.p, dqs.p, dqd.p,
+                         da.p, dperm.p, shared_positions ? window : -1, dout.p, dv.p, dser.p, dfb.p);
+    STEREO_HIP_CHECK(hipGetLastError());
+    STEREO_HIP_CHECK(hipDeviceSynchronize());
+    STEREO_HIP_CHECK(hipMemcpy(msg_out, dout.p, sizeof(double) * MK, hipMemcpyDeviceToHost));
+    STEREO_HIP_CHECK(hipMemcpy(vmin, dv.p, sizeof(double) * M, hipMemcpyDeviceToHost));
+    if (used_serial) STEREO_HIP_CHECK(hipMemcpy(used_serial, dser.p, sizeof(int32_t) * M, hipMemcpyDeviceToHost));
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
 }
 
 int stereo_trws_plan_path(stereo_trws_plan *P) {

@@ -285,3 +285,23 @@ def simulate_schedule(sched, workgroups, visit=1.0, handover=0.0):
             heapq.heappush(free_at, run_time[k])
             start_next()
     return float(done_t.max()), finished == R
+
+
+def messages(kernel, Di, gamma, msg_in, q_source, q_dest, alpha, lam, certificate=True, window=-1,
+             shared_positions=None):
+    """M message updates on the device (stereo_trws_messages): arrays are M x K (row = message),
+    gamma / alpha length M.  Returns (msg_out M x K, vmin M, used_serial M)."""
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    Di, msg_in, q_source, q_dest = c(Di), c(msg_in), c(q_source), c(q_dest)
+    M, K = Di.shape
+    gamma, alpha = c(np.broadcast_to(gamma, (M,))), c(np.broadcast_to(alpha, (M,)))
+    out, vmin, ser = np.zeros((M, K)), np.zeros(M), np.zeros(M, np.int32)
+    sp = c(shared_positions) if shared_positions is not None else None
+    err = _lib.errbuf()
+    rc = _lib.lib().stereo_trws_messages(C.c_int(int(kernel)), C.c_int(K), C.c_int64(M), _ptr(Di), _ptr(gamma),
+                                         _ptr(msg_in), _ptr(q_source), _ptr(q_dest), _ptr(alpha), C.c_double(float(lam)),
+                                         C.c_int(int(bool(certificate))), C.c_int(int(window)),
+                                         _ptr(sp) if sp is not None else None, _ptr(out), _ptr(vmin),
+                                         _ptr(ser, C.c_int32), err, C.c_size_t(len(err)))
+    _lib.check(rc, err)
+    return out, vmin, ser

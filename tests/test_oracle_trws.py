@@ -150,3 +150,24 @@ def test_unsupported_kernel_and_modes(oracle):
     a = oracle.trws(1, p["unary"], p["conn"], p["q"], p["qprim"], p["alphas"], 1.0, 3, 0.0, mode=0)
     b = oracle.trws(1, p["unary"], p["conn"], p["q"], p["qprim"], p["alphas"], 1.0, 3, 0.0, mode=1)
     assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]  # tie-free data: both message forms agree
+
+
+def test_restated_envelope_equals_reference_classes_on_adversarial_messages(oracle):
+    """tests/adversarial.py (near-tangent cones, ramps, vTrunc ties, near-duplicate positions): the
+    oracle's envelope restatement against the reference's own type classes, bit for bit."""
+    if not oracle.have_ref_types():
+        pytest.skip("oracle/_ref/libref_trws_types.so not present")
+    import adversarial
+    n = 0
+    for seed in range(16):
+        kernel = 1 + seed % 2
+        K = (7, 33, 60, 64)[(seed // 2) % 4]
+        b = adversarial.batch(seed, kernel, K, 150)
+        for m in range(150):
+            args = (kernel, b["Di"][m], float(b["gamma"][m]), b["msg"][m], b["qd"][m], b["qs"][m],
+                    float(b["alpha"][m]), b["lam"], 0, 0)
+            a, va = oracle.update_message(*args, impl="envelope")
+            r, vr = oracle.update_message(*args, impl="ref")
+            assert np.array_equal(a, r) and va == vr, (seed, m)
+            n += 1
+    assert n == 2400

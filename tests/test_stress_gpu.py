@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("tool,seed", [("stress_trws.py", 11), ("stress_rd.py", 12), ("stress_improve.py", 13)])
+@pytest.mark.parametrize("tool,seed", [("stress_trws.py", 11), ("stress_rd.py", 12), ("stress_improve.py", 13),
+                                       ("stress_certificate.py", 14)])
 def test_randomised_parity(tool, seed, hip, oracle):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "8", str(seed)], capture_output=True,
                        text=True, timeout=300)
