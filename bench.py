@@ -236,6 +236,19 @@ def main():
     sweep_ms, sweep_launches = plan.stats()
     serial_msgs = plan.serial_messages()
     _, energy, lb, iters = plan.result(want_labels=False)
+    # labelled extra, never `value`: the same volume with the nodes visited in index order
+    # (STEREO_TRWS_ORDER_INDEX: MRFEnergy without SetAutomaticOrdering; H + W - 1 dependency levels,
+    # no serial border chain) -- a valid TRW-S schedule whose results are not the gateway's
+    from stereo_amd.trws import ORDER_INDEX
+    alt = TrwsPlan(1, K, N, conn.T, message_mode=(0 if args.message_mode == "exact" else 1) | ORDER_INDEX)
+    alt.bind_device(d_unary.data_ptr(), d_alpha.data_ptr(), 8.0, d_positions=d_pos.data_ptr())
+    alt.iterate(args.warmup, max_relgap=NEVER)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    alt.iterate(args.steps, max_relgap=NEVER)
+    alt_dt = time.perf_counter() - t1
+    _, alt_en, alt_lb, _ = alt.result(want_labels=False)
+    alt.close()
 
     if rank == 0:
         a = analyze(N, conn.T)
@@ -276,6 +289,11 @@ def main():
             "serial_envelope_messages": serial_msgs,
             "serial_envelope_fraction": serial_msgs / (2.0 * E * max(args.steps, 1)),  # 2E message updates per iteration
             "final_energy": energy, "final_lower_bound": lb, "iterations_done": iters,
+            "index_order_option": {"iterations_per_s": args.steps / alt_dt, "ms_per_step": alt_dt / args.steps * 1e3,
+                                   "energy": alt_en, "lower_bound": alt_lb,
+                                   "note": "STEREO_TRWS_ORDER_INDEX on rank 0's volume: node index order (MRFEnergy without "
+                                           "SetAutomaticOrdering), H+W-1 dependency levels; NOT the gateway's labels -- "
+                                           "reported next to the headline, never as `value`"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": {4: "trws_pipe2_kernel", 3: "trws_wide_kernel", 2: "trws_pipe_kernel", 1: "trws_persistent_kernel", 0: "trws_sweep_kernel (per level)"}[plan.path()]

@@ -69,6 +69,12 @@ typedef struct stereo_trws_plan stereo_trws_plan;
 /* flags */
 #define STEREO_TRWS_MESSAGES_EXACT 0   /* reference lower-envelope semantics (default) */
 #define STEREO_TRWS_MESSAGES_MINPLUS 1 /* plain min-plus; equal unless exact ties occur */
+/* OR-ed into message_mode: visit the nodes in index order -- MRFEnergy's order when the gateway
+ * does NOT call SetAutomaticOrdering (trws_mex.cpp:121; nodes keep the order of AddNode,
+ * MRFEnergy.cpp:37-76).  On an image grid the dependency DAG then has H + W - 1 anti-diagonal
+ * levels and no serial border chain (the gateway's order: ~2 (H + W)): a faster, equally valid
+ * TRW-S schedule whose labels / energies are NOT the gateway's.  Explicit opt-in only. */
+#define STEREO_TRWS_ORDER_INDEX 0x100
 
 int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint32_t *conn,
                             int message_mode, stereo_trws_plan **plan, char *err,

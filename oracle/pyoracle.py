@@ -87,7 +87,7 @@ def _conn(conn):
 # --------------------------------------------------------------------- TRW-S
 
 def trws(kernel, unary, conn, q, qprim, alphas, tol, maxiter=1000, max_relgap=0.0, mode=0,
-         use_ref_types=False, want_trace=False):
+         use_ref_types=False, want_trace=False, ordering=0):
     """unary (N,K), q/qprim (E,K) row-major == MATLAB K x N / K x E column-major.
     conn zero-based (E,2).  Returns labels (1-based float64 like the gateway),
     energy, lower bound, iterations [, trace]."""
@@ -109,11 +109,13 @@ def trws(kernel, unary, conn, q, qprim, alphas, tol, maxiter=1000, max_relgap=0.
         msg_fn = C.cast(r.ref_update_message, C.c_void_p)
         col_fn = C.cast(r.ref_add_column, C.c_void_p)
     trace = np.zeros((int(maxiter), 3)) if want_trace else None
+    lib().oracle_set_ordering(C.c_int(int(ordering)))   # 0: SetAutomaticOrdering, 1: node index order
     rc = lib().oracle_trws(C.c_int(int(kernel)), pu, pc, pq, pqp, pa, C.c_double(tol),
                            C.c_double(maxiter), C.c_double(max_relgap), C.c_int(K),
                            C.c_int64(N), C.c_int64(E), C.c_int(mode), msg_fn, col_fn,
                            lab.ctypes.data_as(_dp), C.byref(en), C.byref(lb), C.byref(it),
                            trace.ctypes.data_as(_dp) if want_trace else None)
+    lib().oracle_set_ordering(C.c_int(0))
     if rc:
         raise RuntimeError("oracle_trws failed rc=%d" % rc)
     out = (lab, en.value, lb.value, it.value)

@@ -401,6 +401,17 @@ static double do_update(solver_t *S, int64_t e, const double *Di, double gamma, 
   return vmin;
 }
 
+/* Node order of the NEXT oracle_trws call (test infrastructure): 0 = SetAutomaticOrdering
+ * (trws_mex.cpp:121, the reference gateway), 1 = node index order -- what MRFEnergy uses when
+ * SetAutomaticOrdering is NOT called (nodes are ordered as they were added, MRFEnergy.cpp:37-76);
+ * on the image grid its dependency DAG has H + W - 1 anti-diagonal levels.  A different, equally
+ * valid TRW-S schedule: results differ from the gateway's, so it is an explicitly labelled option. */
+static int g_ordering = 0;
+void oracle_set_ordering(int ordering) { g_ordering = ordering; }
+static void graph_order_index(graph_t *g) {
+  for (int64_t i = 0; i < g->N; ++i) { g->order[i] = i; g->rank[i] = i; }
+}
+
 /* Full solver = trws_mex.cpp:27-147 behind the C boundary.
  * unary K x N, q/qprim K x E (label fastest = MATLAB column major), conn 2 x E
  * zero based, alphas E.  labelling is 1-based like the gateway's.
@@ -418,7 +429,8 @@ int oracle_trws(int kernel, const double *unary, const uint32_t *conn, const dou
   graph_t g;
   int rc = graph_init(&g, N, E, conn);
   if (rc) { graph_free(&g); return rc; }
-  if (graph_order(&g)) { graph_free(&g); return 3; }
+  if (g_ordering == 1) graph_order_index(&g);
+  else if (graph_order(&g)) { graph_free(&g); return 3; }
   graph_orient(&g);
 
   solver_t S;

@@ -3325,6 +3325,8 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
   if (nstrips > 1 && !owner && !share) return fail("stereo_trws_plan_create: strips need an owner per node", err, errcap);
   if (kernel != 1 && kernel != 2) return fail("Unsupported kernel", err, errcap);
   if (K < 1 || K > 8 * kWave) return fail("stereo_trws: K must be in [1, 512]", err, errcap);
+  const int ordering = (message_mode & STEREO_TRWS_ORDER_INDEX) ? 1 : 0;
+  message_mode &= ~STEREO_TRWS_ORDER_INDEX;
   if (message_mode != STEREO_TRWS_MESSAGES_EXACT && message_mode != STEREO_TRWS_MESSAGES_MINPLUS)
     return fail("stereo_trws: unknown message mode", err, errcap);
   if (stereo_hip_device_count() < 1)
@@ -3356,21 +3358,21 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
       P->graph = share->graph;
     } else {
       static std::mutex cache_mutex;
-      static struct { int64_t N = -1, E = -1, capacity = -1, cus = -1; int nstrips = 1; std::vector<uint32_t> conn; std::vector<int32_t> owner;
+      static struct { int64_t N = -1, E = -1, capacity = -1, cus = -1; int nstrips = 1, ordering = 0; std::vector<uint32_t> conn; std::vector<int32_t> owner;
                       std::shared_ptr<const TrwsGraph> g; } cache;
       std::lock_guard<std::mutex> lock(cache_mutex);
       const bool hit = cache.g && cache.N == N && cache.E == E && cache.capacity == capacity && cache.cus == P->cus &&
-                       cache.nstrips == nstrips &&
+                       cache.nstrips == nstrips && cache.ordering == ordering &&
                        std::memcmp(cache.conn.data(), conn, sizeof(uint32_t) * 2 * (size_t)E) == 0 &&
                        (nstrips == 1 || std::memcmp(cache.owner.data(), owner, sizeof(int32_t) * (size_t)N) == 0);
       if (hit) {
         P->graph = cache.g;
       } else {
         auto fresh = std::make_shared<TrwsGraph>();
-        if (!build_trws_graph(N, E, conn, *fresh, gerr, capacity, nstrips > 1 ? owner : nullptr, nstrips, P->cus)) return fail(gerr, err, errcap);
+        if (!build_trws_graph(N, E, conn, *fresh, gerr, capacity, nstrips > 1 ? owner : nullptr, nstrips, P->cus, ordering)) return fail(gerr, err, errcap);
         P->graph = fresh;
         if (N <= (1 << 20)) {  // (the descriptors of a 3000 x 2000 grid are 3 GB: not worth keeping)
-          cache.N = N; cache.E = E; cache.capacity = capacity; cache.cus = P->cus; cache.nstrips = nstrips;
+          cache.N = N; cache.E = E; cache.capacity = capacity; cache.cus = P->cus; cache.nstrips = nstrips; cache.ordering = ordering;
           cache.conn.assign(conn, conn + 2 * (size_t)E); cache.g = fresh;
           if (nstrips > 1) cache.owner.assign(owner, owner + N); else cache.owner.clear();
         } else {

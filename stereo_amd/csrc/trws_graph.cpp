@@ -58,7 +58,7 @@ class Boundary {
 #define TICK(name) do { if (std::getenv("STEREO_HIP_GRAPH_VERBOSE")) { auto now_ = std::chrono::steady_clock::now(); std::fprintf(stderr, "[graph] -> %s: %.1f ms\n", name, std::chrono::duration<double, std::milli>(now_ - tick_).count()); tick_ = now_; } } while (0)
 bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
                       std::string &err, int64_t max_resident_runs, const int32_t *owner_in, int nstrips,
-                      int64_t certainly_resident) {
+                      int64_t certainly_resident, int ordering) {
   auto tick_ = std::chrono::steady_clock::now();
   if (N <= 0 || E < 0) { err = "build_trws_graph: empty problem"; return false; }
   if (N >= INT32_MAX || E >= INT32_MAX) { err = "build_trws_graph: more than 2^31 nodes/edges"; return false; }
@@ -88,9 +88,11 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
     ++deg[a]; ++deg[b];
   }
   TICK("0");
-  // ---- SetAutomaticOrdering
+  // ---- SetAutomaticOrdering (or, as a labelled option, the node index order)
   g.order.resize(N); g.rank.assign(N, -1);
-  {
+  if (ordering == 1) {
+    for (int64_t i = 0; i < N; ++i) { g.order[i] = (int32_t)i; g.rank[i] = (int32_t)i; }
+  } else {
     const int max_deg = *std::max_element(deg.begin(), deg.end());
     std::vector<uint8_t> where(N, 2);  // 2 untouched list, 1 boundary, 0 ordered
     std::vector<int64_t> stamp(N, 0);

@@ -90,7 +90,12 @@ struct TrwsGraph {
 // certainly_resident: workgroups sure to be resident whatever the kernel's LDS use (the CU count).
 bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
                       std::string &err, int64_t max_resident_runs = 0,
-                      const int32_t *owner = nullptr, int nstrips = 1, int64_t certainly_resident = 256);
+                      const int32_t *owner = nullptr, int nstrips = 1, int64_t certainly_resident = 256,
+                      int ordering = 0);
+// ordering: 0 = SetAutomaticOrdering (ordering.cpp:7-157, what the gateway calls, trws_mex.cpp:121);
+// 1 = node index order, MRFEnergy's order when SetAutomaticOrdering is not called (nodes in the
+// order they were added, MRFEnergy.cpp:37-76).  On the image grid: H + W - 1 anti-diagonal levels,
+// no serial border chain.  Another valid TRW-S schedule, not the gateway's results.
 
 // Descriptor words added for strips (layout of the rest: trws.hip NodeDesc)
 //   word 43: bits 0-7 outgoing message k goes to the neighbouring strip; bits 8-15 which one

@@ -17,6 +17,7 @@ from ._lib import StereoHipError
 
 MESSAGES_EXACT = 0
 MESSAGES_MINPLUS = 1
+ORDER_INDEX = 0x100   # OR into message_mode: node index order instead of SetAutomaticOrdering (stereo_hip.h)
 
 
 def _f(a):

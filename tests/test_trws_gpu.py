@@ -158,3 +158,36 @@ def test_teddy_size_matches_oracle(kernel, K, general, hip, oracle):
     assert plan.path() == 2
     assert np.array_equal(lab, ref[0]), "labels differ at %d nodes" % int((lab != ref[0]).sum())
     assert en == ref[1] and lb == ref[2] and it == ref[3]
+
+
+INDEX_ORDER = [
+    # seed, H, W, K, kernel, kind, integer, tol, iters
+    (401, 12, 14, 8, 1, "general", False, 1.5, 5),
+    (402, 20, 30, 16, 2, "general", False, 3.0, 4),
+    (403, 10, 12, 12, 1, "fronto", True, 3.0, 6),
+    (404, 9, 8, 100, 1, "general", False, 3.0, 3),
+    (405, 30, 26, 200, 1, "fronto", False, 8.0, 3),
+]
+
+
+@pytest.mark.parametrize("case", INDEX_ORDER, ids=[str(c[0]) for c in INDEX_ORDER])
+def test_index_order_option_matches_oracle_in_that_order(case, hip, oracle):
+    """STEREO_TRWS_ORDER_INDEX: MRFEnergy's node order when SetAutomaticOrdering is not called
+    (H + W - 1 dependency levels on a grid).  Not the gateway's results -- an explicit option -- but
+    bit-identical to the oracle run in the same order; and different from the gateway order's."""
+    from stereo_amd.trws import TrwsPlan, ORDER_INDEX
+    seed, H, W, K, kernel, kind, integer, tol, iters = case
+    p = trws_problem(seed, H, W, K, kind=kind, integer=integer)
+    lab_o, en_o, lb_o, it_o = oracle.trws(kernel, p["unary"], p["conn"], p["q"], p["qprim"], p["alphas"], tol,
+                                          iters, -1e300, mode=1, ordering=1)
+    plan = TrwsPlan(kernel, K, H * W, p["conn"].T, message_mode=ORDER_INDEX)
+    if kind == "fronto":
+        plan.upload(p["unary"].T, p["alphas"], tol, positions=np.arange(K, dtype=np.float64))
+    else:
+        plan.upload(p["unary"].T, p["alphas"], tol, q=p["q"].T, qprim=p["qprim"].T)
+    assert plan.info()["levels"] == H + W - 1
+    plan.iterate(iters, max_relgap=-1e300)
+    lab, en, lb, it = plan.result()
+    assert it == it_o and np.array_equal(lab, lab_o) and en == en_o and lb == lb_o
+    ref = oracle.trws(kernel, p["unary"], p["conn"], p["q"], p["qprim"], p["alphas"], tol, iters, -1e300, mode=1)
+    assert ref[2] != lb_o     # (the gateway's order gives another bound after the same iterations)

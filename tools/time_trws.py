@@ -1,5 +1,5 @@
 """Development tool: time TRW-S iterations of a synthetic volume for a given kernel / size.
-usage: time_trws.py [kernel=1] [H=375] [W=450] [K=60] [tol=8] [iters=10] [general=0] [volume=noise|ncc]
+usage: time_trws.py [kernel=1] [H=375] [W=450] [K=60] [tol=8] [iters=10] [general=0] [volume=noise|ncc] [index_order=0]
 general=1: per-edge positions q != qprim (label k + jitter), as a fusion of K plane proposals has them."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +16,8 @@ K = int(a[3]) if len(a) > 3 else 60
 tol = float(a[4]) if len(a) > 4 else 8.0
 iters = int(a[5]) if len(a) > 5 else 10
 general = int(a[6]) if len(a) > 6 else 0
-volume = a[7] if len(a) > 7 else "noise"   # "ncc": NCC cost volume of a synthetic pair (bench.py's workload)
+volume = a[7] if len(a) > 7 else "noise"
+index_order = int(a[8]) if len(a) > 8 else 0   # 1: STEREO_TRWS_ORDER_INDEX (not the gateway's node order)   # "ncc": NCC cost volume of a synthetic pair (bench.py's workload)
 dev = torch.device("cuda", 0)
 conn = grid_conn(H, W); E = conn.shape[0]; N = H * W
 if volume == "ncc":
@@ -27,7 +28,7 @@ if volume == "ncc":
     d_unary = torch.from_numpy(np.ascontiguousarray(40.0 * (1.0 - ncc.T))).to(dev)
 else:
     d_unary = torch.from_numpy(synthetic_volume(H, W, K, seed=1)).to(dev)
-plan = TrwsPlan(kernel, K, N, conn.T)
+plan = TrwsPlan(kernel, K, N, conn.T, message_mode=0x100 if index_order else 0)
 d_alpha = torch.ones(E, dtype=torch.float64, device=dev)
 d_pos = torch.arange(K, dtype=torch.float64, device=dev)
 if general:
