@@ -144,7 +144,7 @@ int stereo_trws_messages(int kernel, int K, int64_t M, const double *Di, const d
                          int32_t *used_serial, char *err, size_t errcap);
 
 /* Diagnostics: which sweep implementation the plan's current inputs select.
- * 0 level-synchronous launches, 1 generic persistent kernel, 2 pipelined kernel (K <= 64),
+ * 1 generic persistent kernel, 2 pipelined kernel (K <= 64),
  * 3 wide pipelined kernel (64 < K <= 256, shared strictly ascending positions),
  * 4 two-labels-per-lane pipelined kernel (64 < K <= 128, linear kernel, any positions).
  * All give identical results.  Negative on a NULL plan. */

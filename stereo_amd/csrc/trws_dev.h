@@ -1,0 +1,814 @@
+// Device-side common part of the TRW-S kernels (see trws_plan.hip for the overview): launch
+// parameters, hand-over accesses, wave reductions, the message update routines (certified min-plus
+// fast path, second look, serial lower-envelope construction) and the descriptor decoding shared
+// by the sweep kernel families (trws_generic.hip, trws_pipe.hip, trws_pipe2.hip, trws_wide.hip).
+// Everything but the launch-parameter structs has internal linkage (anonymous namespace).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "trws_graph.h"
+
+namespace stereo {
+
+struct DevParams {
+  int K, Kp, kernel;
+  double lambda;
+  const double *unary;
+  double *msg;
+  const double *q, *qprim;          // per edge, or null when `pos` is used
+  const double *pos;                // shared positions
+  const uint16_t *perm_q, *perm_qp;  // per edge sort permutations (null with pos)
+  const uint16_t *perm_pos;
+  const double *alpha;
+  const uint8_t *mdir;
+  const int32_t *tail;
+  const int32_t *order;
+  const int32_t *fptr, *fidx, *bptr, *bidx;
+  const double *gamma;
+  const int32_t *lb_pos_node, *lb_pos_edge;
+  double *lbterms, *eterms;
+  int32_t *x;
+  // persistent dataflow sweeps
+  const int32_t *run_ptr[2];
+  const int32_t *run_order[2];  // ticket -> run (nullptr: identity)
+  int nruns[2];
+  const int32_t *dep_ptr[2], *dep_rank[2];
+  const int8_t *in_slot[2];
+  int32_t *done;    // per rank: epoch of the last completed visit
+  int32_t *ticket;  // run dispenser of the current launch
+  int32_t *abort_flag;
+  int N;
+  unsigned long long *fallbacks;  // messages that needed the serial envelope (diagnostics)
+  int certificate;                // 0: always run the serial envelope
+  unsigned long long *prof;       // optional: 8 phase-cycle accumulators (development)
+  const int32_t *desc[2];         // packed node descriptors of the pipelined kernels
+  int prof_run;
+  int debug;  // development switches: 2 / 4 profile backward / forward sweeps only, 256 no windowed paths,
+              // 512 serial envelopes by the lane-read loop instead of the mask construction
+              // (none of them changes a result)
+  unsigned long long *timeline;  // optional [2][nruns][2] wall-clock stamps (development)
+  int window;  // wide kernel: sources within lambda of a destination lie within +-window indices
+  double uniform_step;  // wide kernel: != 0 if pos[k+d] - pos[k] == d * step exactly for |d| <= window <= 16
+  int win_ok;  // shared strictly ascending positions and window <= 16: windowed min-plus allowed
+  double pos_gap;  // smallest distance of two neighbouring shared positions (ascending case)
+  double pos_first, pos_last;  // ... their two ends
+  // Row strips (one plan per strip, normally one per GPU): a plan dispenses only its own runs and
+  // writes what the neighbouring strips read -- messages on edges that cross the boundary, the
+  // completion flag and the label of a boundary node -- straight into THEIR arrays (same index
+  // space on every strip; over xGMI when the neighbour is another GPU).  [0] previous, [1] next strip.
+  int ntickets[2];
+  double *peer_msg0, *peer_msg1;      // (scalars, not arrays: an index computed at run time would put
+  int32_t *peer_done0, *peer_done1;   //  the whole parameter block into scratch memory)
+  int32_t *peer_x0, *peer_x1;
+};
+
+// Several strips of one problem in ONE launch (row strips that share a device: logical strips, or
+// a process that owns more than one band): workgroup b works for strip s with first[s] <= b <
+// first[s + 1], on that strip's parameters.  One launch, so that all of them are resident
+// together whatever the runtime does with streams (strips wait for each other in both directions).
+constexpr int kMaxGroup = 16;
+struct GroupArgs {
+  const DevParams *pp;
+  int n;
+  int first[kMaxGroup + 1];
+};
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kWaveVecs = 5;  // K-vectors of LDS scratch per wave
+
+// ---- hand-over accesses (sc0 sc1): data handed between workgroups inside one launch never sits
+// in a per-CU L1 or a non-coherent L2 (cdna_hip_programming.md G16, R1/R2).  System scope, not
+// agent scope: with row strips the other workgroup may run on the neighbouring GPU and write into
+// this GPU's memory over xGMI; on one GPU both scopes cost the same (measured: 68.6 vs 68.6
+// iterations/s at 450x375x60, 132.2 vs 132.2 ms at 1500x1000x256).
+#ifndef STEREO_HANDOVER_SCOPE
+#define STEREO_HANDOVER_SCOPE __HIP_MEMORY_SCOPE_SYSTEM
+#endif
+__device__ __forceinline__ double ld_sc1(const double *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, STEREO_HANDOVER_SCOPE);
+}
+__device__ __forceinline__ void st_sc1(double *p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, STEREO_HANDOVER_SCOPE);
+}
+__device__ __forceinline__ int ld_sc1(const int32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, STEREO_HANDOVER_SCOPE);
+}
+__device__ __forceinline__ void st_sc1(int32_t *p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, STEREO_HANDOVER_SCOPE);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+// min / max of two doubles as ONE instruction.  std::fmin / fmax cost ~1.6x as much here: in IEEE
+// mode the compiler puts a canonicalising v_max_f64 x, x, x in front of every v_min / v_max
+// (tools/micro_valu.hip: 13 vs 8 cycles per wave instruction).  Same result for every non-NaN input
+// (the sign of a zero result may differ, which no comparison or sum downstream can see).
+__device__ __forceinline__ double min_raw(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double max_raw(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// wave-uniform predicate -> scalar branch
+#define UNI(c) (__builtin_amdgcn_ballot_w64(c) != 0)
+
+// ---- DPP wave reductions (gfx9 row_bcast forms): ~20 VALU instead of 12 ds_bpermute.
+// The combined value ends up in lane 63 and is broadcast with v_readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+}
+#define DPP_REDUCE_STEPS(STEP) \
+  STEP(0xB1, 0xF) STEP(0x4E, 0xF) STEP(0x141, 0xF) STEP(0x140, 0xF) STEP(0x142, 0xA) STEP(0x143, 0xC)
+__device__ __forceinline__ double wave_min_dpp(double v) {
+#define STEP(C, M) { const double o = dpp_f64<C, M>(v); v = min_raw(o, v); }
+  DPP_REDUCE_STEPS(STEP)
+#undef STEP
+  return readlane_f64(v, 63);
+}
+__device__ __forceinline__ double wave_max_dpp(double v) {
+#define STEP(C, M) { const double o = dpp_f64<C, M>(v); v = max_raw(o, v); }
+  DPP_REDUCE_STEPS(STEP)
+#undef STEP
+  return readlane_f64(v, 63);
+}
+// minimum of `a` and maximum of `b` over the wave in one interleaved pass (two independent chains)
+__device__ __forceinline__ void wave_min_max_dpp(double &a, double &b) {
+#define STEP(C, M) { const double oa = dpp_f64<C, M>(a), ob = dpp_f64<C, M>(b); a = min_raw(oa, a); b = max_raw(ob, b); }
+  DPP_REDUCE_STEPS(STEP)
+#undef STEP
+  a = readlane_f64(a, 63); b = readlane_f64(b, 63);
+}
+// lexicographic (value, index) minimum -> index of the FIRST minimum, uniform
+__device__ __forceinline__ int wave_argmin_dpp(double v, int i) {
+#define STEP(C, M) { const double ov = dpp_f64<C, M>(v); const int oi = dpp_i32<C, M>(i); \
+                     if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; } }
+  DPP_REDUCE_STEPS(STEP)
+#undef STEP
+  return __builtin_amdgcn_readlane(i, 63);
+}
+
+
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double o = __shfl_xor(v, off, kWave);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+// (value, index) lexicographic minimum: the FIRST minimum wins
+// (typeStereoLinear.h:242-249 strict '>').
+__device__ __forceinline__ void wave_argmin(double &v, int &i) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double ov = __shfl_xor(v, off, kWave);
+    int oi = __shfl_xor(i, off, kWave);
+    if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+
+template <int KERNEL>
+__device__ __forceinline__ double pair_cost(double alpha, double d, double h) {
+  // typeStereoLinear.h:474 m_alpha*std::abs(d) + hj ; typeStereoQuadratic.h:484 m_alpha*val*val + hj
+  if (KERNEL == 1) return alpha * fabs(d) + h;
+  return alpha * d * d + h;
+}
+
+// Serial construction of the lower envelope, executed by ONE lane, exactly as
+// typeStereoLinear.h:401-460 / typeStereoQuadratic.h:407-470 do it, including
+// their tie and "numerical stability" behaviour (stale breakpoints survive pops).
+// Hs/Qs: heights / positions in ascending position order.  Stack entries are
+// stored by value (sh, sq) with breakpoints z.
+template <int KERNEL>
+__device__ void build_envelope(int K, double alpha, const double *Hs, const double *Qs,
+                               double *sh, double *sq, double *z) {
+  const double inf = __builtin_huge_val();
+  int top = 0;
+  double hj = Hs[0], qj = Qs[0], zt = -inf;
+  sh[0] = hj; sq[0] = qj; z[0] = -inf; z[1] = inf;
+  for (int k = 1; k < K; ++k) {
+    const double hk = Hs[k], qk = Qs[k];
+    for (int guard = k; guard >= 0; --guard) {
+      if (KERNEL == 1) {
+        const double dist = alpha * fabs(qk - qj);
+        if (dist + hk < hj) {
+          if (top == 0) {
+            sh[0] = hk; sq[0] = qk; z[0] = -inf; z[1] = inf; hj = hk; qj = qk;
+            break;  // the reference re-compares the new bottom with itself and breaks
+          }
+          --top; hj = sh[top]; qj = sq[top];
+        } else if (dist + hj <= hk) {
+          break;
+        } else {
+          const double s = ((hk - hj) + alpha * (qk + qj)) / (2 * alpha);
+          if (s >= qk) break;
+          if (s <= qj) break;
+          ++top; sh[top] = hk; sq[top] = qk; z[top] = s; z[top + 1] = inf; hj = hk; qj = qk;
+          break;
+        }
+      } else {
+        if (qk - qj < 1e-8) {
+          if (hj > hk) {
+            if (top == 0) {
+              sh[0] = hk; sq[0] = qk; z[0] = -inf; z[1] = inf; hj = hk; qj = qk; zt = -inf;
+              break;
+            }
+            --top; hj = sh[top]; qj = sq[top]; zt = z[top];
+          } else {
+            break;
+          }
+        } else {
+          const double s = ((hk + alpha * qk * qk) - (hj + alpha * qj * qj)) / (2 * alpha * (qk - qj));
+          if (s <= zt) {
+            --top;
+            if (top < 0) { top = 0; break; }  // unreachable for finite input (z[0] = -inf)
+            hj = sh[top]; qj = sq[top]; zt = z[top];
+          } else {
+            ++top; sh[top] = hk; sq[top] = qk; z[top] = s; z[top + 1] = inf; hj = hk; qj = qk; zt = s;
+            break;
+          }
+        }
+      }
+    }
+  }
+}
+
+// The same construction with the whole state in registers, for K <= 64: lane k
+// holds the k-th sorted source (hs, qs); afterwards lane j holds stack slot j
+// (sh, sq) and zz = z[j+1].  All arithmetic is wave-uniform (operands come from
+// v_readlane), so every lane computes exactly what the reference's scalar code
+// computes; branches are scalar.  Returns the highest slot ever written.
+template <int KERNEL>
+__device__ __forceinline__ int build_envelope_regs(int K, double alpha, double hs, double qs,
+                                                   double &sh, double &sq, double &zz, int lane) {
+  const double inf = __builtin_huge_val();
+  int top = 0, maxtop = 0;
+  double hj = readlane_f64(hs, 0), qj = readlane_f64(qs, 0), zt = -inf;
+  sh = hj; sq = qj; zz = inf;
+  for (int k = 1; k < K; ++k) {
+    const double hk = readlane_f64(hs, k), qk = readlane_f64(qs, k);
+    for (;;) {
+      if (KERNEL == 1) {
+        const double dist = alpha * fabs(qk - qj);
+        if (UNI(dist + hk < hj)) {
+          if (top == 0) {
+            if (lane == 0) { sh = hk; sq = qk; zz = inf; }
+            hj = hk; qj = qk;
+            break;
+          }
+          --top; hj = readlane_f64(sh, top); qj = readlane_f64(sq, top);
+        } else if (UNI(dist + hj <= hk)) {
+          break;
+        } else {
+          const double s = ((hk - hj) + alpha * (qk + qj)) / (2 * alpha);
+          if (UNI(s >= qk)) break;
+          if (UNI(s <= qj)) break;
+          if (lane == top) zz = s;  // z[top+1] = s
+          ++top;
+          if (lane == top) { sh = hk; sq = qk; zz = inf; }
+          hj = hk; qj = qk;
+          break;
+        }
+      } else {
+        if (UNI(qk - qj < 1e-8)) {
+          if (UNI(hj > hk)) {
+            if (top == 0) {
+              if (lane == 0) { sh = hk; sq = qk; zz = inf; }
+              hj = hk; qj = qk; zt = -inf;
+              break;
+            }
+            --top; hj = readlane_f64(sh, top); qj = readlane_f64(sq, top);
+            zt = top == 0 ? -inf : readlane_f64(zz, top - 1);
+          } else {
+            break;
+          }
+        } else {
+          const double s = ((hk + alpha * qk * qk) - (hj + alpha * qj * qj)) / (2 * alpha * (qk - qj));
+          if (UNI(s <= zt)) {
+            if (top == 0) break;  // unreachable for finite input (z[0] = -inf)
+            --top; hj = readlane_f64(sh, top); qj = readlane_f64(sq, top);
+            zt = top == 0 ? -inf : readlane_f64(zz, top - 1);
+          } else {
+            if (lane == top) zz = s;
+            ++top;
+            if (lane == top) { sh = hk; sq = qk; zz = inf; }
+            hj = hk; qj = qk; zt = s;
+            break;
+          }
+        }
+      }
+    }
+    maxtop = top > maxtop ? top : maxtop;
+  }
+  return maxtop;
+}
+
+// ---- the linear-kernel construction without its inner loop -------------------------------------
+// Every comparison of typeStereoLinear.h:401-460 involves the new cone k and the cone j on top of
+// the stack, nothing else -- so all of them can be evaluated up front for source k against ALL
+// sources j at once (lane j), giving three 64-bit masks per k, and the stack itself shrinks to a
+// bit set over source indices (sources arrive in ascending position order and the stack is a
+// subsequence of them: top = highest set bit, pop = clear it).  One trip per source, no dependent
+// chain of lane reads and scalar branches per pop:
+//   m1[j]: dist + hk <  hj   (j is dominated: pop)           typeStereoLinear.h:417-431
+//   m2[j]: dist + hj <= hk   (k is dominated: drop k)         :432-435
+//   m3[j]: s >= qk or s <= qj ("numerical stability": drop k) :444-449
+// with s = ((hk - hj) + alpha (qk + qj)) / (2 alpha).  The two tests on s are made on the numerator:
+// x -> fl(x / c) is monotone, so s >= qk <=> num >= thi(qk) with thi = the smallest double whose
+// quotient reaches qk, and s <= qj <=> num <= tlo(qj) with tlo the largest one whose quotient stays
+// at or below qj; both thresholds are found per lane by stepping ulp-wise from fl(q c) (a handful of
+// divisions per message instead of one per pair).  Slot contents are recorded per lane exactly as
+// the serial code leaves them (stale breakpoints above `top` included): lane t = slot t holds the
+// source stored there and the pair whose crossing is z[t+1]; values are filled in at the end with
+// one vector division.  Returns false (nothing done) on inputs outside the argument above.
+__device__ __forceinline__ double ulp_up(double x) {    // next double above a finite x
+  long long b = __double_as_longlong(x);
+  b = x > 0 ? b + 1 : x < 0 ? b - 1 : 1;                // +-0 -> smallest positive denormal
+  return __longlong_as_double(b);
+}
+__device__ __forceinline__ double ulp_down(double x) {  // next double below a finite x
+  long long b = __double_as_longlong(x);
+  b = x > 0 ? b - 1 : x < 0 ? b + 1 : (long long)0x8000000000000001ull;
+  return __longlong_as_double(b);
+}
+
+__device__ __forceinline__ bool build_envelope_masks(int K, double alpha, double hs, double qs, double &sh,
+                                                     double &sq, double &zz, int lane, int &maxtop_out) {
+  const double inf = __builtin_huge_val();
+  const bool act = lane < K;
+  const double c = 2 * alpha;
+  bool ok = alpha > 0 && c < inf && (!act || (fabs(hs) < inf && fabs(qs) < inf));
+  // thresholds on the numerator (see above); at most kSteps ulp steps from fl(q c), else give up
+  constexpr int kSteps = 6;
+  double thi = qs * c, tlo = thi;
+  ok = ok && (!act || fabs(thi) < 1e300);
+  if (!UNI(!ok)) {
+    // thi: smallest x with fl(x / c) >= qs
+    bool settled = !act;
+    {
+      const bool above = thi / c >= qs;   // start inside the set: walk down to its edge, else walk up into it
+      for (int i = 0; i < kSteps; ++i) {
+        const double nx = above ? ulp_down(thi) : ulp_up(thi);
+        const bool in = nx / c >= qs;
+        if (above) { if (in && !settled) thi = nx; else settled = true; }
+        else { if (!settled) thi = nx; if (in) settled = true; }
+      }
+      if (above) {  // settled only if the last step left the set
+        settled = settled || !(ulp_down(thi) / c >= qs);
+      }
+    }
+    ok = ok && settled;
+    // tlo: largest x with fl(x / c) <= qs
+    settled = !act;
+    {
+      const bool below = tlo / c <= qs;
+      for (int i = 0; i < kSteps; ++i) {
+        const double nx = below ? ulp_up(tlo) : ulp_down(tlo);
+        const bool in = nx / c <= qs;
+        if (below) { if (in && !settled) tlo = nx; else settled = true; }
+        else { if (!settled) tlo = nx; if (in) settled = true; }
+      }
+      if (below) settled = settled || !(ulp_up(tlo) / c <= qs);
+    }
+    ok = ok && settled;
+  }
+  if (UNI(!ok)) return false;
+  unsigned long long A = 1;      // source 0 is the bottom of the stack
+  int top = 0, maxtop = 0;
+  int src = 0, zk = -1, zj = 0;  // lane t: slot t holds source `src`; z[t+1] = crossing of (zk, zj), inf if zk < 0
+  for (int k = 1; k < K; ++k) {
+    const double hk = readlane_f64(hs, k), qk = readlane_f64(qs, k), thik = readlane_f64(thi, k);
+    const double dist = alpha * fabs(qk - qs);
+    const unsigned long long m1 = __builtin_amdgcn_ballot_w64(dist + hk < hs);
+    const unsigned long long m2 = __builtin_amdgcn_ballot_w64(dist + hs <= hk);
+    const double num = (hk - hs) + alpha * (qk + qs);
+    const unsigned long long m3 = __builtin_amdgcn_ballot_w64(num >= thik || num <= tlo);
+    const unsigned long long B = A & ~m1;
+    if (B == 0) {  // every cone on the stack is dominated: k becomes the bottom (typeStereoLinear.h:419-425)
+      A = 1ull << k;
+      if (lane == 0) { src = k; zk = -1; }
+      top = 0;
+      continue;
+    }
+    const int js = 63 - __builtin_clzll(B);   // the cone k meets: the highest one it does not dominate
+    A &= (2ull << js) - 1;                    // (js < k <= 63)
+    top = __builtin_popcountll(A) - 1;
+    if (((m2 | m3) >> js) & 1) continue;
+    if (lane == top) { zk = k; zj = js; }
+    ++top;
+    if (lane == top) { src = k; zk = -1; }
+    A |= 1ull << k;
+    maxtop = top > maxtop ? top : maxtop;
+  }
+  sh = __shfl(hs, src, kWave); sq = __shfl(qs, src, kWave);
+  const double hk = __shfl(hs, zk < 0 ? 0 : zk, kWave), qk = __shfl(qs, zk < 0 ? 0 : zk, kWave);
+  const double hj = __shfl(hs, zj, kWave), qj = __shfl(qs, zj, kWave);
+  const double s = ((hk - hj) + alpha * (qk + qj)) / (2 * alpha);
+  zz = zk < 0 ? inf : s;
+  maxtop_out = maxtop;
+  return true;
+}
+
+// Certified fast path of the truncated QUADRATIC message (typeStereoQuadratic.h:329-501), K <= 64,
+// lane = source and destination label.  The reference builds the lower envelope of the parabolas
+// alpha (t - q_s)^2 + h_s as the lower convex hull of the points (q_s, g_s = h_s + alpha q_s^2) --
+// its breakpoint s = (g_k - g_j) / (2 alpha (q_k - q_j)) is the hull slope over 2 alpha -- by a
+// monotone-chain scan, then picks for destination t the stack slot with z[slot] < t <= z[slot+1].
+// Suppose that at t the smallest cost c_j(t) is separated from every other source's cost by more
+// than delta.  Since c_s(t) - c_j(t) = 2 alpha (q_s - q_j) (sigma(j,s) - t), every exact slope from
+// j to a later source exceeds t + delta / (2 alpha Q) and every slope from an earlier source to j is
+// below t - delta / (2 alpha Q) (Q = span of the source positions).  If the rounding error of any
+// computed breakpoint that involves j (<= ~1e-14 G / (alpha gap), G >= |g|, gap = distance from
+// a useful source to the nearest other source) is smaller than that margin, then (i) j is pushed
+// when its turn comes (no near-duplicate position: gap > 1e-8 regime), (ii) no later source pops it
+// (its breakpoint against j stays above j's own), and (iii) j's two breakpoints on the final stack
+// bracket t; breakpoints increase strictly along the stack by construction (a push requires
+// s > z[top]), so the walk stops at j: the reference returns exactly alpha (t-q_j)^2 + h_j, the
+// plain min-plus value.  Sources with h >= vTrunc cost >= vTrunc everywhere: they are covered by
+// the margin to vTrunc.  Destinations whose minimum is >= vTrunc return vTrunc whatever is picked.
+// Returns "needs the serial construction"; m1 = min-plus value over the useful sources.
+__device__ __forceinline__ bool message_quad_fast(double lambda, int K, double alpha, double h, double qsrc,
+                                                  double t, double vtrunc, int lane, const double *hq,
+                                                  double &m1_out, int window = -1, double shared_gap = 0) {
+  const double inf = __builtin_huge_val();
+  const bool act = lane < K;
+  double scale = act ? fabs(h) + alpha * qsrc * qsrc + alpha * t * t : 0.0;  // >= |g| and >= cost / 4
+  scale = wave_max_dpp(scale);
+  double qlo = act ? qsrc : inf, qhi = act ? qsrc : -inf;
+  wave_min_max_dpp(qlo, qhi);  // smallest and largest source position
+  const double delta = 1e-9 * (scale + fabs(alpha * lambda) + fabs(vtrunc));
+  unsigned long long mask = __builtin_amdgcn_ballot_w64(act && h < vtrunc);
+  double m1 = inf, m2 = inf;
+  // `gap` must not become a wave-uniform constant: this compiler (AMD clang 22, gfx950) then merges it
+  // with the uniform `shared_gap` in scalar registers and emits s_mov_b64 with a 64-bit literal, which
+  // the encoder truncates to its low half (+inf -> 0.0).  build.sh greps the ISA for that pattern.
+  double gap = inf;
+  asm volatile("" : "+v"(gap));
+  if (window >= 0 && __builtin_popcountll(mask) > 2 * window + 1) {
+    // shared strictly ascending positions (padded table): a source more than `window` indices away
+    // lies farther than sqrt(lambda (1 + 1e-9)) and costs >= vTrunc bit for bit (alpha > 0; the two
+    // roundings of alpha d d lose less than the 1e-9), so it is covered by the margin to vTrunc
+    for (int d = -window; d <= window; ++d) {
+      const double hj = hq[4 * (lane + d)], qj = hq[4 * (lane + d) + 1];
+      const double c = pair_cost<2>(alpha, t - qj, hj);
+      const double lo = min_raw(m1, c), hi = max_raw(m1, c);
+      m2 = min_raw(m2, hi);
+      m1 = lo;
+    }
+    gap = shared_gap;
+    mask = 0;
+  }
+  while (mask) {
+    const int j = __builtin_ctzll(mask);
+    mask &= mask - 1;
+    double hj, qj;
+    if (hq) { hj = hq[4 * j]; qj = hq[4 * j + 1]; }
+    else { hj = readlane_f64(h, j); qj = readlane_f64(qsrc, j); }
+    const double c = pair_cost<2>(alpha, t - qj, hj);
+    const double lo = min_raw(m1, c), hi = max_raw(m1, c);
+    m2 = min_raw(m2, hi);  // second smallest, equal costs of two sources count
+    m1 = lo;
+    const double dq = fabs(qsrc - qj);
+    gap = lane != j ? min_raw(gap, dq) : gap;
+  }
+  gap = wave_min_dpp(act ? gap : inf);
+  bool bad = !(delta < inf) || !(alpha > 0) || !(gap > 4e-8);
+  // breakpoint error <= ~7 eps G / (alpha gap) must stay below the slope margin delta / (2 alpha Q):
+  // delta gap > 1.6e-15 G Q, tested with a factor 60 in hand
+  bad = bad || !(1e-13 * scale * (qhi - qlo) < delta * gap);
+  bad = bad || (m1 < vtrunc && !(m2 - m1 > delta && vtrunc - m1 > delta));
+  m1_out = m1;
+  return UNI(act && bad);
+}
+
+constexpr int kMaxSlots = TrwsGraph::kMaxSlots;
+constexpr int kSpinLimit = 1 << 22;  // polls before a launch gives up (bounded spin)
+
+// ---- fast persistent sweep: K <= 64, <= 4 edges per list, <= 2 foreign dependencies ----
+// Same dataflow schedule as trws_persistent_kernel, restructured so that in
+// steady state a node visit touches no memory on its critical path:
+//  * lane = label; every wave keeps D, the outgoing-list messages and the
+//    incoming messages of the node in registers and forms Di redundantly, so the
+//    only workgroup traffic is the LDS hand-over of the new messages;
+//  * a packed 128-byte descriptor per processing position replaces the chains of
+//    dependent index loads; descriptor, unary and previous-sweep messages of the
+//    NEXT node are fetched while the current node's messages are computed, and
+//    so are the foreign incoming messages once their flags are seen raised;
+//  * a node's completion flag is raised in the middle of the next visit, when
+//    its write-through stores have long drained, so no store latency is exposed.
+struct NodeDesc {
+  int node, rank, nout, nin, ndep, md, lbn, urgent, remote, epos;
+  int e[8], slot[8], dep[4], lbe[8], xn[8];
+};
+#define RLI(v, i) __builtin_amdgcn_readlane((v), (i))
+__device__ __forceinline__ NodeDesc decode_desc(int w) {
+  NodeDesc d;
+  d.node = RLI(w, 0); d.rank = RLI(w, 1);
+  const int f = RLI(w, 2);
+  d.nout = f & 15; d.nin = (f >> 4) & 15; d.ndep = (f >> 8) & 15; d.md = (f >> 16) & 255;
+  d.lbn = RLI(w, 3);
+  d.e[0] = RLI(w, 4); d.e[1] = RLI(w, 5); d.e[2] = RLI(w, 6); d.e[3] = RLI(w, 7);
+  d.e[4] = RLI(w, 8); d.e[5] = RLI(w, 9); d.e[6] = RLI(w, 10); d.e[7] = RLI(w, 11);
+  d.slot[0] = RLI(w, 12); d.slot[1] = RLI(w, 13); d.slot[2] = RLI(w, 14); d.slot[3] = RLI(w, 15);
+  d.slot[4] = RLI(w, 16); d.slot[5] = RLI(w, 17); d.slot[6] = RLI(w, 18); d.slot[7] = RLI(w, 19);
+  d.dep[0] = RLI(w, 20); d.dep[1] = RLI(w, 21); d.dep[2] = RLI(w, 22); d.dep[3] = RLI(w, 23);
+  d.lbe[0] = RLI(w, 24); d.lbe[1] = RLI(w, 25); d.lbe[2] = RLI(w, 26); d.lbe[3] = RLI(w, 27);
+  d.lbe[4] = RLI(w, 28); d.lbe[5] = RLI(w, 29); d.lbe[6] = RLI(w, 30); d.lbe[7] = RLI(w, 31);
+  d.xn[0] = RLI(w, 32); d.xn[1] = RLI(w, 33); d.xn[2] = RLI(w, 34); d.xn[3] = RLI(w, 35);
+  d.xn[4] = RLI(w, 36); d.xn[5] = RLI(w, 37); d.xn[6] = RLI(w, 38); d.xn[7] = RLI(w, 39);
+  d.urgent = RLI(w, 40);
+  d.remote = RLI(w, kDescRemote); d.epos = RLI(w, kDescEpos);
+  return d;
+}
+
+// bounded wait for one completion flag; returns false if the launch must give up
+__device__ __forceinline__ bool wait_flag(const DevParams &p, int rank, int epoch) {
+  const int32_t *flag = p.done + rank;
+  int spins = 0;
+  while (ld_sc1(flag) < epoch) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > kSpinLimit || ((spins & 1023) == 0 && ld_sc1(p.abort_flag))) {
+      st_sc1(p.abort_flag, 1);
+      return false;
+    }
+  }
+  return true;
+}
+
+// ---- lane exchange lane ^ S without an address register where the hardware offers one
+template <int S>
+__device__ __forceinline__ unsigned xor_lane_u32(unsigned v) {
+  if (S == 1) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+  if (S == 2) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  if (S == 8) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false);  // row_ror:8
+  if (S == 4 || S == 16) return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (S << 10));    // bit mode: xor S
+  return (unsigned)__shfl_xor((int)v, S, kWave);
+}
+// Bitonic sort of two independent sets of 64 unsigned keys (one key of each per lane), ascending by lane.
+template <int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_step2(unsigned &a, unsigned &b, int lane) {
+  const unsigned oa = xor_lane_u32<STRIDE>(a), ob = xor_lane_u32<STRIDE>(b);
+  const bool keep_min = ((lane & STRIDE) == 0) == ((lane & SIZE) == 0);
+  a = keep_min ? (a < oa ? a : oa) : (a > oa ? a : oa);
+  b = keep_min ? (b < ob ? b : ob) : (b > ob ? b : ob);
+}
+__device__ __forceinline__ void wave_sort2(unsigned &a, unsigned &b, int lane) {
+  bitonic_step2<2, 1>(a, b, lane);
+  bitonic_step2<4, 2>(a, b, lane); bitonic_step2<4, 1>(a, b, lane);
+  bitonic_step2<8, 4>(a, b, lane); bitonic_step2<8, 2>(a, b, lane); bitonic_step2<8, 1>(a, b, lane);
+  bitonic_step2<16, 8>(a, b, lane); bitonic_step2<16, 4>(a, b, lane); bitonic_step2<16, 2>(a, b, lane);
+  bitonic_step2<16, 1>(a, b, lane);
+  bitonic_step2<32, 16>(a, b, lane); bitonic_step2<32, 8>(a, b, lane); bitonic_step2<32, 4>(a, b, lane);
+  bitonic_step2<32, 2>(a, b, lane); bitonic_step2<32, 1>(a, b, lane);
+  bitonic_step2<64, 32>(a, b, lane); bitonic_step2<64, 16>(a, b, lane); bitonic_step2<64, 8>(a, b, lane);
+  bitonic_step2<64, 4>(a, b, lane); bitonic_step2<64, 2>(a, b, lane); bitonic_step2<64, 1>(a, b, lane);
+}
+
+// Second look at a message whose certificate failed (cold path, kept out of line so that it costs the
+// hot path no registers).  A cone whose apex lies above vTrunc by more than alpha times the whole
+// position range cannot touch a useful cone -- every useful cone dominates it with that margin
+// wherever they meet -- so it neither counts for the magnitude behind delta nor for the tangency
+// test.  Out-of-range plane proposals (unary ~ 4e7, dispmap_ncc.m:245) would otherwise inflate delta
+// and send almost every message of such a fusion to the serial construction.  Returns "still bad";
+// m1 = min-plus value over the useful sources.
+__device__ __attribute__((noinline)) bool message_second_look(double lambda, int K, double alpha, double h,
+                                                              double qsrc, double t, double vtrunc,
+                                                              double delta, int lane, double &m1_out) {
+  const double inf = __builtin_huge_val();
+  const bool act = lane < K;
+  const double aq = alpha * qsrc;
+  const double qabs = wave_max_dpp(act ? max_raw(fabs(qsrc), fabs(t)) : 0.0);
+  const bool rel = act && h <= vtrunc + 2.000002 * fabs(alpha) * qabs;
+  const double mag2 = max_raw(wave_max_dpp(act ? (rel ? fabs(h) : 0.0) + fabs(aq) + alpha * fabs(t) : 0.0), fabs(vtrunc));
+  const double delta2 = 1e-9 * (mag2 + fabs(alpha * lambda));
+  if (!(delta2 < delta)) return true;
+  const double ui = h - aq, vi = h + aq;
+  unsigned long long mask = __builtin_amdgcn_ballot_w64(act && h < vtrunc);
+  double m1 = inf, m2 = inf;
+  bool bad = false;
+  while (mask) {
+    const int j = __builtin_ctzll(mask);
+    mask &= mask - 1;
+    const double hj = readlane_f64(h, j), qj = readlane_f64(qsrc, j);
+    const double c = pair_cost<1>(alpha, t - qj, hj);
+    const double lo = min_raw(m1, c), hi = max_raw(m1, c);
+    m2 = hi > lo ? min_raw(m2, hi) : m2;
+    m1 = lo;
+    const double aqj = alpha * qj;
+    const bool near = (fabs(ui - (hj - aqj)) <= delta2) || (fabs(vi - (hj + aqj)) <= delta2);
+    bad = bad || (near && qsrc != qj && rel);
+  }
+  bad = bad || (m1 < vtrunc && !(m2 - m1 > delta2 && vtrunc - m1 > delta2));
+  m1_out = m1;
+  return UNI(act && bad);
+}
+
+// Message update with everything in registers (K <= 64): h = gamma*Di - old message,
+// qsrc / t = source / destination positions, perm = ascending order of the sources
+// (only touched by the serial fallback).  Returns the normalised message in `out`.
+template <int KERNEL>
+__device__ __forceinline__ double message_regs(const DevParams &p, int K, double alpha, double h,
+                                               double qsrc, double t, const uint16_t *perm,
+                                               double &outmsg, int lane, double *hq = nullptr,
+                                               int window = -1) {
+  const double inf = __builtin_huge_val();
+  const bool act = lane < K;
+  // hmin and the magnitude behind delta in one interleaved reduction
+  const double aq = alpha * qsrc;
+  double hmin = h, mag = act ? fabs(h) + fabs(aq) + alpha * fabs(t) : 0.0;  // inactive lanes hold h = +inf
+  wave_min_max_dpp(hmin, mag);
+  double out, vmin;
+  if (UNI(alpha == 0)) {
+    out = hmin; vmin = hmin;  // typeStereoLinear.h:390-396
+  } else {
+    const double vtrunc = hmin + alpha * p.lambda;
+    bool need_serial = true;
+    out = vtrunc;
+// (per-phase cycle counters of a message: compiled in only with -DSTEREO_HIP_MESSAGE_PROFILE -- even
+// the untaken branches cost 5 % of a Teddy iteration: 15.4 vs 14.55 ms)
+#ifndef STEREO_HIP_MESSAGE_PROFILE
+#define MSTAMP(slot) do { } while (0)
+#else
+    long long tm0 = p.prof ? (long long)__builtin_readcyclecounter() : 0;  // development profile: slots 8..15
+#define MSTAMP(slot) do { if (p.prof) { const long long n_ = (long long)__builtin_readcyclecounter(); if (lane == 0) { atomicAdd(p.prof + (slot), (unsigned long long)(n_ - tm0)); atomicAdd(p.prof + (slot) + 1, 1ull); } tm0 = n_; } } while (0)
+#endif
+    if (KERNEL == 1 && p.certificate) {
+      // Fast path (DESIGN.md "message certificate").  Only "useful" sources, those with
+      // h < vTrunc, can produce a value below the truncation level: cost >= h for every
+      // other source.  Min-plus over the useful sources is therefore the plain min-plus
+      // result; the certificate demands (i) every pair of cones with distinct apex positions
+      // of which at least one is useful is delta-separated from tangency (|u_i-u_j| > delta
+      // and |v_i-v_j| > delta with u = h - alpha q, v = h + alpha q), so each comparison
+      // the reference's serial envelope construction makes on a useful cone is decided as
+      // in real arithmetic, and (ii) at every destination whose minimum beats vTrunc the
+      // minimum is delta-separated from the next larger cost and from vTrunc, so rounding
+      // in the envelope's breakpoints cannot pick another value.  Otherwise: serial path.
+      const double ui = h - aq, vi = h + aq;
+      const double delta = 1e-9 * (mag + fabs(alpha * p.lambda));
+      const bool useful = act && h < vtrunc;
+      unsigned long long mask = __builtin_amdgcn_ballot_w64(useful);
+      double m1 = inf, m2 = inf;
+      bool bad = !(delta < inf);
+      // The sources are broadcast from a per-wave LDS table (one ds_read_b128 per source instead of
+      // eight v_readlane); two sources per trip keep two independent dependency chains in flight.
+      // m1 / m2 = smallest and second smallest DISTINCT cost seen so far.
+      // table entry of a source: (h, q, u, v) -- the tangency test then needs no arithmetic on the source
+      if (hq) {
+        hq[4 * lane] = h; hq[4 * lane + 1] = qsrc; hq[4 * lane + 2] = ui; hq[4 * lane + 3] = vi;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+#define STEREO_SRC(J, HJ, QJ)                                                        \
+  double HJ, QJ, HJ##u, HJ##v;                                                       \
+  if (hq) { HJ = hq[4 * (J)]; QJ = hq[4 * (J) + 1]; HJ##u = hq[4 * (J) + 2]; HJ##v = hq[4 * (J) + 3]; } \
+  else {                                                                             \
+    HJ = readlane_f64(h, (J)); QJ = readlane_f64(qsrc, (J));                         \
+    const double aqj_ = alpha * QJ;                                                  \
+    HJ##u = HJ - aqj_; HJ##v = HJ + aqj_;                                            \
+  }
+#define STEREO_ACC(HJ, QJ)                                                           \
+  {                                                                                  \
+    const double c = pair_cost<1>(alpha, t - QJ, HJ);                                \
+    const double lo = min_raw(m1, c), hi = max_raw(m1, c);                           \
+    m2 = hi > lo ? min_raw(m2, hi) : m2;                                             \
+    m1 = lo;                                                                         \
+    const bool near = (fabs(ui - HJ##u) <= delta) || (fabs(vi - HJ##v) <= delta);    \
+    bad = bad || (near && qsrc != QJ);                                               \
+  }
+      if (window >= 0 && __builtin_popcountll(mask) > 32) {
+        // Flat h (the zig-zag rows: gamma = 1/6 .. 1/8 makes almost every source useful) on shared
+        // strictly ascending positions.  The pair loop below would be K^2; instead
+        //  * tangency for ALL pairs by sorting u and v (conservative superset of the useful pairs):
+        //    keys quantised to 32 bits over a range that certainly contains them, "within delta"
+        //    tested as "within delta / resolution + 2 units";
+        //  * min-plus only over the sources inside the truncation window of each destination (a source
+        //    farther than lambda costs >= vTrunc exactly); the table is padded with +inf entries.
+        const double hmax = wave_max_dpp(act ? h : -inf);
+        const double ap0 = alpha * p.pos_first, ap1 = alpha * p.pos_last;
+        const double aplo = min_raw(ap0, ap1), aphi = max_raw(ap0, ap1);
+        const double span = (hmax - hmin) + (aphi - aplo);  // >= max u - min u and >= max v - min v
+        const double scale = 4294967040.0 / span;           // (2^32 - 256) / span
+        bad = bad || !(span < inf) || !(span > 0) || !(delta * scale < 1e9);
+        unsigned ku = 0xFFFFFFFFu, kv = 0xFFFFFFFFu;
+        if (act && !bad) {
+          ku = (unsigned)((ui - (hmin - aphi)) * scale);
+          kv = (unsigned)((vi - (hmin + aplo)) * scale);
+        }
+        wave_sort2(ku, kv, lane);
+        const unsigned un = (unsigned)__shfl_down((int)ku, 1, kWave), vn = (unsigned)__shfl_down((int)kv, 1, kWave);
+        const unsigned thr = bad ? 0u : (unsigned)(delta * scale) + 2u;
+        bad = bad || (lane + 1 < K && (un - ku <= thr || vn - kv <= thr));
+        for (int d = -window; d <= window; ++d) {
+          const double hj = hq[4 * (lane + d)], qj = hq[4 * (lane + d) + 1];
+          const double c = pair_cost<1>(alpha, t - qj, hj);
+          const double lo = min_raw(m1, c), hi = max_raw(m1, c);
+          m2 = hi > lo ? min_raw(m2, hi) : m2;
+          m1 = lo;
+        }
+      } else {
+      while (mask) {
+        const int j0 = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const int j1 = mask ? __builtin_ctzll(mask) : j0;  // a source visited twice changes nothing
+        mask &= mask - 1;
+        STEREO_SRC(j0, hj0, qj0)
+        STEREO_SRC(j1, hj1, qj1)
+        STEREO_ACC(hj0, qj0)
+        STEREO_ACC(hj1, qj1)
+      }
+      }
+#undef STEREO_SRC
+#undef STEREO_ACC
+      bad = bad || (m1 < vtrunc && !(m2 - m1 > delta && vtrunc - m1 > delta));
+      need_serial = UNI(act && bad);
+      MSTAMP(8);
+      if (need_serial) { need_serial = message_second_look(p.lambda, K, alpha, h, qsrc, t, vtrunc, delta, lane, m1); MSTAMP(10); }
+      out = m1 < vtrunc ? m1 : vtrunc;
+      if (need_serial && lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
+    }
+    if (KERNEL == 2 && p.certificate) {
+      if (hq) {
+        hq[4 * lane] = h; hq[4 * lane + 1] = qsrc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      double m1;
+      need_serial = message_quad_fast(p.lambda, K, alpha, h, qsrc, t, vtrunc, lane, hq, m1, hq ? window : -1, p.pos_gap);
+      out = m1 < vtrunc ? m1 : vtrunc;
+      if (need_serial && lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
+    }
+    if (need_serial) {
+      const int idx = act ? perm[lane] : lane;
+      const double hs = __shfl(h, idx, kWave), qs = __shfl(qsrc, idx, kWave);
+      double sh, sq, zz;
+      int maxtop = 0;
+      bool built = false;
+      if (KERNEL == 1 && !(p.debug & 512)) built = build_envelope_masks(K, alpha, hs, qs, sh, sq, zz, lane, maxtop);
+      if (!built) maxtop = build_envelope_regs<KERNEL>(K, alpha, hs, qs, sh, sq, zz, lane);
+      MSTAMP(12);
+      // the reference walks up the stack while z[j+1] < t (typeStereoLinear.h:462-479): the slot it
+      // stops at is the FIRST one whose upper breakpoint is not below t (stale slots above `top`
+      // included, hence up to the highest slot ever written); found top-down so that the lowest wins
+      int slot = maxtop;
+      for (int j = maxtop - 1; j >= 0; --j) {
+        const double zj1 = readlane_f64(zz, j);
+        slot = !(zj1 < t) ? j : slot;
+      }
+      const double ch = __shfl(sh, slot, kWave), cq = __shfl(sq, slot, kWave);
+      const double c = pair_cost<KERNEL>(alpha, t - cq, ch);
+      out = c < vtrunc ? c : vtrunc;
+      MSTAMP(14);
+    }
+#undef MSTAMP
+    vmin = wave_min_dpp(act ? out : inf);
+  }
+  outmsg = out - vmin;
+  return vmin;
+}
+
+#undef RLI
+
+constexpr int kPipeCompute = 8;  // one compute wave per outgoing message (<= 8 per node)
+constexpr int kPipeWaves = kPipeCompute + 4;  // loader, storer, (idle), primal: the primal wave lands on SIMD 3,
+                                              // which otherwise hosts one compute wave only
+constexpr int kPipeThreads = kPipeWaves * kWave;
+// LDS stage layout (doubles): D[64] m[8][64] qv[8][64] qpv[8][64] | a[8] | ints: desc[64] px[8]
+constexpr int kStD = 0, kStM = 64, kStQ = 64 + 512, kStQP = 64 + 1024, kStA = 64 + 1536;
+constexpr int kStI = kStA + 8;                    // int area starts here (as doubles)
+constexpr int kStageDoubles = kStI + 36;          // 64 + 8 ints = 36 doubles
+constexpr int kScalDoubles = 16;                  // newv[8], node_vmin, prim_e, x (as int)
+constexpr int kPipePad = 16;                      // source tables are padded by this many (+inf) entries on both sides
+constexpr int kPipeTab = 4 * (kWave + 2 * kPipePad);  // doubles per compute wave: (h, q, u, v) x 96
+
+__device__ __forceinline__ int group_strip(const GroupArgs &ga) {
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i) s = (i < ga.n && (int)blockIdx.x >= ga.first[i]) ? i : s;  // static indices only
+  return s;
+}
+
+}  // namespace
+}  // namespace stereo

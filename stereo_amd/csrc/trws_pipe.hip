@@ -1,0 +1,336 @@
+// TRW-S pipelined sweep kernel for K <= 64 (both smoothness kernels): role-specialised waves, one
+// barrier per visit.  Part of libstereo_hip.so; overview in trws_plan.hip.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/stereo_hip.h"
+#include "common.h"
+#include "trws_dev.h"
+#include "trws_launch.h"
+
+namespace stereo {
+namespace {
+
+// ---- pipelined persistent sweep (K <= 64): role-specialised waves ---------------------
+// Same dataflow schedule and arithmetic as trws_persistent_kernel, but the global-memory traffic
+// of a visit is taken off the critical path by dedicated waves of the workgroup:
+//   waves 0-7  compute: read the staged node from LDS, form Di, compute outgoing message
+//              `wave` in registers, hand it over in LDS
+//   wave 8     loader:  while node i is computed, decodes the descriptor of node i+1, waits
+//              for its foreign completion flags, fetches unary / messages / weights /
+//              positions / neighbour labels and stages them in LDS
+//   wave 9     storer:  while node i is computed, writes node i-1's new messages and scalars
+//              to HBM (write-through), drains, raises node i-1's completion flag
+//   wave 11    primal:  labelling + energy term of node i (previous iteration's primal pass);
+//              wave 10 idles so that the primal wave shares a SIMD with one compute wave only
+// One s_barrier per visit.  The compute waves never touch global memory, so no load or
+// store latency is ever exposed on the chain of dependent visits.
+template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
+__device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double *stage0 = lds;                                   // 2 stages
+  double *hand = lds + 2 * kStageDoubles;                 // ring of 4 x 8 x 64: the last visits' new messages
+  double *scal = hand + 4 * 8 * kWave;                    // 2 x kScalDoubles
+  double *hqtab = scal + 2 * kScalDoubles;                // per compute wave: 64 x (h, q, u, v)
+  int *ctl = (int *)(hqtab + kPipeCompute * kPipeTab);    // [0] run, [1] abort
+  int *dring = ctl + 4;                                   // the last three descriptors (the storer's comes from here, not from HBM)
+  const int K = p.K;
+  const double inf = __builtin_huge_val();
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  constexpr int D = BACKWARD ? 1 : 0;
+  constexpr int DW = TrwsGraph::kDescWords;
+  const int32_t *desc = p.desc[D];
+  const bool act = lane < K;
+  const double posk = (SHARED && act) ? p.pos[lane] : 0.0;
+  if (tid == 0) ctl[1] = 0;
+  if (wave < kPipeCompute && lane < 2 * kPipePad) {
+    // padding of the source tables (entries -16 .. -1 and 64 .. 79): never overwritten afterwards
+    double *e = hqtab + wave * kPipeTab + 4 * (lane < kPipePad ? lane : kWave + lane);
+    e[0] = inf; e[1] = 0; e[2] = 0; e[3] = 0;
+  }
+  if ((p.debug & 2) && !BACKWARD) p.prof = nullptr;  // profile backward sweeps only
+  if ((p.debug & 4) && BACKWARD) p.prof = nullptr;   // profile forward sweeps only
+
+  for (;;) {
+    if (tid == 0) { const int t_ = atomicAdd(p.ticket, 1); ctl[0] = t_ < p.ntickets[D] ? (p.run_order[D] ? p.run_order[D][t_] : t_) : p.nruns[D]; }
+    __syncthreads();
+    const int run = __builtin_amdgcn_readfirstlane(ctl[0]);
+    __syncthreads();
+    if (run >= p.nruns[D]) break;
+    const int p0 = p.run_ptr[D][run], p1 = p.run_ptr[D][run + 1];
+    int xprev = 0, xprev2 = 0;  // primal wave: labels of the previous two nodes of the run
+    int wnext = 0;              // loader: raw descriptor word of the node after next (prefetched)
+    if (wave == kPipeCompute) wnext = desc[(size_t)p0 * DW + lane];
+    if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2] = wall_clock64();
+    unsigned long long busy = 0;
+
+    for (int pos = p0 - 1; pos <= p1; ++pos) {
+      const long long tstart = p.prof ? (long long)__builtin_readcyclecounter() : 0;
+      double *st = stage0 + (pos & 1) * kStageDoubles;          // node `pos`
+      double *stn = stage0 + ((pos + 1) & 1) * kStageDoubles;   // node `pos + 1`
+      double *hcur = hand + (pos & 3) * 8 * kWave, *hprev = hand + ((pos - 1) & 3) * 8 * kWave;
+      double *hprev2 = hand + ((pos - 2) & 3) * 8 * kWave;
+      double *sc = scal + (pos & 1) * kScalDoubles;
+      const bool have_node = pos >= p0 && pos < p1;
+
+      if (wave < kPipeCompute) {
+        // ------------------------------------------------------------ compute
+        if (UPDATE && have_node) {
+          const int *sti = (const int *)(st + kStI);
+          const int f = __builtin_amdgcn_readfirstlane(sti[2]);
+          const int nout = f & 15, nin = (f >> 4) & 15, md = (f >> 16) & 255, ntot = nout + nin;
+          const unsigned slA = (unsigned)__builtin_amdgcn_readfirstlane(sti[41]);
+          const unsigned slB = (unsigned)__builtin_amdgcn_readfirstlane(sti[42]);
+          if (wave < nout || (BACKWARD && wave == 0)) {  // waves without a message stay out of the way
+          double Di = act ? st[kStD + lane] : 0.0;
+          double mown = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (j < ntot) {
+              double v;
+              const int sl = j >= nout ? (int)(signed char)(((j < 4 ? slA : slB) >> (8 * (j & 3))) & 255) : -1;
+              if (sl >= 8) v = hprev2[(sl - 8) * kWave + lane];
+              else if (sl >= 0) v = hprev[sl * kWave + lane];
+              else v = st[kStM + j * kWave + lane];
+              Di += v;
+              if (j == wave && j < nout) mown = v;
+            }
+          }
+          double node_vmin = 0;
+          if (BACKWARD) {
+            node_vmin = wave_min_dpp(act ? Di : inf);
+            Di -= node_vmin;
+            if (tid == 0) sc[8] = node_vmin;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (j == wave && j < nout) {
+              const double gamma = (double)1 / (double)(nout > nin ? nout : nin);
+              const double h = act ? gamma * Di - mown : inf;
+              const bool src_is_qprim = ((BACKWARD ? 1 : 0) == ((md >> j) & 1));
+              double qsrc = posk, qdst = posk;
+              const uint16_t *perm = p.perm_pos;
+              if (!SHARED) {
+                const double a_ = act ? st[kStQ + j * kWave + lane] : 0.0;
+                const double b_ = act ? st[kStQP + j * kWave + lane] : 0.0;
+                qsrc = src_is_qprim ? b_ : a_;
+                qdst = src_is_qprim ? a_ : b_;
+                const int e = __builtin_amdgcn_readfirstlane(sti[4 + j]);
+                perm = (src_is_qprim ? p.perm_qp : p.perm_q) + (size_t)e * K;
+              }
+              const double alpha = st[kStA + j];
+              double newm = 0;
+              const double v = message_regs<KERNEL>(p, K, alpha, h, qsrc, qdst, perm, newm, lane,
+                                                    hqtab + wave * kPipeTab + 4 * kPipePad, (SHARED && p.win_ok) ? p.window : -1);
+              if (act) hcur[j * kWave + lane] = newm;
+              if (BACKWARD && lane == 0) sc[j] = v;
+            }
+          }
+          }
+        }
+      } else if (wave == kPipeCompute) {
+        // ------------------------------------------------------------ loader: stage node pos + 1
+        if (pos + 1 >= p0 && pos + 1 < p1) {
+          const int w = wnext;
+          if (pos + 2 < p1) wnext = desc[(size_t)(pos + 2) * DW + lane];
+          const NodeDesc nx = decode_desc(w);
+          int *stni = (int *)(stn + kStI);
+          stni[lane] = w;
+          dring[((pos + 1) % 3) * kWave + lane] = w;
+          const int ntot = nx.nout + nx.nin;
+          // everything that does not depend on other workgroups is requested first ...
+          double dk = 0, mv[8], qv[8], qpv[8];
+          if (act) dk = p.unary[(size_t)nx.node * K + lane];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            mv[j] = 0; qv[j] = 0; qpv[j] = 0;
+            if (j < ntot && act) {
+              const size_t off = (size_t)nx.e[j] * K + lane;
+              if (j < nx.nout && (UPDATE || PRIMAL)) mv[j] = p.msg[off];
+              if (!SHARED) { qv[j] = p.q[off]; qpv[j] = p.qprim[off]; }
+            }
+          }
+          double av = 0;
+          int pxv = 0, xn = 0, sl = 0;
+          if (lane < ntot) {
+            int ej = 0;  // lane j fetches the scalars of edge j
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (lane == j) { ej = nx.e[j]; xn = nx.xn[j]; sl = nx.slot[j]; }
+            av = p.alpha[ej];
+          }
+          // ... then the completion flags of the foreign neighbours, then their data
+          // (all flags are polled together: lane j watches dependency j)
+          if (nx.ndep > 0) {
+            int myrank = nx.dep[0];
+#pragma unroll
+            for (int j = 1; j < 4; ++j)
+              if (lane == j) myrank = nx.dep[j];
+            const bool watching = lane < nx.ndep;
+            int spins = 0;
+            bool ok = true;
+            for (;;) {
+              const int v = watching ? ld_sc1(p.done + myrank) : epoch;
+              if (!UNI(v < epoch)) break;
+              __builtin_amdgcn_s_sleep(1);
+              if (++spins > kSpinLimit || ((spins & 1023) == 0 && ld_sc1(p.abort_flag))) { ok = false; break; }
+            }
+            if (!ok && lane == 0) { st_sc1(p.abort_flag, 1); ctl[1] = 1; }
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (UPDATE && j >= nx.nout && j < ntot && nx.slot[j] < 0 && act)
+              mv[j] = ld_sc1(p.msg + (size_t)nx.e[j] * K + lane);
+          if (PRIMAL && lane < ntot && lane >= nx.nout && sl < 0) pxv = ld_sc1(p.x + xn);
+          if (act) stn[kStD + lane] = dk;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (j < ntot && act) {
+              stn[kStM + j * kWave + lane] = mv[j];
+              if (!SHARED) { stn[kStQ + j * kWave + lane] = qv[j]; stn[kStQP + j * kWave + lane] = qpv[j]; }
+            }
+          }
+          if (lane < 8) { stn[kStA + lane] = av; stni[64 + lane] = pxv; }
+        }
+      } else if (wave == kPipeCompute + 1) {
+        // ------------------------------------------------------------ storer: node pos - 1
+        if (pos - 1 >= p0) {
+          const NodeDesc pd = decode_desc(dring[((pos - 1) % 3) * kWave + lane]);
+          const double *scp = scal + ((pos + 1) & 1) * kScalDoubles;  // parity of pos - 1
+          if (UPDATE) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              if (j < pd.nout) {
+                double *mb = ((pd.remote >> j) & 1) ? (((pd.remote >> (8 + j)) & 1) ? p.peer_msg1 : p.peer_msg0) : p.msg;
+                if (act) st_sc1(mb + (size_t)pd.e[j] * K + lane, hprev[j * kWave + lane]);
+                if (BACKWARD && lane == 0) p.lbterms[pd.lbe[j]] = scp[j];
+              }
+            }
+            if (BACKWARD && lane == 0) p.lbterms[pd.lbn] = scp[8];
+          }
+          if (PRIMAL && lane == 0) {
+            const int xi = ((const int *)(scp + 10))[0];
+            st_sc1(p.x + pd.node, xi);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_x0 + pd.node, xi);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_x1 + pd.node, xi);
+            p.eterms[pd.epos] = scp[9];
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) {
+            st_sc1(p.done + pd.rank, epoch);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_done0 + pd.rank, epoch);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_done1 + pd.rank, epoch);
+          }
+        }
+      } else if (wave == kPipeCompute + 3) {
+        // ------------------------------------------------------------ primal of node pos
+        if (PRIMAL && have_node) {
+          const int *sti = (const int *)(st + kStI);
+          const int f = __builtin_amdgcn_readfirstlane(sti[2]);
+          const int nout = f & 15, nin = (f >> 4) & 15, md = (f >> 16) & 255, ntot = nout + nin;
+          double db = act ? st[kStD + lane] : 0.0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (j >= nout && j < ntot) {
+              const int sl = __builtin_amdgcn_readfirstlane(sti[12 + j]);
+              const int ks = sl >= 8 ? xprev2 : sl >= 0 ? xprev : __builtin_amdgcn_readfirstlane(sti[64 + j]);
+              const int mdj = (md >> j) & 1;
+              double d;
+              if (SHARED) {
+                const double pks = readlane_f64(posk, ks);
+                d = mdj == 0 ? pks - posk : posk - pks;
+              } else {
+                const double qvj = act ? st[kStQ + j * kWave + lane] : 0.0;
+                const double qpj = act ? st[kStQP + j * kWave + lane] : 0.0;
+                d = mdj == 0 ? readlane_f64(qpj, ks) - qvj : qpj - readlane_f64(qvj, ks);
+              }
+              const double v = KERNEL == 1 ? fabs(d) : d * d;
+              db += st[kStA + j] * (v < p.lambda ? v : p.lambda);
+            }
+          }
+          double di = db;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j < nout) di += st[kStM + j * kWave + lane];
+          const int bi = wave_argmin_dpp(act ? di : inf, act ? lane : 0x7fffffff);
+          xprev2 = xprev; xprev = bi;
+          const double eb = readlane_f64(db, bi);
+          if (lane == 0) { sc[9] = eb; ((int *)(sc + 10))[0] = bi; }
+        }
+      }
+      if (p.prof) busy += (unsigned long long)((long long)__builtin_readcyclecounter() - tstart);
+      __syncthreads();
+      if (ctl[1]) return;  // a dependency wait gave up (bounded spin); host reports it
+    }
+    if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2 + 1] = wall_clock64();
+    if (p.prof && lane == 0 && (p.prof_run < 0 || run == p.prof_run)) {
+      // busy cycles before the barrier per role: compute (wave 0), loader, storer, primal; steps
+      const int slot = wave == 0 ? 0 : wave == kPipeCompute ? 1 : wave == kPipeCompute + 1 ? 2 : wave == kPipeCompute + 3 ? 3 : -1;
+      if (slot >= 0) atomicAdd(p.prof + slot, busy);
+      if (wave == 0) atomicAdd(p.prof + 6, (unsigned long long)(p1 - p0));
+    }
+  }
+}
+
+template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
+__global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, int epoch) {
+  pipe_body<KERNEL, BACKWARD, PRIMAL, UPDATE, SHARED>(p, epoch);
+}
+
+template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
+__global__ __launch_bounds__(kPipeThreads) void trws_pipe_group_kernel(GroupArgs ga, int epoch) {
+  pipe_body<KERNEL, BACKWARD, PRIMAL, UPDATE, SHARED>(ga.pp[group_strip(ga)], epoch);
+}
+
+}  // namespace
+
+size_t pipe_lds_bytes() {
+  return sizeof(double) * (2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * kPipeTab + 2 + 3 * kWave / 2);
+}
+int pipe_threads() { return kPipeThreads; }
+
+void pipe_set_attributes() {
+  const int lds = (int)pipe_lds_bytes();
+#define SET_P(KER, BW, PR, UP)                                                                                                          \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_pipe_kernel<KER, BW, PR, UP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));        \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_pipe_kernel<KER, BW, PR, UP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));       \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_pipe_group_kernel<KER, BW, PR, UP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));  \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_pipe_group_kernel<KER, BW, PR, UP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds))
+  SET_P(1, false, false, true); SET_P(1, true, false, true); SET_P(1, false, true, true); SET_P(1, false, true, false);
+  SET_P(2, false, false, true); SET_P(2, true, false, true); SET_P(2, false, true, true); SET_P(2, false, true, false);
+#undef SET_P
+}
+
+#define PIPE_SWITCH(NAME, ARG)                                                                                          \
+  const size_t plds = pipe_lds_bytes();                                                                                 \
+  const dim3 grid(blocks), block(kPipeThreads);                                                                         \
+  _Pragma("clang diagnostic push")                                                                                      \
+  if (kernel == 1) { PIPE4(NAME, 1, ARG) } else { PIPE4(NAME, 2, ARG) }                                                 \
+  _Pragma("clang diagnostic pop")                                                                                       \
+  STEREO_HIP_CHECK(hipGetLastError());
+#define PIPE1(NAME, KER, BW, PR, UP, ARG)                                                                               \
+  do {                                                                                                                  \
+    if (shared) hipLaunchKernelGGL((NAME<KER, BW, PR, UP, true>), grid, block, plds, s, ARG, epoch);                     \
+    else hipLaunchKernelGGL((NAME<KER, BW, PR, UP, false>), grid, block, plds, s, ARG, epoch);                           \
+  } while (0)
+#define PIPE4(NAME, KER, ARG)                                                                                           \
+  switch (what) {                                                                                                       \
+    case 0: PIPE1(NAME, KER, false, false, true, ARG); break;                                                           \
+    case 1: PIPE1(NAME, KER, true, false, true, ARG); break;                                                            \
+    case 2: PIPE1(NAME, KER, false, true, true, ARG); break;                                                            \
+    default: PIPE1(NAME, KER, false, true, false, ARG); break;                                                          \
+  }
+
+void launch_pipe(int kernel, bool shared, int what, int blocks, hipStream_t s, const DevParams &p, int epoch) {
+  PIPE_SWITCH(trws_pipe_kernel, p)
+}
+void launch_pipe_group(int kernel, bool shared, int what, int blocks, hipStream_t s, const GroupArgs &ga, int epoch) {
+  PIPE_SWITCH(trws_pipe_group_kernel, ga)
+}
+#undef PIPE4
+#undef PIPE1
+#undef PIPE_SWITCH
+
+}  // namespace stereo

@@ -1,0 +1,1140 @@
+// TRW-S simultaneous fusion on MI355X (gfx950): kernels, plan object, C ABI.
+//
+// Replaces the reference's trws_mex gateway + MRFEnergy core + TypeStereo*
+// message update (cpp/trws_mex.cpp, cpp/trw-s/{minimize,ordering,MRFEnergy}.cpp,
+// cpp/trw-s/typeStereo{Linear,Quadratic}.h).  Built with -ffp-contract=off: the
+// reference runs SSE2 doubles without FMA and every value below is computed
+// with the same association of + - * / so results are bit identical.
+//
+// Layout in HBM (all label-fastest, exactly MATLAB's K x N / K x E column major):
+//   unary [N][K]   messages [E][K]   q,qprim [E][K] (or one shared positions[K])
+//   perm_q, perm_qp [E][K] uint16: ascending sort permutation of q(:,e), qprim(:,e)
+// Work decomposition: the reference node order induces a dependency DAG.  One persistent
+// launch per sweep walks it as a dataflow: workgroups draw "runs" (a grid row, the border
+// chain) from a ticket counter and hand messages over in LDS inside a run, through HBM +
+// completion flags between runs.  Four kernel families, identical results
+// (stereo_trws_plan_path), one translation unit each over the common device header trws_dev.h:
+//   trws_pipe.hip     K <= 64, role-specialised waves, both smoothness kernels
+//   trws_pipe2.hip    64 < K <= 128, two labels per lane, linear kernel, per-edge positions
+//   trws_wide.hip     64 < K <= 256, shared strictly ascending positions, linear kernel
+//   trws_generic.hip  everything else (any graph, K <= 512, min-plus message mode)
+// The three descriptor-driven families walk the chain schedule of trws_graph.h; messages take a
+// certified min-plus fast path and fall back to the reference's serial envelope
+// construction when the certificate fails.  This file: plan object, host logic, C ABI.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "../../include/stereo_hip.h"
+#include "common.h"
+#include "trws_graph.h"
+#include "trws_dev.h"
+#include "trws_launch.h"
+
+namespace stereo {
+
+std::string &last_error() {
+  static thread_local std::string s;
+  return s;
+}
+
+namespace {
+
+// Ascending sort permutation of each K-vector (ties: lower index first), one
+// wave per vector, bitonic network in LDS.  Replaces the per-edge std::sort of
+// trws_mex.cpp:84-119 (which re-sorts after every push_back).
+__global__ __launch_bounds__(kWave) void argsort_kernel(const double *vals, uint16_t *perm, int K,
+                                                        int P, int64_t count) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double *v = lds;
+  int *id = (int *)(lds + P);
+  const int lane = threadIdx.x;
+  for (int64_t a = blockIdx.x; a < count; a += gridDim.x) {
+    const double *src = vals + (size_t)a * K;
+    for (int i = lane; i < P; i += kWave) {
+      v[i] = i < K ? src[i] : __builtin_huge_val();
+      id[i] = i < K ? i : (0x10000 + i);
+    }
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int t = lane; t < P / 2; t += kWave) {
+          const int lo = (t / stride) * (stride * 2) + (t % stride);
+          const int hi = lo + stride;
+          const bool up = ((lo & size) == 0);
+          const double a0 = v[lo], a1 = v[hi];
+          const int i0 = id[lo], i1 = id[hi];
+          const bool gt = (a0 > a1) || (a0 == a1 && i0 > i1);
+          if (gt == up) { v[lo] = a1; v[hi] = a0; id[lo] = i1; id[hi] = i0; }
+        }
+        __syncthreads();
+      }
+    }
+    uint16_t *dstp = perm + (size_t)a * K;
+    for (int i = lane; i < K; i += kWave) dstp[i] = (uint16_t)id[i];
+    __syncthreads();
+  }
+}
+
+// Rows whose ascending order holds two equal values (the order of equal positions needs the
+// reference gateway's own sort sequence, see gateway_order below); one thread per row.
+__global__ __launch_bounds__(kBlock) void equal_values_kernel(const double *vals, const uint16_t *perm, int K,
+                                                             int64_t count, uint8_t *flag) {
+  const int64_t a = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (a >= count) return;
+  const double *v = vals + (size_t)a * K;
+  const uint16_t *pm = perm + (size_t)a * K;
+  bool eq = false;
+  double prev = v[pm[0]];
+  for (int k = 1; k < K; ++k) { const double x = v[pm[k]]; eq = eq || x == prev; prev = x; }
+  flag[a] = eq ? 1 : 0;
+}
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const double *vals, const int64_t *rows, int64_t n, int K,
+                                                            double *out) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t < n * K) out[t] = vals[(size_t)rows[t / K] * K + t % K];
+}
+__global__ __launch_bounds__(kBlock) void scatter_perm_kernel(const uint16_t *in, const int64_t *rows, int64_t n, int K,
+                                                             uint16_t *perm) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t < n * K) perm[(size_t)rows[t / K] * K + t % K] = in[t];
+}
+
+// ---- single message updates (diagnostic entry point stereo_trws_messages) ------------------
+// One wave per message through message_regs -- the routine the pipelined sweep kernel computes
+// its messages with (certified fast path, second look, serial construction), table in LDS as
+// there -- so that the certificate can be attacked with hand-placed near-tangent cones.
+template <int KERNEL>
+__global__ __launch_bounds__(kWave) void trws_messages_kernel(DevParams p, int K, int64_t M, const double *Di,
+                                                             const double *gamma, const double *msg_in,
+                                                             const double *qsrc, const double *qdst,
+                                                             const double *alpha, const uint16_t *perm, int window,
+                                                             double *msg_out, double *vmin, int32_t *serial,
+                                                             unsigned long long *counters) {
+  __shared__ __attribute__((aligned(16))) double tab[kPipeTab];
+  const int lane = threadIdx.x;
+  const bool act = lane < K;
+  if (lane < 2 * kPipePad) {
+    double *e = tab + 4 * (lane < kPipePad ? lane : kWave + lane);
+    e[0] = __builtin_huge_val(); e[1] = 0; e[2] = 0; e[3] = 0;
+  }
+  __syncthreads();
+  for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
+    const size_t o = (size_t)m * K + lane;
+    const double h = act ? gamma[m] * Di[o] - msg_in[o] : __builtin_huge_val();
+    const double qs = act ? qsrc[o] : 0.0, qt = act ? qdst[o] : 0.0;
+    p.fallbacks = counters + blockIdx.x;  // (one counter per workgroup: its messages run one after the other)
+    unsigned long long before = 0;
+    if (lane == 0) before = *p.fallbacks;
+    before = __shfl(before, 0, kWave);
+    double out = 0;
+    const double v = message_regs<KERNEL>(p, K, alpha[m], h, qs, qt, perm + (size_t)m * K, out, lane,
+                                          tab + 4 * kPipePad, window);
+    __threadfence();
+    if (act) msg_out[o] = out;
+    if (lane == 0) { vmin[m] = v; serial[m] = (int32_t)(*p.fallbacks - before); }
+  }
+}
+
+}  // namespace
+}  // namespace stereo
+
+// --------------------------------------------------------------------- plan
+
+using namespace stereo;
+
+struct stereo_trws_plan {
+  int kernel = 1, K = 0, Kp = 0, mode = 0, device = 0;
+  int64_t N = 0, E = 0;
+  std::shared_ptr<const TrwsGraph> graph;  // host-side analysis; shared with the cache of the last connectivity
+  // device copies of the graph
+  DevBuf<int32_t> d_tail, d_order, d_fptr, d_fidx, d_bptr, d_bidx, d_lbn, d_lbe, d_x;
+  DevBuf<uint8_t> d_mdir;
+  DevBuf<double> d_gamma, d_msg, d_lbterms, d_eterms;
+  // persistent sweep schedule
+  DevBuf<int32_t> d_run_order[2], d_chain_run_ptr[2], d_chain_run_order[2];
+  DevBuf<int32_t> d_run_ptr[2], d_dep_ptr[2], d_dep_rank[2], d_done, d_ctl;  // d_ctl: [ticket, abort]
+  DevBuf<int8_t> d_in_slot[2];
+  DevBuf<int32_t> d_desc[2];
+  bool fast = false;
+  bool wide = false;  // 64 < K <= 256 with shared strictly ascending positions: trws_wide_kernel
+  bool fast2 = false; // 64 < K <= 128, linear kernel, any positions: trws_pipe2_kernel (when not wide)
+  bool wide_allowed = false;
+  bool pos_ascending = false;  // shared positions finite and strictly ascending
+  double pos_first = 0, pos_last = 0, pos_gap = 0;
+  int window = 0;
+  double uniform_step = 0;
+  DevBuf<unsigned long long> d_fallbacks, d_prof, d_timeline;
+  bool certificate = true;
+  int epoch = 0;
+  bool fwd_pending = false;  // the forward sweep of the next iteration has already run
+  int grid_blocks = 0;
+  // inputs (owned unless bound)
+  DevBuf<double> o_unary, o_q, o_qprim, o_pos, o_alpha;
+  DevBuf<uint16_t> d_perm_q, d_perm_qp, d_perm_pos;
+  const double *unary = nullptr, *q = nullptr, *qprim = nullptr, *pos = nullptr, *alpha = nullptr;
+  double lambda = 0;
+  bool have_inputs = false;
+  PinnedBuf<double> h_lb, h_en;
+  PinnedBuf<int32_t> h_x, h_ctl;
+  hipStream_t issue_stream = nullptr;
+  stereo_trws_plan *timed_by = nullptr;  // first plan of the group launch this plan was issued in
+  double energy = 0, lb = 0;
+  int64_t iterations = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // the lower-bound terms of an iteration go to the host on their own stream while the next
+  // launch (forward sweep + primal) runs, and are summed there meanwhile
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_bwd = nullptr, ev_lb = nullptr;
+  bool lb_in_flight = false;
+  double sweep_ms = 0;
+  int64_t sweep_launches = 0;
+  bool time_sweeps = false;
+  // row strips (one plan per strip; see DevParams)
+  int nstrips = 1, strip = 0;
+  DevBuf<int32_t> d_tickets[2];
+  int ntickets[2] = {0, 0};
+  int64_t n_lb = 0, n_en = 0;  // lower-bound / energy terms this plan writes (strip-local with strips)
+  double *peer_msg[2] = {nullptr, nullptr};
+  int32_t *peer_done[2] = {nullptr, nullptr}, *peer_x[2] = {nullptr, nullptr};
+  bool need_peer[2] = {false, false};
+  void *ipc_mapped[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  DevBuf<DevParams> d_group;         // parameters of the strips launched together with this one (first plan of a group)
+  PinnedBuf<DevParams> h_group;
+  hipStream_t own_stream = nullptr;  // strips launch concurrently: never on the NULL stream
+  bool issued = false;
+  int cus = 256;
+  ~stereo_trws_plan() {
+    for (int w = 0; w < 2; ++w)
+      for (int k = 0; k < 3; ++k)
+        if (ipc_mapped[w][k]) (void)hipIpcCloseMemHandle(ipc_mapped[w][k]);
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (ev_bwd) (void)hipEventDestroy(ev_bwd);
+    if (ev_lb) (void)hipEventDestroy(ev_lb);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
+  }
+};
+
+namespace {
+
+size_t persistent_lds_bytes(int Kp) { return generic_lds_bytes(Kp); }
+
+DevParams make_params(stereo_trws_plan *P) {
+  DevParams p{};
+  p.K = P->K; p.Kp = P->Kp; p.kernel = P->kernel; p.lambda = P->lambda;
+  p.unary = P->unary; p.msg = P->d_msg.p; p.q = P->q; p.qprim = P->qprim; p.pos = P->pos;
+  p.perm_q = P->d_perm_q.p; p.perm_qp = P->d_perm_qp.p; p.perm_pos = P->d_perm_pos.p;
+  p.alpha = P->alpha; p.mdir = P->d_mdir.p; p.tail = P->d_tail.p; p.order = P->d_order.p;
+  p.fptr = P->d_fptr.p; p.fidx = P->d_fidx.p; p.bptr = P->d_bptr.p; p.bidx = P->d_bidx.p;
+  p.gamma = P->d_gamma.p; p.lb_pos_node = P->d_lbn.p; p.lb_pos_edge = P->d_lbe.p;
+  p.lbterms = P->d_lbterms.p; p.eterms = P->d_eterms.p; p.x = P->d_x.p;
+  // the descriptor-driven kernels walk the chain schedule (trws_graph.h), the generic ones the
+  // rank-contiguous runs
+  const bool chain = P->graph->fast_ok && (P->wide || P->fast2 || P->fast);
+  for (int d = 0; d < 2; ++d) {
+    if (chain) {
+      p.run_ptr[d] = P->d_chain_run_ptr[d].p; p.nruns[d] = (int)P->graph->sweep[d].chain_run_ptr.size() - 1;
+      p.run_order[d] = P->d_chain_run_order[d].p;
+    } else {
+      p.run_ptr[d] = P->d_run_ptr[d].p; p.nruns[d] = (int)P->graph->sweep[d].run_ptr.size() - 1;
+      p.run_order[d] = P->d_run_order[d].p;
+    }
+    p.dep_ptr[d] = P->d_dep_ptr[d].p; p.dep_rank[d] = P->d_dep_rank[d].p;
+    p.in_slot[d] = P->d_in_slot[d].p;
+  }
+  for (int d = 0; d < 2; ++d) {
+    p.ntickets[d] = P->nstrips > 1 ? P->ntickets[d] : p.nruns[d];
+    if (P->nstrips > 1) p.run_order[d] = P->d_tickets[d].p;
+  }
+  p.peer_msg0 = P->peer_msg[0]; p.peer_msg1 = P->peer_msg[1];
+  p.peer_done0 = P->peer_done[0]; p.peer_done1 = P->peer_done[1];
+  p.peer_x0 = P->peer_x[0]; p.peer_x1 = P->peer_x[1];
+  p.done = P->d_done.p; p.ticket = P->d_ctl.p; p.abort_flag = P->d_ctl.p + 1; p.N = (int)P->N;
+  p.fallbacks = P->d_fallbacks.p; p.certificate = P->certificate ? 1 : 0;
+  p.prof = P->d_prof.p;
+  p.timeline = P->d_timeline.p;
+  p.desc[0] = P->d_desc[0].p; p.desc[1] = P->d_desc[1].p;
+  p.prof_run = -1;
+  p.window = P->window;
+  p.uniform_step = P->uniform_step;
+  p.pos_first = P->pos_first; p.pos_last = P->pos_last;
+  p.debug = 0;
+  if (const char *dbg = std::getenv("STEREO_HIP_TRWS_DEBUG")) p.debug = std::atoi(dbg);
+  p.win_ok = (P->pos_ascending && P->window <= 16 && !(p.debug & 256)) ? 1 : 0;
+  p.pos_gap = P->pos_gap;
+  if (const char *pr = std::getenv("STEREO_HIP_TRWS_PROF_RUN")) p.prof_run = std::atoi(pr);
+  return p;
+}
+
+// One persistent launch: 0 = forward, 1 = backward, 2 = forward + primal of the
+// previous iteration, 3 = primal only.
+void launch_persistent(stereo_trws_plan *P, const DevParams &p, int what, hipStream_t s) {
+  const int epoch = ++P->epoch;
+  STEREO_HIP_CHECK(hipMemsetAsync(P->d_ctl.p, 0, sizeof(int32_t), s));  // ticket = 0
+  if (P->wide) launch_wide(what, std::min(P->grid_blocks, P->cus), s, p, epoch);
+  else if (P->fast2) launch_pipe2(P->pos != nullptr, what, std::min(P->grid_blocks, P->cus), s, p, epoch);
+  else if (P->fast) launch_pipe(P->kernel, P->pos != nullptr, what, P->grid_blocks, s, p, epoch);
+  else launch_generic(P->kernel, P->mode, what, P->grid_blocks, persistent_lds_bytes(P->Kp), s, p, epoch);
+  if (what != 3) P->sweep_launches += 1;
+}
+
+void persistent_iteration(stereo_trws_plan *P, const DevParams &p, hipStream_t s) {
+  if (P->time_sweeps) STEREO_HIP_CHECK(hipEventRecord(P->ev0, s));
+  if (!P->fwd_pending) launch_persistent(P, p, 0, s);
+  launch_persistent(P, p, 1, s);
+  // the backward sweep's lower-bound terms travel while the next launch runs
+  STEREO_HIP_CHECK(hipEventRecord(P->ev_bwd, s));
+  STEREO_HIP_CHECK(hipStreamWaitEvent(P->copy_stream, P->ev_bwd, 0));
+  STEREO_HIP_CHECK(hipMemcpyAsync(P->h_lb.p, P->d_lbterms.p, sizeof(double) * P->n_lb, hipMemcpyDeviceToHost,
+                                  P->copy_stream));
+  STEREO_HIP_CHECK(hipEventRecord(P->ev_lb, P->copy_stream));
+  P->lb_in_flight = true;
+  // forward sweep of the NEXT iteration fused with this iteration's primal
+  launch_persistent(P, p, 2, s);
+  P->fwd_pending = true;
+  if (P->time_sweeps) STEREO_HIP_CHECK(hipEventRecord(P->ev1, s));
+}
+
+void run_argsort(const double *vals, uint16_t *perm, int K, int64_t count, hipStream_t s) {
+  int Pw = 2;
+  while (Pw < K) Pw <<= 1;
+  const size_t lds = (size_t)Pw * (sizeof(double) + sizeof(int));
+  const int64_t grid = std::min<int64_t>(count, 256 * 32);
+  hipLaunchKernelGGL(argsort_kernel, dim3((unsigned)grid), dim3(kWave), lds, s, vals, perm, K, Pw, count);
+  STEREO_HIP_CHECK(hipGetLastError());
+}
+
+// Zero messages (MRFEnergy.cpp:115-133), labels, flags and every piece of iteration state.
+void reset_state(stereo_trws_plan *P) {
+  STEREO_HIP_CHECK(hipMemset(P->d_msg.p, 0, sizeof(double) * (size_t)P->E * P->K));
+  STEREO_HIP_CHECK(hipMemset(P->d_x.p, 0, sizeof(int32_t) * P->N));
+  STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * P->N));
+  STEREO_HIP_CHECK(hipMemset(P->d_ctl.p, 0, sizeof(int32_t) * 2));
+  STEREO_HIP_CHECK(hipDeviceSynchronize());
+  P->iterations = 0; P->energy = 0; P->lb = 0; P->epoch = 0; P->fwd_pending = false;
+  P->lb_in_flight = false; P->issued = false;
+}
+
+// The order in which the reference's gateway hands EQUAL positions to the message code.
+// trws_mex.cpp:84-97 pushes one (value, index) pair at a time and calls std::sort on the whole
+// vector after every push, comparing values only (:16-20).  std::sort is not stable: up to 16
+// elements it is an insertion sort (equal values stay in index order -- what argsort_kernel
+// produces), beyond that its introsort may swap equal values.  Equal positions are no corner
+// case: simultaneous_fusion appends the current assignment as a label (dispmap_super.m:158), so
+// wherever a proposal's plane is the current plane two labels coincide exactly.  For such vectors
+// the same sequence of calls is made here, with the std::sort of the toolchain in use -- what a
+// reference built with that toolchain does.
+void gateway_order(const double *v, int K, uint16_t *perm) {
+  typedef std::pair<double, int> Pair;
+  struct Cmp {
+    bool operator()(const Pair &a, const Pair &b) const { return a.first < b.first; }
+  };
+  std::vector<Pair> pr;
+  pr.reserve(K);
+  for (int j = 0; j < K; ++j) {
+    pr.push_back(Pair(v[j], j));
+    std::sort(pr.begin(), pr.end(), Cmp());
+  }
+  for (int j = 0; j < K; ++j) perm[j] = (uint16_t)pr[j].second;
+}
+
+// After argsort_kernel: rows with equal values get the gateway's order (K > 16 only, see above).
+void fix_equal_positions(const double *d_vals, uint16_t *d_perm, int K, int64_t count) {
+  if (K <= 16 || count <= 0) return;
+  DevBuf<uint8_t> d_flag;
+  d_flag.alloc(count);
+  hipLaunchKernelGGL(equal_values_kernel, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, 0, d_vals,
+                     d_perm, K, count, d_flag.p);
+  STEREO_HIP_CHECK(hipGetLastError());
+  std::vector<uint8_t> flag(count);
+  STEREO_HIP_CHECK(hipMemcpy(flag.data(), d_flag.p, count, hipMemcpyDeviceToHost));
+  std::vector<int64_t> rows;
+  for (int64_t a = 0; a < count; ++a)
+    if (flag[a]) rows.push_back(a);
+  const int64_t n = (int64_t)rows.size();
+  if (n == 0) return;
+  DevBuf<int64_t> d_rows;
+  DevBuf<double> d_g;
+  DevBuf<uint16_t> d_p;
+  d_rows.upload(rows.data(), n);
+  d_g.alloc((size_t)n * K); d_p.alloc((size_t)n * K);
+  const unsigned gb = (unsigned)(((int64_t)n * K + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(gb), dim3(kBlock), 0, 0, d_vals, d_rows.p, n, K, d_g.p);
+  STEREO_HIP_CHECK(hipGetLastError());
+  std::vector<double> g((size_t)n * K);
+  STEREO_HIP_CHECK(hipMemcpy(g.data(), d_g.p, sizeof(double) * n * K, hipMemcpyDeviceToHost));
+  std::vector<uint16_t> pm((size_t)n * K);
+  const int64_t T = std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency() / 2, 64, n / 256 + 1}));
+  std::vector<std::thread> pool;
+  auto work = [&](int64_t a, int64_t b) { for (int64_t i = a; i < b; ++i) gateway_order(&g[(size_t)i * K], K, &pm[(size_t)i * K]); };
+  for (int64_t t = 1; t < T; ++t) pool.emplace_back(work, n * t / T, n * (t + 1) / T);
+  work(0, n / T);
+  for (auto &th : pool) th.join();
+  STEREO_HIP_CHECK(hipMemcpy(d_p.p, pm.data(), sizeof(uint16_t) * n * K, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(scatter_perm_kernel, dim3(gb), dim3(kBlock), 0, 0, d_p.p, d_rows.p, n, K, d_perm);
+  STEREO_HIP_CHECK(hipGetLastError());
+  STEREO_HIP_CHECK(hipDeviceSynchronize());
+}
+
+void finish_inputs(stereo_trws_plan *P) {
+  // New inputs start a new minimisation: the forward sweep of the next iteration has usually run
+  // already with the OLD inputs (persistent_iteration fuses it with the primal pass), so the
+  // messages on the device belong to no state the reference could be in with the new ones.
+  if (P->iterations > 0 || P->fwd_pending) reset_state(P);
+  if (P->pos) {
+    P->d_perm_pos.alloc(P->K);
+    run_argsort(P->pos, P->d_perm_pos.p, P->K, 1, nullptr);
+    fix_equal_positions(P->pos, P->d_perm_pos.p, P->K, 1);
+    P->d_perm_q.release(); P->d_perm_qp.release();
+  } else {
+    P->d_perm_q.alloc((size_t)P->E * P->K);
+    P->d_perm_qp.alloc((size_t)P->E * P->K);
+    run_argsort(P->q, P->d_perm_q.p, P->K, P->E, nullptr);
+    run_argsort(P->qprim, P->d_perm_qp.p, P->K, P->E, nullptr);
+    fix_equal_positions(P->q, P->d_perm_q.p, P->K, P->E);
+    fix_equal_positions(P->qprim, P->d_perm_qp.p, P->K, P->E);
+  }
+  STEREO_HIP_CHECK(hipDeviceSynchronize());
+  // shared positions that are finite and strictly ascending: truncation window in index steps
+  // (windowed min-plus of the pipelined kernel's flat-h path; the wide-label kernel requires it)
+  P->wide = false; P->uniform_step = 0; P->pos_ascending = false; P->window = 0;
+  if (P->pos && P->lambda >= 0) {
+    std::vector<double> hp(P->K);
+    STEREO_HIP_CHECK(hipMemcpy(hp.data(), P->pos, sizeof(double) * P->K, hipMemcpyDeviceToHost));
+    bool asc = std::isfinite(hp[0]);
+    for (int k = 1; k < P->K && asc; ++k) asc = std::isfinite(hp[k]) && hp[k] > hp[k - 1];
+    if (asc) {
+      // a source farther than lambda from a destination (squared distance for kernel 2)
+      // costs >= vTrunc, so min-plus only needs the sources within +-window indices
+      int w = 0;
+      for (int k = 0, lo = 0; k < P->K; ++k) {
+        for (;; ++lo) {
+          const double d = hp[k] - hp[lo];
+          if ((P->kernel == 1 ? d : d * d) <= (P->kernel == 1 ? P->lambda : P->lambda * (1 + 1e-9))) break;
+        }
+        w = std::max(w, k - lo);
+      }
+      P->window = w;
+      P->pos_ascending = true;
+      P->pos_first = hp[0]; P->pos_last = hp[P->K - 1];
+      P->pos_gap = std::numeric_limits<double>::infinity();
+      for (int k = 1; k < P->K; ++k) P->pos_gap = std::min(P->pos_gap, hp[k] - hp[k - 1]);
+      P->wide = P->wide_allowed;
+      // exact arithmetic progression inside the window?  (then alpha |t - q| = alpha |d step| bit for bit)
+      P->uniform_step = 0;
+      if (w <= 16 && P->K > 1) {
+        const double step = hp[1] - hp[0];
+        bool uni = step > 0;
+        for (int d = 1; d <= w && uni; ++d)
+          for (int k = 0; k + d < P->K && uni; ++k) uni = (hp[k + d] - hp[k]) == (double)d * step;
+        if (uni) P->uniform_step = step;
+      }
+    }
+  }
+  P->have_inputs = true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int stereo_hip_abi_version(void) { return STEREO_HIP_ABI_VERSION; }
+
+int stereo_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+__global__ void warm_up_kernel() {}
+
+int stereo_hip_warm_up(void) {
+  if (stereo_hip_device_count() < 1) return 1;
+  if (hipFree(nullptr) != hipSuccess) return 1;
+  hipLaunchKernelGGL(warm_up_kernel, dim3(1), dim3(64), 0, 0);
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  // every runtime service the QPBO path uses (cooperative launch, occupancy query, function
+  // attributes, the Improve kernels) once, on a frustrated triangle that stays unlabelled
+  const double U[3] = {0, 0, 0}, same[3] = {1, 1, 1}, diff[3] = {0, 0, 0};
+  const uint32_t conn[6] = {0, 1, 1, 2, 2, 0};
+  double lab[3], en = 0, lb = 0, nu = 0;
+  char err[256];
+  return stereo_rd(U, U, same, diff, diff, same, conn, 3, 3, 1, lab, &en, &lb, &nu, err, sizeof(err));
+}
+
+int stereo_hip_set_device(int device) {
+  if (hipSetDevice(device) != hipSuccess) {
+    last_error() = "hipSetDevice failed";
+    return 1;
+  }
+  return 0;
+}
+
+const char *stereo_hip_last_error(void) { return last_error().c_str(); }
+
+static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint32_t *conn, int message_mode,
+                            const int32_t *owner, int nstrips, int strip, int max_blocks,
+                            stereo_trws_plan *share, bool strip_api, stereo_trws_plan **plan, char *err, size_t errcap) {
+  if (!plan) return fail("stereo_trws_plan_create: plan is NULL", err, errcap);
+  *plan = nullptr;
+  if (nstrips < 1 || strip < 0 || strip >= nstrips) return fail("stereo_trws_plan_create: strip out of range", err, errcap);
+  if (nstrips > 1 && !owner && !share) return fail("stereo_trws_plan_create: strips need an owner per node", err, errcap);
+  if (kernel != 1 && kernel != 2) return fail("Unsupported kernel", err, errcap);
+  if (K < 1 || K > 8 * kWave) return fail("stereo_trws: K must be in [1, 512]", err, errcap);
+  const int ordering = (message_mode & STEREO_TRWS_ORDER_INDEX) ? 1 : 0;
+  message_mode &= ~STEREO_TRWS_ORDER_INDEX;
+  if (message_mode != STEREO_TRWS_MESSAGES_EXACT && message_mode != STEREO_TRWS_MESSAGES_MINPLUS)
+    return fail("stereo_trws: unknown message mode", err, errcap);
+  if (stereo_hip_device_count() < 1)
+    return fail("stereo_trws: no HIP device available (the HIP path has no CPU fallback)", err, errcap);
+  try {
+    std::unique_ptr<stereo_trws_plan> P(new stereo_trws_plan);
+    P->kernel = kernel; P->K = K; P->Kp = (K + 1) & ~1; P->mode = message_mode; P->N = N; P->E = E;
+    P->nstrips = nstrips; P->strip = strip;
+    std::string gerr;
+    // Workgroups that stay resident: runs beyond that are cut / dispensed by dependency level.  The
+    // bound comes from the device in use (a partitioned or masked MI355X exposes fewer CUs): one
+    // workgroup per CU is what is certain to be resident, LDS decides how many more fit.
+    STEREO_HIP_CHECK(hipGetDevice(&P->device));
+    {
+      int cus = 0;
+      STEREO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, P->device));
+      P->cus = std::max(cus, 1);
+    }
+    const bool wide_candidate = kernel == 1 && K > kWave && K <= 256 && message_mode == STEREO_TRWS_MESSAGES_EXACT;
+    const int64_t per_cu = std::min<int64_t>(std::max<int64_t>(1, (int64_t)(160 * 1024) / (int64_t)persistent_lds_bytes(P->Kp)), 4);
+    const int64_t capacity = wide_candidate ? P->cus : P->cus * per_cu;
+    // The analysis depends on the connectivity only (ordering, lists, schedules: 0.2-0.6 s at Teddy
+    // size); consecutive plans for the same image grid -- every trws() call of a fusion loop --
+    // share the last one.
+    if (share) {
+      // the strips of one process share one analysis (it is the same on every strip)
+      if (!share->graph || share->N != N || share->E != E || share->graph->nstrips != nstrips)
+        return fail("stereo_trws_plan_create: the plan to share the graph analysis with belongs to another problem", err, errcap);
+      P->graph = share->graph;
+    } else {
+      static std::mutex cache_mutex;
+      static struct { int64_t N = -1, E = -1, capacity = -1, cus = -1; int nstrips = 1, ordering = 0; std::vector<uint32_t> conn; std::vector<int32_t> owner;
+                      std::shared_ptr<const TrwsGraph> g; } cache;
+      std::lock_guard<std::mutex> lock(cache_mutex);
+      const bool hit = cache.g && cache.N == N && cache.E == E && cache.capacity == capacity && cache.cus == P->cus &&
+                       cache.nstrips == nstrips && cache.ordering == ordering &&
+                       std::memcmp(cache.conn.data(), conn, sizeof(uint32_t) * 2 * (size_t)E) == 0 &&
+                       (nstrips == 1 || std::memcmp(cache.owner.data(), owner, sizeof(int32_t) * (size_t)N) == 0);
+      if (hit) {
+        P->graph = cache.g;
+      } else {
+        auto fresh = std::make_shared<TrwsGraph>();
+        if (!build_trws_graph(N, E, conn, *fresh, gerr, capacity, nstrips > 1 ? owner : nullptr, nstrips, P->cus, ordering)) return fail(gerr, err, errcap);
+        P->graph = fresh;
+        if (N <= (1 << 20)) {  // (the descriptors of a 3000 x 2000 grid are 3 GB: not worth keeping)
+          cache.N = N; cache.E = E; cache.capacity = capacity; cache.cus = P->cus; cache.nstrips = nstrips; cache.ordering = ordering;
+          cache.conn.assign(conn, conn + 2 * (size_t)E); cache.g = fresh;
+          if (nstrips > 1) cache.owner.assign(owner, owner + N); else cache.owner.clear();
+        } else {
+          cache.g.reset(); cache.conn.clear(); cache.owner.clear(); cache.N = -1;
+        }
+      }
+    }
+    const TrwsGraph &g = *P->graph;
+    P->d_tail.upload(g.tail.data(), g.tail.size());
+    P->d_order.upload(g.order.data(), g.order.size());
+    P->d_fptr.upload(g.fptr.data(), g.fptr.size());
+    P->d_fidx.upload(g.fidx.data(), g.fidx.size());
+    P->d_bptr.upload(g.bptr.data(), g.bptr.size());
+    P->d_bidx.upload(g.bidx.data(), g.bidx.size());
+    P->d_lbn.upload(g.lb_pos_node.data(), g.lb_pos_node.size());
+    P->d_lbe.upload(g.lb_pos_edge.data(), g.lb_pos_edge.size());
+    P->d_mdir.upload(g.mdir.data(), g.mdir.size());
+    P->d_gamma.upload(g.gamma.data(), g.gamma.size());
+    for (int d = 0; d < 2; ++d) {
+      const TrwsGraph::Sweep &S = g.sweep[d];
+      P->d_run_ptr[d].upload(S.run_ptr.data(), S.run_ptr.size());
+      if (!S.run_order.empty()) P->d_run_order[d].upload(S.run_order.data(), S.run_order.size());
+      P->d_dep_ptr[d].upload(S.dep_ptr.data(), S.dep_ptr.size());
+      P->d_dep_rank[d].upload(S.dep_rank.data(), S.dep_rank.size());
+      P->d_in_slot[d].upload(S.in_slot.data(), S.in_slot.size());
+      if (g.fast_ok) {
+        P->d_desc[d].upload(S.desc.data(), S.desc.size());
+        P->d_chain_run_ptr[d].upload(S.chain_run_ptr.data(), S.chain_run_ptr.size());
+        if (!S.chain_run_order.empty()) P->d_chain_run_order[d].upload(S.chain_run_order.data(), S.chain_run_order.size());
+      }
+    }
+    P->fast = g.fast_ok && K <= kWave && message_mode == STEREO_TRWS_MESSAGES_EXACT;
+    P->wide_allowed = g.fast_ok && kernel == 1 && K > kWave && K <= 256 && message_mode == STEREO_TRWS_MESSAGES_EXACT;
+    P->fast2 = g.fast_ok && kernel == 1 && K > kWave && K <= 2 * kWave && message_mode == STEREO_TRWS_MESSAGES_EXACT;
+    if (const char *f = std::getenv("STEREO_HIP_TRWS_FAST")) {
+      P->fast = P->fast && std::string(f) != "0";
+      P->wide_allowed = P->wide_allowed && std::string(f) != "0";
+      P->fast2 = P->fast2 && std::string(f) != "0";
+    }
+    if (nstrips > 1) {
+      // a strip walks the chain schedule with one of the descriptor-driven kernels
+      if (!(P->fast || P->wide_allowed || P->fast2))
+        return fail("stereo_trws: row strips need a graph and label count the pipelined kernels take "
+                    "(<= 8 edges per node; K <= 64, or K <= 128 with the linear kernel, or K <= 256 with shared positions)", err, errcap);
+      for (int d = 0; d < 2; ++d) {
+        const TrwsGraph::Sweep &S = g.sweep[d];
+        const int64_t R = (int64_t)S.chain_run_ptr.size() - 1;
+        std::vector<int32_t> mine;
+        for (int64_t t = 0; t < R; ++t) {
+          const int32_t run = S.chain_run_order.empty() ? (int32_t)t : S.chain_run_order[t];
+          if (S.chain_run_strip[run] == strip) mine.push_back(run);
+        }
+        P->ntickets[d] = (int)mine.size();
+        P->d_tickets[d].upload(mine.data(), mine.size());
+        // which neighbours this strip writes to (it must be connected to them before it iterates)
+        for (int64_t q = 0; q < N; ++q) {
+          const uint32_t rem = (uint32_t)S.desc[(size_t)q * TrwsGraph::kDescWords + kDescRemote];
+          if (g.owner[g.order[S.chain_rank[q]]] != strip) continue;
+          if (rem & (1u << 16)) P->need_peer[0] = true;
+          if (rem & (1u << 17)) P->need_peer[1] = true;
+        }
+      }
+    }
+    if (strip_api) STEREO_HIP_CHECK(hipStreamCreateWithFlags(&P->own_stream, hipStreamNonBlocking));
+    P->n_lb = nstrips > 1 ? g.strip_lb_terms[strip] : g.lb_terms;
+    P->n_en = nstrips > 1 ? g.strip_nodes[strip] : N;
+    P->d_done.alloc(N);
+    P->d_ctl.alloc(2);
+    P->d_fallbacks.alloc(1);
+    STEREO_HIP_CHECK(hipMemset(P->d_fallbacks.p, 0, sizeof(unsigned long long)));
+    if (const char *c = std::getenv("STEREO_HIP_TRWS_CERTIFICATE")) P->certificate = std::string(c) != "0";
+    if (std::getenv("STEREO_HIP_TRWS_PROF")) { P->d_prof.alloc(32); STEREO_HIP_CHECK(hipMemset(P->d_prof.p, 0, 256)); }
+    if (std::getenv("STEREO_HIP_TRWS_TIMELINE"))
+      P->d_timeline.alloc(4 * std::max({g.sweep[0].run_ptr.size(), g.sweep[0].chain_run_ptr.size(), g.sweep[1].chain_run_ptr.size()}) + 4);
+    STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * N));
+    STEREO_HIP_CHECK(hipMemset(P->d_ctl.p, 0, sizeof(int32_t) * 2));
+    {
+      // one workgroup per concurrently active run, capped by what stays resident
+      int64_t runs = std::max<int64_t>((int64_t)g.sweep[0].run_ptr.size() - 1, 1);
+      if (g.fast_ok)
+        runs = std::max<int64_t>({runs, (int64_t)g.sweep[0].chain_run_ptr.size() - 1, (int64_t)g.sweep[1].chain_run_ptr.size() - 1});
+      if (nstrips > 1) runs = std::max<int64_t>({1, (int64_t)P->ntickets[0], (int64_t)P->ntickets[1]});
+      P->grid_blocks = (int)std::min<int64_t>(runs, P->cus * per_cu);
+      if (max_blocks > 0) P->grid_blocks = std::min(P->grid_blocks, max_blocks);
+    }
+    P->d_msg.alloc((size_t)E * K);
+    P->d_lbterms.alloc(P->n_lb);
+    P->d_eterms.alloc(P->n_en);
+    P->d_x.alloc(N);
+    P->h_lb.alloc(P->n_lb); P->h_en.alloc(P->n_en); P->h_x.alloc(N); P->h_ctl.alloc(2);
+    P->h_ctl.p[0] = P->h_ctl.p[1] = 0;
+    STEREO_HIP_CHECK(hipMemset(P->d_msg.p, 0, sizeof(double) * (size_t)E * K));
+    STEREO_HIP_CHECK(hipMemset(P->d_x.p, 0, sizeof(int32_t) * N));
+    STEREO_HIP_CHECK(hipEventCreate(&P->ev0));
+    STEREO_HIP_CHECK(hipEventCreate(&P->ev1));
+    STEREO_HIP_CHECK(hipEventCreateWithFlags(&P->ev_bwd, hipEventDisableTiming));
+    STEREO_HIP_CHECK(hipEventCreateWithFlags(&P->ev_lb, hipEventDisableTiming));
+    STEREO_HIP_CHECK(hipStreamCreateWithFlags(&P->copy_stream, hipStreamNonBlocking));
+    STEREO_HIP_CHECK(hipDeviceSynchronize());
+    // every sweep kernel may need more than the default 64 KiB of dynamic LDS
+    const int plds = (int)persistent_lds_bytes(P->Kp);
+    if (plds > 160 * 1024) return fail("stereo_trws: K too large for LDS", err, errcap);
+    generic_set_attributes(plds);
+    if (P->fast || strip_api) pipe_set_attributes();
+    if (P->fast2) pipe2_set_attributes();
+    if (P->wide_allowed || strip_api) wide_set_attributes();
+    *plan = P.release();
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  } catch (const std::exception &e) {
+    return fail(std::string("stereo_trws_plan_create: ") + e.what(), err, errcap);
+  }
+}
+
+int stereo_trws_plan_create(int kernel, int K, int64_t N, int64_t E, const uint32_t *conn,
+                            int message_mode, stereo_trws_plan **plan, char *err, size_t errcap) {
+  return plan_create_impl(kernel, K, N, E, conn, message_mode, nullptr, 1, 0, 0, nullptr, false, plan, err, errcap);
+}
+
+int stereo_trws_plan_create_strip(int kernel, int K, int64_t N, int64_t E, const uint32_t *conn, int message_mode,
+                                  const int32_t *owner, int nstrips, int strip, int max_workgroups,
+                                  stereo_trws_plan *share_analysis_with, stereo_trws_plan **plan, char *err,
+                                  size_t errcap) {
+  return plan_create_impl(kernel, K, N, E, conn, message_mode, owner, nstrips, strip, max_workgroups,
+                          share_analysis_with, true, plan, err, errcap);
+}
+
+void stereo_trws_plan_destroy(stereo_trws_plan *plan) {
+  if (plan && plan->d_timeline.p) {
+    const bool chain = plan->graph->fast_ok && (plan->wide || plan->fast2 || plan->fast);
+    const size_t R = (chain ? plan->graph->sweep[0].chain_run_ptr.size() : plan->graph->sweep[0].run_ptr.size()) - 1;
+    std::vector<unsigned long long> t(4 * (R + 1));
+    if (hipMemcpy(t.data(), plan->d_timeline.p, sizeof(unsigned long long) * 4 * R, hipMemcpyDeviceToHost) == hipSuccess) {
+      for (int d = 0; d < 2; ++d) {
+        const unsigned long long t0 = t[(size_t)d * R * 2];
+        std::fprintf(stderr, "[stereo_hip timeline] dir %d (us since run 0 start): ", d);
+        for (size_t r = 0; r < R; r += (r < 8 ? 1 : R / 12 + 1))
+          std::fprintf(stderr, "run%zu[%.0f..%.0f] ", r, (t[(d * R + r) * 2] - t0) / 100.0, (t[(d * R + r) * 2 + 1] - t0) / 100.0);
+        std::fprintf(stderr, "last[%.0f..%.0f]\n", (t[(d * R + R - 1) * 2] - t0) / 100.0, (t[(d * R + R - 1) * 2 + 1] - t0) / 100.0);
+      }
+    }
+  }
+  if (plan && plan->d_prof.p) {
+    unsigned long long v[32];
+    if (hipMemcpy(v, plan->d_prof.p, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess) {
+      if (!plan->wide)
+        std::fprintf(stderr, "[stereo_hip prof] cycles: p0 %llu p1 %llu p2 %llu p3 %llu p4 %llu | p5 %llu steps %llu\n",
+                     v[0], v[1], v[2], v[3], v[4], v[5], v[6]);
+      if (!plan->wide && v[9])
+        std::fprintf(stderr, "[stereo_hip prof messages] certified attempt %.0f cycles x %llu | second look %.0f x %llu | "
+                             "serial construction %.0f x %llu | walk %.0f x %llu\n",
+                     (double)v[8] / v[9], v[9], v[11] ? (double)v[10] / v[11] : 0.0, v[11], v[13] ? (double)v[12] / v[13] : 0.0,
+                     v[13], v[15] ? (double)v[14] / v[15] : 0.0, v[15]);
+      if (plan->wide && v[22]) {
+        std::fprintf(stderr, "[stereo_hip prof wide] cycles per visit of wave 0:");
+        for (int i = 0; i < 16; ++i) std::fprintf(stderr, " [%d] %.0f", i, (double)v[i] / v[22]);
+        std::fprintf(stderr, " | loader A %.0f B %.0f storer %.0f primal %.0f | hw barrier wait %.0f | visits %llu\n",
+                     (double)v[16] / v[22], (double)v[17] / v[22], (double)v[18] / v[22], (double)v[19] / v[22],
+                     (double)v[21] / v[22], v[22]);
+      }
+    }
+  }
+  delete plan;
+}
+
+int stereo_trws_plan_upload(stereo_trws_plan *P, const double *unary, const double *q,
+                            const double *qprim, const double *positions, const double *alphas,
+                            double tol, char *err, size_t errcap) {
+  if (!P || !unary || !alphas) return fail("stereo_trws_plan_upload: NULL argument", err, errcap);
+  const bool shared = (q == nullptr && qprim == nullptr);
+  if (shared && !positions) return fail("stereo_trws_plan_upload: need q/qprim or positions", err, errcap);
+  if (!shared && (!q || !qprim)) return fail("stereo_trws_plan_upload: q and qprim must both be given", err, errcap);
+  try {
+    const size_t K = P->K;
+    P->o_unary.upload(unary, (size_t)P->N * K);
+    P->o_alpha.upload(alphas, (size_t)P->E);
+    P->unary = P->o_unary.p; P->alpha = P->o_alpha.p;
+    if (shared) {
+      P->o_pos.upload(positions, K);
+      P->pos = P->o_pos.p; P->q = P->qprim = nullptr;
+      P->o_q.release(); P->o_qprim.release();
+    } else {
+      P->o_q.upload(q, (size_t)P->E * K);
+      P->o_qprim.upload(qprim, (size_t)P->E * K);
+      P->q = P->o_q.p; P->qprim = P->o_qprim.p; P->pos = nullptr;
+    }
+    P->lambda = tol;
+    finish_inputs(P);
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+int stereo_trws_plan_bind_device(stereo_trws_plan *P, const double *d_unary, const double *d_q,
+                                 const double *d_qprim, const double *d_positions,
+                                 const double *d_alphas, double tol, char *err, size_t errcap) {
+  if (!P || !d_unary || !d_alphas) return fail("stereo_trws_plan_bind_device: NULL argument", err, errcap);
+  const bool shared = (d_q == nullptr && d_qprim == nullptr);
+  if (shared && !d_positions) return fail("stereo_trws_plan_bind_device: need q/qprim or positions", err, errcap);
+  if (!shared && (!d_q || !d_qprim)) return fail("stereo_trws_plan_bind_device: q and qprim must both be given", err, errcap);
+  try {
+    P->unary = d_unary; P->alpha = d_alphas; P->lambda = tol;
+    if (shared) { P->pos = d_positions; P->q = P->qprim = nullptr; }
+    else { P->q = d_q; P->qprim = d_qprim; P->pos = nullptr; }
+    finish_inputs(P);
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+int stereo_trws_plan_reset(stereo_trws_plan *P, char *err, size_t errcap) {
+  if (!P) return fail("stereo_trws_plan_reset: NULL plan", err, errcap);
+  try {
+    reset_state(P);
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+// One iteration's launches and device-to-host copies, without waiting for any of them.
+static void issue_iteration(stereo_trws_plan *P, const DevParams &p, hipStream_t s) {
+  persistent_iteration(P, p, s);
+  if (!P->lb_in_flight)
+    STEREO_HIP_CHECK(hipMemcpyAsync(P->h_lb.p, P->d_lbterms.p, sizeof(double) * P->n_lb, hipMemcpyDeviceToHost, s));
+  STEREO_HIP_CHECK(hipMemcpyAsync(P->h_en.p, P->d_eterms.p, sizeof(double) * P->n_en, hipMemcpyDeviceToHost, s));
+  STEREO_HIP_CHECK(hipMemcpyAsync(P->h_ctl.p, P->d_ctl.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  P->issued = true;
+}
+
+// Waits for the iteration issued last and sums its lower-bound and energy terms in the
+// reference's order (minimize.cpp:82,92 and :260): sequential, bit exact.  Returns false if a
+// sweep gave up waiting on a dependency flag.
+static bool collect_iteration(stereo_trws_plan *P, hipStream_t s, double *lb_out, double *en_out) {
+  double lb = 0, en = 0;
+  if (P->lb_in_flight) {  // summed while the forward sweep + primal launch is still running
+    STEREO_HIP_CHECK(hipEventSynchronize(P->ev_lb));
+    for (int64_t i = 0; i < P->n_lb; ++i) lb += P->h_lb.p[i];
+  }
+  STEREO_HIP_CHECK(hipStreamSynchronize(s));
+  P->issued = false;
+  if (P->h_ctl.p[1]) return false;
+  if (P->time_sweeps && (!P->timed_by || P->timed_by->time_sweeps)) {
+    float ms = 0;
+    stereo_trws_plan *T = P->timed_by ? P->timed_by : P;
+    STEREO_HIP_CHECK(hipEventElapsedTime(&ms, T->ev0, T->ev1));
+    P->sweep_ms += ms;
+  }
+  if (!P->lb_in_flight)
+    for (int64_t i = 0; i < P->n_lb; ++i) lb += P->h_lb.p[i];
+  P->lb_in_flight = false;
+  for (int64_t i = 0; i < P->n_en; ++i) en += P->h_en.p[i];
+  *lb_out = lb; *en_out = en;
+  return true;
+}
+
+static const char *kGaveUp = "stereo_trws: a persistent sweep gave up waiting on a dependency flag";
+
+static int strip_ready(stereo_trws_plan *P, const char *who, char *err, size_t errcap) {
+  if (!P) return fail(std::string(who) + ": NULL plan", err, errcap);
+  if (!P->have_inputs) return fail(std::string(who) + ": no inputs uploaded/bound", err, errcap);
+  for (int w = 0; w < 2; ++w)
+    if (P->need_peer[w] && !(P->peer_msg[w] && P->peer_done[w] && P->peer_x[w]))
+      return fail(std::string(who) + ": strip is not connected to its " + (w ? "next" : "previous") + " neighbour", err, errcap);
+  return 0;
+}
+
+int stereo_trws_plan_iterate(stereo_trws_plan *P, int iters, double max_relgap, void *stream,
+                             int *done_iters, int *stopped, char *err, size_t errcap) {
+  if (!P) return fail("stereo_trws_plan_iterate: NULL plan", err, errcap);
+  if (!P->have_inputs) return fail("stereo_trws_plan_iterate: no inputs uploaded/bound", err, errcap);
+  if (P->nstrips > 1)
+    return fail("stereo_trws_plan_iterate: a strip iterates through stereo_trws_plan_issue / _collect / _commit "
+                "(its energy and bound are partial sums)", err, errcap);
+  if (done_iters) *done_iters = 0;
+  if (stopped) *stopped = 0;
+  hipStream_t s = (hipStream_t)stream;
+  try {
+    const DevParams p = make_params(P);
+    for (int it = 0; it < iters; ++it) {
+      issue_iteration(P, p, s);
+      double lb = 0, en = 0;
+      if (!collect_iteration(P, s, &lb, &en)) return fail(kGaveUp, err, errcap);
+      P->lb = lb; P->energy = en; P->iterations += 1;
+      if (done_iters) *done_iters += 1;
+      const double rel_gap = (en - lb) / en;  // minimize.cpp:105
+      if (rel_gap < max_relgap) {
+        if (stopped) *stopped = 1;
+        break;
+      }
+    }
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+// One fused launch for the strips of a group (what: as in launch_persistent).
+static void launch_group(stereo_trws_plan *const *G, int n, int what, hipStream_t s) {
+  stereo_trws_plan *P0 = G[0];
+  GroupArgs ga{};
+  ga.pp = P0->d_group.p; ga.n = n;
+  int total = 0;
+  const int epoch = P0->epoch + 1;
+  for (int i = 0; i < n; ++i) {
+    stereo_trws_plan *P = G[i];
+    ++P->epoch;
+    STEREO_HIP_CHECK(hipMemsetAsync(P->d_ctl.p, 0, sizeof(int32_t), s));  // ticket = 0
+    ga.first[i] = total;
+    total += P0->wide ? std::min(P->grid_blocks, P->cus) : P->grid_blocks;
+    if (what != 3) P->sweep_launches += 1;
+  }
+  ga.first[n] = total;
+  if (P0->wide) launch_wide_group(what, total, s, ga, epoch);
+  else launch_pipe_group(P0->kernel, P0->pos != nullptr, what, total, s, ga, epoch);
+  STEREO_HIP_CHECK(hipGetLastError());
+}
+
+int stereo_trws_plans_issue(stereo_trws_plan *const *plans, int n, void *stream, char *err, size_t errcap) {
+  if (!plans || n < 1 || n > kMaxGroup) return fail("stereo_trws_plans_issue: need 1 .. 16 plans", err, errcap);
+  for (int i = 0; i < n; ++i) {
+    if (int rc = strip_ready(plans[i], "stereo_trws_plans_issue", err, errcap)) return rc;
+    stereo_trws_plan *P = plans[i], *P0 = plans[0];
+    if (P->issued) return fail("stereo_trws_plans_issue: the previous iteration has not been collected", err, errcap);
+    if (P->device != P0->device || P->graph != P0->graph || P->K != P0->K || P->kernel != P0->kernel ||
+        P->epoch != P0->epoch || P->fwd_pending != P0->fwd_pending || P->wide != P0->wide || P->fast != P0->fast ||
+        (P->pos == nullptr) != (P0->pos == nullptr) || P->mode != P0->mode)
+      return fail("stereo_trws_plans_issue: the plans are not strips of one problem on one device in the same state", err, errcap);
+    if (!(P->wide || P->fast))
+      return fail("stereo_trws_plans_issue: strips run on the pipelined kernels only (K <= 64, or K <= 256 with shared "
+                  "ascending positions and the linear kernel)", err, errcap);
+  }
+  try {
+    stereo_trws_plan *P0 = plans[0];
+    hipStream_t s = stream ? (hipStream_t)stream : P0->own_stream;
+    if (!s) return fail("stereo_trws_plans_issue: a plain plan needs an explicit stream here", err, errcap);
+    if (P0->d_group.n < (size_t)n) { P0->d_group.alloc(kMaxGroup); P0->h_group.alloc(kMaxGroup); }
+    for (int i = 0; i < n; ++i) P0->h_group.p[i] = make_params(plans[i]);
+    STEREO_HIP_CHECK(hipMemcpyAsync(P0->d_group.p, P0->h_group.p, sizeof(DevParams) * n, hipMemcpyHostToDevice, s));
+    if (P0->time_sweeps) STEREO_HIP_CHECK(hipEventRecord(P0->ev0, s));
+    if (!P0->fwd_pending) launch_group(plans, n, 0, s);
+    launch_group(plans, n, 1, s);
+    // the backward sweep's lower-bound terms travel while the next launch runs
+    STEREO_HIP_CHECK(hipEventRecord(P0->ev_bwd, s));
+    for (int i = 0; i < n; ++i) {
+      stereo_trws_plan *P = plans[i];
+      STEREO_HIP_CHECK(hipStreamWaitEvent(P->copy_stream, P0->ev_bwd, 0));
+      STEREO_HIP_CHECK(hipMemcpyAsync(P->h_lb.p, P->d_lbterms.p, sizeof(double) * P->n_lb, hipMemcpyDeviceToHost, P->copy_stream));
+      STEREO_HIP_CHECK(hipEventRecord(P->ev_lb, P->copy_stream));
+      P->lb_in_flight = true;
+    }
+    launch_group(plans, n, 2, s);  // forward sweep of the NEXT iteration fused with this iteration's primal
+    if (P0->time_sweeps) STEREO_HIP_CHECK(hipEventRecord(P0->ev1, s));
+    for (int i = 0; i < n; ++i) {
+      stereo_trws_plan *P = plans[i];
+      P->fwd_pending = true;
+      STEREO_HIP_CHECK(hipMemcpyAsync(P->h_en.p, P->d_eterms.p, sizeof(double) * P->n_en, hipMemcpyDeviceToHost, s));
+      STEREO_HIP_CHECK(hipMemcpyAsync(P->h_ctl.p, P->d_ctl.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      P->issued = true; P->issue_stream = s; P->timed_by = P0;
+    }
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+int stereo_trws_plan_issue(stereo_trws_plan *P, void *stream, char *err, size_t errcap) {
+  return stereo_trws_plans_issue(&P, 1, stream, err, errcap);
+}
+
+int stereo_trws_plan_collect(stereo_trws_plan *P, double *lb_part, double *energy_part, char *err, size_t errcap) {
+  if (!P) return fail("stereo_trws_plan_collect: NULL plan", err, errcap);
+  if (!P->issued) return fail("stereo_trws_plan_collect: nothing was issued", err, errcap);
+  try {
+    double lb = 0, en = 0;
+    if (!collect_iteration(P, P->issue_stream, &lb, &en)) return fail(kGaveUp, err, errcap);
+    if (lb_part) *lb_part = lb;
+    if (energy_part) *energy_part = en;
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+int stereo_trws_plan_commit(stereo_trws_plan *P, double lower_bound, double energy, char *err, size_t errcap) {
+  if (!P) return fail("stereo_trws_plan_commit: NULL plan", err, errcap);
+  P->lb = lower_bound; P->energy = energy; P->iterations += 1;
+  return 0;
+}
+
+int stereo_trws_plan_connect(stereo_trws_plan *P, int which, stereo_trws_plan *peer, char *err, size_t errcap) {
+  if (!P || !peer || (which != 0 && which != 1)) return fail("stereo_trws_plan_connect: bad argument", err, errcap);
+  if (P->N != peer->N || P->E != peer->E || P->K != peer->K || P->nstrips != peer->nstrips ||
+      peer->strip != P->strip + (which ? 1 : -1))
+    return fail("stereo_trws_plan_connect: the peer is not the neighbouring strip of the same problem", err, errcap);
+  try {
+    if (peer->device != P->device) {  // one process driving several GPUs: map the neighbour's memory
+      int can = 0;
+      STEREO_HIP_CHECK(hipDeviceCanAccessPeer(&can, P->device, peer->device));
+      if (!can) return fail("stereo_trws_plan_connect: no peer access between the two devices", err, errcap);
+      int cur = 0;
+      STEREO_HIP_CHECK(hipGetDevice(&cur));
+      STEREO_HIP_CHECK(hipSetDevice(P->device));
+      const hipError_t e = hipDeviceEnablePeerAccess(peer->device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) STEREO_HIP_CHECK(e);
+      (void)hipGetLastError();
+      STEREO_HIP_CHECK(hipSetDevice(cur));
+    }
+    P->peer_msg[which] = peer->d_msg.p; P->peer_done[which] = peer->d_done.p; P->peer_x[which] = peer->d_x.p;
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+int stereo_trws_plan_ipc_export(stereo_trws_plan *P, void *handles, size_t cap, char *err, size_t errcap) {
+  if (!P || !handles) return fail("stereo_trws_plan_ipc_export: NULL argument", err, errcap);
+  if (cap < STEREO_TRWS_IPC_BYTES) return fail("stereo_trws_plan_ipc_export: buffer smaller than STEREO_TRWS_IPC_BYTES", err, errcap);
+  static_assert(3 * sizeof(hipIpcMemHandle_t) <= STEREO_TRWS_IPC_BYTES, "STEREO_TRWS_IPC_BYTES");
+  try {
+    hipIpcMemHandle_t h[3];
+    STEREO_HIP_CHECK(hipIpcGetMemHandle(&h[0], P->d_msg.p));
+    STEREO_HIP_CHECK(hipIpcGetMemHandle(&h[1], P->d_done.p));
+    STEREO_HIP_CHECK(hipIpcGetMemHandle(&h[2], P->d_x.p));
+    std::memset(handles, 0, STEREO_TRWS_IPC_BYTES);
+    std::memcpy(handles, h, sizeof(h));
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+int stereo_trws_plan_ipc_connect(stereo_trws_plan *P, int which, const void *handles, char *err, size_t errcap) {
+  if (!P || !handles || (which != 0 && which != 1)) return fail("stereo_trws_plan_ipc_connect: bad argument", err, errcap);
+  try {
+    hipIpcMemHandle_t h[3];
+    std::memcpy(h, handles, sizeof(h));
+    void *ptr[3] = {nullptr, nullptr, nullptr};
+    for (int k = 0; k < 3; ++k) {
+      if (P->ipc_mapped[which][k]) { (void)hipIpcCloseMemHandle(P->ipc_mapped[which][k]); P->ipc_mapped[which][k] = nullptr; }
+      STEREO_HIP_CHECK(hipIpcOpenMemHandle(&ptr[k], h[k], hipIpcMemLazyEnablePeerAccess));
+      P->ipc_mapped[which][k] = ptr[k];
+    }
+    P->peer_msg[which] = (double *)ptr[0]; P->peer_done[which] = (int32_t *)ptr[1]; P->peer_x[which] = (int32_t *)ptr[2];
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+int stereo_trws_plan_debug_flags(stereo_trws_plan *P, int32_t *done, int32_t *ctl) {
+  if (!P) return 1;
+  if (done && hipMemcpy(done, P->d_done.p, sizeof(int32_t) * P->N, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  if (ctl && hipMemcpy(ctl, P->d_ctl.p, sizeof(int32_t) * 2, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  return 0;
+}
+
+int stereo_trws_plan_strip_info(stereo_trws_plan *P, int *nstrips, int *strip, int64_t *own_nodes, int64_t *runs_forward,
+                                int64_t *runs_backward, int *needs_previous, int *needs_next) {
+  if (!P) return 1;
+  if (nstrips) *nstrips = P->nstrips;
+  if (strip) *strip = P->strip;
+  if (own_nodes) *own_nodes = P->n_en;
+  if (runs_forward) *runs_forward = P->nstrips > 1 ? P->ntickets[0] : (int64_t)P->graph->sweep[0].chain_run_ptr.size() - 1;
+  if (runs_backward) *runs_backward = P->nstrips > 1 ? P->ntickets[1] : (int64_t)P->graph->sweep[1].chain_run_ptr.size() - 1;
+  if (needs_previous) *needs_previous = P->need_peer[0] ? 1 : 0;
+  if (needs_next) *needs_next = P->need_peer[1] ? 1 : 0;
+  return 0;
+}
+
+int stereo_trws_plan_result(stereo_trws_plan *P, double *labelling, double *energy,
+                            double *lower_bound, double *iterations, char *err, size_t errcap) {
+  if (!P) return fail("stereo_trws_plan_result: NULL plan", err, errcap);
+  try {
+    if (labelling) {
+      STEREO_HIP_CHECK(hipMemcpy(P->h_x.p, P->d_x.p, sizeof(int32_t) * P->N, hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < P->N; ++i) labelling[i] = (double)(P->h_x.p[i] + 1);  // trws_mex.cpp:137
+    }
+    if (energy) *energy = P->energy;
+    if (lower_bound) *lower_bound = P->lb;
+    if (iterations) *iterations = (double)P->iterations;
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+int stereo_trws_plan_info(stereo_trws_plan *P, int64_t *rank, int64_t *levels,
+                          int64_t *max_level_nodes, char *err, size_t errcap) {
+  if (!P) return fail("stereo_trws_plan_info: NULL plan", err, errcap);
+  if (rank) for (int64_t i = 0; i < P->N; ++i) rank[i] = P->graph->rank[i];
+  if (levels) *levels = (int64_t)P->graph->level_ptr.size() - 1;
+  if (max_level_nodes) *max_level_nodes = P->graph->max_level_nodes;
+  return 0;
+}
+
+int stereo_trws_plan_stats(stereo_trws_plan *P, double *sweep_ms, int64_t *sweep_launches, int reset) {
+  if (!P) return 1;
+  if (sweep_ms) *sweep_ms = P->sweep_ms;
+  if (sweep_launches) *sweep_launches = P->sweep_launches;
+  if (reset) { P->sweep_ms = 0; P->sweep_launches = 0; }
+  P->time_sweeps = true;
+  return 0;
+}
+
+int stereo_trws_plan_counters(stereo_trws_plan *P, int64_t *serial_messages, int reset) {
+  if (!P) return 1;
+  unsigned long long v = 0;
+  if (hipMemcpy(&v, P->d_fallbacks.p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  if (serial_messages) *serial_messages = (int64_t)v;
+  if (reset && hipMemset(P->d_fallbacks.p, 0, sizeof(v)) != hipSuccess) return 1;
+  return 0;
+}
+
+int stereo_trws_messages(int kernel, int K, int64_t M, const double *Di, const double *gamma, const double *msg_in,
+                         const double *q_source, const double *q_dest, const double *alpha, double lambda,
+                         int certificate, int window, const double *shared_positions, double *msg_out,
+                         double *vmin, int32_t *used_serial, char *err, size_t errcap) {
+  if (kernel != 1 && kernel != 2) return fail("Unsupported kernel", err, errcap);
+  if (K < 1 || K > kWave || M < 1) return fail("stereo_trws_messages: K must be in [1, 64], M >= 1", err, errcap);
+  if (!Di || !gamma || !msg_in || !q_source || !q_dest || !alpha || !msg_out || !vmin)
+    return fail("stereo_trws_messages: NULL argument", err, errcap);
+  if (stereo_hip_device_count() < 1) return fail("stereo_trws_messages: no HIP device available", err, errcap);
+  try {
+    const size_t MK = (size_t)M * K;
+    DevBuf<double> dD, dg, dm, dqs, dqd, da, dout, dv;
+    DevBuf<uint16_t> dperm;
+    DevBuf<int32_t> dser;
+    DevBuf<unsigned long long> dfb;
+    dD.upload(Di, MK); dg.upload(gamma, M); dm.upload(msg_in, MK); dqs.upload(q_source, MK); dqd.upload(q_dest, MK);
+    da.upload(alpha, M); dout.alloc(MK); dv.alloc(M); dperm.alloc(MK); dser.alloc(M); dfb.alloc(4096);
+    STEREO_HIP_CHECK(hipMemset(dfb.p, 0, sizeof(unsigned long long) * 4096));
+    run_argsort(dqs.p, dperm.p, K, M, nullptr);
+    fix_equal_positions(dqs.p, dperm.p, K, M);
+    DevParams p{};
+    p.K = K; p.Kp = (K + 1) & ~1; p.kernel = kernel; p.lambda = lambda; p.certificate = certificate ? 1 : 0;
+    p.fallbacks = dfb.p;
+    if (shared_positions) { p.pos_first = shared_positions[0]; p.pos_last = shared_positions[K - 1]; }
+    if (kernel == 2 && shared_positions) {
+      p.pos_gap = std::numeric_limits<double>::infinity();
+      for (int k = 1; k < K; ++k) p.pos_gap = std::min(p.pos_gap, shared_positions[k] - shared_positions[k - 1]);
+    }
+    if (const char *dbg = std::getenv("STEREO_HIP_TRWS_DEBUG")) p.debug = std::atoi(dbg);
+    const unsigned grid = (unsigned)std::min<int64_t>(M, 4096);
+    if (kernel == 1)
+      hipLaunchKernelGGL(trws_messages_kernel<1>, dim3(grid), dim3(kWave), 0, 0, p, K, M, dD.p, dg.p, dm.p, dqs.p, dqd.p,
+                         da.p, dperm.p, shared_positions ? window : -1, dout.p, dv.p, dser.p, dfb.p);
+    else
+      hipLaunchKernelGGL(trws_messages_kernel<2>, dim3(grid), dim3(kWave), 0, 0, p, K, M, dD.p, dg.p, dm.p, dqs.p, dqd.p,
+                         da.p, dperm.p, shared_positions ? window : -1, dout.p, dv.p, dser.p, dfb.p);
+    STEREO_HIP_CHECK(hipGetLastError());
+    STEREO_HIP_CHECK(hipDeviceSynchronize());
+    STEREO_HIP_CHECK(hipMemcpy(msg_out, dout.p, sizeof(double) * MK, hipMemcpyDeviceToHost));
+    STEREO_HIP_CHECK(hipMemcpy(vmin, dv.p, sizeof(double) * M, hipMemcpyDeviceToHost));
+    if (used_serial) STEREO_HIP_CHECK(hipMemcpy(used_serial, dser.p, sizeof(int32_t) * M, hipMemcpyDeviceToHost));
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+int stereo_trws_plan_path(stereo_trws_plan *P) {
+  if (!P) return -1;
+  return P->wide ? 3 : P->fast2 ? 4 : P->fast ? 2 : 1;
+}
+
+int stereo_trws(int kernel, const double *unary, const uint32_t *conn, const double *q,
+                const double *qprim, const double *alphas, double tol, double maxiter,
+                double max_relgap, int K, int64_t N, int64_t E, double *labelling, double *energy,
+                double *lower_bound, double *iterations, char *err, size_t errcap) {
+  if (kernel != 1 && kernel != 2) return fail("Unsupported kernel", err, errcap);  // trws_mex.cpp:162
+  if (!unary || !conn || !q || !qprim || !alphas || !labelling || !energy || !lower_bound || !iterations)
+    return fail("stereo_trws: NULL argument", err, errcap);
+  stereo_trws_plan *P = nullptr;
+  int mode = STEREO_TRWS_MESSAGES_EXACT;
+  if (const char *m = std::getenv("STEREO_HIP_TRWS_MESSAGES"))
+    if (std::string(m) == "minplus") mode = STEREO_TRWS_MESSAGES_MINPLUS;
+  int rc = stereo_trws_plan_create(kernel, K, N, E, conn, mode, &P, err, errcap);
+  if (rc) return rc;
+  rc = stereo_trws_plan_upload(P, unary, q, qprim, nullptr, alphas, tol, err, errcap);
+  if (!rc) {
+    // Minimize_TRW_S always runs at least one iteration (minimize.cpp:31,100-101)
+    int itmax = (int)maxiter;  // trws_mex.cpp:125
+    if (itmax < 1) itmax = 1;
+    rc = stereo_trws_plan_iterate(P, itmax, max_relgap, nullptr, nullptr, nullptr, err, errcap);
+  }
+  if (!rc) rc = stereo_trws_plan_result(P, labelling, energy, lower_bound, iterations, err, errcap);
+  stereo_trws_plan_destroy(P);
+  return rc;
+}
+
+}  // extern "C"
+

@@ -1,0 +1,733 @@
+// TRW-S pipelined sweep kernel for 64 < K <= 256 on shared strictly ascending positions (the large
+// grids), linear kernel.  Part of libstereo_hip.so; overview in trws_plan.hip.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/stereo_hip.h"
+#include "common.h"
+#include "trws_dev.h"
+#include "trws_launch.h"
+
+namespace stereo {
+namespace {
+
+// ---- wide-label pipelined sweep: 64 < K <= 256, shared strictly ascending positions -------
+// The regime of the large grids (3000x2000x256).  A lane holds four labels (k = c * 64 + lane).
+// Per message K^2 pair costs are too many, so
+//  * min-plus only looks at the sources inside the truncation window of each destination
+//    (a source farther than lambda costs >= vTrunc exactly, by monotone rounding);
+//  * the certificate's tangency test ("no two u = h - alpha q, nor two v = h + alpha q, within
+//    delta") is a closest-pair test by bucketing -- conservative (all pairs, not only those
+//    with a useful cone), O(K) instead of O(K^2).
+// Three compute waves per outgoing message, each forming Di and H = gamma Di - m itself (cheap,
+// and no barrier between them): wave 3j does the windowed min-plus, waves 3j+1 / 3j+2 the u / v
+// closest-pair tests and post their verdicts in LDS; wave 3j waits for the two verdicts,
+// normalises and hands over.  Loader / storer / primal waves as in trws_pipe_kernel (the loader is
+// split in two: data nobody else writes, and data behind completion flags, so that the two HBM
+// round trips of a visit overlap); one
+// hardware barrier per visit.  Nodes with more than four outgoing messages take a second round
+// (message j + 4 on the same waves).  If the certificate fails, wave 3j runs the reference's
+// serial envelope construction in LDS (one at a time per workgroup: shared scratch, rare).
+// Kernel 1 (truncated linear) only; kernel 2 above K = 64 stays on the generic kernel.
+constexpr int kWideCompute = 12;
+constexpr int kWideWaves = kWideCompute + 4;  // + loader (own data), loader (foreign data), storer, primal
+constexpr int kWideThreads = kWideWaves * kWave;
+constexpr int kWS = 260;    // LDS row stride in doubles (>= 256 + 1 breakpoints, multiple of 4)
+constexpr int kWPad = 16;   // min-plus source table is padded by this many (+inf, 0) entries on both sides
+constexpr int kWScr = 2 * (256 + 2 * kWPad);  // per compute wave scratch: (h, q) source table | 256 keys + 516 ints
+constexpr int kWBuckets = 512;
+constexpr int kWStI = kWS + 8 * kWS + 8;            // int area of a stage (in doubles)
+constexpr int kWStage = kWStI + 36;
+// stage: D[kWS] m[8][kWS] a[8] | ints desc[64] px[8]
+
+struct WidePtrs {
+  double *stage0, *hand, *scr, *fb, *pos, *scal, *msc;
+  int *dring, *flags, *hflag, *ctl;
+};
+__device__ __forceinline__ WidePtrs wide_carve(double *lds) {
+  WidePtrs w;
+  w.stage0 = lds;                            // 2 * kWStage
+  w.hand = w.stage0 + 2 * kWStage;           // 3 * 8 * kWS : new messages of the last three visits
+  w.scr = w.hand + 3 * 8 * kWS;              // kWideCompute * kWScr
+  w.fb = w.scr + kWideCompute * kWScr;       // 4 * kWS : sources, stack, breakpoints of the serial construction
+  w.pos = w.fb + 4 * kWS;                    // kWS
+  w.scal = w.pos + kWS;                      // 2 * kScalDoubles
+  w.msc = w.scal + 2 * kScalDoubles;         // [8][2]: hmin, hmax of H_j for the closest-pair waves
+  w.dring = (int *)(w.msc + 16);             // 3 * 64 descriptor words (for the storer)
+  w.flags = w.dring + 3 * 64;                // [8][2] verdicts of the closest-pair waves
+  w.hflag = w.flags + 16;                    // [8] "H_j is in the min-plus wave's table" (visit token)
+  w.ctl = w.hflag + 8;                       // [0] run, [1] abort, [2] lock of the serial scratch
+  return w;
+}
+constexpr int kWideLdsDoubles = 2 * kWStage + 3 * 8 * kWS + kWideCompute * kWScr + 4 * kWS + kWS + 2 * kScalDoubles + 16 + 96 + 8 + 4 + 2;
+static_assert(kWideLdsDoubles * 8 <= 160 * 1024, "wide kernel LDS");
+
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// inclusive prefix sum over the wave (Hillis-Steele inside rows of 16, then row broadcasts)
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+// True if two of the first K keys (key i = c * 64 + lane lives in r[c] of `lane`) are within
+// delta of each other.  mn <= every key <= mn + span.  One wave, no sort: counting sort into
+// 512 equal-width buckets (LDS counters), then every key is compared with the rest of its
+// bucket and the whole next bucket.  Buckets are wider than 2 delta, so keys two or more
+// buckets apart cannot be near.  Conservative `true` on degenerate key distributions.
+// scr: 256 doubles + 516 ints.
+__device__ __forceinline__ bool keys_within(const double (&r)[4], int K, int C, double delta, double mn,
+                                            double span, double *scr, int lane) {
+  const double inf = __builtin_huge_val();
+  double *sorted = scr;
+  int *cnt = (int *)(scr + 256);  // counters, afterwards start[0 .. kWBuckets + 1]
+  if (!(span > (2.0 * kWBuckets) * delta) || !(span < inf)) return true;
+  const double scale = (double)kWBuckets / span;
+  ((int4 *)cnt)[2 * lane] = make_int4(0, 0, 0, 0);
+  ((int4 *)cnt)[2 * lane + 1] = make_int4(0, 0, 0, 0);
+  WSYNC();
+  int b[4], rank[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    b[c] = 0; rank[c] = 0;
+    if (c < C && c * kWave + lane < K) {
+      const int bb = (int)((r[c] - mn) * scale);
+      b[c] = bb > kWBuckets - 1 ? kWBuckets - 1 : bb < 0 ? 0 : bb;
+      rank[c] = __hip_atomic_fetch_add(cnt + b[c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+  }
+  WSYNC();
+  const int4 c0 = ((int4 *)cnt)[2 * lane], c1 = ((int4 *)cnt)[2 * lane + 1];  // buckets 8 lane .. 8 lane + 7
+  const int tot = c0.x + c0.y + c0.z + c0.w + c1.x + c1.y + c1.z + c1.w;
+  const int incl = wave_incl_scan_i32(tot);
+  int e = incl - tot;
+  int4 s0, s1;
+  s0.x = e; e += c0.x; s0.y = e; e += c0.y; s0.z = e; e += c0.z; s0.w = e; e += c0.w;
+  s1.x = e; e += c1.x; s1.y = e; e += c1.y; s1.z = e; e += c1.z; s1.w = e;
+  ((int4 *)cnt)[2 * lane] = s0;
+  ((int4 *)cnt)[2 * lane + 1] = s1;
+  if (lane == kWave - 1) { cnt[kWBuckets] = incl; cnt[kWBuckets + 1] = incl; }
+  WSYNC();
+  int st4[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) st4[c] = cnt[b[c]];  // unconditional: one LDS round trip for all four
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (c < C && c * kWave + lane < K) sorted[st4[c] + rank[c]] = r[c];
+  WSYNC();
+  double u[4];
+  int len[4], bq[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) u[c] = sorted[c * kWave + lane];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int bb = (c < C && c * kWave + lane < K) ? (int)((u[c] - mn) * scale) : 0;
+    bq[c] = bb > kWBuckets - 1 ? kWBuckets - 1 : bb < 0 ? 0 : bb;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) len[c] = cnt[bq[c] + 2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int q = c * kWave + lane;
+    len[c] = (c < C && q < K) ? len[c] - q : 0;  // keys q+1 .. q+len-1 share the bucket or the next one
+  }
+  bool bad = false;
+  for (int i = 1;; ++i) {
+    bool any = false;
+    double o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {  // unconditional reads first: one LDS round trip per step
+      const int q = c * kWave + lane + i;
+      o[c] = sorted[q < 256 ? q : 255];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool on = i < len[c];
+      any = any || on;
+      bad = bad || (on && !(fabs(o[c] - u[c]) > delta));
+    }
+    if (!UNI(any)) break;
+    if (i >= 24) { bad = true; break; }  // crowded buckets: give up, serial path decides
+  }
+  return UNI(bad);
+}
+
+template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE>
+__device__ __forceinline__ void wide_body(DevParams p, int epoch) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const WidePtrs L = wide_carve(lds);
+  const int K = p.K;
+  const int C = (K + kWave - 1) / kWave;  // 64-label chunks
+  const double inf = __builtin_huge_val();
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  constexpr int D = BACKWARD ? 1 : 0;
+  constexpr int DW = TrwsGraph::kDescWords;
+  const int32_t *desc = p.desc[D];
+  for (int k = tid; k < kWS; k += kWideThreads) L.pos[k] = k < K ? p.pos[k] : inf;
+  // positions on an exact arithmetic progression (checked on the host: pos[k+d] - pos[k] == d * step
+  // bit for bit): the min-plus source table then holds h only and alpha |d step| is formed once per d
+  const double ustep = p.uniform_step;
+  const bool uniform = ustep != 0;
+  if (wave < kWideCompute && wave % 3 == 0 && lane < 2 * kWPad) {
+    // padding of the min-plus source tables, never overwritten afterwards
+    if (uniform) (L.scr + wave * kWScr)[lane < kWPad ? lane : K + lane] = inf;
+    else ((double2 *)(L.scr + wave * kWScr))[lane < kWPad ? lane : K + lane] = make_double2(inf, 0.0);
+  }
+  if (tid < 16) L.flags[tid] = -1;
+  if (tid < 8) L.hflag[tid] = -1;
+  if (tid == 0) { L.ctl[1] = 0; L.ctl[2] = 0; }
+  double posr[4];  // this lane's four label positions
+#pragma unroll
+  for (int c = 0; c < 4; ++c) posr[c] = c * kWave + lane < K ? p.pos[c * kWave + lane] : inf;
+  const double pos_first = p.pos[0], pos_last = p.pos[K - 1];
+  // development profile (STEREO_HIP_TRWS_PROF): cycles of wave 0 per phase [0..15], busy cycles of
+  // loader / storer / primal [16..18], hardware-barrier wait of wave 0 [19], visits [20]
+  unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pbusy = 0, pwait = 0, pvis = 0;
+#define WSTAMP(i) do { if (p.prof) { const long long now_ = (long long)__builtin_readcyclecounter(); pacc[i] += (unsigned long long)(now_ - tmark); tmark = now_; } } while (0)
+  __syncthreads();
+
+  for (;;) {
+    if (tid == 0) { const int t_ = atomicAdd(p.ticket, 1); L.ctl[0] = t_ < p.ntickets[D] ? (p.run_order[D] ? p.run_order[D][t_] : t_) : p.nruns[D]; }
+    __syncthreads();
+    const int run = __builtin_amdgcn_readfirstlane(L.ctl[0]);
+    __syncthreads();
+    if (run >= p.nruns[D]) break;
+    const int p0 = p.run_ptr[D][run], p1 = p.run_ptr[D][run + 1];
+    if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2] = wall_clock64();
+
+    // One visit loop per role (not one loop with a role switch inside): state carried from visit
+    // to visit -- the loader's parked registers -- then occupies registers in that role only.
+#define WIDE_VISITS_BEGIN     for (int pos = p0 - 1; pos <= p1; ++pos) { \
+      double *st = L.stage0 + (pos & 1) * kWStage; \
+      double *stn = L.stage0 + ((pos + 1) & 1) * kWStage; \
+      const int hb = ((pos % 3) + 3) % 3, hb1 = (((pos - 1) % 3) + 3) % 3, hb2 = (((pos - 2) % 3) + 3) % 3; \
+      double *hcur = L.hand + hb * 8 * kWS, *hprev = L.hand + hb1 * 8 * kWS, *hprev2 = L.hand + hb2 * 8 * kWS; \
+      double *sc = L.scal + (pos & 1) * kScalDoubles; \
+      const bool have_node = pos >= p0 && pos < p1; \
+      long long tmark = p.prof ? (long long)__builtin_readcyclecounter() : 0; \
+      const long long tvisit = tmark; \
+      (void)st; (void)stn; (void)hcur; (void)hprev; (void)hprev2; (void)sc; (void)have_node; (void)tvisit;
+#define WIDE_VISITS_END_(BARRIER)       if (p.prof) { \
+        const long long now_ = (long long)__builtin_readcyclecounter(); \
+        if (wave == 0) pvis += have_node ? 1 : 0; \
+        pbusy += (unsigned long long)(now_ - tvisit); \
+        tmark = now_; \
+      } \
+      BARRIER; \
+      if (p.prof && wave == 0) pwait += (unsigned long long)((long long)__builtin_readcyclecounter() - tmark); \
+      if (L.ctl[1]) { \
+        if (tid == 0) st_sc1(p.abort_flag, 1); \
+        return; \
+      } \
+    }
+#define WIDE_VISITS_END WIDE_VISITS_END_(__syncthreads())
+    if (wave < kWideCompute) {
+      WIDE_VISITS_BEGIN
+        // ======================================================== compute waves
+        const int j0 = wave / 3, role = wave - 3 * j0;  // role 0: min-plus, 1: u test, 2: v test
+        if (UPDATE && have_node) {
+          const int *sti = (const int *)(st + kWStI);
+          const int f = __builtin_amdgcn_readfirstlane(sti[2]);
+          const int nout = f & 15, nin = (f >> 4) & 15, ntot = nout + nin;
+          const bool fast_msg = KERNEL == 1 && p.certificate != 0;
+          const bool working = j0 < nout && (role == 0 || fast_msg);
+          if (working || (BACKWARD && wave == 0)) {
+            bool valid[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) valid[c] = c * kWave + lane < K;
+            double di[4] = {inf, inf, inf, inf};
+            if (role == 0) {
+            const unsigned slA = (unsigned)__builtin_amdgcn_readfirstlane(sti[41]);
+            const unsigned slB = (unsigned)__builtin_amdgcn_readfirstlane(sti[42]);
+            // Di = D + messages in list order (from the ring where the neighbour was one of
+            // the last two visits of this run), formed by the min-plus wave of each message
+            // (reads are unconditional -- rows are padded to 256 -- and masked afterwards, so that
+            // all of them are in flight together)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) di[c] = st[c * kWave + lane];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+              if (jj < ntot) {
+                const int sl = jj >= nout ? (int)(signed char)(((jj < 4 ? slA : slB) >> (8 * (jj & 3))) & 255) : -1;
+                const double *src = sl >= 8 ? hprev2 + (sl - 8) * kWS : sl >= 0 ? hprev + sl * kWS : st + kWS + jj * kWS;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) di[c] += src[c * kWave + lane];
+              }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) di[c] = valid[c] ? di[c] : inf;
+            if (BACKWARD) {
+              const double dm = min_raw(min_raw(di[0], di[1]), min_raw(di[2], di[3]));
+              const double node_vmin = wave_min_dpp(dm);
+              if (wave == 0 && lane == 0) sc[8] = node_vmin;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) di[c] -= node_vmin;
+            }
+            }
+            WSTAMP(0);
+            for (int j = j0; working && j < nout; j += 4) {
+              const double gamma = (double)1 / (double)(nout > nin ? nout : nin);
+              const double alpha = st[kWS + 8 * kWS + j];
+              const bool constant = UNI(alpha == 0);
+              double h[4] = {inf, inf, inf, inf}, hmin = 0, hmax = 0;
+              double2 *mtab = (double2 *)(L.scr + (wave - role) * kWScr) + kWPad;  // the min-plus wave's (h, q) table
+              double *htab = L.scr + (wave - role) * kWScr + kWPad;                // ... or h only (uniform positions)
+              if (role == 0) {
+                double hlo = inf, hhi = -inf;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) h[c] = gamma * di[c] - st[kWS + j * kWS + c * kWave + lane];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                  hlo = min_raw(hlo, valid[c] ? h[c] : inf); hhi = max_raw(hhi, valid[c] ? h[c] : -inf);
+                  h[c] = valid[c] ? h[c] : inf;
+                }
+                hmin = wave_min_dpp(hlo); hmax = wave_max_dpp(hhi);
+                if (fast_msg && !constant) {
+                  // publish H_j for the two closest-pair waves (and as this wave's source table)
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) {
+                    if (valid[c]) {
+                      if (uniform) htab[c * kWave + lane] = h[c];
+                      else mtab[c * kWave + lane] = make_double2(h[c], posr[c]);
+                    }
+                  }
+                  if (lane == 0) { L.msc[2 * j] = hmin; L.msc[2 * j + 1] = hmax; }
+                  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                  if (lane == 0) __hip_atomic_store(L.hflag + j, pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+              } else if (!constant) {
+                int spins = 0;
+                while (__hip_atomic_load(L.hflag + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != pos) {
+                  __builtin_amdgcn_s_sleep(0);
+                  if (++spins > kSpinLimit) { if (lane == 0) L.ctl[1] = 1; break; }  // bounded
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                double hv[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) hv[c] = uniform ? htab[c * kWave + lane] : mtab[c * kWave + lane].x;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) h[c] = valid[c] ? hv[c] : inf;
+                hmin = L.msc[2 * j]; hmax = L.msc[2 * j + 1];
+              }
+              const double vtrunc = hmin + alpha * p.lambda;
+              const double ap0 = alpha * pos_first, ap1 = alpha * pos_last;
+              const double aplo = min_raw(ap0, ap1), aphi = max_raw(ap0, ap1);
+              const double mag = max_raw(fabs(hmin), fabs(hmax)) + 2 * max_raw(fabs(ap0), fabs(ap1));
+              const double delta = 1e-9 * (mag + fabs(alpha * p.lambda));
+              double *scr = L.scr + wave * kWScr;
+              WSTAMP(1);
+              if (role != 0) {
+                // ---- tangency: no two u = h - alpha q (role 1) / v = h + alpha q (role 2) within delta
+                if (!constant) {
+                  const double sgn = role == 2 ? 1.0 : -1.0;
+                  double r[4];
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) r[c] = h[c] + sgn * (alpha * posr[c]);
+                  const double mn = role == 2 ? hmin + aplo : hmin - aphi;
+                  const double mx = role == 2 ? hmax + aphi : hmax - aplo;
+                  bool bad = !(delta < inf);
+                  if (!bad) bad = keys_within(r, K, C, delta, mn, mx - mn, scr, lane);
+                  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                  if (lane == 0)
+                    __hip_atomic_store(L.flags + 2 * j + (role - 1), (pos << 1) | (bad ? 1 : 0), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                WSTAMP(2);
+              } else {
+                double out[4] = {0, 0, 0, 0}, vmin = 0;
+                if (constant) {
+                  // typeStereoLinear.h:390-396: message = min H everywhere, normalised to zero
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) out[c] = hmin;
+                  vmin = hmin;
+                } else {
+                  // source table: (h, q) pairs at index kWPad + k, (+inf, 0) padding on both sides
+                  // (written above, when H_j was published)
+                  double2 *tab = mtab;
+                  WSYNC();
+                  bool serial = !fast_msg;
+                  if (fast_msg) {
+                    // ---- windowed min-plus: smallest and second smallest cost per destination
+                    // (equal costs from two sources count as a zero margin: serial path decides)
+                    double m1[4] = {inf, inf, inf, inf}, m2[4] = {inf, inf, inf, inf};
+                    const int w = p.window;
+                    if (uniform && w <= kWPad) {
+                      for (int d = -w; d <= w; ++d) {
+                        const double ad = alpha * fabs((double)d * ustep);  // == alpha |t - q| exactly
+                        double hs[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) hs[c] = htab[c * kWave + lane + d];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                          const double cst = ad + hs[c];
+                          const double lo_ = min_raw(m1[c], cst), hi_ = max_raw(m1[c], cst);
+                          m2[c] = min_raw(m2[c], hi_);
+                          m1[c] = lo_;
+                        }
+                      }
+                    } else if (w <= kWPad) {
+                      for (int d = -w; d <= w; ++d) {
+                        double2 sv[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) sv[c] = tab[c * kWave + lane + d];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                          const double cst = pair_cost<1>(alpha, posr[c] - sv[c].y, sv[c].x);
+                          const double lo_ = min_raw(m1[c], cst), hi_ = max_raw(m1[c], cst);
+                          m2[c] = min_raw(m2[c], hi_);
+                          m1[c] = lo_;
+                        }
+                      }
+                    } else {
+                      for (int d = -w; d <= w; ++d) {
+                        double2 sv[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                          const int i = c * kWave + lane + d;
+                          sv[c] = tab[i < 0 ? 0 : i > K - 1 ? K - 1 : i];
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                          const int i = c * kWave + lane + d;
+                          double cst = pair_cost<1>(alpha, posr[c] - sv[c].y, sv[c].x);
+                          cst = (i >= 0 && i < K) ? cst : inf;
+                          const double lo_ = min_raw(m1[c], cst), hi_ = max_raw(m1[c], cst);
+                          m2[c] = min_raw(m2[c], hi_);
+                          m1[c] = lo_;
+                        }
+                      }
+                    }
+                    bool bad = false;
+                    double vloc = inf;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                      if (valid[c]) {
+                        bad = bad || (m1[c] < vtrunc && !(m2[c] - m1[c] > delta && vtrunc - m1[c] > delta));
+                        out[c] = m1[c] < vtrunc ? m1[c] : vtrunc;
+                        vloc = min_raw(vloc, out[c]);
+                      }
+                    }
+                    vmin = wave_min_dpp(vloc);
+                    serial = UNI(bad);
+                    WSTAMP(3);
+                    // the verdicts of the two closest-pair waves of this message
+                    {
+                      int spins = 0;
+                      for (;;) {
+                        const int v = lane < 2 ? __hip_atomic_load(L.flags + 2 * j + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : (pos << 1);
+                        const bool ready = (v >> 1) == pos;
+                        if (!UNI(!ready)) { serial = serial || UNI((v & 1) != 0); break; }
+                        __builtin_amdgcn_s_sleep(0);
+                        if (++spins > kSpinLimit) { if (lane == 0) L.ctl[1] = 1; break; }  // bounded
+                      }
+                      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
+                    WSTAMP(4);
+                  }
+                  if (serial) {
+                    // the reference's serial construction in LDS; the stack lives in a scratch
+                    // shared by the workgroup (rare path): take its lock
+                    if (lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
+                    if (lane == 0) {
+                      int spins = 0;
+                      while (__hip_atomic_exchange(L.ctl + 2, 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > kSpinLimit) { L.ctl[1] = 1; break; }
+                      }
+                    }
+                    WSYNC();
+                    double *sh = L.fb, *sq = L.fb + kWS, *z = L.fb + 2 * kWS, *Hs = L.fb + 3 * kWS;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                      if (valid[c]) Hs[c * kWave + lane] = h[c];
+                    WSYNC();
+                    if (lane == 0) build_envelope<KERNEL>(K, alpha, Hs, L.pos, sh, sq, z);
+                    WSYNC();
+                    double vloc = inf;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                      const int k = c * kWave + lane;
+                      if (c < C && k < K) {
+                        int jj = 0;
+                        while (z[jj + 1] < posr[c]) ++jj;
+                        const double cst = pair_cost<KERNEL>(alpha, posr[c] - sq[jj], sh[jj]);
+                        out[c] = cst < vtrunc ? cst : vtrunc;
+                        vloc = min_raw(vloc, out[c]);
+                      }
+                    }
+                    WSYNC();
+                    if (lane == 0) __hip_atomic_store(L.ctl + 2, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    vmin = wave_min_dpp(vloc);
+                  }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                  const int k = c * kWave + lane;
+                  if (c < C && k < K) hcur[j * kWS + k] = out[c] - vmin;
+                }
+                if (BACKWARD && lane == 0) sc[j] = vmin;
+                WSTAMP(5);
+              }
+            }
+          }
+        }
+      WIDE_VISITS_END
+    } else if (wave == kWideCompute) {
+      int wnext = desc[(size_t)p0 * DW + lane];
+      WIDE_VISITS_BEGIN
+        // ======================================================== loader A: node pos + 1, own data
+        if (pos + 1 >= p0 && pos + 1 < p1) {
+          const int w = wnext;
+          if (pos + 2 < p1) wnext = desc[(size_t)(pos + 2) * DW + lane];
+          const NodeDesc nx = decode_desc(w);
+          int *stni = (int *)(stn + kWStI);
+          stni[lane] = w;
+          L.dring[((pos + 1) % 3) * 64 + lane] = w;
+          const int ntot = nx.nout + nx.nin;
+          // all requests go out before anything is consumed (registers first, LDS at the end)
+          double dk[4], mv[8][4];
+          bool okc[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            okc[c] = c < C && c * kWave + lane < K;
+            dk[c] = okc[c] ? p.unary[(size_t)nx.node * K + c * kWave + lane] : 0.0;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              mv[j][c] = 0;
+              if (j < nx.nout && (UPDATE || PRIMAL) && okc[c]) mv[j][c] = p.msg[(size_t)nx.e[j] * K + c * kWave + lane];
+            }
+          }
+          double av = 0;
+          if (lane < ntot) {
+            int ej = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (lane == j) ej = nx.e[j];
+            av = p.alpha[ej];
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (okc[c]) {
+              stn[c * kWave + lane] = dk[c];
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if (j < nx.nout) stn[kWS + j * kWS + c * kWave + lane] = mv[j][c];
+            }
+          }
+          if (lane < 8) stn[kWS + 8 * kWS + lane] = av;
+        }
+      WIDE_VISITS_END
+    } else if (wave == kWideCompute + 1) {
+      int wnext = desc[(size_t)p0 * DW + lane];
+      WIDE_VISITS_BEGIN
+        // ======================================================== loader B: node pos + 1, data behind flags
+        if (pos + 1 >= p0 && pos + 1 < p1) {
+          const int w = wnext;
+          if (pos + 2 < p1) wnext = desc[(size_t)(pos + 2) * DW + lane];
+          const NodeDesc nx = decode_desc(w);
+          int *stni = (int *)(stn + kWStI);
+          const int ntot = nx.nout + nx.nin;
+          int pxv = 0, xn = 0, sl = 0;
+          if (lane < ntot) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (lane == j) { xn = nx.xn[j]; sl = nx.slot[j]; }
+          }
+          if (nx.ndep > 0) {
+            int myrank = nx.dep[0];
+#pragma unroll
+            for (int j = 1; j < 4; ++j)
+              if (lane == j) myrank = nx.dep[j];
+            const bool watching = lane < nx.ndep;
+            int spins = 0;
+            bool ok = true;
+            for (;;) {
+              const int v = watching ? ld_sc1(p.done + myrank) : epoch;
+              if (!UNI(v < epoch)) break;
+              __builtin_amdgcn_s_sleep(1);
+              if (++spins > kSpinLimit || ((spins & 1023) == 0 && ld_sc1(p.abort_flag))) { ok = false; break; }
+            }
+            if (!ok && lane == 0) { st_sc1(p.abort_flag, 1); L.ctl[1] = 1; }
+          }
+          double mv[8][4];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              mv[j][c] = 0;
+              if (UPDATE && j >= nx.nout && j < ntot && nx.slot[j] < 0 && c < C && c * kWave + lane < K)
+                mv[j][c] = ld_sc1(p.msg + (size_t)nx.e[j] * K + c * kWave + lane);
+            }
+          }
+          if (PRIMAL && lane < ntot && lane >= nx.nout && sl < 0) pxv = ld_sc1(p.x + xn);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (UPDATE && j >= nx.nout && j < ntot && nx.slot[j] < 0) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                if (c < C && c * kWave + lane < K) stn[kWS + j * kWS + c * kWave + lane] = mv[j][c];
+            }
+          }
+          if (lane < 8) stni[64 + lane] = pxv;
+        }
+      WIDE_VISITS_END
+    } else if (wave == kWideCompute + 2) {
+      WIDE_VISITS_BEGIN
+        // ======================================================== storer: node pos - 1
+        if (pos - 1 >= p0) {
+          const NodeDesc pd = decode_desc(L.dring[((pos - 1) % 3) * 64 + lane]);
+          const double *scp = L.scal + ((pos + 1) & 1) * kScalDoubles;
+          if (UPDATE) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              if (j < pd.nout) {
+                double *mb = ((pd.remote >> j) & 1) ? (((pd.remote >> (8 + j)) & 1) ? p.peer_msg1 : p.peer_msg0) : p.msg;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                  const int k = c * kWave + lane;
+                  if (c < C && k < K) st_sc1(mb + (size_t)pd.e[j] * K + k, hprev[j * kWS + k]);
+                }
+                if (BACKWARD && lane == 0) p.lbterms[pd.lbe[j]] = scp[j];
+              }
+            }
+            if (BACKWARD && lane == 0) p.lbterms[pd.lbn] = scp[8];
+          }
+          if (PRIMAL && lane == 0) {
+            const int xi = ((const int *)(scp + 10))[0];
+            st_sc1(p.x + pd.node, xi);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_x0 + pd.node, xi);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_x1 + pd.node, xi);
+            p.eterms[pd.epos] = scp[9];
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) {
+            st_sc1(p.done + pd.rank, epoch);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_done0 + pd.rank, epoch);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_done1 + pd.rank, epoch);
+          }
+        }
+      WIDE_VISITS_END
+    } else {
+      int xprev = 0, xprev2 = 0;
+      WIDE_VISITS_BEGIN
+        // ======================================================== primal of node pos
+        if (PRIMAL && have_node) {
+          const int *sti = (const int *)(st + kWStI);
+          const int f = __builtin_amdgcn_readfirstlane(sti[2]);
+          const int nout = f & 15, nin = (f >> 4) & 15, md = (f >> 16) & 255, ntot = nout + nin;
+          double db[4], di[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int k = c * kWave + lane;
+            db[c] = (c < C && k < K) ? st[k] : inf;
+          }
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            if (jj >= nout && jj < ntot) {
+              const int sl = __builtin_amdgcn_readfirstlane(sti[12 + jj]);
+              const int ks = sl >= 8 ? xprev2 : sl >= 0 ? xprev : __builtin_amdgcn_readfirstlane(sti[64 + jj]);
+              const double pks = L.pos[ks], aj = st[kWS + 8 * kWS + jj];
+              const bool fwd = ((md >> jj) & 1) == 0;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                if (c < C) {
+                  const double d = fwd ? pks - posr[c] : posr[c] - pks;
+                  const double v = KERNEL == 1 ? fabs(d) : d * d;
+                  db[c] += aj * (v < p.lambda ? v : p.lambda);
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) di[c] = db[c];
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            if (jj < nout) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const int k = c * kWave + lane;
+                if (c < C && k < K) di[c] += st[kWS + jj * kWS + k];
+              }
+            }
+          }
+          double bestv = inf, bestdb = 0;
+          int besti = 0x7fffffff;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {  // ascending k per lane: strict '<' keeps the first minimum
+            const int k = c * kWave + lane;
+            if (c < C && k < K && di[c] < bestv) { bestv = di[c]; besti = k; bestdb = db[c]; }
+          }
+          const int bi = wave_argmin_dpp(bestv, besti);
+          const double eb = readlane_f64(bestdb, bi & (kWave - 1));  // the lane owning label bi
+          xprev2 = xprev; xprev = bi;
+          if (lane == 0) { sc[9] = eb; ((int *)(sc + 10))[0] = bi; }
+        }
+            WIDE_VISITS_END
+    }
+#undef WIDE_VISITS_BEGIN
+#undef WIDE_VISITS_END
+#undef WIDE_VISITS_END_
+    if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2 + 1] = wall_clock64();
+  }
+#undef WSTAMP
+  if (p.prof && lane == 0) {
+    if (wave == 0) {
+      for (int i = 0; i < 16; ++i) atomicAdd(p.prof + i, pacc[i]);
+      atomicAdd(p.prof + 21, pwait);
+      atomicAdd(p.prof + 22, pvis);
+    }
+    if (wave >= kWideCompute) atomicAdd(p.prof + 16 + (wave - kWideCompute), pbusy);
+    if (wave == 1) for (int i = 0; i < 3; ++i) atomicAdd(p.prof + 8 + i, pacc[i]);  // a closest-pair wave
+  }
+}
+template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE>
+__global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, int epoch) {
+  wide_body<KERNEL, BACKWARD, PRIMAL, UPDATE>(p, epoch);
+}
+template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE>
+__global__ __launch_bounds__(kWideThreads) void trws_wide_group_kernel(GroupArgs ga, int epoch) {
+  wide_body<KERNEL, BACKWARD, PRIMAL, UPDATE>(ga.pp[group_strip(ga)], epoch);
+}
+#undef WSYNC
+
+}  // namespace
+
+size_t wide_lds_bytes() { return sizeof(double) * kWideLdsDoubles; }
+
+void wide_set_attributes() {
+  const int wlds = (int)wide_lds_bytes();
+#define SET_W(NAME)                                                                                                             \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<1, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wlds)); \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<1, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wlds));  \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<1, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wlds));  \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<1, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, wlds))
+  SET_W(trws_wide_kernel); SET_W(trws_wide_group_kernel);
+#undef SET_W
+}
+
+#define WIDE_SWITCH(NAME, ARG)                                                                                     \
+  const size_t wlds = wide_lds_bytes();                                                                            \
+  const dim3 wgrid(blocks), wblock(kWideThreads);                                                                  \
+  switch (what) {                                                                                                  \
+    case 0: hipLaunchKernelGGL((NAME<1, false, false, true>), wgrid, wblock, wlds, s, ARG, epoch); break;          \
+    case 1: hipLaunchKernelGGL((NAME<1, true, false, true>), wgrid, wblock, wlds, s, ARG, epoch); break;           \
+    case 2: hipLaunchKernelGGL((NAME<1, false, true, true>), wgrid, wblock, wlds, s, ARG, epoch); break;           \
+    default: hipLaunchKernelGGL((NAME<1, false, true, false>), wgrid, wblock, wlds, s, ARG, epoch); break;         \
+  }                                                                                                                \
+  STEREO_HIP_CHECK(hipGetLastError());
+
+void launch_wide(int what, int blocks, hipStream_t s, const DevParams &p, int epoch) { WIDE_SWITCH(trws_wide_kernel, p) }
+void launch_wide_group(int what, int blocks, hipStream_t s, const GroupArgs &ga, int epoch) { WIDE_SWITCH(trws_wide_group_kernel, ga) }
+#undef WIDE_SWITCH
+
+}  // namespace stereo

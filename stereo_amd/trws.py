@@ -171,7 +171,7 @@ class TrwsPlan:
         return dict(rank=rank, levels=lv.value, max_level_nodes=mx.value)
 
     def path(self):
-        """0 levels, 1 generic persistent, 2 pipelined (K <= 64), 3 wide pipelined, 4 pipelined with two
+        """1 generic persistent, 2 pipelined (K <= 64), 3 wide pipelined, 4 pipelined with two
         labels per lane (64 < K <= 128)."""
         return int(_lib.lib().stereo_trws_plan_path(self._h))
 
