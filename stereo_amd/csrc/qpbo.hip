@@ -57,71 +57,9 @@ struct QpboDev {
   int ntiles;
 };
 
-__global__ __launch_bounds__(kQB) void qpbo_push_kernel(QpboDev g) {
-  const int v = blockIdx.x * kQB + threadIdx.x;
-  if (v >= g.n) return;
-  double e = g.ex[v];
-  const int hv = g.h[v];
-  if (!(e > 0) || hv >= g.n) return;
-  if (hv == 1) {
-    const double s = g.snk[v];
-    if (s > 0) {
-      const double d = e < s ? e : s;
-      g.snk[v] = s - d;
-      e -= d;
-    }
-  }
-  const int a0 = g.aptr[v], a1 = g.aptr[v + 1];
-  for (int a = a0; a < a1 && e > 0; ++a) {
-    const double ra = g.r[a];
-    if (ra > 0 && hv == g.h[g.head[a]] + 1) {
-      const double d = e < ra ? e : ra;
-      g.r[a] = ra - d;
-      g.r[g.rev[a]] += d;
-      g.delta[a] = d;
-      e -= d;
-    }
-  }
-  g.ex[v] = e;
-}
-
-// arcs are stored grouped by tail node, so "arc a of node v" is simply index a
-__global__ __launch_bounds__(kQB) void qpbo_gather_relabel_kernel(QpboDev g) {
-  const int v = blockIdx.x * kQB + threadIdx.x;
-  if (v >= g.n) return;
-  double e = g.ex[v];
-  const int a0 = g.aptr[v], a1 = g.aptr[v + 1];
-  for (int a = a0; a < a1; ++a) {
-    const int b = g.rev[a];
-    const double d = g.delta[b];
-    if (d != 0) { e += d; g.delta[b] = 0; }
-  }
-  g.ex[v] = e;
-  int hv = g.h[v];
-  if (e > 0 && hv < g.n) {
-    int hmin = g.n;
-    if (g.snk[v] > 0) hmin = 0;
-    for (int a = a0; a < a1; ++a)
-      if (g.r[a] > 0) {
-        const int hw = g.h[g.head[a]];
-        hmin = hw < hmin ? hw : hmin;
-      }
-    if (hmin + 1 > hv) hv = hmin + 1 < g.n ? hmin + 1 : g.n;
-    if (hv < g.n) atomicAdd(g.counters, 1);
-  }
-  g.h2[v] = hv;
-}
-
-__global__ __launch_bounds__(kQB) void qpbo_count_active_kernel(QpboDev g) {
-  const int v = blockIdx.x * kQB + threadIdx.x;
-  if (v >= g.n) return;
-  if (g.ex[v] > 0 && g.h[v] < g.n) atomicAdd(g.counters, 1);
-}
-
-
 // ---- the whole max-flow in ONE launch -------------------------------------------------------
-// The multi-launch loop above is launch bound (a Teddy move is ~800 launches of a few
-// microseconds of work each).  This kernel runs the same synchronous rounds -- push | barrier |
+// A loop of launches is launch bound (round 1 measured ~800 launches of a few microseconds of
+// work each for a Teddy move).  This kernel runs synchronous rounds -- push | barrier |
 // gather + relabel | barrier -- and the level-synchronous global relabelling between grid-wide
 // barriers: one workgroup of 1024 threads per CU, all resident (cooperative launch), nodes
 // in a grid-stride loop.  Everything one workgroup writes and another reads inside the launch
@@ -719,19 +657,6 @@ __global__ __launch_bounds__(kQB) void rd_energy_terms_kernel(int64_t N, int64_t
   }
 }
 
-// pull-style exact relabelling: one level per launch, no queues, no host round trip per level
-__global__ __launch_bounds__(kQB) void qpbo_relabel_init_kernel(QpboDev g) {
-  const int v = blockIdx.x * kQB + threadIdx.x;
-  if (v >= g.n) return;
-  g.h[v] = g.snk[v] > 0 ? 1 : g.n;
-}
-__global__ __launch_bounds__(kQB) void qpbo_relabel_level_kernel(QpboDev g, int level, int32_t *changed) {
-  const int v = blockIdx.x * kQB + threadIdx.x;
-  if (v >= g.n || g.h[v] != g.n) return;
-  for (int a = g.aptr[v]; a < g.aptr[v + 1]; ++a)
-    if (g.r[a] > 0 && g.h[g.head[a]] == level) { g.h[v] = level + 1; *changed = 1; return; }
-}
-
 // ---- host-side construction ----------------------------------------------
 
 struct Pair {
@@ -921,28 +846,6 @@ struct QpboSolver {
     g.perm = d_perm.p; g.pos_of = d_posof.p; g.ntiles = (int)(perm.size() / kMB);
   }
 
-  // exact distances to the sink in the residual graph; returns #active nodes.  Levels are
-  // launched in batches, the host only looks at the "anything changed" words between batches.
-  int global_relabel() {
-    const int batch = 64;
-    hipLaunchKernelGGL(qpbo_relabel_init_kernel, dim3(grid()), dim3(kQB), 0, 0, g);
-    std::vector<int32_t> flags(batch);
-    if (d_flags.n < (size_t)batch) d_flags.alloc(batch);
-    for (int level = 1;;) {
-      STEREO_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(int32_t) * batch, 0));
-      for (int k = 0; k < batch; ++k, ++level)
-        hipLaunchKernelGGL(qpbo_relabel_level_kernel, dim3(grid()), dim3(kQB), 0, 0, g, level, d_flags.p + k);
-      STEREO_HIP_CHECK(hipMemcpy(flags.data(), d_flags.p, sizeof(int32_t) * batch, hipMemcpyDeviceToHost));
-      if (!flags[batch - 1]) break;  // a level that changes nothing ends the search
-    }
-    int32_t cnt = 0;
-    STEREO_HIP_CHECK(hipMemsetAsync(d_cnt.p, 0, sizeof(int32_t), 0));
-    hipLaunchKernelGGL(qpbo_count_active_kernel, dim3(grid()), dim3(kQB), 0, 0, g);
-    STEREO_HIP_CHECK(hipMemcpy(&cnt, d_cnt.p, sizeof(cnt), hipMemcpyDeviceToHost));
-    ++relabels;
-    return cnt;
-  }
-
   // AddUnaryTerm(i, 0, INFTY) with INFTY = 1 + max over the two saturation sums of node i
   // (QPBO_extra.cpp:241-254, :1185-1199), applied to the push-relabel state: more source
   // capacity at i, more sink capacity at its mate.
@@ -974,12 +877,8 @@ struct QpboSolver {
     STEREO_HIP_CHECK(hipMemcpy(h.data(), g.h, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
   }
 
-  // One cooperative launch runs the whole max-flow (qpbo_maxflow_kernel); the multi-launch loop
-  // is kept behind STEREO_HIP_QPBO_PERSISTENT=0 for comparison.
+  // One cooperative launch runs the whole max-flow (qpbo_maxflow_kernel).
   void maxflow(bool warm = false) {
-    const char *pe = std::getenv("STEREO_HIP_QPBO_PERSISTENT");
-    const bool persistent = !(pe && std::string(pe) == "0");
-    if (!persistent) { maxflow_launches(); return; }
     int relabel_every = 256;
     if (const char *e = std::getenv("STEREO_HIP_QPBO_RELABEL_EVERY")) relabel_every = std::max(1, std::atoi(e));
     if (d_ctl.n < (size_t)QpboCtl::kWords) d_ctl.alloc(QpboCtl::kWords);
@@ -1025,36 +924,6 @@ struct QpboSolver {
     if (std::getenv("STEREO_HIP_QPBO_VERBOSE")) { std::vector<int32_t> tr(1040); (void)hipMemcpy(tr.data(), d_cnt.p, sizeof(int32_t) * 1040, hipMemcpyDeviceToHost); std::fprintf(stderr, "[stereo_hip qpbo] active per round:"); for (int i = 0; i < host_ctl[QpboCtl::kRounds] && i < 1024; i += (i < 32 ? 1 : 8)) std::fprintf(stderr, " %d", tr[16 + i]); std::fprintf(stderr, "\n"); }
     iterations += host_ctl[QpboCtl::kRounds];
     relabels += host_ctl[QpboCtl::kRelabels];
-  }
-
-  void maxflow_launches() {
-    int active = global_relabel();
-
-    int check_every = 8;  // grows: easy instances finish within a few sweeps
-    int relabel_every = 256;
-    if (const char *e = std::getenv("STEREO_HIP_QPBO_RELABEL_EVERY")) relabel_every = std::max(1, std::atoi(e));
-    int since_relabel = 0;
-    while (active > 0) {
-      for (int k = 0; k < check_every; ++k) {
-        hipLaunchKernelGGL(qpbo_push_kernel, dim3(grid()), dim3(kQB), 0, 0, g);
-        if (k == check_every - 1) STEREO_HIP_CHECK(hipMemsetAsync(d_cnt.p, 0, sizeof(int32_t), 0));
-        hipLaunchKernelGGL(qpbo_gather_relabel_kernel, dim3(grid()), dim3(kQB), 0, 0, g);
-        std::swap(g.h, g.h2);
-      }
-      iterations += check_every;
-      since_relabel += check_every;
-      if (check_every < 32) check_every *= 2;
-      int32_t cnt = 0;
-      STEREO_HIP_CHECK(hipMemcpy(&cnt, d_cnt.p, sizeof(cnt), hipMemcpyDeviceToHost));
-      active = cnt;
-      if (active > 0 && since_relabel >= relabel_every) {
-        active = global_relabel();
-        since_relabel = 0;
-      }
-    }
-    // heights may be stale lower bounds: one exact BFS defines T
-    global_relabel();
-    STEREO_HIP_CHECK(hipGetLastError());
   }
 };
 

@@ -156,10 +156,9 @@ def test_plan_equals_stateless_and_reference(hip, oracle):
                 assert np.array_equal(r[0], b[0]), k
 
 
-def test_grid_hint_and_persistent_kernel_do_not_change_results(hip, monkeypatch):
-    """The image-patch work partition (stereo_rd_plan_set_grid) and the single-launch max-flow
-    are schedules, not algorithms: labels / unlabelled counts identical to the index-range
-    partition and to the multi-launch loop, energies and bounds to 1e-12."""
+def test_grid_hint_does_not_change_results(hip):
+    """The image-patch work partition (stereo_rd_plan_set_grid) is a schedule, not an algorithm:
+    labels / unlabelled counts identical to the index-range partition, energies and bounds to 1e-12."""
     from stereo_amd.rd import RdPlan
     H, W = 70, 90   # several 16 x 32 patches, ragged at both borders
     probs = [fusion_problem(311, H, W), glass_problem(312, H, W, 3.0, True), fusion_problem(313, H, W, nonsub_boost=5.0)]
@@ -169,9 +168,5 @@ def test_grid_hint_and_persistent_kernel_do_not_change_results(hip, monkeypatch)
     for p in probs:
         args = (p["U0"], p["U1"], p["E00"], p["E01"], p["E10"], p["E11"])
         a, b = plain.solve(*args), hinted.solve(*args)
-        monkeypatch.setenv("STEREO_HIP_QPBO_PERSISTENT", "0")   # multi-launch loop
-        c = plain.solve(*args)
-        monkeypatch.delenv("STEREO_HIP_QPBO_PERSISTENT")
-        for x in (b, c):
-            assert np.array_equal(a[0], x[0]) and a[3] == x[3]
-            assert _rel(a[1], x[1]) < 1e-12 and _rel(a[2], x[2]) < 1e-12
+        assert np.array_equal(a[0], b[0]) and a[3] == b[3]
+        assert _rel(a[1], b[1]) < 1e-12 and _rel(a[2], b[2]) < 1e-12
