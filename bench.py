@@ -358,6 +358,17 @@ def main():
                 extra["end_to_end"] = {"moves_per_s": 1.0 / tm, "ms_per_move": tm * 1e3, "energy": dm.energy(),
                                        "what": "dispmap_ncc.binary_fusion on a synthetic %dx%d pair, %d fronto-parallel "
                                                "proposals: pairwise terms + unaries + QPBO + scatter + energy on the device" % (W, H, len(planes) - 1)}
+                # the same moves with the proposals built on the device from their plane: 32 bytes
+                # cross PCIe per move instead of 4 x N doubles
+                dm.restart()
+                pps = [stereo_amd.PlaneProposal([0.0, 0.0, 1.0, -float(d)]) for d in np.linspace(2, K - 3, 9)]
+                dm.binary_fusion(pps[0])
+                t1 = time.perf_counter()
+                for pl in pps[1:]:
+                    dm.binary_fusion(pl)
+                tm2 = (time.perf_counter() - t1) / (len(pps) - 1)
+                extra["end_to_end_device_proposals"] = {"moves_per_s": 1.0 / tm2, "ms_per_move": tm2 * 1e3, "energy": dm.energy(),
+                                                        "energy_equal_to_end_to_end": bool(dm.energy() == extra["end_to_end"]["energy"])}
                 out["binary_fusion"] = extra
             except Exception as exc:  # the headline number must not depend on the secondary one
                 out["binary_fusion"] = {"error": str(exc)}

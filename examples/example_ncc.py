@@ -23,6 +23,7 @@ def main():
     ap.add_argument("images", nargs="*")
     ap.add_argument("--disparities", type=int, default=51)   # example_ncc.m:13 ships 0:1:50
     ap.add_argument("--maxiter", type=int, default=100)
+    ap.add_argument("--host-proposals", action="store_true")
     args = ap.parse_args()
     import stereo_amd
     if len(args.images) == 2:
@@ -37,11 +38,16 @@ def main():
     dm = stereo_amd.dispmap_ncc(images, disparities, 1, 40.0, tol)
     print("NCC volume + winner-takes-all start: %.2f s, energy %.6f" % (time.time() - t0, dm.energy()))
     H, W = dm.sz
-    proposals = [dm.generate_new_plane_RANSAC(x, y, 5) for x in range(10, W + 1, 50) for y in range(10, H + 1, 50)]
-    for d in range(0, int(disparities.max()) + 1, 10):
-        p = np.zeros_like(dm.assignment)
-        p[2], p[3] = 1, -d
-        proposals.append(p)
+    # plane fits and proposals on the device (--host-proposals: the reference-shaped 4 x N arrays instead)
+    if args.host_proposals:
+        proposals = [dm.generate_new_plane_RANSAC(x, y, 5) for x in range(10, W + 1, 50) for y in range(10, H + 1, 50)]
+        for d in range(0, int(disparities.max()) + 1, 10):
+            p = np.zeros_like(dm.assignment)
+            p[2], p[3] = 1, -d
+            proposals.append(p)
+    else:
+        proposals = [dm.generate_new_plane_RANSAC(x, y, 5, on_device=True) for x in range(10, W + 1, 50) for y in range(10, H + 1, 50)]
+        proposals += [stereo_amd.PlaneProposal([0.0, 0.0, 1.0, -float(d)]) for d in range(0, int(disparities.max()) + 1, 10)]
     t0 = time.time()
     for p in proposals:
         dm.binary_fusion(p)

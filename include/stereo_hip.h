@@ -356,6 +356,26 @@ int stereo_fusion_get_assignment(stereo_fusion *ctx, double *assignment, double 
 int stereo_fusion_binary(stereo_fusion *ctx, const double *proposal, int improve, double *energy,
                          double *rd_energy, double *lower_bound, double *num_unlabelled, char *err,
                          size_t errcap);
+/* Proposals built on the device.  The proposals of the reference's examples are one
+ * plane for every pixel (example_ncc.m:24-41: plane fits and fronto-parallel planes, repmat'ed at
+ * dispmap_ncc.m:65) or one plane per image segment (dispmap_globalstereo.m:154-192): `planes` is
+ * 4 x S, `segments` N ids in [0, S) (may be NULL when S == 1, or to reuse the ids of the last call).
+ * Same move as stereo_fusion_binary; 32 S bytes cross PCIe instead of 32 N. */
+int stereo_fusion_binary_planes(stereo_fusion *ctx, const double *planes, int S, const int32_t *segments,
+                                int improve, double *energy, double *rd_energy, double *lower_bound,
+                                double *num_unlabelled, char *err, size_t errcap);
+/* dispmap_ncc.m:48-92 generate_new_plane_RANSAC / fit_plane_to_points on the device: plane [a b 1 d]
+ * through the winner-takes-all disparities (:208-221) within radius r of pixel (x, y) (one based,
+ * x = column); kernel 1: 20 rounds of IRLS, kernel 2: total least squares.  The reference's
+ * svd(...) V(:, end) is computed as the smallest eigenvector of the 3 x 3 normal matrix (MATLAB's svd
+ * lies outside the reference tree: agreement to rounding, not bit for bit).  npoints (may be NULL):
+ * pixels inside the radius. */
+int stereo_fusion_fit_plane(stereo_fusion *ctx, double x, double y, double r, double *plane,
+                            double *npoints, char *err, size_t errcap);
+/* stereo_fusion_simultaneous with K single-plane proposals (planes 4 x K) built on the device */
+int stereo_fusion_simultaneous_planes(stereo_fusion *ctx, const double *planes, int K, double maxiter,
+                                      double max_relgap, double *energy, double *trws_energy,
+                                      double *lower_bound, double *iterations, char *err, size_t errcap);
 /* one simultaneous fusion (dispmap_super.m:153-198): the K proposals (4 x N x K) and the current
  * assignment (appended as label K+1, :160) compete per pixel; unary K x N, q / qprim K x E, TRW-S
  * (stereo_trws_plan, options maxiter / max_relgap as in trws.m) and the scatter of the winning

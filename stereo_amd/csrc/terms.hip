@@ -524,6 +524,94 @@ __global__ __launch_bounds__(kTB) void fusion_sum_kernel(const double *x, int64_
   if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
 }
 
+// ---- proposals built on the device --------------------------------------------
+// A proposal of the reference's examples is never an arbitrary 4 x N array: it is one plane for
+// every pixel (example_ncc.m:24-41: plane fits and fronto-parallel planes, repmat'ed,
+// dispmap_ncc.m:65) or one plane per image segment (dispmap_globalstereo.m:154-192 SegPln).  Built
+// from a 4 x S table (+ an N-vector of segment ids) in HBM, so a move uploads 32 S bytes, not 32 N.
+__global__ __launch_bounds__(kTB) void proposal_from_planes_kernel(int64_t N, const double *planes, int S,
+                                                                  const int32_t *segments, double *prop) {
+  const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
+  if (i >= N) return;
+  int sgm = segments ? segments[i] : 0;
+  sgm = sgm < 0 ? 0 : sgm >= S ? S - 1 : sgm;
+  prop[4 * i] = planes[4 * sgm]; prop[4 * i + 1] = planes[4 * sgm + 1];
+  prop[4 * i + 2] = planes[4 * sgm + 2]; prop[4 * i + 3] = planes[4 * sgm + 3];
+}
+
+// dispmap_ncc.m:48-92 generate_new_plane_RANSAC + fit_plane_to_points: the plane through the
+// winner-takes-all disparities of the pixels within radius r of (x, y) (1-based, x = column): total
+// least squares (kernel 2) or 20 rounds of iteratively reweighted least squares (kernel 1).  The
+// reference takes V(:, end) of svd(w .* cost): the eigenvector of the smallest eigenvalue of
+// sum_i w_i^2 c_i c_i' -- found here by cyclic Jacobi rotations of that 3 x 3 matrix (MATLAB's svd
+// is outside the reference tree: agreement with a LAPACK SVD to ~1e-9, not bit for bit; the sign
+// of the vector cancels in p / p(3)).  At most (2r+1)^2 points: one thread does the arithmetic in
+// the reference's order (pixels in column-major order), the rest of the wave idles.
+constexpr int kFitMax = 1024;
+__global__ __launch_bounds__(64) void fit_plane_kernel(const double *best, int H, int W, double x, double y, double r,
+                                                      int kernel, double *out /* 4 + count */) {
+  __shared__ double px[kFitMax], py[kFitMax], pz[kFitMax], wt[kFitMax];
+  if (threadIdx.x != 0) return;
+  int n = 0;
+  const int c0 = (int)fmax(1.0, floor(x - r)), c1 = (int)fmin((double)W, ceil(x + r));
+  const int r0 = (int)fmax(1.0, floor(y - r)), r1 = (int)fmin((double)H, ceil(y + r));
+  for (int c = c0; c <= c1; ++c)
+    for (int rr = r0; rr <= r1; ++rr) {
+      const double dx = (double)c - x, dy = (double)rr - y;
+      if (sqrt(dx * dx + dy * dy) < r && n < kFitMax) {
+        px[n] = c; py[n] = rr; pz[n] = best[(size_t)(c - 1) * H + (rr - 1)]; wt[n] = 1.0; ++n;
+      }
+    }
+  out[4] = n;
+  if (n < 3) { out[0] = 0; out[1] = 0; out[2] = 1; out[3] = 0; return; }
+  double cx = 0, cy = 0, cz = 0;
+  for (int i = 0; i < n; ++i) { cx += px[i]; cy += py[i]; cz += pz[i]; }
+  cx /= n; cy /= n; cz /= n;
+  double v[3] = {0, 0, 1};
+  const int rounds = kernel == 1 ? 20 : 1;
+  for (int it = 0; it < rounds; ++it) {
+    double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int i = 0; i < n; ++i) {
+      const double w = wt[i], a = -(px[i] - cx) * w, b = -(py[i] - cy) * w, c = -(pz[i] - cz) * w;
+      A[0][0] += a * a; A[0][1] += a * b; A[0][2] += a * c; A[1][1] += b * b; A[1][2] += b * c; A[2][2] += c * c;
+    }
+    A[1][0] = A[0][1]; A[2][0] = A[0][2]; A[2][1] = A[1][2];
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 30; ++sweep) {
+      const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+      if (off < 1e-300) break;
+      for (int pp = 0; pp < 2; ++pp)
+        for (int q = pp + 1; q < 3; ++q) {
+          if (A[pp][q] == 0) continue;
+          const double theta = (A[q][q] - A[pp][pp]) / (2 * A[pp][q]);
+          const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+          const double cs = 1 / sqrt(t * t + 1), sn = t * cs;
+          for (int k = 0; k < 3; ++k) {  // A <- A J
+            const double akp = A[k][pp], akq = A[k][q];
+            A[k][pp] = cs * akp - sn * akq; A[k][q] = sn * akp + cs * akq;
+          }
+          for (int k = 0; k < 3; ++k) {  // A <- J' A
+            const double apk = A[pp][k], aqk = A[q][k];
+            A[pp][k] = cs * apk - sn * aqk; A[q][k] = sn * apk + cs * aqk;
+          }
+          for (int k = 0; k < 3; ++k) {
+            const double vkp = V[k][pp], vkq = V[k][q];
+            V[k][pp] = cs * vkp - sn * vkq; V[k][q] = sn * vkp + cs * vkq;
+          }
+        }
+    }
+    int m = 0;
+    if (A[1][1] < A[m][m]) m = 1;
+    if (A[2][2] < A[m][m]) m = 2;
+    v[0] = V[0][m]; v[1] = V[1][m]; v[2] = V[2][m];
+    if (kernel == 1)
+      for (int i = 0; i < n; ++i)  // w = sqrt(abs(cost * V(:, end)))
+        wt[i] = sqrt(fabs(-(px[i] - cx) * v[0] + -(py[i] - cy) * v[1] + -(pz[i] - cz) * v[2]));
+  }
+  const double p4 = -(v[0] * cx + v[1] * cy + v[2] * cz);
+  out[0] = v[0] / v[2]; out[1] = v[1] / v[2]; out[2] = v[2] / v[2]; out[3] = p4 / v[2];
+}
+
 template <class F>
 int guarded(const char *what, char *err, size_t errcap, F f) {
   if (stereo_hip_device_count() < 1)
@@ -706,6 +794,9 @@ struct stereo_fusion {
   int D = 0, C = 0;
   double unary_weight = 0, dmin = 0, dmax = 0, col_thresh = 0;
   bool ascending = false;  // strictly ascending disparities: the sampler bisects instead of scanning
+  DevBuf<double> best, plane_tab, fit_out;   // proposals built on the device: WTA disparities, 4 x S planes
+  DevBuf<int32_t> segments;
+  bool have_best = false, have_segments = false;
   bool have_assignment = false;
   double energy = 0;
   std::vector<double> h_lab;
@@ -791,6 +882,7 @@ int stereo_fusion_unary_ncc(stereo_fusion *F, const double *ncc, int D, const do
     F->ncc.upload(ncc, (size_t)F->N * D); F->disparities.upload(disparities, D);
     F->D = D; F->unary_weight = unary_weight; F->unary_kind = 1;
     F->ascending = strictly_ascending(disparities, D);
+    F->have_best = false;
     F->dmin = F->dmax = disparities[0];
     for (int i = 1; i < D; ++i) { F->dmin = std::min(F->dmin, disparities[i]); F->dmax = std::max(F->dmax, disparities[i]); }
     F->have_assignment = false;
@@ -829,19 +921,25 @@ int stereo_fusion_get_assignment(stereo_fusion *F, double *assignment, double *e
   });
 }
 
-int stereo_fusion_binary(stereo_fusion *F, const double *proposal, int improve, double *energy,
-                         double *rd_energy, double *lower_bound, double *num_unlabelled, char *err,
-                         size_t errcap) {
-  if (!F || !proposal) return fail("stereo_fusion_binary: bad argument", err, errcap);
-  if (!F->have_assignment) return fail("stereo_fusion: no assignment set", err, errcap);
-  return guarded("stereo_fusion_binary", err, errcap, [&] {
+// the 4 x S plane table (+ segment ids) of a proposal -> 4 x N on the device
+static void fusion_build_proposal(stereo_fusion *F, const double *planes, int S, const int32_t *segments, double *d_prop) {
+  check_planes(planes, S);
+  if (S > 1 && !segments && !F->have_segments) throw std::runtime_error("stereo_fusion: more than one plane needs segment ids");
+  if (segments) { F->segments.upload(segments, F->N); F->have_segments = true; }
+  F->plane_tab.upload(planes, (size_t)4 * S);
+  hipLaunchKernelGGL(proposal_from_planes_kernel, dim3(blocks(F->N)), dim3(kTB), 0, 0, F->N, F->plane_tab.p, S,
+                     S > 1 ? F->segments.p : (const int32_t *)nullptr, d_prop);
+}
+
+// one binary fusion move with the proposal already in F->prop
+static void fusion_binary_core(stereo_fusion *F, int improve, double *energy, double *rd_energy, double *lower_bound,
+                               double *num_unlabelled, double t_start) {
+  {
     const int64_t N = F->N, E = F->E;
     const bool verbose = std::getenv("STEREO_HIP_FUSION_VERBOSE") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t[6];
-    t[0] = now();
-    check_planes(proposal, N);
-    F->prop.upload(proposal, 4 * N);
+    t[0] = t_start;
     hipLaunchKernelGGL(pairwise_terms_kernel, dim3(blocks(E)), dim3(kTB), 0, 0, F->kernel, E, F->conn.p, F->points.p,
                        F->cur.p, F->prop.p, F->weights.p, F->tol, F->d_min, F->d_step, F->E00.p, F->E01.p,
                        F->E10.p, F->E11.p);
@@ -867,21 +965,68 @@ int stereo_fusion_binary(stereo_fusion *F, const double *proposal, int improve, 
     if (rd_energy) *rd_energy = e;
     if (lower_bound) *lower_bound = lb;
     if (num_unlabelled) *num_unlabelled = unl;
+  }
+}
+
+static double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int stereo_fusion_binary(stereo_fusion *F, const double *proposal, int improve, double *energy,
+                         double *rd_energy, double *lower_bound, double *num_unlabelled, char *err,
+                         size_t errcap) {
+  if (!F || !proposal) return fail("stereo_fusion_binary: bad argument", err, errcap);
+  if (!F->have_assignment) return fail("stereo_fusion: no assignment set", err, errcap);
+  return guarded("stereo_fusion_binary", err, errcap, [&] {
+    const double t0 = wall_ms();
+    check_planes(proposal, F->N);
+    F->prop.upload(proposal, 4 * F->N);
+    fusion_binary_core(F, improve, energy, rd_energy, lower_bound, num_unlabelled, t0);
   });
 }
 
-int stereo_fusion_simultaneous(stereo_fusion *F, const double *proposals, int K, double maxiter,
-                               double max_relgap, double *energy, double *trws_energy, double *lower_bound,
-                               double *iterations, char *err, size_t errcap) {
-  if (!F || !proposals || K < 1) return fail("stereo_fusion_simultaneous: bad argument", err, errcap);
+int stereo_fusion_binary_planes(stereo_fusion *F, const double *planes, int S, const int32_t *segments, int improve,
+                                double *energy, double *rd_energy, double *lower_bound, double *num_unlabelled,
+                                char *err, size_t errcap) {
+  if (!F || !planes || S < 1) return fail("stereo_fusion_binary_planes: bad argument", err, errcap);
   if (!F->have_assignment) return fail("stereo_fusion: no assignment set", err, errcap);
+  return guarded("stereo_fusion_binary_planes", err, errcap, [&] {
+    const double t0 = wall_ms();
+    fusion_build_proposal(F, planes, S, segments, F->prop.p);
+    fusion_binary_core(F, improve, energy, rd_energy, lower_bound, num_unlabelled, t0);
+  });
+}
+
+int stereo_fusion_fit_plane(stereo_fusion *F, double x, double y, double r, double *plane, double *npoints, char *err,
+                            size_t errcap) {
+  if (!F || !plane) return fail("stereo_fusion_fit_plane: bad argument", err, errcap);
+  if (F->unary_kind != 1) return fail("stereo_fusion_fit_plane: needs the NCC volume (dispmap_ncc)", err, errcap);
+  if (!(r > 0) || (2 * r + 3) * (2 * r + 3) > kFitMax) return fail("stereo_fusion_fit_plane: radius out of range", err, errcap);
+  return guarded("stereo_fusion_fit_plane", err, errcap, [&] {
+    if (!F->have_best) {  // best_disp_from_ncc (dispmap_ncc.m:208-221), once per volume
+      F->best.alloc(F->N);
+      hipLaunchKernelGGL(ncc_best_disp_kernel, dim3(blocks(F->N)), dim3(kTB), 0, 0, F->ncc.p, F->H, F->W, F->D, 0,
+                         F->disparities.p, F->best.p);
+      F->have_best = true;
+    }
+    if (F->fit_out.n < 8) F->fit_out.alloc(8);
+    hipLaunchKernelGGL(fit_plane_kernel, dim3(1), dim3(64), 0, 0, F->best.p, F->H, F->W, x, y, r, F->kernel, F->fit_out.p);
+    double h[5];
+    STEREO_HIP_CHECK(hipMemcpy(h, F->fit_out.p, sizeof(h), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; ++k) plane[k] = h[k];
+    if (npoints) *npoints = h[4];
+  });
+}
+
+// proposals: 4 x N x K host array, or NULL with plane_tab = 4 x K (one plane per proposal, built on the device)
+static int fusion_simultaneous_impl(stereo_fusion *F, const double *proposals, const double *plane_tab, int K,
+                                    double maxiter, double max_relgap, double *energy, double *trws_energy,
+                                    double *lower_bound, double *iterations, char *err, size_t errcap) {
   return guarded("stereo_fusion_simultaneous", err, errcap, [&] {
     const int64_t N = F->N, E = F->E;
     const int Kt = K + 1;  // proposals{end+1} = self.assignment (dispmap_super.m:160)
     const bool verbose = std::getenv("STEREO_HIP_FUSION_VERBOSE") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    check_planes(proposals, N * K);
+    if (proposals) check_planes(proposals, N * K); else check_planes(plane_tab, K);
     char e2[256] = {0};
     if (!F->trws || F->trws_K != Kt) {
       if (F->trws) { stereo_trws_plan_destroy(F->trws); F->trws = nullptr; }
@@ -893,7 +1038,14 @@ int stereo_fusion_simultaneous(stereo_fusion *F, const double *proposals, int K,
       F->qK.alloc((size_t)std::max<int64_t>(E, 1) * Kt); F->qpK.alloc((size_t)std::max<int64_t>(E, 1) * Kt);
       F->labels.alloc(N); F->h_label.resize(N);
     }
-    STEREO_HIP_CHECK(hipMemcpy(F->props.p, proposals, sizeof(double) * 4 * N * K, hipMemcpyHostToDevice));
+    if (proposals) {
+      STEREO_HIP_CHECK(hipMemcpy(F->props.p, proposals, sizeof(double) * 4 * N * K, hipMemcpyHostToDevice));
+    } else {
+      F->plane_tab.upload(plane_tab, (size_t)4 * K);
+      for (int k = 0; k < K; ++k)
+        hipLaunchKernelGGL(proposal_from_planes_kernel, dim3(blocks(N)), dim3(kTB), 0, 0, N, F->plane_tab.p + 4 * k, 1,
+                           (const int32_t *)nullptr, F->props.p + (size_t)k * 4 * N);
+    }
     STEREO_HIP_CHECK(hipMemcpy(F->props.p + (size_t)4 * N * K, F->cur.p, sizeof(double) * 4 * N, hipMemcpyDeviceToDevice));
     // unary (K x N, dispmap_super.m:164-172) and positions (:177-183) on the device
     for (int k = 0; k < Kt; ++k) {
@@ -936,6 +1088,24 @@ int stereo_fusion_simultaneous(stereo_fusion *F, const double *proposals, int K,
     if (lower_bound) *lower_bound = tlb;
     if (iterations) *iterations = tit;
   });
+}
+
+int stereo_fusion_simultaneous(stereo_fusion *F, const double *proposals, int K, double maxiter,
+                               double max_relgap, double *energy, double *trws_energy, double *lower_bound,
+                               double *iterations, char *err, size_t errcap) {
+  if (!F || !proposals || K < 1) return fail("stereo_fusion_simultaneous: bad argument", err, errcap);
+  if (!F->have_assignment) return fail("stereo_fusion: no assignment set", err, errcap);
+  return fusion_simultaneous_impl(F, proposals, nullptr, K, maxiter, max_relgap, energy, trws_energy, lower_bound,
+                                  iterations, err, errcap);
+}
+
+int stereo_fusion_simultaneous_planes(stereo_fusion *F, const double *planes, int K, double maxiter, double max_relgap,
+                                      double *energy, double *trws_energy, double *lower_bound, double *iterations,
+                                      char *err, size_t errcap) {
+  if (!F || !planes || K < 1) return fail("stereo_fusion_simultaneous_planes: bad argument", err, errcap);
+  if (!F->have_assignment) return fail("stereo_fusion: no assignment set", err, errcap);
+  return fusion_simultaneous_impl(F, nullptr, planes, K, maxiter, max_relgap, energy, trws_energy, lower_bound,
+                                  iterations, err, errcap);
 }
 
 }  // extern "C"

@@ -11,7 +11,7 @@ import numpy as np
 
 from . import terms as T
 from ._lib import StereoHipError
-from .fusion import FusionContext
+from .fusion import FusionContext, PlaneProposal
 from .rd import RdPlan, rd  # noqa: F401
 from .trws import trws
 
@@ -149,7 +149,19 @@ class dispmap_super:
 
     # ---- moves
     def binary_fusion(self, proposal):
-        """dispmap_super.m:61-84"""
+        """dispmap_super.m:61-84.  `proposal`: 4 x N planes as in the reference, or a PlaneProposal
+        (plane table, built into the 4 x N array on the device)."""
+        if isinstance(proposal, PlaneProposal):
+            ctx = self._context()
+            if ctx is None:
+                proposal = proposal.expand(self.sz[0] * self.sz[1])
+            else:
+                if not self._ctx_has_assignment:
+                    ctx.set_assignment(self._assignment)
+                    self._ctx_has_assignment = True
+                self.stored_energy, e, lb, num_unlabelled = ctx.binary_planes(proposal, self._improve)
+                self._host_stale = True
+                return e, lb, num_unlabelled
         proposal = np.asfortranarray(proposal, dtype=np.float64)
         if proposal.shape != self._assignment.shape:
             raise StereoHipError("Binary fusion: Proposals is of wrong size")
@@ -216,11 +228,20 @@ class dispmap_super:
         if not isinstance(proposal_cell, (list, tuple)):
             raise StereoHipError("Input proposals should be given in cell array.")
         ctx = self._context()
+        N = self.sz[0] * self.sz[1]
+        single = all(isinstance(p, PlaneProposal) and p.segments is None for p in proposal_cell)
+        if not single:
+            proposal_cell = [p.expand(N) if isinstance(p, PlaneProposal) else p for p in proposal_cell]
         if ctx is not None:
             # device-resident: proposals go up, unary / positions / TRW-S / scatter stay in HBM
             if not self._ctx_has_assignment:
                 ctx.set_assignment(self._assignment)
                 self._ctx_has_assignment = True
+            if single:   # K planes instead of K x 4 x N doubles
+                tab = np.concatenate([p.planes for p in proposal_cell], axis=1)
+                self.stored_energy, e, lb, iterations = ctx.simultaneous_planes(tab, self.maxiter, self._max_relgap)
+                self._host_stale = True
+                return e, lb, iterations
             self.stored_energy, e, lb, iterations = ctx.simultaneous(proposal_cell, self.maxiter, self._max_relgap)
             self._host_stale = True
             return e, lb, iterations
@@ -299,9 +320,16 @@ class dispmap_ncc(dispmap_super):
     # ---- proposals (dispmap_ncc.m:48-92).  Host side: a few dozen points and 3 x 3 SVDs per
     # proposal; MATLAB's svd is outside the reference tree, so this mirrors the arithmetic with
     # numpy's (parity unpinned -- proposals are inputs of the parity-tested path, not outputs).
-    def generate_new_plane_RANSAC(self, x, y, r):
+    def generate_new_plane_RANSAC(self, x, y, r, on_device=False):
         """dispmap_ncc.m:48-66: plane fitted to the winner-takes-all disparities within radius r
-        of pixel (x, y) (1-based, x = column), repeated for every pixel."""
+        of pixel (x, y) (1-based, x = column), repeated for every pixel.  on_device: the fit runs in
+        the device-resident context (stereo_fusion_fit_plane) and a PlaneProposal comes back instead
+        of the 4 x N array -- nothing of size N crosses PCIe for the proposal or the move."""
+        if on_device:
+            ctx = self._context()
+            if ctx is not None:
+                plane, _ = ctx.fit_plane(x, y, r)
+                return PlaneProposal(plane)
         pts = self.points
         best = np.asarray(self.best_disp_from_ncc()).T.reshape(-1)      # column-major pixel order
         ids = np.sqrt((pts[0] - x) ** 2 + (pts[1] - y) ** 2) < r

@@ -17,6 +17,24 @@ def _p(a, t=C.c_double):
     return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
 
 
+class PlaneProposal:
+    """A proposal given by a table of planes instead of a 4 x N array: one plane for every pixel
+    (what dispmap_ncc.generate_new_plane_RANSAC and the fronto-parallel proposals of example_ncc.m
+    are, before their repmat) or one plane per image segment (`segments`: N ids, pixel order
+    col * H + row; the SegPln proposals of dispmap_globalstereo.m:154-192).  The device-resident
+    moves build the 4 x N array in HBM; expand() gives the reference-shaped array."""
+
+    def __init__(self, planes, segments=None):
+        self.planes = np.asfortranarray(np.asarray(planes, np.float64).reshape(4, -1))
+        self.segments = None if segments is None else np.ascontiguousarray(np.asarray(segments).reshape(-1), dtype=np.int32)
+        if self.segments is None and self.planes.shape[1] != 1:
+            raise StereoHipError("more than one plane needs segment ids")
+
+    def expand(self, N):
+        idx = np.zeros(N, np.int64) if self.segments is None else self.segments.astype(np.int64)
+        return np.asfortranarray(self.planes[:, idx])
+
+
 class FusionContext:
     def __init__(self, H, W, kernel, tol, conn0, weights, d_min=0.0, d_step=0.0):
         conn = np.asfortranarray(np.asarray(conn0), dtype=np.uint32)
@@ -68,6 +86,31 @@ class FusionContext:
         self._call(_lib.lib().stereo_fusion_binary, _p(_f(proposal)), C.c_int(int(bool(improve))), C.byref(e),
                    C.byref(re_), C.byref(lb), C.byref(nu))
         return e.value, re_.value, lb.value, nu.value
+
+    def binary_planes(self, proposal, improve=False):
+        """binary() with a PlaneProposal: the 4 x N proposal is built on the device."""
+        e, re_, lb, nu = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        seg = proposal.segments
+        self._call(_lib.lib().stereo_fusion_binary_planes, _p(proposal.planes), C.c_int(proposal.planes.shape[1]),
+                   _p(seg, C.c_int32) if seg is not None else None, C.c_int(int(bool(improve))), C.byref(e),
+                   C.byref(re_), C.byref(lb), C.byref(nu))
+        return e.value, re_.value, lb.value, nu.value
+
+    def fit_plane(self, x, y, r):
+        """dispmap_ncc.m:48-92 on the device -> (plane [a b 1 d], number of pixels inside the radius)"""
+        pl = np.zeros(4)
+        n = C.c_double()
+        self._call(_lib.lib().stereo_fusion_fit_plane, C.c_double(float(x)), C.c_double(float(y)), C.c_double(float(r)),
+                   _p(pl), C.byref(n))
+        return pl, int(n.value)
+
+    def simultaneous_planes(self, planes, maxiter=1000, max_relgap=0.0):
+        """simultaneous() with K single-plane proposals (4 x K) built on the device."""
+        planes = np.asfortranarray(np.asarray(planes, np.float64).reshape(4, -1))
+        e, te, lb, it = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        self._call(_lib.lib().stereo_fusion_simultaneous_planes, _p(planes), C.c_int(planes.shape[1]), C.c_double(maxiter),
+                   C.c_double(max_relgap), C.byref(e), C.byref(te), C.byref(lb), C.byref(it))
+        return e.value, te.value, lb.value, it.value
 
     def simultaneous(self, proposals, maxiter=1000, max_relgap=0.0):
         """proposals: list of 4 x N plane arrays (the current assignment is appended on the device).

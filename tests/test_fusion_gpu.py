@@ -115,3 +115,41 @@ def test_context_simultaneous_equals_stateless(kernel, hip):
     # a binary move after it still works on the resident state
     dm.binary_fusion(props[0])
     assert np.isfinite(dm.energy())
+
+
+def test_proposals_built_on_the_device(hip, oracle):
+    """plane-table proposals (one plane for all pixels / one per segment) built in HBM give
+    the very move the 4 x N array gives; the device plane fit (dispmap_ncc.m:48-92) agrees with the
+    NumPy mirror of the reference's IRLS / SVD to rounding."""
+    import os
+    from stereo_amd import PlaneProposal
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "teddy_crop.npz"))
+    im0, im1 = g["im0"].astype(np.float64), g["im1"].astype(np.float64)
+    H, W = im0.shape[:2]
+    N = H * W
+    for kernel in (1, 2):
+        a = hip.dispmap_ncc([im0, im1], np.arange(0, 24.0), kernel, 40.0, 8.0)
+        b = hip.dispmap_ncc([im0, im1], np.arange(0, 24.0), kernel, 40.0, 8.0)
+        # device plane fits against the host mirror
+        for (x, y) in ((10, 10), (40, 30), (90, 60), (3, 2)):
+            host = a.generate_new_plane_RANSAC(x, y, 5)
+            dev = a.generate_new_plane_RANSAC(x, y, 5, on_device=True)
+            assert isinstance(dev, PlaneProposal)
+            assert np.allclose(dev.planes[:, 0], host[:, 0], rtol=1e-6, atol=1e-6), (kernel, x, y, dev.planes[:, 0], host[:, 0])
+        # the same sequence of moves from plane tables and from 4 x N arrays
+        seg = ((np.arange(H)[:, None] // 20) * 8 + (np.arange(W)[None, :] // 30)).T.reshape(-1)
+        rng = np.random.default_rng(kernel)
+        S = int(seg.max()) + 1
+        props = [PlaneProposal([0.0, 0.0, 1.0, -7.0]), PlaneProposal([0.03, -0.02, 1.0, -12.0]),
+                 PlaneProposal(np.stack([rng.normal(0, 0.05, S), rng.normal(0, 0.05, S), np.ones(S), -rng.uniform(0, 23, S)]), seg)]
+        for P in props:
+            ra = a.binary_fusion(P)
+            rb = b.binary_fusion(P.expand(N))
+            assert ra == rb and a.energy() == b.energy()
+            assert np.array_equal(a.assignment, b.assignment)
+        a.restart(); b.restart()
+        a.maxiter = b.maxiter = 8
+        single = props[:2] + [PlaneProposal([0.0, 0.0, 1.0, -15.0])]
+        ra = a.simultaneous_fusion(single)
+        rb = b.simultaneous_fusion([P.expand(N) for P in single])
+        assert ra == rb and np.array_equal(a.assignment, b.assignment)
