@@ -97,7 +97,8 @@ __device__ __forceinline__ bool grid_sync(int32_t *ctl, unsigned &gen) {
 }
 
 __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *ctl, int relabel_every, int max_rounds,
-                                                            int tiled, int switch_at, int incremental) {
+                                                            int tiled, int switch_at, int incremental, int first_interval,
+                                                            int adaptive) {
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // tile state of the tiled rounds
   __shared__ int s_red;
   __shared__ int s_h[kMB];
@@ -209,9 +210,15 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
 
   int active = 0;
   if (!global_relabel(active)) return;
-  int rounds = 0, since_relabel = 0, interval = relabel_every < 8 ? relabel_every : 8, stagnant = 0, last_active = active;
+  int rounds = 0, since_relabel = 0, interval = relabel_every < first_interval ? relabel_every : first_interval, stagnant = 0, last_active = active;
 
-  while (active > 0 && rounds < max_rounds && (tiled <= 0 || rounds < switch_at)) {
+  // When to leave the plain rounds for the tiled ones: at round `switch_at` at the latest, and earlier if
+  // the excess left over by an exact relabelling drains slowly -- two rounds after the relabelling more
+  // than 70 % of it is still there (real NCC fusion moves: 1748 -> 1463, a long tail the tiled rounds
+  // cut short; noisy synthetic terms: 322 -> 65, done within a dozen plain rounds).
+  int after_relabel = -1;
+  bool slow_tail = false;
+  while (active > 0 && rounds < max_rounds && (tiled <= 0 || (rounds < switch_at && !slow_tail))) {
     // ---- push (old heights; a pair of arcs is only modified by the endpoint that is higher)
     for (int v = first; v < n; v += stride) {
       double e = g.ex[v];
@@ -324,9 +331,11 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     // end the solve after a handful of rounds, so the interval starts small and doubles.
     stagnant = active >= last_active ? stagnant + 1 : 0;  // no progress: what is left is probably cut off
     last_active = active;
+    if (adaptive && after_relabel > 0 && since_relabel == 2 && (long long)active * 10 > (long long)after_relabel * 7) slow_tail = true;
     if (active > 0 && (since_relabel >= interval || (stagnant >= 2 && since_relabel >= 4))) {
       if (!global_relabel(active)) return;
       since_relabel = 0; stagnant = 0; last_active = active;
+      after_relabel = active;
       interval = interval * 2 < relabel_every ? interval * 2 : relabel_every;
     }
   }
@@ -912,7 +921,11 @@ struct QpboSolver {
     if (const char *e = std::getenv("STEREO_HIP_QPBO_SWITCH")) switch_at = std::max(0, std::atoi(e));
     int incremental = warm ? 1 : 0;
     if (const char *e = std::getenv("STEREO_HIP_QPBO_WARM")) incremental = incremental && std::atoi(e) != 0;
-    void *args[] = {&gg, &ctl, &relabel_every, &max_rounds, &tiled, &switch_at, &incremental};
+    int first_interval = 4;  // first relabelling after four rounds: by then the excess that is cut off from the sink just climbs
+    if (const char *e = std::getenv("STEREO_HIP_QPBO_FIRST_INTERVAL")) first_interval = std::max(1, std::atoi(e));
+    int adaptive = 1;
+    if (const char *e = std::getenv("STEREO_HIP_QPBO_ADAPTIVE")) adaptive = std::atoi(e) != 0;
+    void *args[] = {&gg, &ctl, &relabel_every, &max_rounds, &tiled, &switch_at, &incremental, &first_interval, &adaptive};
     STEREO_HIP_CHECK(hipLaunchCooperativeKernel((const void *)qpbo_maxflow_kernel, dim3(blocks), dim3(kMB), args, dyn, 0));
     int32_t host_ctl[QpboCtl::kWords];
     STEREO_HIP_CHECK(hipMemcpy(host_ctl, d_ctl.p, sizeof(host_ctl), hipMemcpyDeviceToHost));
