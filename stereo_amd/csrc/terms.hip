@@ -244,27 +244,31 @@ __device__ __forceinline__ void ncc_load(const NccFast &p, int64_t Npx, int row_
 
 // Statistics of the shifted image where the 5 x 5 window leaves the image on the right: its columns
 // >= W are zero for imtr but not for im1, so the pre-pass planes do not apply (last two columns only).
-__device__ __forceinline__ void ncc_right_border(const NccFast &p, int64_t Npx, int row, int c, int d,
-                                                           double &bT0, double &bT1, double &bT2, double &meanT,
-                                                           double &nT) {
-  const int H = p.H, W = p.W;
+// Out of line (arguments and result by value, in registers): inlined, its 75 unrolled taps cost the
+// column walk a hundred VGPRs and half of its occupancy.
+struct NccStat { double b0, b1, b2, mean, nrm; };
+__device__ __attribute__((noinline)) NccStat ncc_right_border(const double *im1, int H, int W, int64_t Npx, int row, int c, int d) {
   double b0 = 0, b1 = 0, b2 = 0, q0 = 0, q1 = 0, q2 = 0;
+#pragma unroll 1
   for (int dx = -2; dx <= 2; ++dx)
+#pragma unroll 1
     for (int dy = -2; dy <= 2; ++dy) {
       const int rr = row + dy, cc = c + dx;
       const bool in = !(rr < 0 || rr >= H || cc < 0 || cc >= W || cc - d < 0);
       const size_t a = in ? (size_t)(cc - d) * H + rr : 0;
-      const double v0 = in ? p.im1[a] : 0.0, v1 = in ? p.im1[Npx + a] : 0.0, v2 = in ? p.im1[2 * Npx + a] : 0.0;
+      const double v0 = in ? im1[a] : 0.0, v1 = in ? im1[Npx + a] : 0.0, v2 = in ? im1[2 * Npx + a] : 0.0;
       b0 += v0; q0 += v0 * v0; b1 += v1; q1 += v1 * v1; b2 += v2; q2 += v2 * v2;
     }
   const double mscale = 1.0 / 25.0 / 3.0;
-  bT0 = b0; bT1 = b1; bT2 = b2;
-  meanT = (b0 * mscale + b1 * mscale) + b2 * mscale;
+  NccStat o;
+  o.b0 = b0; o.b1 = b1; o.b2 = b2;
+  o.mean = (b0 * mscale + b1 * mscale) + b2 * mscale;
   const double u1 = (q0 + q1) + q2;
-  const double u2 = (meanT * b0 + meanT * b1) + meanT * b2;
-  const double varT = u1 - 2 * u2 + 75.0 * meanT * meanT;
+  const double u2 = (o.mean * b0 + o.mean * b1) + o.mean * b2;
+  const double varT = u1 - 2 * u2 + 75.0 * o.mean * o.mean;
   const double nn = sqrt(fabs(varT));
-  nT = varT < 0 ? -nn : nn;
+  o.nrm = varT < 0 ? -nn : nn;
+  return o;
 }
 
 // value of the lane above (UP) / below in the wave of 64; the lane that falls off the end reads 0
@@ -302,6 +306,7 @@ __global__ __launch_bounds__(kNccWaves * 64, 2) void ncc_cross_kernel(NccFast p)
   ncc_load(p, Npx, row_c, c_begin - 2, d, cur); P2 = product(c_begin, cur);
   ncc_load(p, Npx, row_c, c_begin - 1, d, cur); P3 = product(c_begin + 1, cur);
   ncc_load(p, Npx, row_c, c_begin, d, cur);
+#pragma unroll 1
   for (int c = c_begin; c < c_end; ++c) {
     ncc_load(p, Npx, row_c, c + 1, d, nxt);  // the next step's loads travel while this one computes
     const double P4 = product(c + 2, cur);
@@ -313,7 +318,10 @@ __global__ __launch_bounds__(kNccWaves * 64, 2) void ncc_cross_kernel(NccFast p)
     double val = 0.0;
     const bool live = outlane && dvalid && c >= d;  // columns left of round(d + 1) are masked (dispmap_ncc.m:190-191)
     double bT0 = cur.bT0, bT1 = cur.bT1, bT2 = cur.bT2, meanT = cur.meanT, nT = cur.nT;
-    if (c + 2 >= W && live) ncc_right_border(p, Npx, row, c, d, bT0, bT1, bT2, meanT, nT);
+    if (c + 2 >= W && live) {
+      const NccStat o = ncc_right_border(p.im1, H, W, Npx, row, c, d);
+      bT0 = o.b0; bT1 = o.b1; bT2 = o.b2; meanT = o.mean; nT = o.nrm;
+    }
     {
       const double c2 = (cur.meanL * bT0 + cur.meanL * bT1) + cur.meanL * bT2;
       const double c3 = (meanT * cur.bL0 + meanT * cur.bL1) + meanT * cur.bL2;
