@@ -84,7 +84,7 @@ def algorithmic_bytes_per_sweep_pair(info_deg, K):
     return float(fwd.sum() + bwd.sum())
 
 
-def scale_leg(args, rank, local_rank, world, dist, dev):
+def scale_leg(args, rank, local_rank, world, dist, dev, index_order=False):
     """Strong scaling of ONE large image (BASELINE.json configs[3]: synthetic 3000 x 2000 x 256-label
     volume) over the `world` GPUs: rank g owns band g of the rows (stereo_amd.strips), boundary
     messages / flags / labels go to the neighbour GPU as peer stores over xGMI, energy and bound are
@@ -104,11 +104,12 @@ def scale_leg(args, rank, local_rank, world, dist, dev):
     d_alpha = torch.ones(E, dtype=torch.float64, device=dev)
     d_pos = torch.arange(K, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
+    mode = 0x100 if index_order else 0   # STEREO_TRWS_ORDER_INDEX: labelled extra, not the gateway's node order
     if world == 1:
-        solver = TrwsPlan(1, K, N, conn.T)
+        solver = TrwsPlan(1, K, N, conn.T, message_mode=mode)
         plan = solver
     else:
-        solver = TrwsStripRank(1, K, H, W, conn.T, rank, world, dist, dev)
+        solver = TrwsStripRank(1, K, H, W, conn.T, rank, world, dist, dev, message_mode=mode)
         plan = solver.plan
     solver.bind_device(d_unary.data_ptr(), d_alpha.data_ptr(), 8.0, d_positions=d_pos.data_ptr(),
                        keepalive=(d_unary, d_alpha, d_pos))
@@ -381,6 +382,16 @@ def main():
             scale = scale_leg(args, rank, local_rank, world, dist, dev)
         except Exception as exc:  # the headline line must not depend on the scaling leg
             scale = {"error": "%s: %s" % (type(exc).__name__, exc), "n_gpus": world}
+        try:   # the same image and strips with the nodes in index order (no serial border chain): labelled extra
+            torch.cuda.empty_cache()
+            alt_scale = scale_leg(args, rank, local_rank, world, dist, dev, index_order=True)
+            if rank == 0 and scale is not None and alt_scale is not None:
+                scale["index_order_option"] = {k: alt_scale[k] for k in ("value", "unit", "ms_per_iteration", "hbm_frac_per_gpu",
+                                                                         "energy", "lower_bound")}
+                scale["index_order_option"]["note"] = "STEREO_TRWS_ORDER_INDEX: not the gateway's node order / labels"
+        except Exception as exc:
+            if rank == 0 and scale is not None:
+                scale["index_order_option"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     if rank == 0:
         if scale is not None:
             out["scale"] = scale

@@ -155,3 +155,21 @@ def test_two_processes_hand_over_through_ipc(shape, hip):
            "127.0.0.1", "--master-port", "29533", os.path.join(root, "tools", "strips_ipc_check.py")] + [str(v) for v in shape]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "IPC_STRIPS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("G", [2, 3])
+def test_strips_with_the_index_order_option(G, hip, oracle):
+    """Row strips under STEREO_TRWS_ORDER_INDEX (runs are columns there, every one of them crosses
+    every strip boundary): same labels as the oracle run in that order."""
+    from stereo_amd.strips import make_strips
+    from stereo_amd.trws import ORDER_INDEX
+    H, W, K = 21, 17, 10
+    p = trws_problem(120, H, W, K, kind="general")
+    lab_o, en_o, lb_o, _ = oracle.trws(1, p["unary"], p["conn"], p["q"], p["qprim"], p["alphas"], 2.5, 4, -1e300,
+                                       mode=1, ordering=1)
+    s = make_strips(1, K, H, W, p["conn"].T, G, message_mode=ORDER_INDEX)
+    s.upload(p["unary"].T, p["alphas"], 2.5, q=p["q"].T, qprim=p["qprim"].T)
+    s.iterate(4, max_relgap=-1e300)
+    lab, en, lb, _ = s.result()
+    s.close()
+    assert np.array_equal(lab, lab_o) and _close(en, en_o) and _close(lb, lb_o)
