@@ -40,9 +40,11 @@ def synthetic_volume(H, W, K, seed):
     return np.ascontiguousarray(cost.transpose(1, 0, 2).reshape(H * W, K))  # node id = col*H + row
 
 
-def synthetic_volume_device(H, W, K, seed, dev):
+def synthetic_volume_device(H, W, K, seed, dev, nodes=None):
     """The same construction on the device (torch RNG), for volumes too large to build on the host
-    in reasonable time (3000 x 2000 x 256: 12 GB)."""
+    in reasonable time (3000 x 2000 x 256: 12 GB).  nodes (device int64 tensor): keep only the rows
+    of these nodes, in this order -- a strip's share of the SAME volume (the random stream is
+    drawn chunk by chunk for all nodes, so every rank sees the values a single GPU would)."""
     import torch
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
@@ -51,13 +53,18 @@ def synthetic_volume_device(H, W, K, seed, dev):
     truth = (0.25 * K + 0.5 * K * (cols / W) + 0.1 * K * torch.sin(rows / 37.0)).clamp(0, K - 1)
     mask = ((torch.div(rows, 60, rounding_mode="floor") + torch.div(cols, 75, rounding_mode="floor")) % 2) == 0
     truth = torch.where(mask, truth * 0.6, truth).reshape(H * W, 1)  # node id = col*H + row
-    out = torch.empty(H * W, K, dtype=torch.float64, device=dev)
+    out = torch.empty(H * W if nodes is None else nodes.numel(), K, dtype=torch.float64, device=dev)
     lab = torch.arange(K, device=dev, dtype=torch.float64)[None, :]
     step = max(1, (1 << 26) // K)
     for a in range(0, H * W, step):
         b = min(H * W, a + step)
-        out[a:b] = torch.clamp((lab - truth[a:b]).abs() / 4.0, max=1.0) * 30.0
-        out[a:b] += torch.rand(b - a, K, generator=g, device=dev, dtype=torch.float64) * 10.0
+        chunk = torch.clamp((lab - truth[a:b]).abs() / 4.0, max=1.0) * 30.0
+        chunk += torch.rand(b - a, K, generator=g, device=dev, dtype=torch.float64) * 10.0
+        if nodes is None:
+            out[a:b] = chunk
+        else:
+            here = (nodes >= a) & (nodes < b)
+            out[here] = chunk[nodes[here] - a]
     return out
 
 
@@ -100,19 +107,30 @@ def scale_leg(args, rank, local_rank, world, dist, dev, index_order=False):
     t_setup = time.perf_counter()
     conn = grid_conn(H, W)
     E = conn.shape[0]
-    d_unary = synthetic_volume_device(H, W, K, 1, dev)   # the same volume on every rank (same seed)
-    d_alpha = torch.ones(E, dtype=torch.float64, device=dev)
     d_pos = torch.arange(K, dtype=torch.float64, device=dev)
-    torch.cuda.synchronize()
     mode = 0x100 if index_order else 0   # STEREO_TRWS_ORDER_INDEX: labelled extra, not the gateway's node order
     if world == 1:
         solver = TrwsPlan(1, K, N, conn.T, message_mode=mode)
         plan = solver
+        d_unary = synthetic_volume_device(H, W, K, 1, dev)
+        d_alpha = torch.ones(E, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        solver.bind_device(d_unary.data_ptr(), d_alpha.data_ptr(), 8.0, d_positions=d_pos.data_ptr(),
+                           keepalive=(d_unary, d_alpha, d_pos))
+        stored = (N, E)
     else:
-        solver = TrwsStripRank(1, K, H, W, conn.T, rank, world, dist, dev, message_mode=mode)
+        # a rank stores its band only: the rows of its own nodes + one halo row per neighbour and the
+        # messages of the edges at its own nodes (strip-local ids, stereo_trws_plan_strip_layout)
+        solver = TrwsStripRank(1, K, H, W, conn.T, rank, world, dist, dev, message_mode=mode,
+                               max_workgroups=(256 // world if args.one_gpu else 0))
         plan = solver.plan
-    solver.bind_device(d_unary.data_ptr(), d_alpha.data_ptr(), 8.0, d_positions=d_pos.data_ptr(),
-                       keepalive=(d_unary, d_alpha, d_pos))
+        nodes, n_own, edges = plan.layout()
+        d_unary = synthetic_volume_device(H, W, K, 1, dev, nodes=torch.from_numpy(nodes.astype(np.int64)).to(dev))
+        d_alpha = torch.ones(len(edges), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        plan.bind_device_strip(d_unary.data_ptr(), d_alpha.data_ptr(), 8.0, d_positions=d_pos.data_ptr(),
+                               keepalive=(d_unary, d_alpha, d_pos))
+        stored = (len(nodes), len(edges))
     plan.stats(reset=True)
     setup_s = time.perf_counter() - t_setup
     NEVER = -1e300
@@ -153,6 +171,8 @@ def scale_leg(args, rank, local_rank, world, dist, dev, index_order=False):
             "serial_envelope_messages": serial, "energy": energy, "lower_bound": lb, "label_sum": crc,
             "transport": "none (one GPU)" if world == 1 else "peer stores over xGMI into HIP-IPC-mapped neighbour arrays + flag; "
                          "RCCL all_gather of 2 doubles per iteration",
+            "stored_per_gpu": {"nodes": int(stored[0]), "edges": int(stored[1]),
+                               "unary_and_message_bytes": int((stored[0] + stored[1]) * K * 8)},
             "setup_s": setup_s}
 
 
@@ -179,7 +199,14 @@ def main():
 
     import torch
     from stereo_amd import dist as D
-    rank, local_rank, world, dist = D.init("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    # STEREO_BENCH_ONE_GPU=1: development aid for boxes with a single GPU -- all ranks share GPU 0
+    # (rendezvous over gloo; the strips' workgroups split the CUs) so that the N > 1 code path, IPC
+    # hand-over included, can be run end to end.  Not a measurement.
+    one_gpu = bool(os.environ.get("STEREO_BENCH_ONE_GPU"))
+    rank, local_rank, world, dist = D.init(("gloo" if one_gpu else "nccl") if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    if one_gpu:
+        local_rank = 0
+    args.one_gpu = one_gpu
     torch.cuda.set_device(local_rank)
 
     import stereo_amd

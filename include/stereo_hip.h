@@ -155,12 +155,17 @@ int stereo_trws_plan_path(stereo_trws_plan *plan);
  * sharded is exactly that sweep under the order of ordering.cpp:42-152, and the labels are the
  * ones a single plan returns, bit for bit.  `owner[i]` names the strip that visits node i; strips
  * form a chain (an edge joins nodes of one strip or of strips g, g+1) -- for an image, bands of
- * rows.  One plan per strip, normally one process and one GPU each; every strip keeps the index
- * space of the whole problem (same array offsets everywhere) but only touches its own nodes, the
- * edges at them and the boundary row of each neighbour.  A boundary node's new messages, its
- * completion flag and its label are written by the visiting workgroup straight into the
- * neighbouring strip's arrays (peer stores over xGMI + flag; nothing is staged through the host
- * and there is no collective on the data path).  Energy and lower bound come back as per-strip
+ * rows.  One plan per strip, normally one process and one GPU each.  A strip stores only what
+ * it touches -- its own nodes, the nodes one edge away (halo) and the edges with an own endpoint,
+ * under strip-local ids -- so the messages and unaries of a large problem are divided among the
+ * GPUs (1/G each plus a boundary row).  A boundary node's new messages, its completion flag and
+ * its label are written by the visiting workgroup straight into the neighbouring strip's arrays,
+ * at the neighbour's ids (peer stores over xGMI + flag; nothing is staged through the host and
+ * there is no collective on the data path).  stereo_trws_plan_upload / _bind_device still take
+ * the arrays of the WHOLE problem and keep the strip's rows (a gather into arrays owned by the
+ * plan, so the full ones may be freed afterwards); stereo_trws_plan_bind_device_strip takes
+ * arrays that are strip-local already, in the order stereo_trws_plan_strip_layout reports.
+ * stereo_trws_plan_result fills the labels of the strip's nodes (1 elsewhere).  Energy and lower bound come back as per-strip
  * partial sums (each in the reference's summation order restricted to the strip); the caller adds
  * them in strip order -- the only cross-strip reduction, two doubles per iteration -- so they
  * agree with the single-plan values to rounding (1e-12 relative), not bit for bit.
@@ -201,6 +206,18 @@ int stereo_trws_plan_collect(stereo_trws_plan *plan, double *lower_bound_part, d
                              char *err, size_t errcap);
 int stereo_trws_plan_commit(stereo_trws_plan *plan, double lower_bound, double energy, char *err,
                             size_t errcap);
+/* What a strip stores.  nodes (n_nodes entries): global id of local node i -- the n_own own nodes
+ * in ascending order, then the halo; edges (n_edges): global id of local edge e, ascending.  Any
+ * output may be NULL (ask for the counts first).  A plan of the whole problem reports identity. */
+int stereo_trws_plan_strip_layout(stereo_trws_plan *plan, int64_t *n_nodes, int64_t *n_own,
+                                  int64_t *n_edges, int32_t *nodes, int32_t *edges);
+/* stereo_trws_plan_bind_device with strip-local arrays: d_unary K x n_nodes, d_alphas n_edges,
+ * d_q / d_qprim K x n_edges (or shared d_positions), rows in the order of strip_layout.  The
+ * arrays stay the caller's. */
+int stereo_trws_plan_bind_device_strip(stereo_trws_plan *plan, const double *d_unary,
+                                       const double *d_q, const double *d_qprim,
+                                       const double *d_positions, const double *d_alphas,
+                                       double tol, char *err, size_t errcap);
 /* Diagnostics (any output may be NULL). */
 int stereo_trws_plan_strip_info(stereo_trws_plan *plan, int *nstrips, int *strip, int64_t *own_nodes,
                                 int64_t *runs_forward, int64_t *runs_backward, int *needs_previous,

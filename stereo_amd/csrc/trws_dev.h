@@ -522,6 +522,7 @@ constexpr int kSpinLimit = 1 << 22;  // polls before a launch gives up (bounded 
 struct NodeDesc {
   int node, rank, nout, nin, ndep, md, lbn, urgent, remote, epos;
   int e[8], slot[8], dep[4], lbe[8], xn[8];
+  int re[8], pn[2];  // strips: edge / node ids in the neighbouring strip's numbering (only the storers read them)
 };
 #define RLI(v, i) __builtin_amdgcn_readlane((v), (i))
 __device__ __forceinline__ NodeDesc decode_desc(int w) {
@@ -541,6 +542,9 @@ __device__ __forceinline__ NodeDesc decode_desc(int w) {
   d.xn[4] = RLI(w, 36); d.xn[5] = RLI(w, 37); d.xn[6] = RLI(w, 38); d.xn[7] = RLI(w, 39);
   d.urgent = RLI(w, 40);
   d.remote = RLI(w, kDescRemote); d.epos = RLI(w, kDescEpos);
+  d.re[0] = RLI(w, 45); d.re[1] = RLI(w, 46); d.re[2] = RLI(w, 47); d.re[3] = RLI(w, 48);
+  d.re[4] = RLI(w, 49); d.re[5] = RLI(w, 50); d.re[6] = RLI(w, 51); d.re[7] = RLI(w, 52);
+  d.pn[0] = RLI(w, 53); d.pn[1] = RLI(w, 54);
   return d;
 }
 

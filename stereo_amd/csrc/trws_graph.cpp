@@ -507,6 +507,75 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
   return true;
 }
 
+
+namespace {
+// local ids of strip s: node_l / edge_l are -1 where the strip holds nothing
+void strip_ids(const TrwsGraph &g, int s, std::vector<int32_t> &node_l, std::vector<int32_t> &edge_l,
+               std::vector<int32_t> *nodes, std::vector<int32_t> *edges, int64_t *n_own) {
+  const int64_t N = (int64_t)g.owner.size(), E = (int64_t)g.tail.size();
+  node_l.assign(N, -1); edge_l.assign(E, -1);
+  std::vector<uint8_t> halo(N, 0);
+  int32_t el = 0;
+  for (int64_t e = 0; e < E; ++e) {
+    const bool a = g.owner[g.tail[e]] == s, b = g.owner[g.head[e]] == s;
+    if (!a && !b) continue;
+    edge_l[e] = el++;
+    if (edges) edges->push_back((int32_t)e);
+    if (!a) halo[g.tail[e]] = 1;
+    if (!b) halo[g.head[e]] = 1;
+  }
+  int32_t nl = 0;
+  for (int64_t i = 0; i < N; ++i)
+    if (g.owner[i] == s) { node_l[i] = nl++; if (nodes) nodes->push_back((int32_t)i); }
+  if (n_own) *n_own = nl;
+  for (int64_t i = 0; i < N; ++i)
+    if (halo[i]) { node_l[i] = nl++; if (nodes) nodes->push_back((int32_t)i); }
+}
+}  // namespace
+
+bool build_strip_layout(const TrwsGraph &g, int strip, StripLayout &out, std::string &err) {
+  constexpr int W = TrwsGraph::kDescWords;
+  out = StripLayout();
+  std::vector<int32_t> node_l, edge_l, node_p[2], edge_p[2];
+  strip_ids(g, strip, node_l, edge_l, &out.nodes, &out.edges, &out.n_own);
+  if (strip > 0) strip_ids(g, strip - 1, node_p[0], edge_p[0], nullptr, nullptr, nullptr);
+  if (strip + 1 < g.nstrips) strip_ids(g, strip + 1, node_p[1], edge_p[1], nullptr, nullptr, nullptr);
+  bool sound = true;
+  for (int d = 0; d < 2; ++d) {
+    const TrwsGraph::Sweep &S = g.sweep[d];
+    const int64_t R = (int64_t)S.chain_run_ptr.size() - 1;
+    out.run_ptr[d].assign(1, 0);
+    for (int64_t t = 0; t < R; ++t) {
+      const int32_t run = S.chain_run_order.empty() ? (int32_t)t : S.chain_run_order[t];
+      if (S.chain_run_strip[run] != strip) continue;
+      for (int64_t q = S.chain_run_ptr[run]; q < S.chain_run_ptr[run + 1]; ++q) {
+        const int32_t *G = &S.desc[(size_t)q * W];
+        const size_t at = out.desc[d].size();
+        out.desc[d].insert(out.desc[d].end(), G, G + W);
+        int32_t *D = &out.desc[d][at];
+        const int nout = G[2] & 15, nin = (G[2] >> 4) & 15, nd = (G[2] >> 8) & 15;
+        const uint32_t rem = (uint32_t)G[kDescRemote];
+        D[0] = node_l[G[0]];
+        D[1] = D[0];  // the flag of a node sits at its local node id
+        for (int k = 0; k < 8; ++k) {
+          if (k < nout + nin) D[4 + k] = edge_l[G[4 + k]];
+          if (k >= nout && k < nout + nin) D[32 + k] = node_l[G[32 + k]];
+          if (k < nout && ((rem >> k) & 1)) D[kDescPeerEdge + k] = edge_p[(rem >> (8 + k)) & 1][G[4 + k]];
+        }
+        for (int k = 0; k < nd && k < 4; ++k) D[20 + k] = node_l[g.order[G[20 + k]]];
+        if (rem & (1u << 16)) { D[kDescPeerNode] = node_p[0][G[0]]; out.need_peer[0] = true; }
+        if (rem & (1u << 17)) { D[kDescPeerNode + 1] = node_p[1][G[0]]; out.need_peer[1] = true; }
+        for (int k = 0; k < 64; ++k)
+          if ((k <= 1 || (k >= 4 && k < 4 + nout + nin) || (k >= 20 && k < 20 + nd) || (k >= 32 + nout && k < 32 + nout + nin) ||
+               k >= kDescPeerEdge) && D[k] < 0) sound = false;
+      }
+      out.run_ptr[d].push_back((int32_t)(out.desc[d].size() / W));
+    }
+  }
+  if (!sound) err = "stereo_trws: a strip refers to a node or edge outside its halo (strips must be consecutive in the visiting order)";
+  return sound;
+}
+
 }  // namespace stereo
 
 extern "C" int stereo_trws_analyze(int64_t N, int64_t E, const uint32_t *conn, int64_t *rank,

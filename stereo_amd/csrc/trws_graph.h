@@ -103,5 +103,24 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
 //            previous / next strip's memory
 //   word 44: TrwsGraph::e_pos of the node
 constexpr int kDescRemote = 43, kDescEpos = 44;
+//   words 45-52: with strip-local storage, the id of outgoing edge k in the neighbouring strip's
+//            numbering (valid where bit k of word 43 is set)
+//   words 53, 54: the node's id in the previous / next strip's numbering (bits 16 / 17 of word 43)
+constexpr int kDescPeerEdge = 45, kDescPeerNode = 53;
+
+// Strip-local storage.  A strip keeps arrays only for what it touches: its own nodes, the nodes
+// one edge away (whose flags it waits on and whose labels its primal pass reads), and the edges
+// with an own endpoint.  Local ids: own nodes in ascending global id, then the halo nodes in
+// ascending global id; edges in ascending global id.  A flag is indexed by the local NODE id.
+// The descriptors of the strip's own visits are renumbered accordingly and laid out run after
+// run in ticket order, so the kernels see an ordinary single-strip problem of the local size
+// plus the peer ids of words 45-54.
+struct StripLayout {
+  int64_t n_own = 0;
+  std::vector<int32_t> nodes, edges;  // local id -> global id
+  std::vector<int32_t> desc[2], run_ptr[2];
+  bool need_peer[2] = {false, false};
+};
+bool build_strip_layout(const TrwsGraph &g, int strip, StripLayout &out, std::string &err);
 
 }  // namespace stereo

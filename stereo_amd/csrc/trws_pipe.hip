@@ -204,7 +204,8 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
             for (int j = 0; j < 8; ++j) {
               if (j < pd.nout) {
                 double *mb = ((pd.remote >> j) & 1) ? (((pd.remote >> (8 + j)) & 1) ? p.peer_msg1 : p.peer_msg0) : p.msg;
-                if (act) st_sc1(mb + (size_t)pd.e[j] * K + lane, hprev[j * kWave + lane]);
+                const int ej = ((pd.remote >> j) & 1) ? pd.re[j] : pd.e[j];  // the neighbour numbers the edge itself
+                if (act) st_sc1(mb + (size_t)ej * K + lane, hprev[j * kWave + lane]);
                 if (BACKWARD && lane == 0) p.lbterms[pd.lbe[j]] = scp[j];
               }
             }
@@ -213,15 +214,15 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           if (PRIMAL && lane == 0) {
             const int xi = ((const int *)(scp + 10))[0];
             st_sc1(p.x + pd.node, xi);
-            if (pd.remote & (1 << 16)) st_sc1(p.peer_x0 + pd.node, xi);
-            if (pd.remote & (1 << 17)) st_sc1(p.peer_x1 + pd.node, xi);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_x0 + pd.pn[0], xi);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_x1 + pd.pn[1], xi);
             p.eterms[pd.epos] = scp[9];
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0) {
             st_sc1(p.done + pd.rank, epoch);
-            if (pd.remote & (1 << 16)) st_sc1(p.peer_done0 + pd.rank, epoch);
-            if (pd.remote & (1 << 17)) st_sc1(p.peer_done1 + pd.rank, epoch);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_done0 + pd.pn[0], epoch);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_done1 + pd.pn[1], epoch);
           }
         }
       } else if (wave == kPipeCompute + 3) {

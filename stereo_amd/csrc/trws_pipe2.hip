@@ -318,9 +318,10 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, i
             for (int j = 0; j < 8; ++j) {
               if (j < pd.nout) {
                 double *mb = ((pd.remote >> j) & 1) ? (((pd.remote >> (8 + j)) & 1) ? p.peer_msg1 : p.peer_msg0) : p.msg;
+                const int ej = ((pd.remote >> j) & 1) ? pd.re[j] : pd.e[j];  // the neighbour numbers the edge itself
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
-                  if (act[c]) st_sc1(mb + (size_t)pd.e[j] * K + kk[c], hprev[j * k2W + kk[c]]);
+                  if (act[c]) st_sc1(mb + (size_t)ej * K + kk[c], hprev[j * k2W + kk[c]]);
                 if (BACKWARD && lane == 0) p.lbterms[pd.lbe[j]] = scp[j];
               }
             }
@@ -329,15 +330,15 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, i
           if (PRIMAL && lane == 0) {
             const int xi = ((const int *)(scp + 10))[0];
             st_sc1(p.x + pd.node, xi);
-            if (pd.remote & (1 << 16)) st_sc1(p.peer_x0 + pd.node, xi);
-            if (pd.remote & (1 << 17)) st_sc1(p.peer_x1 + pd.node, xi);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_x0 + pd.pn[0], xi);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_x1 + pd.pn[1], xi);
             p.eterms[pd.epos] = scp[9];
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0) {
             st_sc1(p.done + pd.rank, epoch);
-            if (pd.remote & (1 << 16)) st_sc1(p.peer_done0 + pd.rank, epoch);
-            if (pd.remote & (1 << 17)) st_sc1(p.peer_done1 + pd.rank, epoch);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_done0 + pd.pn[0], epoch);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_done1 + pd.pn[1], epoch);
           }
         }
       } else if (wave == kPipeCompute + 3) {

@@ -206,6 +206,11 @@ struct stereo_trws_plan {
   DevBuf<int32_t> d_tickets[2];
   int ntickets[2] = {0, 0};
   int64_t n_lb = 0, n_en = 0;  // lower-bound / energy terms this plan writes (strip-local with strips)
+  // what the arrays on the device are sized for: the whole problem, or with strips the strip's own
+  // nodes + halo and the edges with an own endpoint (StripLayout, trws_graph.h)
+  int64_t Nl = 0, El = 0;
+  std::unique_ptr<StripLayout> layout;
+  DevBuf<int64_t> d_lnodes, d_ledges;  // local -> global ids, for gathering the strip's inputs
   double *peer_msg[2] = {nullptr, nullptr};
   int32_t *peer_done[2] = {nullptr, nullptr}, *peer_x[2] = {nullptr, nullptr};
   bool need_peer[2] = {false, false};
@@ -256,13 +261,15 @@ DevParams make_params(stereo_trws_plan *P) {
     p.in_slot[d] = P->d_in_slot[d].p;
   }
   for (int d = 0; d < 2; ++d) {
-    p.ntickets[d] = P->nstrips > 1 ? P->ntickets[d] : p.nruns[d];
-    if (P->nstrips > 1) p.run_order[d] = P->d_tickets[d].p;
+    if (P->nstrips > 1) {  // the strip's own runs, already in ticket order
+      p.run_ptr[d] = P->d_chain_run_ptr[d].p; p.nruns[d] = P->ntickets[d]; p.run_order[d] = nullptr;
+    }
+    p.ntickets[d] = p.nruns[d];
   }
   p.peer_msg0 = P->peer_msg[0]; p.peer_msg1 = P->peer_msg[1];
   p.peer_done0 = P->peer_done[0]; p.peer_done1 = P->peer_done[1];
   p.peer_x0 = P->peer_x[0]; p.peer_x1 = P->peer_x[1];
-  p.done = P->d_done.p; p.ticket = P->d_ctl.p; p.abort_flag = P->d_ctl.p + 1; p.N = (int)P->N;
+  p.done = P->d_done.p; p.ticket = P->d_ctl.p; p.abort_flag = P->d_ctl.p + 1; p.N = (int)P->Nl;
   p.fallbacks = P->d_fallbacks.p; p.certificate = P->certificate ? 1 : 0;
   p.prof = P->d_prof.p;
   p.timeline = P->d_timeline.p;
@@ -319,9 +326,9 @@ void run_argsort(const double *vals, uint16_t *perm, int K, int64_t count, hipSt
 
 // Zero messages (MRFEnergy.cpp:115-133), labels, flags and every piece of iteration state.
 void reset_state(stereo_trws_plan *P) {
-  STEREO_HIP_CHECK(hipMemset(P->d_msg.p, 0, sizeof(double) * (size_t)P->E * P->K));
-  STEREO_HIP_CHECK(hipMemset(P->d_x.p, 0, sizeof(int32_t) * P->N));
-  STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * P->N));
+  STEREO_HIP_CHECK(hipMemset(P->d_msg.p, 0, sizeof(double) * (size_t)P->El * P->K));
+  STEREO_HIP_CHECK(hipMemset(P->d_x.p, 0, sizeof(int32_t) * P->Nl));
+  STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * P->Nl));
   STEREO_HIP_CHECK(hipMemset(P->d_ctl.p, 0, sizeof(int32_t) * 2));
   STEREO_HIP_CHECK(hipDeviceSynchronize());
   P->iterations = 0; P->energy = 0; P->lb = 0; P->epoch = 0; P->fwd_pending = false;
@@ -400,12 +407,12 @@ void finish_inputs(stereo_trws_plan *P) {
     fix_equal_positions(P->pos, P->d_perm_pos.p, P->K, 1);
     P->d_perm_q.release(); P->d_perm_qp.release();
   } else {
-    P->d_perm_q.alloc((size_t)P->E * P->K);
-    P->d_perm_qp.alloc((size_t)P->E * P->K);
-    run_argsort(P->q, P->d_perm_q.p, P->K, P->E, nullptr);
-    run_argsort(P->qprim, P->d_perm_qp.p, P->K, P->E, nullptr);
-    fix_equal_positions(P->q, P->d_perm_q.p, P->K, P->E);
-    fix_equal_positions(P->qprim, P->d_perm_qp.p, P->K, P->E);
+    P->d_perm_q.alloc((size_t)P->El * P->K);
+    P->d_perm_qp.alloc((size_t)P->El * P->K);
+    run_argsort(P->q, P->d_perm_q.p, P->K, P->El, nullptr);
+    run_argsort(P->qprim, P->d_perm_qp.p, P->K, P->El, nullptr);
+    fix_equal_positions(P->q, P->d_perm_q.p, P->K, P->El);
+    fix_equal_positions(P->qprim, P->d_perm_qp.p, P->K, P->El);
   }
   STEREO_HIP_CHECK(hipDeviceSynchronize());
   // shared positions that are finite and strictly ascending: truncation window in index steps
@@ -550,6 +557,27 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
       }
     }
     const TrwsGraph &g = *P->graph;
+    P->Nl = N; P->El = E;
+    if (nstrips > 1) {
+      if (!g.fast_ok)
+        return fail("stereo_trws: row strips need a graph the pipelined kernels take (<= 8 edges per node)", err, errcap);
+      P->layout.reset(new StripLayout);
+      if (!build_strip_layout(g, strip, *P->layout, gerr)) return fail(gerr, err, errcap);
+      const StripLayout &L = *P->layout;
+      P->Nl = (int64_t)L.nodes.size(); P->El = (int64_t)L.edges.size();
+      std::vector<int64_t> ids(L.nodes.begin(), L.nodes.end());
+      P->d_lnodes.upload(ids.data(), ids.size());
+      ids.assign(L.edges.begin(), L.edges.end());
+      P->d_ledges.upload(ids.data(), ids.size());
+      for (int d = 0; d < 2; ++d) {
+        P->d_desc[d].upload(L.desc[d].data(), L.desc[d].size());
+        P->d_chain_run_ptr[d].upload(L.run_ptr[d].data(), L.run_ptr[d].size());
+        P->ntickets[d] = (int)L.run_ptr[d].size() - 1;
+        P->need_peer[d] = L.need_peer[d];
+      }
+      // (the generic kernels' index arrays are not needed: a strip runs a descriptor-driven kernel)
+      P->layout->desc[0] = std::vector<int32_t>(); P->layout->desc[1] = std::vector<int32_t>();
+    } else {
     P->d_tail.upload(g.tail.data(), g.tail.size());
     P->d_order.upload(g.order.data(), g.order.size());
     P->d_fptr.upload(g.fptr.data(), g.fptr.size());
@@ -573,6 +601,7 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
         if (!S.chain_run_order.empty()) P->d_chain_run_order[d].upload(S.chain_run_order.data(), S.chain_run_order.size());
       }
     }
+    }
     P->fast = g.fast_ok && K <= kWave && message_mode == STEREO_TRWS_MESSAGES_EXACT;
     P->wide_allowed = g.fast_ok && kernel == 1 && K > kWave && K <= 256 && message_mode == STEREO_TRWS_MESSAGES_EXACT;
     P->fast2 = g.fast_ok && kernel == 1 && K > kWave && K <= 2 * kWave && message_mode == STEREO_TRWS_MESSAGES_EXACT;
@@ -586,29 +615,11 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
       if (!(P->fast || P->wide_allowed || P->fast2))
         return fail("stereo_trws: row strips need a graph and label count the pipelined kernels take "
                     "(<= 8 edges per node; K <= 64, or K <= 128 with the linear kernel, or K <= 256 with shared positions)", err, errcap);
-      for (int d = 0; d < 2; ++d) {
-        const TrwsGraph::Sweep &S = g.sweep[d];
-        const int64_t R = (int64_t)S.chain_run_ptr.size() - 1;
-        std::vector<int32_t> mine;
-        for (int64_t t = 0; t < R; ++t) {
-          const int32_t run = S.chain_run_order.empty() ? (int32_t)t : S.chain_run_order[t];
-          if (S.chain_run_strip[run] == strip) mine.push_back(run);
-        }
-        P->ntickets[d] = (int)mine.size();
-        P->d_tickets[d].upload(mine.data(), mine.size());
-        // which neighbours this strip writes to (it must be connected to them before it iterates)
-        for (int64_t q = 0; q < N; ++q) {
-          const uint32_t rem = (uint32_t)S.desc[(size_t)q * TrwsGraph::kDescWords + kDescRemote];
-          if (g.owner[g.order[S.chain_rank[q]]] != strip) continue;
-          if (rem & (1u << 16)) P->need_peer[0] = true;
-          if (rem & (1u << 17)) P->need_peer[1] = true;
-        }
-      }
     }
     if (strip_api) STEREO_HIP_CHECK(hipStreamCreateWithFlags(&P->own_stream, hipStreamNonBlocking));
     P->n_lb = nstrips > 1 ? g.strip_lb_terms[strip] : g.lb_terms;
     P->n_en = nstrips > 1 ? g.strip_nodes[strip] : N;
-    P->d_done.alloc(N);
+    P->d_done.alloc(P->Nl);
     P->d_ctl.alloc(2);
     P->d_fallbacks.alloc(1);
     STEREO_HIP_CHECK(hipMemset(P->d_fallbacks.p, 0, sizeof(unsigned long long)));
@@ -616,7 +627,7 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
     if (std::getenv("STEREO_HIP_TRWS_PROF")) { P->d_prof.alloc(32); STEREO_HIP_CHECK(hipMemset(P->d_prof.p, 0, 256)); }
     if (std::getenv("STEREO_HIP_TRWS_TIMELINE"))
       P->d_timeline.alloc(4 * std::max({g.sweep[0].run_ptr.size(), g.sweep[0].chain_run_ptr.size(), g.sweep[1].chain_run_ptr.size()}) + 4);
-    STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * N));
+    STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * P->Nl));
     STEREO_HIP_CHECK(hipMemset(P->d_ctl.p, 0, sizeof(int32_t) * 2));
     {
       // one workgroup per concurrently active run, capped by what stays resident
@@ -627,14 +638,14 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
       P->grid_blocks = (int)std::min<int64_t>(runs, P->cus * per_cu);
       if (max_blocks > 0) P->grid_blocks = std::min(P->grid_blocks, max_blocks);
     }
-    P->d_msg.alloc((size_t)E * K);
+    P->d_msg.alloc((size_t)P->El * K);
     P->d_lbterms.alloc(P->n_lb);
     P->d_eterms.alloc(P->n_en);
-    P->d_x.alloc(N);
-    P->h_lb.alloc(P->n_lb); P->h_en.alloc(P->n_en); P->h_x.alloc(N); P->h_ctl.alloc(2);
+    P->d_x.alloc(P->Nl);
+    P->h_lb.alloc(P->n_lb); P->h_en.alloc(P->n_en); P->h_x.alloc(P->Nl); P->h_ctl.alloc(2);
     P->h_ctl.p[0] = P->h_ctl.p[1] = 0;
-    STEREO_HIP_CHECK(hipMemset(P->d_msg.p, 0, sizeof(double) * (size_t)E * K));
-    STEREO_HIP_CHECK(hipMemset(P->d_x.p, 0, sizeof(int32_t) * N));
+    STEREO_HIP_CHECK(hipMemset(P->d_msg.p, 0, sizeof(double) * (size_t)P->El * K));
+    STEREO_HIP_CHECK(hipMemset(P->d_x.p, 0, sizeof(int32_t) * P->Nl));
     STEREO_HIP_CHECK(hipEventCreate(&P->ev0));
     STEREO_HIP_CHECK(hipEventCreate(&P->ev1));
     STEREO_HIP_CHECK(hipEventCreateWithFlags(&P->ev_bwd, hipEventDisableTiming));
@@ -717,16 +728,24 @@ int stereo_trws_plan_upload(stereo_trws_plan *P, const double *unary, const doub
   if (!shared && (!q || !qprim)) return fail("stereo_trws_plan_upload: q and qprim must both be given", err, errcap);
   try {
     const size_t K = P->K;
-    P->o_unary.upload(unary, (size_t)P->N * K);
-    P->o_alpha.upload(alphas, (size_t)P->E);
+    // a strip keeps the rows of its own nodes + halo and of the edges with an own endpoint
+    std::vector<double> part;
+    auto rows = [&](const double *full, const std::vector<int32_t> &ids, size_t width) {
+      part.resize(ids.size() * width);
+      for (size_t i = 0; i < ids.size(); ++i) std::memcpy(&part[i * width], full + (size_t)ids[i] * width, sizeof(double) * width);
+      return part.data();
+    };
+    const bool local = P->nstrips > 1;
+    P->o_unary.upload(local ? rows(unary, P->layout->nodes, K) : unary, (size_t)P->Nl * K);
+    P->o_alpha.upload(local ? rows(alphas, P->layout->edges, 1) : alphas, (size_t)P->El);
     P->unary = P->o_unary.p; P->alpha = P->o_alpha.p;
     if (shared) {
       P->o_pos.upload(positions, K);
       P->pos = P->o_pos.p; P->q = P->qprim = nullptr;
       P->o_q.release(); P->o_qprim.release();
     } else {
-      P->o_q.upload(q, (size_t)P->E * K);
-      P->o_qprim.upload(qprim, (size_t)P->E * K);
+      P->o_q.upload(local ? rows(q, P->layout->edges, K) : q, (size_t)P->El * K);
+      P->o_qprim.upload(local ? rows(qprim, P->layout->edges, K) : qprim, (size_t)P->El * K);
       P->q = P->o_q.p; P->qprim = P->o_qprim.p; P->pos = nullptr;
     }
     P->lambda = tol;
@@ -745,6 +764,47 @@ int stereo_trws_plan_bind_device(stereo_trws_plan *P, const double *d_unary, con
   if (shared && !d_positions) return fail("stereo_trws_plan_bind_device: need q/qprim or positions", err, errcap);
   if (!shared && (!d_q || !d_qprim)) return fail("stereo_trws_plan_bind_device: q and qprim must both be given", err, errcap);
   try {
+    P->lambda = tol;
+    if (P->nstrips > 1) {
+      // the arrays cover the whole problem: the strip gathers its rows into arrays of its own
+      // (the caller may free the full ones afterwards; stereo_trws_plan_bind_device_strip takes
+      // arrays that are strip-local already)
+      auto rows = [&](const double *full, DevBuf<double> &own, const DevBuf<int64_t> &ids, int64_t n, int width) {
+        own.alloc((size_t)n * width);
+        const unsigned gb = (unsigned)((n * width + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(gb), dim3(kBlock), 0, 0, full, ids.p, n, width, own.p);
+        STEREO_HIP_CHECK(hipGetLastError());
+        return (const double *)own.p;
+      };
+      P->unary = rows(d_unary, P->o_unary, P->d_lnodes, P->Nl, P->K);
+      P->alpha = rows(d_alphas, P->o_alpha, P->d_ledges, P->El, 1);
+      if (shared) { P->pos = d_positions; P->q = P->qprim = nullptr; }
+      else {
+        P->q = rows(d_q, P->o_q, P->d_ledges, P->El, P->K);
+        P->qprim = rows(d_qprim, P->o_qprim, P->d_ledges, P->El, P->K);
+        P->pos = nullptr;
+      }
+      STEREO_HIP_CHECK(hipDeviceSynchronize());
+    } else {
+      P->unary = d_unary; P->alpha = d_alphas;
+      if (shared) { P->pos = d_positions; P->q = P->qprim = nullptr; }
+      else { P->q = d_q; P->qprim = d_qprim; P->pos = nullptr; }
+    }
+    finish_inputs(P);
+    return 0;
+  } catch (const HipError &e) {
+    return fail(e.msg, err, errcap);
+  }
+}
+
+int stereo_trws_plan_bind_device_strip(stereo_trws_plan *P, const double *d_unary, const double *d_q,
+                                       const double *d_qprim, const double *d_positions,
+                                       const double *d_alphas, double tol, char *err, size_t errcap) {
+  if (!P || !d_unary || !d_alphas) return fail("stereo_trws_plan_bind_device_strip: NULL argument", err, errcap);
+  const bool shared = (d_q == nullptr && d_qprim == nullptr);
+  if (shared && !d_positions) return fail("stereo_trws_plan_bind_device_strip: need q/qprim or positions", err, errcap);
+  if (!shared && (!d_q || !d_qprim)) return fail("stereo_trws_plan_bind_device_strip: q and qprim must both be given", err, errcap);
+  try {
     P->unary = d_unary; P->alpha = d_alphas; P->lambda = tol;
     if (shared) { P->pos = d_positions; P->q = P->qprim = nullptr; }
     else { P->q = d_q; P->qprim = d_qprim; P->pos = nullptr; }
@@ -753,6 +813,17 @@ int stereo_trws_plan_bind_device(stereo_trws_plan *P, const double *d_unary, con
   } catch (const HipError &e) {
     return fail(e.msg, err, errcap);
   }
+}
+
+int stereo_trws_plan_strip_layout(stereo_trws_plan *P, int64_t *n_nodes, int64_t *n_own, int64_t *n_edges,
+                                  int32_t *nodes, int32_t *edges) {
+  if (!P) return 1;
+  if (n_nodes) *n_nodes = P->Nl;
+  if (n_own) *n_own = P->n_en;
+  if (n_edges) *n_edges = P->El;
+  for (int64_t i = 0; nodes && i < P->Nl; ++i) nodes[i] = P->layout ? P->layout->nodes[i] : (int32_t)i;
+  for (int64_t e = 0; edges && e < P->El; ++e) edges[e] = P->layout ? P->layout->edges[e] : (int32_t)e;
+  return 0;
 }
 
 int stereo_trws_plan_reset(stereo_trws_plan *P, char *err, size_t errcap) {
@@ -997,6 +1068,12 @@ int stereo_trws_plan_ipc_connect(stereo_trws_plan *P, int which, const void *han
 
 int stereo_trws_plan_debug_flags(stereo_trws_plan *P, int32_t *done, int32_t *ctl) {
   if (!P) return 1;
+  if (done && P->layout) {  // per global rank, like a plan of the whole problem (0 where the strip holds nothing)
+    std::vector<int32_t> f(P->Nl);
+    if (hipMemcpy(f.data(), P->d_done.p, sizeof(int32_t) * P->Nl, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    std::fill(done, done + P->N, 0);
+    for (int64_t i = 0; i < P->Nl; ++i) done[P->graph->rank[P->layout->nodes[i]]] = f[i];
+  } else
   if (done && hipMemcpy(done, P->d_done.p, sizeof(int32_t) * P->N, hipMemcpyDeviceToHost) != hipSuccess) return 1;
   if (ctl && hipMemcpy(ctl, P->d_ctl.p, sizeof(int32_t) * 2, hipMemcpyDeviceToHost) != hipSuccess) return 1;
   return 0;
@@ -1020,7 +1097,11 @@ int stereo_trws_plan_result(stereo_trws_plan *P, double *labelling, double *ener
   if (!P) return fail("stereo_trws_plan_result: NULL plan", err, errcap);
   try {
     if (labelling) {
-      STEREO_HIP_CHECK(hipMemcpy(P->h_x.p, P->d_x.p, sizeof(int32_t) * P->N, hipMemcpyDeviceToHost));
+      STEREO_HIP_CHECK(hipMemcpy(P->h_x.p, P->d_x.p, sizeof(int32_t) * P->Nl, hipMemcpyDeviceToHost));
+      if (P->layout) {  // a strip: its own nodes and halo; label 1 elsewhere
+        for (int64_t i = 0; i < P->N; ++i) labelling[i] = 1.0;
+        for (int64_t i = 0; i < P->Nl; ++i) labelling[P->layout->nodes[i]] = (double)(P->h_x.p[i] + 1);
+      } else
       for (int64_t i = 0; i < P->N; ++i) labelling[i] = (double)(P->h_x.p[i] + 1);  // trws_mex.cpp:137
     }
     if (energy) *energy = P->energy;

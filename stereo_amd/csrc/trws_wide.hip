@@ -592,10 +592,11 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
             for (int j = 0; j < 8; ++j) {
               if (j < pd.nout) {
                 double *mb = ((pd.remote >> j) & 1) ? (((pd.remote >> (8 + j)) & 1) ? p.peer_msg1 : p.peer_msg0) : p.msg;
+                const int ej = ((pd.remote >> j) & 1) ? pd.re[j] : pd.e[j];  // the neighbour numbers the edge itself
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                   const int k = c * kWave + lane;
-                  if (c < C && k < K) st_sc1(mb + (size_t)pd.e[j] * K + k, hprev[j * kWS + k]);
+                  if (c < C && k < K) st_sc1(mb + (size_t)ej * K + k, hprev[j * kWS + k]);
                 }
                 if (BACKWARD && lane == 0) p.lbterms[pd.lbe[j]] = scp[j];
               }
@@ -605,15 +606,15 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           if (PRIMAL && lane == 0) {
             const int xi = ((const int *)(scp + 10))[0];
             st_sc1(p.x + pd.node, xi);
-            if (pd.remote & (1 << 16)) st_sc1(p.peer_x0 + pd.node, xi);
-            if (pd.remote & (1 << 17)) st_sc1(p.peer_x1 + pd.node, xi);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_x0 + pd.pn[0], xi);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_x1 + pd.pn[1], xi);
             p.eterms[pd.epos] = scp[9];
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0) {
             st_sc1(p.done + pd.rank, epoch);
-            if (pd.remote & (1 << 16)) st_sc1(p.peer_done0 + pd.rank, epoch);
-            if (pd.remote & (1 << 17)) st_sc1(p.peer_done1 + pd.rank, epoch);
+            if (pd.remote & (1 << 16)) st_sc1(p.peer_done0 + pd.pn[0], epoch);
+            if (pd.remote & (1 << 17)) st_sc1(p.peer_done1 + pd.pn[1], epoch);
           }
         }
       WIDE_VISITS_END

@@ -87,6 +87,25 @@ class _StripPlan:
                                                      vp(d_alphas), C.c_double(float(tol)), err, C.c_size_t(len(err)))
         _lib.check(rc, err)
 
+    def bind_device_strip(self, d_unary, d_alphas, tol, d_q=None, d_qprim=None, d_positions=None, keepalive=()):
+        """Like bind_device with arrays that hold the strip's rows only (order: layout())."""
+        self._keep = list(keepalive)
+        vp = lambda x: C.c_void_p(int(x)) if x else None
+        err = _lib.errbuf()
+        rc = _lib.lib().stereo_trws_plan_bind_device_strip(self._h, vp(d_unary), vp(d_q), vp(d_qprim), vp(d_positions),
+                                                           vp(d_alphas), C.c_double(float(tol)), err, C.c_size_t(len(err)))
+        _lib.check(rc, err)
+
+    def layout(self):
+        """(nodes, n_own, edges): global ids of the strip's local nodes (own ones first) and edges."""
+        nn, no, ne = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.lib().stereo_trws_plan_strip_layout(self._h, C.byref(nn), C.byref(no), C.byref(ne), None, None)
+        nodes = np.zeros(nn.value, dtype=np.int32)
+        edges = np.zeros(ne.value, dtype=np.int32)
+        _lib.lib().stereo_trws_plan_strip_layout(self._h, None, None, None, nodes.ctypes.data_as(C.c_void_p),
+                                                 edges.ctypes.data_as(C.c_void_p))
+        return nodes, int(no.value), edges
+
     def reset(self):
         err = _lib.errbuf()
         _lib.check(_lib.lib().stereo_trws_plan_reset(self._h, err, C.c_size_t(len(err))), err)

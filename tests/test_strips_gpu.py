@@ -173,3 +173,36 @@ def test_strips_with_the_index_order_option(G, hip, oracle):
     lab, en, lb, _ = s.result()
     s.close()
     assert np.array_equal(lab, lab_o) and _close(en, en_o) and _close(lb, lb_o)
+
+
+def test_a_strip_stores_its_own_rows_only(hip, oracle):
+    """Strip-local storage: each of G strips holds N/G nodes + a halo row per neighbour and the
+    edges at its own nodes; strip-local arrays bound on the device (bind_device_strip, the
+    multi-GPU entry: no rank ever materialises the whole volume) give the oracle's labels."""
+    import torch
+    from stereo_amd.strips import make_strips
+    H, W, K, G = 40, 36, 16, 4
+    p = trws_problem(131, H, W, K, kind="general")
+    lab_o, en_o, lb_o, _ = oracle.trws(1, p["unary"], p["conn"], p["q"], p["qprim"], p["alphas"], 2.0, 3, -1e300, mode=1)
+    s = make_strips(1, K, H, W, p["conn"].T, G)
+    N, E = H * W, p["conn"].shape[0]
+    keep = []
+    for g, pl in enumerate(s.plans):
+        nodes, n_own, edges = pl.layout()
+        assert n_own == np.sum(s._owner == g) and np.all(s._owner[nodes[:n_own]] == g)
+        assert np.all(np.diff(nodes[:n_own]) > 0) and np.all(np.diff(nodes[n_own:]) > 0) and np.all(np.diff(edges) > 0)
+        halo = nodes[n_own:]
+        assert np.all(s._owner[halo] != g) and len(halo) <= 2 * (W + 2)
+        touching = (s._owner[p["conn"][:, 0]] == g) | (s._owner[p["conn"][:, 1]] == g)
+        assert np.array_equal(edges, np.nonzero(touching)[0])
+        assert len(nodes) < N // G + 2 * (W + 2) + W and len(edges) < E // G + 6 * W
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        u, a = dev(p["unary"][nodes]), dev(p["alphas"][edges])          # rows = nodes / edges, K fastest
+        q, qp = dev(p["q"][edges]), dev(p["qprim"][edges])
+        keep += [u, a, q, qp]
+        pl.bind_device_strip(u.data_ptr(), a.data_ptr(), 2.0, d_q=q.data_ptr(), d_qprim=qp.data_ptr())
+    torch.cuda.synchronize()
+    done, _ = s.iterate(3, max_relgap=-1e300)
+    lab, en, lb, _ = s.result()
+    s.close()
+    assert done == 3 and np.array_equal(lab, lab_o) and _close(en, en_o) and _close(lb, lb_o)
