@@ -55,6 +55,12 @@ struct QpboDev {
   // (a 16 x 32 pixel patch and its mates when the grid shape is known).
   const int32_t *perm, *pos_of;
   int ntiles;
+  // tiled rounds: dirty[parity][tile] = the tile holds excess that can still move, or flow was
+  // pushed into it across its border in the last round; other tiles are skipped
+  int32_t *dirty;
+  // the same idea for the label-correcting relabelling: rdirty[parity][tile] = a height next to
+  // the tile (or inside it) went down in the last step
+  int32_t *rdirty;
 };
 
 // ---- the whole max-flow in ONE launch -------------------------------------------------------
@@ -135,6 +141,11 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
       const int old_h = warm ? ldc(h + v) : n;
       stc(h + v, ldc(g.snk + v) > 0 ? 1 : (old_h < n ? old_h : n));
     }
+    // A tile is relaxed again only if a height next to it went down in the last step (every tile in
+    // the first): once a tile has reached its fixpoint it stays there until an input changes.  The
+    // search front crosses the image, the warm search of an Improve step touches a small region.
+    int rpar = 0;
+    for (int T = first; T < g.ntiles; T += stride) { stc(g.rdirty + T, 1); stc(g.rdirty + g.ntiles + T, 0); }
     // residuals do not change during the relabelling: after this invalidate plain loads of r see
     // what the (write-through, sc1) pushes stored
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -143,9 +154,16 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
       slotC = (slotC + 1) % 3;
       clear_next(QpboCtl::kChanged, slotC);
       bool any_changed = false;
+      int32_t *rd_in = g.rdirty + (size_t)rpar * g.ntiles, *rd_out = g.rdirty + (size_t)(rpar ^ 1) * g.ntiles;
+      rpar ^= 1;
       for (int T = blockIdx.x; T < g.ntiles; T += gridDim.x) {
+        const int is_dirty = ldc(rd_in + T);
+        __syncthreads();  // every thread has read the flag before it is cleared
+        if (!is_dirty) continue;
+        if (threadIdx.x == 0) stc(rd_in + T, 0);
         const int v = g.perm[T * kMB + threadIdx.x];
         int my = n, winfo[kArcRegs], exth[kArcRegs], a0 = 0, a1 = 0;
+        int extT[kArcRegs];  // tile of the arc's head if it is another tile (whatever the residual), else -1
         if (v >= 0) {
           my = ldc(h + v);
           a0 = g.aptr[v]; a1 = g.aptr[v + 1];
@@ -153,11 +171,14 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         s_h[threadIdx.x] = my;
 #pragma unroll
         for (int k = 0; k < kArcRegs; ++k) {
-          winfo[k] = -1; exth[k] = n;
-          if (a0 + k < a1 && g.r[a0 + k] > 0) {
+          winfo[k] = -1; exth[k] = n; extT[k] = -1;
+          if (a0 + k < a1) {
             const int w = g.head[a0 + k], pw = g.pos_of[w];
-            if (pw / kMB == T) winfo[k] = pw % kMB;
-            else { winfo[k] = -2; exth[k] = ldc(h + w); }
+            if (pw / kMB != T) extT[k] = pw / kMB;
+            if (g.r[a0 + k] > 0) {
+              if (pw / kMB == T) winfo[k] = pw % kMB;
+              else { winfo[k] = -2; exth[k] = ldc(h + w); }
+            }
           }
         }
         __syncthreads();
@@ -179,7 +200,17 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
           ch = best < my;
           if (ch) { my = best; s_h[threadIdx.x] = my; }  // heights only decrease: racing readers are harmless
         } while (__syncthreads_or(ch));
-        if (my < start) { stc(h + v, my); any_changed = true; }
+        if (my < start) {
+          stc(h + v, my); any_changed = true;
+          // whoever has a residual arc INTO v may come down now: the tiles of v's neighbours
+#pragma unroll
+          for (int k = 0; k < kArcRegs; ++k)
+            if (extT[k] >= 0) stc(rd_out + extT[k], 1);
+          for (int a = a0 + kArcRegs; a < a1; ++a) {
+            const int tw = g.pos_of[g.head[a]] / kMB;
+            if (tw != T) stc(rd_out + tw, 1);
+          }
+        }
         __syncthreads();
       }
       if (__syncthreads_or(any_changed) && threadIdx.x == 0)
@@ -359,22 +390,35 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
       stc(g.ex + v, g.ex[v]); stc(g.snk + v, g.snk[v]);
     }
     h = g.h; h2 = g.h2;
+    int G = 0;  // global round number: pushes of round G land in delta buffer G & 1
+    // Few tiles hold excess after the plain rounds (7k active nodes in some dozens of 660 tiles on
+    // the long globalstereo moves): a tile without excess that can move and without flow arriving
+    // over its border does not change in a round, so it is skipped -- exactly, not heuristically.
+    // After an exact relabelling every tile is looked at once (nodes may have become active again).
+    auto mark_all_dirty = [&]() {
+      for (int T = first; T < g.ntiles; T += stride) stc(g.dirty + (size_t)((G + 1) & 1) * g.ntiles + T, 1);
+    };
+    mark_all_dirty();
     if (!grid_sync(ctl, gen)) return;
     double *s_ex = dyn_lds, *s_snk = dyn_lds + kMB, *s_r = dyn_lds + 2 * kMB, *s_d = dyn_lds + 6 * kMB;
-    int G = 0;  // global round number: pushes of round G land in delta buffer G & 1
     // L local rounds (L == 0: only take in what was pushed across tile borders); counts the active
     // nodes and one more per workgroup that pushed across a border (that flow is still in transit)
     auto tile_round = [&](int L) -> bool {
       ++G;
       double *dout = g.delta + (size_t)(G & 1) * g.m, *din = g.delta + (size_t)((G + 1) & 1) * g.m;
+      int32_t *dirty_in = g.dirty + (size_t)(G & 1) * g.ntiles, *dirty_out = g.dirty + (size_t)((G + 1) & 1) * g.ntiles;
       slotA = (slotA + 1) % 3;
       clear_next(QpboCtl::kActive, slotA);
       int cnt = 0;
       bool crossed = false;
       for (int T = blockIdx.x; T < g.ntiles; T += gridDim.x) {
+        const int is_dirty = ldc(dirty_in + T);
+        __syncthreads();  // every thread has read the flag before it is cleared
+        if (!is_dirty) continue;
+        if (threadIdx.x == 0) stc(dirty_in + T, 0);
         const int v = g.perm[T * kMB + threadIdx.x];
         const bool valid = v >= 0;
-        int loc[4] = {-1, -1, -1, -1}, rvk[4] = {0, 0, 0, 0}, exth[4] = {n, n, n, n}, a0 = 0, deg = 0;
+        int loc[4] = {-1, -1, -1, -1}, rvk[4] = {0, 0, 0, 0}, exth[4] = {n, n, n, n}, extT[4] = {0, 0, 0, 0}, a0 = 0, deg = 0;
         double e = 0;
         int hv = n;
         if (valid) {
@@ -392,7 +436,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
               rvk[k] = rvs[k] - g.aptr[w];
               rk[k] = ldc(g.r + a);
               if (pw / kMB == T) loc[k] = pw % kMB;
-              else { exth[k] = ldc(h + w); din_k[k] = ldc(din + rvs[k]); }
+              else { exth[k] = ldc(h + w); din_k[k] = ldc(din + rvs[k]); extT[k] = pw / kMB; }
             }
           }
 #pragma unroll
@@ -435,7 +479,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
                       const double d = e < ra ? e : ra;
                       s_r[threadIdx.x * 4 + k] = ra - d;
                       if (local) s_d[loc[k] * 4 + rvk[k]] = d;
-                      else { stc(dout + a0 + k, d); crossed = true; }
+                      else { stc(dout + a0 + k, d); stc(dirty_out + extT[k], 1); crossed = true; }
                       e -= d;
                     }
                   }
@@ -487,7 +531,9 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
             if (k < deg) stc(g.r + a0 + k, s_r[threadIdx.x * 4 + k]);
           if (s_ex[threadIdx.x] > 0 && hnew < n) ++cnt;
         }
-        __syncthreads();  // the tile buffers are reused
+        // (also the barrier before the tile buffers are reused)
+        const int left = __syncthreads_or(valid && s_ex[threadIdx.x] > 0 && s_h[threadIdx.x] < n);
+        if (left && threadIdx.x == 0) stc(dirty_out + T, 1);
       }
       if (threadIdx.x == 0) s_red = 0;
       __syncthreads();
@@ -510,11 +556,13 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         last_active = active;
         if (active > 0 && (since_relabel >= interval || (stagnant >= 2 && since_relabel >= 4))) {
           if (!tile_round(0)) return;  // nothing in transit while the residual graph is searched
+          mark_all_dirty();
           if (!global_relabel(active)) return;
           since_relabel = 0; stagnant = 0; last_active = active;
           interval = interval * 2 < relabel_every ? interval * 2 : relabel_every;
         }
       }
+      mark_all_dirty();
       if (!global_relabel(active)) return;  // exact heights: anything left over is cut off
     } while (active > 0 && rounds < max_rounds);
     exact = true;
@@ -793,7 +841,7 @@ namespace {
 struct QpboSolver {
   QpboProblem P;
   int n = 0, m = 0;
-  DevBuf<int32_t> d_aptr, d_head, d_rev, d_h, d_h2, d_cnt, d_flags, d_ctl, d_perm, d_posof;
+  DevBuf<int32_t> d_aptr, d_head, d_rev, d_h, d_h2, d_cnt, d_flags, d_ctl, d_perm, d_posof, d_dirty;
   DevBuf<double> d_r, d_delta, d_ex, d_snk;
   std::vector<double> snk0;
   QpboDev g{};
@@ -853,6 +901,9 @@ struct QpboSolver {
       if (perm[q] >= 0) posof[perm[q]] = (int32_t)q;
     d_perm.upload(perm.data(), perm.size()); d_posof.upload(posof.data(), posof.size());
     g.perm = d_perm.p; g.pos_of = d_posof.p; g.ntiles = (int)(perm.size() / kMB);
+    d_dirty.alloc((size_t)4 * std::max(g.ntiles, 1));
+    STEREO_HIP_CHECK(hipMemset(d_dirty.p, 0, sizeof(int32_t) * 4 * std::max(g.ntiles, 1)));
+    g.dirty = d_dirty.p; g.rdirty = d_dirty.p + (size_t)2 * std::max(g.ntiles, 1);
   }
 
   // AddUnaryTerm(i, 0, INFTY) with INFTY = 1 + max over the two saturation sums of node i
