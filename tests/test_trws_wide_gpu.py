@@ -170,3 +170,37 @@ def test_two_labels_per_lane_kernel_matches_oracle(case, hip, oracle):
     if not integer:
         E = p["conn"].shape[0]
         assert plan.serial_messages() < 0.2 * (2 * E * maxiter + E)
+
+
+def test_wide_kernel_matches_oracle_at_300x400x256(hip, oracle):
+    """The wide-label kernel at a size where every mechanism is in play (more rows than resident
+    workgroups, the cut border chain, two row strips) against the CPU oracle, not another HIP
+    kernel: 2 iterations of a 300 x 400 x 256 volume, labels and both scalars bit for bit
+    (the strips' scalars to 1e-12: they are partial sums added in strip order)."""
+    from helpers import grid_conn
+    from stereo_amd.trws import TrwsPlan
+    from stereo_amd.strips import make_strips
+    H, W, K = 300, 400, 256
+    rng = np.random.default_rng(5)
+    conn = grid_conn(H, W)
+    E = conn.shape[0]
+    truth = (0.3 * K + 0.4 * K * np.arange(W)[None, :] / W + 10 * np.sin(np.arange(H)[:, None] / 23.0)).T.reshape(-1, 1)
+    unary = np.minimum(np.abs(np.arange(K)[None, :] - truth) / 4.0, 1.0) * 30.0 + rng.uniform(0, 10, size=(H * W, K))
+    alphas = rng.uniform(0.5, 2.0, size=E)
+    pos = np.arange(K, dtype=np.float64)
+    q = np.ascontiguousarray(np.broadcast_to(pos, (E, K)))
+    lab_o, en_o, lb_o, it_o = oracle.trws(1, unary, conn, q, q, alphas, 8.0, 2, -1e300, mode=1)
+    del q
+    plan = TrwsPlan(1, K, H * W, conn.T)
+    plan.upload(unary.T, alphas, 8.0, positions=pos)
+    assert plan.path() == 3
+    plan.iterate(2, max_relgap=-1e300)
+    lab, en, lb, it = plan.result()
+    assert it == it_o and np.array_equal(lab, lab_o) and en == en_o and lb == lb_o
+    s = make_strips(1, K, H, W, conn.T, 2)
+    s.upload(unary.T, alphas, 8.0, positions=pos)
+    s.iterate(2, max_relgap=-1e300)
+    lab2, en2, lb2, _ = s.result()
+    s.close()
+    assert np.array_equal(lab2, lab_o)
+    assert abs(en2 - en_o) <= 1e-12 * abs(en_o) and abs(lb2 - lb_o) <= 1e-12 * abs(lb_o)
