@@ -91,7 +91,7 @@ def algorithmic_bytes_per_sweep_pair(info_deg, K):
     return float(fwd.sum() + bwd.sum())
 
 
-def scale_leg(args, rank, local_rank, world, dist, dev, index_order=False):
+def scale_leg(args, rank, local_rank, world, dist, dev, index_order=False, minplus=False):
     """Strong scaling of ONE large image (BASELINE.json configs[3]: synthetic 3000 x 2000 x 256-label
     volume) over the `world` GPUs: rank g owns band g of the rows (stereo_amd.strips), boundary
     messages / flags / labels go to the neighbour GPU as peer stores over xGMI, energy and bound are
@@ -108,7 +108,9 @@ def scale_leg(args, rank, local_rank, world, dist, dev, index_order=False):
     conn = grid_conn(H, W)
     E = conn.shape[0]
     d_pos = torch.arange(K, dtype=torch.float64, device=dev)
-    mode = 0x100 if index_order else 0   # STEREO_TRWS_ORDER_INDEX: labelled extra, not the gateway's node order
+    # labelled extras: STEREO_TRWS_ORDER_INDEX (not the gateway's node order), STEREO_TRWS_MESSAGES_MINPLUS
+    # (plain min-plus messages: the reference's bits unless a message's certificate would have failed)
+    mode = (0x100 if index_order else 0) | (1 if minplus else 0)
     if world == 1:
         solver = TrwsPlan(1, K, N, conn.T, message_mode=mode)
         plan = solver
@@ -409,16 +411,27 @@ def main():
             scale = scale_leg(args, rank, local_rank, world, dist, dev)
         except Exception as exc:  # the headline line must not depend on the scaling leg
             scale = {"error": "%s: %s" % (type(exc).__name__, exc), "n_gpus": world}
-        try:   # the same image and strips with the nodes in index order (no serial border chain): labelled extra
-            torch.cuda.empty_cache()
-            alt_scale = scale_leg(args, rank, local_rank, world, dist, dev, index_order=True)
-            if rank == 0 and scale is not None and alt_scale is not None:
-                scale["index_order_option"] = {k: alt_scale[k] for k in ("value", "unit", "ms_per_iteration", "hbm_frac_per_gpu",
-                                                                         "energy", "lower_bound")}
-                scale["index_order_option"]["note"] = "STEREO_TRWS_ORDER_INDEX: not the gateway's node order / labels"
-        except Exception as exc:
-            if rank == 0 and scale is not None:
-                scale["index_order_option"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        # the same image and strips under the two labelled options (and both): not the reference's bits
+        notes = {"minplus_option": "STEREO_TRWS_MESSAGES_MINPLUS: windowed min-plus messages, no certificate / envelope "
+                                   "construction (equal to the reference unless a certificate would have failed)",
+                 "index_order_option": "STEREO_TRWS_ORDER_INDEX: not the gateway's node order / labels",
+                 "index_order_minplus_option": "both options"}
+        for key, io, mp in (("minplus_option", False, True), ("index_order_option", True, False),
+                            ("index_order_minplus_option", True, True)):
+            try:
+                torch.cuda.empty_cache()
+                alt_scale = scale_leg(args, rank, local_rank, world, dist, dev, index_order=io, minplus=mp)
+                if rank == 0 and scale is not None and alt_scale is not None:
+                    scale[key] = {k: alt_scale[k] for k in ("value", "unit", "ms_per_iteration", "hbm_frac_per_gpu",
+                                                            "energy", "lower_bound")}
+                    scale[key]["note"] = notes[key]
+                    if mp:  # did plain min-plus give the exact messages' bits on this volume?
+                        ref = scale["index_order_option"] if io else scale
+                        scale[key]["energy_and_bound_equal_to_exact_messages"] = bool(
+                            ref.get("energy") == alt_scale["energy"] and ref.get("lower_bound") == alt_scale["lower_bound"])
+            except Exception as exc:
+                if rank == 0 and scale is not None:
+                    scale[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     if rank == 0:
         if scale is not None:
             out["scale"] = scale

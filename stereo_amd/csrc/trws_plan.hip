@@ -271,6 +271,7 @@ DevParams make_params(stereo_trws_plan *P) {
   p.peer_x0 = P->peer_x[0]; p.peer_x1 = P->peer_x[1];
   p.done = P->d_done.p; p.ticket = P->d_ctl.p; p.abort_flag = P->d_ctl.p + 1; p.N = (int)P->Nl;
   p.fallbacks = P->d_fallbacks.p; p.certificate = P->certificate ? 1 : 0;
+  p.lean = (P->wide && P->mode == STEREO_TRWS_MESSAGES_MINPLUS) ? 1 : 0;
   p.prof = P->d_prof.p;
   p.timeline = P->d_timeline.p;
   p.desc[0] = P->d_desc[0].p; p.desc[1] = P->d_desc[1].p;
@@ -451,6 +452,9 @@ void finish_inputs(stereo_trws_plan *P) {
       }
     }
   }
+  if (P->nstrips > 1 && !(P->fast || P->fast2 || P->wide))
+    throw HipError{"stereo_trws: row strips with these inputs would need the generic kernel, which has no strip support "
+                   "(K > 128 or the MINPLUS mode need shared strictly ascending positions)"};
   P->have_inputs = true;
 }
 
@@ -521,7 +525,7 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
       STEREO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, P->device));
       P->cus = std::max(cus, 1);
     }
-    const bool wide_candidate = kernel == 1 && K > kWave && K <= 256 && message_mode == STEREO_TRWS_MESSAGES_EXACT;
+    const bool wide_candidate = kernel == 1 && K > kWave && K <= 256;  // (either message mode: MINPLUS runs it lean)
     const int64_t per_cu = std::min<int64_t>(std::max<int64_t>(1, (int64_t)(160 * 1024) / (int64_t)persistent_lds_bytes(P->Kp)), 4);
     const int64_t capacity = wide_candidate ? P->cus : P->cus * per_cu;
     // The analysis depends on the connectivity only (ordering, lists, schedules: 0.2-0.6 s at Teddy
@@ -547,7 +551,7 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
         auto fresh = std::make_shared<TrwsGraph>();
         if (!build_trws_graph(N, E, conn, *fresh, gerr, capacity, nstrips > 1 ? owner : nullptr, nstrips, P->cus, ordering)) return fail(gerr, err, errcap);
         P->graph = fresh;
-        if (N <= (1 << 20)) {  // (the descriptors of a 3000 x 2000 grid are 3 GB: not worth keeping)
+        if (N <= (1 << 23)) {  // (3000 x 2000: 3 GB of descriptors stay in host memory until the next connectivity)
           cache.N = N; cache.E = E; cache.capacity = capacity; cache.cus = P->cus; cache.nstrips = nstrips; cache.ordering = ordering;
           cache.conn.assign(conn, conn + 2 * (size_t)E); cache.g = fresh;
           if (nstrips > 1) cache.owner.assign(owner, owner + N); else cache.owner.clear();
@@ -603,7 +607,7 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
     }
     }
     P->fast = g.fast_ok && K <= kWave && message_mode == STEREO_TRWS_MESSAGES_EXACT;
-    P->wide_allowed = g.fast_ok && kernel == 1 && K > kWave && K <= 256 && message_mode == STEREO_TRWS_MESSAGES_EXACT;
+    P->wide_allowed = g.fast_ok && kernel == 1 && K > kWave && K <= 256;
     P->fast2 = g.fast_ok && kernel == 1 && K > kWave && K <= 2 * kWave && message_mode == STEREO_TRWS_MESSAGES_EXACT;
     if (const char *f = std::getenv("STEREO_HIP_TRWS_FAST")) {
       P->fast = P->fast && std::string(f) != "0";

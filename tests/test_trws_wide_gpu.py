@@ -204,3 +204,35 @@ def test_wide_kernel_matches_oracle_at_300x400x256(hip, oracle):
     s.close()
     assert np.array_equal(lab2, lab_o)
     assert abs(en2 - en_o) <= 1e-12 * abs(en_o) and abs(lb2 - lb_o) <= 1e-12 * abs(lb_o)
+
+
+LEAN = [
+    # seed, H, W, K, positions, integer, tol, maxiter
+    (71, 9, 11, 256, "grid", False, 8.0, 4),
+    (72, 8, 9, 100, "irregular", False, 5.0, 3),
+    (73, 7, 8, 129, "half", False, 6.0, 3),
+    (74, 6, 7, 256, "grid", True, 8.0, 4),        # integer costs: ties everywhere, min-plus does not care
+    (75, 6, 6, 200, "grid", False, 1e9, 3),       # no truncation
+    (76, 12, 13, 72, "grid", False, 0.0, 3),      # lambda = 0
+]
+
+
+@pytest.mark.parametrize("case", LEAN, ids=[str(c[0]) for c in LEAN])
+def test_minplus_mode_on_the_wide_kernel_matches_the_bruteforce_oracle(case, hip, oracle):
+    """STEREO_TRWS_MESSAGES_MINPLUS with 64 < K <= 256 and shared ascending positions runs the wide
+    kernel "lean" (windowed min-plus only: no certificate, no envelope construction).  Min-plus is
+    order independent, so the bits are those of the oracle's brute-force O(K^2) messages (mode 0)."""
+    from stereo_amd.trws import TrwsPlan, MESSAGES_MINPLUS
+    seed, H, W, K, pk, integer, tol, maxiter = case
+    p = trws_problem(seed, H, W, K, kind="fronto", integer=integer)
+    pos = _positions(pk, K, np.random.default_rng(seed + 1000))
+    E = p["conn"].shape[0]
+    q = np.tile(pos, (E, 1))
+    lab_o, en_o, lb_o, it_o = oracle.trws(1, p["unary"], p["conn"], q, q, p["alphas"], tol, maxiter, -1e300, mode=0)
+    plan = TrwsPlan(1, K, H * W, p["conn"].T, message_mode=MESSAGES_MINPLUS)
+    plan.upload(p["unary"].T, p["alphas"], tol, positions=pos)
+    assert plan.path() == 3
+    plan.iterate(maxiter, max_relgap=-1e300)
+    lab, en, lb, it = plan.result()
+    assert plan.serial_messages() == 0
+    assert it == it_o and np.array_equal(lab, lab_o) and en == en_o and lb == lb_o

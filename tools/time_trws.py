@@ -1,5 +1,5 @@
 """Development tool: time TRW-S iterations of a synthetic volume for a given kernel / size.
-usage: time_trws.py [kernel=1] [H=375] [W=450] [K=60] [tol=8] [iters=10] [general=0] [volume=noise|ncc] [index_order=0]
+usage: time_trws.py [kernel=1] [H=375] [W=450] [K=60] [tol=8] [iters=10] [general=0] [volume=noise|ncc] [index_order=0] [minplus=0]
 general=1: per-edge positions q != qprim (label k + jitter), as a fusion of K plane proposals has them."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,7 +28,8 @@ if volume == "ncc":
     d_unary = torch.from_numpy(np.ascontiguousarray(40.0 * (1.0 - ncc.T))).to(dev)
 else:
     d_unary = torch.from_numpy(synthetic_volume(H, W, K, seed=1)).to(dev)
-plan = TrwsPlan(kernel, K, N, conn.T, message_mode=0x100 if index_order else 0)
+minplus = int(a[9]) if len(a) > 9 else 0       # 1: STEREO_TRWS_MESSAGES_MINPLUS (plain min-plus messages)
+plan = TrwsPlan(kernel, K, N, conn.T, message_mode=(0x100 if index_order else 0) | (1 if minplus else 0))
 d_alpha = torch.ones(E, dtype=torch.float64, device=dev)
 d_pos = torch.arange(K, dtype=torch.float64, device=dev)
 if general:
