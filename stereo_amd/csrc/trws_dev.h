@@ -42,7 +42,7 @@ struct DevParams {
   int N;
   unsigned long long *fallbacks;  // messages that needed the serial envelope (diagnostics)
   int certificate;                // 0: always run the serial envelope
-  int lean;                       // wide kernel, STEREO_TRWS_MESSAGES_MINPLUS: windowed min-plus only, no certificate, no envelope
+  int lean;                       // STEREO_TRWS_MESSAGES_MINPLUS in the wide-label regime: 2 = trws_chunk_kernel, 1 = the wide kernel without its certificate
   unsigned long long *prof;       // optional: 8 phase-cycle accumulators (development)
   const int32_t *desc[2];         // packed node descriptors of the pipelined kernels
   int prof_run;
