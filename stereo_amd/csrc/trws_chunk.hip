@@ -36,7 +36,7 @@ constexpr int kWStage = kWStI + 36;
 // stage: D[kWS] m[8][kWS] a[8] | ints desc[64] px[8]
 
 struct ChunkPtrs {
-  double *stage0, *hand, *tab, *ptab, *pos, *scal, *redn, *redh, *redv;
+  double *stage0, *hand, *tab, *ptab, *pos, *scal, *redn, *redh;
   int *dring, *ctl;
 };
 __device__ __forceinline__ ChunkPtrs chunk_carve(double *lds) {
@@ -49,12 +49,11 @@ __device__ __forceinline__ ChunkPtrs chunk_carve(double *lds) {
   w.scal = w.pos + kWS;                      // 2 * kScalDoubles
   w.redn = w.scal + 2 * kScalDoubles;        // [4] min Di per chunk (backward sweep)
   w.redh = w.redn + 4;                       // [4][4] min H_j per chunk
-  w.redv = w.redh + 16;                      // [4][4] min of the new message per chunk
-  w.dring = (int *)(w.redv + 16);            // 3 * 64 descriptor words (for the storer)
+  w.dring = (int *)(w.redh + 16);            // 3 * 64 descriptor words (for the storer)
   w.ctl = w.dring + 3 * 64;                  // [0] run, [1] abort, [3] arrivals at the compute waves' barrier (counts up)
   return w;
 }
-constexpr int kChunkLdsDoubles = 2 * kWStage + 3 * 8 * kWS + 5 * kCTab + kWS + 2 * kScalDoubles + 36 + 96 + 4;
+constexpr int kChunkLdsDoubles = 2 * kWStage + 3 * 8 * kWS + 5 * kCTab + kWS + 2 * kScalDoubles + 20 + 96 + 4;
 
 template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE>
 __device__ __forceinline__ void chunk_body(DevParams p, int epoch) {
@@ -130,6 +129,7 @@ __device__ __forceinline__ void chunk_body(DevParams p, int epoch) {
       const bool mine = wave < C;            // the chunk exists
       const bool valid = off < K;
       const double posv = valid ? p.pos[off] : 0.0;
+      const double dabs = fabs((double)(lane - kWPad) * ustep);  // |d step| for d = lane - kWPad
       // barrier among the C compute waves: LDS writes before it are visible after it
       auto csync = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -189,13 +189,12 @@ __device__ __forceinline__ void chunk_body(DevParams p, int epoch) {
           const int w = p.window;
           for (int j0 = 0; j0 < nout; j0 += 4) {
             // ---- H_j = gamma Di - m_j of up to four messages into their tables, and the chunks' minima
-            double alpha[4], out[4], mold[4];
+            double alpha[4], mold[4];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {  // (reads first)
               const int j = j0 + jj < nout ? j0 + jj : j0;
               alpha[jj] = st[kWS + 8 * kWS + j];
               mold[jj] = st[kWS + j * kWS + off];
-              out[jj] = 0;
             }
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -209,26 +208,31 @@ __device__ __forceinline__ void chunk_body(DevParams p, int epoch) {
             }
             csync();
             WSTAMP(1);
-            // ---- windowed min-plus (a source farther than lambda costs >= vTrunc exactly)
+            // ---- windowed min-plus (a source farther than lambda costs >= vTrunc exactly), normalised.
+            // The smallest entry of the new message is min H_j itself: the d = 0 term of destination t
+            // is h_t + alpha 0 = h_t, every other term is some h_s plus a non-negative cost, and
+            // vTrunc = min H_j + alpha lambda is no smaller -- so no second reduction across the chunks.
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
               if (j0 + jj < nout) {
+                const int j = j0 + jj;
                 const double a = alpha[jj];
-                const double vtrunc = across(L.redh + jj * 4) + a * p.lambda;
+                const double hmin = across(L.redh + jj * 4);
+                const double vtrunc = hmin + a * p.lambda;
                 const double *tb = L.tab + jj * kCTab + kWPad + off;
                 double m1 = inf;
                 if (uniform && w <= kWPad) {
-                  // eight table reads in flight at a time (the padding keeps every index inside the
-                  // table; offsets beyond the window are masked)
-                  for (int d0 = -w; d0 <= w; d0 += 8) {
-                    double hs[8];
+                  // lane kWPad + d of `adm` holds alpha |d step| (== alpha |t - q| exactly); the loop
+                  // takes it from there (two v_readlane) instead of recomputing it in every lane
+                  const double adm = a * dabs;
+                  if (w == 8) {
+                    double hs[17];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) hs[u] = tb[d0 + u <= w ? d0 + u : w];
+                    for (int u = 0; u < 17; ++u) hs[u] = tb[u - 8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                      const double cst = a * fabs((double)(d0 + u) * ustep) + hs[u];
-                      m1 = min_raw(m1, d0 + u <= w ? cst : inf);
-                    }
+                    for (int u = 0; u < 17; ++u) m1 = min_raw(m1, readlane_f64(adm, kWPad - 8 + u) + hs[u]);
+                  } else {
+                    for (int d = -w; d <= w; ++d) m1 = min_raw(m1, readlane_f64(adm, kWPad + d) + tb[d]);
                   }
                 } else if (w <= kWPad) {
                   const double *pb = L.ptab + kWPad + off;
@@ -241,23 +245,13 @@ __device__ __forceinline__ void chunk_body(DevParams p, int epoch) {
                   }
                 }
                 const double o = m1 < vtrunc ? m1 : vtrunc;
-                out[jj] = o;
-                const double lv = wave_min_dpp(valid ? o : inf);
-                if (lane == 0) L.redv[jj * 4 + wave] = lv;
+                if (valid) hcur[j * kWS + off] = o - hmin;
+                if (BACKWARD && wave == 0 && lane == 0) sc[j] = hmin;
               }
             }
-            csync();
             WSTAMP(2);
-            // ---- normalise and hand over
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              if (j0 + jj < nout) {
-                const int j = j0 + jj;
-                const double vmin = across(L.redv + jj * 4);
-                if (valid) hcur[j * kWS + off] = out[jj] - vmin;
-                if (BACKWARD && wave == 0 && lane == 0) sc[j] = vmin;
-              }
-            }
+            // (a second round reuses the tables and slots: every wave must be done reading them)
+            if (j0 + 4 < nout) csync();
             WSTAMP(3);
           }
         }
@@ -465,8 +459,9 @@ __device__ __forceinline__ void chunk_body(DevParams p, int epoch) {
   }
 #undef WSTAMP
   if (p.prof && lane == 0) {
+    // slots [4 w .. 4 w + 3]: the four phases of compute wave w
+    if (wave < kChunkCompute) for (int i = 0; i < 4; ++i) atomicAdd(p.prof + 4 * wave + i, pacc[i]);
     if (wave == 0) {
-      for (int i = 0; i < 16; ++i) atomicAdd(p.prof + i, pacc[i]);
       atomicAdd(p.prof + 21, pwait);
       atomicAdd(p.prof + 22, pvis);
     }

@@ -42,7 +42,7 @@ struct DevParams {
   int N;
   unsigned long long *fallbacks;  // messages that needed the serial envelope (diagnostics)
   int certificate;                // 0: always run the serial envelope
-  int lean;                       // STEREO_TRWS_MESSAGES_MINPLUS in the wide-label regime: 2 = trws_chunk_kernel, 1 = the wide kernel without its certificate
+  int lean;                       // STEREO_TRWS_MESSAGES_MINPLUS in the wide-label regime (trws_chunk_kernel)
   unsigned long long *prof;       // optional: 8 phase-cycle accumulators (development)
   const int32_t *desc[2];         // packed node descriptors of the pipelined kernels
   int prof_run;
@@ -788,7 +788,12 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
       MSTAMP(14);
     }
 #undef MSTAMP
-    vmin = wave_min_dpp(act ? out : inf);
+    // Smallest entry of the message.  With the same positions on both sides (lane k: source k and
+    // destination k) a certified linear message has its minimum at min H exactly: destination t sees
+    // its own source at distance 0 (h_t + alpha 0 = h_t), every other term is some h_s plus a
+    // non-negative cost, and vTrunc = min H + alpha lambda is no smaller -- no reduction needed.
+    if (KERNEL == 1 && p.certificate && !need_serial && !UNI(act && qsrc != t)) vmin = hmin;
+    else vmin = wave_min_dpp(act ? out : inf);
   }
   outmsg = out - vmin;
   return vmin;

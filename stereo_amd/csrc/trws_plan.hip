@@ -271,9 +271,8 @@ DevParams make_params(stereo_trws_plan *P) {
   p.peer_x0 = P->peer_x[0]; p.peer_x1 = P->peer_x[1];
   p.done = P->d_done.p; p.ticket = P->d_ctl.p; p.abort_flag = P->d_ctl.p + 1; p.N = (int)P->Nl;
   p.fallbacks = P->d_fallbacks.p; p.certificate = P->certificate ? 1 : 0;
-  // MINPLUS on the wide-label regime: the chunk-parallel kernel (trws_chunk.hip); STEREO_HIP_TRWS_LEAN_WIDE=1
-  // (development) runs the wide kernel with its certificate switched off instead -- same bits
-  p.lean = (P->wide && P->mode == STEREO_TRWS_MESSAGES_MINPLUS) ? (std::getenv("STEREO_HIP_TRWS_LEAN_WIDE") ? 1 : 2) : 0;
+  // MINPLUS in the wide-label regime runs the chunk-parallel kernel (trws_chunk.hip)
+  p.lean = (P->wide && P->mode == STEREO_TRWS_MESSAGES_MINPLUS) ? 1 : 0;
   p.prof = P->d_prof.p;
   p.timeline = P->d_timeline.p;
   p.desc[0] = P->d_desc[0].p; p.desc[1] = P->d_desc[1].p;
@@ -294,7 +293,7 @@ DevParams make_params(stereo_trws_plan *P) {
 void launch_persistent(stereo_trws_plan *P, const DevParams &p, int what, hipStream_t s) {
   const int epoch = ++P->epoch;
   STEREO_HIP_CHECK(hipMemsetAsync(P->d_ctl.p, 0, sizeof(int32_t), s));  // ticket = 0
-  if (P->wide && p.lean == 2) launch_chunk(what, std::min(P->grid_blocks, P->cus), s, p, epoch);
+  if (P->wide && p.lean) launch_chunk(what, std::min(P->grid_blocks, P->cus), s, p, epoch);
   else if (P->wide) launch_wide(what, std::min(P->grid_blocks, P->cus), s, p, epoch);
   else if (P->fast2) launch_pipe2(P->pos != nullptr, what, std::min(P->grid_blocks, P->cus), s, p, epoch);
   else if (P->fast) launch_pipe(P->kernel, P->pos != nullptr, what, P->grid_blocks, s, p, epoch);
@@ -936,7 +935,7 @@ static void launch_group(stereo_trws_plan *const *G, int n, int what, hipStream_
     if (what != 3) P->sweep_launches += 1;
   }
   ga.first[n] = total;
-  if (P0->wide && P0->mode == STEREO_TRWS_MESSAGES_MINPLUS && !std::getenv("STEREO_HIP_TRWS_LEAN_WIDE")) launch_chunk_group(what, total, s, ga, epoch);
+  if (P0->wide && P0->mode == STEREO_TRWS_MESSAGES_MINPLUS) launch_chunk_group(what, total, s, ga, epoch);
   else if (P0->wide) launch_wide_group(what, total, s, ga, epoch);
   else launch_pipe_group(P0->kernel, P0->pos != nullptr, what, total, s, ga, epoch);
   STEREO_HIP_CHECK(hipGetLastError());

@@ -236,11 +236,8 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           const int *sti = (const int *)(st + kWStI);
           const int f = __builtin_amdgcn_readfirstlane(sti[2]);
           const int nout = f & 15, nin = (f >> 4) & 15, ntot = nout + nin;
-          // lean (STEREO_TRWS_MESSAGES_MINPLUS): the message is the windowed min-plus, full stop -- the
-          // closest-pair waves stay idle, no second minimum, no verdicts, no serial construction
-          const bool lean = KERNEL == 1 && p.lean != 0;
-          const bool fast_msg = KERNEL == 1 && (p.certificate != 0 || lean);
-          const bool working = j0 < nout && (role == 0 || (fast_msg && !lean));
+          const bool fast_msg = KERNEL == 1 && p.certificate != 0;
+          const bool working = j0 < nout && (role == 0 || fast_msg);
           if (working || (BACKWARD && wave == 0)) {
             bool valid[4];
 #pragma unroll
@@ -361,16 +358,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                     // (equal costs from two sources count as a zero margin: serial path decides)
                     double m1[4] = {inf, inf, inf, inf}, m2[4] = {inf, inf, inf, inf};
                     const int w = p.window;
-                    if (lean && uniform && w <= kWPad) {
-                      for (int d = -w; d <= w; ++d) {
-                        const double ad = alpha * fabs((double)d * ustep);
-                        double hs[4];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) hs[c] = htab[c * kWave + lane + d];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) m1[c] = min_raw(m1[c], ad + hs[c]);
-                      }
-                    } else if (uniform && w <= kWPad) {
+                    if (uniform && w <= kWPad) {
                       for (int d = -w; d <= w; ++d) {
                         const double ad = alpha * fabs((double)d * ustep);  // == alpha |t - q| exactly
                         double hs[4];
@@ -417,20 +405,20 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                       }
                     }
                     bool bad = false;
-                    double vloc = inf;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                       if (valid[c]) {
-                        bad = bad || (!lean && m1[c] < vtrunc && !(m2[c] - m1[c] > delta && vtrunc - m1[c] > delta));
+                        bad = bad || (m1[c] < vtrunc && !(m2[c] - m1[c] > delta && vtrunc - m1[c] > delta));
                         out[c] = m1[c] < vtrunc ? m1[c] : vtrunc;
-                        vloc = min_raw(vloc, out[c]);
                       }
                     }
-                    vmin = wave_min_dpp(vloc);
+                    // the smallest entry of a min-plus message on shared positions is min H itself
+                    // (destination t sees source t at distance 0; vTrunc >= min H): no reduction
+                    vmin = hmin;
                     serial = UNI(bad);
                     WSTAMP(3);
                     // the verdicts of the two closest-pair waves of this message
-                    if (!lean) {
+                    {
                       int spins = 0;
                       for (;;) {
                         const int v = lane < 2 ? __hip_atomic_load(L.flags + 2 * j + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : (pos << 1);

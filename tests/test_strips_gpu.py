@@ -206,3 +206,21 @@ def test_a_strip_stores_its_own_rows_only(hip, oracle):
     lab, en, lb, _ = s.result()
     s.close()
     assert done == 3 and np.array_equal(lab, lab_o) and _close(en, en_o) and _close(lb, lb_o)
+
+
+def test_strips_in_the_minplus_mode_on_the_chunk_kernel(hip, oracle):
+    """MINPLUS messages with K = 200 run the chunk-parallel kernel; as two strips (group launch)
+    they still give the brute-force oracle's labels."""
+    from stereo_amd.strips import make_strips
+    from stereo_amd.trws import MESSAGES_MINPLUS
+    H, W, K = 14, 12, 200
+    p = trws_problem(141, H, W, K, kind="fronto")
+    pos = np.arange(K, dtype=np.float64)
+    lab_o, en_o, lb_o, _ = oracle.trws(1, p["unary"], p["conn"], p["q"], p["qprim"], p["alphas"], 6.0, 3, -1e300, mode=0)
+    s = make_strips(1, K, H, W, p["conn"].T, 2, message_mode=MESSAGES_MINPLUS)
+    s.upload(p["unary"].T, p["alphas"], 6.0, positions=pos)
+    s.iterate(3, max_relgap=-1e300)
+    lab, en, lb, _ = s.result()
+    assert s.path() == 3
+    s.close()
+    assert np.array_equal(lab, lab_o) and _close(en, en_o) and _close(lb, lb_o)

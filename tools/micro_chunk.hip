@@ -17,6 +17,7 @@ __global__ __launch_bounds__(512) void k(double *out, long long *cyc, int iters,
   __shared__ double tab[2][288];
   __shared__ double red[2][4];
   __shared__ int cnt;
+  extern __shared__ double aux[];  // 4 x 9 x 260 doubles for the aux waves
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < 9 * 260; i += 512) rows[i] = i * 0.001;
   for (int i = tid; i < 2 * 288; i += 512) tab[0][i] = 1e300;
@@ -64,6 +65,41 @@ __global__ __launch_bounds__(512) void k(double *out, long long *cyc, int iters,
     } else if (MODE == 1) {
       int spins = 0;
       while (__hip_atomic_load(gflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 1 && ++spins < 8) __builtin_amdgcn_s_sleep(1);
+    } else if (MODE == 2) {
+      // what a loader wave does: ~130 v_readlane (descriptor decode), nine 2 KB rows from memory into LDS
+      int w = gflag[64 + lane + (it & 7) * 64];
+      int sacc = 0;
+#pragma unroll
+      for (int r = 0; r < 64; ++r) sacc += __builtin_amdgcn_readlane(w, r);
+#pragma unroll
+      for (int r = 0; r < 64; ++r) sacc ^= __builtin_amdgcn_readlane(w + sacc, r);
+      double v[9][4];
+#pragma unroll
+      for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[j][c] = out[512 + ((sacc & 7) + j) * 256 + c * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) aux[(wave - 4) * 9 * 260 + j * 260 + c * 64 + lane] = v[j][c];
+    } else if (MODE == 3) {
+      int w = gflag[64 + lane + (it & 7) * 64];
+      int sacc = 0;
+#pragma unroll
+      for (int r = 0; r < 64; ++r) sacc += __builtin_amdgcn_readlane(w, r);
+#pragma unroll
+      for (int r = 0; r < 64; ++r) sacc ^= __builtin_amdgcn_readlane(w + sacc, r);
+      if (sacc == 12345) out[0] = 1;
+    } else if (MODE == 4) {
+      double v[9][4];
+#pragma unroll
+      for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[j][c] = out[512 + ((it & 7) + j) * 256 + c * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) aux[(wave - 4) * 9 * 260 + j * 260 + c * 64 + lane] = v[j][c];
     }
     if (use_barrier) __syncthreads();
   }
@@ -75,9 +111,10 @@ __global__ __launch_bounds__(512) void k(double *out, long long *cyc, int iters,
 template <int MODE>
 void run(const char *what, int use_barrier) {
   double *out; long long *cyc; int *gflag;
-  hipMalloc(&out, 512 * 8); hipMalloc(&cyc, 8); hipMalloc(&gflag, 4); hipMemset(gflag, 0, 4);
+  hipMalloc(&out, (512 + 32 * 256) * 8); hipMemset(out, 0, (512 + 32 * 256) * 8); hipMalloc(&cyc, 8); hipMalloc(&gflag, 4 * 1024); hipMemset(gflag, 0, 4 * 1024);
   const int iters = 20000;
-  hipLaunchKernelGGL(k<MODE>, dim3(1), dim3(512), 0, 0, out, cyc, iters, gflag, use_barrier);
+  hipFuncSetAttribute((const void *)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 9 * 260 * 8);
+  hipLaunchKernelGGL(k<MODE>, dim3(1), dim3(512), 4 * 9 * 260 * 8, 0, out, cyc, iters, gflag, use_barrier);
   hipDeviceSynchronize();
   long long h; hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
   printf("%-60s %.0f cycles per visit\n", what, (double)h / iters);
@@ -88,5 +125,8 @@ int main() {
   run<0>("4 compute waves, 4 idle waves exit the loop body at once", 0);
   run<0>("the same + one s_barrier of all 8 waves per visit", 1);
   run<1>("4 compute + 4 waves polling a global flag (s_sleep 1), barrier", 1);
+  run<2>("4 compute + 4 loader-like waves (readlanes + 18 KB to LDS), barrier", 1);
+  run<3>("4 compute + 4 waves doing 128 v_readlane each, barrier", 1);
+  run<4>("4 compute + 4 waves moving 18 KB from memory to LDS each, barrier", 1);
   return 0;
 }

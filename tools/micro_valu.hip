@@ -34,17 +34,28 @@ __global__ void k(double *out, long long *cyc, int iters) {
   for (int i = 0; i < 8; ++i) s += a[i];
   out[threadIdx.x] = s;
   if (threadIdx.x == 0) cyc[0] = t1 - t0;
+  atomicMax((unsigned long long *)cyc + 1, (unsigned long long)(t1 - t0));  // the slowest wave
 }
 
 int main() {
   double *out; long long *cyc;
-  hipMalloc(&out, 64 * 8); hipMalloc(&cyc, 8);
-  hipMemset(out, 0, 64 * 8);
+  hipMalloc(&out, 1024 * 8); hipMalloc(&cyc, 16);
+  hipMemset(out, 0, 1024 * 8);
   const char *names[] = {"v_add_f64", "v_min_f64(+add)", "v_max_f64", "v_mul_f64", "cmp+select(+add)", "dependent ds_read", "asm v_min_f64", "v_add_u32", "v_min_i32 / cmp+cndmask b32", "v_mov_dpp", "v_fma_f64"};
   const int iters = 2000;
   long long h;
 #define RUN(OP) hipLaunchKernelGGL(k<OP>, dim3(1), dim3(64), 0, 0, out, cyc, iters); hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost); \
   printf("%-22s %.2f cycles per instruction group (8 independent chains)\n", names[OP], (double)h / (iters * 8.0));
   RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10)
+  // how the cost per wave changes with more waves on the CU (1 wave per SIMD at 256 threads, 2 at 512, 4 at 1024)
+  for (int threads = 64; threads <= 1024; threads *= 2) {
+    long long hh[2];
+    hipMemset(cyc, 0, 16);
+    hipLaunchKernelGGL(k<0>, dim3(1), dim3(threads), 0, 0, out, cyc, iters); hipMemcpy(hh, cyc, 16, hipMemcpyDeviceToHost);
+    printf("v_add_f64, %4d threads in the workgroup: %.2f cycles per instruction of wave 0, %.2f of the slowest wave\n", threads, (double)hh[0] / (iters * 8.0), (double)hh[1] / (iters * 8.0));
+    hipMemset(cyc, 0, 16);
+    hipLaunchKernelGGL(k<7>, dim3(1), dim3(threads), 0, 0, out, cyc, iters); hipMemcpy(hh, cyc, 16, hipMemcpyDeviceToHost);
+    printf("v_add_u32, %4d threads in the workgroup: %.2f cycles per instruction of wave 0, %.2f of the slowest wave\n", threads, (double)hh[0] / (iters * 8.0), (double)hh[1] / (iters * 8.0));
+  }
   return 0;
 }
