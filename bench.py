@@ -187,6 +187,9 @@ def main():
     ap.add_argument("--width", type=int, default=450)
     ap.add_argument("--labels", type=int, default=60)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the labelled index-order extra (profiling: its launches are the same kernel and "
+                         "would be averaged into the headline kernel's rocprofv3 statistics)")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--message-mode", choices=["exact", "minplus"], default="exact")
     ap.add_argument("--volume", choices=["ncc", "noise"], default="ncc",
@@ -270,15 +273,17 @@ def main():
     # (STEREO_TRWS_ORDER_INDEX: MRFEnergy without SetAutomaticOrdering; H + W - 1 dependency levels,
     # no serial border chain) -- a valid TRW-S schedule whose results are not the gateway's
     from stereo_amd.trws import ORDER_INDEX
-    alt = TrwsPlan(1, K, N, conn.T, message_mode=(0 if args.message_mode == "exact" else 1) | ORDER_INDEX)
-    alt.bind_device(d_unary.data_ptr(), d_alpha.data_ptr(), 8.0, d_positions=d_pos.data_ptr())
-    alt.iterate(args.warmup, max_relgap=NEVER)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    alt.iterate(args.steps, max_relgap=NEVER)
-    alt_dt = time.perf_counter() - t1
-    _, alt_en, alt_lb, _ = alt.result(want_labels=False)
-    alt.close()
+    alt_dt = alt_en = alt_lb = float("nan")
+    if not args.no_extras:
+        alt = TrwsPlan(1, K, N, conn.T, message_mode=(0 if args.message_mode == "exact" else 1) | ORDER_INDEX)
+        alt.bind_device(d_unary.data_ptr(), d_alpha.data_ptr(), 8.0, d_positions=d_pos.data_ptr())
+        alt.iterate(args.warmup, max_relgap=NEVER)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        alt.iterate(args.steps, max_relgap=NEVER)
+        alt_dt = time.perf_counter() - t1
+        _, alt_en, alt_lb, _ = alt.result(want_labels=False)
+        alt.close()
 
     if rank == 0:
         a = analyze(N, conn.T)
@@ -330,6 +335,8 @@ def main():
                                    + " (one persistent launch per sweep)", "bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches_per_iter},
         }
+        if args.no_extras:
+            out.pop("index_order_option")
         if world == 1 and not args.no_cpu_baseline:  # reported baseline: rank 0 at N=1 only
             from oracle import pyoracle
             q = np.tile(np.arange(K, dtype=np.float64), (E, 1))
