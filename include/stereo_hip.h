@@ -222,6 +222,15 @@ int stereo_trws_plan_bind_device_strip(stereo_trws_plan *plan, const double *d_u
                                        const double *d_q, const double *d_qprim,
                                        const double *d_positions, const double *d_alphas,
                                        double tol, char *err, size_t errcap);
+/* The same without a device: what strip `strip` of the problem stores, and the descriptors of its
+ * own visits in sweep `direction` (0 forward, 1 backward) after renumbering -- n_visits x 64 words,
+ * layout in stereo_amd/csrc/trws_graph.h (words 0 node, 4-11 edges, 20-23 dependencies, 32-39
+ * neighbours, 43 remote bits, 45-52 / 53-54 the neighbour strips' ids).  Sizes first (arrays
+ * NULL), then the arrays.  For tests of the multi-GPU decomposition on a host without GPUs. */
+int stereo_trws_strip_layout_host(int64_t N, int64_t E, const uint32_t *conn, const int32_t *owner,
+                                  int nstrips, int strip, int direction, int64_t *n_nodes,
+                                  int64_t *n_own, int64_t *n_edges, int64_t *n_visits, int32_t *nodes,
+                                  int32_t *edges, int32_t *desc, char *err, size_t errcap);
 /* Diagnostics (any output may be NULL). */
 int stereo_trws_plan_strip_info(stereo_trws_plan *plan, int *nstrips, int *strip, int64_t *own_nodes,
                                 int64_t *runs_forward, int64_t *runs_backward, int *needs_previous,

@@ -664,3 +664,32 @@ extern "C" int stereo_trws_schedule_strips(int64_t N, int64_t E, const uint32_t 
   return schedule_impl(N, E, conn, max_resident_runs, direction, owner, nstrips, rank_at, run_ptr, nruns, ticket_run,
                        pred_rank, dep_ptr, dep_rank, run_strip, remote, "stereo_trws_schedule_strips", err, errcap);
 }
+
+// Host-only view of what one strip stores and of its renumbered descriptors (no device needed):
+// lets a CPU test check that the ids a strip writes into its neighbours' arrays are the ids the
+// neighbours use themselves.
+extern "C" int stereo_trws_strip_layout_host(int64_t N, int64_t E, const uint32_t *conn, const int32_t *owner,
+                                             int nstrips, int strip, int direction, int64_t *n_nodes, int64_t *n_own,
+                                             int64_t *n_edges, int64_t *n_visits, int32_t *nodes, int32_t *edges,
+                                             int32_t *desc, char *err, size_t errcap) {
+  if (!conn || !owner || nstrips < 1 || strip < 0 || strip >= nstrips || (direction != 0 && direction != 1))
+    return stereo::fail("stereo_trws_strip_layout_host: bad argument", err, errcap);
+  try {
+    stereo::TrwsGraph g;
+    std::string gerr;
+    if (!stereo::build_trws_graph(N, E, conn, g, gerr, 0, owner, nstrips)) return stereo::fail(gerr, err, errcap);
+    if (!g.fast_ok) return stereo::fail("stereo_trws_strip_layout_host: graph outside the descriptor-driven kernels' range", err, errcap);
+    stereo::StripLayout L;
+    if (!stereo::build_strip_layout(g, strip, L, gerr)) return stereo::fail(gerr, err, errcap);
+    if (n_nodes) *n_nodes = (int64_t)L.nodes.size();
+    if (n_own) *n_own = L.n_own;
+    if (n_edges) *n_edges = (int64_t)L.edges.size();
+    if (n_visits) *n_visits = (int64_t)(L.desc[direction].size() / stereo::TrwsGraph::kDescWords);
+    if (nodes) std::copy(L.nodes.begin(), L.nodes.end(), nodes);
+    if (edges) std::copy(L.edges.begin(), L.edges.end(), edges);
+    if (desc) std::copy(L.desc[direction].begin(), L.desc[direction].end(), desc);
+    return 0;
+  } catch (const std::exception &e) {
+    return stereo::fail(std::string("stereo_trws_strip_layout_host: ") + e.what(), err, errcap);
+  }
+}

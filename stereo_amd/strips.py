@@ -367,6 +367,24 @@ def schedule_strips(N, connectivity0, direction, owner, nstrips, max_resident_ru
                 dep_ptr=dep_ptr, dep_rank=dep_rank[:dep_ptr[N]], run_strip=run_strip[:R], remote=remote)
 
 
+def strip_layout_host(N, connectivity0, owner, nstrips, strip, direction):
+    """Host-only: what a strip stores and its renumbered descriptors (stereo_trws_strip_layout_host).
+    Returns dict(nodes, n_own, edges, desc (n_visits x 64 int32))."""
+    c = _conn_f(connectivity0)
+    E = c.shape[1]
+    owner = np.ascontiguousarray(owner, dtype=np.int32)
+    nn, no, ne, nv = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    err = _lib.errbuf()
+    f = _lib.lib().stereo_trws_strip_layout_host
+    head = (C.c_int64(N), C.c_int64(E), _ptr(c, C.c_uint32), _ptr(owner, C.c_int32), C.c_int(nstrips), C.c_int(strip),
+            C.c_int(direction), C.byref(nn), C.byref(no), C.byref(ne), C.byref(nv))
+    _lib.check(f(*head, None, None, None, err, C.c_size_t(len(err))), err)
+    nodes, edges = np.zeros(nn.value, np.int32), np.zeros(ne.value, np.int32)
+    desc = np.zeros((nv.value, 64), np.int32)
+    _lib.check(f(*head, _ptr(nodes, C.c_int32), _ptr(edges, C.c_int32), _ptr(desc, C.c_int32), err, C.c_size_t(len(err))), err)
+    return dict(nodes=nodes, n_own=int(no.value), edges=edges, desc=desc)
+
+
 def dataflow_reference(sched, analysis_in):
     """Serial model of one sweep: value[r] = mix(r, values of every incoming neighbour), in the
     order of the schedule positions.  `analysis_in[r]` = ranks of the incoming neighbours of rank r

@@ -184,3 +184,60 @@ def test_gloo_ranks_hand_over_strip_boundaries(world, tmp_path):
     assert all(r["ok"]) and len(r["ok"]) == world
     # per sweep a boundary row hands 17 columns (+ the two border-chain crossings) each way
     assert all(n > 0 for n in r["sent"])
+
+
+@pytest.mark.parametrize("shape,G", [((20, 24), 2), ((21, 17), 4), ((9, 30), 3), ((12, 5), 6)])
+def test_strip_local_ids_agree_between_neighbours(shape, G):
+    """Strip-local storage (what lets 8 GPUs hold a volume none of them could hold alone): every
+    strip numbers its nodes, halo and edges itself, and writes boundary messages / flags / labels
+    into its neighbours' arrays at THEIR ids (descriptor words 45-54).  Checked on the host: the
+    strips partition the visits, every id is inside the strip's arrays, and a peer id names, in the
+    neighbour's own numbering, the very edge / node the writer means."""
+    from stereo_amd.strips import strip_layout_host, row_strip_owner
+    H, W = shape
+    N = H * W
+    conn = grid_conn(H, W)
+    E = conn.shape[0]
+    own = row_strip_owner(H, W, G)
+    for direction in (0, 1):
+        L = [strip_layout_host(N, conn.T, own, G, s, direction) for s in range(G)]
+        visited = np.zeros(N, dtype=np.int64)
+        for s in range(G):
+            nodes, n_own, edges, desc = L[s]["nodes"], L[s]["n_own"], L[s]["edges"], L[s]["desc"]
+            assert np.all(own[nodes[:n_own]] == s) and np.all(own[nodes[n_own:]] != s)
+            assert len(np.unique(nodes)) == len(nodes) and len(np.unique(edges)) == len(edges)
+            touching = (own[conn[:, 0]] == s) | (own[conn[:, 1]] == s)
+            assert np.array_equal(edges, np.nonzero(touching)[0])
+            assert desc.shape[0] == n_own                      # one visit per own node and sweep
+            for D in desc:
+                v = D[0]
+                assert 0 <= v < n_own and D[1] == v
+                gv = nodes[v]
+                visited[gv] += 1
+                nout, nin, nd = D[2] & 15, (D[2] >> 4) & 15, (D[2] >> 8) & 15
+                rem = int(D[43]) & 0xFFFFFFFF
+                for k in range(nout + nin):
+                    assert 0 <= D[4 + k] < len(edges)
+                    ge = edges[D[4 + k]]
+                    assert gv in conn[ge]                      # the edge is at this node
+                    other = conn[ge, 0] + conn[ge, 1] - gv
+                    if k >= nout:                              # incoming: the neighbour whose label the primal reads
+                        assert nodes[D[32 + k]] == other
+                    elif (rem >> k) & 1:                       # outgoing into a neighbour strip
+                        peer = s + (1 if (rem >> (8 + k)) & 1 else -1)
+                        assert own[other] == peer
+                        assert L[peer]["edges"][D[45 + k]] == ge          # the neighbour's id of the same edge
+                    else:
+                        assert own[other] == s
+                for k in range(nd):
+                    assert 0 <= D[20 + k] < len(nodes)         # a flag this strip holds (own node or halo)
+                if rem & (1 << 16):
+                    assert s > 0 and L[s - 1]["nodes"][D[53]] == gv     # flag / label also raised at strip - 1 ...
+                if rem & (1 << 17):
+                    assert s + 1 < G and L[s + 1]["nodes"][D[54]] == gv  # ... / strip + 1, at their id of this node
+                # a node next to another strip's node is announced there
+                nbr_strips = {int(own[conn[e, 0] + conn[e, 1] - gv]) for e in np.nonzero((conn[:, 0] == gv) | (conn[:, 1] == gv))[0]}
+                out_strips = {s + (1 if (rem >> (8 + k)) & 1 else -1) for k in range(nout) if (rem >> k) & 1}
+                assert out_strips <= nbr_strips - {s}
+                assert bool(rem & (1 << 16)) == (s - 1 in out_strips) and bool(rem & (1 << 17)) == (s + 1 in out_strips)
+        assert np.all(visited == 1)

@@ -12,6 +12,7 @@ from oracle import pyoracle as po
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t0, n, bad = time.time(), 0, 0
+modes = {}
 while time.time() - t0 < budget:
     H, W = int(rng.integers(1, 70)), int(rng.integers(2, 70))
     K = int(rng.choice([2, 3, 5, 8, 16, 31, 60, 64, 65, 100, 200, 256]))
@@ -33,18 +34,35 @@ while time.time() - t0 < budget:
         q = np.tile(pos, (p["conn"].shape[0], 1)); qp = q
     else:
         q, qp = p["q"], p["qprim"]
-    ref = po.trws(kernel, p["unary"], p["conn"], q, qp, p["alphas"], tol, iters, -1e300, mode=1)
-    plan = TrwsPlan(kernel, K, H * W, p["conn"].T)
+    # message mode, node order and row strips drawn too (strips: labels bit for bit, scalars to 1e-12)
+    minplus = bool(rng.integers(0, 4) == 0)
+    ordering = int(rng.integers(0, 4) == 0)
+    G = int(rng.choice([1, 1, 2, 3]))
+    if G > 1 and (H < 2 * G or (minplus and not (shared and K > 64)) or (K > 64 and not shared) or (kernel == 2 and K > 64)):
+        G = 1
+    ref = po.trws(kernel, p["unary"], p["conn"], q, qp, p["alphas"], tol, iters, -1e300, mode=0 if minplus else 1,
+                  ordering=ordering)
+    mode = (1 if minplus else 0) | (0x100 if ordering else 0)
+    if G == 1:
+        plan = TrwsPlan(kernel, K, H * W, p["conn"].T, message_mode=mode)
+    else:
+        from stereo_amd.strips import make_strips
+        plan = make_strips(kernel, K, H, W, p["conn"].T, G, message_mode=mode)
     if shared:
         plan.upload(p["unary"].T, p["alphas"], tol, positions=pos)
     else:
         plan.upload(p["unary"].T, p["alphas"], tol, q=q.T, qprim=qp.T)
     plan.iterate(iters, max_relgap=-1e300)
     got = plan.result()
-    ok = np.array_equal(got[0], ref[0]) and got[1] == ref[1] and got[2] == ref[2]
+    path = plan.path()
+    plan.close()
+    close = lambda a, b: abs(a - b) <= 1e-12 * max(abs(a), abs(b), 1.0)
+    ok = np.array_equal(got[0], ref[0]) and ((got[1] == ref[1] and got[2] == ref[2]) if G == 1 else (close(got[1], ref[1]) and close(got[2], ref[2])))
+    modes[(minplus, ordering, G, path)] = modes.get((minplus, ordering, G, path), 0) + 1
     n += 1
     if not ok:
         bad += 1
-        print("MISMATCH", dict(seed=seed, H=H, W=W, K=K, kernel=kernel, shared=shared, integer=integer, tol=tol, iters=iters, path=plan.path()))
+        print("MISMATCH", dict(seed=seed, H=H, W=W, K=K, kernel=kernel, shared=shared, integer=integer, tol=tol, iters=iters, path=path, minplus=minplus, ordering=ordering, strips=G))
 print("stress: %d problems, %d mismatches, %.0f s" % (n, bad, time.time() - t0))
+print("(minplus, index order, strips, kernel path) -> problems:", sorted(modes.items()))
 sys.exit(1 if bad else 0)
