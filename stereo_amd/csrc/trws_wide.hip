@@ -38,8 +38,8 @@ constexpr int kWPad = 16;   // min-plus source table is padded by this many (+in
 constexpr int kWScr = 2 * (256 + 2 * kWPad);  // per compute wave scratch: (h, q) source table | 256 keys + 516 ints
 constexpr int kWBuckets = 512;
 constexpr int kWStI = kWS + 8 * kWS + 8;            // int area of a stage (in doubles)
-constexpr int kWStage = kWStI + 36;
-// stage: D[kWS] m[8][kWS] a[8] | ints desc[64] px[8]
+constexpr int kWStage = kWStI + 40;  // ints: desc[64] px[8] row[8]
+// stage: D[kWS] m[8][kWS] a[8] | ints desc[64] px[8] row[8] (row: where Di's k-th message row lives in LDS, in doubles)
 
 struct WidePtrs {
   double *stage0, *hand, *scr, *fb, *pos, *scal, *msc;
@@ -244,8 +244,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
             for (int c = 0; c < 4; ++c) valid[c] = c * kWave + lane < K;
             double di[4] = {inf, inf, inf, inf};
             if (role == 0) {
-            const unsigned slA = (unsigned)__builtin_amdgcn_readfirstlane(sti[41]);
-            const unsigned slB = (unsigned)__builtin_amdgcn_readfirstlane(sti[42]);
+            const int myrow = sti[72 + (lane & 7)];  // LDS offsets of the message rows (written by loader A)
             // Di = D + messages in list order (from the ring where the neighbour was one of
             // the last two visits of this run), formed by the min-plus wave of each message
             // (reads are unconditional -- rows are padded to 256 -- and masked afterwards, so that
@@ -255,8 +254,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
               if (jj < ntot) {
-                const int sl = jj >= nout ? (int)(signed char)(((jj < 4 ? slA : slB) >> (8 * (jj & 3))) & 255) : -1;
-                const double *src = sl >= 8 ? hprev2 + (sl - 8) * kWS : sl >= 0 ? hprev + sl * kWS : st + kWS + jj * kWS;
+                const double *src = lds + __builtin_amdgcn_readlane(myrow, jj);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) di[c] += src[c * kWave + lane];
               }
@@ -489,6 +487,21 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           const NodeDesc nx = decode_desc(w);
           int *stni = (int *)(stn + kWStI);
           stni[lane] = w;
+          {
+            // where the compute waves find the node's message rows at visit pos + 1 (offsets into the
+            // workgroup's LDS, in doubles): a message handed over inside the run sits in the ring of
+            // the last two visits, everything else in this stage -- decided here, once, instead of by
+            // every compute wave in scalar code on its critical path
+            int sl = -1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (lane == j) sl = j >= nx.nout ? nx.slot[j] : -1;
+            const int hb1n = ((pos % 3) + 3) % 3, hb2n = (((pos - 1) % 3) + 3) % 3;  // hprev / hprev2 of visit pos + 1
+            const int row = sl >= 8 ? (int)(L.hand - lds) + hb2n * 8 * kWS + (sl - 8) * kWS
+                          : sl >= 0 ? (int)(L.hand - lds) + hb1n * 8 * kWS + sl * kWS
+                                    : (int)(stn - lds) + kWS + lane * kWS;
+            if (lane < 8) stni[72 + lane] = row;
+          }
           L.dring[((pos + 1) % 3) * 64 + lane] = w;
           const int ntot = nx.nout + nx.nin;
           // all requests go out before anything is consumed (registers first, LDS at the end)

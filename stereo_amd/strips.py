@@ -178,6 +178,12 @@ def _conn_f(connectivity0):
     return np.asfortranarray(c, dtype=np.uint32)
 
 
+def _relgap(en, lb):
+    """(E - LB) / E as minimize.cpp:105 computes it in C: E == 0 gives inf or NaN, never an exception."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return float(np.float64(en - lb) / np.float64(en))
+
+
 def _combine(parts):
     """Partial (lb, energy) sums added in strip order: deterministic, independent of arrival order."""
     lb = en = 0.0
@@ -255,7 +261,7 @@ class TrwsStrips:
             self.lb, self.energy = lb, en
             self.iterations += 1
             done += 1
-            if (en - lb) / en < max_relgap:  # minimize.cpp:105
+            if _relgap(en, lb) < max_relgap:  # minimize.cpp:105
                 return done, True
         return done, False
 
@@ -331,7 +337,7 @@ class TrwsStripRank:
             self.lb, self.energy = lb, en
             self.iterations += 1
             done += 1
-            if (en - lb) / en < max_relgap:
+            if _relgap(en, lb) < max_relgap:
                 return done, True
         return done, False
 

@@ -224,3 +224,20 @@ def test_strips_in_the_minplus_mode_on_the_chunk_kernel(hip, oracle):
     assert s.path() == 3
     s.close()
     assert np.array_equal(lab, lab_o) and _close(en, en_o) and _close(lb, lb_o)
+
+
+def test_strips_stop_test_with_zero_energy(hip, oracle):
+    """(E - LB) / E with E == 0 is inf or NaN in minimize.cpp:105, not an error: an all-zero problem
+    iterates to maxiter (found by tools/stress_trws.py)."""
+    from stereo_amd.strips import make_strips
+    H, W, K = 6, 7, 5
+    p = trws_problem(151, H, W, K, kind="fronto")
+    p["unary"][:] = 0.0
+    pos = np.arange(K, dtype=np.float64)
+    lab_o, en_o, lb_o, it_o = oracle.trws(1, p["unary"], p["conn"], p["q"], p["qprim"], p["alphas"], 2.0, 3, 0.0, mode=1)
+    s = make_strips(1, K, H, W, p["conn"].T, 2)
+    s.upload(p["unary"].T, p["alphas"], 2.0, positions=pos)
+    done, stopped = s.iterate(3, max_relgap=0.0)
+    lab, en, lb, _ = s.result()
+    s.close()
+    assert en_o == 0.0 and en == 0.0 and done == it_o and np.array_equal(lab, lab_o)
