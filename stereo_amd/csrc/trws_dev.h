@@ -808,7 +808,7 @@ constexpr int kPipeThreads = kPipeWaves * kWave;
 // LDS stage layout (doubles): D[64] m[8][64] qv[8][64] qpv[8][64] | a[8] | ints: desc[64] px[8]
 constexpr int kStD = 0, kStM = 64, kStQ = 64 + 512, kStQP = 64 + 1024, kStA = 64 + 1536;
 constexpr int kStI = kStA + 8;                    // int area starts here (as doubles)
-constexpr int kStageDoubles = kStI + 36;          // 64 + 8 ints = 36 doubles
+constexpr int kStageDoubles = kStI + 40;          // ints: desc[64] px[8] row[8] (where Di's k-th message row lives in LDS)
 constexpr int kScalDoubles = 16;                  // newv[8], node_vmin, prim_e, x (as int)
 constexpr int kPipePad = 16;                      // source tables are padded by this many (+inf) entries on both sides
 constexpr int kPipeTab = 4 * (kWave + 2 * kPipePad);  // doubles per compute wave: (h, q, u, v) x 96

@@ -81,19 +81,14 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           const int *sti = (const int *)(st + kStI);
           const int f = __builtin_amdgcn_readfirstlane(sti[2]);
           const int nout = f & 15, nin = (f >> 4) & 15, md = (f >> 16) & 255, ntot = nout + nin;
-          const unsigned slA = (unsigned)__builtin_amdgcn_readfirstlane(sti[41]);
-          const unsigned slB = (unsigned)__builtin_amdgcn_readfirstlane(sti[42]);
+          const int myrow = sti[72 + (lane & 7)];  // LDS offsets (doubles) of the node's message rows, from the loader
           if (wave < nout || (BACKWARD && wave == 0)) {  // waves without a message stay out of the way
           double Di = act ? st[kStD + lane] : 0.0;
           double mown = 0;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             if (j < ntot) {
-              double v;
-              const int sl = j >= nout ? (int)(signed char)(((j < 4 ? slA : slB) >> (8 * (j & 3))) & 255) : -1;
-              if (sl >= 8) v = hprev2[(sl - 8) * kWave + lane];
-              else if (sl >= 0) v = hprev[sl * kWave + lane];
-              else v = st[kStM + j * kWave + lane];
+              const double v = lds[__builtin_amdgcn_readlane(myrow, j) + lane];
               Di += v;
               if (j == wave && j < nout) mown = v;
             }
@@ -139,6 +134,19 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           int *stni = (int *)(stn + kStI);
           stni[lane] = w;
           dring[((pos + 1) % 3) * kWave + lane] = w;
+          {
+            // where the compute waves find the node's message rows at visit pos + 1: a message handed
+            // over inside the run sits in the ring of the last two visits, everything else in this
+            // stage -- decided once here instead of by every compute wave in scalar code
+            int slr = -1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (lane == j) slr = j >= nx.nout ? nx.slot[j] : -1;
+            const int row = slr >= 8 ? (int)(hand - lds) + ((pos - 1) & 3) * 8 * kWave + (slr - 8) * kWave
+                          : slr >= 0 ? (int)(hand - lds) + (pos & 3) * 8 * kWave + slr * kWave
+                                     : (int)(stn - lds) + kStM + lane * kWave;
+            if (lane < 8) stni[72 + lane] = row;
+          }
           const int ntot = nx.nout + nx.nin;
           // everything that does not depend on other workgroups is requested first ...
           double dk = 0, mv[8], qv[8], qpv[8];
