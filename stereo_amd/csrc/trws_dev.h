@@ -805,9 +805,10 @@ constexpr int kPipeCompute = 8;  // one compute wave per outgoing message (<= 8 
 constexpr int kPipeWaves = kPipeCompute + 4;  // loader, storer, (idle), primal: the primal wave lands on SIMD 3,
                                               // which otherwise hosts one compute wave only
 constexpr int kPipeThreads = kPipeWaves * kWave;
-// LDS stage layout (doubles): D[64] m[8][64] qv[8][64] qpv[8][64] | a[8] | ints: desc[64] px[8]
+// LDS stage layout (doubles): D[64] m[8][64] qv[8][64] qpv[8][64] | a[8] gamma pad | ints: desc[64] px[8] row[8]
 constexpr int kStD = 0, kStM = 64, kStQ = 64 + 512, kStQP = 64 + 1024, kStA = 64 + 1536;
-constexpr int kStI = kStA + 8;                    // int area starts here (as doubles)
+constexpr int kStG = kStA + 8;                    // gamma = 1 / max(n_out, n_in) of the node (the loader's division)
+constexpr int kStI = kStA + 10;                   // int area starts here (as doubles)
 constexpr int kStageDoubles = kStI + 40;          // ints: desc[64] px[8] row[8] (where Di's k-th message row lives in LDS)
 constexpr int kScalDoubles = 16;                  // newv[8], node_vmin, prim_e, x (as int)
 constexpr int kPipePad = 16;                      // source tables are padded by this many (+inf) entries on both sides

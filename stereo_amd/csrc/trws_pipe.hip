@@ -102,7 +102,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             if (j == wave && j < nout) {
-              const double gamma = (double)1 / (double)(nout > nin ? nout : nin);
+              const double gamma = st[kStG];  // (double)1 / (double)max(n_out, n_in), MRFEnergy.cpp:207-228
               const double h = act ? gamma * Di - mown : inf;
               const bool src_is_qprim = ((BACKWARD ? 1 : 0) == ((md >> j) & 1));
               double qsrc = posk, qdst = posk;
@@ -201,6 +201,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
             }
           }
           if (lane < 8) { stn[kStA + lane] = av; stni[64 + lane] = pxv; }
+          if (lane == 0) stn[kStG] = (double)1 / (double)(nx.nout > nx.nin ? nx.nout : nx.nin);
         }
       } else if (wave == kPipeCompute + 1) {
         // ------------------------------------------------------------ storer: node pos - 1
