@@ -31,7 +31,8 @@ constexpr int kChunkThreads = kChunkWaves * kWave;
 constexpr int kWS = 260;    // LDS row stride in doubles
 constexpr int kWPad = 16;   // the H tables are padded by this many +inf entries on both sides
 constexpr int kCTab = 256 + 2 * kWPad;
-constexpr int kWStI = kWS + 8 * kWS + 8;            // int area of a stage (in doubles)
+constexpr int kWStG = kWS + 8 * kWS + 8;            // gamma = 1 / max(n_out, n_in) of the node (the loader's division)
+constexpr int kWStI = kWS + 8 * kWS + 10;           // int area of a stage (in doubles)
 constexpr int kWStage = kWStI + 40;  // ints: desc[64] px[8] row[8]
 // stage: D[kWS] m[8][kWS] a[8] | ints desc[64] px[8] row[8] (row: where Di's k-th message row lives in LDS, in doubles)
 
@@ -182,7 +183,7 @@ __device__ __forceinline__ void chunk_body(DevParams p, int epoch) {
             di -= node_vmin;
           }
           WSTAMP(0);
-          const double gamma = (double)1 / (double)(nout > nin ? nout : nin);
+          const double gamma = st[kWStG];  // (double)1 / (double)max(n_out, n_in)
           const int w = p.window;
           for (int j0 = 0; j0 < nout; j0 += 4) {
             // ---- H_j = gamma Di - m_j of up to four messages into their tables, and the chunks' minima
@@ -314,6 +315,7 @@ __device__ __forceinline__ void chunk_body(DevParams p, int epoch) {
             }
           }
           if (lane < 8) stn[kWS + 8 * kWS + lane] = av;
+          if (lane == 0) stn[kWStG] = (double)1 / (double)(nx.nout > nx.nin ? nx.nout : nx.nin);
         }
       CHUNK_VISITS_END
     } else if (wave == kChunkCompute + 1) {

@@ -84,14 +84,12 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           const int myrow = sti[72 + (lane & 7)];  // LDS offsets (doubles) of the node's message rows, from the loader
           if (wave < nout || (BACKWARD && wave == 0)) {  // waves without a message stay out of the way
           double Di = act ? st[kStD + lane] : 0.0;
-          double mown = 0;
+          // (this wave's own old message is one of the rows; it is read once more below rather than
+          //  picked out of the loop with eight selects)
+          const double mown = st[kStM + (wave < nout ? wave : 0) * kWave + lane];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            if (j < ntot) {
-              const double v = lds[__builtin_amdgcn_readlane(myrow, j) + lane];
-              Di += v;
-              if (j == wave && j < nout) mown = v;
-            }
+            if (j < ntot) Di += lds[__builtin_amdgcn_readlane(myrow, j) + lane];
           }
           double node_vmin = 0;
           if (BACKWARD) {
@@ -99,9 +97,9 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
             Di -= node_vmin;
             if (tid == 0) sc[8] = node_vmin;
           }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if (j == wave && j < nout) {
+          {
+            const int j = wave;  // one compute wave per outgoing message
+            if (j < nout) {
               const double gamma = st[kStG];  // (double)1 / (double)max(n_out, n_in), MRFEnergy.cpp:207-228
               const double h = act ? gamma * Di - mown : inf;
               const bool src_is_qprim = ((BACKWARD ? 1 : 0) == ((md >> j) & 1));

@@ -37,7 +37,8 @@ constexpr int kWS = 260;    // LDS row stride in doubles (>= 256 + 1 breakpoints
 constexpr int kWPad = 16;   // min-plus source table is padded by this many (+inf, 0) entries on both sides
 constexpr int kWScr = 2 * (256 + 2 * kWPad);  // per compute wave scratch: (h, q) source table | 256 keys + 516 ints
 constexpr int kWBuckets = 512;
-constexpr int kWStI = kWS + 8 * kWS + 8;            // int area of a stage (in doubles)
+constexpr int kWStG = kWS + 8 * kWS + 8;            // gamma = 1 / max(n_out, n_in) of the node (the loader's division)
+constexpr int kWStI = kWS + 8 * kWS + 10;           // int area of a stage (in doubles)
 constexpr int kWStage = kWStI + 40;  // ints: desc[64] px[8] row[8]
 // stage: D[kWS] m[8][kWS] a[8] | ints desc[64] px[8] row[8] (row: where Di's k-th message row lives in LDS, in doubles)
 
@@ -271,7 +272,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
             }
             WSTAMP(0);
             for (int j = j0; working && j < nout; j += 4) {
-              const double gamma = (double)1 / (double)(nout > nin ? nout : nin);
+              const double gamma = st[kWStG];  // (double)1 / (double)max(n_out, n_in)
               const double alpha = st[kWS + 8 * kWS + j];
               const bool constant = UNI(alpha == 0);
               double h[4] = {inf, inf, inf, inf}, hmin = 0, hmax = 0;
@@ -538,6 +539,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
             }
           }
           if (lane < 8) stn[kWS + 8 * kWS + lane] = av;
+          if (lane == 0) stn[kWStG] = (double)1 / (double)(nx.nout > nx.nin ? nx.nout : nx.nin);
         }
       WIDE_VISITS_END
     } else if (wave == kWideCompute + 1) {
