@@ -82,7 +82,9 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, i
           const unsigned slB = (unsigned)__builtin_amdgcn_readfirstlane(sti[42]);
           if (wave < nout || (BACKWARD && wave == 0)) {
             double Di[2] = {st[k2StD + kk[0]], st[k2StD + kk[1]]};
-            double mown[2] = {0, 0};
+            // (this wave's own old message is read directly rather than picked out of the loop)
+            const int jown = wave < nout ? wave : 0;
+            const double mown[2] = {st[k2StM + jown * k2W + kk[0]], st[k2StM + jown * k2W + kk[1]]};
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               if (j < ntot) {
@@ -90,7 +92,6 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, i
                 const double *row = sl >= 8 ? hprev2 + (sl - 8) * k2W : sl >= 0 ? hprev + sl * k2W : st + k2StM + j * k2W;
                 const double v0 = row[kk[0]], v1 = row[kk[1]];
                 Di[0] += v0; Di[1] += v1;
-                if (j == wave && j < nout) { mown[0] = v0; mown[1] = v1; }
               }
             }
             if (BACKWARD) {
@@ -98,9 +99,9 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, i
               Di[0] -= node_vmin; Di[1] -= node_vmin;
               if (tid == 0) sc[8] = node_vmin;
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              if (j == wave && j < nout) {
+            {
+              const int j = wave;  // one compute wave per outgoing message: ONE instance of the message code
+              if (j < nout) {
                 const double gamma = (double)1 / (double)(nout > nin ? nout : nin);
                 const bool src_is_qprim = ((BACKWARD ? 1 : 0) == ((md >> j) & 1));
                 const double alpha = st[k2StA + j];
