@@ -21,8 +21,9 @@ namespace {
 // fails the reference's serial construction runs in the wave's own LDS scratch.
 constexpr int k2W = 2 * kWave;                      // row width
 constexpr int k2StD = 0, k2StM = k2W, k2StQ = k2W + 8 * k2W, k2StQP = k2W + 16 * k2W, k2StA = k2W + 24 * k2W;
-constexpr int k2StI = k2StA + 8;
-constexpr int k2Stage = k2StI + 36;
+constexpr int k2StG = k2StA + 8;                     // gamma = 1 / max(n_out, n_in) (the loader's division)
+constexpr int k2StI = k2StA + 10;
+constexpr int k2Stage = k2StI + 40;                  // ints: desc[64] px[8] row[8] (LDS offsets of the node's message rows)
 constexpr int k2Fb = 5 * (k2W + 2);                 // serial scratch per compute wave: sorted h, q; stack h, q; breakpoints
 constexpr int k2LdsDoubles = 2 * k2Stage + 4 * 8 * k2W + 2 * kScalDoubles + kPipeCompute * 4 * k2W + kPipeCompute * k2Fb + 2;
 static_assert(k2LdsDoubles * 8 <= 160 * 1024, "pipe2 kernel LDS");
@@ -78,8 +79,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, i
           const int *sti = (const int *)(st + k2StI);
           const int f = __builtin_amdgcn_readfirstlane(sti[2]);
           const int nout = f & 15, nin = (f >> 4) & 15, md = (f >> 16) & 255, ntot = nout + nin;
-          const unsigned slA = (unsigned)__builtin_amdgcn_readfirstlane(sti[41]);
-          const unsigned slB = (unsigned)__builtin_amdgcn_readfirstlane(sti[42]);
+          const int myrow = sti[72 + (lane & 7)];  // where the node's message rows live in LDS (from the loader)
           if (wave < nout || (BACKWARD && wave == 0)) {
             double Di[2] = {st[k2StD + kk[0]], st[k2StD + kk[1]]};
             // (this wave's own old message is read directly rather than picked out of the loop)
@@ -88,8 +88,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, i
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               if (j < ntot) {
-                const int sl = j >= nout ? (int)(signed char)(((j < 4 ? slA : slB) >> (8 * (j & 3))) & 255) : -1;
-                const double *row = sl >= 8 ? hprev2 + (sl - 8) * k2W : sl >= 0 ? hprev + sl * k2W : st + k2StM + j * k2W;
+                const double *row = lds + __builtin_amdgcn_readlane(myrow, j);
                 const double v0 = row[kk[0]], v1 = row[kk[1]];
                 Di[0] += v0; Di[1] += v1;
               }
@@ -102,7 +101,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, i
             {
               const int j = wave;  // one compute wave per outgoing message: ONE instance of the message code
               if (j < nout) {
-                const double gamma = (double)1 / (double)(nout > nin ? nout : nin);
+                const double gamma = st[k2StG];  // (double)1 / (double)max(n_out, n_in)
                 const bool src_is_qprim = ((BACKWARD ? 1 : 0) == ((md >> j) & 1));
                 const double alpha = st[k2StA + j];
                 double h[2], qsrc[2], qdst[2];
@@ -243,6 +242,17 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, i
           const NodeDesc nx = decode_desc(w);
           int *stni = (int *)(stn + k2StI);
           stni[lane] = w;
+          {
+            int slr = -1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (lane == j) slr = j >= nx.nout ? nx.slot[j] : -1;
+            const int row = slr >= 8 ? (int)(hand - lds) + ((pos - 1) & 3) * 8 * k2W + (slr - 8) * k2W
+                          : slr >= 0 ? (int)(hand - lds) + (pos & 3) * 8 * k2W + slr * k2W
+                                     : (int)(stn - lds) + k2StM + lane * k2W;
+            if (lane < 8) stni[72 + lane] = row;
+            if (lane == 0) stn[k2StG] = (double)1 / (double)(nx.nout > nx.nin ? nx.nout : nx.nin);
+          }
           const int ntot = nx.nout + nx.nin;
           double dk[2] = {0, 0}, mv[8][2], qv[8][2], qpv[8][2];
 #pragma unroll
