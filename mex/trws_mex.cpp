@@ -4,8 +4,8 @@
 //       trws_mex(int32 kernel, unary KxN, uint32 connectivity-1 2xE, q KxE, qprim KxE,
 //                alphas Ex1, tol 1x1, options)
 // Build inside MATLAB:  mex -I<repo>/include mex/trws_mex.cpp -L<repo>/stereo_amd -lstereo_hip
-// (this image has no MATLAB / mex.h: the file is compile-checked by a maintainer, the C ABI
-// underneath is what tests/ exercise through ctypes).
+// (this image has no MATLAB: tests/test_mex_gateways.py compiles this file against the small
+// MATLAB-API host of tests/mexhost and calls mexFunction.)
 #include <cstring>
 #include <string>
 
