@@ -93,3 +93,46 @@ def test_c_abi_from_a_plain_c_host(hip, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "stereo_rd rc 0 energy 2 bound 2 unlabelled 0" in r.stdout and "stereo_trws rc 0 energy 3 bound 3 iterations 5" in r.stdout
+
+
+@pytest.mark.gpu
+def test_fusion_gateway_equals_the_binding(hip):
+    """fusion_mex (the optional gateway of the device-resident fusion context): the same sequence of
+    commands through mexFunction and through the ctypes binding, equal energies and assignments."""
+    import host
+    from oracle import terms as ot
+    from stereo_amd.fusion import FusionContext
+    from stereo_amd import terms as T
+    H, W, D = 9, 11, 6
+    N = H * W
+    conn = T.construct_neighborhood(H, W)
+    w = np.linspace(0.5, 1.5, conn.shape[1])
+    rng = np.random.default_rng(3)
+    ncc = np.asfortranarray(rng.uniform(-1, 1, size=(H, W, D)))
+    disps = np.arange(float(D))
+    ctx = FusionContext(H, W, 1, 2.0, conn, w)
+    ctx.unary_ncc(ncc, disps, 3.0)
+    g = host.Gateway("fusion_mex")
+    (h,) = g.call(1, "create", float(H), float(W), np.int32(1), 2.0, conn.astype(np.uint32), w.reshape(1, -1), 0.0, 0.0)
+    assert h.dtype == np.uint64 and h[0, 0] != 0
+    with pytest.raises(host.MexError, match="Overload unary_cost"):   # dispmap_super.m:200-203
+        g.call(1, "set_assignment", h, ot.fronto_parallel(1.0, N))
+    g.call(0, "unary_ncc", h, ncc, disps.reshape(1, -1), 3.0)
+    a = ot.fronto_parallel(1.0, N)
+    (e,) = g.call(1, "set_assignment", h, a)
+    assert e[0, 0] == ctx.set_assignment(a)
+    for d, improve in ((3.0, 0.0), (4.0, 1.0)):
+        prop = ot.fronto_parallel(d, N)
+        out = g.call(4, "binary", h, prop, improve)
+        ref = ctx.binary(prop, improve=bool(improve))
+        assert tuple(float(x[0, 0]) for x in out) == tuple(ref)
+    props = [ot.fronto_parallel(d, N) for d in (0.0, 2.0, 5.0)]
+    out = g.call(4, "simultaneous", h, np.stack(props, axis=2), 6.0, -1.0)
+    ref = ctx.simultaneous(props, maxiter=6, max_relgap=-1.0)
+    assert tuple(float(x[0, 0]) for x in out) == tuple(ref)
+    got, e2 = g.call(2, "get_assignment", h, float(N))
+    want, e3 = ctx.get_assignment()
+    assert np.array_equal(got, want) and e2[0, 0] == e3
+    with pytest.raises(host.MexError, match="unknown command"):
+        g.call(0, "nonsense", h)
+    g.call(0, "destroy", h)
