@@ -366,7 +366,11 @@ __device__ __forceinline__ bool build_envelope_masks(int K, double alpha, double
   constexpr int kSteps = 6;
   double thi = qs * c, tlo = thi;
   ok = ok && (!act || fabs(thi) < 1e300);
-  if (!UNI(!ok)) {
+  // c a power of two (alpha = 1, 2, 1/2 ...: unit smoothness weights) and nothing near the ends of the
+  // exponent range: x -> x / c is exact, so both thresholds are q c itself and no stepping is needed
+  const bool exact_c = (__double_as_longlong(c) & 0x000FFFFFFFFFFFFFll) == 0 && c > 1e-100 && c < 1e100 &&
+                       !UNI(act && qs != 0 && !(fabs(qs) > 1e-100 && fabs(qs) < 1e100));
+  if (!UNI(!ok) && !exact_c) {
     // thi: smallest x with fl(x / c) >= qs
     bool settled = !act;
     {
