@@ -44,6 +44,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
   const int32_t *desc = p.desc[D];
   const bool act = lane < K;
   const double posk = (SHARED && act) ? p.pos[lane] : 0.0;
+  int look_streak = 0;  // failed second looks in a row (this compute wave): see message_regs
   if (tid == 0) ctl[1] = 0;
   if (wave < kPipeCompute && lane < 2 * kPipePad) {
     // padding of the source tables (entries -16 .. -1 and 64 .. 79): never overwritten afterwards
@@ -116,7 +117,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
               const double alpha = st[kStA + j];
               double newm = 0;
               const double v = message_regs<KERNEL>(p, K, alpha, h, qsrc, qdst, perm, newm, lane,
-                                                    hqtab + wave * kPipeTab + 4 * kPipePad, (SHARED && p.win_ok) ? p.window : -1);
+                                                    hqtab + wave * kPipeTab + 4 * kPipePad, (SHARED && p.win_ok) ? p.window : -1, &look_streak);
               if (act) hcur[j * kWave + lane] = newm;
               if (BACKWARD && lane == 0) sc[j] = v;
             }
