@@ -356,13 +356,15 @@ __device__ __forceinline__ double ulp_down(double x) {  // next double below a f
   return __longlong_as_double(b);
 }
 
-__device__ __forceinline__ bool build_envelope_masks(int K, double alpha, double hs, double qs, double &sh,
-                                                     double &sq, double &zz, int lane, int &maxtop_out) {
+// Numerator thresholds of the construction below: thi = smallest x with fl(x / c) >= qs, tlo = largest
+// x with fl(x / c) <= qs (c = 2 alpha).  false: inputs outside the argument (the caller falls back).
+__device__ __forceinline__ bool envelope_thresholds(int K, double alpha, double hs, double qs, double &thi_out,
+                                                    double &tlo_out, int lane) {
   const double inf = __builtin_huge_val();
   const bool act = lane < K;
   const double c = 2 * alpha;
   bool ok = alpha > 0 && c < inf && (!act || (fabs(hs) < inf && fabs(qs) < inf));
-  // thresholds on the numerator (see above); at most kSteps ulp steps from fl(q c), else give up
+  // at most kSteps ulp steps from fl(q c), else give up
   constexpr int kSteps = 6;
   double thi = qs * c, tlo = thi;
   ok = ok && (!act || fabs(thi) < 1e300);
@@ -400,40 +402,70 @@ __device__ __forceinline__ bool build_envelope_masks(int K, double alpha, double
     }
     ok = ok && settled;
   }
-  if (UNI(!ok)) return false;
+  thi_out = thi; tlo_out = tlo;
+  return !UNI(!ok);
+}
+
+// The three masks of source k (see above); lane j holds source j's (hs, qs, tlo).
+__device__ __forceinline__ void envelope_masks_of(double alpha, double hk, double qk, double thik, double hs, double qs,
+                                                  double tlo, unsigned long long &m1, unsigned long long &m2,
+                                                  unsigned long long &m3) {
+  const double dist = alpha * fabs(qk - qs);
+  m1 = __builtin_amdgcn_ballot_w64(dist + hk < hs);
+  m2 = __builtin_amdgcn_ballot_w64(dist + hs <= hk);
+  const double num = (hk - hs) + alpha * (qk + qs);
+  m3 = __builtin_amdgcn_ballot_w64(num >= thik || num <= tlo);
+}
+
+// State of the bit-set stack while the sources are taken in (lane t: slot t).
+struct EnvelopeStack {
   unsigned long long A = 1;      // source 0 is the bottom of the stack
   int top = 0, maxtop = 0;
   int src = 0, zk = -1, zj = 0;  // lane t: slot t holds source `src`; z[t+1] = crossing of (zk, zj), inf if zk < 0
+};
+__device__ __forceinline__ void envelope_take(EnvelopeStack &S, int k, unsigned long long m1, unsigned long long m2,
+                                              unsigned long long m3, int lane) {
+  const unsigned long long B = S.A & ~m1;
+  if (B == 0) {  // every cone on the stack is dominated: k becomes the bottom (typeStereoLinear.h:419-425)
+    S.A = 1ull << k;
+    if (lane == 0) { S.src = k; S.zk = -1; }
+    S.top = 0;
+    return;
+  }
+  const int js = 63 - __builtin_clzll(B);   // the cone k meets: the highest one it does not dominate
+  S.A &= (2ull << js) - 1;                  // (js < k <= 63)
+  S.top = __builtin_popcountll(S.A) - 1;
+  if (((m2 | m3) >> js) & 1) return;
+  if (lane == S.top) { S.zk = k; S.zj = js; }
+  ++S.top;
+  if (lane == S.top) { S.src = k; S.zk = -1; }
+  S.A |= 1ull << k;
+  S.maxtop = S.top > S.maxtop ? S.top : S.maxtop;
+}
+// slot contents -> (sh, sq, zz) as the serial code leaves them
+__device__ __forceinline__ void envelope_fill(const EnvelopeStack &S, double alpha, double hs, double qs, double &sh,
+                                              double &sq, double &zz) {
+  const double inf = __builtin_huge_val();
+  sh = __shfl(hs, S.src, kWave); sq = __shfl(qs, S.src, kWave);
+  const double hk = __shfl(hs, S.zk < 0 ? 0 : S.zk, kWave), qk = __shfl(qs, S.zk < 0 ? 0 : S.zk, kWave);
+  const double hj = __shfl(hs, S.zj, kWave), qj = __shfl(qs, S.zj, kWave);
+  const double s = ((hk - hj) + alpha * (qk + qj)) / (2 * alpha);
+  zz = S.zk < 0 ? inf : s;
+}
+
+__device__ __forceinline__ bool build_envelope_masks(int K, double alpha, double hs, double qs, double &sh,
+                                                     double &sq, double &zz, int lane, int &maxtop_out) {
+  double thi, tlo;
+  if (!envelope_thresholds(K, alpha, hs, qs, thi, tlo, lane)) return false;
+  EnvelopeStack S;
   for (int k = 1; k < K; ++k) {
     const double hk = readlane_f64(hs, k), qk = readlane_f64(qs, k), thik = readlane_f64(thi, k);
-    const double dist = alpha * fabs(qk - qs);
-    const unsigned long long m1 = __builtin_amdgcn_ballot_w64(dist + hk < hs);
-    const unsigned long long m2 = __builtin_amdgcn_ballot_w64(dist + hs <= hk);
-    const double num = (hk - hs) + alpha * (qk + qs);
-    const unsigned long long m3 = __builtin_amdgcn_ballot_w64(num >= thik || num <= tlo);
-    const unsigned long long B = A & ~m1;
-    if (B == 0) {  // every cone on the stack is dominated: k becomes the bottom (typeStereoLinear.h:419-425)
-      A = 1ull << k;
-      if (lane == 0) { src = k; zk = -1; }
-      top = 0;
-      continue;
-    }
-    const int js = 63 - __builtin_clzll(B);   // the cone k meets: the highest one it does not dominate
-    A &= (2ull << js) - 1;                    // (js < k <= 63)
-    top = __builtin_popcountll(A) - 1;
-    if (((m2 | m3) >> js) & 1) continue;
-    if (lane == top) { zk = k; zj = js; }
-    ++top;
-    if (lane == top) { src = k; zk = -1; }
-    A |= 1ull << k;
-    maxtop = top > maxtop ? top : maxtop;
+    unsigned long long m1, m2, m3;
+    envelope_masks_of(alpha, hk, qk, thik, hs, qs, tlo, m1, m2, m3);
+    envelope_take(S, k, m1, m2, m3, lane);
   }
-  sh = __shfl(hs, src, kWave); sq = __shfl(qs, src, kWave);
-  const double hk = __shfl(hs, zk < 0 ? 0 : zk, kWave), qk = __shfl(qs, zk < 0 ? 0 : zk, kWave);
-  const double hj = __shfl(hs, zj, kWave), qj = __shfl(qs, zj, kWave);
-  const double s = ((hk - hj) + alpha * (qk + qj)) / (2 * alpha);
-  zz = zk < 0 ? inf : s;
-  maxtop_out = maxtop;
+  envelope_fill(S, alpha, hs, qs, sh, sq, zz);
+  maxtop_out = S.maxtop;
   return true;
 }
 
