@@ -667,6 +667,43 @@ __device__ __attribute__((noinline)) bool message_second_look(double lambda, int
   return UNI(act && bad);
 }
 
+// Evaluation of a constructed envelope at destination t (typeStereoLinear.h:462-479): the reference
+// walks up the stack while z[j+1] < t, so the slot it stops at is the FIRST one whose upper breakpoint
+// is not below t (stale slots above `top` included, hence up to the highest slot ever written) --
+// which is also the first slot where the RUNNING MAXIMUM of the breakpoints reaches t, and a running
+// maximum can be bisected: a 64-lane max-scan and six lane reads per destination instead of one pass
+// per stack slot (the stack holds most of the K cones on ramp-like data).  Slots from maxtop on count
+// as +inf, so the search ends at maxtop when nothing below stops it.
+template <int KERNEL>
+__device__ __forceinline__ double envelope_value(const DevParams &p, double alpha, double t, double vtrunc, double sh,
+                                                 double sq, double zz, int maxtop, int lane) {
+  const double inf = __builtin_huge_val();
+  int slot;
+  if (p.debug & 1024) {
+    slot = maxtop;
+    for (int j = maxtop - 1; j >= 0; --j) {
+      const double zj1 = readlane_f64(zz, j);
+      slot = !(zj1 < t) ? j : slot;
+    }
+  } else {
+    double zm = (lane >= maxtop || zz != zz) ? inf : zz;  // (a NaN breakpoint stops the walk like +inf does)
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const double up = __shfl_up(zm, o, kWave);
+      zm = (lane >= o && up > zm) ? up : zm;
+    }
+    slot = 0;
+#pragma unroll
+    for (int step = kWave / 2; step >= 1; step >>= 1) {
+      const double probe = __shfl(zm, slot + step - 1, kWave);
+      slot = probe < t ? slot + step : slot;
+    }
+  }
+  const double ch = __shfl(sh, slot, kWave), cq = __shfl(sq, slot, kWave);
+  const double c = pair_cost<KERNEL>(alpha, t - cq, ch);
+  return c < vtrunc ? c : vtrunc;
+}
+
 // Message update with everything in registers (K <= 64): h = gamma*Di - old message,
 // qsrc / t = source / destination positions, perm = ascending order of the sources
 // (only touched by the serial fallback).  Returns the normalised message in `out`.
@@ -824,37 +861,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
       if (KERNEL == 1 && !(p.debug & 512)) built = build_envelope_masks(K, alpha, hs, qs, sh, sq, zz, lane, maxtop);
       if (!built) maxtop = build_envelope_regs<KERNEL>(K, alpha, hs, qs, sh, sq, zz, lane);
       MSTAMP(12);
-      // the reference walks up the stack while z[j+1] < t (typeStereoLinear.h:462-479): the slot it
-      // stops at is the FIRST one whose upper breakpoint is not below t (stale slots above `top`
-      // included, hence up to the highest slot ever written); found top-down so that the lowest wins
-      // (... which is also the first slot where the RUNNING MAXIMUM of the breakpoints reaches t,
-      // and a running maximum can be bisected: a 64-lane max-scan and six lane reads per destination
-      // instead of one pass per stack slot -- the stack holds most of the K cones on ramp-like data.
-      // Slots from maxtop on count as +inf, so the search ends at maxtop when nothing below stops it.)
-      int slot;
-      if (p.debug & 1024) {
-        slot = maxtop;
-        for (int j = maxtop - 1; j >= 0; --j) {
-          const double zj1 = readlane_f64(zz, j);
-          slot = !(zj1 < t) ? j : slot;
-        }
-      } else {
-        double zm = (lane >= maxtop || zz != zz) ? inf : zz;  // (a NaN breakpoint stops the walk like +inf does)
-#pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) {
-          const double up = __shfl_up(zm, o, kWave);
-          zm = (lane >= o && up > zm) ? up : zm;
-        }
-        slot = 0;
-#pragma unroll
-        for (int step = kWave / 2; step >= 1; step >>= 1) {
-          const double probe = __shfl(zm, slot + step - 1, kWave);
-          slot = probe < t ? slot + step : slot;
-        }
-      }
-      const double ch = __shfl(sh, slot, kWave), cq = __shfl(sq, slot, kWave);
-      const double c = pair_cost<KERNEL>(alpha, t - cq, ch);
-      out = c < vtrunc ? c : vtrunc;
+      out = envelope_value<KERNEL>(p, alpha, t, vtrunc, sh, sq, zz, maxtop, lane);
       MSTAMP(14);
     }
 #undef MSTAMP
