@@ -417,17 +417,57 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                     serial = UNI(bad);
                     WSTAMP(3);
                     // the verdicts of the two closest-pair waves of this message
+                    bool crowded = false;
                     {
                       int spins = 0;
                       for (;;) {
                         const int v = lane < 2 ? __hip_atomic_load(L.flags + 2 * j + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : (pos << 1);
                         const bool ready = (v >> 1) == pos;
-                        if (!UNI(!ready)) { serial = serial || UNI((v & 1) != 0); break; }
+                        if (!UNI(!ready)) { crowded = UNI((v & 1) != 0); break; }
                         __builtin_amdgcn_s_sleep(0);
                         if (++spins > kSpinLimit) { if (lane == 0) L.ctl[1] = 1; break; }  // bounded
                       }
                       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     }
+                    if (!serial && crowded) {
+                      // Second look.  The closest-pair waves test ALL pairs of cones (conservative, O(K));
+                      // the certificate only asks for the pairs with a USEFUL cone (h < vTrunc), of which
+                      // there are usually a dozen or two among 256: those against everybody, directly
+                      // (the test of trws_pipe_kernel's certified path, same delta as above).  On the
+                      // noise-like volumes this leaves the serial construction -- one lane, 256 sources,
+                      // ~0.1 ms -- to the messages that really have a near tangency.
+                      double uu[4], vv[4];
+                      int nuse = 0;
+                      unsigned long long um[4];
+#pragma unroll
+                      for (int c = 0; c < 4; ++c) {
+                        const double aq = alpha * posr[c];
+                        uu[c] = h[c] - aq; vv[c] = h[c] + aq;
+                        um[c] = __builtin_amdgcn_ballot_w64(valid[c] && h[c] < vtrunc);
+                        nuse += __builtin_popcountll(um[c]);
+                      }
+                      bool near_any = nuse > 64 || !(delta < inf);  // flat H (or no finite scale): the serial construction decides
+                      if (!near_any) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                          unsigned long long mk = um[c];
+                          while (mk) {
+                            const int i = c * kWave + __builtin_ctzll(mk);
+                            mk &= mk - 1;
+                            const double hi = uniform ? htab[i] : mtab[i].x, qi = L.pos[i];
+                            const double aqi = alpha * qi;
+                            const double ui = hi - aqi, vi = hi + aqi;
+#pragma unroll
+                            for (int cc = 0; cc < 4; ++cc) {
+                              const bool near = (fabs(uu[cc] - ui) <= delta) || (fabs(vv[cc] - vi) <= delta);
+                              near_any = near_any || (valid[cc] && near && posr[cc] != qi);
+                            }
+                          }
+                        }
+                      }
+                      crowded = UNI(near_any);
+                    }
+                    serial = serial || crowded;
                     WSTAMP(4);
                   }
                   if (serial) {
