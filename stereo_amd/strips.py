@@ -303,8 +303,12 @@ class TrwsStripRank:
         self.plan = _StripPlan(kernel, K, self.N, conn, self.owner, world, rank, message_mode, max_workgroups, None)
         # exchange the IPC handles of (messages, flags, labels) with both neighbours
         mine = self.plan.ipc_export()
-        gathered = [None] * world
-        dist.all_gather_object(gathered, mine)
+        # (a plain all_gather of IPC_BYTES bytes per rank on the device: the same call under RCCL and
+        #  under gloo, no pickling collective)
+        mine_t = torch.tensor(list(mine), dtype=torch.uint8, device=device)
+        all_t = [torch.zeros(IPC_BYTES, dtype=torch.uint8, device=device) for _ in range(world)]
+        dist.all_gather(all_t, mine_t)
+        gathered = [bytes(t.cpu().numpy().tobytes()) for t in all_t]
         if rank > 0:
             self.plan.ipc_connect(0, gathered[rank - 1])
         if rank + 1 < world:
