@@ -59,6 +59,16 @@ struct DevBuf {
     static const char *poison = std::getenv("STEREO_HIP_POISON");
     if (poison) STEREO_HIP_CHECK(hipMemset(p, std::atoi(poison), count * sizeof(T)));
   }
+  // Fine-grained device memory: what one GPU's kernel stores there is visible to a kernel running on
+  // another GPU (system-scope accesses) without waiting for a kernel boundary -- the arrays a row
+  // strip's neighbours write into while it runs.  (Ordinary hipMalloc memory is coarse-grained: the
+  // runtime only promises cross-device visibility at synchronisation points.)
+  void alloc_fine_grained(size_t count) {
+    release();
+    if (count == 0) count = 1;
+    STEREO_HIP_CHECK(hipExtMallocWithFlags((void **)&p, count * sizeof(T), hipDeviceMallocFinegrained));
+    n = count;
+  }
   void upload(const T *src, size_t count, hipStream_t s = nullptr) {
     if (count > n || !p) alloc(count);
     if (count == 0 || !src) return;

@@ -625,7 +625,12 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
     if (strip_api) STEREO_HIP_CHECK(hipStreamCreateWithFlags(&P->own_stream, hipStreamNonBlocking));
     P->n_lb = nstrips > 1 ? g.strip_lb_terms[strip] : g.lb_terms;
     P->n_en = nstrips > 1 ? g.strip_nodes[strip] : N;
-    P->d_done.alloc(P->Nl);
+    // Strips that may have a neighbour on ANOTHER GPU keep the three arrays the neighbour writes into
+    // (messages, flags, labels) in fine-grained memory (common.h); strips that share the only visible
+    // device (logical strips, tests) stay in ordinary memory.  STEREO_HIP_STRIPS_FINEGRAINED=0/1 overrides.
+    bool fine = nstrips > 1 && stereo_hip_device_count() > 1;
+    if (const char *fg = std::getenv("STEREO_HIP_STRIPS_FINEGRAINED")) fine = nstrips > 1 && std::atoi(fg) != 0;
+    if (fine) P->d_done.alloc_fine_grained(P->Nl); else P->d_done.alloc(P->Nl);
     P->d_ctl.alloc(2);
     P->d_fallbacks.alloc(1);
     STEREO_HIP_CHECK(hipMemset(P->d_fallbacks.p, 0, sizeof(unsigned long long)));
@@ -644,10 +649,10 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
       P->grid_blocks = (int)std::min<int64_t>(runs, P->cus * per_cu);
       if (max_blocks > 0) P->grid_blocks = std::min(P->grid_blocks, max_blocks);
     }
-    P->d_msg.alloc((size_t)P->El * K);
+    if (fine) P->d_msg.alloc_fine_grained((size_t)P->El * K); else P->d_msg.alloc((size_t)P->El * K);
     P->d_lbterms.alloc(P->n_lb);
     P->d_eterms.alloc(P->n_en);
-    P->d_x.alloc(P->Nl);
+    if (fine) P->d_x.alloc_fine_grained(P->Nl); else P->d_x.alloc(P->Nl);
     P->h_lb.alloc(P->n_lb); P->h_en.alloc(P->n_en); P->h_x.alloc(P->Nl); P->h_ctl.alloc(2);
     P->h_ctl.p[0] = P->h_ctl.p[1] = 0;
     STEREO_HIP_CHECK(hipMemset(P->d_msg.p, 0, sizeof(double) * (size_t)P->El * K));
