@@ -47,7 +47,8 @@ struct DevParams {
   const int32_t *desc[2];         // packed node descriptors of the pipelined kernels
   int prof_run;
   int debug;  // development switches: 2 / 4 profile backward / forward sweeps only, 256 no windowed paths,
-              // 512 serial envelopes by the lane-read loop instead of the mask construction
+              // 512 serial envelopes by the lane-read loop instead of the mask construction, 2048 by the
+              // bit-set walk instead of the closed form (build_envelope_parallel)
               // (none of them changes a result)
   unsigned long long *timeline;  // optional [2][nruns][2] wall-clock stamps (development)
   int window;  // wide kernel: sources within lambda of a destination lie within +-window indices
@@ -469,6 +470,123 @@ __device__ __forceinline__ bool build_envelope_masks(int K, double alpha, double
   return true;
 }
 
+// ---- the linear-kernel construction without ANY serial loop (round 3) --------------------------
+// The bit-set form above still walks the sources one after the other (~60 dependent steps of ~66
+// instructions: 33 k cycles per message, and on volumes with flat columns one such message per row
+// sits on the sweep's critical path).  Its state, however, has a closed form.  Let R1_k = {j < k :
+// cone k dominates cone j} (the pop test, typeStereoLinear.h:417), one 64-bit row per source from one
+// ballot.  A cone leaves the stack when the first later cone that dominates it arrives, PROVIDED the
+// serial code gets to test it, i.e. provided everything above it on the stack goes at the same time.
+// Assume that for now: with D_k = OR of the rows before k (a prefix OR over lanes) the stack in front
+// of source k is S_k = P & ~D_k & below(k), P = the set of sources that were pushed, and k meets
+// js(k) = the highest bit of S_k & ~R1_k.  Whether k is pushed is ONE pair test against js(k) (the
+// drop tests :432-449), evaluated by lane k on demand, so P is the fixed point of
+//     P(k) = [S_k & ~R1_k empty]  or  not dropped(k, js(k)),
+// unique because P(k) only depends on P(j), j < k; iterating from "all pushed" settles at least one
+// more source per round and in practice everything within a few rounds (a pushed source mostly stays
+// pushed).  The assumption is then CHECKED: the cones k dominates must be a top segment of S_k (no
+// bit of S_k & R1_k below js(k)); transitivity of dominance makes that hold in exact arithmetic, a
+// rounding accident makes this routine return false and the bit-set walk above runs instead.  With
+// the check the closed form IS the serial code's trace, by induction over k: same stack in front of
+// k, same pops, same cone met, same drop tests, same push.  Slot contents as the serial code leaves
+// them (stale slots above `top` included): source k lands in slot popcount(S_k & ~R1_k); lane t
+// takes the LAST source written to slot t and the last breakpoint written to z[t+1] (a push at slot
+// t resets it to +inf, a push at slot t+1 sets it) -- two LDS atomic maxima over (time, payload).
+// tab: 64 x 4 doubles (this wave's source table), scr: 129 ints, both this wave's own LDS.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_or_u64(unsigned long long v) {
+  const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+  const unsigned l2 = (unsigned)__builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+  const unsigned h2 = (unsigned)__builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+  return v | (((unsigned long long)h2 << 32) | l2);
+}
+__device__ __forceinline__ bool build_envelope_parallel(int K, double alpha, double hs, double qs, double *tab, int *scr,
+                                                        double &sh, double &sq, double &zz, int lane, int &maxtop_out) {
+  const double inf = __builtin_huge_val();
+  const bool act = lane < K;
+  double thi, tlo;
+  if (!envelope_thresholds(K, alpha, hs, qs, thi, tlo, lane)) return false;
+  tab[4 * lane] = hs; tab[4 * lane + 1] = qs; tab[4 * lane + 2] = thi; tab[4 * lane + 3] = tlo;
+  ((long long *)scr)[lane] = 0;
+  if (lane == 0) scr[128] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // rows of the pop test: lane k keeps row k
+  // (four sources per trip, their table reads issued together; rows of sources >= K land in lanes
+  //  that take no part, row 0 is masked below)
+  unsigned r1lo = 0, r1hi = 0;
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    double hk[4], qk[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { hk[i] = tab[4 * (k0 + i)]; qk[i] = tab[4 * (k0 + i) + 1]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double dist = alpha * fabs(qk[i] - qs);
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(dist + hk[i] < hs);
+      // (v_writelane with the lane number in m0: this clang has no writelane builtin, and with two
+      //  different SGPR operands the instruction would break gfx9's one-scalar-operand rule)
+      asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+          : "+v"(r1lo), "+v"(r1hi) : "s"((unsigned)m), "s"((unsigned)(m >> 32)), "s"(k0 + i) : "m0");
+    }
+  }
+  const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const unsigned long long R1 = ((((unsigned long long)r1hi) << 32) | r1lo) & below;
+  // D_k: exclusive prefix OR of the rows (row_shr 1 2 4 8, row_bcast 15 / 31, then one wave shift)
+  unsigned long long D = R1;
+  D = dpp_or_u64<0x111, 0xF>(D); D = dpp_or_u64<0x112, 0xF>(D); D = dpp_or_u64<0x114, 0xF>(D);
+  D = dpp_or_u64<0x118, 0xF>(D); D = dpp_or_u64<0x142, 0xA>(D); D = dpp_or_u64<0x143, 0xC>(D);
+  {
+    const int lo = (int)(unsigned)D, hi = (int)(unsigned)(D >> 32);
+    const unsigned l2 = (unsigned)__builtin_amdgcn_update_dpp(0, lo, 0x138, 0xF, 0xF, false);  // wave_shr:1
+    const unsigned h2 = (unsigned)__builtin_amdgcn_update_dpp(0, hi, 0x138, 0xF, 0xF, false);
+    D = ((unsigned long long)h2 << 32) | l2;
+  }
+  const unsigned long long cand = ~(D | R1) & below;
+  unsigned long long P = K >= 64 ? ~0ull : ((1ull << K) - 1);
+  unsigned long long B = 0;
+  int js = 0;
+  bool settled = false;
+  for (int round = 0; round <= K; ++round) {
+    B = P & cand;
+    js = B ? 63 - __builtin_clzll(B) : 0;
+    const double hj = tab[4 * js], qj = tab[4 * js + 1], tloj = tab[4 * js + 3];
+    const double dist = alpha * fabs(qs - qj);
+    const double num = (hs - hj) + alpha * (qs + qj);
+    const bool dropped = (dist + hj <= hs) || (num >= thi) || (num <= tloj);
+    const unsigned long long np = __builtin_amdgcn_ballot_w64(act && (B == 0 || !dropped)) | 1ull;
+    if (np == P) { settled = true; break; }
+    P = np;
+  }
+  if (!settled) return false;
+  // the cones a source dominates must be what the serial code pops: a top segment of its stack
+  {
+    const unsigned long long S = P & ~D & below;
+    const bool bad = act && B != 0 && (S & R1 & ((1ull << js) - 1)) != 0;
+    if (UNI(bad)) return false;
+  }
+  const bool pushed = act && ((P >> lane) & 1);
+  const int t = B ? __builtin_popcountll(B) : 0;
+  if (pushed) {
+    if (lane > 0) atomicMax(scr + 2 * t, lane << 8);
+    if (B) atomicMax(scr + 2 * (t - 1) + 1, (lane << 8) | js);
+    atomicMax(scr + 128, t);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int src = scr[2 * lane] >> 8, zw = scr[2 * lane + 1];
+  const bool have_z = (zw >> 8) > src;
+  const int zk = have_z ? zw >> 8 : 0, zj = zw & 255;
+  sh = tab[4 * src]; sq = tab[4 * src + 1];
+  const double hk = tab[4 * zk], qk = tab[4 * zk + 1];
+  const double hj = tab[4 * zj], qj = tab[4 * zj + 1];
+  const double s = ((hk - hj) + alpha * (qk + qj)) / (2 * alpha);
+  zz = have_z ? s : inf;
+  maxtop_out = __builtin_amdgcn_readfirstlane(scr[128]);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return true;
+}
+
 // Certified fast path of the truncated QUADRATIC message (typeStereoQuadratic.h:329-501), K <= 64,
 // lane = source and destination label.  The reference builds the lower envelope of the parabolas
 // alpha (t - q_s)^2 + h_s as the lower convex hull of the points (q_s, g_s = h_s + alpha q_s^2) --
@@ -855,10 +973,14 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
     if (need_serial) {
       const int idx = act ? perm[lane] : lane;
       const double hs = __shfl(h, idx, kWave), qs = __shfl(qsrc, idx, kWave);
-      double sh, sq, zz;
+      double sh = 0, sq = 0, zz = 0;
       int maxtop = 0;
       bool built = false;
-      if (KERNEL == 1 && !(p.debug & 512)) built = build_envelope_masks(K, alpha, hs, qs, sh, sq, zz, lane, maxtop);
+      if (KERNEL == 1 && !(p.debug & 512)) {
+        // (hq + 4 (64 + pad): the scratch words behind this wave's table, see kPipeTab)
+        if (hq && !(p.debug & 2048)) built = build_envelope_parallel(K, alpha, hs, qs, hq, (int *)(hq + 4 * (kWave + 16)), sh, sq, zz, lane, maxtop);
+        if (!built) built = build_envelope_masks(K, alpha, hs, qs, sh, sq, zz, lane, maxtop);
+      }
       if (!built) maxtop = build_envelope_regs<KERNEL>(K, alpha, hs, qs, sh, sq, zz, lane);
       MSTAMP(12);
       out = envelope_value<KERNEL>(p, alpha, t, vtrunc, sh, sq, zz, maxtop, lane);
@@ -889,7 +1011,8 @@ constexpr int kStI = kStA + 10;                   // int area starts here (as do
 constexpr int kStageDoubles = kStI + 40;          // ints: desc[64] px[8] row[8] (where Di's k-th message row lives in LDS)
 constexpr int kScalDoubles = 16;                  // newv[8], node_vmin, prim_e, x (as int)
 constexpr int kPipePad = 16;                      // source tables are padded by this many (+inf) entries on both sides
-constexpr int kPipeTab = 4 * (kWave + 2 * kPipePad);  // doubles per compute wave: (h, q, u, v) x 96
+constexpr int kPipeScr = 66;                      // doubles of scratch behind a wave's table: 129 ints of build_envelope_parallel
+constexpr int kPipeTab = 4 * (kWave + 2 * kPipePad) + kPipeScr;  // doubles per compute wave: (h, q, u, v) x 96 + scratch
 
 __device__ __forceinline__ int group_strip(const GroupArgs &ga) {
   int s = 0;

@@ -229,10 +229,15 @@ class dispmap_super:
             raise StereoHipError("Input proposals should be given in cell array.")
         ctx = self._context()
         N = self.sz[0] * self.sz[1]
-        single = all(isinstance(p, PlaneProposal) and p.segments is None for p in proposal_cell)
+        single = len(proposal_cell) > 0 and all(isinstance(p, PlaneProposal) and p.segments is None for p in proposal_cell)
         if not single:
             proposal_cell = [p.expand(N) if isinstance(p, PlaneProposal) else p for p in proposal_cell]
-        if ctx is not None:
+        for p in proposal_cell:
+            if np.shape(p) != (4, N) and not isinstance(p, PlaneProposal):
+                raise StereoHipError("Simultaneous fusion: Proposals is of wrong size")
+        # (an empty cell: the reference appends the current assignment and runs trws with that one
+        #  label, dispmap_super.m:158 -- the stateless path below does the same)
+        if ctx is not None and len(proposal_cell) > 0:
             # device-resident: proposals go up, unary / positions / TRW-S / scatter stay in HBM
             if not self._ctx_has_assignment:
                 ctx.set_assignment(self._assignment)

@@ -110,3 +110,24 @@ def piecewise_planar(H, W, cell, rng, d_lo, d_hi, slant=0.3):
     p4 = -(d0 + a * cx + b * cy)
     planes = np.stack([a, b, np.ones_like(a), p4])                     # 4 x H x W
     return np.asfortranarray(planes.transpose(0, 2, 1).reshape(4, H * W))
+
+
+def piecewise_planar_from_disparity(H, W, cell, rng, dmap, slant=0.05, jitter=0.5):
+    """One proposal, 4 x N, that follows a given H x W disparity map: per cell x cell block a plane
+    [a b 1 p4] through (block centre, block median of dmap + jitter) with a small random slant, so
+    that neighbouring pixels of one block share a plane (q == qprim inside, != across blocks) and
+    different proposals win in different parts of the image."""
+    rows, cols = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    by, bx = rows // cell, cols // cell
+    nb = (by.max() + 1, bx.max() + 1)
+    med = np.zeros(nb)
+    for i in range(nb[0]):
+        for j in range(nb[1]):
+            med[i, j] = np.median(dmap[i * cell:(i + 1) * cell, j * cell:(j + 1) * cell])
+    a = rng.normal(0, slant, nb)[by, bx]
+    b = rng.normal(0, slant, nb)[by, bx]
+    d0 = (med + rng.normal(0, jitter, nb))[by, bx]
+    cx, cy = (bx + 0.5) * cell, (by + 0.5) * cell
+    p4 = -(d0 + a * cx + b * cy)
+    planes = np.stack([a, b, np.ones_like(a), p4])                     # 4 x H x W
+    return np.asfortranarray(planes.transpose(0, 2, 1).reshape(4, H * W))

@@ -160,6 +160,49 @@ def test_teddy_size_matches_oracle(kernel, K, general, hip, oracle):
     assert en == ref[1] and lb == ref[2] and it == ref[3]
 
 
+@pytest.mark.parametrize("source", ["teddy", "synthetic"])
+def test_named_workload_ncc_volume_full_size_matches_oracle(source, hip, oracle):
+    """BASELINE.json configs[1] / the bench's workload at full size: the NCC cost volume (5x5xRGB,
+    unary = 40 (1 - ncc), dispmap_ncc.m:107-115) of the reference's Teddy pair (tests/golden/
+    teddy_pair.npz = data/teddy/im2.png, im6.png) and of the bench's synthetic pair, 450 x 375 x 60
+    fronto-parallel labels, kernel 1, tol 8: five TRW-S iterations bit for bit against the oracle.
+    The masked columns of the volume are flat (dispmap_ncc.m:190-191), so a few per cent of the
+    messages fail the certificate and take the reference's serial envelope construction under the
+    sweep kernel's real scheduling -- asserted, this is what the noise-volume test above never does."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from helpers import grid_conn
+    from stereo_amd import terms as T
+    from stereo_amd.trws import TrwsPlan
+    H, W, K = 375, 450, 60
+    if source == "teddy":
+        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "teddy_pair.npz"))
+        im0, im1 = g["im0"].astype(np.float64), g["im1"].astype(np.float64)
+    else:
+        from bench import synthetic_pair
+        im0, im1 = synthetic_pair(H, W, K, seed=0)
+    assert im0.shape == (H, W, 3)
+    ncc = T.ncc_volume(im0, im1, np.arange(K, dtype=np.float64), 2, layout=1)       # label-fastest: K x N
+    unary = np.ascontiguousarray(40.0 * (1.0 - ncc.T))                               # N x K
+    conn = grid_conn(H, W)
+    E = conn.shape[0]
+    pos = np.arange(K, dtype=np.float64)
+    plan = TrwsPlan(1, K, H * W, conn.T)
+    plan.upload(unary.T, np.ones(E), 8.0, positions=pos)
+    plan.serial_messages(reset=True)
+    iters = 5
+    plan.iterate(iters, max_relgap=-1e300)
+    lab, en, lb, it = plan.result()
+    serial = plan.serial_messages()
+    q = np.tile(pos, (E, 1))
+    ref = oracle.trws(1, unary, conn, q, q, np.ones(E), 8.0, iters, -1e300, mode=1)
+    assert plan.path() == 2
+    assert serial > 0.005 * 2 * E * iters, "only %d messages took the serial construction" % serial
+    assert np.array_equal(lab, ref[0]), "labels differ at %d nodes" % int((lab != ref[0]).sum())
+    assert en == ref[1] and lb == ref[2] and it == ref[3]
+
+
 INDEX_ORDER = [
     # seed, H, W, K, kernel, kind, integer, tol, iters
     (401, 12, 14, 8, 1, "general", False, 1.5, 5),
