@@ -102,6 +102,8 @@ def scale_leg(args, rank, local_rank, world, dist, dev, index_order=False, minpl
     from stereo_amd.trws import TrwsPlan
     from stereo_amd.strips import TrwsStripRank, row_strip_owner
     from helpers import grid_conn
+    from stereo_amd import _lib
+    _cus = _lib.lib().stereo_hip_device_cus
     H, W, K = args.scale_height, args.scale_width, args.scale_labels
     N = H * W
     t_setup = time.perf_counter()
@@ -124,7 +126,7 @@ def scale_leg(args, rank, local_rank, world, dist, dev, index_order=False, minpl
         # a rank stores its band only: the rows of its own nodes + one halo row per neighbour and the
         # messages of the edges at its own nodes (strip-local ids, stereo_trws_plan_strip_layout)
         solver = TrwsStripRank(1, K, H, W, conn.T, rank, world, dist, dev, message_mode=mode,
-                               max_workgroups=(256 // world if args.one_gpu else 0))
+                               max_workgroups=((int(_cus()) or 256) // world if args.one_gpu else 0))
         plan = solver.plan
         nodes, n_own, edges = plan.layout()
         d_unary = synthetic_volume_device(H, W, K, 1, dev, nodes=torch.from_numpy(nodes.astype(np.int64)).to(dev))
@@ -193,7 +195,10 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--message-mode", choices=["exact", "minplus"], default="exact")
     ap.add_argument("--volume", choices=["ncc", "noise"], default="ncc",
-                    help="ncc: NCC cost volume of a synthetic image pair (the named workload); noise: planted signal + noise")
+                    help="ncc: NCC cost volume of an image pair (the named workload); noise: planted signal + noise")
+    ap.add_argument("--pair", choices=["teddy", "synthetic"], default="teddy",
+                    help="image pair behind the NCC volume: the reference's Teddy pair (tests/golden/teddy_pair.npz = "
+                         "data/teddy/im2.png, im6.png; 450x375 only) or the synthetic textured pair")
     ap.add_argument("--no-scale", action="store_true", help="skip the 3000x2000x256 strong-scaling leg")
     ap.add_argument("--scale-height", type=int, default=2000)
     ap.add_argument("--scale-width", type=int, default=3000)
@@ -234,14 +239,23 @@ def main():
         # so the volume has exact ties like the real Teddy volume and part of the messages take the
         # reference's serial envelope construction.
         from stereo_amd import terms as T
-        im0, im1 = synthetic_pair(H, W, K, seed=rank)
+        teddy = os.path.join(ROOT, "tests", "golden", "teddy_pair.npz")
+        if args.pair == "teddy" and (H, W) == (375, 450) and os.path.exists(teddy):
+            g = np.load(teddy)      # every rank solves the same Teddy problem (weak scaling: one pair per GPU)
+            im0, im1 = g["im0"].astype(np.float64), g["im1"].astype(np.float64)
+            pair = "teddy"
+        else:
+            im0, im1 = synthetic_pair(H, W, K, seed=rank)
+            pair = "synthetic"
         ncc = T.ncc_volume(im0, im1, np.arange(K, dtype=np.float64), 2, layout=1)     # K x N, label fastest
         h_unary = np.ascontiguousarray(40.0 * (1.0 - ncc.T))                          # (N, K)
         d_unary = torch.from_numpy(h_unary).to(dev)
     elif big:
         d_unary = synthetic_volume_device(H, W, K, 1 + rank, dev)
+        pair = "none"
     else:
         d_unary = torch.from_numpy(synthetic_volume(H, W, K, seed=1 + rank)).to(dev)
+        pair = "none"
     plan = TrwsPlan(1, K, N, conn.T, message_mode=0 if args.message_mode == "exact" else 1)
     # inputs live in HBM as torch tensors (plumbing only) and are bound, not copied
     d_alpha = torch.ones(E, dtype=torch.float64, device=dev)
@@ -297,9 +311,10 @@ def main():
         # HBM traffic per launch from the committed PMC passes of this same workload (profiles/),
         # corrected as MI355X_MICROARCH.md prescribes; null if the workload differs from them
         traffic = None
-        pmc = {(375, 450, 60, "ncc"): "r02_trws_teddy60_ncc_pmc_hbm.json",
-               (375, 450, 60, "noise"): "r01_trws_teddy60_pmc_hbm.json",
-               (1000, 1500, 256, "noise"): "r01_trws_wide256_1500x1000_pmc_hbm.json"}.get((H, W, K, volume))
+        pmc = {(375, 450, 60, "ncc", "teddy"): "r03_trws_teddy60_pmc_hbm.json",
+               (375, 450, 60, "ncc", "synthetic"): "r02_trws_teddy60_ncc_pmc_hbm.json",
+               (375, 450, 60, "noise", "none"): "r01_trws_teddy60_pmc_hbm.json",
+               (1000, 1500, 256, "noise", "none"): "r01_trws_wide256_1500x1000_pmc_hbm.json"}.get((H, W, K, volume, pair))
         if pmc and os.path.exists(os.path.join(ROOT, "profiles", pmc)):
             traffic = json.load(open(os.path.join(ROOT, "profiles", pmc)))["per_launch"]["hbm_bytes_corrected"]
         out = {
@@ -314,10 +329,12 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": ("teddy pair (the reference's data/teddy/im2.png, im6.png, committed as tests/golden/teddy_pair.npz)"
+                     if pair == "teddy" else "synthetic"),
             "config": {"workload": "configs[1]: %s, %dx%dx%d labels, TRW-S (trws.m drop-in), "
                                    "kernel 1, tol 8, alphas 1, fronto-parallel labels" % (
-                                       "NCC cost volume (5x5xRGB, unary weight 40) of a synthetic image pair" if volume == "ncc"
+                                       "NCC cost volume (5x5xRGB, unary weight 40) of %s" % (
+                                           "the Teddy pair" if pair == "teddy" else "a synthetic image pair") if volume == "ncc"
                                        else "synthetic cost volume (planted signal + noise)", W, H, K),
                        "nodes": N, "directed_edges": E, "message_mode": "exact (reference envelope)" if args.message_mode == "exact" else "minplus",
                        "parallelism": "independent image pair per GPU" if world > 1 else "1 GPU"},

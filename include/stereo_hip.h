@@ -22,15 +22,23 @@
 extern "C" {
 #endif
 
-#define STEREO_HIP_ABI_VERSION 1
+/* Bumped whenever an entry point is added or a signature changes; the Python binding refuses a
+ * library that reports another version (a stale libstereo_hip.so).  3: stereo_hip_device_cus, plan
+ * entry points select their plan's device, wall-clock bound on cross-workgroup waits. */
+#define STEREO_HIP_ABI_VERSION 3
 
 /* ---- library ---------------------------------------------------------- */
 
 int stereo_hip_abi_version(void);
 /* Number of visible HIP devices (0 if none / runtime failure). */
 int stereo_hip_device_count(void);
-/* Selects the device used by subsequent calls of this thread (default 0). */
+/* Selects the device used by subsequent calls of this thread (default 0).  A plan stays on the
+ * device that was current when it was created: every plan entry point makes that device current for
+ * its own duration. */
 int stereo_hip_set_device(int device);
+/* Compute units of the current device (0 without a device): the number of workgroups of a persistent
+ * sweep launch that are certain to be resident together. */
+int stereo_hip_device_cus(void);
 /* Creates the HIP context of the current device and launches one empty kernel, so that the
  * runtime's one-time initialisation happens now.  Optional; it matters to callers that seed libc
  * rand() for QPBO Improve (QPBO_extra.cpp:13-27 draws its permutation from it): the runtime

@@ -7,11 +7,15 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstereo_hip.so")
+# STEREO_HIP_LIB: another build of the same library (development: the message-profile flavour,
+# stereo_amd/csrc/build.sh -DSTEREO_HIP_MESSAGE_PROFILE with STEREO_HIP_OUT set)
+LIB_PATH = os.environ.get("STEREO_HIP_LIB") or os.path.join(_HERE, "libstereo_hip.so")
 
 _dp = C.POINTER(C.c_double)
 _u32p = C.POINTER(C.c_uint32)
 _i64p = C.POINTER(C.c_int64)
+
+ABI_VERSION = 3   # include/stereo_hip.h: STEREO_HIP_ABI_VERSION
 
 _lib = None
 
@@ -35,6 +39,9 @@ def lib():
         except ImportError:
             pass
         L = C.CDLL(LIB_PATH)
+        if L.stereo_hip_abi_version() != ABI_VERSION:
+            raise StereoHipError("%s reports ABI version %d, this binding needs %d: rebuild it with "
+                                 "stereo_amd/csrc/build.sh" % (LIB_PATH, L.stereo_hip_abi_version(), ABI_VERSION))
         L.stereo_hip_last_error.restype = C.c_char_p
         L.stereo_trws_plan_destroy.restype = None
         L.stereo_rd_plan_destroy.restype = None

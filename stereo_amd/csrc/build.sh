@@ -5,17 +5,17 @@
 # The device assembly is kept (-save-temps, under csrc/_build/) and checked for one known
 # miscompile of this toolchain: s_mov_b64 with a 64-bit literal, which the encoder truncates
 # to its low 32 bits (a wave-uniform +inf became 0.0 that way).
-# -Wno-inline-asm: trws_dev.h names m0 as clobbered by its v_writelane sequence (the lane number
+#: trws_dev.h names m0 as clobbered by its v_writelane sequence (the lane number
 # travels in m0); clang warns about any reserved register on a clobber list.
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-OUT="$ROOT/stereo_amd/libstereo_hip.so"
-TMP="$HERE/_build"
+OUT="${STEREO_HIP_OUT:-$ROOT/stereo_amd/libstereo_hip.so}"
+TMP="${STEREO_HIP_TMP:-$HERE/_build}"
 mkdir -p "$TMP"
 rm -f "$TMP"/*.o "$TMP"/*.log
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-command-line-argument -Wno-inline-asm -I$ROOT/include -save-temps=obj"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-command-line-argument -I$ROOT/include -save-temps=obj"
 pids=()
 objs=()
 for src in "$HERE"/*.hip "$HERE"/*.cpp; do

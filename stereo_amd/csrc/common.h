@@ -36,6 +36,22 @@ struct HipError {
     }                                                                                   \
   } while (0)
 
+// A plan lives on the device that was current when it was created.  Every entry point that
+// allocates, launches, copies or synchronises for a plan makes that device current for its own
+// duration and restores the caller's afterwards (a process may drive one plan per GPU).
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceScope(int device) {
+    if (device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+  }
+  DeviceScope(const DeviceScope &) = delete;
+  DeviceScope &operator=(const DeviceScope &) = delete;
+  ~DeviceScope() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
 template <class T>
 struct DevBuf {
   T *p = nullptr;

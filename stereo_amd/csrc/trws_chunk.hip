@@ -341,14 +341,18 @@ __device__ __forceinline__ void chunk_body(DevParams p, int epoch) {
               if (lane == j) myrank = nx.dep[j];
             const bool watching = lane < nx.ndep;
             int spins = 0;
+            long long t0 = 0;
             bool ok = true;
             for (;;) {
               const int v = watching ? ld_sc1(p.done + myrank) : epoch;
               if (!UNI(v < epoch)) break;
-              __builtin_amdgcn_s_sleep(1);
-              if (++spins > kSpinLimit || ((spins & 1023) == 0 && ld_sc1(p.abort_flag))) { ok = false; break; }
+              if (!keep_waiting(p, spins, t0)) {   // wall-clock bound, or somebody else gave up
+                if (lane == __builtin_ctzll(__builtin_amdgcn_ballot_w64(v < epoch))) report_give_up(p, nx.rank, myrank, v, epoch);
+                ok = false;
+                break;
+              }
             }
-            if (!ok && lane == 0) { st_sc1(p.abort_flag, 1); L.ctl[1] = 1; }
+            if (!ok && lane == 0) L.ctl[1] = 1;
           }
           double mv[8][4];
 #pragma unroll

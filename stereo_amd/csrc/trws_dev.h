@@ -38,7 +38,8 @@ struct DevParams {
   const int8_t *in_slot[2];
   int32_t *done;    // per rank: epoch of the last completed visit
   int32_t *ticket;  // run dispenser of the current launch
-  int32_t *abort_flag;
+  int32_t *abort_flag;  // (d_ctl + 1; the four words behind it take the give-up report, see report_give_up)
+  long long spin_ticks; // how long a visit may wait for another workgroup's flag: 100 MHz wall-clock ticks
   int N;
   unsigned long long *fallbacks;  // messages that needed the serial envelope (diagnostics)
   int certificate;                // 0: always run the serial envelope
@@ -125,13 +126,40 @@ __device__ __forceinline__ double max_raw(double a, double b) {
   asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// acc = min(acc, x) where `take` holds, else acc.  NOT a conditional expression around min_raw: the
+// compiler does not execute inline assembly speculatively, so that form becomes an exec-mask region
+// with a branch around one instruction -- in the pair loop of every message (found in the ISA in
+// round 3: five of the ~24 instructions per source).
+__device__ __forceinline__ double min_raw_if(bool take, double acc, double x) {
+  return min_raw(acc, take ? x : __builtin_huge_val());
+}
 // wave-uniform predicate -> scalar branch
 #define UNI(c) (__builtin_amdgcn_ballot_w64(c) != 0)
 
 // ---- DPP wave reductions (gfx9 row_bcast forms): ~20 VALU instead of 12 ds_bpermute.
 // The combined value ends up in lane 63 and is broadcast with v_readlane.
+// (steps that write every lane from a valid source lane -- ROW_MASK 0xF: the quad / row permutations --
+//  name no `old` value: the compiler then emits the bare v_mov_b32_dpp instead of copying the register
+//  first, 3 instead of 5 instructions per step of a double; the row_bcast steps keep `old` = the
+//  lane's own value for the rows they leave alone)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+#ifndef STEREO_DPP_OLD
+  if (ROW_MASK == 0xF) {
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  } else
+#endif
+  {
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+  }
+  return __hiloint2double(hi, lo);
+}
+// (old = the lane's own value wherever the pattern has no source lane: shifts, scans)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64_keep(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
   hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
@@ -139,6 +167,9 @@ __device__ __forceinline__ double dpp_f64(double v) {
 }
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_i32(int v) {
+#ifndef STEREO_DPP_OLD
+  if (ROW_MASK == 0xF) return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+#endif
   return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
 }
 #define DPP_REDUCE_STEPS(STEP) \
@@ -360,7 +391,7 @@ __device__ __forceinline__ double ulp_down(double x) {  // next double below a f
 // Numerator thresholds of the construction below: thi = smallest x with fl(x / c) >= qs, tlo = largest
 // x with fl(x / c) <= qs (c = 2 alpha).  false: inputs outside the argument (the caller falls back).
 __device__ __forceinline__ bool envelope_thresholds(int K, double alpha, double hs, double qs, double &thi_out,
-                                                    double &tlo_out, int lane) {
+                                                    double &tlo_out, int lane, bool *exact_c_out = nullptr) {
   const double inf = __builtin_huge_val();
   const bool act = lane < K;
   const double c = 2 * alpha;
@@ -404,6 +435,7 @@ __device__ __forceinline__ bool envelope_thresholds(int K, double alpha, double 
     ok = ok && settled;
   }
   thi_out = thi; tlo_out = tlo;
+  if (exact_c_out) *exact_c_out = exact_c;
   return !UNI(!ok);
 }
 
@@ -500,35 +532,111 @@ __device__ __forceinline__ unsigned long long dpp_or_u64(unsigned long long v) {
   const unsigned h2 = (unsigned)__builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
   return v | (((unsigned long long)h2 << 32) | l2);
 }
+// Rows K0 .. K0 + 3 of the pop test: lane j compares source K0 + i (from the table) with its own source
+// j; the ballot is row K0 + i, kept by lane K0 + i (v_writelane, lane number as a literal: this clang has
+// no writelane builtin, and a lane number in an SGPR next to the SGPR data would break gfx9's
+// one-scalar-operand rule).
+template <int K0>
+__device__ __forceinline__ void envelope_rows4(const double *tab, double alpha, double hs, double qs, unsigned &lo,
+                                               unsigned &hi) {
+  double hk[4], qk[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { hk[i] = tab[4 * (K0 + i)]; qk[i] = tab[4 * (K0 + i) + 1]; }
+  unsigned long long m[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double dist = alpha * fabs(qk[i] - qs);
+    m[i] = __builtin_amdgcn_ballot_w64(dist + hk[i] < hs);
+  }
+  // A v_writelane must not directly follow the v_cmp that writes the SGPR pair it takes its data from:
+  // the result is then occasionally stale (found by the certificate stress, 3 in 1000 constructions;
+  // the compiler's hazard recogniser does not look inside inline assembly).  The scheduling barriers
+  // keep all four compares in front of the four writes, which puts six instructions between the last
+  // compare and the write that reads its mask (one statement: between separate ones the compiler adds s_nops).
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("v_writelane_b32 %0, %2, %10\n\tv_writelane_b32 %1, %3, %10\n\t"
+               "v_writelane_b32 %0, %4, %11\n\tv_writelane_b32 %1, %5, %11\n\t"
+               "v_writelane_b32 %0, %6, %12\n\tv_writelane_b32 %1, %7, %12\n\t"
+               "v_writelane_b32 %0, %8, %13\n\tv_writelane_b32 %1, %9, %13"
+               : "+v"(lo), "+v"(hi)
+               : "s"((unsigned)m[0]), "s"((unsigned)(m[0] >> 32)), "s"((unsigned)m[1]), "s"((unsigned)(m[1] >> 32)),
+                 "s"((unsigned)m[2]), "s"((unsigned)(m[2] >> 32)), "s"((unsigned)m[3]), "s"((unsigned)(m[3] >> 32)),
+                 "n"(K0), "n"(K0 + 1), "n"(K0 + 2), "n"(K0 + 3));
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+#ifdef STEREO_HIP_MESSAGE_PROFILE
+// (phase times collected in registers and written at the end: an atomic per stamp costs ~1 k cycles)
+#define PSTAMP(slot) do { if (prof) { const long long n_ = (long long)__builtin_readcyclecounter(); pacc[((slot) - 16) / 2] += n_ - pt0; pt0 = (long long)__builtin_readcyclecounter(); } } while (0)
+#else
+#define PSTAMP(slot) do { } while (0)
+#endif
 __device__ __forceinline__ bool build_envelope_parallel(int K, double alpha, double hs, double qs, double *tab, int *scr,
-                                                        double &sh, double &sq, double &zz, int lane, int &maxtop_out) {
+                                                        double &sh, double &sq, double &zz, int lane, int &maxtop_out,
+                                                        double mag, unsigned long long *prof = nullptr, int dbg = 0) {
   const double inf = __builtin_huge_val();
   const bool act = lane < K;
+#ifdef STEREO_HIP_MESSAGE_PROFILE
+  long long pt0 = prof ? (long long)__builtin_readcyclecounter() : 0;  // development profile: slots 16..27
+  long long pacc[4] = {0, 0, 0, 0};
+#endif
   double thi, tlo;
-  if (!envelope_thresholds(K, alpha, hs, qs, thi, tlo, lane)) return false;
+  bool exact_c = false;
+  if (!envelope_thresholds(K, alpha, hs, qs, thi, tlo, lane, &exact_c)) return false;
+  PSTAMP(16);
   tab[4 * lane] = hs; tab[4 * lane + 1] = qs; tab[4 * lane + 2] = thi; tab[4 * lane + 3] = tlo;
   ((long long *)scr)[lane] = 0;
-  if (lane == 0) scr[128] = 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  // rows of the pop test: lane k keeps row k
-  // (four sources per trip, their table reads issued together; rows of sources >= K land in lanes
-  //  that take no part, row 0 is masked below)
+  // rows of the pop test: lane k keeps row k.  In exact arithmetic source k dominates source j < k iff
+  // v_k < v_j (v = h + alpha q), so its row is EMPTY unless v_k comes within the rounding of the largest
+  // v in front of it -- decided with a margin of 1e-12 x magnitude, two thousand times the rounding of
+  // either side of the comparison -- and only the other rows are computed: all of them by the unrolled
+  // groups below when they are many, one by one (two per trip) when they are few.
   unsigned r1lo = 0, r1hi = 0;
-  for (int k0 = 0; k0 < K; k0 += 4) {
-    double hk[4], qk[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { hk[i] = tab[4 * (k0 + i)]; qk[i] = tab[4 * (k0 + i) + 1]; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const double dist = alpha * fabs(qk[i] - qs);
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(dist + hk[i] < hs);
-      // (v_writelane with the lane number in m0: this clang has no writelane builtin, and with two
-      //  different SGPR operands the instruction would break gfx9's one-scalar-operand rule)
-      asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
-          : "+v"(r1lo), "+v"(r1hi) : "s"((unsigned)m), "s"((unsigned)(m >> 32)), "s"(k0 + i) : "m0");
+  unsigned long long need;
+  {
+    const double v = act ? hs + alpha * qs : -inf;
+    double pm = v;  // inclusive prefix maximum over the lanes, then shifted by one lane
+#define STEREO_SCAN(C, M) { const double o = dpp_f64_keep<C, M>(pm); pm = max_raw(o, pm); }
+    STEREO_SCAN(0x111, 0xF) STEREO_SCAN(0x112, 0xF) STEREO_SCAN(0x114, 0xF) STEREO_SCAN(0x118, 0xF)
+    STEREO_SCAN(0x142, 0xA) STEREO_SCAN(0x143, 0xC)
+#undef STEREO_SCAN
+    pm = dpp_f64_keep<0x138, 0xF>(pm);  // wave_shr:1 (lane 0 keeps its own value and is not asked)
+    need = __builtin_amdgcn_ballot_w64(act && lane > 0 && !(v - pm > 1e-12 * mag));
+  }
+  const int nrows = __builtin_popcountll(need);
+  if (nrows > 20) {
+    // (four sources per group, their table reads issued together, the lane numbers of v_writelane as
+    //  literals -- hence the unrolled groups; rows of sources >= K land in lanes that take no part, row 0
+    //  is masked below)
+#define STEREO_ROWS4(K0) if (K > (K0)) envelope_rows4<(K0)>(tab, alpha, hs, qs, r1lo, r1hi);
+    STEREO_ROWS4(0) STEREO_ROWS4(4) STEREO_ROWS4(8) STEREO_ROWS4(12) STEREO_ROWS4(16) STEREO_ROWS4(20) STEREO_ROWS4(24)
+    STEREO_ROWS4(28) STEREO_ROWS4(32) STEREO_ROWS4(36) STEREO_ROWS4(40) STEREO_ROWS4(44) STEREO_ROWS4(48) STEREO_ROWS4(52)
+    STEREO_ROWS4(56) STEREO_ROWS4(60)
+#undef STEREO_ROWS4
+  } else {
+    unsigned long long todo = need;
+    while (todo) {
+      const int k0 = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const int k1 = todo ? __builtin_ctzll(todo) : k0;  // (a row written twice is the same row)
+      todo &= todo - 1;
+      const double hk0 = tab[4 * k0], qk0 = tab[4 * k0 + 1], hk1 = tab[4 * k1], qk1 = tab[4 * k1 + 1];
+      const unsigned long long m0 = __builtin_amdgcn_ballot_w64(alpha * fabs(qk0 - qs) + hk0 < hs);
+      const unsigned long long m1 = __builtin_amdgcn_ballot_w64(alpha * fabs(qk1 - qs) + hk1 < hs);
+      // (lane numbers in m0 here; the s_nop keeps the first write four instructions behind the compare
+      //  that produced its mask -- see envelope_rows4 -- and the second write follows another three)
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_mov_b32 m0, %6\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0\n\t"
+                   "s_mov_b32 m0, %7\n\ts_nop 0\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0"
+                   : "+v"(r1lo), "+v"(r1hi)
+                   : "s"((unsigned)m0), "s"((unsigned)(m0 >> 32)), "s"((unsigned)m1), "s"((unsigned)(m1 >> 32)), "s"(k0), "s"(k1)
+                   : "m0");
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
+  PSTAMP(18);
   const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const unsigned long long R1 = ((((unsigned long long)r1hi) << 32) | r1lo) & below;
   // D_k: exclusive prefix OR of the rows (row_shr 1 2 4 8, row_bcast 15 / 31, then one wave shift)
@@ -542,34 +650,95 @@ __device__ __forceinline__ bool build_envelope_parallel(int K, double alpha, dou
     D = ((unsigned long long)h2 << 32) | l2;
   }
   const unsigned long long cand = ~(D | R1) & below;
+  // The drop tests of source `lane` against the cone it meets (typeStereoLinear.h:432-449), evaluated
+  // up front against its six highest candidates (three at a time: one table read latency for each three): a round of
+  // the fixed point below is then a handful of bit operations.  `known` / `dropm`: candidates tested so
+  // far / those that drop this source; a round that meets another candidate tests it then.
+  // (per-lane bit sets as two 32-bit words: 64-bit shifts and compares are several times as expensive as
+  //  32-bit instructions here, and a round of the fixed point is little else)
+  const unsigned cand_lo = (unsigned)cand, cand_hi = (unsigned)(cand >> 32);
+  unsigned known_lo = 0, known_hi = 0, dropm_lo = 0, dropm_hi = 0;
+  auto top_bit = [](unsigned lo, unsigned hi) {   // index of the highest set bit (0 for the empty set: test lo | hi)
+    const int a = 31 - __builtin_clz(lo | 1u), b2 = 63 - __builtin_clz(hi | 1u);
+    return hi ? b2 : a;
+  };
+  // tests the (up to) three highest sources of `from` that have not been tested yet
+  auto test3 = [&](unsigned from_lo, unsigned from_hi) {
+    unsigned r_lo = from_lo & ~known_lo, r_hi = from_hi & ~known_hi;
+    int c[3];
+    bool real[3];
+    double hj[3], qj[3], tj[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      real[i] = (r_lo | r_hi) != 0;
+      c[i] = top_bit(r_lo, r_hi);
+      const unsigned bit = 1u << (c[i] & 31);
+      r_hi &= c[i] >= 32 ? ~bit : ~0u; r_lo &= c[i] >= 32 ? ~0u : ~bit;
+      hj[i] = tab[4 * c[i]]; qj[i] = tab[4 * c[i] + 1]; tj[i] = tab[4 * c[i] + 3];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double dist = alpha * fabs(qs - qj[i]);
+      const double num = (hs - hj[i]) + alpha * (qs + qj[i]);
+      // (| and selects, not || and branches: the compiler turns short-circuit conditions on per-lane
+      //  values into nested exec-mask regions, three per candidate here)
+      const bool dropped = (dist + hj[i] <= hs) | (num >= thi) | (num <= tj[i]);
+      const unsigned bit = real[i] ? 1u << (c[i] & 31) : 0u, dbit = dropped ? bit : 0u;
+      const bool up = c[i] >= 32;
+      known_hi |= up ? bit : 0u; known_lo |= up ? 0u : bit;
+      dropm_hi |= up ? dbit : 0u; dropm_lo |= up ? 0u : dbit;
+    }
+  };
+  test3(cand_lo, cand_hi);
+  test3(cand_lo, cand_hi);   // (six up front: on noisy ramps the cone a source meets is rarely its nearest candidate)
+  if (dbg & 4096) { known_lo = known_hi = dropm_lo = dropm_hi = 0; }
   unsigned long long P = K >= 64 ? ~0ull : ((1ull << K) - 1);
-  unsigned long long B = 0;
+  unsigned B_lo = 0, B_hi = 0;
   int js = 0;
   bool settled = false;
-  for (int round = 0; round <= K; ++round) {
-    B = P & cand;
-    js = B ? 63 - __builtin_clzll(B) : 0;
-    const double hj = tab[4 * js], qj = tab[4 * js + 1], tloj = tab[4 * js + 3];
-    const double dist = alpha * fabs(qs - qj);
-    const double num = (hs - hj) + alpha * (qs + qj);
-    const bool dropped = (dist + hj <= hs) || (num >= thi) || (num <= tloj);
-    const unsigned long long np = __builtin_amdgcn_ballot_w64(act && (B == 0 || !dropped)) | 1ull;
+  int extra_rounds = 0, late_tests = 0;
+  for (int round = 0; round <= K + 8; ++round) {
+    B_lo = (unsigned)P & cand_lo; B_hi = (unsigned)(P >> 32) & cand_hi;
+    const bool empty = (B_lo | B_hi) == 0;
+    js = top_bit(B_lo, B_hi);
+    const unsigned kw = js >= 32 ? known_hi : known_lo, dw = js >= 32 ? dropm_hi : dropm_lo;
+    const bool tested = (kw >> (js & 31)) & 1, drops = (dw >> (js & 31)) & 1;
+    // a source meets a cone it has not been tested against (its higher candidates were all dropped):
+    // that one and the next two that are still in P, which is where the following rounds tend to land
+    if (UNI(act & !empty & !tested)) { test3(B_lo, B_hi); ++late_tests; continue; }
+    const unsigned long long np = __builtin_amdgcn_ballot_w64(act & (empty | !drops)) | 1ull;
     if (np == P) { settled = true; break; }
     P = np;
+    ++extra_rounds;
   }
+  const unsigned long long B = ((unsigned long long)B_hi << 32) | B_lo;
+  (void)extra_rounds; (void)nrows; (void)late_tests;  // (read by the profile flavour only)
+  PSTAMP(20);
+#ifdef STEREO_HIP_MESSAGE_PROFILE
+  if (prof && lane == 0) {
+    atomicAdd(prof + 24, (unsigned long long)extra_rounds);                    // extra rounds of the fixed point
+    atomicAdd(prof + 26, (unsigned long long)__builtin_popcountll(P));         // pushed sources
+    atomicAdd(prof + 27, (unsigned long long)nrows);                           // rows of the pop test that were computed
+    atomicAdd(prof + 28, (unsigned long long)late_tests);                      // rounds that had to test more candidates
+  }
+#endif
   if (!settled) return false;
   // the cones a source dominates must be what the serial code pops: a top segment of its stack
   {
     const unsigned long long S = P & ~D & below;
     const bool bad = act && B != 0 && (S & R1 & ((1ull << js) - 1)) != 0;
-    if (UNI(bad)) return false;
+    if (UNI(bad)) {
+#ifdef STEREO_HIP_MESSAGE_PROFILE
+      if (prof && lane == 0) atomicAdd(prof + 25, 1ull);  // top-segment check failed
+#endif
+      return false;
+    }
   }
   const bool pushed = act && ((P >> lane) & 1);
   const int t = B ? __builtin_popcountll(B) : 0;
   if (pushed) {
     if (lane > 0) atomicMax(scr + 2 * t, lane << 8);
     if (B) atomicMax(scr + 2 * (t - 1) + 1, (lane << 8) | js);
-    atomicMax(scr + 128, t);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -579,13 +748,22 @@ __device__ __forceinline__ bool build_envelope_parallel(int K, double alpha, dou
   sh = tab[4 * src]; sq = tab[4 * src + 1];
   const double hk = tab[4 * zk], qk = tab[4 * zk + 1];
   const double hj = tab[4 * zj], qj = tab[4 * zj + 1];
-  const double s = ((hk - hj) + alpha * (qk + qj)) / (2 * alpha);
+  // (2 alpha a power of two: the quotient by multiplication, exact either way)
+  const double num = (hk - hj) + alpha * (qk + qj);
+  const double s = (exact_c && !(dbg & 8192)) ? num * (1.0 / (2 * alpha)) : num / (2 * alpha);
   zz = have_z ? s : inf;
-  maxtop_out = __builtin_amdgcn_readfirstlane(scr[128]);
+  // slots fill up from 0: the highest slot ever written is the highest one that holds a source
+  maxtop_out = 63 - __builtin_clzll(__builtin_amdgcn_ballot_w64(src != 0) | 1ull);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  PSTAMP(22);
+#ifdef STEREO_HIP_MESSAGE_PROFILE
+  if (prof && lane == 0)
+    for (int i = 0; i < 4; ++i) { atomicAdd(prof + 16 + 2 * i, (unsigned long long)pacc[i]); atomicAdd(prof + 17 + 2 * i, 1ull); }
+#endif
   return true;
 }
+#undef PSTAMP
 
 // Certified fast path of the truncated QUADRATIC message (typeStereoQuadratic.h:329-501), K <= 64,
 // lane = source and destination label.  The reference builds the lower envelope of the parabolas
@@ -647,7 +825,7 @@ __device__ __forceinline__ bool message_quad_fast(double lambda, int K, double a
     m2 = min_raw(m2, hi);  // second smallest, equal costs of two sources count
     m1 = lo;
     const double dq = fabs(qsrc - qj);
-    gap = lane != j ? min_raw(gap, dq) : gap;
+    gap = min_raw_if(lane != j, gap, dq);
   }
   gap = wave_min_dpp(act ? gap : inf);
   bool bad = !(delta < inf) || !(alpha > 0) || !(gap > 4e-8);
@@ -660,7 +838,28 @@ __device__ __forceinline__ bool message_quad_fast(double lambda, int K, double a
 }
 
 constexpr int kMaxSlots = TrwsGraph::kMaxSlots;
-constexpr int kSpinLimit = 1 << 22;  // polls before a launch gives up (bounded spin)
+constexpr int kSpinLimit = 1 << 22;  // polls before a wait INSIDE a workgroup (LDS flags) gives up
+
+// Waiting for ANOTHER workgroup -- with row strips possibly another process on another GPU, whose
+// launch may start late -- is bounded by wall-clock time (DevParams::spin_ticks of the 100 MHz
+// s_memrealtime counter; STEREO_HIP_TRWS_SPIN_SECONDS), not by a poll count: one step of such a wait.
+// Every 1024 polls it looks at the abort flag (somebody else gave up) and at the clock.
+__device__ __forceinline__ bool keep_waiting(const DevParams &p, int &spins, long long &t0) {
+  __builtin_amdgcn_s_sleep(1);
+  if ((++spins & 1023) != 0) return true;
+  if (ld_sc1(p.abort_flag)) return false;
+  const long long now = (long long)wall_clock64();
+  if (spins == 1024) { t0 = now; return true; }
+  return now - t0 < p.spin_ticks;
+}
+// The first visit that gives up says what it was waiting for (the host turns it into the error text):
+// abort_flag[1..4] = visiting rank, awaited rank, value seen in its flag, epoch expected.
+__device__ __forceinline__ void report_give_up(const DevParams &p, int visiting_rank, int awaited_rank, int seen, int epoch) {
+  if (atomicCAS(p.abort_flag, 0, 1) == 0) {
+    st_sc1(p.abort_flag + 1, visiting_rank); st_sc1(p.abort_flag + 2, awaited_rank);
+    st_sc1(p.abort_flag + 3, seen); st_sc1(p.abort_flag + 4, epoch);
+  }
+}
 
 // ---- fast persistent sweep: K <= 64, <= 4 edges per list, <= 2 foreign dependencies ----
 // Same dataflow schedule as trws_persistent_kernel, restructured so that in
@@ -704,13 +903,13 @@ __device__ __forceinline__ NodeDesc decode_desc(int w) {
 }
 
 // bounded wait for one completion flag; returns false if the launch must give up
-__device__ __forceinline__ bool wait_flag(const DevParams &p, int rank, int epoch) {
+__device__ __forceinline__ bool wait_flag(const DevParams &p, int rank, int epoch, int visiting_rank = -1) {
   const int32_t *flag = p.done + rank;
-  int spins = 0;
-  while (ld_sc1(flag) < epoch) {
-    __builtin_amdgcn_s_sleep(1);
-    if (++spins > kSpinLimit || ((spins & 1023) == 0 && ld_sc1(p.abort_flag))) {
-      st_sc1(p.abort_flag, 1);
+  int spins = 0, v;
+  long long t0 = 0;
+  while ((v = ld_sc1(flag)) < epoch) {
+    if (!keep_waiting(p, spins, t0)) {
+      report_give_up(p, visiting_rank, rank, v, epoch);
       return false;
     }
   }
@@ -753,17 +952,26 @@ __device__ __forceinline__ void wave_sort2(unsigned &a, unsigned &b, int lane) {
 // test.  Out-of-range plane proposals (unary ~ 4e7, dispmap_ncc.m:245) would otherwise inflate delta
 // and send almost every message of such a fusion to the serial construction.  Returns "still bad";
 // m1 = min-plus value over the useful sources.
-__device__ __attribute__((noinline)) bool message_second_look(double lambda, int K, double alpha, double h,
-                                                              double qsrc, double t, double vtrunc,
-                                                              double delta, int lane, double &m1_out) {
-  const double inf = __builtin_huge_val();
+// (the cheap part -- does leaving out the far cones shrink delta at all? -- is inline at the call site:
+//  a call costs this kernel ~10 k cycles of register traffic, and on volumes whose failures are exact
+//  ties, e.g. the flat columns of an NCC volume, it never does)
+__device__ __forceinline__ bool second_look_applies(double lambda, int K, double alpha, double h, double qsrc, double t,
+                                                    double vtrunc, double delta, int lane, double &delta2_out, bool &rel_out) {
   const bool act = lane < K;
   const double aq = alpha * qsrc;
   const double qabs = wave_max_dpp(act ? max_raw(fabs(qsrc), fabs(t)) : 0.0);
   const bool rel = act && h <= vtrunc + 2.000002 * fabs(alpha) * qabs;
   const double mag2 = max_raw(wave_max_dpp(act ? (rel ? fabs(h) : 0.0) + fabs(aq) + alpha * fabs(t) : 0.0), fabs(vtrunc));
   const double delta2 = 1e-9 * (mag2 + fabs(alpha * lambda));
-  if (!(delta2 < delta)) return true;
+  delta2_out = delta2; rel_out = rel;
+  return delta2 < delta;
+}
+__device__ __attribute__((noinline)) bool message_second_look(int K, double alpha, double h, double qsrc, double t,
+                                                              double vtrunc, double delta2, bool rel, int lane,
+                                                              double &m1_out) {
+  const double inf = __builtin_huge_val();
+  const bool act = lane < K;
+  const double aq = alpha * qsrc;
   const double ui = h - aq, vi = h + aq;
   unsigned long long mask = __builtin_amdgcn_ballot_w64(act && h < vtrunc);
   double m1 = inf, m2 = inf;
@@ -774,7 +982,7 @@ __device__ __attribute__((noinline)) bool message_second_look(double lambda, int
     const double hj = readlane_f64(h, j), qj = readlane_f64(qsrc, j);
     const double c = pair_cost<1>(alpha, t - qj, hj);
     const double lo = min_raw(m1, c), hi = max_raw(m1, c);
-    m2 = hi > lo ? min_raw(m2, hi) : m2;
+    m2 = min_raw_if(hi > lo, m2, hi);
     m1 = lo;
     const double aqj = alpha * qj;
     const bool near = (fabs(ui - (hj - aqj)) <= delta2) || (fabs(vi - (hj + aqj)) <= delta2);
@@ -794,30 +1002,54 @@ __device__ __attribute__((noinline)) bool message_second_look(double lambda, int
 // as +inf, so the search ends at maxtop when nothing below stops it.
 template <int KERNEL>
 __device__ __forceinline__ double envelope_value(const DevParams &p, double alpha, double t, double vtrunc, double sh,
-                                                 double sq, double zz, int maxtop, int lane) {
+                                                 double sq, double zz, int maxtop, int lane, double *tab = nullptr) {
   const double inf = __builtin_huge_val();
   int slot;
+  double ch, cq;
   if (p.debug & 1024) {
     slot = maxtop;
     for (int j = maxtop - 1; j >= 0; --j) {
       const double zj1 = readlane_f64(zz, j);
       slot = !(zj1 < t) ? j : slot;
     }
+    ch = __shfl(sh, slot, kWave); cq = __shfl(sq, slot, kWave);
   } else {
     double zm = (lane >= maxtop || zz != zz) ? inf : zz;  // (a NaN breakpoint stops the walk like +inf does)
+    if (tab) {
+      // running maximum by DPP (no LDS round trips), then the slots' (running maximum, height, position)
+      // go to this wave's table and the bisection reads them from there: one ds_read per probe instead of
+      // two ds_bpermute, and one for the answer
+#define STEREO_SCAN(C, M) { const double o = dpp_f64_keep<C, M>(zm); zm = max_raw(o, zm); }
+      STEREO_SCAN(0x111, 0xF) STEREO_SCAN(0x112, 0xF) STEREO_SCAN(0x114, 0xF) STEREO_SCAN(0x118, 0xF)
+      STEREO_SCAN(0x142, 0xA) STEREO_SCAN(0x143, 0xC)
+#undef STEREO_SCAN
+      tab[4 * lane] = zm; tab[4 * lane + 1] = sh; tab[4 * lane + 2] = sq;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      slot = 0;
 #pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-      const double up = __shfl_up(zm, o, kWave);
-      zm = (lane >= o && up > zm) ? up : zm;
-    }
-    slot = 0;
+      for (int step = kWave / 2; step >= 1; step >>= 1) {
+        const double probe = tab[4 * (slot + step - 1)];
+        slot = probe < t ? slot + step : slot;
+      }
+      ch = tab[4 * slot + 1]; cq = tab[4 * slot + 2];
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    } else {
 #pragma unroll
-    for (int step = kWave / 2; step >= 1; step >>= 1) {
-      const double probe = __shfl(zm, slot + step - 1, kWave);
-      slot = probe < t ? slot + step : slot;
+      for (int o = 1; o < kWave; o <<= 1) {
+        const double up = __shfl_up(zm, o, kWave);
+        zm = (lane >= o && up > zm) ? up : zm;
+      }
+      slot = 0;
+#pragma unroll
+      for (int step = kWave / 2; step >= 1; step >>= 1) {
+        const double probe = __shfl(zm, slot + step - 1, kWave);
+        slot = probe < t ? slot + step : slot;
+      }
+      ch = __shfl(sh, slot, kWave); cq = __shfl(sq, slot, kWave);
     }
   }
-  const double ch = __shfl(sh, slot, kWave), cq = __shfl(sq, slot, kWave);
   const double c = pair_cost<KERNEL>(alpha, t - cq, ch);
   return c < vtrunc ? c : vtrunc;
 }
@@ -889,7 +1121,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
   {                                                                                  \
     const double c = pair_cost<1>(alpha, t - QJ, HJ);                                \
     const double lo = min_raw(m1, c), hi = max_raw(m1, c);                           \
-    m2 = hi > lo ? min_raw(m2, hi) : m2;                                             \
+    m2 = min_raw_if(hi > lo, m2, hi);                                                \
     m1 = lo;                                                                         \
     const bool near = (fabs(ui - HJ##u) <= delta) || (fabs(vi - HJ##v) <= delta);    \
     bad = bad || (near && qsrc != QJ);                                               \
@@ -921,20 +1153,31 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
           const double hj = hq[4 * (lane + d)], qj = hq[4 * (lane + d) + 1];
           const double c = pair_cost<1>(alpha, t - qj, hj);
           const double lo = min_raw(m1, c), hi = max_raw(m1, c);
-          m2 = hi > lo ? min_raw(m2, hi) : m2;
+          m2 = min_raw_if(hi > lo, m2, hi);
           m1 = lo;
         }
       } else {
-      while (mask) {
-        const int j0 = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        const int j1 = mask ? __builtin_ctzll(mask) : j0;  // a source visited twice changes nothing
-        mask &= mask - 1;
-        STEREO_SRC(j0, hj0, qj0)
-        STEREO_SRC(j1, hj1, qj1)
-        STEREO_ACC(hj0, qj0)
+      // (a wave whose last certificate failed checks after every trip whether this one has failed
+      //  already: in the flat columns of an NCC volume the failures come in runs)
+      //  -- its own copy of the loop, so that the check costs the other waves nothing)
+#define STEREO_TRIP                                                                   \
+        const int j0 = __builtin_ctzll(mask);                                          \
+        mask &= mask - 1;                                                              \
+        const int j1 = mask ? __builtin_ctzll(mask) : j0; /* a source visited twice changes nothing */ \
+        mask &= mask - 1;                                                              \
+        STEREO_SRC(j0, hj0, qj0)                                                       \
+        STEREO_SRC(j1, hj1, qj1)                                                       \
+        STEREO_ACC(hj0, qj0)                                                           \
         STEREO_ACC(hj1, qj1)
+      if (look_streak && *look_streak > 0) {
+        while (mask) {
+          if (UNI(act && bad)) break;
+          STEREO_TRIP
+        }
+      } else {
+        while (mask) { STEREO_TRIP }
       }
+#undef STEREO_TRIP
       }
 #undef STEREO_SRC
 #undef STEREO_ACC
@@ -949,12 +1192,17 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
       if (need_serial) {
         const int streak = look_streak ? *look_streak : 0;
         if (streak < 4 || (streak & 31) == 0) {
-          need_serial = message_second_look(p.lambda, K, alpha, h, qsrc, t, vtrunc, delta, lane, m1);
+          double delta2;
+          bool rel;
+          if (second_look_applies(p.lambda, K, alpha, h, qsrc, t, vtrunc, delta, lane, delta2, rel) && !(p.debug & 32768))
+            need_serial = message_second_look(K, alpha, h, qsrc, t, vtrunc, delta2, rel, lane, m1);
           MSTAMP(10);
           if (look_streak) *look_streak = need_serial ? streak + 1 : 0;
         } else {
           *look_streak = streak + 1;
         }
+      } else if (look_streak) {
+        *look_streak = 0;
       }
       out = m1 < vtrunc ? m1 : vtrunc;
       if (need_serial && lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
@@ -978,12 +1226,12 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
       bool built = false;
       if (KERNEL == 1 && !(p.debug & 512)) {
         // (hq + 4 (64 + pad): the scratch words behind this wave's table, see kPipeTab)
-        if (hq && !(p.debug & 2048)) built = build_envelope_parallel(K, alpha, hs, qs, hq, (int *)(hq + 4 * (kWave + 16)), sh, sq, zz, lane, maxtop);
+        if (hq && !(p.debug & 2048)) built = build_envelope_parallel(K, alpha, hs, qs, hq, (int *)(hq + 4 * (kWave + 16)), sh, sq, zz, lane, maxtop, mag, p.prof, p.debug);
         if (!built) built = build_envelope_masks(K, alpha, hs, qs, sh, sq, zz, lane, maxtop);
       }
       if (!built) maxtop = build_envelope_regs<KERNEL>(K, alpha, hs, qs, sh, sq, zz, lane);
       MSTAMP(12);
-      out = envelope_value<KERNEL>(p, alpha, t, vtrunc, sh, sq, zz, maxtop, lane);
+      out = envelope_value<KERNEL>(p, alpha, t, vtrunc, sh, sq, zz, maxtop, lane, hq);
       MSTAMP(14);
     }
 #undef MSTAMP

@@ -205,7 +205,7 @@ __device__ double update_message(const DevParams &p, int e, const double *Di, do
           for (int it = 0; it < 2; ++it) {
             const double c = pair_cost<1>(alpha, tt[it] - qj, hj);
             const double lo = min_raw(m1[it], c), hi = max_raw(m1[it], c);
-            m2[it] = hi > lo ? min_raw(m2[it], hi) : m2[it];
+            m2[it] = min_raw_if(hi > lo, m2[it], hi);
             m1[it] = lo;
             const bool near = (fabs(ck_u[it] - uj) <= delta) || (fabs(ck_v[it] - vj) <= delta);
             bad = bad || (near && ck_q[it] != qj && rel[it] && lane + it * kWave < K);
@@ -421,11 +421,11 @@ __global__ __launch_bounds__(kBlock) void trws_persistent_kernel(DevParams p, in
       int gave_up = 0;
       if (tid < nd) {
         const int32_t *flag = p.done + p.dep_rank[D][d0 + tid];
-        int spins = 0;
-        while (ld_sc1(flag) < epoch) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > kSpinLimit || ((spins & 1023) == 0 && ld_sc1(p.abort_flag))) {
-            st_sc1(p.abort_flag, 1);
+        int spins = 0, v;
+        long long t0 = 0;
+        while ((v = ld_sc1(flag)) < epoch) {
+          if (!keep_waiting(p, spins, t0)) {
+            report_give_up(p, r, p.dep_rank[D][d0 + tid], v, epoch);
             gave_up = 1;
             break;
           }

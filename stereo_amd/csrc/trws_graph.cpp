@@ -368,22 +368,33 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
       std::vector<int32_t> order(R), ticket_of_run(R);
       for (int64_t k = 0; k < R; ++k) order[k] = (int32_t)k;
       if (cut) std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return first_lev[x] < first_lev[y]; });
+      // With strips every strip has its own dispenser and its own (smaller) set of workgroups: the
+      // tickets that count are the positions among the strip's OWN runs, a dependency in another
+      // strip's run is served by that strip's workgroups, and the test is made whatever the run count
+      // (a strip may be launched with fewer workgroups than it has runs: logical strips that share a
+      // device, max_workgroups, a partitioned GPU).
       auto look_ahead_ok = [&]() {
-        for (int64_t t = 0; t < R; ++t) ticket_of_run[order[t]] = (int32_t)t;
-        std::vector<int32_t> ahead(R, 0);  // per ticket: farthest ticket it waits for, minus its own
+        std::vector<int32_t> strip_of_run(R, 0), seen(std::max(nstrips, 1), 0);
+        if (own) for (int64_t k = 0; k < R; ++k) strip_of_run[k] = own[g.order[run_head[k]]];
+        for (int64_t t = 0; t < R; ++t) ticket_of_run[order[t]] = seen[strip_of_run[order[t]]]++;
+        std::vector<std::vector<int32_t>> ahead(std::max(nstrips, 1));  // per strip and ticket: farthest ticket it waits for, minus its own
+        for (int s2 = 0; s2 < std::max(nstrips, 1); ++s2) ahead[s2].assign(seen[s2], 0);
         for (int64_t r = 0; r < N; ++r)
           for (int32_t x : deps[r]) {
-            const int32_t mine = ticket_of_run[run_of[r]], theirs = ticket_of_run[run_of[x]];
-            ahead[mine] = std::max(ahead[mine], theirs - mine);
+            const int32_t rm = run_of[r], rt = run_of[x];
+            if (strip_of_run[rm] != strip_of_run[rt]) continue;
+            const int32_t mine = ticket_of_run[rm], theirs = ticket_of_run[rt];
+            ahead[strip_of_run[rm]][mine] = std::max(ahead[strip_of_run[rm]][mine], theirs - mine);
           }
-        for (int64_t t = 0; t < R; ++t)
-          if (ahead[t] > 1 || (ahead[t] == 1 && t + 1 < R && ahead[t + 1] > 0)) return false;
+        for (const auto &a : ahead)
+          for (size_t t = 0; t < a.size(); ++t)
+            if (a[t] > 1 || (a[t] == 1 && t + 1 < a.size() && a[t + 1] > 0)) return false;
         return true;
       };
       // (checked whenever there are more runs than CUs: one workgroup per CU is all that is certain
       // to be resident, whatever max_resident_runs the caller derived from its kernel's LDS use)
       const int64_t resident = max_resident_runs > 0 ? std::min(max_resident_runs, std::max<int64_t>(certainly_resident, 1)) : 0;
-      if (ok && resident > 0 && R > resident && !look_ahead_ok()) {
+      if (ok && ((resident > 0 && R > resident) || nstrips > 1) && !look_ahead_ok()) {
         if (cut) {  // try creation order before giving up
           for (int64_t k = 0; k < R; ++k) order[k] = (int32_t)k;
           ok = look_ahead_ok();

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, i
                           for (int c = 0; c < 2; ++c) {
                             const double cst = pair_cost<1>(alpha, qdst[c] - qj, hj);
                             const double lo = min_raw(m1[c], cst), hi = max_raw(m1[c], cst);
-                            m2[c] = hi > lo ? min_raw(m2[c], hi) : m2[c];
+                            m2[c] = min_raw_if(hi > lo, m2[c], hi);
                             m1[c] = lo;
                             const bool near = (fabs(ui[c] - uj) <= dl) || (fabs(vi[c] - vj) <= dl);
                             bad = bad || (near && qsrc[c] != qj && rel[c]);
@@ -286,14 +286,18 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, i
               if (lane == j) myrank = nx.dep[j];
             const bool watching = lane < nx.ndep;
             int spins = 0;
+            long long t0 = 0;
             bool ok = true;
             for (;;) {
               const int v = watching ? ld_sc1(p.done + myrank) : epoch;
               if (!UNI(v < epoch)) break;
-              __builtin_amdgcn_s_sleep(1);
-              if (++spins > kSpinLimit || ((spins & 1023) == 0 && ld_sc1(p.abort_flag))) { ok = false; break; }
+              if (!keep_waiting(p, spins, t0)) {   // wall-clock bound, or somebody else gave up
+                if (lane == __builtin_ctzll(__builtin_amdgcn_ballot_w64(v < epoch))) report_give_up(p, nx.rank, myrank, v, epoch);
+                ok = false;
+                break;
+              }
             }
-            if (!ok && lane == 0) { st_sc1(p.abort_flag, 1); ctl[1] = 1; }
+            if (!ok && lane == 0) ctl[1] = 1;
           }
 #pragma unroll
           for (int j = 0; j < 8; ++j) {

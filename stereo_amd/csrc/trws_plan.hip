@@ -44,6 +44,8 @@
 
 namespace stereo {
 
+constexpr int kCtlWords = 8;  // d_ctl: ticket, abort flag, four words of give-up report, two spare
+
 std::string &last_error() {
   static thread_local std::string s;
   return s;
@@ -164,7 +166,7 @@ struct stereo_trws_plan {
   DevBuf<double> d_gamma, d_msg, d_lbterms, d_eterms;
   // persistent sweep schedule
   DevBuf<int32_t> d_run_order[2], d_chain_run_ptr[2], d_chain_run_order[2];
-  DevBuf<int32_t> d_run_ptr[2], d_dep_ptr[2], d_dep_rank[2], d_done, d_ctl;  // d_ctl: [ticket, abort]
+  DevBuf<int32_t> d_run_ptr[2], d_dep_ptr[2], d_dep_rank[2], d_done, d_ctl;  // d_ctl: [ticket, abort, give-up report x 4]
   DevBuf<int8_t> d_in_slot[2];
   DevBuf<int32_t> d_desc[2];
   bool fast = false;
@@ -178,6 +180,7 @@ struct stereo_trws_plan {
   DevBuf<unsigned long long> d_fallbacks, d_prof, d_timeline;
   bool certificate = true;
   int epoch = 0;
+  long long spin_ticks = 0;  // wall-clock bound of a wait for another workgroup (100 MHz ticks)
   bool fwd_pending = false;  // the forward sweep of the next iteration has already run
   int grid_blocks = 0;
   // inputs (owned unless bound)
@@ -270,6 +273,7 @@ DevParams make_params(stereo_trws_plan *P) {
   p.peer_done0 = P->peer_done[0]; p.peer_done1 = P->peer_done[1];
   p.peer_x0 = P->peer_x[0]; p.peer_x1 = P->peer_x[1];
   p.done = P->d_done.p; p.ticket = P->d_ctl.p; p.abort_flag = P->d_ctl.p + 1; p.N = (int)P->Nl;
+  p.spin_ticks = P->spin_ticks;
   p.fallbacks = P->d_fallbacks.p; p.certificate = P->certificate ? 1 : 0;
   // MINPLUS in the wide-label regime runs the chunk-parallel kernel (trws_chunk.hip)
   p.lean = (P->wide && P->mode == STEREO_TRWS_MESSAGES_MINPLUS) ? 1 : 0;
@@ -332,7 +336,7 @@ void reset_state(stereo_trws_plan *P) {
   STEREO_HIP_CHECK(hipMemset(P->d_msg.p, 0, sizeof(double) * (size_t)P->El * P->K));
   STEREO_HIP_CHECK(hipMemset(P->d_x.p, 0, sizeof(int32_t) * P->Nl));
   STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * P->Nl));
-  STEREO_HIP_CHECK(hipMemset(P->d_ctl.p, 0, sizeof(int32_t) * 2));
+  STEREO_HIP_CHECK(hipMemset(P->d_ctl.p, 0, sizeof(int32_t) * kCtlWords));
   STEREO_HIP_CHECK(hipDeviceSynchronize());
   P->iterations = 0; P->energy = 0; P->lb = 0; P->epoch = 0; P->fwd_pending = false;
   P->lb_in_flight = false; P->issued = false;
@@ -488,6 +492,13 @@ int stereo_hip_warm_up(void) {
   return stereo_rd(U, U, same, diff, diff, same, conn, 3, 3, 1, lab, &en, &lb, &nu, err, sizeof(err));
 }
 
+int stereo_hip_device_cus(void) {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  return cus;
+}
+
 int stereo_hip_set_device(int device) {
   if (hipSetDevice(device) != hipSuccess) {
     last_error() = "hipSetDevice failed";
@@ -631,15 +642,23 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
     bool fine = nstrips > 1 && stereo_hip_device_count() > 1;
     if (const char *fg = std::getenv("STEREO_HIP_STRIPS_FINEGRAINED")) fine = nstrips > 1 && std::atoi(fg) != 0;
     if (fine) P->d_done.alloc_fine_grained(P->Nl); else P->d_done.alloc(P->Nl);
-    P->d_ctl.alloc(2);
+    P->d_ctl.alloc(kCtlWords);
     P->d_fallbacks.alloc(1);
     STEREO_HIP_CHECK(hipMemset(P->d_fallbacks.p, 0, sizeof(unsigned long long)));
     if (const char *c = std::getenv("STEREO_HIP_TRWS_CERTIFICATE")) P->certificate = std::string(c) != "0";
+    {
+      // how long a visit may wait for another workgroup before the launch gives up: inside one launch
+      // a flag is late by microseconds; a neighbouring strip's launch belongs to another process and
+      // may start seconds later (code-object load, a busy host)
+      double secs = nstrips > 1 ? 120.0 : 20.0;
+      if (const char *c = std::getenv("STEREO_HIP_TRWS_SPIN_SECONDS")) secs = std::max(0.001, std::atof(c));
+      P->spin_ticks = (long long)(secs * 1e8);
+    }
     if (std::getenv("STEREO_HIP_TRWS_PROF")) { P->d_prof.alloc(32); STEREO_HIP_CHECK(hipMemset(P->d_prof.p, 0, 256)); }
     if (std::getenv("STEREO_HIP_TRWS_TIMELINE"))
       P->d_timeline.alloc(4 * std::max({g.sweep[0].run_ptr.size(), g.sweep[0].chain_run_ptr.size(), g.sweep[1].chain_run_ptr.size()}) + 4);
     STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * P->Nl));
-    STEREO_HIP_CHECK(hipMemset(P->d_ctl.p, 0, sizeof(int32_t) * 2));
+    STEREO_HIP_CHECK(hipMemset(P->d_ctl.p, 0, sizeof(int32_t) * kCtlWords));
     {
       // one workgroup per concurrently active run, capped by what stays resident
       int64_t runs = std::max<int64_t>((int64_t)g.sweep[0].run_ptr.size() - 1, 1);
@@ -653,8 +672,8 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
     P->d_lbterms.alloc(P->n_lb);
     P->d_eterms.alloc(P->n_en);
     if (fine) P->d_x.alloc_fine_grained(P->Nl); else P->d_x.alloc(P->Nl);
-    P->h_lb.alloc(P->n_lb); P->h_en.alloc(P->n_en); P->h_x.alloc(P->Nl); P->h_ctl.alloc(2);
-    P->h_ctl.p[0] = P->h_ctl.p[1] = 0;
+    P->h_lb.alloc(P->n_lb); P->h_en.alloc(P->n_en); P->h_x.alloc(P->Nl); P->h_ctl.alloc(kCtlWords);
+    std::memset(P->h_ctl.p, 0, sizeof(int32_t) * kCtlWords);
     STEREO_HIP_CHECK(hipMemset(P->d_msg.p, 0, sizeof(double) * (size_t)P->El * K));
     STEREO_HIP_CHECK(hipMemset(P->d_x.p, 0, sizeof(int32_t) * P->Nl));
     STEREO_HIP_CHECK(hipEventCreate(&P->ev0));
@@ -693,6 +712,7 @@ int stereo_trws_plan_create_strip(int kernel, int K, int64_t N, int64_t E, const
 }
 
 void stereo_trws_plan_destroy(stereo_trws_plan *plan) {
+  DeviceScope device_scope_(plan ? plan->device : -1);
   if (plan && plan->d_timeline.p) {
     const bool chain = plan->graph->fast_ok && (plan->wide || plan->fast2 || plan->fast);
     const size_t R = (chain ? plan->graph->sweep[0].chain_run_ptr.size() : plan->graph->sweep[0].run_ptr.size()) - 1;
@@ -718,6 +738,12 @@ void stereo_trws_plan_destroy(stereo_trws_plan *plan) {
                              "serial construction %.0f x %llu | walk %.0f x %llu\n",
                      (double)v[8] / v[9], v[9], v[11] ? (double)v[10] / v[11] : 0.0, v[11], v[13] ? (double)v[12] / v[13] : 0.0,
                      v[13], v[15] ? (double)v[14] / v[15] : 0.0, v[15]);
+      if (!plan->wide && v[17])
+        std::fprintf(stderr, "[stereo_hip prof closed form] thresholds %.0f cycles | rows %.0f | scan + fixed point %.0f | slots + fill %.0f | "
+                             "x %llu, extra rounds %.2f (%.2f with late tests), pushed %.1f, rows computed %.1f, top-segment check failed %llu\n",
+                     (double)v[16] / v[17], v[19] ? (double)v[18] / v[19] : 0.0, v[21] ? (double)v[20] / v[21] : 0.0,
+                     v[23] ? (double)v[22] / v[23] : 0.0, v[17], v[21] ? (double)v[24] / v[21] : 0.0, v[21] ? (double)v[28] / v[21] : 0.0,
+                     v[21] ? (double)v[26] / v[21] : 0.0, v[21] ? (double)v[27] / v[21] : 0.0, v[25]);
       if (plan->wide && v[22]) {
         std::fprintf(stderr, "[stereo_hip prof wide] cycles per visit of wave 0:");
         for (int i = 0; i < 16; ++i) std::fprintf(stderr, " [%d] %.0f", i, (double)v[i] / v[22]);
@@ -733,6 +759,7 @@ void stereo_trws_plan_destroy(stereo_trws_plan *plan) {
 int stereo_trws_plan_upload(stereo_trws_plan *P, const double *unary, const double *q,
                             const double *qprim, const double *positions, const double *alphas,
                             double tol, char *err, size_t errcap) {
+  DeviceScope device_scope_(P ? P->device : -1);
   if (!P || !unary || !alphas) return fail("stereo_trws_plan_upload: NULL argument", err, errcap);
   const bool shared = (q == nullptr && qprim == nullptr);
   if (shared && !positions) return fail("stereo_trws_plan_upload: need q/qprim or positions", err, errcap);
@@ -770,6 +797,7 @@ int stereo_trws_plan_upload(stereo_trws_plan *P, const double *unary, const doub
 int stereo_trws_plan_bind_device(stereo_trws_plan *P, const double *d_unary, const double *d_q,
                                  const double *d_qprim, const double *d_positions,
                                  const double *d_alphas, double tol, char *err, size_t errcap) {
+  DeviceScope device_scope_(P ? P->device : -1);
   if (!P || !d_unary || !d_alphas) return fail("stereo_trws_plan_bind_device: NULL argument", err, errcap);
   const bool shared = (d_q == nullptr && d_qprim == nullptr);
   if (shared && !d_positions) return fail("stereo_trws_plan_bind_device: need q/qprim or positions", err, errcap);
@@ -811,6 +839,7 @@ int stereo_trws_plan_bind_device(stereo_trws_plan *P, const double *d_unary, con
 int stereo_trws_plan_bind_device_strip(stereo_trws_plan *P, const double *d_unary, const double *d_q,
                                        const double *d_qprim, const double *d_positions,
                                        const double *d_alphas, double tol, char *err, size_t errcap) {
+  DeviceScope device_scope_(P ? P->device : -1);
   if (!P || !d_unary || !d_alphas) return fail("stereo_trws_plan_bind_device_strip: NULL argument", err, errcap);
   const bool shared = (d_q == nullptr && d_qprim == nullptr);
   if (shared && !d_positions) return fail("stereo_trws_plan_bind_device_strip: need q/qprim or positions", err, errcap);
@@ -838,6 +867,7 @@ int stereo_trws_plan_strip_layout(stereo_trws_plan *P, int64_t *n_nodes, int64_t
 }
 
 int stereo_trws_plan_reset(stereo_trws_plan *P, char *err, size_t errcap) {
+  DeviceScope device_scope_(P ? P->device : -1);
   if (!P) return fail("stereo_trws_plan_reset: NULL plan", err, errcap);
   try {
     reset_state(P);
@@ -853,7 +883,7 @@ static void issue_iteration(stereo_trws_plan *P, const DevParams &p, hipStream_t
   if (!P->lb_in_flight)
     STEREO_HIP_CHECK(hipMemcpyAsync(P->h_lb.p, P->d_lbterms.p, sizeof(double) * P->n_lb, hipMemcpyDeviceToHost, s));
   STEREO_HIP_CHECK(hipMemcpyAsync(P->h_en.p, P->d_eterms.p, sizeof(double) * P->n_en, hipMemcpyDeviceToHost, s));
-  STEREO_HIP_CHECK(hipMemcpyAsync(P->h_ctl.p, P->d_ctl.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  STEREO_HIP_CHECK(hipMemcpyAsync(P->h_ctl.p, P->d_ctl.p, kCtlWords * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   P->issued = true;
 }
 
@@ -883,7 +913,24 @@ static bool collect_iteration(stereo_trws_plan *P, hipStream_t s, double *lb_out
   return true;
 }
 
-static const char *kGaveUp = "stereo_trws: a persistent sweep gave up waiting on a dependency flag";
+// What a sweep that gave up says (h_ctl[2..5] = report_give_up's words; all zero when the give-up came
+// from a wait inside a workgroup, which has no report).
+static std::string gave_up_text(const stereo_trws_plan *P) {
+  const int32_t *c = P->h_ctl.p;
+  char b[512];
+  const double secs = (double)P->spin_ticks / 1e8;
+  if (c[2] == 0 && c[3] == 0 && c[4] == 0 && c[5] == 0) {
+    std::snprintf(b, sizeof(b), "stereo_trws: a persistent sweep gave up waiting on a dependency flag (strip %d of %d, device %d)",
+                  P->strip, P->nstrips, P->device);
+  } else {
+    const bool halo = P->layout && (int64_t)c[3] >= P->layout->n_own;  // (strip-local ids: own nodes first, then the halo)
+    std::snprintf(b, sizeof(b), "stereo_trws: a persistent sweep gave up waiting on a dependency flag: strip %d of %d (device %d), "
+                  "the visit of rank %d waited %.0f s for the completion flag of rank %d (found %d, expected epoch %d)%s",
+                  P->strip, P->nstrips, P->device, c[2], secs, c[3], c[4], c[5],
+                  halo ? " -- a node of the NEIGHBOURING strip: is that strip's process / launch running?" : "");
+  }
+  return b;
+}
 
 static int strip_ready(stereo_trws_plan *P, const char *who, char *err, size_t errcap) {
   if (!P) return fail(std::string(who) + ": NULL plan", err, errcap);
@@ -896,6 +943,7 @@ static int strip_ready(stereo_trws_plan *P, const char *who, char *err, size_t e
 
 int stereo_trws_plan_iterate(stereo_trws_plan *P, int iters, double max_relgap, void *stream,
                              int *done_iters, int *stopped, char *err, size_t errcap) {
+  DeviceScope device_scope_(P ? P->device : -1);
   if (!P) return fail("stereo_trws_plan_iterate: NULL plan", err, errcap);
   if (!P->have_inputs) return fail("stereo_trws_plan_iterate: no inputs uploaded/bound", err, errcap);
   if (P->nstrips > 1)
@@ -909,7 +957,7 @@ int stereo_trws_plan_iterate(stereo_trws_plan *P, int iters, double max_relgap, 
     for (int it = 0; it < iters; ++it) {
       issue_iteration(P, p, s);
       double lb = 0, en = 0;
-      if (!collect_iteration(P, s, &lb, &en)) return fail(kGaveUp, err, errcap);
+      if (!collect_iteration(P, s, &lb, &en)) return fail(gave_up_text(P), err, errcap);
       P->lb = lb; P->energy = en; P->iterations += 1;
       if (done_iters) *done_iters += 1;
       const double rel_gap = (en - lb) / en;  // minimize.cpp:105
@@ -947,6 +995,7 @@ static void launch_group(stereo_trws_plan *const *G, int n, int what, hipStream_
 }
 
 int stereo_trws_plans_issue(stereo_trws_plan *const *plans, int n, void *stream, char *err, size_t errcap) {
+  DeviceScope device_scope_(plans && n > 0 && plans[0] ? plans[0]->device : -1);
   if (!plans || n < 1 || n > kMaxGroup) return fail("stereo_trws_plans_issue: need 1 .. 16 plans", err, errcap);
   for (int i = 0; i < n; ++i) {
     if (int rc = strip_ready(plans[i], "stereo_trws_plans_issue", err, errcap)) return rc;
@@ -985,7 +1034,7 @@ int stereo_trws_plans_issue(stereo_trws_plan *const *plans, int n, void *stream,
       stereo_trws_plan *P = plans[i];
       P->fwd_pending = true;
       STEREO_HIP_CHECK(hipMemcpyAsync(P->h_en.p, P->d_eterms.p, sizeof(double) * P->n_en, hipMemcpyDeviceToHost, s));
-      STEREO_HIP_CHECK(hipMemcpyAsync(P->h_ctl.p, P->d_ctl.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      STEREO_HIP_CHECK(hipMemcpyAsync(P->h_ctl.p, P->d_ctl.p, kCtlWords * sizeof(int32_t), hipMemcpyDeviceToHost, s));
       P->issued = true; P->issue_stream = s; P->timed_by = P0;
     }
     return 0;
@@ -999,11 +1048,12 @@ int stereo_trws_plan_issue(stereo_trws_plan *P, void *stream, char *err, size_t 
 }
 
 int stereo_trws_plan_collect(stereo_trws_plan *P, double *lb_part, double *energy_part, char *err, size_t errcap) {
+  DeviceScope device_scope_(P ? P->device : -1);
   if (!P) return fail("stereo_trws_plan_collect: NULL plan", err, errcap);
   if (!P->issued) return fail("stereo_trws_plan_collect: nothing was issued", err, errcap);
   try {
     double lb = 0, en = 0;
-    if (!collect_iteration(P, P->issue_stream, &lb, &en)) return fail(kGaveUp, err, errcap);
+    if (!collect_iteration(P, P->issue_stream, &lb, &en)) return fail(gave_up_text(P), err, errcap);
     if (lb_part) *lb_part = lb;
     if (energy_part) *energy_part = en;
     return 0;
@@ -1013,12 +1063,14 @@ int stereo_trws_plan_collect(stereo_trws_plan *P, double *lb_part, double *energ
 }
 
 int stereo_trws_plan_commit(stereo_trws_plan *P, double lower_bound, double energy, char *err, size_t errcap) {
+  DeviceScope device_scope_(P ? P->device : -1);
   if (!P) return fail("stereo_trws_plan_commit: NULL plan", err, errcap);
   P->lb = lower_bound; P->energy = energy; P->iterations += 1;
   return 0;
 }
 
 int stereo_trws_plan_connect(stereo_trws_plan *P, int which, stereo_trws_plan *peer, char *err, size_t errcap) {
+  DeviceScope device_scope_(P ? P->device : -1);
   if (!P || !peer || (which != 0 && which != 1)) return fail("stereo_trws_plan_connect: bad argument", err, errcap);
   if (P->N != peer->N || P->E != peer->E || P->K != peer->K || P->nstrips != peer->nstrips ||
       peer->strip != P->strip + (which ? 1 : -1))
@@ -1044,6 +1096,7 @@ int stereo_trws_plan_connect(stereo_trws_plan *P, int which, stereo_trws_plan *p
 }
 
 int stereo_trws_plan_ipc_export(stereo_trws_plan *P, void *handles, size_t cap, char *err, size_t errcap) {
+  DeviceScope device_scope_(P ? P->device : -1);
   if (!P || !handles) return fail("stereo_trws_plan_ipc_export: NULL argument", err, errcap);
   if (cap < STEREO_TRWS_IPC_BYTES) return fail("stereo_trws_plan_ipc_export: buffer smaller than STEREO_TRWS_IPC_BYTES", err, errcap);
   static_assert(3 * sizeof(hipIpcMemHandle_t) <= STEREO_TRWS_IPC_BYTES, "STEREO_TRWS_IPC_BYTES");
@@ -1061,6 +1114,7 @@ int stereo_trws_plan_ipc_export(stereo_trws_plan *P, void *handles, size_t cap, 
 }
 
 int stereo_trws_plan_ipc_connect(stereo_trws_plan *P, int which, const void *handles, char *err, size_t errcap) {
+  DeviceScope device_scope_(P ? P->device : -1);
   if (!P || !handles || (which != 0 && which != 1)) return fail("stereo_trws_plan_ipc_connect: bad argument", err, errcap);
   try {
     hipIpcMemHandle_t h[3];
@@ -1079,6 +1133,7 @@ int stereo_trws_plan_ipc_connect(stereo_trws_plan *P, int which, const void *han
 }
 
 int stereo_trws_plan_debug_flags(stereo_trws_plan *P, int32_t *done, int32_t *ctl) {
+  DeviceScope device_scope_(P ? P->device : -1);
   if (!P) return 1;
   if (done && P->layout) {  // per global rank, like a plan of the whole problem (0 where the strip holds nothing)
     std::vector<int32_t> f(P->Nl);
@@ -1106,6 +1161,7 @@ int stereo_trws_plan_strip_info(stereo_trws_plan *P, int *nstrips, int *strip, i
 
 int stereo_trws_plan_result(stereo_trws_plan *P, double *labelling, double *energy,
                             double *lower_bound, double *iterations, char *err, size_t errcap) {
+  DeviceScope device_scope_(P ? P->device : -1);
   if (!P) return fail("stereo_trws_plan_result: NULL plan", err, errcap);
   try {
     if (labelling) {
@@ -1135,6 +1191,7 @@ int stereo_trws_plan_info(stereo_trws_plan *P, int64_t *rank, int64_t *levels,
 }
 
 int stereo_trws_plan_stats(stereo_trws_plan *P, double *sweep_ms, int64_t *sweep_launches, int reset) {
+  DeviceScope device_scope_(P ? P->device : -1);
   if (!P) return 1;
   if (sweep_ms) *sweep_ms = P->sweep_ms;
   if (sweep_launches) *sweep_launches = P->sweep_launches;
@@ -1144,6 +1201,7 @@ int stereo_trws_plan_stats(stereo_trws_plan *P, double *sweep_ms, int64_t *sweep
 }
 
 int stereo_trws_plan_counters(stereo_trws_plan *P, int64_t *serial_messages, int reset) {
+  DeviceScope device_scope_(P ? P->device : -1);
   if (!P) return 1;
   unsigned long long v = 0;
   if (hipMemcpy(&v, P->d_fallbacks.p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 1;

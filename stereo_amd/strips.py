@@ -197,7 +197,7 @@ class TrwsStrips:
     """All strips of one problem in this process (same call surface as TrwsPlan where it matters).
 
     On ONE GPU the strips' persistent launches must all be resident together: every strip gets
-    `workgroups_per_strip` workgroups (default: CU count // nstrips)."""
+    `workgroups_per_strip` workgroups (default: the device's CU count // nstrips)."""
 
     def __init__(self, kernel, K, N, connectivity0, owner, nstrips, message_mode=MESSAGES_EXACT,
                  workgroups_per_strip=None, devices=None):
@@ -209,7 +209,10 @@ class TrwsStrips:
         self._owner = owner
         self._devices = list(devices) if devices else None
         if workgroups_per_strip is None:
-            workgroups_per_strip = 0 if devices else max(2, 256 // self.nstrips)
+            # strips that share a device share its CUs: one workgroup per CU is what is certain to be
+            # resident, and every strip's launch must be resident together with its neighbours'
+            cus = int(_lib.lib().stereo_hip_device_cus()) or 256
+            workgroups_per_strip = 0 if devices else max(2, cus // self.nstrips)
         self.plans = []
         for g in range(self.nstrips):
             if devices:
@@ -319,12 +322,31 @@ class TrwsStripRank:
         self.energy = self.lb = 0.0
         self.iterations = 0
 
+    # New inputs reset the strip's state (messages, flags, labels: stereo_trws_plan_reset) -- arrays the
+    # neighbouring ranks write into while THEIR kernels run.  Two barriers keep the reset apart from
+    # every rank's sweeps: nobody resets while a neighbour may still be running the old problem, and
+    # nobody issues the new problem's first sweep into arrays a slower neighbour has yet to wipe.
+    def _quiesced(self, fn, *a, **kw):
+        self.dist.barrier()
+        try:
+            return fn(*a, **kw)
+        finally:
+            self.dist.barrier()
+
     def bind_device(self, *a, **kw):
-        self.plan.bind_device(*a, **kw)
+        self._quiesced(self.plan.bind_device, *a, **kw)
+        self.iterations = 0
+
+    def bind_device_strip(self, *a, **kw):
+        self._quiesced(self.plan.bind_device_strip, *a, **kw)
         self.iterations = 0
 
     def upload(self, *a, **kw):
-        self.plan.upload(*a, **kw)
+        self._quiesced(self.plan.upload, *a, **kw)
+        self.iterations = 0
+
+    def reset(self):
+        self._quiesced(self.plan.reset)
         self.iterations = 0
 
     def iterate(self, iters, max_relgap=0.0):

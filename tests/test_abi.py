@@ -33,7 +33,10 @@ def test_every_declared_symbol_is_exported():
 
 def test_abi_version():
     from stereo_amd import _lib
-    assert _lib.lib().stereo_hip_abi_version() == 1
+    # the header's number, the library's and the binding's agree (a stale .so is refused at load)
+    text = open(os.path.join(ROOT, "include", "stereo_hip.h")).read()
+    declared = int(re.search(r"#define STEREO_HIP_ABI_VERSION (\d+)", text).group(1))
+    assert _lib.lib().stereo_hip_abi_version() == declared == _lib.ABI_VERSION >= 3
 
 
 def test_no_cpu_fallback_without_device():

@@ -38,7 +38,7 @@ def main():
     kind = "fronto" if K > 64 else "general"
     p = trws_problem(7, H, W, K, kind=kind)
     dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
-    s = TrwsStripRank(1, K, H, W, p["conn"].T, rank, world, dist, dev, max_workgroups=max(2, 256 // world) if ndev < world else 0)
+    s = TrwsStripRank(1, K, H, W, p["conn"].T, rank, world, dist, dev, max_workgroups=max(2, (int(_lib.lib().stereo_hip_device_cus()) or 256) // world) if ndev < world else 0)
     if kind == "fronto":
         s.upload(p["unary"].T, p["alphas"], 8.0, positions=np.arange(K, dtype=np.float64))
     else:

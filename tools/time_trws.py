@@ -1,5 +1,5 @@
 """Development tool: time TRW-S iterations of a synthetic volume for a given kernel / size.
-usage: time_trws.py [kernel=1] [H=375] [W=450] [K=60] [tol=8] [iters=10] [general=0] [volume=noise|ncc] [index_order=0] [minplus=0]
+usage: time_trws.py [kernel=1] [H=375] [W=450] [K=60] [tol=8] [iters=10] [general=0] [volume=noise|ncc|teddy] [index_order=0] [minplus=0]
 general=1: per-edge positions q != qprim (label k + jitter), as a fusion of K plane proposals has them."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,10 +20,15 @@ volume = a[7] if len(a) > 7 else "noise"
 index_order = int(a[8]) if len(a) > 8 else 0   # 1: STEREO_TRWS_ORDER_INDEX (not the gateway's node order)   # "ncc": NCC cost volume of a synthetic pair (bench.py's workload)
 dev = torch.device("cuda", 0)
 conn = grid_conn(H, W); E = conn.shape[0]; N = H * W
-if volume == "ncc":
+if volume in ("ncc", "teddy"):
     from bench import synthetic_pair
     from stereo_amd import terms as T
-    im0, im1 = synthetic_pair(H, W, K, seed=0)
+    if volume == "teddy":   # the reference's Teddy pair (375 x 450)
+        g = np.load(os.path.join(ROOT, "tests", "golden", "teddy_pair.npz"))
+        im0, im1 = g["im0"].astype(np.float64), g["im1"].astype(np.float64)
+        H, W = im0.shape[:2]; conn = grid_conn(H, W); E = conn.shape[0]; N = H * W
+    else:
+        im0, im1 = synthetic_pair(H, W, K, seed=0)
     ncc = T.ncc_volume(im0, im1, np.arange(K, dtype=np.float64), 2, layout=1)
     d_unary = torch.from_numpy(np.ascontiguousarray(40.0 * (1.0 - ncc.T))).to(dev)
 else:
