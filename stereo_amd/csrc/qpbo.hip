@@ -102,9 +102,14 @@ __device__ __forceinline__ bool grid_sync(int32_t *ctl, unsigned &gen) {
   return __hip_atomic_load(ctl + QpboCtl::kAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
 }
 
+// improve_perm != nullptr: the launch is the whole loop of QPBO::Improve (QPBO_extra.cpp:1190-1200) --
+// find the next node of the permutation that is not strongly labelled, fix it to 0 with the
+// reference's INFTY term, maximise the flow again from the current heights, until the permutation
+// is exhausted -- instead of one launch and three host round trips per fixed node (round 2: 100-250
+// re-solves of ~0.3 ms each on the hard globalstereo moves).  improve_N = number of variables.
 __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *ctl, int relabel_every, int max_rounds,
                                                             int tiled, int switch_at, int incremental, int first_interval,
-                                                            int adaptive) {
+                                                            int adaptive, const int32_t *improve_perm, int improve_N) {
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // tile state of the tiled rounds
   __shared__ int s_red;
   __shared__ int s_h[kMB];
@@ -239,7 +244,12 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     return true;
   };
 
+  int improve_from = 0, improve_steps = 0;
+  bool solve = improve_perm == nullptr;   // the Improve launch starts from a maximal flow: first find a node to fix
+  for (;;) {
+  if (solve) {
   int active = 0;
+  relabels_done = 0;
   if (!global_relabel(active)) return;
   int rounds = 0, since_relabel = 0, interval = relabel_every < first_interval ? relabel_every : first_interval, stagnant = 0, last_active = active;
 
@@ -572,12 +582,60 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
   // heights may be stale lower bounds: one exact BFS defines T; leave it in g.h
   if (!exact && !global_relabel(active)) return;
   if (h != g.h) {
-    for (int v = first; v < n; v += stride) g.h[v] = ldc(h + v);
+    for (int v = first; v < n; v += stride) stc(g.h + v, ldc(h + v));
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     ctl[QpboCtl::kRounds] += rounds;
     if (rounds >= max_rounds && active > 0) ctl[QpboCtl::kAbort] = 2;
   }
+  h = g.h; h2 = g.h2;
+  }  // solve
+  if (!improve_perm) break;
+  // ---- Improve: the next node of the permutation whose two sides are both / neither connected to the
+  // sink (not strongly labelled).  Two result words used in turn (one is cleared while the other is in
+  // use), heights in g.h are exact and written through.
+  {
+    // what the plain rounds stored with ordinary stores (excess, sink capacities) must be in memory
+    // before another workgroup's thread rewrites a node's terminal capacities below
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const int N = improve_N;
+    int32_t *word = ctl + (improve_steps & 1 ? 10 : 15), *other = ctl + (improve_steps & 1 ? 15 : 10);
+    if (improve_steps == 0 && blockIdx.x == 0 && threadIdx.x == 0) { stc(word, N); stc(other, N); }   // both start at "none"
+    if (!grid_sync(ctl, gen)) return;   // (every workgroup's final heights and terminal capacities are in memory)
+    int mine = N;
+    for (int j = improve_from + first; j < N; j += stride) {
+      const int i = improve_perm[j];
+      if ((ldc(g.h + i) < n) == (ldc(g.h + i + N) < n)) { mine = j; break; }   // (ascending j: the first one is this thread's smallest)
+    }
+    if (threadIdx.x == 0) s_red = N;
+    __syncthreads();
+    if (mine < N) atomicMin(&s_red, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_red < N) __hip_atomic_fetch_min(word, s_red, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!grid_sync(ctl, gen)) return;
+    const int next = ldc(word);
+    if (next >= N) break;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      stc(other, N);
+      // AddUnaryTerm(i, 0, INFTY), INFTY = max(-t_i + sum of outgoing residuals, t_i + sum of incoming) + 1
+      // evaluated on node i (QPBO_extra.cpp:241-254, :1177-1187), same summation order as the reference
+      const int i = improve_perm[next], im = i + N;
+      const double exi = ldc(g.ex + i), ski = ldc(g.snk + i), exm = ldc(g.ex + im), skm = ldc(g.snk + im);
+      const double tcap = exi - ski;
+      double c1 = -tcap, c2 = tcap;
+      for (int a = g.aptr[i]; a < g.aptr[i + 1]; ++a) { c1 += ldc(g.r + a); c2 += ldc(g.r + g.rev[a]); }
+      const double INFTY = (c1 > c2 ? c1 : c2) + 1;
+      const double t0 = exi - ski + INFTY, t1 = exm - skm - INFTY;
+      stc(g.ex + i, t0 > 0 ? t0 : 0.0); stc(g.snk + i, t0 < 0 ? -t0 : 0.0);
+      stc(g.ex + im, t1 > 0 ? t1 : 0.0); stc(g.snk + im, t1 < 0 ? -t1 : 0.0);
+    }
+    improve_from = next + 1;
+    ++improve_steps;
+    incremental = 1;   // the heights stay a valid labelling when a unary term changes: warm search
+    solve = true;
+    if (!grid_sync(ctl, gen)) return;
+  }
+  }  // for (;;)
 }
 
 // ---- Improve (QPBO_extra.cpp:1151-1233) helpers: the loop over the rand() permutation stays on the
@@ -918,27 +976,34 @@ struct QpboSolver {
   // not strongly labelled when its turn comes is fixed to 0 and the flow is maximised again.
   // `h` returns the final heights.
   void improve(const std::vector<int32_t> &perm, std::vector<int32_t> &h) {
-    const int N = (int)P.N;
-    DevBuf<int32_t> d_perm, d_next;
+    // one cooperative launch walks the whole permutation (qpbo_maxflow_kernel, improve_perm);
+    // STEREO_HIP_QPBO_IMPROVE_HOST=1 keeps round 2's host loop (one launch per fixed node) for comparison
+    DevBuf<int32_t> d_perm;
     d_perm.upload(perm.data(), perm.size());
-    d_next.alloc(1);
-    for (int from = 0; from < N;) {
-      int32_t next = N;
-      STEREO_HIP_CHECK(hipMemcpyAsync(d_next.p, &next, sizeof(next), hipMemcpyHostToDevice, 0));
-      hipLaunchKernelGGL(qpbo_next_ambiguous_kernel, dim3((unsigned)((N - from + 255) / 256)), dim3(256), 0, 0,
-                         d_perm.p, from, N, n, g.h, d_next.p);
-      STEREO_HIP_CHECK(hipMemcpy(&next, d_next.p, sizeof(next), hipMemcpyDeviceToHost));
-      if (next >= N) break;
-      fix_to_zero(perm[next]);
-      maxflow(true);
-      from = next + 1;
+    if (!std::getenv("STEREO_HIP_QPBO_IMPROVE_HOST")) {
+      maxflow(true, d_perm.p);
+    } else {
+      const int N = (int)P.N;
+      DevBuf<int32_t> d_next;
+      d_next.alloc(1);
+      for (int from = 0; from < N;) {
+        int32_t next = N;
+        STEREO_HIP_CHECK(hipMemcpyAsync(d_next.p, &next, sizeof(next), hipMemcpyHostToDevice, 0));
+        hipLaunchKernelGGL(qpbo_next_ambiguous_kernel, dim3((unsigned)((N - from + 255) / 256)), dim3(256), 0, 0,
+                           d_perm.p, from, N, n, g.h, d_next.p);
+        STEREO_HIP_CHECK(hipMemcpy(&next, d_next.p, sizeof(next), hipMemcpyDeviceToHost));
+        if (next >= N) break;
+        fix_to_zero(perm[next]);
+        maxflow(true);
+        from = next + 1;
+      }
     }
     h.resize(n);
     STEREO_HIP_CHECK(hipMemcpy(h.data(), g.h, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
   }
 
   // One cooperative launch runs the whole max-flow (qpbo_maxflow_kernel).
-  void maxflow(bool warm = false) {
+  void maxflow(bool warm = false, const int32_t *improve_perm = nullptr) {
     int relabel_every = 256;
     if (const char *e = std::getenv("STEREO_HIP_QPBO_RELABEL_EVERY")) relabel_every = std::max(1, std::atoi(e));
     if (d_ctl.n < (size_t)QpboCtl::kWords) d_ctl.alloc(QpboCtl::kWords);
@@ -976,7 +1041,9 @@ struct QpboSolver {
     if (const char *e = std::getenv("STEREO_HIP_QPBO_FIRST_INTERVAL")) first_interval = std::max(1, std::atoi(e));
     int adaptive = 1;
     if (const char *e = std::getenv("STEREO_HIP_QPBO_ADAPTIVE")) adaptive = std::atoi(e) != 0;
-    void *args[] = {&gg, &ctl, &relabel_every, &max_rounds, &tiled, &switch_at, &incremental, &first_interval, &adaptive};
+    int improve_N = (int)P.N;
+    void *args[] = {&gg, &ctl, &relabel_every, &max_rounds, &tiled, &switch_at, &incremental, &first_interval, &adaptive,
+                    &improve_perm, &improve_N};
     STEREO_HIP_CHECK(hipLaunchCooperativeKernel((const void *)qpbo_maxflow_kernel, dim3(blocks), dim3(kMB), args, dyn, 0));
     int32_t host_ctl[QpboCtl::kWords];
     STEREO_HIP_CHECK(hipMemcpy(host_ctl, d_ctl.p, sizeof(host_ctl), hipMemcpyDeviceToHost));

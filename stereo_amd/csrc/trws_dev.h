@@ -573,7 +573,7 @@ __device__ __forceinline__ void envelope_rows4(const double *tab, double alpha, 
 #endif
 __device__ __forceinline__ bool build_envelope_parallel(int K, double alpha, double hs, double qs, double *tab, int *scr,
                                                         double &sh, double &sq, double &zz, int lane, int &maxtop_out,
-                                                        double mag, unsigned long long *prof = nullptr, int dbg = 0) {
+                                                        double mag, unsigned long long *prof = nullptr) {
   const double inf = __builtin_huge_val();
   const bool act = lane < K;
 #ifdef STEREO_HIP_MESSAGE_PROFILE
@@ -628,11 +628,11 @@ __device__ __forceinline__ bool build_envelope_parallel(int K, double alpha, dou
       // (lane numbers in m0 here; the s_nop keeps the first write four instructions behind the compare
       //  that produced its mask -- see envelope_rows4 -- and the second write follows another three)
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_mov_b32 m0, %6\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0\n\t"
-                   "s_mov_b32 m0, %7\n\ts_nop 0\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0"
-                   : "+v"(r1lo), "+v"(r1hi)
-                   : "s"((unsigned)m0), "s"((unsigned)(m0 >> 32)), "s"((unsigned)m1), "s"((unsigned)(m1 >> 32)), "s"(k0), "s"(k1)
-                   : "m0");
+      unsigned keep_m0;   // (m0 is the compiler's; it is put back before the statement ends)
+      asm volatile("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %7\n\ts_nop 2\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\t"
+                   "s_mov_b32 m0, %8\n\ts_nop 0\n\tv_writelane_b32 %0, %5, m0\n\tv_writelane_b32 %1, %6, m0\n\ts_mov_b32 m0, %2"
+                   : "+v"(r1lo), "+v"(r1hi), "=&s"(keep_m0)
+                   : "s"((unsigned)m0), "s"((unsigned)(m0 >> 32)), "s"((unsigned)m1), "s"((unsigned)(m1 >> 32)), "s"(k0), "s"(k1));
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -689,9 +689,14 @@ __device__ __forceinline__ bool build_envelope_parallel(int K, double alpha, dou
       dropm_hi |= up ? dbit : 0u; dropm_lo |= up ? 0u : dbit;
     }
   };
+#ifdef STEREO_HIP_MESSAGE_PROFILE
+  const long long pt_a = (long long)__builtin_readcyclecounter();
+#endif
   test3(cand_lo, cand_hi);
   test3(cand_lo, cand_hi);   // (six up front: on noisy ramps the cone a source meets is rarely its nearest candidate)
-  if (dbg & 4096) { known_lo = known_hi = dropm_lo = dropm_hi = 0; }
+#ifdef STEREO_HIP_MESSAGE_PROFILE
+  const long long pt_b = (long long)__builtin_readcyclecounter();
+#endif
   unsigned long long P = K >= 64 ? ~0ull : ((1ull << K) - 1);
   unsigned B_lo = 0, B_hi = 0;
   int js = 0;
@@ -720,6 +725,8 @@ __device__ __forceinline__ bool build_envelope_parallel(int K, double alpha, dou
     atomicAdd(prof + 26, (unsigned long long)__builtin_popcountll(P));         // pushed sources
     atomicAdd(prof + 27, (unsigned long long)nrows);                           // rows of the pop test that were computed
     atomicAdd(prof + 28, (unsigned long long)late_tests);                      // rounds that had to test more candidates
+    atomicAdd(prof + 29, (unsigned long long)(pt_b - pt_a));                   // cycles of the six up-front drop tests
+    atomicAdd(prof + 30, (unsigned long long)((long long)__builtin_readcyclecounter() - pt_b));  // ... of the rounds
   }
 #endif
   if (!settled) return false;
@@ -750,7 +757,7 @@ __device__ __forceinline__ bool build_envelope_parallel(int K, double alpha, dou
   const double hj = tab[4 * zj], qj = tab[4 * zj + 1];
   // (2 alpha a power of two: the quotient by multiplication, exact either way)
   const double num = (hk - hj) + alpha * (qk + qj);
-  const double s = (exact_c && !(dbg & 8192)) ? num * (1.0 / (2 * alpha)) : num / (2 * alpha);
+  const double s = exact_c ? num * (1.0 / (2 * alpha)) : num / (2 * alpha);
   zz = have_z ? s : inf;
   // slots fill up from 0: the highest slot ever written is the highest one that holds a source
   maxtop_out = 63 - __builtin_clzll(__builtin_amdgcn_ballot_w64(src != 0) | 1ull);
@@ -1194,7 +1201,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
         if (streak < 4 || (streak & 31) == 0) {
           double delta2;
           bool rel;
-          if (second_look_applies(p.lambda, K, alpha, h, qsrc, t, vtrunc, delta, lane, delta2, rel) && !(p.debug & 32768))
+          if (second_look_applies(p.lambda, K, alpha, h, qsrc, t, vtrunc, delta, lane, delta2, rel))
             need_serial = message_second_look(K, alpha, h, qsrc, t, vtrunc, delta2, rel, lane, m1);
           MSTAMP(10);
           if (look_streak) *look_streak = need_serial ? streak + 1 : 0;
@@ -1226,7 +1233,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
       bool built = false;
       if (KERNEL == 1 && !(p.debug & 512)) {
         // (hq + 4 (64 + pad): the scratch words behind this wave's table, see kPipeTab)
-        if (hq && !(p.debug & 2048)) built = build_envelope_parallel(K, alpha, hs, qs, hq, (int *)(hq + 4 * (kWave + 16)), sh, sq, zz, lane, maxtop, mag, p.prof, p.debug);
+        if (hq && !(p.debug & 2048)) built = build_envelope_parallel(K, alpha, hs, qs, hq, (int *)(hq + 4 * (kWave + 16)), sh, sq, zz, lane, maxtop, mag, p.prof);
         if (!built) built = build_envelope_masks(K, alpha, hs, qs, sh, sq, zz, lane, maxtop);
       }
       if (!built) maxtop = build_envelope_regs<KERNEL>(K, alpha, hs, qs, sh, sq, zz, lane);

@@ -685,6 +685,8 @@ extern "C" int stereo_trws_strip_layout_host(int64_t N, int64_t E, const uint32_
                                              int32_t *desc, char *err, size_t errcap) {
   if (!conn || !owner || nstrips < 1 || strip < 0 || strip >= nstrips || (direction != 0 && direction != 1))
     return stereo::fail("stereo_trws_strip_layout_host: bad argument", err, errcap);
+  if (nstrips < 2)  // (one strip is the plain plan: no owner table is kept for it)
+    return stereo::fail("stereo_trws_strip_layout_host: a strip layout needs at least two strips", err, errcap);
   try {
     stereo::TrwsGraph g;
     std::string gerr;

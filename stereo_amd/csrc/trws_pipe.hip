@@ -72,7 +72,6 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
       double *st = stage0 + (pos & 1) * kStageDoubles;          // node `pos`
       double *stn = stage0 + ((pos + 1) & 1) * kStageDoubles;   // node `pos + 1`
       double *hcur = hand + (pos & 3) * 8 * kWave, *hprev = hand + ((pos - 1) & 3) * 8 * kWave;
-      double *hprev2 = hand + ((pos - 2) & 3) * 8 * kWave;
       double *sc = scal + (pos & 1) * kScalDoubles;
       const bool have_node = pos >= p0 && pos < p1;
 

@@ -69,7 +69,6 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, i
       double *st = stage0 + (pos & 1) * k2Stage;
       double *stn = stage0 + ((pos + 1) & 1) * k2Stage;
       double *hcur = hand + (pos & 3) * 8 * k2W, *hprev = hand + ((pos - 1) & 3) * 8 * k2W;
-      double *hprev2 = hand + ((pos - 2) & 3) * 8 * k2W;
       double *sc = scal + (pos & 1) * kScalDoubles;
       const bool have_node = pos >= p0 && pos < p1;
 

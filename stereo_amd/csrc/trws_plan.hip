@@ -740,10 +740,12 @@ void stereo_trws_plan_destroy(stereo_trws_plan *plan) {
                      v[13], v[15] ? (double)v[14] / v[15] : 0.0, v[15]);
       if (!plan->wide && v[17])
         std::fprintf(stderr, "[stereo_hip prof closed form] thresholds %.0f cycles | rows %.0f | scan + fixed point %.0f | slots + fill %.0f | "
-                             "x %llu, extra rounds %.2f (%.2f with late tests), pushed %.1f, rows computed %.1f, top-segment check failed %llu\n",
+                             "x %llu, extra rounds %.2f (%.2f with late tests), pushed %.1f, rows computed %.1f, top-segment check failed %llu, "
+                             "up-front tests %.0f cycles, rounds %.0f cycles\n",
                      (double)v[16] / v[17], v[19] ? (double)v[18] / v[19] : 0.0, v[21] ? (double)v[20] / v[21] : 0.0,
                      v[23] ? (double)v[22] / v[23] : 0.0, v[17], v[21] ? (double)v[24] / v[21] : 0.0, v[21] ? (double)v[28] / v[21] : 0.0,
-                     v[21] ? (double)v[26] / v[21] : 0.0, v[21] ? (double)v[27] / v[21] : 0.0, v[25]);
+                     v[21] ? (double)v[26] / v[21] : 0.0, v[21] ? (double)v[27] / v[21] : 0.0, v[25],
+                     v[21] ? (double)v[29] / v[21] : 0.0, v[21] ? (double)v[30] / v[21] : 0.0);
       if (plan->wide && v[22]) {
         std::fprintf(stderr, "[stereo_hip prof wide] cycles per visit of wave 0:");
         for (int i = 0; i < 16; ++i) std::fprintf(stderr, " [%d] %.0f", i, (double)v[i] / v[22]);
