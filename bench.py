@@ -132,8 +132,10 @@ def scale_leg(args, rank, local_rank, world, dist, dev, index_order=False, minpl
         d_unary = synthetic_volume_device(H, W, K, 1, dev, nodes=torch.from_numpy(nodes.astype(np.int64)).to(dev))
         d_alpha = torch.ones(len(edges), dtype=torch.float64, device=dev)
         torch.cuda.synchronize()
-        plan.bind_device_strip(d_unary.data_ptr(), d_alpha.data_ptr(), 8.0, d_positions=d_pos.data_ptr(),
-                               keepalive=(d_unary, d_alpha, d_pos))
+        # (through the rank object: it brackets the state reset with barriers, so that no rank issues its
+        #  first sweep into arrays a slower neighbour has yet to wipe)
+        solver.bind_device_strip(d_unary.data_ptr(), d_alpha.data_ptr(), 8.0, d_positions=d_pos.data_ptr(),
+                                 keepalive=(d_unary, d_alpha, d_pos))
         stored = (len(nodes), len(edges))
     plan.stats(reset=True)
     setup_s = time.perf_counter() - t_setup
@@ -165,8 +167,29 @@ def scale_leg(args, rank, local_rank, world, dist, dev, index_order=False, minpl
     frac = bytes_launch / avg_launch_s / 1e9 / HBM_PEAK_GBS
     frac_min = -D.max_over_ranks(dist, -frac, dev)
     frac_max = D.max_over_ranks(dist, frac, dev)
+    # who took part: one line per rank (device, strip size) gathered on rank 0 -- a reader of a multi-GPU
+    # record sees at once whether N different devices ran N strips of one image
+    import socket
+    me = {"rank": rank, "device": int(dev.index if dev.index is not None else 0), "host": socket.gethostname(),
+          "own_nodes": int(own_nodes), "sweep_launch_ms": avg_launch_s * 1e3}
+    ranks = [me]
+    if dist is not None and world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, me)
+        ranks = gathered
     if rank != 0:
         return None
+    # N = 1 results of the default scale workload (driver-run BENCH_r02 / BENCH_r03, 1 warm-up + 3 timed
+    # iterations): labels are the same at any N, energy and bound agree to 1e-12 relative
+    ref1 = None
+    if (H, W, K, args.scale_warmup + args.scale_steps, index_order, minplus) == (2000, 3000, 256, 4, False, False):
+        ref1 = {"label_sum": 624442294, "energy": 47220100.82134177, "lower_bound": 47214056.1673238}
+    n1 = None
+    if ref1 is not None:
+        n1 = dict(ref1, label_sum_equal=bool(crc == ref1["label_sum"]),
+                  energy_rel_diff=abs(energy - ref1["energy"]) / abs(ref1["energy"]),
+                  lower_bound_rel_diff=abs(lb - ref1["lower_bound"]) / abs(ref1["lower_bound"]),
+                  source="committed constants of the N = 1 run (BENCH_r02.json scale object)")
     return {"workload": "configs[3]: synthetic %dx%dx%d-label cost volume, TRW-S, kernel 1, tol 8, ONE image tiled "
                         "into %d row strips" % (W, H, K, world),
             "n_gpus": world, "scaling": "strong", "value": args.scale_steps / dt, "unit": "iterations/s",
@@ -177,7 +200,12 @@ def scale_leg(args, rank, local_rank, world, dist, dev, index_order=False, minpl
                          "RCCL all_gather of 2 doubles per iteration",
             "stored_per_gpu": {"nodes": int(stored[0]), "edges": int(stored[1]),
                                "unary_and_message_bytes": int((stored[0] + stored[1]) * K * 8)},
-            "setup_s": setup_s}
+            "setup_s": setup_s,
+            "ranks": ranks, "distinct_devices": len({(r["host"], r["device"]) for r in ranks}),
+            "collective_backend": (dist.get_backend() if dist is not None and world > 1 else "none"),
+            "n1_reference": n1,
+            "note": "THIS object is the north star's 1 -> N scaling curve (one image, strong scaling); the top-level "
+                    "`value` is N independent Teddy problems (weak scaling)"}
 
 
 def main():

@@ -40,6 +40,7 @@ struct DevParams {
   int32_t *ticket;  // run dispenser of the current launch
   int32_t *abort_flag;  // (d_ctl + 1; the four words behind it take the give-up report, see report_give_up)
   long long spin_ticks; // how long a visit may wait for another workgroup's flag: 100 MHz wall-clock ticks
+  int n_own;            // strips: local node ids >= n_own are the halo (a neighbouring strip's nodes); else N
   int N;
   unsigned long long *fallbacks;  // messages that needed the serial envelope (diagnostics)
   int certificate;                // 0: always run the serial envelope
@@ -851,13 +852,16 @@ constexpr int kSpinLimit = 1 << 22;  // polls before a wait INSIDE a workgroup (
 // launch may start late -- is bounded by wall-clock time (DevParams::spin_ticks of the 100 MHz
 // s_memrealtime counter; STEREO_HIP_TRWS_SPIN_SECONDS), not by a poll count: one step of such a wait.
 // Every 1024 polls it looks at the abort flag (somebody else gave up) and at the clock.
-__device__ __forceinline__ bool keep_waiting(const DevParams &p, int &spins, long long &t0) {
+// `halo`: the wait is for a node of a neighbouring strip.  Waits for the strip's own nodes get twice the
+// time: when a neighbour is missing, the visit that waits for IT gives up first and names the cause,
+// the visits queued up behind it inside the strip see the abort flag and leave quietly.
+__device__ __forceinline__ bool keep_waiting(const DevParams &p, int &spins, long long &t0, bool halo) {
   __builtin_amdgcn_s_sleep(1);
   if ((++spins & 1023) != 0) return true;
   if (ld_sc1(p.abort_flag)) return false;
   const long long now = (long long)wall_clock64();
   if (spins == 1024) { t0 = now; return true; }
-  return now - t0 < p.spin_ticks;
+  return now - t0 < (halo ? p.spin_ticks : 2 * p.spin_ticks);
 }
 // The first visit that gives up says what it was waiting for (the host turns it into the error text):
 // abort_flag[1..4] = visiting rank, awaited rank, value seen in its flag, epoch expected.
@@ -915,7 +919,7 @@ __device__ __forceinline__ bool wait_flag(const DevParams &p, int rank, int epoc
   int spins = 0, v;
   long long t0 = 0;
   while ((v = ld_sc1(flag)) < epoch) {
-    if (!keep_waiting(p, spins, t0)) {
+    if (!keep_waiting(p, spins, t0, rank >= p.n_own)) {
       report_give_up(p, visiting_rank, rank, v, epoch);
       return false;
     }

@@ -424,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void trws_persistent_kernel(DevParams p, in
         int spins = 0, v;
         long long t0 = 0;
         while ((v = ld_sc1(flag)) < epoch) {
-          if (!keep_waiting(p, spins, t0)) {
+          if (!keep_waiting(p, spins, t0, p.dep_rank[D][d0 + tid] >= p.n_own)) {
             report_give_up(p, r, p.dep_rank[D][d0 + tid], v, epoch);
             gave_up = 1;
             break;

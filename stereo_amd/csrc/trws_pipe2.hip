@@ -290,8 +290,9 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, i
             for (;;) {
               const int v = watching ? ld_sc1(p.done + myrank) : epoch;
               if (!UNI(v < epoch)) break;
-              if (!keep_waiting(p, spins, t0)) {   // wall-clock bound, or somebody else gave up
-                if (lane == __builtin_ctzll(__builtin_amdgcn_ballot_w64(v < epoch))) report_give_up(p, nx.rank, myrank, v, epoch);
+              const unsigned long long late = __builtin_amdgcn_ballot_w64(v < epoch), late_halo = __builtin_amdgcn_ballot_w64(v < epoch && myrank >= p.n_own);
+              if (!keep_waiting(p, spins, t0, late_halo != 0)) {   // wall-clock bound, or somebody else gave up
+                if (lane == __builtin_ctzll(late_halo ? late_halo : late)) report_give_up(p, nx.rank, myrank, v, epoch);
                 ok = false;
                 break;
               }

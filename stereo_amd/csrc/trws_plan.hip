@@ -274,6 +274,7 @@ DevParams make_params(stereo_trws_plan *P) {
   p.peer_x0 = P->peer_x[0]; p.peer_x1 = P->peer_x[1];
   p.done = P->d_done.p; p.ticket = P->d_ctl.p; p.abort_flag = P->d_ctl.p + 1; p.N = (int)P->Nl;
   p.spin_ticks = P->spin_ticks;
+  p.n_own = P->layout ? (int)P->layout->n_own : (int)P->Nl;
   p.fallbacks = P->d_fallbacks.p; p.certificate = P->certificate ? 1 : 0;
   // MINPLUS in the wide-label regime runs the chunk-parallel kernel (trws_chunk.hip)
   p.lean = (P->wide && P->mode == STEREO_TRWS_MESSAGES_MINPLUS) ? 1 : 0;

@@ -157,6 +157,59 @@ def test_two_processes_hand_over_through_ipc(shape, hip):
     assert r.returncode == 0 and "IPC_STRIPS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_two_processes_on_two_devices(hip):
+    """The real multi-GPU path, wherever two GPUs are visible: rank g on device g, RCCL for the handle
+    exchange and the 2-double all_gather, fine-grained neighbour arrays mapped through HIP IPC, peer
+    stores over xGMI polled from the neighbour's HBM; two problems in a row (the second upload
+    resets arrays the neighbour writes into).  Skipped on the 1-GPU boxes of this pool."""
+    import os
+    import subprocess
+    import sys
+    if hip.device_count() < 2:
+        pytest.skip("one GPU visible: the cross-device hand-over needs two")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for shape in ((40, 46, 16), (30, 24, 256)):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", "29541", os.path.join(root, "tools", "strips_ipc_check.py")] + [str(v) for v in shape]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "IPC_STRIPS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        assert "backend nccl devices [0, 1]" in r.stdout, r.stdout[-2000:]
+
+
+def test_one_process_driving_two_devices(hip, oracle):
+    """TrwsStrips(devices=[0, 1]): one process, one strip per GPU, peer access instead of IPC; every plan
+    entry point selects its plan's device (DeviceScope).  Skipped with one GPU."""
+    from stereo_amd.strips import TrwsStrips, row_strip_owner
+    if hip.device_count() < 2:
+        pytest.skip("one GPU visible")
+    H, W, K = 24, 20, 12
+    p = trws_problem(161, H, W, K, kind="general")
+    lab_o, en_o, lb_o, _ = oracle.trws(1, p["unary"], p["conn"], p["q"], p["qprim"], p["alphas"], 2.5, 4, -1e300, mode=1)
+    s = TrwsStrips(1, K, H * W, p["conn"].T, row_strip_owner(H, W, 2), 2, devices=[0, 1])
+    for _ in range(2):   # (bound twice: the second upload resets the strips)
+        s.upload(p["unary"].T, p["alphas"], 2.5, q=p["q"].T, qprim=p["qprim"].T)
+        s.iterate(4, max_relgap=-1e300)
+        lab, en, lb, _ = s.result()
+        assert np.array_equal(lab, lab_o) and _close(en, en_o) and _close(lb, lb_o)
+    s.close()
+
+
+def test_a_starved_wait_reports_what_it_waited_for(hip, monkeypatch):
+    """A strip whose neighbour never runs: the sweep gives up after STEREO_HIP_TRWS_SPIN_SECONDS of wall
+    clock (not after a poll count) and the error names the strip, the waiting visit and the flag."""
+    from stereo_amd.strips import make_strips
+    monkeypatch.setenv("STEREO_HIP_TRWS_SPIN_SECONDS", "0.2")
+    H, W, K = 10, 9, 6
+    p = trws_problem(171, H, W, K, kind="general")
+    s = make_strips(1, K, H, W, p["conn"].T, 2)
+    s.upload(p["unary"].T, p["alphas"], 2.0, q=p["q"].T, qprim=p["qprim"].T)
+    with pytest.raises(hip.StereoHipError, match=r"gave up waiting on a dependency flag: strip 1 of 2 .* NEIGHBOURING strip"):
+        s.plans[1].issue()          # strip 0 is never launched: strip 1 starves on its first boundary node
+        s.plans[1].collect()
+    s.close()
+
+
 @pytest.mark.parametrize("G", [2, 3])
 def test_strips_with_the_index_order_option(G, hip, oracle):
     """Row strips under STEREO_TRWS_ORDER_INDEX (runs are columns there, every one of them crosses

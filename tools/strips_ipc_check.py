@@ -36,34 +36,42 @@ def main():
     from helpers import trws_problem
     _lib.lib().stereo_hip_set_device(local)
     kind = "fronto" if K > 64 else "general"
-    p = trws_problem(7, H, W, K, kind=kind)
     dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
-    s = TrwsStripRank(1, K, H, W, p["conn"].T, rank, world, dist, dev, max_workgroups=max(2, (int(_lib.lib().stereo_hip_device_cus()) or 256) // world) if ndev < world else 0)
-    if kind == "fronto":
-        s.upload(p["unary"].T, p["alphas"], 8.0, positions=np.arange(K, dtype=np.float64))
-    else:
-        s.upload(p["unary"].T, p["alphas"], 3.0, q=p["q"].T, qprim=p["qprim"].T)
-    iters = 4
-    done, _ = s.iterate(iters, max_relgap=-1e300)
-    assert done == iters
-    idx, lab = s.own_labels()
-    parts = [None] * world
-    dist.all_gather_object(parts, (idx, lab))
+    conn = trws_problem(7, H, W, K, kind=kind)["conn"]
+    s = TrwsStripRank(1, K, H, W, conn.T, rank, world, dist, dev,
+                      max_workgroups=max(2, (int(_lib.lib().stereo_hip_device_cus()) or 256) // world) if ndev < world else 0)
     ok = True
-    if rank == 0:
-        full = np.zeros(H * W)
-        for i, l in parts:
-            full[i] = l
-        one = TrwsPlan(1, K, H * W, p["conn"].T)
+    iters = 4
+    # two problems one after the other on the same strips: the second upload resets arrays the
+    # neighbouring rank writes into (TrwsStripRank brackets it with barriers)
+    for seed in (7, 8):
+        p = trws_problem(seed, H, W, K, kind=kind)
         if kind == "fronto":
-            one.upload(p["unary"].T, p["alphas"], 8.0, positions=np.arange(K, dtype=np.float64))
+            s.upload(p["unary"].T, p["alphas"], 8.0, positions=np.arange(K, dtype=np.float64))
         else:
-            one.upload(p["unary"].T, p["alphas"], 3.0, q=p["q"].T, qprim=p["qprim"].T)
-        one.iterate(iters, max_relgap=-1e300)
-        lab1, en1, lb1, _ = one.result()
-        ok = bool(np.array_equal(full, lab1)) and abs(s.energy - en1) <= 1e-12 * abs(en1) and abs(s.lb - lb1) <= 1e-12 * abs(lb1)
-        print("strips %d backend %s labels_equal %s energy %.10f vs %.10f lb %.10f vs %.10f" %
-              (world, backend, np.array_equal(full, lab1), s.energy, en1, s.lb, lb1))
+            s.upload(p["unary"].T, p["alphas"], 3.0, q=p["q"].T, qprim=p["qprim"].T)
+        done, _ = s.iterate(iters, max_relgap=-1e300)
+        assert done == iters
+        idx, lab = s.own_labels()
+        parts = [None] * world
+        dist.all_gather_object(parts, (idx, lab, local))
+        if rank == 0:
+            full = np.zeros(H * W)
+            for i, l, _ in parts:
+                full[i] = l
+            one = TrwsPlan(1, K, H * W, p["conn"].T)
+            if kind == "fronto":
+                one.upload(p["unary"].T, p["alphas"], 8.0, positions=np.arange(K, dtype=np.float64))
+            else:
+                one.upload(p["unary"].T, p["alphas"], 3.0, q=p["q"].T, qprim=p["qprim"].T)
+            one.iterate(iters, max_relgap=-1e300)
+            lab1, en1, lb1, _ = one.result()
+            one.close()
+            good = bool(np.array_equal(full, lab1)) and abs(s.energy - en1) <= 1e-12 * abs(en1) and abs(s.lb - lb1) <= 1e-12 * abs(lb1)
+            ok = ok and good
+            print("strips %d backend %s devices %s problem %d labels_equal %s energy %.10f vs %.10f lb %.10f vs %.10f" %
+                  (world, backend, [d for _, _, d in parts], seed, np.array_equal(full, lab1), s.energy, en1, s.lb, lb1))
+    if rank == 0:
         print("IPC_STRIPS_OK" if ok else "IPC_STRIPS_MISMATCH")
     dist.barrier()
     s.close()
