@@ -189,13 +189,13 @@ constexpr int kNccCols = 32;    // columns per workgroup
 struct NccFast {
   int H, W, D;
   const double *im0, *im1;
-  const double *st0, *st1;   // [5][N]: box sums of the three channels, mean, signed norm
+  const double *st0, *st1;   // [5][N]: box sums of the three channels, mean, signed reciprocal norm
   const double *disp;
   double *out;
   int layout;
 };
 
-__global__ __launch_bounds__(kTB) void ncc_stats_kernel(const double *im, int H, int W, int r, double *st) {
+__global__ __launch_bounds__(kTB) void ncc_stats_kernel(const double *im, int H, int W, int r, double *st, double *stT = nullptr) {
   const int64_t px = (int64_t)blockIdx.x * kTB + threadIdx.x;
   const int64_t Npx = (int64_t)H * W;
   if (px >= Npx) return;
@@ -216,9 +216,18 @@ __global__ __launch_bounds__(kTB) void ncc_stats_kernel(const double *im, int H,
   const double var = t1 - 2 * t2 + npatch * 3 * mean * mean;
   // the norm with the sign of the variance term: sqrt of a negative one is imaginary in MATLAB
   // (dispmap_ncc.m:141,171), which the cross kernel resolves from the two signs
-  const double norm = sqrt(fabs(var));
+  // (stored as the RECIPROCAL: the volume kernels multiply by it instead of dividing twice per output --
+  //  a third of their instructions; the quotient moves by an ulp or two, the 1e-12 agreement with the
+  //  NumPy restatement is unaffected.  A zero norm gives +-inf and, as with the division, a non-finite
+  //  value that becomes 0, dispmap_ncc.m:190)
+  const double rnorm = 1.0 / sqrt(fabs(var));
   st[px] = b[0]; st[Npx + px] = b[1]; st[2 * Npx + px] = b[2]; st[3 * Npx + px] = mean;
-  st[4 * Npx + px] = var < 0 ? -norm : norm;
+  st[4 * Npx + px] = var < 0 ? -rnorm : rnorm;
+  if (stT) {   // the same five planes row-major, for ncc_lane_kernel
+    const int64_t t = (int64_t)row * W + col;
+    stT[t] = b[0]; stT[Npx + t] = b[1]; stT[2 * Npx + t] = b[2]; stT[3 * Npx + t] = mean;
+    stT[4 * Npx + t] = var < 0 ? -rnorm : rnorm;
+  }
 }
 
 struct NccCol {  // what one step of the column walk reads: loaded one step ahead
@@ -266,7 +275,7 @@ __device__ __attribute__((noinline)) NccStat ncc_right_border(const double *im1,
   const double u1 = (q0 + q1) + q2;
   const double u2 = (o.mean * b0 + o.mean * b1) + o.mean * b2;
   const double varT = u1 - 2 * u2 + 75.0 * o.mean * o.mean;
-  const double nn = sqrt(fabs(varT));
+  const double nn = 1.0 / sqrt(fabs(varT));   // signed reciprocal, as in the statistics planes
   o.nrm = varT < 0 ? -nn : nn;
   return o;
 }
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(kNccWaves * 64, 2) void ncc_cross_kernel(NccFast p)
       const double c2 = (cur.meanL * bT0 + cur.meanL * bT1) + cur.meanL * bT2;
       const double c3 = (meanT * cur.bL0 + meanT * cur.bL1) + meanT * cur.bL2;
       const double num = c1 - c2 - c3 + npatch3 * meanT * cur.meanL;
-      const double q = num / fabs(cur.nL) / fabs(nT);
+      const double q = num * fabs(cur.nL) * fabs(nT);
       // real(num / normL / normT) with imaginary norms for negative variance terms (dispmap_ncc.m:188-192)
       const bool negL = cur.nL < 0, negT = nT < 0;
       val = negL == negT ? (negL ? -q : q) : 0.0;
@@ -346,6 +355,164 @@ __global__ __launch_bounds__(kNccWaves * 64, 2) void ncc_cross_kernel(NccFast p)
       }
     }
     cur = nxt;
+  }
+}
+
+// ---- NCC volume, label-fastest layout: lane = disparity (round 3) ------------------------------
+// ncc_cross_kernel above has lane = image row, which writes the MATLAB layout (H x W x D) in full rows
+// but reaches the label-fastest layout TRW-S reads only through an LDS transpose with one workgroup
+// barrier per column and 64-byte runs, re-fetching both images for every group of eight disparities
+// (round 2: 151 us for 89 MB, 6 % of the write roofline, 3.8 x the algorithmic traffic).  Here a lane
+// is a disparity: pixel (r, c) of the volume is ONE coalesced store of D doubles, the right image and
+// its statistics are read as im1(r, c - d) from row-major copies (consecutive lanes, consecutive
+// addresses), the left image and its statistics are the same for every lane (scalar loads), and both
+// images are read once per 12-row tile for ALL disparities.  A workgroup is 16 waves = 16 image rows
+// (12 output rows + the 2 + 2 rows the 5 x 5 window needs); a wave walks along its row keeping the
+// window's five column products in registers, posts the horizontal sum in LDS and the 12 output waves
+// add the five rows -- the same association as ncc_cross_kernel (products (c0 + c1) + c2, columns
+// left to right, rows top to bottom), so both kernels give the same bits.
+constexpr int kNlWaves = 16;
+constexpr int kNlRows = kNlWaves - 4;
+
+struct NccLane {
+  int H, W, D;
+  const double *im1;          // MATLAB layout (right-border statistics)
+  const double *i0T, *i1T;    // [3][H][W]: row-major copies of the two images
+  const double *s0T, *s1T;    // [5][H][W]: row-major statistics (ncc_stats_kernel)
+  const double *disp;
+  double *out;                // [W][H][D]
+  int cols;                   // columns per workgroup
+};
+
+// row-major copy of an H x W x 3 image (MATLAB layout: [ch][col][row])
+__global__ __launch_bounds__(kTB) void ncc_transpose_kernel(const double *im, int H, int W, double *out) {
+  __shared__ double tile[16][17];
+  const int64_t Npx = (int64_t)H * W;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int r0 = blockIdx.x * 16, c0 = blockIdx.y * 16, ch = blockIdx.z;
+  if (r0 + tx < H && c0 + ty < W) tile[ty][tx] = im[(size_t)ch * Npx + (size_t)(c0 + ty) * H + r0 + tx];
+  __syncthreads();
+  if (r0 + ty < H && c0 + tx < W) out[(size_t)ch * Npx + (size_t)(r0 + ty) * W + c0 + tx] = tile[tx][ty];
+}
+
+// LDS of ncc_lane_kernel: per wave (= image row) the row segments it reads, staged once per workgroup --
+// every load of a workgroup is in flight together, and the column walk itself touches LDS only:
+//   seg1 [8][kNlSeg1]: im1 (3 channels) and its statistics (5 planes) at columns seg_c0 + x
+//   seg0 [8][kNlSeg0]: im0 and its statistics at columns c_begin - 2 + x
+constexpr int kNlSeg1 = 96, kNlSeg0 = 36;
+constexpr int kNlImDoubles = 3 * (kNlSeg1 + kNlSeg0);   // per wave: the two images' row segments
+constexpr int kNlStDoubles = 5 * (kNlSeg1 + kNlSeg0);   // per OUTPUT wave: their statistics
+constexpr int kNlLdsDoubles = kNlWaves * kNlImDoubles + kNlRows * kNlStDoubles + 4 * kNlWaves * 64;   // + two pairs of horizontal sums
+
+__global__ __launch_bounds__(kNlWaves * 64) void ncc_lane_kernel(NccLane p) {
+  extern __shared__ __attribute__((aligned(16))) double nl_lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double *seg1 = nl_lds + wave * kNlImDoubles, *seg0 = seg1 + 3 * kNlSeg1;                 // images: [3][kNlSeg1], [3][kNlSeg0]
+  const int ow = wave >= 2 && wave < 2 + kNlRows ? wave - 2 : 0;
+  double *sts1 = nl_lds + kNlWaves * kNlImDoubles + ow * kNlStDoubles, *sts0 = sts1 + 5 * kNlSeg1;  // statistics: [5][..]
+  double (*hbuf)[kNlWaves][64] = (double (*)[kNlWaves][64])(nl_lds + kNlWaves * kNlImDoubles + kNlRows * kNlStDoubles);   // [4][16][64]
+  const int H = p.H, W = p.W;
+  const int64_t Npx = (int64_t)H * W;
+  const int row = blockIdx.x * kNlRows - 2 + wave;
+  const int di = blockIdx.y * 64 + lane;
+  const bool dvalid = di < p.D;
+  const int d = dvalid ? (int)p.disp[di] : (int)p.disp[blockIdx.y * 64];
+  // smallest / largest disparity of this 64-label chunk (the host checked that the segment holds the span)
+  int dmin = d, dmax = d;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int a = __shfl_xor(dmin, o, 64), b2 = __shfl_xor(dmax, o, 64);
+    dmin = a < dmin ? a : dmin; dmax = b2 > dmax ? b2 : dmax;
+  }
+  const int c_begin = blockIdx.z * p.cols, c_end = c_begin + p.cols < W ? c_begin + p.cols : W;
+  const bool rvalid = row >= 0 && row < H;
+  const int row_c = row < 0 ? 0 : row > H - 1 ? H - 1 : row;
+  const size_t rowoff = (size_t)row_c * W;
+  const bool outw = wave >= 2 && wave < 2 + kNlRows && row < H;   // (uniform) this wave writes a row of the volume
+  const int seg_c0 = c_begin - 2 - dmax, seg0_c0 = c_begin - 2;
+  // ---- stage the row segments (clamped columns: what lies outside the image is masked below)
+  {
+    double v1[8][2], v0[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const double *src1 = (k < 3 ? p.i1T + (size_t)k * Npx : p.s1T + (size_t)(k - 3) * Npx) + rowoff;
+      const double *src0 = (k < 3 ? p.i0T + (size_t)k * Npx : p.s0T + (size_t)(k - 3) * Npx) + rowoff;
+      // (image planes: zero outside the image and in rows outside it, so that the products need no
+      //  mask in the loop -- the shifted image is zero-filled, conv2 pads with zeros)
+      const bool need = k < 3 || outw;   // (uniform) statistics only where a row of the volume is written
+#pragma unroll
+      for (int hlf = 0; hlf < 2; ++hlf) {
+        const int gg = seg_c0 + lane + 64 * hlf, g = gg < 0 ? 0 : gg > W - 1 ? W - 1 : gg;
+        const double v = need ? src1[g] : 0.0;
+        v1[k][hlf] = (k < 3 && (gg < 0 || gg > W - 1 || !rvalid)) ? 0.0 : v;
+      }
+      const int gg0 = seg0_c0 + lane, g0 = gg0 < 0 ? 0 : gg0 > W - 1 ? W - 1 : gg0;
+      const double v = need ? src0[g0] : 0.0;
+      v0[k] = (k < 3 && (gg0 < 0 || gg0 > W - 1 || !rvalid)) ? 0.0 : v;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k >= 3 && !outw) continue;
+      double *d1 = k < 3 ? seg1 + k * kNlSeg1 : sts1 + (k - 3) * kNlSeg1;
+      double *d0 = k < 3 ? seg0 + k * kNlSeg0 : sts0 + (k - 3) * kNlSeg0;
+      d1[lane] = v1[k][0];
+      if (lane + 64 < kNlSeg1) d1[lane + 64] = v1[k][1];
+      if (lane < kNlSeg0) d0[lane] = v0[k];
+    }
+  }
+  __syncthreads();
+  const double npatch3 = 75.0;
+  // sum over the channels of im0(row, c) * imtr(row, c), c = column of the product (indices are inside the
+  // segments by construction; columns outside the image hold zeros)
+  const double *s1d = seg1 - d - seg_c0;   // this lane's view of seg1: s1d[c] = plane 0 at column c - d
+  const double *s0c = seg0 - seg0_c0;
+  const double *t1d = sts1 - d - seg_c0, *t0c = sts0 - seg0_c0;   // the same views of the statistics
+  auto product = [&](int c) -> double {
+    const double l0 = s0c[c], l1 = s0c[kNlSeg0 + c], l2 = s0c[2 * kNlSeg0 + c];
+    const double r0 = s1d[c], r1 = s1d[kNlSeg1 + c], r2 = s1d[2 * kNlSeg1 + c];
+    return (l0 * r0 + l1 * r1) + l2 * r2;
+  };
+  double P0 = product(c_begin - 2), P1 = product(c_begin - 1), P2 = product(c_begin), P3 = product(c_begin + 1);
+  // two columns per workgroup barrier (the horizontal sums of both are posted first)
+  double *outp = p.out + ((size_t)c_begin * H + (row_c)) * p.D + di;   // this lane's element of pixel (row, c_begin)
+  const size_t ostep = (size_t)H * p.D;
+  auto emit = [&](int c, double h, const double (*hb)[64], double *dst) {
+    const double hm2 = hb[wave - 2][lane], hm1 = hb[wave - 1][lane], hp1 = hb[wave + 1][lane], hp2 = hb[wave + 2][lane];
+    const double bL0 = t0c[c], bL1 = t0c[kNlSeg0 + c], bL2 = t0c[2 * kNlSeg0 + c];
+    const double meanL = t0c[3 * kNlSeg0 + c], nL = t0c[4 * kNlSeg0 + c];
+    double bT0 = t1d[c], bT1 = t1d[kNlSeg1 + c], bT2 = t1d[2 * kNlSeg1 + c];
+    double meanT = t1d[3 * kNlSeg1 + c], nT = t1d[4 * kNlSeg1 + c];
+    const double c1 = (((hm2 + hm1) + h) + hp1) + hp2;
+    const bool live = dvalid && c >= d;  // columns left of round(d + 1) are masked (dispmap_ncc.m:190-191)
+    if (c + 2 >= W && live) {
+      const NccStat o = ncc_right_border(p.im1, H, W, Npx, row, c, d);
+      bT0 = o.b0; bT1 = o.b1; bT2 = o.b2; meanT = o.mean; nT = o.nrm;
+    }
+    const double c2 = (meanL * bT0 + meanL * bT1) + meanL * bT2;
+    const double c3 = (meanT * bL0 + meanT * bL1) + meanT * bL2;
+    const double num = c1 - c2 - c3 + npatch3 * meanT * meanL;
+    const double q = num * fabs(nL) * fabs(nT);
+    // real(num / normL / normT) with imaginary norms for negative variance terms (dispmap_ncc.m:188-192)
+    const bool negL = nL < 0, negT = nT < 0;
+    double val = negL == negT ? (negL ? -q : q) : 0.0;
+    if (!isfinite(val) || !live) val = 0.0;
+    if (dvalid) *dst = val;
+  };
+  int parity = 0;
+#pragma unroll 1
+  for (int c = c_begin; c < c_end; c += 2, parity ^= 1) {
+    const double Pa = product(c + 2), Pb = product(c + 3);
+    const double ha = (((P0 + P1) + P2) + P3) + Pa;
+    const double hb2 = (((P1 + P2) + P3) + Pa) + Pb;
+    P0 = P2; P1 = P3; P2 = Pa; P3 = Pb;
+    double (*hA)[64] = hbuf[2 * parity], (*hB)[64] = hbuf[2 * parity + 1];
+    hA[wave][lane] = ha; hB[wave][lane] = hb2;
+    __syncthreads();   // (double buffered: the other pair is written by the next step, after every wave has read this one)
+    if (outw) {
+      emit(c, ha, hA, outp);
+      if (c + 1 < c_end) emit(c + 1, hb2, hB, outp + ostep);
+    }
+    outp += 2 * ostep;
   }
 }
 
@@ -668,8 +835,44 @@ void launch_ncc_volume(const double *d_im0, const double *d_im1, int H, int W, c
   }
   DevBuf<double> st0, st1;
   st0.alloc(5 * npx); st1.alloc(5 * npx);
-  hipLaunchKernelGGL(ncc_stats_kernel, dim3(blocks(npx)), dim3(kTB), 0, 0, d_im0, H, W, patchsize, st0.p);
-  hipLaunchKernelGGL(ncc_stats_kernel, dim3(blocks(npx)), dim3(kTB), 0, 0, d_im1, H, W, patchsize, st1.p);
+  // (ncc_lane_kernel stages 96 columns of the right image per row: the disparities of every 64-label
+  //  chunk must span less than that minus the workgroup's own columns)
+  bool lanes_ok = layout == 1 && !std::getenv("STEREO_HIP_NCC_ROWLANES");
+  int span = 0;
+  for (int c0 = 0; c0 < D && lanes_ok; c0 += 64) {
+    double lo = h_disp[c0], hi = h_disp[c0];
+    for (int i = c0; i < std::min(D, c0 + 64); ++i) { lo = std::min(lo, h_disp[i]); hi = std::max(hi, h_disp[i]); }
+    span = std::max(span, (int)(hi - lo));
+  }
+  lanes_ok = lanes_ok && span + 5 + 8 <= kNlSeg1;
+  if (lanes_ok) {
+    // label-fastest volume: lane = disparity (ncc_lane_kernel) over row-major copies of images and statistics
+    DevBuf<double> s0T, s1T, i0T, i1T;
+    s0T.alloc(5 * npx); s1T.alloc(5 * npx); i0T.alloc(3 * npx); i1T.alloc(3 * npx);
+    const dim3 tg((H + 15) / 16, (W + 15) / 16, 3);
+    hipLaunchKernelGGL(ncc_transpose_kernel, tg, dim3(kTB), 0, 0, d_im0, H, W, i0T.p);
+    hipLaunchKernelGGL(ncc_transpose_kernel, tg, dim3(kTB), 0, 0, d_im1, H, W, i1T.p);
+    hipLaunchKernelGGL(ncc_stats_kernel, dim3(blocks(npx)), dim3(kTB), 0, 0, d_im0, H, W, patchsize, st0.p, s0T.p);
+    hipLaunchKernelGGL(ncc_stats_kernel, dim3(blocks(npx)), dim3(kTB), 0, 0, d_im1, H, W, patchsize, st1.p, s1T.p);
+    // enough workgroups for every CU: the columns are cut so that row tiles x column chunks x 64-label
+    // chunks reach ~2 workgroups per CU (each chunk re-computes four columns of products)
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int rt = (H + kNlRows - 1) / kNlRows, dc = (D + 63) / 64;
+    int chunks = std::max(1, (2 * cus + rt * dc - 1) / (rt * dc));
+    int cols = std::max(8, (W + chunks - 1) / chunks);
+    cols = std::min({cols, kNlSeg0 - 5, kNlSeg1 - 5 - span});   // what the staged segments hold (two columns per step: one more product column)
+    chunks = (W + cols - 1) / cols;
+    NccLane f{H, W, D, d_im1, i0T.p, i1T.p, s0T.p, s1T.p, d_disp, d_out, cols};
+    const size_t lds = sizeof(double) * kNlLdsDoubles;
+    STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)ncc_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ncc_lane_kernel, dim3(rt, dc, chunks), dim3(kNlWaves * 64), lds, 0, f);
+    STEREO_HIP_CHECK(hipGetLastError());
+    STEREO_HIP_CHECK(hipDeviceSynchronize());  // the staging buffers are released on return
+    return;
+  }
+  hipLaunchKernelGGL(ncc_stats_kernel, dim3(blocks(npx)), dim3(kTB), 0, 0, d_im0, H, W, patchsize, st0.p, (double *)nullptr);
+  hipLaunchKernelGGL(ncc_stats_kernel, dim3(blocks(npx)), dim3(kTB), 0, 0, d_im1, H, W, patchsize, st1.p, (double *)nullptr);
   NccFast f{H, W, D, d_im0, d_im1, st0.p, st1.p, d_disp, d_out, layout};
   const dim3 grid((H + kNccRows - 1) / kNccRows, (D + kNccWaves - 1) / kNccWaves, (W + kNccCols - 1) / kNccCols);
   hipLaunchKernelGGL(ncc_cross_kernel, grid, dim3(kNccWaves * 64), 0, 0, f);
