@@ -46,7 +46,9 @@ def main():
             p[2], p[3] = 1, -d
             proposals.append(p)
     else:
-        proposals = [dm.generate_new_plane_RANSAC(x, y, 5, on_device=True) for x in range(10, W + 1, 50) for y in range(10, H + 1, 50)]
+        t0 = time.time()
+        proposals = dm.generate_plane_lattice(radius=5)      # the whole 10:50:W x 10:50:H lattice in one launch
+        print("plane lattice: %d local fits in %.1f ms (one launch)" % (len(proposals), (time.time() - t0) * 1e3))
         proposals += [stereo_amd.PlaneProposal([0.0, 0.0, 1.0, -float(d)]) for d in range(0, int(disparities.max()) + 1, 10)]
     t0 = time.time()
     for p in proposals:
@@ -55,6 +57,13 @@ def main():
     single = dm.energy()
     print("iterative binary fusion: %d moves in %.3f s (%.1f moves/s), energy %.6f" % (
         len(proposals), dt, len(proposals) / dt, single))
+    # the same proposals revisited until none changes the energy (dispmap_super.m:85-152): one native call
+    dm.restart()
+    t0 = time.time()
+    n = dm.binary_fuse_until_convergence(proposals, rng=np.random.default_rng(1))
+    dt = time.time() - t0
+    print("binary_fuse_until_convergence: %d moves in %.3f s (%.1f moves/s, schedule on the resident state), energy %.6f" % (
+        n - 1, dt, (n - 1) / dt, dm.energy()))
     dm.restart()
     dm.maxiter = args.maxiter
     t0 = time.time()

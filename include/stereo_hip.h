@@ -24,8 +24,9 @@ extern "C" {
 
 /* Bumped whenever an entry point is added or a signature changes; the Python binding refuses a
  * library that reports another version (a stale libstereo_hip.so).  3: stereo_hip_device_cus, plan
- * entry points select their plan's device, wall-clock bound on cross-workgroup waits. */
-#define STEREO_HIP_ABI_VERSION 3
+ * entry points select their plan's device, wall-clock bound on cross-workgroup waits.  4: stereo_fusion_fit_planes,
+ * stereo_fusion_fuse_until_convergence. */
+#define STEREO_HIP_ABI_VERSION 4
 
 /* ---- library ---------------------------------------------------------- */
 
@@ -410,6 +411,19 @@ int stereo_fusion_binary_planes(stereo_fusion *ctx, const double *planes, int S,
  * pixels inside the radius. */
 int stereo_fusion_fit_plane(stereo_fusion *ctx, double x, double y, double r, double *plane,
                             double *npoints, char *err, size_t errcap);
+/* binary_fuse_until_convergence (dispmap_super.m:85-152) in one call on the resident state: n
+ * proposals (either `proposals`, 4 x N x n column major, or `planes`, 4 x n single planes built on the
+ * device; the other NULL), the 1-based revisit schedule `ids` exactly as the reference's loop indexes
+ * it (ids(iter + 1) in trip iter; the caller concatenates 1:n with its random draws and applies the
+ * reference's diff filter), at most `maxiter` trips.  n_energies = length(E), what the reference
+ * returns; energies (cap entries, may be NULL) = E itself. */
+int stereo_fusion_fuse_until_convergence(stereo_fusion *ctx, const double *proposals, const double *planes, int n,
+                                         const int64_t *ids, int64_t n_ids, int64_t maxiter, int improve,
+                                         double *n_energies, double *energies, int64_t cap, char *err, size_t errcap);
+/* The same fit for n centres in ONE launch (xs, ys: 1-based pixel coordinates; planes: 4 x n column
+ * major; npoints: n or NULL) -- the lattice `for x = 10:50:W, for y = 10:50:H` of example_ncc.m:24-32. */
+int stereo_fusion_fit_planes(stereo_fusion *ctx, const double *xs, const double *ys, int n, double r,
+                             double *planes, double *npoints, char *err, size_t errcap);
 /* stereo_fusion_simultaneous with K single-plane proposals (planes 4 x K) built on the device */
 int stereo_fusion_simultaneous_planes(stereo_fusion *ctx, const double *planes, int K, double maxiter,
                                       double max_relgap, double *energy, double *trws_energy,

@@ -723,10 +723,14 @@ __global__ __launch_bounds__(kTB) void proposal_from_planes_kernel(int64_t N, co
 // of the vector cancels in p / p(3)).  At most (2r+1)^2 points: one thread does the arithmetic in
 // the reference's order (pixels in column-major order), the rest of the wave idles.
 constexpr int kFitMax = 1024;
-__global__ __launch_bounds__(64) void fit_plane_kernel(const double *best, int H, int W, double x, double y, double r,
-                                                      int kernel, double *out /* 4 + count */) {
+// One workgroup per fit: blockIdx.x picks the centre (xy = [x_0 y_0 x_1 y_1 ...], 1-based pixel
+// coordinates) and the output slot -- the whole lattice of example_ncc.m:24-32 is one launch.
+__global__ __launch_bounds__(64) void fit_plane_kernel(const double *best, int H, int W, const double *xy, double r,
+                                                      int kernel, double *out_all /* (4 + count) per fit */) {
   __shared__ double px[kFitMax], py[kFitMax], pz[kFitMax], wt[kFitMax];
   if (threadIdx.x != 0) return;
+  const double x = xy[2 * blockIdx.x], y = xy[2 * blockIdx.x + 1];
+  double *out = out_all + 5 * (size_t)blockIdx.x;
   int n = 0;
   const int c0 = (int)fmax(1.0, floor(x - r)), c1 = (int)fmin((double)W, ceil(x + r));
   const int r0 = (int)fmax(1.0, floor(y - r)), r1 = (int)fmin((double)H, ceil(y + r));
@@ -1206,25 +1210,81 @@ int stereo_fusion_binary_planes(stereo_fusion *F, const double *planes, int S, c
   });
 }
 
-int stereo_fusion_fit_plane(stereo_fusion *F, double x, double y, double r, double *plane, double *npoints, char *err,
-                            size_t errcap) {
-  if (!F || !plane) return fail("stereo_fusion_fit_plane: bad argument", err, errcap);
-  if (F->unary_kind != 1) return fail("stereo_fusion_fit_plane: needs the NCC volume (dispmap_ncc)", err, errcap);
-  if (!(r > 0) || (2 * r + 3) * (2 * r + 3) > kFitMax) return fail("stereo_fusion_fit_plane: radius out of range", err, errcap);
-  return guarded("stereo_fusion_fit_plane", err, errcap, [&] {
+// binary_fuse_until_convergence (dispmap_super.m:85-152) as ONE call: the n proposals go to the device
+// once (4 x N x n arrays, or a 4 x n table of single planes that are expanded there), the revisit
+// schedule `ids` (1-based, what the reference builds from 1:n and its randi draws, with its
+// `ids([diff(ids) == 0]) = 0` filter already applied by the caller) is walked here with the reference's
+// loop -- the loop variable bumped inside the body, the exact `~=` on consecutive energies, the
+// `visited` bookkeeping -- and every move runs on the resident state; nothing of size N crosses PCIe
+// between moves and no interpreter sits between them.  energies: E(1) = energy before the first move,
+// then one entry per move (at most cap; n_energies = length(E) = what the reference returns).
+int stereo_fusion_fuse_until_convergence(stereo_fusion *F, const double *proposals, const double *planes, int n,
+                                         const int64_t *ids, int64_t n_ids, int64_t maxiter, int improve,
+                                         double *n_energies, double *energies, int64_t cap, char *err, size_t errcap) {
+  if (!F || (!proposals && !planes) || n < 1 || !ids || n_ids < 0 || maxiter < 0)
+    return fail("stereo_fusion_fuse_until_convergence: bad argument", err, errcap);
+  if (!F->have_assignment) return fail("stereo_fusion: no assignment set", err, errcap);
+  for (int64_t i = 0; i < n_ids; ++i)
+    if (ids[i] < 1 || ids[i] > n) return fail("stereo_fusion_fuse_until_convergence: proposal id out of range", err, errcap);
+  return guarded("stereo_fusion_fuse_until_convergence", err, errcap, [&] {
+    const int64_t N = F->N;
+    DevBuf<double> all;   // the proposals, resident for the whole schedule
+    all.alloc((size_t)4 * N * n);
+    if (proposals) {
+      check_planes(proposals, N * n);
+      STEREO_HIP_CHECK(hipMemcpy(all.p, proposals, sizeof(double) * 4 * N * n, hipMemcpyHostToDevice));
+    } else {
+      check_planes(planes, n);
+      for (int k = 0; k < n; ++k) fusion_build_proposal(F, planes + 4 * k, 1, nullptr, all.p + (size_t)4 * N * k);
+    }
+    std::vector<double> E(1, F->energy);
+    std::vector<char> visited((size_t)n, 0);
+    for (int64_t it = 1; it <= maxiter; ++it) {
+      const int64_t it1 = it + 1;                    // iter = iter + 1 inside the for body (dispmap_super.m:108)
+      if (it1 > n_ids) break;
+      const int64_t pid = ids[it1 - 1];
+      if (visited[pid - 1]) continue;
+      STEREO_HIP_CHECK(hipMemcpyAsync(F->prop.p, all.p + (size_t)4 * N * (pid - 1), sizeof(double) * 4 * N, hipMemcpyDeviceToDevice, 0));
+      fusion_binary_core(F, improve, nullptr, nullptr, nullptr, nullptr, wall_ms());
+      E.push_back(F->energy);
+      if (E[E.size() - 2] != E.back()) std::fill(visited.begin(), visited.end(), 0);   // E(end-1) ~= E(end)
+      else visited[pid - 1] = 1;
+      if (std::all_of(visited.begin(), visited.end(), [](char v) { return v != 0; })) break;
+    }
+    if (n_energies) *n_energies = (double)E.size();
+    if (energies) for (int64_t i = 0; i < cap && i < (int64_t)E.size(); ++i) energies[i] = E[i];
+  });
+}
+
+int stereo_fusion_fit_planes(stereo_fusion *F, const double *xs, const double *ys, int n, double r, double *planes,
+                             double *npoints, char *err, size_t errcap) {
+  if (!F || !planes || !xs || !ys || n < 1) return fail("stereo_fusion_fit_planes: bad argument", err, errcap);
+  if (F->unary_kind != 1) return fail("stereo_fusion_fit_planes: needs the NCC volume (dispmap_ncc)", err, errcap);
+  if (!(r > 0) || (2 * r + 3) * (2 * r + 3) > kFitMax) return fail("stereo_fusion_fit_planes: radius out of range", err, errcap);
+  return guarded("stereo_fusion_fit_planes", err, errcap, [&] {
     if (!F->have_best) {  // best_disp_from_ncc (dispmap_ncc.m:208-221), once per volume
       F->best.alloc(F->N);
       hipLaunchKernelGGL(ncc_best_disp_kernel, dim3(blocks(F->N)), dim3(kTB), 0, 0, F->ncc.p, F->H, F->W, F->D, 0,
                          F->disparities.p, F->best.p);
       F->have_best = true;
     }
-    if (F->fit_out.n < 8) F->fit_out.alloc(8);
-    hipLaunchKernelGGL(fit_plane_kernel, dim3(1), dim3(64), 0, 0, F->best.p, F->H, F->W, x, y, r, F->kernel, F->fit_out.p);
-    double h[5];
-    STEREO_HIP_CHECK(hipMemcpy(h, F->fit_out.p, sizeof(h), hipMemcpyDeviceToHost));
-    for (int k = 0; k < 4; ++k) plane[k] = h[k];
-    if (npoints) *npoints = h[4];
+    std::vector<double> xy(2 * (size_t)n), h(5 * (size_t)n);
+    for (int i = 0; i < n; ++i) { xy[2 * i] = xs[i]; xy[2 * i + 1] = ys[i]; }
+    DevBuf<double> d_xy;
+    d_xy.upload(xy.data(), xy.size());
+    if (F->fit_out.n < h.size()) F->fit_out.alloc(h.size());
+    hipLaunchKernelGGL(fit_plane_kernel, dim3((unsigned)n), dim3(64), 0, 0, F->best.p, F->H, F->W, d_xy.p, r, F->kernel, F->fit_out.p);
+    STEREO_HIP_CHECK(hipMemcpy(h.data(), F->fit_out.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+      for (int k = 0; k < 4; ++k) planes[4 * i + k] = h[5 * i + k];
+      if (npoints) npoints[i] = h[5 * i + 4];
+    }
   });
+}
+
+int stereo_fusion_fit_plane(stereo_fusion *F, double x, double y, double r, double *plane, double *npoints, char *err,
+                            size_t errcap) {
+  return stereo_fusion_fit_planes(F, &x, &y, 1, r, plane, npoints, err, errcap);
 }
 
 // proposals: 4 x N x K host array, or NULL with plane_tab = 4 x K (one plane per proposal, built on the device)

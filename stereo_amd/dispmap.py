@@ -186,10 +186,12 @@ class dispmap_super:
         self.assignment = a
         return e, lb, num_unlabelled
 
-    def binary_fuse_until_convergence(self, proposal_cell, rng=None):
+    def binary_fuse_until_convergence(self, proposal_cell, rng=None, device_loop=True):
         """dispmap_super.m:85-152, including its quirks (the loop variable is bumped inside the
         body, so ids(2) is fused first).  `rng` supplies the random revisit order (MATLAB's
-        randi stream cannot be reproduced): a numpy Generator or an explicit id list."""
+        randi stream cannot be reproduced): a numpy Generator or an explicit id list.
+        device_loop: run the schedule natively on the resident state (one call); False keeps the loop
+        here, one binary_fusion call per move (the same moves, the same energies)."""
         if not isinstance(proposal_cell, (list, tuple)):
             raise StereoHipError("Input proposals should be given in cell array.")
         n = len(proposal_cell)
@@ -202,6 +204,30 @@ class dispmap_super:
         ids = np.concatenate([np.arange(1, n + 1), rand_ids])
         ids[:-1][np.diff(ids) == 0] = 0         # ids([diff(ids) == 0]) = 0 zeroes the FIRST of a repeated pair
         ids = ids[(ids >= 1) & (ids <= n)]
+        # (a subclass with its own binary_fusion keeps the loop below, which calls it)
+        native = device_loop and type(self).binary_fusion is dispmap_super.binary_fusion and hasattr(self, "tol")
+        ctx = self._context() if native else None
+        if ctx is not None and n > 0:
+            # the whole schedule in one native call on the resident state (stereo_fusion_fuse_until_convergence):
+            # same loop, same exact energy comparisons, no interpreter and no PCIe traffic between moves
+            N = self.sz[0] * self.sz[1]
+            if not self._ctx_has_assignment:
+                ctx.set_assignment(self._assignment)
+                self._ctx_has_assignment = True
+            single = all(isinstance(p, PlaneProposal) and p.segments is None for p in proposal_cell)
+            if single:
+                E = ctx.fuse_until_convergence(ids, self.maxiter, planes=np.concatenate([p.planes for p in proposal_cell], axis=1),
+                                               improve=self._improve)
+            else:
+                props = [p.expand(N) if isinstance(p, PlaneProposal) else np.asfortranarray(p, dtype=np.float64) for p in proposal_cell]
+                for p in props:
+                    if p.shape != (4, N):
+                        raise StereoHipError("Binary fusion: Proposals is of wrong size")
+                E = ctx.fuse_until_convergence(ids, self.maxiter, proposals=props, improve=self._improve)
+            self.stored_energy = float(E[-1])
+            self._host_stale = True
+            self.fusion_energies = [float(e) for e in E]
+            return len(E)
         E = [self.energy()]
         visited = np.zeros(n, dtype=bool)
         for it in range(1, self.maxiter + 1):
@@ -221,6 +247,7 @@ class dispmap_super:
                 visited[pid - 1] = True
             if visited.all():
                 break
+        self.fusion_energies = [float(e) for e in E]
         return len(E)
 
     def simultaneous_fusion(self, proposal_cell):
@@ -340,6 +367,19 @@ class dispmap_ncc(dispmap_super):
         ids = np.sqrt((pts[0] - x) ** 2 + (pts[1] - y) ** 2) < r
         p = self.fit_plane_to_points(np.vstack([pts[:, ids], best[ids]]))
         return np.asfortranarray(np.repeat(p.reshape(4, 1), self.sz[0] * self.sz[1], axis=1))
+
+    def generate_plane_lattice(self, radius=5, first=10, step=50, on_device=True):
+        """The proposal lattice of example_ncc.m:24-32: `for x = first:step:W, for y = first:step:H`, one
+        local plane fit (generate_new_plane_RANSAC) per point, in that order.  on_device: ALL fits in one
+        launch (stereo_fusion_fit_planes), PlaneProposals come back; otherwise the host fits, 4 x N arrays."""
+        xs = [x for x in range(first, self.sz[1] + 1, step) for _ in range(first, self.sz[0] + 1, step)]
+        ys = [y for _ in range(first, self.sz[1] + 1, step) for y in range(first, self.sz[0] + 1, step)]
+        if on_device:
+            ctx = self._context()
+            if ctx is not None and xs:
+                planes, _ = ctx.fit_planes(xs, ys, radius)
+                return [PlaneProposal(planes[:, i]) for i in range(planes.shape[1])]
+        return [self.generate_new_plane_RANSAC(x, y, radius) for x, y in zip(xs, ys)]
 
     def fit_plane_to_points(self, points):
         """dispmap_ncc.m:67-92: total least squares (kernel 2) or 20 rounds of iteratively

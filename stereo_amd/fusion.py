@@ -104,6 +104,35 @@ class FusionContext:
                    _p(pl), C.byref(n))
         return pl, int(n.value)
 
+    def fuse_until_convergence(self, ids, maxiter, proposals=None, planes=None, improve=False):
+        """The whole revisit schedule of dispmap_super.m:85-152 in one native call.  proposals: list of
+        4 x N arrays, or planes: 4 x n table of single planes.  -> (energies E as the reference keeps them)"""
+        ids = np.ascontiguousarray(ids, np.int64).reshape(-1)
+        if proposals is not None:
+            stack = np.asfortranarray(np.stack([np.asarray(P, np.float64) for P in proposals], axis=2))  # 4 x N x n
+            n, pp, tp = stack.shape[2], _p(stack), None
+        else:
+            tab = np.asfortranarray(np.asarray(planes, np.float64).reshape(4, -1))
+            n, pp, tp = tab.shape[1], None, _p(tab)
+        cap = int(maxiter) + 2
+        E = np.zeros(cap)
+        nE = C.c_double()
+        self._call(_lib.lib().stereo_fusion_fuse_until_convergence, pp, tp, C.c_int(n), _p(ids, C.c_int64),
+                   C.c_int64(ids.size), C.c_int64(int(maxiter)), C.c_int(int(bool(improve))), C.byref(nE), _p(E),
+                   C.c_int64(cap))
+        return E[:int(nE.value)]
+
+    def fit_planes(self, xs, ys, r):
+        """fit_plane for many centres in one launch -> (planes 4 x n, pixel counts n)"""
+        xs = np.ascontiguousarray(xs, np.float64).reshape(-1)
+        ys = np.ascontiguousarray(ys, np.float64).reshape(-1)
+        if xs.shape != ys.shape or xs.size < 1:
+            raise StereoHipError("fit_planes: xs and ys must have the same, non-zero length")
+        pl = np.zeros((4, xs.size), order="F")
+        cnt = np.zeros(xs.size)
+        self._call(_lib.lib().stereo_fusion_fit_planes, _p(xs), _p(ys), C.c_int(int(xs.size)), C.c_double(float(r)), _p(pl), _p(cnt))
+        return pl, cnt.astype(np.int64)
+
     def simultaneous_planes(self, planes, maxiter=1000, max_relgap=0.0):
         """simultaneous() with K single-plane proposals (4 x K) built on the device."""
         planes = np.asfortranarray(np.asarray(planes, np.float64).reshape(4, -1))

@@ -153,3 +153,90 @@ def test_proposals_built_on_the_device(hip, oracle):
         ra = a.simultaneous_fusion(single)
         rb = b.simultaneous_fusion([P.expand(N) for P in single])
         assert ra == rb and np.array_equal(a.assignment, b.assignment)
+
+
+def test_plane_lattice_in_one_launch(hip):
+    """the proposal lattice of example_ncc.m:24-32 -- `for x = 10:50:W, for y = 10:50:H`,
+    a local plane fit of the winner-takes-all disparities at every point (dispmap_ncc.m:48-92) -- as ONE
+    launch (stereo_fusion_fit_planes), against the NumPy mirror of the reference's SVD / IRLS, same order."""
+    import os
+    from stereo_amd import PlaneProposal
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "teddy_pair.npz"))
+    im0, im1 = g["im0"][100:260, 150:330].astype(np.float64), g["im1"][100:260, 150:330].astype(np.float64)   # 160 x 180
+    for kernel in (1, 2):
+        dm = hip.dispmap_ncc([im0, im1], np.arange(0, 32.0), kernel, 40.0, 8.0)
+        dev = dm.generate_plane_lattice(radius=5)
+        host = dm.generate_plane_lattice(radius=5, on_device=False)
+        assert len(dev) == len(host) == 4 * 4                 # x = 10, 60, 110, 160; y = 10, 60, 110, 160
+        for k, (d, h) in enumerate(zip(dev, host)):
+            assert isinstance(d, PlaneProposal)
+            assert np.allclose(d.planes[:, 0], h[:, 0], rtol=1e-6, atol=1e-6), (kernel, k, d.planes[:, 0], h[:, 0])
+        # one call, many centres == many calls, one centre (bit for bit)
+        ctx = dm._context()
+        one = [ctx.fit_plane(x, y, 5)[0] for x in (10, 60) for y in (10, 110)]
+        many, cnt = ctx.fit_planes([10, 10, 60, 60], [10, 110, 10, 110], 5)
+        assert np.array_equal(np.stack(one, 1), many) and cnt.min() > 50
+
+
+class _OracleSchedule:
+    """binary_fuse_until_convergence of the mirrored class (the reference's loop, stereo_amd/dispmap.py)
+    driving the ORACLE's moves: dispmap_super's schedule code with OraclePipeline.binary_fusion."""
+
+    def __init__(self, ref):
+        from stereo_amd.dispmap import dispmap_super
+        self.ref = ref
+        self._loop = dispmap_super.binary_fuse_until_convergence
+        self.maxiter = 1000
+        self.sz = (ref.H, ref.W)
+        self._improve = False
+
+    def _context(self):
+        return None
+
+    def energy(self):
+        return self.ref.energy()
+
+    def binary_fusion(self, P):
+        return self.ref.binary_fusion(np.asarray(P))
+
+    def run(self, props, ids):
+        return self._loop(self, props, rng=ids, device_loop=False)
+
+
+def test_fuse_until_convergence_on_the_device_matches_the_loop_and_the_oracle(hip, oracle):
+    """dispmap_super.m:85-152 as one native call on the resident state
+    (stereo_fusion_fuse_until_convergence) == the same schedule as a Python loop of binary_fusion calls
+    (energies bit for bit, planes bit for bit, 4 x N arrays and plane tables alike) == the schedule run
+    over the oracle's moves (reference QPBO library): planes bit for bit, energies to 1e-9."""
+    if not oracle.have_ref_qpbo():
+        pytest.skip("oracle/_ref/libref_qpbo.so not present")
+    import os
+    from test_pipeline_gpu import OraclePipeline, _crop
+    from stereo_amd import PlaneProposal
+    im0, im1 = _crop()
+    H, W = im0.shape[:2]
+    N = H * W
+    disps = np.arange(0, 24.0)
+    planes = [[0.0, 0.0, 1.0, -3.0], [0.0, 0.0, 1.0, -9.0], [0.04, -0.02, 1.0, -14.0], [0.0, 0.0, 1.0, -19.0], [-0.03, 0.05, 1.0, -8.0]]
+    table = [PlaneProposal(p) for p in planes]
+    arrays = [t.expand(N) for t in table]
+    ids = list(np.random.default_rng(5).integers(1, len(planes) + 1, 60))
+    a = hip.dispmap_ncc([im0, im1], disps, 1, 40.0, 8.0)      # native schedule, 4 x N arrays
+    b = hip.dispmap_ncc([im0, im1], disps, 1, 40.0, 8.0)      # native schedule, plane table
+    c = hip.dispmap_ncc([im0, im1], disps, 1, 40.0, 8.0)      # Python loop
+    for dm in (a, b, c):
+        dm.maxiter = 40
+    na = a.binary_fuse_until_convergence(arrays, rng=ids)
+    nb = b.binary_fuse_until_convergence(table, rng=ids)
+    nc = c.binary_fuse_until_convergence(arrays, rng=ids, device_loop=False)
+    assert na == nb == nc and na >= 6
+    assert a.fusion_energies == b.fusion_energies == c.fusion_energies
+    assert np.array_equal(a.assignment, c.assignment) and np.array_equal(b.assignment, c.assignment)
+    assert a.energy() == c.energy() == a.fusion_energies[-1]
+    ref = OraclePipeline(oracle, im0, im1, disps, 1, 40.0, 8.0, ncc=a.ncc)
+    sched = _OracleSchedule(ref)
+    sched.maxiter = 40
+    nr = sched.run(arrays, ids)
+    assert nr == na
+    assert np.array_equal(a.assignment, ref.a)
+    assert all(abs(x - y) <= 1e-9 * abs(y) for x, y in zip(a.fusion_energies, sched.fusion_energies))
