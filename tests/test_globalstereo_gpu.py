@@ -76,6 +76,7 @@ def _run(hip, oracle, im0, im1, disp_range, factor, seg, cells, seed0, kernel=1)
     d_lo, d_hi = gs.d_min, gs.d_min + gs.d_step
     total_unlabelled = 0
     tie_pixels = 0
+    resync = []
     for k, cell in enumerate(cells):
         prop = piecewise_planar(H, W, cell, rng, d_lo, d_hi)
         U0, U1 = ref.unary(ref.a), ref.unary(prop)
@@ -94,9 +95,18 @@ def _run(hip, oracle, im0, im1, disp_range, factor, seg, cells, seed0, kernel=1)
             # warns about it); both labellings have the same energy (asserted above to 1e-9, and
             # the two solvers' energies agree to ~1e-11 here).
             assert np.all(U0[differ] == U1[differ]), "move %d: %d pixels differ outside exact ties" % (k, int((U0[differ] != U1[differ]).sum()))
-            tie_pixels += int(differ.sum())
+            # ... and few of them, PER MOVE (a regression inside a summed allowance would be invisible):
+            # at most 1e-4 of the pixels and never more than a tenth of the exact ties of the move
+            n_diff, n_ties = int(differ.sum()), int((U0 == U1).sum())
+            resync.append((k, n_diff, n_ties))
+            assert n_diff <= max(1, 1e-4 * N), "move %d: %d tie pixels took the other plane (%d exact ties)" % (k, n_diff, n_ties)
+            assert n_diff <= max(1, 0.1 * n_ties), (k, n_diff, n_ties)
+            tie_pixels += n_diff
             gs.assignment = ref.a.copy()      # same state on both sides for the next move
         total_unlabelled += nu_r
+    # (shown with pytest -s / in the failure report: move, resynchronised pixels, exact ties of that move)
+    print("globalstereo parity: %d moves, %d pixels of %d resynchronised at exact ties, per move %s" % (
+        len(cells), tie_pixels, N, resync))
     assert tie_pixels <= 1e-4 * N * len(cells), tie_pixels
     return total_unlabelled, gs.energy()
 
