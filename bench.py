@@ -342,7 +342,8 @@ def main():
         pmc = {(375, 450, 60, "ncc", "teddy"): "r03_trws_teddy60_pmc_hbm.json",
                (375, 450, 60, "ncc", "synthetic"): "r02_trws_teddy60_ncc_pmc_hbm.json",
                (375, 450, 60, "noise", "none"): "r01_trws_teddy60_pmc_hbm.json",
-               (1000, 1500, 256, "noise", "none"): "r01_trws_wide256_1500x1000_pmc_hbm.json"}.get((H, W, K, volume, pair))
+               (1000, 1500, 256, "noise", "none"): "r01_trws_wide256_1500x1000_pmc_hbm.json",
+               (2000, 3000, 256, "noise", "none"): "r03_trws_wide256_3000x2000_pmc_hbm.json"}.get((H, W, K, volume, pair))
         if pmc and os.path.exists(os.path.join(ROOT, "profiles", pmc)):
             traffic = json.load(open(os.path.join(ROOT, "profiles", pmc)))["per_launch"]["hbm_bytes_corrected"]
         out = {
