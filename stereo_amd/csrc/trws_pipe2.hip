@@ -29,7 +29,7 @@ constexpr int k2LdsDoubles = 2 * k2Stage + 4 * 8 * k2W + 2 * kScalDoubles + kPip
 static_assert(k2LdsDoubles * 8 <= 160 * 1024, "pipe2 kernel LDS");
 
 template <bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
-__global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, int epoch) {
+__device__ __forceinline__ void pipe2_body(DevParams p, int epoch) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double *stage0 = lds;                                   // 2 stages
   double *hand = lds + 2 * k2Stage;                       // ring of 4 x 8 x 128
@@ -417,37 +417,56 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, i
   }
 }
 
+template <bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
+__global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, int epoch) {
+  pipe2_body<BACKWARD, PRIMAL, UPDATE, SHARED>(p, epoch);
+}
+
+// row strips that share a device: one launch, workgroup b works for the strip group_strip() names
+template <bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
+__global__ __launch_bounds__(kPipeThreads) void trws_pipe2_group_kernel(GroupArgs ga, int epoch) {
+  pipe2_body<BACKWARD, PRIMAL, UPDATE, SHARED>(ga.pp[group_strip(ga)], epoch);
+}
+
 }  // namespace
 
 size_t pipe2_lds_bytes() { return sizeof(double) * k2LdsDoubles; }
 
 void pipe2_set_attributes() {
   const int lds2 = (int)pipe2_lds_bytes();
-#define SET_LDS2(SH)                                                                               \
-  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_pipe2_kernel<false, false, true, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2)); \
-  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_pipe2_kernel<true, false, true, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));  \
-  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_pipe2_kernel<false, true, true, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));  \
-  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_pipe2_kernel<false, true, false, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2))
-  SET_LDS2(true); SET_LDS2(false);
+#define SET_LDS2(NAME, SH)                                                                                                            \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<false, false, true, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2)); \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<true, false, true, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));  \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<false, true, true, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));  \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<false, true, false, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2))
+  SET_LDS2(trws_pipe2_kernel, true); SET_LDS2(trws_pipe2_kernel, false);
+  SET_LDS2(trws_pipe2_group_kernel, true); SET_LDS2(trws_pipe2_group_kernel, false);
 #undef SET_LDS2
 }
 
-void launch_pipe2(bool shared, int what, int blocks, hipStream_t s, const DevParams &p, int epoch) {
-  const size_t lds2 = pipe2_lds_bytes();
-  const dim3 grid2(blocks), block2(kPipeThreads);
-#define PIPE2(BW, PR, UP)                                                                         \
-  do {                                                                                            \
-    if (shared) hipLaunchKernelGGL((trws_pipe2_kernel<BW, PR, UP, true>), grid2, block2, lds2, s, p, epoch);  \
-    else hipLaunchKernelGGL((trws_pipe2_kernel<BW, PR, UP, false>), grid2, block2, lds2, s, p, epoch);        \
-  } while (0)
-  switch (what) {
-    case 0: PIPE2(false, false, true); break;
-    case 1: PIPE2(true, false, true); break;
-    case 2: PIPE2(false, true, true); break;
-    default: PIPE2(false, true, false); break;
-  }
-#undef PIPE2
+#define PIPE2_SWITCH(NAME, ARG)                                                                   \
+  const size_t lds2 = pipe2_lds_bytes();                                                          \
+  const dim3 grid2(blocks), block2(kPipeThreads);                                                 \
+  switch (what) {                                                                                 \
+    case 0: PIPE2(NAME, false, false, true, ARG); break;                                          \
+    case 1: PIPE2(NAME, true, false, true, ARG); break;                                           \
+    case 2: PIPE2(NAME, false, true, true, ARG); break;                                           \
+    default: PIPE2(NAME, false, true, false, ARG); break;                                         \
+  }                                                                                               \
   STEREO_HIP_CHECK(hipGetLastError());
+#define PIPE2(NAME, BW, PR, UP, ARG)                                                              \
+  do {                                                                                            \
+    if (shared) hipLaunchKernelGGL((NAME<BW, PR, UP, true>), grid2, block2, lds2, s, ARG, epoch);  \
+    else hipLaunchKernelGGL((NAME<BW, PR, UP, false>), grid2, block2, lds2, s, ARG, epoch);        \
+  } while (0)
+
+void launch_pipe2(bool shared, int what, int blocks, hipStream_t s, const DevParams &p, int epoch) {
+  PIPE2_SWITCH(trws_pipe2_kernel, p)
 }
+void launch_pipe2_group(bool shared, int what, int blocks, hipStream_t s, const GroupArgs &ga, int epoch) {
+  PIPE2_SWITCH(trws_pipe2_group_kernel, ga)
+}
+#undef PIPE2
+#undef PIPE2_SWITCH
 
 }  // namespace stereo

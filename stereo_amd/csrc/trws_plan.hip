@@ -987,12 +987,13 @@ static void launch_group(stereo_trws_plan *const *G, int n, int what, hipStream_
     ++P->epoch;
     STEREO_HIP_CHECK(hipMemsetAsync(P->d_ctl.p, 0, sizeof(int32_t), s));  // ticket = 0
     ga.first[i] = total;
-    total += P0->wide ? std::min(P->grid_blocks, P->cus) : P->grid_blocks;
+    total += (P0->wide || P0->fast2) ? std::min(P->grid_blocks, P->cus) : P->grid_blocks;
     if (what != 3) P->sweep_launches += 1;
   }
   ga.first[n] = total;
   if (P0->wide && P0->mode == STEREO_TRWS_MESSAGES_MINPLUS) launch_chunk_group(what, total, s, ga, epoch);
   else if (P0->wide) launch_wide_group(what, total, s, ga, epoch);
+  else if (P0->fast2) launch_pipe2_group(P0->pos != nullptr, what, total, s, ga, epoch);
   else launch_pipe_group(P0->kernel, P0->pos != nullptr, what, total, s, ga, epoch);
   STEREO_HIP_CHECK(hipGetLastError());
 }
@@ -1005,12 +1006,12 @@ int stereo_trws_plans_issue(stereo_trws_plan *const *plans, int n, void *stream,
     stereo_trws_plan *P = plans[i], *P0 = plans[0];
     if (P->issued) return fail("stereo_trws_plans_issue: the previous iteration has not been collected", err, errcap);
     if (P->device != P0->device || P->graph != P0->graph || P->K != P0->K || P->kernel != P0->kernel ||
-        P->epoch != P0->epoch || P->fwd_pending != P0->fwd_pending || P->wide != P0->wide || P->fast != P0->fast ||
+        P->epoch != P0->epoch || P->fwd_pending != P0->fwd_pending || P->wide != P0->wide || P->fast != P0->fast || P->fast2 != P0->fast2 ||
         (P->pos == nullptr) != (P0->pos == nullptr) || P->mode != P0->mode)
       return fail("stereo_trws_plans_issue: the plans are not strips of one problem on one device in the same state", err, errcap);
-    if (!(P->wide || P->fast))
-      return fail("stereo_trws_plans_issue: strips run on the pipelined kernels only (K <= 64, or K <= 256 with shared "
-                  "ascending positions and the linear kernel)", err, errcap);
+    if (!(P->wide || P->fast || P->fast2))
+      return fail("stereo_trws_plans_issue: strips run on the pipelined kernels only (K <= 64; K <= 128 with the linear "
+                  "kernel; K <= 256 with shared ascending positions and the linear kernel)", err, errcap);
   }
   try {
     stereo_trws_plan *P0 = plans[0];

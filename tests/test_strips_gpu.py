@@ -102,6 +102,32 @@ def test_wide_kernel_strips_k256(G, hip, oracle):
     assert np.array_equal(lab, lab1) and _close(en, en1) and _close(lb, lb1)
 
 
+@pytest.mark.parametrize("G", [2, 3])
+@pytest.mark.parametrize("integer", [False, True], ids=["real", "integer"])
+def test_k128_kernel_strips_with_per_edge_positions(G, integer, hip, oracle):
+    """64 < K <= 128 with per-edge positions (the 3D-label moves of config 5 with many proposals):
+    the two-labels-per-lane pipelined kernel as strips, vs the oracle on a small grid and vs the
+    single plan on a larger one.  Integer costs force exact ties through the serial envelopes."""
+    from stereo_amd.trws import TrwsPlan
+    K = 100
+    H, W = 10, 12
+    p = trws_problem(131 + integer, H, W, K, kind="general", integer=integer)
+    lab_o, en_o, lb_o, _ = oracle.trws(1, p["unary"], p["conn"], p["q"], p["qprim"], p["alphas"], 6.0, 3, -1e300, mode=1)
+    (lab, en, lb, _), path, _ = _run_strips(p, 1, K, H, W, G, 6.0, 3)
+    assert path == 4
+    assert np.array_equal(lab, lab_o) and _close(en, en_o) and _close(lb, lb_o)
+    H, W = 48, 52
+    p = trws_problem(133 + integer, H, W, K, kind="general", integer=integer)
+    one = TrwsPlan(1, K, H * W, p["conn"].T)
+    one.upload(p["unary"].T, p["alphas"], 6.0, q=p["q"].T, qprim=p["qprim"].T)
+    one.iterate(3, max_relgap=-1e300)
+    lab1, en1, lb1, _ = one.result()
+    assert one.path() == 4
+    (lab, en, lb, _), path, _ = _run_strips(p, 1, K, H, W, G, 6.0, 3)
+    assert path == 4
+    assert np.array_equal(lab, lab1) and _close(en, en1) and _close(lb, lb1)
+
+
 def test_strips_with_fewer_workgroups_than_runs(hip, oracle):
     """Each strip has more rows than workgroups: runs wait for tickets inside a strip while the
     strips wait for each other across the boundary -- no deadlock, same labels."""
