@@ -12,6 +12,14 @@
 namespace stereo {
 namespace {
 
+// per-phase cycle counters (STEREO_HIP_TRWS_PROF) are compiled in only with -DSTEREO_HIP_MESSAGE_PROFILE:
+// sixteen 64-bit accumulators live across the visit loop cost registers the compute role needs
+#ifdef STEREO_HIP_MESSAGE_PROFILE
+#define WIDE_PROF(p) ((p).prof != nullptr)
+#else
+#define WIDE_PROF(p) false
+#endif
+
 // ---- wide-label pipelined sweep: 64 < K <= 256, shared strictly ascending positions -------
 // The regime of the large grids (3000x2000x256).  A lane holds four labels (k = c * 64 + lane).
 // Per message K^2 pair costs are too many, so
@@ -37,6 +45,7 @@ constexpr int kWS = 260;    // LDS row stride in doubles (>= 256 + 1 breakpoints
 constexpr int kWPad = 16;   // min-plus source table is padded by this many (+inf, 0) entries on both sides
 constexpr int kWScr = 2 * (256 + 2 * kWPad);  // per compute wave scratch: (h, q) source table | 256 keys + 516 ints
 constexpr int kWBuckets = 512;
+constexpr int kWideSparse = 32;  // up to this many useful cones are evaluated one by one, more by the dense window loop
 constexpr int kWStG = kWS + 8 * kWS + 8;            // gamma = 1 / max(n_out, n_in) of the node (the loader's division)
 constexpr int kWStI = kWS + 8 * kWS + 10;           // int area of a stage (in doubles)
 constexpr int kWStage = kWStI + 40;  // ints: desc[64] px[8] row[8]
@@ -159,6 +168,37 @@ __device__ __forceinline__ bool keys_within(const double (&r)[4], int K, int C, 
   return UNI(bad);
 }
 
+// Tangency test of the certified path: does any cone have its u or v key within delta of the key of
+// one of the USEFUL cones (bit masks um, one per 64-label chunk)?  Cone number n of the useful ones
+// (in label order) is looked at when n % mod == r, so that several waves can share the work.  A
+// useful cone's keys are read from its own lane, so it matches itself -- and,
+// positions being strictly ascending, nobody else unless there is a near tangency: the number of
+// matches is counted with scalar instructions and compared with what the cones alone give.
+__device__ __forceinline__ bool useful_cone_ties(const unsigned long long (&um)[4], int mod, int r,
+                                                 const double (&uu)[4], const double (&vv)[4], double delta) {
+  int turn = 0, matches = 0, mine = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    unsigned long long mk = um[c];
+    while (mk) {
+      const int l = __builtin_ctzll(mk);
+      mk &= mk - 1;
+      const bool take = turn == r;
+      turn = turn + 1 == mod ? 0 : turn + 1;
+      if (take) {
+        const double ui = readlane_f64(uu[c], l), vi = readlane_f64(vv[c], l);
+        ++mine;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          matches += __builtin_popcountll(__builtin_amdgcn_ballot_w64(fabs(uu[cc] - ui) <= delta));
+          matches += __builtin_popcountll(__builtin_amdgcn_ballot_w64(fabs(vv[cc] - vi) <= delta));
+        }
+      }
+    }
+  }
+  return matches != 2 * mine;
+}
+
 template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE>
 __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -184,14 +224,13 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
   if (tid < 16) L.flags[tid] = -1;
   if (tid < 8) L.hflag[tid] = -1;
   if (tid == 0) { L.ctl[1] = 0; L.ctl[2] = 0; }
-  double posr[4];  // this lane's four label positions
-#pragma unroll
-  for (int c = 0; c < 4; ++c) posr[c] = c * kWave + lane < K ? p.pos[c * kWave + lane] : inf;
+#define WPOS(c) (L.pos[(c) * kWave + lane])        // this lane's four label positions (+inf beyond K)
+#define WVALID(c) ((c) * kWave + lane < K)
   const double pos_first = p.pos[0], pos_last = p.pos[K - 1];
   // development profile (STEREO_HIP_TRWS_PROF): cycles of wave 0 per phase [0..15], busy cycles of
   // loader / storer / primal [16..18], hardware-barrier wait of wave 0 [19], visits [20]
   unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pbusy = 0, pwait = 0, pvis = 0;
-#define WSTAMP(i) do { if (p.prof) { const long long now_ = (long long)__builtin_readcyclecounter(); pacc[i] += (unsigned long long)(now_ - tmark); tmark = now_; } } while (0)
+#define WSTAMP(i) do { if (WIDE_PROF(p)) { const long long now_ = (long long)__builtin_readcyclecounter(); pacc[i] += (unsigned long long)(now_ - tmark); tmark = now_; } } while (0)
   __syncthreads();
 
   for (;;) {
@@ -212,17 +251,17 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
       double *hcur = L.hand + hb * 8 * kWS, *hprev = L.hand + hb1 * 8 * kWS, *hprev2 = L.hand + hb2 * 8 * kWS; \
       double *sc = L.scal + (pos & 1) * kScalDoubles; \
       const bool have_node = pos >= p0 && pos < p1; \
-      long long tmark = p.prof ? (long long)__builtin_readcyclecounter() : 0; \
+      long long tmark = WIDE_PROF(p) ? (long long)__builtin_readcyclecounter() : 0; \
       const long long tvisit = tmark; \
       (void)st; (void)stn; (void)hcur; (void)hprev; (void)hprev2; (void)sc; (void)have_node; (void)tvisit;
-#define WIDE_VISITS_END_(BARRIER)       if (p.prof) { \
+#define WIDE_VISITS_END_(BARRIER)       if (WIDE_PROF(p)) { \
         const long long now_ = (long long)__builtin_readcyclecounter(); \
         if (wave == 0) pvis += have_node ? 1 : 0; \
         pbusy += (unsigned long long)(now_ - tvisit); \
         tmark = now_; \
       } \
       BARRIER; \
-      if (p.prof && wave == 0) pwait += (unsigned long long)((long long)__builtin_readcyclecounter() - tmark); \
+      if (WIDE_PROF(p) && wave == 0) pwait += (unsigned long long)((long long)__builtin_readcyclecounter() - tmark); \
       if (L.ctl[1]) { \
         if (tid == 0) st_sc1(p.abort_flag, 1); \
         return; \
@@ -240,9 +279,6 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           const bool fast_msg = KERNEL == 1 && p.certificate != 0;
           const bool working = j0 < nout && (role == 0 || fast_msg);
           if (working || (BACKWARD && wave == 0)) {
-            bool valid[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) valid[c] = c * kWave + lane < K;
             double di[4] = {inf, inf, inf, inf};
             if (role == 0) {
             const int myrow = sti[72 + (lane & 7)];  // LDS offsets of the message rows (written by loader A)
@@ -261,7 +297,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
               }
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) di[c] = valid[c] ? di[c] : inf;
+            for (int c = 0; c < 4; ++c) di[c] = WVALID(c) ? di[c] : inf;
             if (BACKWARD) {
               const double dm = min_raw(min_raw(di[0], di[1]), min_raw(di[2], di[3]));
               const double node_vmin = wave_min_dpp(dm);
@@ -284,17 +320,17 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                 for (int c = 0; c < 4; ++c) h[c] = gamma * di[c] - st[kWS + j * kWS + c * kWave + lane];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                  hlo = min_raw(hlo, valid[c] ? h[c] : inf); hhi = max_raw(hhi, valid[c] ? h[c] : -inf);
-                  h[c] = valid[c] ? h[c] : inf;
+                  hlo = min_raw(hlo, WVALID(c) ? h[c] : inf); hhi = max_raw(hhi, WVALID(c) ? h[c] : -inf);
+                  h[c] = WVALID(c) ? h[c] : inf;
                 }
                 hmin = wave_min_dpp(hlo); hmax = wave_max_dpp(hhi);
                 if (fast_msg && !constant) {
                   // publish H_j for the two closest-pair waves (and as this wave's source table)
 #pragma unroll
                   for (int c = 0; c < 4; ++c) {
-                    if (valid[c]) {
+                    if (WVALID(c)) {
                       if (uniform) htab[c * kWave + lane] = h[c];
-                      else mtab[c * kWave + lane] = make_double2(h[c], posr[c]);
+                      else mtab[c * kWave + lane] = make_double2(h[c], WPOS(c));
                     }
                   }
                   if (lane == 0) { L.msc[2 * j] = hmin; L.msc[2 * j + 1] = hmax; }
@@ -312,7 +348,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) hv[c] = uniform ? htab[c * kWave + lane] : mtab[c * kWave + lane].x;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) h[c] = valid[c] ? hv[c] : inf;
+                for (int c = 0; c < 4; ++c) h[c] = WVALID(c) ? hv[c] : inf;
                 hmin = L.msc[2 * j]; hmax = L.msc[2 * j + 1];
               }
               const double vtrunc = hmin + alpha * p.lambda;
@@ -322,20 +358,131 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
               const double delta = 1e-9 * (mag + fabs(alpha * p.lambda));
               double *scr = L.scr + wave * kWScr;
               WSTAMP(1);
-              if (role != 0) {
-                // ---- tangency: no two u = h - alpha q (role 1) / v = h + alpha q (role 2) within delta
-                if (!constant) {
-                  const double sgn = role == 2 ? 1.0 : -1.0;
-                  double r[4];
+              // ---- the certified path, shared by the three waves of the message ----------------------
+              // Only USEFUL cones (h < vTrunc; bit masks um) can give a destination a cost below
+              // vTrunc, and only pairs with a useful cone matter to the certificate (the test of
+              // trws_pipe_kernel's path).  With up to kWideSparse of them -- five to eight of 256 on
+              // real volumes -- nothing else is looked at: for useful cone i every lane forms the cost
+              // its four destinations get from i (the reference's own expression), keeps the smallest
+              // and second smallest cost per destination, and counts the destinations t where that
+              // cost is within delta of h_t, i.e. where cone t lies on an arm of cone i (u_t = u_i
+              // to the right of i, v_t = v_i to its left -- a tangency; t = i itself matches, once).
+              // Cone number n is handled by wave n % 3 of the message; the lead wave merges.
+              // With more useful cones (flat H) the window [-w, w] is cut in three ranges of the dense
+              // windowed min-plus and the helper waves run the conservative all-pairs closest-pair
+              // test on u and v.
+              const int w = p.window;
+              double m1[4] = {inf, inf, inf, inf}, m2[4] = {inf, inf, inf, inf};
+              unsigned long long um[4] = {0, 0, 0, 0};
+              int nuse = 0;
+              bool tie = false;
+              const bool certify = fast_msg && !constant;
+              if (certify) {
+                if (role == 0) WSYNC();  // this wave's own table writes
 #pragma unroll
-                  for (int c = 0; c < 4; ++c) r[c] = h[c] + sgn * (alpha * posr[c]);
-                  const double mn = role == 2 ? hmin + aplo : hmin - aphi;
-                  const double mx = role == 2 ? hmax + aphi : hmax - aplo;
-                  bool bad = !(delta < inf);
-                  if (!bad) bad = keys_within(r, K, C, delta, mn, mx - mn, scr, lane);
+                for (int c = 0; c < 4; ++c) {
+                  um[c] = __builtin_amdgcn_ballot_w64(WVALID(c) && h[c] < vtrunc);
+                  nuse += __builtin_popcountll(um[c]);
+                }
+                if (!(delta < inf)) tie = true;  // no finite scale: the serial construction decides
+                else if (nuse <= kWideSparse) {
+                  double pq[4];
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) pq[c] = WPOS(c);
+                  int turn = 0, matches = 0, mine = 0;
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) {
+                    unsigned long long mk = um[c];
+                    while (mk) {
+                      const int l = __builtin_ctzll(mk);
+                      mk &= mk - 1;
+                      const bool take = turn == role;
+                      turn = turn == 2 ? 0 : turn + 1;
+                      if (take) {
+                        const double hi = readlane_f64(h[c], l), qi = readlane_f64(pq[c], l);
+                        ++mine;
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) {
+                          const double cst = pair_cost<1>(alpha, pq[cc] - qi, hi);
+                          const double lo_ = min_raw(m1[cc], cst), hi_ = max_raw(m1[cc], cst);
+                          m2[cc] = min_raw(m2[cc], hi_);
+                          m1[cc] = lo_;
+                          matches += __builtin_popcountll(__builtin_amdgcn_ballot_w64(fabs(cst - h[cc]) <= delta));
+                        }
+                      }
+                    }
+                  }
+                  tie = matches != mine;
+                } else {
+                  const int nd = 2 * w + 1, dbase = nd / 3, drem = nd - 3 * dbase;
+                  const int dlo = role == 0 ? -w : role == 1 ? -w + dbase : -w + 2 * dbase + (drem > 0 ? 1 : 0);
+                  const int dhi = role == 0 ? -w + dbase - 1 : role == 1 ? -w + 2 * dbase + (drem > 0 ? 1 : 0) - 1 : w;
+                  if (uniform && w <= kWPad) {
+                    for (int d = dlo; d <= dhi; ++d) {
+                      const double ad = alpha * fabs((double)d * ustep);  // == alpha |t - q| exactly
+                      double hs[4];
+  #pragma unroll
+                      for (int c = 0; c < 4; ++c) hs[c] = htab[c * kWave + lane + d];
+  #pragma unroll
+                      for (int c = 0; c < 4; ++c) {
+                        const double cst = ad + hs[c];
+                        const double lo_ = min_raw(m1[c], cst), hi_ = max_raw(m1[c], cst);
+                        m2[c] = min_raw(m2[c], hi_);
+                        m1[c] = lo_;
+                      }
+                    }
+                  } else if (w <= kWPad) {
+                    for (int d = dlo; d <= dhi; ++d) {
+                      double2 sv[4];
+  #pragma unroll
+                      for (int c = 0; c < 4; ++c) sv[c] = mtab[c * kWave + lane + d];
+  #pragma unroll
+                      for (int c = 0; c < 4; ++c) {
+                        const double cst = pair_cost<1>(alpha, WPOS(c) - sv[c].y, sv[c].x);
+                        const double lo_ = min_raw(m1[c], cst), hi_ = max_raw(m1[c], cst);
+                        m2[c] = min_raw(m2[c], hi_);
+                        m1[c] = lo_;
+                      }
+                    }
+                  } else {
+                    for (int d = dlo; d <= dhi; ++d) {
+                      double2 sv[4];
+  #pragma unroll
+                      for (int c = 0; c < 4; ++c) {
+                        const int i = c * kWave + lane + d;
+                        sv[c] = mtab[i < 0 ? 0 : i > K - 1 ? K - 1 : i];
+                      }
+  #pragma unroll
+                      for (int c = 0; c < 4; ++c) {
+                        const int i = c * kWave + lane + d;
+                        double cst = pair_cost<1>(alpha, WPOS(c) - sv[c].y, sv[c].x);
+                        cst = (i >= 0 && i < K) ? cst : inf;
+                        const double lo_ = min_raw(m1[c], cst), hi_ = max_raw(m1[c], cst);
+                        m2[c] = min_raw(m2[c], hi_);
+                        m1[c] = lo_;
+                      }
+                    }
+                  }
+                  if (role != 0) {
+                    double r[4];
+                    const double sgn = role == 2 ? 1.0 : -1.0;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) r[c] = h[c] + sgn * (alpha * WPOS(c));
+                    const double mn = role == 2 ? hmin + aplo : hmin - aphi;
+                    const double mx = role == 2 ? hmax + aphi : hmax - aplo;
+                    tie = keys_within(r, K, C, delta, mn, mx - mn, scr, lane);
+                    WSYNC();  // the scratch is reused for the partial results below
+                  }
+                }
+              }
+              if (role != 0) {
+                if (certify) {
+                  // hand the partial results to the lead wave
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) { scr[c * kWave + lane] = m1[c]; scr[256 + c * kWave + lane] = m2[c]; }
                   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                   if (lane == 0)
-                    __hip_atomic_store(L.flags + 2 * j + (role - 1), (pos << 1) | (bad ? 1 : 0), __ATOMIC_RELAXED,
+                    __hip_atomic_store(L.flags + 2 * j + (role - 1), (pos << 1) | (tie ? 1 : 0), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 WSTAMP(2);
@@ -347,76 +494,11 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                   for (int c = 0; c < 4; ++c) out[c] = hmin;
                   vmin = hmin;
                 } else {
-                  // source table: (h, q) pairs at index kWPad + k, (+inf, 0) padding on both sides
-                  // (written above, when H_j was published)
-                  double2 *tab = mtab;
-                  WSYNC();
+                  if (!fast_msg) WSYNC();
                   bool serial = !fast_msg;
                   if (fast_msg) {
-                    // ---- windowed min-plus: smallest and second smallest cost per destination
-                    // (equal costs from two sources count as a zero margin: serial path decides)
-                    double m1[4] = {inf, inf, inf, inf}, m2[4] = {inf, inf, inf, inf};
-                    const int w = p.window;
-                    if (uniform && w <= kWPad) {
-                      for (int d = -w; d <= w; ++d) {
-                        const double ad = alpha * fabs((double)d * ustep);  // == alpha |t - q| exactly
-                        double hs[4];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) hs[c] = htab[c * kWave + lane + d];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                          const double cst = ad + hs[c];
-                          const double lo_ = min_raw(m1[c], cst), hi_ = max_raw(m1[c], cst);
-                          m2[c] = min_raw(m2[c], hi_);
-                          m1[c] = lo_;
-                        }
-                      }
-                    } else if (w <= kWPad) {
-                      for (int d = -w; d <= w; ++d) {
-                        double2 sv[4];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) sv[c] = tab[c * kWave + lane + d];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                          const double cst = pair_cost<1>(alpha, posr[c] - sv[c].y, sv[c].x);
-                          const double lo_ = min_raw(m1[c], cst), hi_ = max_raw(m1[c], cst);
-                          m2[c] = min_raw(m2[c], hi_);
-                          m1[c] = lo_;
-                        }
-                      }
-                    } else {
-                      for (int d = -w; d <= w; ++d) {
-                        double2 sv[4];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                          const int i = c * kWave + lane + d;
-                          sv[c] = tab[i < 0 ? 0 : i > K - 1 ? K - 1 : i];
-                        }
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                          const int i = c * kWave + lane + d;
-                          double cst = pair_cost<1>(alpha, posr[c] - sv[c].y, sv[c].x);
-                          cst = (i >= 0 && i < K) ? cst : inf;
-                          const double lo_ = min_raw(m1[c], cst), hi_ = max_raw(m1[c], cst);
-                          m2[c] = min_raw(m2[c], hi_);
-                          m1[c] = lo_;
-                        }
-                      }
-                    }
-                    bool bad = false;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                      if (valid[c]) {
-                        bad = bad || (m1[c] < vtrunc && !(m2[c] - m1[c] > delta && vtrunc - m1[c] > delta));
-                        out[c] = m1[c] < vtrunc ? m1[c] : vtrunc;
-                      }
-                    }
-                    // the smallest entry of a min-plus message on shared positions is min H itself
-                    // (destination t sees source t at distance 0; vTrunc >= min H): no reduction
-                    vmin = hmin;
-                    serial = UNI(bad);
                     WSTAMP(3);
-                    // the verdicts of the two closest-pair waves of this message
+                    // the two helper waves' verdicts and partial minima
                     bool crowded = false;
                     {
                       int spins = 0;
@@ -429,45 +511,43 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                       }
                       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     }
-                    if (!serial && crowded) {
-                      // Second look.  The closest-pair waves test ALL pairs of cones (conservative, O(K));
-                      // the certificate only asks for the pairs with a USEFUL cone (h < vTrunc), of which
-                      // there are usually a dozen or two among 256: those against everybody, directly
-                      // (the test of trws_pipe_kernel's certified path, same delta as above).  On the
-                      // noise-like volumes this leaves the serial construction -- one lane, 256 sources,
-                      // ~0.1 ms -- to the messages that really have a near tangency.
-                      double uu[4], vv[4];
-                      int nuse = 0;
-                      unsigned long long um[4];
+                    {
+                      const double *pa = L.scr + (wave + 1) * kWScr, *pb = L.scr + (wave + 2) * kWScr;
 #pragma unroll
                       for (int c = 0; c < 4; ++c) {
-                        const double aq = alpha * posr[c];
-                        uu[c] = h[c] - aq; vv[c] = h[c] + aq;
-                        um[c] = __builtin_amdgcn_ballot_w64(valid[c] && h[c] < vtrunc);
-                        nuse += __builtin_popcountll(um[c]);
+                        const double a1 = pa[c * kWave + lane], a2 = pa[256 + c * kWave + lane];
+                        const double b1 = pb[c * kWave + lane], b2 = pb[256 + c * kWave + lane];
+                        const double lo_ = min_raw(a1, b1), hi_ = max_raw(a1, b1);
+                        const double s2 = min_raw(min_raw(a2, b2), hi_);
+                        const double lo2 = min_raw(m1[c], lo_), hi2 = max_raw(m1[c], lo_);
+                        m2[c] = min_raw(min_raw(m2[c], s2), hi2);
+                        m1[c] = lo2;
                       }
-                      bool near_any = nuse > 64 || !(delta < inf);  // flat H (or no finite scale): the serial construction decides
-                      if (!near_any) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                          unsigned long long mk = um[c];
-                          while (mk) {
-                            const int i = c * kWave + __builtin_ctzll(mk);
-                            mk &= mk - 1;
-                            const double hi = uniform ? htab[i] : mtab[i].x, qi = L.pos[i];
-                            const double aqi = alpha * qi;
-                            const double ui = hi - aqi, vi = hi + aqi;
-#pragma unroll
-                            for (int cc = 0; cc < 4; ++cc) {
-                              const bool near = (fabs(uu[cc] - ui) <= delta) || (fabs(vv[cc] - vi) <= delta);
-                              near_any = near_any || (valid[cc] && near && posr[cc] != qi);
-                            }
-                          }
-                        }
-                      }
-                      crowded = UNI(near_any);
                     }
-                    serial = serial || crowded;
+                    bool bad = false;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                      if (WVALID(c)) {
+                        bad = bad || (m1[c] < vtrunc && !(m2[c] - m1[c] > delta && vtrunc - m1[c] > delta));
+                        out[c] = m1[c] < vtrunc ? m1[c] : vtrunc;
+                      }
+                    }
+                    // the smallest entry of a min-plus message on shared positions is min H itself
+                    // (destination t sees source t at distance 0; vTrunc >= min H): no reduction
+                    vmin = hmin;
+                    serial = UNI(bad);
+                    if (nuse > kWideSparse && !serial && crowded) {
+                      // the all-pairs test found two cones close together: only pairs with a useful
+                      // cone matter (flat H with more than 64 of them: the serial construction decides)
+                      double uu[4], vv[4];
+#pragma unroll
+                      for (int c = 0; c < 4; ++c) {
+                        const double aq = alpha * WPOS(c);
+                        uu[c] = h[c] - aq; vv[c] = h[c] + aq;
+                      }
+                      crowded = nuse > 64 || useful_cone_ties(um, 1, 0, uu, vv, delta);
+                    }
+                    serial = serial || crowded || tie;
                     WSTAMP(4);
                   }
                   if (serial) {
@@ -485,7 +565,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                     double *sh = L.fb, *sq = L.fb + kWS, *z = L.fb + 2 * kWS, *Hs = L.fb + 3 * kWS;
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                      if (valid[c]) Hs[c * kWave + lane] = h[c];
+                      if (WVALID(c)) Hs[c * kWave + lane] = h[c];
                     WSYNC();
                     if (lane == 0) build_envelope<KERNEL>(K, alpha, Hs, L.pos, sh, sq, z);
                     WSYNC();
@@ -495,8 +575,8 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                       const int k = c * kWave + lane;
                       if (c < C && k < K) {
                         int jj = 0;
-                        while (z[jj + 1] < posr[c]) ++jj;
-                        const double cst = pair_cost<KERNEL>(alpha, posr[c] - sq[jj], sh[jj]);
+                        while (z[jj + 1] < WPOS(c)) ++jj;
+                        const double cst = pair_cost<KERNEL>(alpha, WPOS(c) - sq[jj], sh[jj]);
                         out[c] = cst < vtrunc ? cst : vtrunc;
                         vloc = min_raw(vloc, out[c]);
                       }
@@ -702,7 +782,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
 #pragma unroll
               for (int c = 0; c < 4; ++c) {
                 if (c < C) {
-                  const double d = fwd ? pks - posr[c] : posr[c] - pks;
+                  const double d = fwd ? pks - WPOS(c) : WPOS(c) - pks;
                   const double v = KERNEL == 1 ? fabs(d) : d * d;
                   db[c] += aj * (v < p.lambda ? v : p.lambda);
                 }
@@ -741,14 +821,16 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
     if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2 + 1] = wall_clock64();
   }
 #undef WSTAMP
-  if (p.prof && lane == 0) {
+#undef WPOS
+#undef WVALID
+  if (WIDE_PROF(p) && lane == 0) {
     if (wave == 0) {
       for (int i = 0; i < 16; ++i) atomicAdd(p.prof + i, pacc[i]);
       atomicAdd(p.prof + 21, pwait);
       atomicAdd(p.prof + 22, pvis);
     }
     if (wave >= kWideCompute) atomicAdd(p.prof + 16 + (wave - kWideCompute), pbusy);
-    if (wave == 1) for (int i = 0; i < 3; ++i) atomicAdd(p.prof + 8 + i, pacc[i]);  // a closest-pair wave
+    if (wave == 1) for (int i = 0; i < 3; ++i) atomicAdd(p.prof + 8 + i, pacc[i]);  // a helper wave
   }
 }
 template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE>
