@@ -655,7 +655,7 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
       if (const char *c = std::getenv("STEREO_HIP_TRWS_SPIN_SECONDS")) secs = std::max(0.001, std::atof(c));
       P->spin_ticks = (long long)(secs * 1e8);
     }
-    if (std::getenv("STEREO_HIP_TRWS_PROF")) { P->d_prof.alloc(32); STEREO_HIP_CHECK(hipMemset(P->d_prof.p, 0, 256)); }
+    if (std::getenv("STEREO_HIP_TRWS_PROF")) { P->d_prof.alloc(64); STEREO_HIP_CHECK(hipMemset(P->d_prof.p, 0, 512)); }
     if (std::getenv("STEREO_HIP_TRWS_TIMELINE"))
       P->d_timeline.alloc(4 * std::max({g.sweep[0].run_ptr.size(), g.sweep[0].chain_run_ptr.size(), g.sweep[1].chain_run_ptr.size()}) + 4);
     STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * P->Nl));
@@ -729,7 +729,7 @@ void stereo_trws_plan_destroy(stereo_trws_plan *plan) {
     }
   }
   if (plan && plan->d_prof.p) {
-    unsigned long long v[32];
+    unsigned long long v[64];
     if (hipMemcpy(v, plan->d_prof.p, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess) {
       if (!plan->wide)
         std::fprintf(stderr, "[stereo_hip prof] cycles: p0 %llu p1 %llu p2 %llu p3 %llu p4 %llu | p5 %llu steps %llu\n",
@@ -753,6 +753,9 @@ void stereo_trws_plan_destroy(stereo_trws_plan *plan) {
         std::fprintf(stderr, " | loader A %.0f B %.0f storer %.0f primal %.0f | hw barrier wait %.0f | visits %llu\n",
                      (double)v[16] / v[22], (double)v[17] / v[22], (double)v[18] / v[22], (double)v[19] / v[22],
                      (double)v[21] / v[22], v[22]);
+        std::fprintf(stderr, "[stereo_hip prof wide] cycles from barrier to barrier arrival, per wave:");
+        for (int i = 0; i < 16; ++i) std::fprintf(stderr, " %.0f", (double)v[32 + i] / v[22]);
+        std::fprintf(stderr, "\n");
       }
     }
   }

@@ -48,8 +48,9 @@ constexpr int kWBuckets = 512;
 constexpr int kWideSparse = 32;  // up to this many useful cones are evaluated one by one, more by the dense window loop
 constexpr int kWStG = kWS + 8 * kWS + 8;            // gamma = 1 / max(n_out, n_in) of the node (the loader's division)
 constexpr int kWStI = kWS + 8 * kWS + 10;           // int area of a stage (in doubles)
-constexpr int kWStage = kWStI + 40;  // ints: desc[64] px[8] row[8]
-// stage: D[kWS] m[8][kWS] a[8] | ints desc[64] px[8] row[8] (row: where Di's k-th message row lives in LDS, in doubles)
+constexpr int kWStS = kWStI + 40;                   // S = D + the node's own (previous-sweep) message rows, added in list order by loader A
+constexpr int kWStage = kWStS + kWS;  // ints: desc[64] px[8] row[8]
+// stage: D[kWS] m[8][kWS] a[8] | ints desc[64] px[8] row[8] (row: where Di's k-th message row lives in LDS, in doubles) | S[kWS]
 
 struct WidePtrs {
   double *stage0, *hand, *scr, *fb, *pos, *scal, *msc;
@@ -216,11 +217,6 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
   // bit for bit): the min-plus source table then holds h only and alpha |d step| is formed once per d
   const double ustep = p.uniform_step;
   const bool uniform = ustep != 0;
-  if (wave < kWideCompute && wave % 3 == 0 && lane < 2 * kWPad) {
-    // padding of the min-plus source tables, never overwritten afterwards
-    if (uniform) (L.scr + wave * kWScr)[lane < kWPad ? lane : K + lane] = inf;
-    else ((double2 *)(L.scr + wave * kWScr))[lane < kWPad ? lane : K + lane] = make_double2(inf, 0.0);
-  }
   if (tid < 16) L.flags[tid] = -1;
   if (tid < 8) L.hflag[tid] = -1;
   if (tid == 0) { L.ctl[1] = 0; L.ctl[2] = 0; }
@@ -230,7 +226,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
   // development profile (STEREO_HIP_TRWS_PROF): cycles of wave 0 per phase [0..15], busy cycles of
   // loader / storer / primal [16..18], hardware-barrier wait of wave 0 [19], visits [20]
   unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pbusy = 0, pwait = 0, pvis = 0;
-#define WSTAMP(i) do { if (WIDE_PROF(p)) { const long long now_ = (long long)__builtin_readcyclecounter(); pacc[i] += (unsigned long long)(now_ - tmark); tmark = now_; } } while (0)
+#define WSTAMP(i) do { if (wprof) { const long long now_ = (long long)__builtin_readcyclecounter(); pacc[i] += (unsigned long long)(now_ - tmark); tmark = now_; } } while (0)
   __syncthreads();
 
   for (;;) {
@@ -240,6 +236,8 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
     __syncthreads();
     if (run >= p.nruns[D]) break;
     const int p0 = p.run_ptr[D][run], p1 = p.run_ptr[D][run + 1];
+    const bool wprof = WIDE_PROF(p) && (p.prof_run < 0 || run == p.prof_run);  // STEREO_HIP_TRWS_PROF_RUN: one run only
+    (void)wprof;
     if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2] = wall_clock64();
 
     // One visit loop per role (not one loop with a role switch inside): state carried from visit
@@ -251,17 +249,17 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
       double *hcur = L.hand + hb * 8 * kWS, *hprev = L.hand + hb1 * 8 * kWS, *hprev2 = L.hand + hb2 * 8 * kWS; \
       double *sc = L.scal + (pos & 1) * kScalDoubles; \
       const bool have_node = pos >= p0 && pos < p1; \
-      long long tmark = WIDE_PROF(p) ? (long long)__builtin_readcyclecounter() : 0; \
+      long long tmark = wprof ? (long long)__builtin_readcyclecounter() : 0; \
       const long long tvisit = tmark; \
       (void)st; (void)stn; (void)hcur; (void)hprev; (void)hprev2; (void)sc; (void)have_node; (void)tvisit;
-#define WIDE_VISITS_END_(BARRIER)       if (WIDE_PROF(p)) { \
+#define WIDE_VISITS_END_(BARRIER)       if (wprof) { \
         const long long now_ = (long long)__builtin_readcyclecounter(); \
         if (wave == 0) pvis += have_node ? 1 : 0; \
         pbusy += (unsigned long long)(now_ - tvisit); \
         tmark = now_; \
       } \
       BARRIER; \
-      if (WIDE_PROF(p) && wave == 0) pwait += (unsigned long long)((long long)__builtin_readcyclecounter() - tmark); \
+      if (wprof && wave == 0) pwait += (unsigned long long)((long long)__builtin_readcyclecounter() - tmark); \
       if (L.ctl[1]) { \
         if (tid == 0) st_sc1(p.abort_flag, 1); \
         return; \
@@ -271,7 +269,10 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
     if (wave < kWideCompute) {
       WIDE_VISITS_BEGIN
         // ======================================================== compute waves
-        const int j0 = wave / 3, role = wave - 3 * j0;  // role 0: min-plus, 1: u test, 2: v test
+        // Three waves per outgoing message (j0 = wave / 3).  All three form Di and H_j themselves --
+        // nothing is handed over before the work can start -- and share the DESTINATIONS of the
+        // message: wave `role` owns label chunk `role` ("A") and a third of chunk 3 ("B").
+        const int j0 = wave / 3, role = wave - 3 * j0;
         if (UPDATE && have_node) {
           const int *sti = (const int *)(st + kWStI);
           const int f = __builtin_amdgcn_readfirstlane(sti[2]);
@@ -280,17 +281,17 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           const bool working = j0 < nout && (role == 0 || fast_msg);
           if (working || (BACKWARD && wave == 0)) {
             double di[4] = {inf, inf, inf, inf};
-            if (role == 0) {
+            {
             const int myrow = sti[72 + (lane & 7)];  // LDS offsets of the message rows (written by loader A)
             // Di = D + messages in list order (from the ring where the neighbour was one of
-            // the last two visits of this run), formed by the min-plus wave of each message
+            // the last two visits of this run)
             // (reads are unconditional -- rows are padded to 256 -- and masked afterwards, so that
             // all of them are in flight together)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) di[c] = st[c * kWave + lane];
+            for (int c = 0; c < 4; ++c) di[c] = st[kWStS + c * kWave + lane];  // D + rows 0 .. nout - 1 (loader A)
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-              if (jj < ntot) {
+              if (jj >= nout && jj < ntot) {
                 const double *src = lds + __builtin_amdgcn_readlane(myrow, jj);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) di[c] += src[c * kWave + lane];
@@ -307,14 +308,18 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
             }
             }
             WSTAMP(0);
+            // this wave's destinations: chunk A = `role` (all lanes), of chunk B = 3 the lanes [lo3, hi3)
+            const int lo3 = role * 22, hi3 = role == 2 ? kWave : lo3 + 22;
+            const bool inB = lane >= lo3 && lane < hi3;
+            const unsigned long long maskB = __builtin_amdgcn_ballot_w64(inB);
+            const int kA = role * kWave + lane, kB = 3 * kWave + lane;
             for (int j = j0; working && j < nout; j += 4) {
               const double gamma = st[kWStG];  // (double)1 / (double)max(n_out, n_in)
               const double alpha = st[kWS + 8 * kWS + j];
               const bool constant = UNI(alpha == 0);
-              double h[4] = {inf, inf, inf, inf}, hmin = 0, hmax = 0;
-              double2 *mtab = (double2 *)(L.scr + (wave - role) * kWScr) + kWPad;  // the min-plus wave's (h, q) table
-              double *htab = L.scr + (wave - role) * kWScr + kWPad;                // ... or h only (uniform positions)
-              if (role == 0) {
+              if (constant && role != 0) continue;
+              double h[4], hmin, hmax;
+              {
                 double hlo = inf, hhi = -inf;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) h[c] = gamma * di[c] - st[kWS + j * kWS + c * kWave + lane];
@@ -324,32 +329,6 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                   h[c] = WVALID(c) ? h[c] : inf;
                 }
                 hmin = wave_min_dpp(hlo); hmax = wave_max_dpp(hhi);
-                if (fast_msg && !constant) {
-                  // publish H_j for the two closest-pair waves (and as this wave's source table)
-#pragma unroll
-                  for (int c = 0; c < 4; ++c) {
-                    if (WVALID(c)) {
-                      if (uniform) htab[c * kWave + lane] = h[c];
-                      else mtab[c * kWave + lane] = make_double2(h[c], WPOS(c));
-                    }
-                  }
-                  if (lane == 0) { L.msc[2 * j] = hmin; L.msc[2 * j + 1] = hmax; }
-                  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                  if (lane == 0) __hip_atomic_store(L.hflag + j, pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-              } else if (!constant) {
-                int spins = 0;
-                while (__hip_atomic_load(L.hflag + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != pos) {
-                  __builtin_amdgcn_s_sleep(0);
-                  if (++spins > kSpinLimit) { if (lane == 0) L.ctl[1] = 1; break; }  // bounded
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                double hv[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) hv[c] = uniform ? htab[c * kWave + lane] : mtab[c * kWave + lane].x;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) h[c] = WVALID(c) ? hv[c] : inf;
-                hmin = L.msc[2 * j]; hmax = L.msc[2 * j + 1];
               }
               const double vtrunc = hmin + alpha * p.lambda;
               const double ap0 = alpha * pos_first, ap1 = alpha * pos_last;
@@ -358,238 +337,207 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
               const double delta = 1e-9 * (mag + fabs(alpha * p.lambda));
               double *scr = L.scr + wave * kWScr;
               WSTAMP(1);
-              // ---- the certified path, shared by the three waves of the message ----------------------
+              // ---- the certified path -----------------------------------------------------------------
               // Only USEFUL cones (h < vTrunc; bit masks um) can give a destination a cost below
               // vTrunc, and only pairs with a useful cone matter to the certificate (the test of
               // trws_pipe_kernel's path).  With up to kWideSparse of them -- five to eight of 256 on
               // real volumes -- nothing else is looked at: for useful cone i every lane forms the cost
-              // its four destinations get from i (the reference's own expression), keeps the smallest
+              // its destinations get from i (the reference's own expression), keeps the smallest
               // and second smallest cost per destination, and counts the destinations t where that
               // cost is within delta of h_t, i.e. where cone t lies on an arm of cone i (u_t = u_i
               // to the right of i, v_t = v_i to its left -- a tangency; t = i itself matches, once).
-              // Cone number n is handled by wave n % 3 of the message; the lead wave merges.
-              // With more useful cones (flat H) the window [-w, w] is cut in three ranges of the dense
-              // windowed min-plus and the helper waves run the conservative all-pairs closest-pair
-              // test on u and v.
-              const int w = p.window;
-              double m1[4] = {inf, inf, inf, inf}, m2[4] = {inf, inf, inf, inf};
+              // With more useful cones (flat H) each wave runs the dense windowed min-plus for its
+              // destinations on a private copy of the source table, and the helper waves the
+              // conservative all-pairs closest-pair test on u and on v.
+              double outA = 0, outB = 0, vmin = 0;
               unsigned long long um[4] = {0, 0, 0, 0};
               int nuse = 0;
-              bool tie = false;
+              bool bad = false, crowded = false;
               const bool certify = fast_msg && !constant;
               if (certify) {
-                if (role == 0) WSYNC();  // this wave's own table writes
+                const int w = p.window;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                   um[c] = __builtin_amdgcn_ballot_w64(WVALID(c) && h[c] < vtrunc);
                   nuse += __builtin_popcountll(um[c]);
                 }
-                if (!(delta < inf)) tie = true;  // no finite scale: the serial construction decides
-                else if (nuse <= kWideSparse) {
-                  double pq[4];
+                double pq[4];
 #pragma unroll
-                  for (int c = 0; c < 4; ++c) pq[c] = WPOS(c);
-                  int turn = 0, matches = 0, mine = 0;
+                for (int c = 0; c < 4; ++c) pq[c] = WPOS(c);
+                const double hA = role == 0 ? h[0] : role == 1 ? h[1] : h[2], hB = h[3];
+                const double pA = role == 0 ? pq[0] : role == 1 ? pq[1] : pq[2], pB = pq[3];
+                double m1A = inf, m2A = inf, m1B = inf, m2B = inf;
+                if (!(delta < inf)) bad = true;  // no finite scale: the serial construction decides
+                else if (nuse <= kWideSparse) {
+                  int matches = 0;
 #pragma unroll
                   for (int c = 0; c < 4; ++c) {
                     unsigned long long mk = um[c];
                     while (mk) {
                       const int l = __builtin_ctzll(mk);
                       mk &= mk - 1;
-                      const bool take = turn == role;
-                      turn = turn == 2 ? 0 : turn + 1;
-                      if (take) {
-                        const double hi = readlane_f64(h[c], l), qi = readlane_f64(pq[c], l);
-                        ++mine;
-#pragma unroll
-                        for (int cc = 0; cc < 4; ++cc) {
-                          const double cst = pair_cost<1>(alpha, pq[cc] - qi, hi);
-                          const double lo_ = min_raw(m1[cc], cst), hi_ = max_raw(m1[cc], cst);
-                          m2[cc] = min_raw(m2[cc], hi_);
-                          m1[cc] = lo_;
-                          matches += __builtin_popcountll(__builtin_amdgcn_ballot_w64(fabs(cst - h[cc]) <= delta));
-                        }
-                      }
+                      const double hi = readlane_f64(h[c], l), qi = readlane_f64(pq[c], l);
+                      const double cA = pair_cost<1>(alpha, pA - qi, hi), cB = pair_cost<1>(alpha, pB - qi, hi);
+                      const double loA = min_raw(m1A, cA), hiA = max_raw(m1A, cA);
+                      const double loB = min_raw(m1B, cB), hiB = max_raw(m1B, cB);
+                      m2A = min_raw(m2A, hiA); m1A = loA;
+                      m2B = min_raw(m2B, hiB); m1B = loB;
+                      matches += __builtin_popcountll(__builtin_amdgcn_ballot_w64(fabs(cA - hA) <= delta));
+                      matches += __builtin_popcountll(__builtin_amdgcn_ballot_w64(fabs(cB - hB) <= delta) & maskB);
                     }
                   }
-                  tie = matches != mine;
+                  const unsigned long long ownA = role == 0 ? um[0] : role == 1 ? um[1] : um[2];
+                  bad = matches != __builtin_popcountll(ownA) + __builtin_popcountll(um[3] & maskB);
                 } else {
-                  const int nd = 2 * w + 1, dbase = nd / 3, drem = nd - 3 * dbase;
-                  const int dlo = role == 0 ? -w : role == 1 ? -w + dbase : -w + 2 * dbase + (drem > 0 ? 1 : 0);
-                  const int dhi = role == 0 ? -w + dbase - 1 : role == 1 ? -w + 2 * dbase + (drem > 0 ? 1 : 0) - 1 : w;
-                  if (uniform && w <= kWPad) {
-                    for (int d = dlo; d <= dhi; ++d) {
-                      const double ad = alpha * fabs((double)d * ustep);  // == alpha |t - q| exactly
-                      double hs[4];
-  #pragma unroll
-                      for (int c = 0; c < 4; ++c) hs[c] = htab[c * kWave + lane + d];
-  #pragma unroll
-                      for (int c = 0; c < 4; ++c) {
-                        const double cst = ad + hs[c];
-                        const double lo_ = min_raw(m1[c], cst), hi_ = max_raw(m1[c], cst);
-                        m2[c] = min_raw(m2[c], hi_);
-                        m1[c] = lo_;
-                      }
-                    }
-                  } else if (w <= kWPad) {
-                    for (int d = dlo; d <= dhi; ++d) {
-                      double2 sv[4];
-  #pragma unroll
-                      for (int c = 0; c < 4; ++c) sv[c] = mtab[c * kWave + lane + d];
-  #pragma unroll
-                      for (int c = 0; c < 4; ++c) {
-                        const double cst = pair_cost<1>(alpha, WPOS(c) - sv[c].y, sv[c].x);
-                        const double lo_ = min_raw(m1[c], cst), hi_ = max_raw(m1[c], cst);
-                        m2[c] = min_raw(m2[c], hi_);
-                        m1[c] = lo_;
-                      }
-                    }
-                  } else {
-                    for (int d = dlo; d <= dhi; ++d) {
-                      double2 sv[4];
-  #pragma unroll
-                      for (int c = 0; c < 4; ++c) {
-                        const int i = c * kWave + lane + d;
-                        sv[c] = mtab[i < 0 ? 0 : i > K - 1 ? K - 1 : i];
-                      }
-  #pragma unroll
-                      for (int c = 0; c < 4; ++c) {
-                        const int i = c * kWave + lane + d;
-                        double cst = pair_cost<1>(alpha, WPOS(c) - sv[c].y, sv[c].x);
-                        cst = (i >= 0 && i < K) ? cst : inf;
-                        const double lo_ = min_raw(m1[c], cst), hi_ = max_raw(m1[c], cst);
-                        m2[c] = min_raw(m2[c], hi_);
-                        m1[c] = lo_;
-                      }
-                    }
-                  }
                   if (role != 0) {
                     double r[4];
                     const double sgn = role == 2 ? 1.0 : -1.0;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) r[c] = h[c] + sgn * (alpha * WPOS(c));
+                    for (int c = 0; c < 4; ++c) r[c] = h[c] + sgn * (alpha * pq[c]);
                     const double mn = role == 2 ? hmin + aplo : hmin - aphi;
                     const double mx = role == 2 ? hmax + aphi : hmax - aplo;
-                    tie = keys_within(r, K, C, delta, mn, mx - mn, scr, lane);
-                    WSYNC();  // the scratch is reused for the partial results below
+                    crowded = keys_within(r, K, C, delta, mn, mx - mn, scr, lane);
+                    WSYNC();  // the scratch now becomes the source table
+                  }
+                  // private source table: (h, q) pairs at index kWPad + k -- h only on uniform positions --,
+                  // (+inf, 0) padding on both sides
+                  double2 *mtab = (double2 *)scr + kWPad;
+                  double *htab = scr + kWPad;
+                  if (lane < 2 * kWPad) {
+                    if (uniform) scr[lane < kWPad ? lane : K + lane] = inf;
+                    else ((double2 *)scr)[lane < kWPad ? lane : K + lane] = make_double2(inf, 0.0);
+                  }
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) {
+                    if (WVALID(c)) {
+                      if (uniform) htab[c * kWave + lane] = h[c];
+                      else mtab[c * kWave + lane] = make_double2(h[c], pq[c]);
+                    }
+                  }
+                  WSYNC();
+                  if (uniform && w <= kWPad) {
+                    for (int d = -w; d <= w; ++d) {
+                      const double ad = alpha * fabs((double)d * ustep);  // == alpha |t - q| exactly
+                      const double sA = htab[kA + d], sB = htab[kB + d];
+                      const double cA = ad + sA, cB = ad + sB;
+                      const double loA = min_raw(m1A, cA), hiA = max_raw(m1A, cA);
+                      const double loB = min_raw(m1B, cB), hiB = max_raw(m1B, cB);
+                      m2A = min_raw(m2A, hiA); m1A = loA;
+                      m2B = min_raw(m2B, hiB); m1B = loB;
+                    }
+                  } else {
+                    for (int d = -w; d <= w; ++d) {
+                      const int iA = kA + d, iB = kB + d;
+                      const double2 sA = mtab[w <= kWPad ? iA : iA < 0 ? 0 : iA > K - 1 ? K - 1 : iA];
+                      const double2 sB = mtab[w <= kWPad ? iB : iB < 0 ? 0 : iB > K - 1 ? K - 1 : iB];
+                      double cA = pair_cost<1>(alpha, pA - sA.y, sA.x), cB = pair_cost<1>(alpha, pB - sB.y, sB.x);
+                      if (w > kWPad) { cA = (iA >= 0 && iA < K) ? cA : inf; cB = (iB >= 0 && iB < K) ? cB : inf; }
+                      const double loA = min_raw(m1A, cA), hiA = max_raw(m1A, cA);
+                      const double loB = min_raw(m1B, cB), hiB = max_raw(m1B, cB);
+                      m2A = min_raw(m2A, hiA); m1A = loA;
+                      m2B = min_raw(m2B, hiB); m1B = loB;
+                    }
                   }
                 }
+                // margins of this wave's destinations
+                const bool badA = kA < K && m1A < vtrunc && !(m2A - m1A > delta && vtrunc - m1A > delta);
+                const bool badB = inB && kB < K && m1B < vtrunc && !(m2B - m1B > delta && vtrunc - m1B > delta);
+                bad = bad || UNI(badA || badB);
+                outA = m1A < vtrunc ? m1A : vtrunc;
+                outB = m1B < vtrunc ? m1B : vtrunc;
+                // the smallest entry of a min-plus message on shared positions is min H itself
+                // (destination t sees source t at distance 0; vTrunc >= min H): no reduction
+                vmin = hmin;
+                if (role < C && kA < K) hcur[j * kWS + kA] = outA - vmin;
+                if (inB && kB < K) hcur[j * kWS + kB] = outB - vmin;
+                WSTAMP(3);
               }
               if (role != 0) {
                 if (certify) {
-                  // hand the partial results to the lead wave
-#pragma unroll
-                  for (int c = 0; c < 4; ++c) { scr[c * kWave + lane] = m1[c]; scr[256 + c * kWave + lane] = m2[c]; }
                   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                   if (lane == 0)
-                    __hip_atomic_store(L.flags + 2 * j + (role - 1), (pos << 1) | (tie ? 1 : 0), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(L.flags + 2 * j + (role - 1), (pos << 2) | (crowded ? 2 : 0) | (bad ? 1 : 0),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 WSTAMP(2);
               } else {
-                double out[4] = {0, 0, 0, 0}, vmin = 0;
+                bool serial = !fast_msg;
                 if (constant) {
                   // typeStereoLinear.h:390-396: message = min H everywhere, normalised to zero
+                  serial = false;
 #pragma unroll
-                  for (int c = 0; c < 4; ++c) out[c] = hmin;
+                  for (int c = 0; c < 4; ++c) {
+                    const int k = c * kWave + lane;
+                    if (c < C && k < K) hcur[j * kWS + k] = hmin - hmin;
+                  }
                   vmin = hmin;
-                } else {
-                  if (!fast_msg) WSYNC();
-                  bool serial = !fast_msg;
-                  if (fast_msg) {
-                    WSTAMP(3);
-                    // the two helper waves' verdicts and partial minima
-                    bool crowded = false;
-                    {
-                      int spins = 0;
-                      for (;;) {
-                        const int v = lane < 2 ? __hip_atomic_load(L.flags + 2 * j + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : (pos << 1);
-                        const bool ready = (v >> 1) == pos;
-                        if (!UNI(!ready)) { crowded = UNI((v & 1) != 0); break; }
-                        __builtin_amdgcn_s_sleep(0);
-                        if (++spins > kSpinLimit) { if (lane == 0) L.ctl[1] = 1; break; }  // bounded
-                      }
-                      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                } else if (fast_msg) {
+                  // the two helper waves' verdicts
+                  int verdict = 0;
+                  {
+                    int spins = 0;
+                    for (;;) {
+                      const int v = lane < 2 ? __hip_atomic_load(L.flags + 2 * j + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : (pos << 2);
+                      const bool ready = (v >> 2) == pos;
+                      if (!UNI(!ready)) { verdict = (UNI((v & 1) != 0) ? 1 : 0) | (UNI((v & 2) != 0) ? 2 : 0); break; }
+                      __builtin_amdgcn_s_sleep(0);
+                      if (++spins > kSpinLimit) { if (lane == 0) L.ctl[1] = 1; break; }  // bounded
                     }
-                    {
-                      const double *pa = L.scr + (wave + 1) * kWScr, *pb = L.scr + (wave + 2) * kWScr;
-#pragma unroll
-                      for (int c = 0; c < 4; ++c) {
-                        const double a1 = pa[c * kWave + lane], a2 = pa[256 + c * kWave + lane];
-                        const double b1 = pb[c * kWave + lane], b2 = pb[256 + c * kWave + lane];
-                        const double lo_ = min_raw(a1, b1), hi_ = max_raw(a1, b1);
-                        const double s2 = min_raw(min_raw(a2, b2), hi_);
-                        const double lo2 = min_raw(m1[c], lo_), hi2 = max_raw(m1[c], lo_);
-                        m2[c] = min_raw(min_raw(m2[c], s2), hi2);
-                        m1[c] = lo2;
-                      }
-                    }
-                    bool bad = false;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                  }
+                  serial = bad || (verdict & 1) != 0;
+                  if (!serial && (verdict & 2) != 0) {
+                    // the all-pairs test found two cones close together: only pairs with a useful
+                    // cone matter (flat H with more than 64 of them: the serial construction decides)
+                    double uu[4], vv[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                      if (WVALID(c)) {
-                        bad = bad || (m1[c] < vtrunc && !(m2[c] - m1[c] > delta && vtrunc - m1[c] > delta));
-                        out[c] = m1[c] < vtrunc ? m1[c] : vtrunc;
-                      }
+                      const double aq = alpha * WPOS(c);
+                      uu[c] = h[c] - aq; vv[c] = h[c] + aq;
                     }
-                    // the smallest entry of a min-plus message on shared positions is min H itself
-                    // (destination t sees source t at distance 0; vTrunc >= min H): no reduction
-                    vmin = hmin;
-                    serial = UNI(bad);
-                    if (nuse > kWideSparse && !serial && crowded) {
-                      // the all-pairs test found two cones close together: only pairs with a useful
-                      // cone matter (flat H with more than 64 of them: the serial construction decides)
-                      double uu[4], vv[4];
-#pragma unroll
-                      for (int c = 0; c < 4; ++c) {
-                        const double aq = alpha * WPOS(c);
-                        uu[c] = h[c] - aq; vv[c] = h[c] + aq;
-                      }
-                      crowded = nuse > 64 || useful_cone_ties(um, 1, 0, uu, vv, delta);
-                    }
-                    serial = serial || crowded || tie;
-                    WSTAMP(4);
+                    serial = nuse > 64 || useful_cone_ties(um, 1, 0, uu, vv, delta);
                   }
-                  if (serial) {
-                    // the reference's serial construction in LDS; the stack lives in a scratch
-                    // shared by the workgroup (rare path): take its lock
-                    if (lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
-                    if (lane == 0) {
-                      int spins = 0;
-                      while (__hip_atomic_exchange(L.ctl + 2, 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
-                        __builtin_amdgcn_s_sleep(2);
-                        if (++spins > kSpinLimit) { L.ctl[1] = 1; break; }
-                      }
-                    }
-                    WSYNC();
-                    double *sh = L.fb, *sq = L.fb + kWS, *z = L.fb + 2 * kWS, *Hs = L.fb + 3 * kWS;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                      if (WVALID(c)) Hs[c * kWave + lane] = h[c];
-                    WSYNC();
-                    if (lane == 0) build_envelope<KERNEL>(K, alpha, Hs, L.pos, sh, sq, z);
-                    WSYNC();
-                    double vloc = inf;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                      const int k = c * kWave + lane;
-                      if (c < C && k < K) {
-                        int jj = 0;
-                        while (z[jj + 1] < WPOS(c)) ++jj;
-                        const double cst = pair_cost<KERNEL>(alpha, WPOS(c) - sq[jj], sh[jj]);
-                        out[c] = cst < vtrunc ? cst : vtrunc;
-                        vloc = min_raw(vloc, out[c]);
-                      }
-                    }
-                    WSYNC();
-                    if (lane == 0) __hip_atomic_store(L.ctl + 2, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    vmin = wave_min_dpp(vloc);
-                  }
+                  WSTAMP(4);
                 }
+                if (serial) {
+                  // the reference's serial construction in LDS; the stack lives in a scratch
+                  // shared by the workgroup (rare path): take its lock
+                  if (lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
+                  if (lane == 0) {
+                    int spins = 0;
+                    while (__hip_atomic_exchange(L.ctl + 2, 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
+                      __builtin_amdgcn_s_sleep(2);
+                      if (++spins > kSpinLimit) { L.ctl[1] = 1; break; }
+                    }
+                  }
+                  WSYNC();
+                  double *sh = L.fb, *sq = L.fb + kWS, *z = L.fb + 2 * kWS, *Hs = L.fb + 3 * kWS;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                  const int k = c * kWave + lane;
-                  if (c < C && k < K) hcur[j * kWS + k] = out[c] - vmin;
+                  for (int c = 0; c < 4; ++c)
+                    if (WVALID(c)) Hs[c * kWave + lane] = h[c];
+                  WSYNC();
+                  if (lane == 0) build_envelope<KERNEL>(K, alpha, Hs, L.pos, sh, sq, z);
+                  WSYNC();
+                  double out[4] = {0, 0, 0, 0}, vloc = inf;
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) {
+                    const int k = c * kWave + lane;
+                    if (c < C && k < K) {
+                      int jj = 0;
+                      while (z[jj + 1] < WPOS(c)) ++jj;
+                      const double cst = pair_cost<KERNEL>(alpha, WPOS(c) - sq[jj], sh[jj]);
+                      out[c] = cst < vtrunc ? cst : vtrunc;
+                      vloc = min_raw(vloc, out[c]);
+                    }
+                  }
+                  WSYNC();
+                  if (lane == 0) __hip_atomic_store(L.ctl + 2, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  vmin = wave_min_dpp(vloc);
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) {
+                    const int k = c * kWave + lane;
+                    if (c < C && k < K) hcur[j * kWS + k] = out[c] - vmin;
+                  }
                 }
                 if (BACKWARD && lane == 0) sc[j] = vmin;
                 WSTAMP(5);
@@ -598,7 +546,102 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           }
         }
       WIDE_VISITS_END
+    } else if (wave == kWideCompute && (K & 1) == 0) {
+      // ======================================================== loader A: own data, two visits deep
+      // During visit pos the registers hold node pos + 1's unary, previous-sweep messages and weight,
+      // requested during visit pos - 1: the HBM latency of one node lies behind the whole visit of
+      // the node before it instead of inside its own.  They go to the stage, then node pos + 2's
+      // requests go out and stay in flight across the barrier.  The loads are issued by hand (16 bytes
+      // per lane: labels 2 lane, 2 lane + 1 of each half row; K is even here) so that the order
+      // "store the old set, then request the new one into the same registers" is the one executed.
+      typedef int wide_v4i __attribute__((ext_vector_type(4)));
+      const wide_v4i zero4 = {0, 0, 0, 0};
+      wide_v4i rd0 = zero4, rd1 = zero4, rm[8][2];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { rm[j][0] = zero4; rm[j][1] = zero4; }
+      double av = 0;
+      const bool ok0 = 2 * lane < K, ok1 = 2 * kWave + 2 * lane < K;
+      int w1 = desc[(size_t)p0 * DW + lane];                                  // the node in the registers
+      int w2 = p0 + 1 < p1 ? desc[(size_t)(p0 + 1) * DW + lane] : 0;          // the one after it
+#define WIDE_LOAD16(DST, PTR, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(DST) : "v"(PTR) : "memory")
+#define WIDE_REQUEST_OWN(W)                                                                               \
+      do {                                                                                                \
+        const NodeDesc rq = decode_desc(W);                                                               \
+        const double *ub = p.unary + (size_t)rq.node * K + 2 * lane;                                      \
+        if (ok0) WIDE_LOAD16(rd0, ub, 0);                                                                 \
+        if (ok1) WIDE_LOAD16(rd1, ub, 1024);                                                              \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
+          if (j < rq.nout && (UPDATE || PRIMAL)) {                                                        \
+            const double *mb = p.msg + (size_t)rq.e[j] * K + 2 * lane;                                    \
+            if (ok0) WIDE_LOAD16(rm[j][0], mb, 0);                                                        \
+            if (ok1) WIDE_LOAD16(rm[j][1], mb, 1024);                                                     \
+          }                                                                                               \
+        }                                                                                                 \
+        av = 0;                                                                                           \
+        if (lane < rq.nout + rq.nin) {                                                                    \
+          int ej = 0;                                                                                     \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                   \
+            if (lane == j) ej = rq.e[j];                                                                  \
+          av = p.alpha[ej];                                                                               \
+        }                                                                                                 \
+      } while (0)
+      WIDE_REQUEST_OWN(w1);
+      WIDE_VISITS_BEGIN
+        if (pos + 1 >= p0 && pos + 1 < p1) {
+          const int w = w1;
+          const NodeDesc nx = decode_desc(w);
+          int *stni = (int *)(stn + kWStI);
+          stni[lane] = w;
+          {
+            // where the compute waves find the node's message rows at visit pos + 1 (offsets into the
+            // workgroup's LDS, in doubles): a message handed over inside the run sits in the ring of
+            // the last two visits, everything else in this stage -- decided here, once, instead of by
+            // every compute wave in scalar code on its critical path
+            int sl = -1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (lane == j) sl = j >= nx.nout ? nx.slot[j] : -1;
+            const int hb1n = ((pos % 3) + 3) % 3, hb2n = (((pos - 1) % 3) + 3) % 3;  // hprev / hprev2 of visit pos + 1
+            const int row = sl >= 8 ? (int)(L.hand - lds) + hb2n * 8 * kWS + (sl - 8) * kWS
+                          : sl >= 0 ? (int)(L.hand - lds) + hb1n * 8 * kWS + sl * kWS
+                                    : (int)(stn - lds) + kWS + lane * kWS;
+            if (lane < 8) stni[72 + lane] = row;
+          }
+          L.dring[((pos + 1) % 3) * 64 + lane] = w;
+          // everything requested during the last visit has arrived once this returns
+          asm volatile("s_waitcnt vmcnt(0)"
+                       : "+v"(rd0), "+v"(rd1), "+v"(rm[0][0]), "+v"(rm[0][1]), "+v"(rm[1][0]), "+v"(rm[1][1]), "+v"(rm[2][0]),
+                         "+v"(rm[2][1]), "+v"(rm[3][0]), "+v"(rm[3][1]), "+v"(rm[4][0]), "+v"(rm[4][1]), "+v"(rm[5][0]),
+                         "+v"(rm[5][1]), "+v"(rm[6][0]), "+v"(rm[6][1]), "+v"(rm[7][0]), "+v"(rm[7][1])
+                       :: "memory");
+          if (ok0) *(wide_v4i *)(stn + 2 * lane) = rd0;
+          if (ok1) *(wide_v4i *)(stn + 2 * kWave + 2 * lane) = rd1;
+          // S = D + rows 0 .. nout - 1, added in list order: the prefix of Di that is known a visit ahead
+          typedef double wide_v2d __attribute__((ext_vector_type(2)));
+          wide_v2d s0 = __builtin_bit_cast(wide_v2d, rd0), s1 = __builtin_bit_cast(wide_v2d, rd1);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (j < nx.nout) {
+              if (ok0) *(wide_v4i *)(stn + kWS + j * kWS + 2 * lane) = rm[j][0];
+              if (ok1) *(wide_v4i *)(stn + kWS + j * kWS + 2 * kWave + 2 * lane) = rm[j][1];
+              s0 += __builtin_bit_cast(wide_v2d, rm[j][0]);
+              s1 += __builtin_bit_cast(wide_v2d, rm[j][1]);
+            }
+          }
+          if (ok0) *(wide_v2d *)(stn + kWStS + 2 * lane) = s0;
+          if (ok1) *(wide_v2d *)(stn + kWStS + 2 * kWave + 2 * lane) = s1;
+          if (lane < 8) stn[kWS + 8 * kWS + lane] = av;
+          if (lane == 0) stn[kWStG] = (double)1 / (double)(nx.nout > nx.nin ? nx.nout : nx.nin);
+          w1 = w2;
+          asm volatile("" ::: "memory");
+          if (pos + 2 < p1) WIDE_REQUEST_OWN(w1);
+          if (pos + 3 < p1) w2 = desc[(size_t)(pos + 3) * DW + lane];
+        }
+      WIDE_VISITS_END
+#undef WIDE_REQUEST_OWN
+#undef WIDE_LOAD16
     } else if (wave == kWideCompute) {
+      // loader A for odd K (no 16-byte alignment of the rows): node pos + 1 during visit pos
       int wnext = desc[(size_t)p0 * DW + lane];
       WIDE_VISITS_BEGIN
         // ======================================================== loader A: node pos + 1, own data
@@ -653,9 +696,11 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           for (int c = 0; c < 4; ++c) {
             if (okc[c]) {
               stn[c * kWave + lane] = dk[c];
+              double sum = dk[c];  // S = D + rows 0 .. nout - 1 in list order
 #pragma unroll
               for (int j = 0; j < 8; ++j)
-                if (j < nx.nout) stn[kWS + j * kWS + c * kWave + lane] = mv[j][c];
+                if (j < nx.nout) { stn[kWS + j * kWS + c * kWave + lane] = mv[j][c]; sum += mv[j][c]; }
+              stn[kWStS + c * kWave + lane] = sum;
             }
           }
           if (lane < 8) stn[kWS + 8 * kWS + lane] = av;
@@ -830,6 +875,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
       atomicAdd(p.prof + 22, pvis);
     }
     if (wave >= kWideCompute) atomicAdd(p.prof + 16 + (wave - kWideCompute), pbusy);
+    atomicAdd(p.prof + 32 + wave, pbusy);
     if (wave == 1) for (int i = 0; i < 3; ++i) atomicAdd(p.prof + 8 + i, pacc[i]);  // a helper wave
   }
 }
