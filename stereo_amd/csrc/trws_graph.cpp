@@ -457,7 +457,16 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
         }
         D[0] = g.order[r];
         D[1] = r;
-        D[2] = (int32_t)((uint32_t)nout | ((uint32_t)nin << 4) | ((uint32_t)nd << 8) | (md << 16));
+        // bit 12: a loader may wait for this node's foreign dependencies while the node two visits
+        // earlier in the run is still being computed (its result only becomes visible one visit
+        // later): true if every dependency comes before that node in this sweep's order -- what is
+        // waited for can then not depend on anything this workgroup still holds back.  False where
+        // two chains feed each other (the interleaved last rows).
+        const int32_t pm = pred[r], pm2 = pm >= 0 ? pred[pm] : -1;
+        const int32_t bound = pm2 >= 0 ? pm2 : pm >= 0 ? pm : r;
+        bool ahead = true;
+        for (int k = 0; k < nd; ++k) ahead = ahead && (d == 0 ? deps[r][k] < bound : deps[r][k] > bound);
+        D[2] = (int32_t)((uint32_t)nout | ((uint32_t)nin << 4) | ((uint32_t)nd << 8) | ((uint32_t)ahead << 12) | (md << 16));
         D[3] = g.lb_pos_node[r];
         for (int k = 0; k < 4; ++k) D[20 + k] = k < nd ? deps[r][k] : 0;
         // strips: which outgoing messages (and whose copy of the flag / label) live in a neighbour's memory

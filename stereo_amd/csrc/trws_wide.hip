@@ -38,7 +38,7 @@ namespace {
 // (message j + 4 on the same waves).  If the certificate fails, wave 3j runs the reference's
 // serial envelope construction in LDS (one at a time per workgroup: shared scratch, rare).
 // Kernel 1 (truncated linear) only; kernel 2 above K = 64 stays on the generic kernel.
-constexpr int kWideCompute = 12;
+constexpr int kWideCompute = 4;
 constexpr int kWideWaves = kWideCompute + 4;  // + loader (own data), loader (foreign data), storer, primal
 constexpr int kWideThreads = kWideWaves * kWave;
 constexpr int kWS = 260;    // LDS row stride in doubles (>= 256 + 1 breakpoints, multiple of 4)
@@ -269,26 +269,26 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
     if (wave < kWideCompute) {
       WIDE_VISITS_BEGIN
         // ======================================================== compute waves
-        // Three waves per outgoing message (j0 = wave / 3).  All three form Di and H_j themselves --
-        // nothing is handed over before the work can start -- and share the DESTINATIONS of the
-        // message: wave `role` owns label chunk `role` ("A") and a third of chunk 3 ("B").
-        const int j0 = wave / 3, role = wave - 3 * j0;
+        // One wave per outgoing message (message j0 = wave; messages 4 .. 7 of the few nodes that have
+        // them in a second round), one wave per SIMD: the four messages of a node do not compete for
+        // an instruction stream, nothing is handed over between waves inside the visit.
+        const int j0 = wave;
         if (UPDATE && have_node) {
           const int *sti = (const int *)(st + kWStI);
           const int f = __builtin_amdgcn_readfirstlane(sti[2]);
           const int nout = f & 15, nin = (f >> 4) & 15, ntot = nout + nin;
           const bool fast_msg = KERNEL == 1 && p.certificate != 0;
-          const bool working = j0 < nout && (role == 0 || fast_msg);
+          const bool working = j0 < nout;
           if (working || (BACKWARD && wave == 0)) {
             double di[4] = {inf, inf, inf, inf};
             {
             const int myrow = sti[72 + (lane & 7)];  // LDS offsets of the message rows (written by loader A)
             // Di = D + messages in list order (from the ring where the neighbour was one of
-            // the last two visits of this run)
+            // the last two visits of this run); the prefix D + rows 0 .. nout - 1 comes from loader A
             // (reads are unconditional -- rows are padded to 256 -- and masked afterwards, so that
             // all of them are in flight together)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) di[c] = st[kWStS + c * kWave + lane];  // D + rows 0 .. nout - 1 (loader A)
+            for (int c = 0; c < 4; ++c) di[c] = st[kWStS + c * kWave + lane];
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
               if (jj >= nout && jj < ntot) {
@@ -308,16 +308,10 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
             }
             }
             WSTAMP(0);
-            // this wave's destinations: chunk A = `role` (all lanes), of chunk B = 3 the lanes [lo3, hi3)
-            const int lo3 = role * 22, hi3 = role == 2 ? kWave : lo3 + 22;
-            const bool inB = lane >= lo3 && lane < hi3;
-            const unsigned long long maskB = __builtin_amdgcn_ballot_w64(inB);
-            const int kA = role * kWave + lane, kB = 3 * kWave + lane;
             for (int j = j0; working && j < nout; j += 4) {
               const double gamma = st[kWStG];  // (double)1 / (double)max(n_out, n_in)
               const double alpha = st[kWS + 8 * kWS + j];
               const bool constant = UNI(alpha == 0);
-              if (constant && role != 0) continue;
               double h[4], hmin, hmax;
               {
                 double hlo = inf, hhi = -inf;
@@ -337,25 +331,29 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
               const double delta = 1e-9 * (mag + fabs(alpha * p.lambda));
               double *scr = L.scr + wave * kWScr;
               WSTAMP(1);
-              // ---- the certified path -----------------------------------------------------------------
-              // Only USEFUL cones (h < vTrunc; bit masks um) can give a destination a cost below
-              // vTrunc, and only pairs with a useful cone matter to the certificate (the test of
-              // trws_pipe_kernel's path).  With up to kWideSparse of them -- five to eight of 256 on
-              // real volumes -- nothing else is looked at: for useful cone i every lane forms the cost
-              // its destinations get from i (the reference's own expression), keeps the smallest
-              // and second smallest cost per destination, and counts the destinations t where that
-              // cost is within delta of h_t, i.e. where cone t lies on an arm of cone i (u_t = u_i
-              // to the right of i, v_t = v_i to its left -- a tangency; t = i itself matches, once).
-              // With more useful cones (flat H) each wave runs the dense windowed min-plus for its
-              // destinations on a private copy of the source table, and the helper waves the
-              // conservative all-pairs closest-pair test on u and on v.
-              double outA = 0, outB = 0, vmin = 0;
-              unsigned long long um[4] = {0, 0, 0, 0};
-              int nuse = 0;
-              bool bad = false, crowded = false;
-              const bool certify = fast_msg && !constant;
-              if (certify) {
+              double out[4] = {0, 0, 0, 0}, vmin = 0;
+              bool serial = !fast_msg;
+              if (constant) {
+                // typeStereoLinear.h:390-396: message = min H everywhere, normalised to zero
+                serial = false;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) out[c] = hmin;
+                vmin = hmin;
+              } else if (fast_msg) {
+                // ---- the certified path ---------------------------------------------------------------
+                // Only USEFUL cones (h < vTrunc; bit masks um) can give a destination a cost below
+                // vTrunc, and only pairs with a useful cone matter to the certificate (the test of
+                // trws_pipe_kernel's path).  With up to kWideSparse of them -- five to eight of 256 on
+                // real volumes -- nothing else is looked at: for useful cone i every lane forms the cost
+                // its four destinations get from i (the reference's own expression), keeps the smallest
+                // and second smallest cost per destination, and counts the destinations t where that
+                // cost is within delta of h_t, i.e. where cone t lies on an arm of cone i (u_t = u_i
+                // to the right of i, v_t = v_i to its left -- a tangency; t = i itself matches, once).
+                // With more useful cones (flat H): the dense windowed min-plus from a padded source
+                // table, and the conservative all-pairs closest-pair test on u and on v by bucketing.
                 const int w = p.window;
+                unsigned long long um[4];
+                int nuse = 0;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                   um[c] = __builtin_amdgcn_ballot_w64(WVALID(c) && h[c] < vtrunc);
@@ -364,9 +362,8 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                 double pq[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) pq[c] = WPOS(c);
-                const double hA = role == 0 ? h[0] : role == 1 ? h[1] : h[2], hB = h[3];
-                const double pA = role == 0 ? pq[0] : role == 1 ? pq[1] : pq[2], pB = pq[3];
-                double m1A = inf, m2A = inf, m1B = inf, m2B = inf;
+                double m1[4] = {inf, inf, inf, inf}, m2[4] = {inf, inf, inf, inf};
+                bool bad = false;
                 if (!(delta < inf)) bad = true;  // no finite scale: the serial construction decides
                 else if (nuse <= kWideSparse) {
                   int matches = 0;
@@ -377,30 +374,45 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                       const int l = __builtin_ctzll(mk);
                       mk &= mk - 1;
                       const double hi = readlane_f64(h[c], l), qi = readlane_f64(pq[c], l);
-                      const double cA = pair_cost<1>(alpha, pA - qi, hi), cB = pair_cost<1>(alpha, pB - qi, hi);
-                      const double loA = min_raw(m1A, cA), hiA = max_raw(m1A, cA);
-                      const double loB = min_raw(m1B, cB), hiB = max_raw(m1B, cB);
-                      m2A = min_raw(m2A, hiA); m1A = loA;
-                      m2B = min_raw(m2B, hiB); m1B = loB;
-                      matches += __builtin_popcountll(__builtin_amdgcn_ballot_w64(fabs(cA - hA) <= delta));
-                      matches += __builtin_popcountll(__builtin_amdgcn_ballot_w64(fabs(cB - hB) <= delta) & maskB);
+#pragma unroll
+                      for (int cc = 0; cc < 4; ++cc) {
+                        const double cst = pair_cost<1>(alpha, pq[cc] - qi, hi);
+                        const double lo_ = min_raw(m1[cc], cst), hi_ = max_raw(m1[cc], cst);
+                        m2[cc] = min_raw(m2[cc], hi_);
+                        m1[cc] = lo_;
+                        matches += __builtin_popcountll(__builtin_amdgcn_ballot_w64(fabs(cst - h[cc]) <= delta));
+                      }
                     }
                   }
-                  const unsigned long long ownA = role == 0 ? um[0] : role == 1 ? um[1] : um[2];
-                  bad = matches != __builtin_popcountll(ownA) + __builtin_popcountll(um[3] & maskB);
+                  bad = matches != nuse;
                 } else {
-                  if (role != 0) {
+                  bool crowded = false;
+                  {
                     double r[4];
-                    const double sgn = role == 2 ? 1.0 : -1.0;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) r[c] = h[c] + sgn * (alpha * pq[c]);
-                    const double mn = role == 2 ? hmin + aplo : hmin - aphi;
-                    const double mx = role == 2 ? hmax + aphi : hmax - aplo;
-                    crowded = keys_within(r, K, C, delta, mn, mx - mn, scr, lane);
-                    WSYNC();  // the scratch now becomes the source table
+                    for (int c = 0; c < 4; ++c) r[c] = h[c] - alpha * pq[c];
+                    crowded = keys_within(r, K, C, delta, hmin - aphi, (hmax - aplo) - (hmin - aphi), scr, lane);
+                    WSYNC();
+                    if (!crowded) {
+#pragma unroll
+                      for (int c = 0; c < 4; ++c) r[c] = h[c] + alpha * pq[c];
+                      crowded = keys_within(r, K, C, delta, hmin + aplo, (hmax + aphi) - (hmin + aplo), scr, lane);
+                      WSYNC();
+                    }
                   }
-                  // private source table: (h, q) pairs at index kWPad + k -- h only on uniform positions --,
-                  // (+inf, 0) padding on both sides
+                  if (crowded) {
+                    // the all-pairs test found two cones close together: only pairs with a useful
+                    // cone matter (flat H with more than 64 of them: the serial construction decides)
+                    double uu[4], vv[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                      const double aq = alpha * pq[c];
+                      uu[c] = h[c] - aq; vv[c] = h[c] + aq;
+                    }
+                    bad = nuse > 64 || useful_cone_ties(um, 1, 0, uu, vv, delta);
+                  }
+                  // source table (the scratch again): (h, q) pairs at index kWPad + k -- h only on uniform
+                  // positions --, (+inf, 0) padding on both sides
                   double2 *mtab = (double2 *)scr + kWPad;
                   double *htab = scr + kWPad;
                   if (lane < 2 * kWPad) {
@@ -418,130 +430,94 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                   if (uniform && w <= kWPad) {
                     for (int d = -w; d <= w; ++d) {
                       const double ad = alpha * fabs((double)d * ustep);  // == alpha |t - q| exactly
-                      const double sA = htab[kA + d], sB = htab[kB + d];
-                      const double cA = ad + sA, cB = ad + sB;
-                      const double loA = min_raw(m1A, cA), hiA = max_raw(m1A, cA);
-                      const double loB = min_raw(m1B, cB), hiB = max_raw(m1B, cB);
-                      m2A = min_raw(m2A, hiA); m1A = loA;
-                      m2B = min_raw(m2B, hiB); m1B = loB;
+                      double hs[4];
+#pragma unroll
+                      for (int c = 0; c < 4; ++c) hs[c] = htab[c * kWave + lane + d];
+#pragma unroll
+                      for (int c = 0; c < 4; ++c) {
+                        const double cst = ad + hs[c];
+                        const double lo_ = min_raw(m1[c], cst), hi_ = max_raw(m1[c], cst);
+                        m2[c] = min_raw(m2[c], hi_);
+                        m1[c] = lo_;
+                      }
                     }
                   } else {
                     for (int d = -w; d <= w; ++d) {
-                      const int iA = kA + d, iB = kB + d;
-                      const double2 sA = mtab[w <= kWPad ? iA : iA < 0 ? 0 : iA > K - 1 ? K - 1 : iA];
-                      const double2 sB = mtab[w <= kWPad ? iB : iB < 0 ? 0 : iB > K - 1 ? K - 1 : iB];
-                      double cA = pair_cost<1>(alpha, pA - sA.y, sA.x), cB = pair_cost<1>(alpha, pB - sB.y, sB.x);
-                      if (w > kWPad) { cA = (iA >= 0 && iA < K) ? cA : inf; cB = (iB >= 0 && iB < K) ? cB : inf; }
-                      const double loA = min_raw(m1A, cA), hiA = max_raw(m1A, cA);
-                      const double loB = min_raw(m1B, cB), hiB = max_raw(m1B, cB);
-                      m2A = min_raw(m2A, hiA); m1A = loA;
-                      m2B = min_raw(m2B, hiB); m1B = loB;
+                      double2 sv[4];
+#pragma unroll
+                      for (int c = 0; c < 4; ++c) {
+                        const int i = c * kWave + lane + d;
+                        sv[c] = mtab[w <= kWPad ? i : i < 0 ? 0 : i > K - 1 ? K - 1 : i];
+                      }
+#pragma unroll
+                      for (int c = 0; c < 4; ++c) {
+                        const int i = c * kWave + lane + d;
+                        double cst = pair_cost<1>(alpha, pq[c] - sv[c].y, sv[c].x);
+                        if (w > kWPad) cst = (i >= 0 && i < K) ? cst : inf;
+                        const double lo_ = min_raw(m1[c], cst), hi_ = max_raw(m1[c], cst);
+                        m2[c] = min_raw(m2[c], hi_);
+                        m1[c] = lo_;
+                      }
                     }
                   }
+                  WSYNC();
                 }
-                // margins of this wave's destinations
-                const bool badA = kA < K && m1A < vtrunc && !(m2A - m1A > delta && vtrunc - m1A > delta);
-                const bool badB = inB && kB < K && m1B < vtrunc && !(m2B - m1B > delta && vtrunc - m1B > delta);
-                bad = bad || UNI(badA || badB);
-                outA = m1A < vtrunc ? m1A : vtrunc;
-                outB = m1B < vtrunc ? m1B : vtrunc;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                  if (WVALID(c)) {
+                    bad = bad || (m1[c] < vtrunc && !(m2[c] - m1[c] > delta && vtrunc - m1[c] > delta));
+                    out[c] = m1[c] < vtrunc ? m1[c] : vtrunc;
+                  }
+                }
                 // the smallest entry of a min-plus message on shared positions is min H itself
                 // (destination t sees source t at distance 0; vTrunc >= min H): no reduction
                 vmin = hmin;
-                if (role < C && kA < K) hcur[j * kWS + kA] = outA - vmin;
-                if (inB && kB < K) hcur[j * kWS + kB] = outB - vmin;
+                serial = UNI(bad);
                 WSTAMP(3);
               }
-              if (role != 0) {
-                if (certify) {
-                  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                  if (lane == 0)
-                    __hip_atomic_store(L.flags + 2 * j + (role - 1), (pos << 2) | (crowded ? 2 : 0) | (bad ? 1 : 0),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                WSTAMP(2);
-              } else {
-                bool serial = !fast_msg;
-                if (constant) {
-                  // typeStereoLinear.h:390-396: message = min H everywhere, normalised to zero
-                  serial = false;
-#pragma unroll
-                  for (int c = 0; c < 4; ++c) {
-                    const int k = c * kWave + lane;
-                    if (c < C && k < K) hcur[j * kWS + k] = hmin - hmin;
-                  }
-                  vmin = hmin;
-                } else if (fast_msg) {
-                  // the two helper waves' verdicts
-                  int verdict = 0;
-                  {
-                    int spins = 0;
-                    for (;;) {
-                      const int v = lane < 2 ? __hip_atomic_load(L.flags + 2 * j + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : (pos << 2);
-                      const bool ready = (v >> 2) == pos;
-                      if (!UNI(!ready)) { verdict = (UNI((v & 1) != 0) ? 1 : 0) | (UNI((v & 2) != 0) ? 2 : 0); break; }
-                      __builtin_amdgcn_s_sleep(0);
-                      if (++spins > kSpinLimit) { if (lane == 0) L.ctl[1] = 1; break; }  // bounded
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                  }
-                  serial = bad || (verdict & 1) != 0;
-                  if (!serial && (verdict & 2) != 0) {
-                    // the all-pairs test found two cones close together: only pairs with a useful
-                    // cone matter (flat H with more than 64 of them: the serial construction decides)
-                    double uu[4], vv[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                      const double aq = alpha * WPOS(c);
-                      uu[c] = h[c] - aq; vv[c] = h[c] + aq;
-                    }
-                    serial = nuse > 64 || useful_cone_ties(um, 1, 0, uu, vv, delta);
-                  }
-                  WSTAMP(4);
-                }
-                if (serial) {
-                  // the reference's serial construction in LDS; the stack lives in a scratch
-                  // shared by the workgroup (rare path): take its lock
-                  if (lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
-                  if (lane == 0) {
-                    int spins = 0;
-                    while (__hip_atomic_exchange(L.ctl + 2, 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
-                      __builtin_amdgcn_s_sleep(2);
-                      if (++spins > kSpinLimit) { L.ctl[1] = 1; break; }
-                    }
-                  }
-                  WSYNC();
-                  double *sh = L.fb, *sq = L.fb + kWS, *z = L.fb + 2 * kWS, *Hs = L.fb + 3 * kWS;
-#pragma unroll
-                  for (int c = 0; c < 4; ++c)
-                    if (WVALID(c)) Hs[c * kWave + lane] = h[c];
-                  WSYNC();
-                  if (lane == 0) build_envelope<KERNEL>(K, alpha, Hs, L.pos, sh, sq, z);
-                  WSYNC();
-                  double out[4] = {0, 0, 0, 0}, vloc = inf;
-#pragma unroll
-                  for (int c = 0; c < 4; ++c) {
-                    const int k = c * kWave + lane;
-                    if (c < C && k < K) {
-                      int jj = 0;
-                      while (z[jj + 1] < WPOS(c)) ++jj;
-                      const double cst = pair_cost<KERNEL>(alpha, WPOS(c) - sq[jj], sh[jj]);
-                      out[c] = cst < vtrunc ? cst : vtrunc;
-                      vloc = min_raw(vloc, out[c]);
-                    }
-                  }
-                  WSYNC();
-                  if (lane == 0) __hip_atomic_store(L.ctl + 2, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                  vmin = wave_min_dpp(vloc);
-#pragma unroll
-                  for (int c = 0; c < 4; ++c) {
-                    const int k = c * kWave + lane;
-                    if (c < C && k < K) hcur[j * kWS + k] = out[c] - vmin;
+              if (serial) {
+                // the reference's serial construction in LDS; the stack lives in a scratch
+                // shared by the workgroup (rare path): take its lock
+                if (lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
+                if (lane == 0) {
+                  int spins = 0;
+                  while (__hip_atomic_exchange(L.ctl + 2, 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > kSpinLimit) { L.ctl[1] = 1; break; }
                   }
                 }
-                if (BACKWARD && lane == 0) sc[j] = vmin;
-                WSTAMP(5);
+                WSYNC();
+                double *sh = L.fb, *sq = L.fb + kWS, *z = L.fb + 2 * kWS, *Hs = L.fb + 3 * kWS;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                  if (WVALID(c)) Hs[c * kWave + lane] = h[c];
+                WSYNC();
+                if (lane == 0) build_envelope<KERNEL>(K, alpha, Hs, L.pos, sh, sq, z);
+                WSYNC();
+                double vloc = inf;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                  const int k = c * kWave + lane;
+                  if (c < C && k < K) {
+                    int jj = 0;
+                    while (z[jj + 1] < WPOS(c)) ++jj;
+                    const double cst = pair_cost<KERNEL>(alpha, WPOS(c) - sq[jj], sh[jj]);
+                    out[c] = cst < vtrunc ? cst : vtrunc;
+                    vloc = min_raw(vloc, out[c]);
+                  }
+                }
+                WSYNC();
+                if (lane == 0) __hip_atomic_store(L.ctl + 2, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                vmin = wave_min_dpp(vloc);
+                WSTAMP(4);
               }
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const int k = c * kWave + lane;
+                if (c < C && k < K) hcur[j * kWS + k] = out[c] - vmin;
+              }
+              if (BACKWARD && lane == 0) sc[j] = vmin;
+              WSTAMP(5);
             }
           }
         }
@@ -707,7 +683,97 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           if (lane == 0) stn[kWStG] = (double)1 / (double)(nx.nout > nx.nin ? nx.nout : nx.nin);
         }
       WIDE_VISITS_END
+    } else if (wave == kWideCompute + 1 && (K & 1) == 0) {
+      // ======================================================== loader B: data behind flags, two visits deep
+      // During visit pos the registers hold node pos + 1's foreign messages and labels; they go to the
+      // stage, then this wave waits for node pos + 2's flags and sends its requests, which stay in
+      // flight across the barrier: flag round trip and fetch round trip of a node overlap with the
+      // visit before its own instead of adding up inside it.  Only where the descriptor allows it
+      // (bit 12 of word 2, trws_graph.cpp): what is waited for must not depend on the nodes this
+      // workgroup has not yet made visible; elsewhere (the interleaved last rows) the node is fetched
+      // during the visit before its own, as loader B always did.
+      typedef int wide_v4i __attribute__((ext_vector_type(4)));
+      const wide_v4i zero4 = {0, 0, 0, 0};
+      wide_v4i rb[8][2];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { rb[j][0] = zero4; rb[j][1] = zero4; }
+      int pxv = 0;
+      bool parked = false;  // the registers hold node pos + 1's data
+      const bool ok0 = 2 * lane < K, ok1 = 2 * kWave + 2 * lane < K;
+      int w1 = desc[(size_t)p0 * DW + lane];
+      int w2 = p0 + 1 < p1 ? desc[(size_t)(p0 + 1) * DW + lane] : 0;
+#define WIDE_LOAD16_SC1(DST, PTR, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF " sc0 sc1" : "=v"(DST) : "v"(PTR) : "memory")
+#define WIDE_REQUEST_FOREIGN(W)                                                                           \
+      do {                                                                                                \
+        const NodeDesc rq = decode_desc(W);                                                               \
+        const int rtot = rq.nout + rq.nin;                                                                \
+        int xn = 0, sl = 0;                                                                               \
+        if (lane < rtot) {                                                                                \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                   \
+            if (lane == j) { xn = rq.xn[j]; sl = rq.slot[j]; }                                            \
+        }                                                                                                 \
+        if (rq.ndep > 0) {                                                                                \
+          int myrank = rq.dep[0];                                                                         \
+          _Pragma("unroll") for (int j = 1; j < 4; ++j)                                                   \
+            if (lane == j) myrank = rq.dep[j];                                                            \
+          const bool watching = lane < rq.ndep;                                                           \
+          int spins = 0;                                                                                  \
+          long long t0 = 0;                                                                               \
+          bool ok = true;                                                                                 \
+          for (;;) {                                                                                      \
+            const int v = watching ? ld_sc1(p.done + myrank) : epoch;                                     \
+            if (!UNI(v < epoch)) break;                                                                   \
+            const unsigned long long late = __builtin_amdgcn_ballot_w64(v < epoch),                       \
+                                     late_halo = __builtin_amdgcn_ballot_w64(v < epoch && myrank >= p.n_own); \
+            if (!keep_waiting(p, spins, t0, late_halo != 0)) { /* wall-clock bound, or somebody else gave up */ \
+              if (lane == __builtin_ctzll(late_halo ? late_halo : late)) report_give_up(p, rq.rank, myrank, v, epoch); \
+              ok = false;                                                                                 \
+              break;                                                                                      \
+            }                                                                                             \
+          }                                                                                               \
+          if (!ok && lane == 0) L.ctl[1] = 1;                                                             \
+        }                                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
+          if (UPDATE && j >= rq.nout && j < rtot && rq.slot[j] < 0) {                                     \
+            const double *mb = p.msg + (size_t)rq.e[j] * K + 2 * lane;                                    \
+            if (ok0) WIDE_LOAD16_SC1(rb[j][0], mb, 0);                                                    \
+            if (ok1) WIDE_LOAD16_SC1(rb[j][1], mb, 1024);                                                 \
+          }                                                                                               \
+        }                                                                                                 \
+        pxv = 0;                                                                                          \
+        if (PRIMAL && lane < rtot && lane >= rq.nout && sl < 0) pxv = ld_sc1(p.x + xn);                   \
+      } while (0)
+      WIDE_VISITS_BEGIN
+        if (pos + 1 >= p0 && pos + 1 < p1) {
+          if (!parked) WIDE_REQUEST_FOREIGN(w1);
+          const NodeDesc nx = decode_desc(w1);
+          int *stni = (int *)(stn + kWStI);
+          const int ntot = nx.nout + nx.nin;
+          // everything requested (during the last visit, or just now) has arrived once this returns
+          asm volatile("s_waitcnt vmcnt(0)"
+                       : "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[2][0]), "+v"(rb[2][1]), "+v"(rb[3][0]),
+                         "+v"(rb[3][1]), "+v"(rb[4][0]), "+v"(rb[4][1]), "+v"(rb[5][0]), "+v"(rb[5][1]), "+v"(rb[6][0]),
+                         "+v"(rb[6][1]), "+v"(rb[7][0]), "+v"(rb[7][1])
+                       :: "memory");
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (UPDATE && j >= nx.nout && j < ntot && nx.slot[j] < 0) {
+              if (ok0) *(wide_v4i *)(stn + kWS + j * kWS + 2 * lane) = rb[j][0];
+              if (ok1) *(wide_v4i *)(stn + kWS + j * kWS + 2 * kWave + 2 * lane) = rb[j][1];
+            }
+          }
+          if (lane < 8) stni[64 + lane] = pxv;
+          w1 = w2;
+          asm volatile("" ::: "memory");
+          parked = pos + 2 < p1 && ((__builtin_amdgcn_readlane(w1, 2) >> 12) & 1) != 0;
+          if (parked) WIDE_REQUEST_FOREIGN(w1);
+          if (pos + 3 < p1) w2 = desc[(size_t)(pos + 3) * DW + lane];
+        }
+      WIDE_VISITS_END
+#undef WIDE_REQUEST_FOREIGN
+#undef WIDE_LOAD16_SC1
     } else if (wave == kWideCompute + 1) {
+      // loader B for odd K (no 16-byte alignment of the rows): node pos + 1 during visit pos
       int wnext = desc[(size_t)p0 * DW + lane];
       WIDE_VISITS_BEGIN
         // ======================================================== loader B: node pos + 1, data behind flags
@@ -876,7 +942,6 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
     }
     if (wave >= kWideCompute) atomicAdd(p.prof + 16 + (wave - kWideCompute), pbusy);
     atomicAdd(p.prof + 32 + wave, pbusy);
-    if (wave == 1) for (int i = 0; i < 3; ++i) atomicAdd(p.prof + 8 + i, pacc[i]);  // a helper wave
   }
 }
 template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE>
