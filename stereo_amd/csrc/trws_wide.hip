@@ -537,8 +537,11 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
       for (int j = 0; j < 8; ++j) { rm[j][0] = zero4; rm[j][1] = zero4; }
       double av = 0;
       const bool ok0 = 2 * lane < K, ok1 = 2 * kWave + 2 * lane < K;
+      // descriptors are fetched three nodes ahead: every load of a visit is waited for at the top of the
+      // next one, so a descriptor requested at the end of a visit would put its latency there
       int w1 = desc[(size_t)p0 * DW + lane];                                  // the node in the registers
       int w2 = p0 + 1 < p1 ? desc[(size_t)(p0 + 1) * DW + lane] : 0;          // the one after it
+      int w3 = p0 + 2 < p1 ? desc[(size_t)(p0 + 2) * DW + lane] : 0;
 #define WIDE_LOAD16(DST, PTR, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(DST) : "v"(PTR) : "memory")
 #define WIDE_REQUEST_OWN(W)                                                                               \
       do {                                                                                                \
@@ -608,10 +611,11 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           if (ok1) *(wide_v2d *)(stn + kWStS + 2 * kWave + 2 * lane) = s1;
           if (lane < 8) stn[kWS + 8 * kWS + lane] = av;
           if (lane == 0) stn[kWStG] = (double)1 / (double)(nx.nout > nx.nin ? nx.nout : nx.nin);
-          w1 = w2;
+          int w4 = 0;
+          if (pos + 4 < p1) w4 = desc[(size_t)(pos + 4) * DW + lane];
+          w1 = w2; w2 = w3; w3 = w4;
           asm volatile("" ::: "memory");
           if (pos + 2 < p1) WIDE_REQUEST_OWN(w1);
-          if (pos + 3 < p1) w2 = desc[(size_t)(pos + 3) * DW + lane];
         }
       WIDE_VISITS_END
 #undef WIDE_REQUEST_OWN
@@ -702,6 +706,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
       const bool ok0 = 2 * lane < K, ok1 = 2 * kWave + 2 * lane < K;
       int w1 = desc[(size_t)p0 * DW + lane];
       int w2 = p0 + 1 < p1 ? desc[(size_t)(p0 + 1) * DW + lane] : 0;
+      int w3 = p0 + 2 < p1 ? desc[(size_t)(p0 + 2) * DW + lane] : 0;  // three nodes ahead, as in loader A
 #define WIDE_LOAD16_SC1(DST, PTR, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF " sc0 sc1" : "=v"(DST) : "v"(PTR) : "memory")
 #define WIDE_REQUEST_FOREIGN(W)                                                                           \
       do {                                                                                                \
@@ -763,11 +768,12 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
             }
           }
           if (lane < 8) stni[64 + lane] = pxv;
-          w1 = w2;
+          int w4 = 0;
+          if (pos + 4 < p1) w4 = desc[(size_t)(pos + 4) * DW + lane];
+          w1 = w2; w2 = w3; w3 = w4;
           asm volatile("" ::: "memory");
           parked = pos + 2 < p1 && ((__builtin_amdgcn_readlane(w1, 2) >> 12) & 1) != 0;
           if (parked) WIDE_REQUEST_FOREIGN(w1);
-          if (pos + 3 < p1) w2 = desc[(size_t)(pos + 3) * DW + lane];
         }
       WIDE_VISITS_END
 #undef WIDE_REQUEST_FOREIGN
