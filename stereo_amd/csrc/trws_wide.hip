@@ -38,7 +38,7 @@ namespace {
 // (message j + 4 on the same waves).  If the certificate fails, wave 3j runs the reference's
 // serial envelope construction in LDS (one at a time per workgroup: shared scratch, rare).
 // Kernel 1 (truncated linear) only; kernel 2 above K = 64 stays on the generic kernel.
-constexpr int kWideCompute = 4;
+constexpr int kWideCompute = 8;
 constexpr int kWideWaves = kWideCompute + 4;  // + loader (own data), loader (foreign data), storer, primal
 constexpr int kWideThreads = kWideWaves * kWave;
 constexpr int kWS = 260;    // LDS row stride in doubles (>= 256 + 1 breakpoints, multiple of 4)
@@ -269,9 +269,11 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
     if (wave < kWideCompute) {
       WIDE_VISITS_BEGIN
         // ======================================================== compute waves
-        // One wave per outgoing message (message j0 = wave; messages 4 .. 7 of the few nodes that have
-        // them in a second round), one wave per SIMD: the four messages of a node do not compete for
-        // an instruction stream, nothing is handed over between waves inside the visit.
+        // One wave per outgoing message (message j0 = wave): the four messages of an ordinary node run
+        // on four SIMDs and do not compete for an instruction stream, nothing is handed over between
+        // waves inside the visit.  Waves 4 .. 7 only work on the nodes with more than four outgoing
+        // messages (the interleaved last rows, six to eight each), whose visits would otherwise take
+        // two rounds on the critical path of the sweep's last serial stretch.
         const int j0 = wave;
         if (UPDATE && have_node) {
           const int *sti = (const int *)(st + kWStI);
@@ -308,7 +310,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
             }
             }
             WSTAMP(0);
-            for (int j = j0; working && j < nout; j += 4) {
+            for (int j = j0; working && j < nout; j += kWideCompute) {
               const double gamma = st[kWStG];  // (double)1 / (double)max(n_out, n_in)
               const double alpha = st[kWS + 8 * kWS + j];
               const bool constant = UNI(alpha == 0);
