@@ -22,22 +22,27 @@ namespace {
 
 // ---- wide-label pipelined sweep: 64 < K <= 256, shared strictly ascending positions -------
 // The regime of the large grids (3000x2000x256).  A lane holds four labels (k = c * 64 + lane).
-// Per message K^2 pair costs are too many, so
-//  * min-plus only looks at the sources inside the truncation window of each destination
-//    (a source farther than lambda costs >= vTrunc exactly, by monotone rounding);
-//  * the certificate's tangency test ("no two u = h - alpha q, nor two v = h + alpha q, within
-//    delta") is a closest-pair test by bucketing -- conservative (all pairs, not only those
-//    with a useful cone), O(K) instead of O(K^2).
-// Three compute waves per outgoing message, each forming Di and H = gamma Di - m itself (cheap,
-// and no barrier between them): wave 3j does the windowed min-plus, waves 3j+1 / 3j+2 the u / v
-// closest-pair tests and post their verdicts in LDS; wave 3j waits for the two verdicts,
-// normalises and hands over.  Loader / storer / primal waves as in trws_pipe_kernel (the loader is
-// split in two: data nobody else writes, and data behind completion flags, so that the two HBM
-// round trips of a visit overlap); one
-// hardware barrier per visit.  Nodes with more than four outgoing messages take a second round
-// (message j + 4 on the same waves).  If the certificate fails, wave 3j runs the reference's
-// serial envelope construction in LDS (one at a time per workgroup: shared scratch, rare).
+// One compute wave per outgoing message, one per SIMD for the four messages of an ordinary node
+// (waves 4 .. 7 serve the six to eight messages of the interleaved last rows): each forms
+// Di = S + incoming rows (S = D + the node's own previous-sweep rows, pre-summed by loader A in list
+// order) and H = gamma Di - m, then
+//  * with up to kWideSparse useful cones (h < vTrunc: five to eight of 256 on real volumes) looks at
+//    nothing else: per useful cone the cost every destination gets from it, the smallest and second
+//    smallest cost per destination, and the number of destinations whose own h lies on an arm of
+//    that cone (the certificate's tangency test for the pairs that matter);
+//  * with more (flat H) runs the dense windowed min-plus from a padded source table (a source farther
+//    than lambda costs >= vTrunc exactly, by monotone rounding) and a closest-pair test on all u and
+//    all v by bucketing -- conservative, O(K) -- refined on the useful cones if it finds a pair.
+// If the certificate fails the wave runs the reference's serial envelope construction in LDS (one at
+// a time per workgroup: shared scratch, rare).  Loader / storer / primal waves as in
+// trws_pipe_kernel; the loader is split in two -- data nobody else writes, and data behind
+// completion flags -- and both run two visits ahead with their requests parked in registers, so
+// that no HBM round trip lies inside a visit.  One hardware barrier per visit.
 // Kernel 1 (truncated linear) only; kernel 2 above K = 64 stays on the generic kernel.
+// (Round-3 history, DESIGN.md 4.7: three waves per message with separate closest-pair waves, then
+// three / two waves sharing the destinations of a message, were all slower than one wave per message:
+// a visit is bound by the instructions its SIMDs issue, and every split repeats Di, H and the
+// reductions.)
 constexpr int kWideCompute = 8;
 constexpr int kWideWaves = kWideCompute + 4;  // + loader (own data), loader (foreign data), storer, primal
 constexpr int kWideThreads = kWideWaves * kWave;
@@ -53,8 +58,8 @@ constexpr int kWStage = kWStS + kWS;  // ints: desc[64] px[8] row[8]
 // stage: D[kWS] m[8][kWS] a[8] | ints desc[64] px[8] row[8] (row: where Di's k-th message row lives in LDS, in doubles) | S[kWS]
 
 struct WidePtrs {
-  double *stage0, *hand, *scr, *fb, *pos, *scal, *msc;
-  int *dring, *flags, *hflag, *ctl;
+  double *stage0, *hand, *scr, *fb, *pos, *scal;
+  int *dring, *ctl;
 };
 __device__ __forceinline__ WidePtrs wide_carve(double *lds) {
   WidePtrs w;
@@ -64,14 +69,11 @@ __device__ __forceinline__ WidePtrs wide_carve(double *lds) {
   w.fb = w.scr + kWideCompute * kWScr;       // 4 * kWS : sources, stack, breakpoints of the serial construction
   w.pos = w.fb + 4 * kWS;                    // kWS
   w.scal = w.pos + kWS;                      // 2 * kScalDoubles
-  w.msc = w.scal + 2 * kScalDoubles;         // [8][2]: hmin, hmax of H_j for the closest-pair waves
-  w.dring = (int *)(w.msc + 16);             // 3 * 64 descriptor words (for the storer)
-  w.flags = w.dring + 3 * 64;                // [8][2] verdicts of the closest-pair waves
-  w.hflag = w.flags + 16;                    // [8] "H_j is in the min-plus wave's table" (visit token)
-  w.ctl = w.hflag + 8;                       // [0] run, [1] abort, [2] lock of the serial scratch
+  w.dring = (int *)(w.scal + 2 * kScalDoubles);  // 3 * 64 descriptor words (for the storer)
+  w.ctl = w.dring + 3 * 64;                  // [0] run, [1] abort, [2] lock of the serial scratch
   return w;
 }
-constexpr int kWideLdsDoubles = 2 * kWStage + 3 * 8 * kWS + kWideCompute * kWScr + 4 * kWS + kWS + 2 * kScalDoubles + 16 + 96 + 8 + 4 + 2;
+constexpr int kWideLdsDoubles = 2 * kWStage + 3 * 8 * kWS + kWideCompute * kWScr + 4 * kWS + kWS + 2 * kScalDoubles + 96 + 2;
 static_assert(kWideLdsDoubles * 8 <= 160 * 1024, "wide kernel LDS");
 
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
@@ -217,8 +219,6 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
   // bit for bit): the min-plus source table then holds h only and alpha |d step| is formed once per d
   const double ustep = p.uniform_step;
   const bool uniform = ustep != 0;
-  if (tid < 16) L.flags[tid] = -1;
-  if (tid < 8) L.hflag[tid] = -1;
   if (tid == 0) { L.ctl[1] = 0; L.ctl[2] = 0; }
 #define WPOS(c) (L.pos[(c) * kWave + lane])        // this lane's four label positions (+inf beyond K)
 #define WVALID(c) ((c) * kWave + lane < K)
