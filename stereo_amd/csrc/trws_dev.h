@@ -1260,8 +1260,8 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
 #undef RLI
 
 constexpr int kPipeCompute = 8;  // one compute wave per outgoing message (<= 8 per node)
-constexpr int kPipeWaves = kPipeCompute + 4;  // loader, storer, (idle), primal: the primal wave lands on SIMD 3,
-                                              // which otherwise hosts one compute wave only
+constexpr int kPipeWaves = kPipeCompute + 4;  // loader (data behind flags), storer, loader A (own data, two visits
+                                              // deep; trws_pipe_kernel only), primal
 constexpr int kPipeThreads = kPipeWaves * kWave;
 // LDS stage layout (doubles): D[64] m[8][64] qv[8][64] qpv[8][64] | a[8] gamma pad | ints: desc[64] px[8] row[8]
 constexpr int kStD = 0, kStM = 64, kStQ = 64 + 512, kStQP = 64 + 1024, kStA = 64 + 1536;

@@ -64,6 +64,39 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
     int xprev = 0, xprev2 = 0;  // primal wave: labels of the previous two nodes of the run
     int wnext = 0;              // loader: raw descriptor word of the node after next (prefetched)
     if (wave == kPipeCompute) wnext = desc[(size_t)p0 * DW + lane];
+    // loader A (own data, two visits deep): descriptors of the next three nodes and the parked requests
+    int wa1 = 0, wa2 = 0, wa3 = 0;
+    double rdk = 0, rmv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rqv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rqpv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rav = 0;
+#define PIPE_LOAD8(DST, PTR) DST = *(PTR)   /* plain loads: the compiler keeps them in flight across the barrier and waits at the first use */
+#define PIPE_REQUEST_OWN(W)                                                                          \
+    do {                                                                                             \
+      const NodeDesc rq = decode_desc(W);                                                            \
+      const int rtot = rq.nout + rq.nin;                                                             \
+      if (act) { const double *a_ = p.unary + (size_t)rq.node * K + lane; PIPE_LOAD8(rdk, a_); }     \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                \
+        if (j < rtot && act) {                                                                       \
+          const size_t off = (size_t)rq.e[j] * K + lane;                                             \
+          if (j < rq.nout && (UPDATE || PRIMAL)) { const double *a_ = p.msg + off; PIPE_LOAD8(rmv[j], a_); } \
+          if (!SHARED) {                                                                             \
+            const double *a_ = p.q + off, *b_ = p.qprim + off;                                       \
+            PIPE_LOAD8(rqv[j], a_); PIPE_LOAD8(rqpv[j], b_);                                         \
+          }                                                                                          \
+        }                                                                                            \
+      }                                                                                              \
+      rav = 0;                                                                                       \
+      if (lane < rtot) {                                                                             \
+        int ej = 0;                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                \
+          if (lane == j) ej = rq.e[j];                                                               \
+        rav = p.alpha[ej];                                                                           \
+      }                                                                                              \
+    } while (0)
+    if (wave == kPipeCompute + 2) {
+      wa1 = desc[(size_t)p0 * DW + lane];
+      if (p0 + 1 < p1) wa2 = desc[(size_t)(p0 + 1) * DW + lane];
+      if (p0 + 2 < p1) wa3 = desc[(size_t)(p0 + 2) * DW + lane];
+      PIPE_REQUEST_OWN(wa1);
+    }
     if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2] = wall_clock64();
     unsigned long long busy = 0;
 
@@ -146,28 +179,18 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
             if (lane < 8) stni[72 + lane] = row;
           }
           const int ntot = nx.nout + nx.nin;
-          // everything that does not depend on other workgroups is requested first ...
-          double dk = 0, mv[8], qv[8], qpv[8];
-          if (act) dk = p.unary[(size_t)nx.node * K + lane];
+          // (everything that does not depend on other workgroups -- unary, previous-sweep messages,
+          //  positions, weights -- is loader A's, below, two visits ahead)
+          double mv[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            mv[j] = 0; qv[j] = 0; qpv[j] = 0;
-            if (j < ntot && act) {
-              const size_t off = (size_t)nx.e[j] * K + lane;
-              if (j < nx.nout && (UPDATE || PRIMAL)) mv[j] = p.msg[off];
-              if (!SHARED) { qv[j] = p.q[off]; qpv[j] = p.qprim[off]; }
-            }
-          }
-          double av = 0;
+          for (int j = 0; j < 8; ++j) mv[j] = 0;
           int pxv = 0, xn = 0, sl = 0;
           if (lane < ntot) {
-            int ej = 0;  // lane j fetches the scalars of edge j
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-              if (lane == j) { ej = nx.e[j]; xn = nx.xn[j]; sl = nx.slot[j]; }
-            av = p.alpha[ej];
+              if (lane == j) { xn = nx.xn[j]; sl = nx.slot[j]; }
           }
-          // ... then the completion flags of the foreign neighbours, then their data
+          // the completion flags of the foreign neighbours, then their data
           // (all flags are polled together: lane j watches dependency j)
           if (nx.ndep > 0) {
             int myrank = nx.dep[0];
@@ -195,16 +218,35 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
             if (UPDATE && j >= nx.nout && j < ntot && nx.slot[j] < 0 && act)
               mv[j] = ld_sc1(p.msg + (size_t)nx.e[j] * K + lane);
           if (PRIMAL && lane < ntot && lane >= nx.nout && sl < 0) pxv = ld_sc1(p.x + xn);
-          if (act) stn[kStD + lane] = dk;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j >= nx.nout && j < ntot && act) stn[kStM + j * kWave + lane] = mv[j];
+          if (lane < 8) stni[64 + lane] = pxv;
+        }
+      } else if (wave == kPipeCompute + 2) {
+        // ------------------------------------------------------------ loader A: own data of node pos + 1
+        // The registers hold what was requested during visit pos - 1 (its HBM latency lies behind a
+        // whole visit, not inside one -- on the serial chains of the reference's node order the visit
+        // was as long as this loader's round trip); it goes to the stage, then node pos + 2's requests
+        // go out and stay in flight across the barrier (plain loads: the compiler waits at their first use,
+        // which is in the next visit).
+        if (pos + 1 >= p0 && pos + 1 < p1) {
+          const NodeDesc nx = decode_desc(wa1);
+          const int ntot = nx.nout + nx.nin;
+          if (act) stn[kStD + lane] = rdk;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             if (j < ntot && act) {
-              stn[kStM + j * kWave + lane] = mv[j];
-              if (!SHARED) { stn[kStQ + j * kWave + lane] = qv[j]; stn[kStQP + j * kWave + lane] = qpv[j]; }
+              if (j < nx.nout) stn[kStM + j * kWave + lane] = rmv[j];
+              if (!SHARED) { stn[kStQ + j * kWave + lane] = rqv[j]; stn[kStQP + j * kWave + lane] = rqpv[j]; }
             }
           }
-          if (lane < 8) { stn[kStA + lane] = av; stni[64 + lane] = pxv; }
+          if (lane < 8) stn[kStA + lane] = rav;
           if (lane == 0) stn[kStG] = (double)1 / (double)(nx.nout > nx.nin ? nx.nout : nx.nin);
+          int wa4 = 0;
+          if (pos + 4 < p1) wa4 = desc[(size_t)(pos + 4) * DW + lane];  // three nodes ahead: waited for at the top of the next visit
+          wa1 = wa2; wa2 = wa3; wa3 = wa4;
+          if (pos + 2 < p1) PIPE_REQUEST_OWN(wa1);
         }
       } else if (wave == kPipeCompute + 1) {
         // ------------------------------------------------------------ storer: node pos - 1
@@ -296,6 +338,9 @@ template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
 __global__ __launch_bounds__(kPipeThreads) void trws_pipe_group_kernel(GroupArgs ga, int epoch) {
   pipe_body<KERNEL, BACKWARD, PRIMAL, UPDATE, SHARED>(ga.pp[group_strip(ga)], epoch);
 }
+
+#undef PIPE_REQUEST_OWN
+#undef PIPE_LOAD8
 
 }  // namespace
 
