@@ -529,9 +529,8 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
       // During visit pos the registers hold node pos + 1's unary, previous-sweep messages and weight,
       // requested during visit pos - 1: the HBM latency of one node lies behind the whole visit of
       // the node before it instead of inside its own.  They go to the stage, then node pos + 2's
-      // requests go out and stay in flight across the barrier.  The loads are issued by hand (16 bytes
-      // per lane: labels 2 lane, 2 lane + 1 of each half row; K is even here) so that the order
-      // "store the old set, then request the new one into the same registers" is the one executed.
+      // requests go out and stay in flight across the barrier (16 bytes per lane: labels 2 lane, 2 lane + 1
+      // of each half row; K is even here).
       typedef int wide_v4i __attribute__((ext_vector_type(4)));
       const wide_v4i zero4 = {0, 0, 0, 0};
       wide_v4i rd0 = zero4, rd1 = zero4, rm[8][2];
@@ -544,7 +543,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
       int w1 = desc[(size_t)p0 * DW + lane];                                  // the node in the registers
       int w2 = p0 + 1 < p1 ? desc[(size_t)(p0 + 1) * DW + lane] : 0;          // the one after it
       int w3 = p0 + 2 < p1 ? desc[(size_t)(p0 + 2) * DW + lane] : 0;
-#define WIDE_LOAD16(DST, PTR, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(DST) : "v"(PTR) : "memory")
+#define WIDE_LOAD16(DST, PTR, OFF) DST = *(const wide_v4i *)((const char *)(PTR) + (OFF))  /* plain loads: in flight across the barrier, waited for at their first use */
 #define WIDE_REQUEST_OWN(W)                                                                               \
       do {                                                                                                \
         const NodeDesc rq = decode_desc(W);                                                               \
@@ -589,12 +588,6 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
             if (lane < 8) stni[72 + lane] = row;
           }
           L.dring[((pos + 1) % 3) * 64 + lane] = w;
-          // everything requested during the last visit has arrived once this returns
-          asm volatile("s_waitcnt vmcnt(0)"
-                       : "+v"(rd0), "+v"(rd1), "+v"(rm[0][0]), "+v"(rm[0][1]), "+v"(rm[1][0]), "+v"(rm[1][1]), "+v"(rm[2][0]),
-                         "+v"(rm[2][1]), "+v"(rm[3][0]), "+v"(rm[3][1]), "+v"(rm[4][0]), "+v"(rm[4][1]), "+v"(rm[5][0]),
-                         "+v"(rm[5][1]), "+v"(rm[6][0]), "+v"(rm[6][1]), "+v"(rm[7][0]), "+v"(rm[7][1])
-                       :: "memory");
           if (ok0) *(wide_v4i *)(stn + 2 * lane) = rd0;
           if (ok1) *(wide_v4i *)(stn + 2 * kWave + 2 * lane) = rd1;
           // S = D + rows 0 .. nout - 1, added in list order: the prefix of Di that is known a visit ahead
@@ -616,7 +609,6 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           int w4 = 0;
           if (pos + 4 < p1) w4 = desc[(size_t)(pos + 4) * DW + lane];
           w1 = w2; w2 = w3; w3 = w4;
-          asm volatile("" ::: "memory");
           if (pos + 2 < p1) WIDE_REQUEST_OWN(w1);
         }
       WIDE_VISITS_END
@@ -699,6 +691,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
       // workgroup has not yet made visible; elsewhere (the interleaved last rows) the node is fetched
       // during the visit before its own, as loader B always did.
       typedef int wide_v4i __attribute__((ext_vector_type(4)));
+      typedef double wide_v2d __attribute__((ext_vector_type(2)));
       const wide_v4i zero4 = {0, 0, 0, 0};
       wide_v4i rb[8][2];
 #pragma unroll
@@ -709,7 +702,13 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
       int w1 = desc[(size_t)p0 * DW + lane];
       int w2 = p0 + 1 < p1 ? desc[(size_t)(p0 + 1) * DW + lane] : 0;
       int w3 = p0 + 2 < p1 ? desc[(size_t)(p0 + 2) * DW + lane] : 0;  // three nodes ahead, as in loader A
-#define WIDE_LOAD16_SC1(DST, PTR, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF " sc0 sc1" : "=v"(DST) : "v"(PTR) : "memory")
+#define WIDE_LOAD16_SC1(DST, PTR, OFF)                                                                     \
+      do {                                                                                                \
+        const double lo_ = ld_sc1((const double *)((const char *)(PTR) + (OFF)));                         \
+        const double hi_ = ld_sc1((const double *)((const char *)(PTR) + (OFF)) + 1);                     \
+        wide_v2d pr_; pr_.x = lo_; pr_.y = hi_;                                                           \
+        DST = __builtin_bit_cast(wide_v4i, pr_);                                                          \
+      } while (0)
 #define WIDE_REQUEST_FOREIGN(W)                                                                           \
       do {                                                                                                \
         const NodeDesc rq = decode_desc(W);                                                               \
@@ -756,12 +755,6 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           const NodeDesc nx = decode_desc(w1);
           int *stni = (int *)(stn + kWStI);
           const int ntot = nx.nout + nx.nin;
-          // everything requested (during the last visit, or just now) has arrived once this returns
-          asm volatile("s_waitcnt vmcnt(0)"
-                       : "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[2][0]), "+v"(rb[2][1]), "+v"(rb[3][0]),
-                         "+v"(rb[3][1]), "+v"(rb[4][0]), "+v"(rb[4][1]), "+v"(rb[5][0]), "+v"(rb[5][1]), "+v"(rb[6][0]),
-                         "+v"(rb[6][1]), "+v"(rb[7][0]), "+v"(rb[7][1])
-                       :: "memory");
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             if (UPDATE && j >= nx.nout && j < ntot && nx.slot[j] < 0) {
@@ -773,7 +766,6 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           int w4 = 0;
           if (pos + 4 < p1) w4 = desc[(size_t)(pos + 4) * DW + lane];
           w1 = w2; w2 = w3; w3 = w4;
-          asm volatile("" ::: "memory");
           parked = pos + 2 < p1 && ((__builtin_amdgcn_readlane(w1, 2) >> 12) & 1) != 0;
           if (parked) WIDE_REQUEST_FOREIGN(w1);
         }
