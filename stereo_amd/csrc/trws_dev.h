@@ -1137,6 +1137,9 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
     const bool near = (fabs(ui - HJ##u) <= delta) || (fabs(vi - HJ##v) <= delta);    \
     bad = bad || (near && qsrc != QJ);                                               \
   }
+#ifdef STEREO_HIP_MESSAGE_PROFILE
+      if (p.prof && lane == 0) { const int nu_ = __builtin_popcountll(mask); atomicAdd(p.prof + 56 + (nu_ > 32 ? 3 : nu_ > 16 ? 2 : nu_ > 8 ? 1 : 0), 1ull); }
+#endif
       if (window >= 0 && __builtin_popcountll(mask) > 32) {
         // Flat h (the zig-zag rows: gamma = 1/6 .. 1/8 makes almost every source useful) on shared
         // strictly ascending positions.  The pair loop below would be K^2; instead

@@ -99,9 +99,18 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
     }
     if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2] = wall_clock64();
     unsigned long long busy = 0;
+#ifdef STEREO_HIP_VISIT_PROFILE
+    unsigned long long vacc[6] = {0, 0, 0, 0, 0, 0};
+#define VSTAMP(i) do { const long long n_ = (long long)__builtin_readcyclecounter(); vacc[i] += (unsigned long long)(n_ - vmark); vmark = n_; } while (0)
+#else
+#define VSTAMP(i) do { } while (0)
+#endif
 
     for (int pos = p0 - 1; pos <= p1; ++pos) {
       const long long tstart = p.prof ? (long long)__builtin_readcyclecounter() : 0;
+#ifdef STEREO_HIP_VISIT_PROFILE
+      long long vmark = (long long)__builtin_readcyclecounter();
+#endif
       double *st = stage0 + (pos & 1) * kStageDoubles;          // node `pos`
       double *stn = stage0 + ((pos + 1) & 1) * kStageDoubles;   // node `pos + 1`
       double *hcur = hand + (pos & 3) * 8 * kWave, *hprev = hand + ((pos - 1) & 3) * 8 * kWave;
@@ -115,6 +124,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           const int f = __builtin_amdgcn_readfirstlane(sti[2]);
           const int nout = f & 15, nin = (f >> 4) & 15, md = (f >> 16) & 255, ntot = nout + nin;
           const int myrow = sti[72 + (lane & 7)];  // LDS offsets (doubles) of the node's message rows, from the loader
+          VSTAMP(0);
           if (wave < nout || (BACKWARD && wave == 0)) {  // waves without a message stay out of the way
           double Di = act ? st[kStD + lane] : 0.0;
           // (this wave's own old message is one of the rows; it is read once more below rather than
@@ -130,6 +140,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
             Di -= node_vmin;
             if (tid == 0) sc[8] = node_vmin;
           }
+          VSTAMP(1);
           {
             const int j = wave;  // one compute wave per outgoing message
             if (j < nout) {
@@ -147,9 +158,11 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
                 perm = (src_is_qprim ? p.perm_qp : p.perm_q) + (size_t)e * K;
               }
               const double alpha = st[kStA + j];
+              VSTAMP(2);
               double newm = 0;
               const double v = message_regs<KERNEL>(p, K, alpha, h, qsrc, qdst, perm, newm, lane,
                                                     hqtab + wave * kPipeTab + 4 * kPipePad, (SHARED && p.win_ok) ? p.window : -1, &look_streak);
+              VSTAMP(3);
               if (act) hcur[j * kWave + lane] = newm;
               if (BACKWARD && lane == 0) sc[j] = v;
             }
@@ -316,7 +329,9 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
         }
       }
       if (p.prof) busy += (unsigned long long)((long long)__builtin_readcyclecounter() - tstart);
+      VSTAMP(4);
       __syncthreads();
+      VSTAMP(5);
       if (ctl[1]) return;  // a dependency wait gave up (bounded spin); host reports it
     }
     if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2 + 1] = wall_clock64();
@@ -324,6 +339,10 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
       // busy cycles before the barrier per role: compute (wave 0), loader, storer, primal; steps
       const int slot = wave == 0 ? 0 : wave == kPipeCompute ? 1 : wave == kPipeCompute + 1 ? 2 : wave == kPipeCompute + 3 ? 3 : -1;
       if (slot >= 0) atomicAdd(p.prof + slot, busy);
+      atomicAdd(p.prof + 32 + wave, busy);  // every wave: cycles from barrier to barrier arrival
+#ifdef STEREO_HIP_VISIT_PROFILE
+      if (wave == 0) for (int i = 0; i < 6; ++i) atomicAdd(p.prof + 48 + i, vacc[i]);
+#endif
       if (wave == 0) atomicAdd(p.prof + 6, (unsigned long long)(p1 - p0));
     }
   }
@@ -341,6 +360,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_group_kernel(GroupArgs
 
 #undef PIPE_REQUEST_OWN
 #undef PIPE_LOAD8
+#undef VSTAMP
 
 }  // namespace
 

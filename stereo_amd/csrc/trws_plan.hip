@@ -734,6 +734,17 @@ void stereo_trws_plan_destroy(stereo_trws_plan *plan) {
       if (!plan->wide)
         std::fprintf(stderr, "[stereo_hip prof] cycles: p0 %llu p1 %llu p2 %llu p3 %llu p4 %llu | p5 %llu steps %llu\n",
                      v[0], v[1], v[2], v[3], v[4], v[5], v[6]);
+      if (!plan->wide && v[6]) {
+        std::fprintf(stderr, "[stereo_hip prof] cycles from barrier to barrier arrival per visit, per wave:");
+        for (int i = 0; i < 12; ++i) std::fprintf(stderr, " %.0f", (double)v[32 + i] / v[6]);
+        std::fprintf(stderr, "\n");
+        if (v[48] | v[49] | v[50])  // -DSTEREO_HIP_VISIT_PROFILE
+          std::fprintf(stderr, "[stereo_hip prof] wave 0 per visit: stage words %.0f | Di %.0f | H, positions %.0f | message %.0f | "
+                               "hand-over %.0f | barrier %.0f\n", (double)v[48] / v[6], (double)v[49] / v[6], (double)v[50] / v[6],
+                       (double)v[51] / v[6], (double)v[52] / v[6], (double)v[53] / v[6]);
+      }
+      if (!plan->wide && (v[56] | v[57] | v[58] | v[59]))
+        std::fprintf(stderr, "[stereo_hip prof messages] useful sources per message: <= 8: %llu, <= 16: %llu, <= 32: %llu, more (flat path): %llu\n", v[56], v[57], v[58], v[59]);
       if (!plan->wide && v[9])
         std::fprintf(stderr, "[stereo_hip prof messages] certified attempt %.0f cycles x %llu | second look %.0f x %llu | "
                              "serial construction %.0f x %llu | walk %.0f x %llu\n",
