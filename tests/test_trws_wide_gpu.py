@@ -77,6 +77,30 @@ def test_wide_kernel_matches_oracle(case, hip, oracle):
         assert plan.serial_messages() < 0.2 * total
 
 
+@pytest.mark.parametrize("pk,K,scale", [("grid", 256, 0.02), ("irregular", 200, 0.05), ("grid", 130, 0.01)],
+                         ids=["grid256", "irregular200", "grid130"])
+def test_wide_kernel_flat_costs_take_the_dense_path(pk, K, scale, hip, oracle):
+    """Unaries with a spread far below alpha * lambda: almost every cone of a message is useful
+    (h < vTrunc), so the kernel leaves its useful-cone loop (at most 32 of them) for the dense
+    windowed min-plus + closest-pair test -- same bits as the oracle, and still certified (no
+    wholesale fall-back to the serial construction)."""
+    from stereo_amd.trws import TrwsPlan
+    H, W, tol, maxiter = 7, 8, 8.0, 3
+    p = trws_problem(71, H, W, K, kind="fronto")
+    unary = np.ascontiguousarray(p["unary"] * scale)
+    pos = _positions(pk, K, np.random.default_rng(1071))
+    E = p["conn"].shape[0]
+    q = np.tile(pos, (E, 1))
+    lab_o, en_o, lb_o, it_o = oracle.trws(1, unary, p["conn"], q, q, p["alphas"], tol, maxiter, -1e300, mode=1)
+    plan = TrwsPlan(1, K, H * W, p["conn"].T)
+    plan.upload(unary.T, p["alphas"], tol, positions=pos)
+    assert plan.path() == 3
+    plan.iterate(maxiter, max_relgap=-1e300)
+    lab, en, lb, it = plan.result()
+    assert it == it_o and np.array_equal(lab, lab_o) and en == en_o and lb == lb_o
+    assert plan.serial_messages() < 0.2 * (2 * E * maxiter + E)
+
+
 def test_wide_kernel_needs_ascending_positions(hip, oracle):
     """Descending or repeated positions cannot use the windowed wide kernel: they run on the
     two-labels-per-lane pipelined kernel (K <= 128), same results."""
