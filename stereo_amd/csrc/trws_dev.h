@@ -927,6 +927,32 @@ __device__ __forceinline__ bool wait_flag(const DevParams &p, int rank, int epoc
   return true;
 }
 
+// The loaders' wait for a node's foreign dependencies: lane j watches the completion flag of
+// dependency j (all flags polled together), bounded by the wall clock (keep_waiting); a wait that
+// gives up reports what it waited for and raises the workgroup's abort word.
+__device__ __forceinline__ void wait_for_dependencies(const DevParams &p, const NodeDesc &nx, int epoch, int lane,
+                                                      int *abort_word) {
+  if (nx.ndep <= 0) return;
+  int myrank = nx.dep[0];
+#pragma unroll
+  for (int j = 1; j < 4; ++j)
+    if (lane == j) myrank = nx.dep[j];
+  const bool watching = lane < nx.ndep;
+  int spins = 0;
+  long long t0 = 0;
+  for (;;) {
+    const int v = watching ? ld_sc1(p.done + myrank) : epoch;
+    if (!UNI(v < epoch)) return;
+    const unsigned long long late = __builtin_amdgcn_ballot_w64(v < epoch),
+                             late_halo = __builtin_amdgcn_ballot_w64(v < epoch && myrank >= p.n_own);
+    if (!keep_waiting(p, spins, t0, late_halo != 0)) {   // wall-clock bound, or somebody else gave up
+      if (lane == __builtin_ctzll(late_halo ? late_halo : late)) report_give_up(p, nx.rank, myrank, v, epoch);
+      if (lane == 0) *abort_word = 1;
+      return;
+    }
+  }
+}
+
 // ---- lane exchange lane ^ S without an address register where the hardware offers one
 template <int S>
 __device__ __forceinline__ unsigned xor_lane_u32(unsigned v) {

@@ -278,27 +278,7 @@ __device__ __forceinline__ void pipe2_body(DevParams p, int epoch) {
               if (lane == j) { ej = nx.e[j]; xn = nx.xn[j]; sl = nx.slot[j]; }
             av = p.alpha[ej];
           }
-          if (nx.ndep > 0) {
-            int myrank = nx.dep[0];
-#pragma unroll
-            for (int j = 1; j < 4; ++j)
-              if (lane == j) myrank = nx.dep[j];
-            const bool watching = lane < nx.ndep;
-            int spins = 0;
-            long long t0 = 0;
-            bool ok = true;
-            for (;;) {
-              const int v = watching ? ld_sc1(p.done + myrank) : epoch;
-              if (!UNI(v < epoch)) break;
-              const unsigned long long late = __builtin_amdgcn_ballot_w64(v < epoch), late_halo = __builtin_amdgcn_ballot_w64(v < epoch && myrank >= p.n_own);
-              if (!keep_waiting(p, spins, t0, late_halo != 0)) {   // wall-clock bound, or somebody else gave up
-                if (lane == __builtin_ctzll(late_halo ? late_halo : late)) report_give_up(p, nx.rank, myrank, v, epoch);
-                ok = false;
-                break;
-              }
-            }
-            if (!ok && lane == 0) ctl[1] = 1;
-          }
+          wait_for_dependencies(p, nx, epoch, lane, ctl + 1);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             if (UPDATE && j >= nx.nout && j < ntot && nx.slot[j] < 0) {
