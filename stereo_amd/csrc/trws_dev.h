@@ -1098,9 +1098,18 @@ template <int KERNEL>
 __device__ __forceinline__ double message_regs(const DevParams &p, int K, double alpha, double h,
                                                double qsrc, double t, const uint16_t *perm,
                                                double &outmsg, int lane, double *hq = nullptr,
-                                               int window = -1, int *look_streak = nullptr) {
+                                               int window = -1, int *look_streak = nullptr,
+                                               unsigned long long *vprof = nullptr) {
   const double inf = __builtin_huge_val();
   const bool act = lane < K;
+#ifdef STEREO_HIP_VISIT_PROFILE
+  // phases of a message for the visit profile (cheap stamps, no atomics): [0] reduction + table,
+  // [1] pair loop / flat path, [2] margins + second look, [3] serial construction + walk, [4] minimum
+  long long vm_ = (long long)__builtin_readcyclecounter();
+#define VMSTAMP(i) do { if (vprof) { const long long n_ = (long long)__builtin_readcyclecounter(); vprof[i] += (unsigned long long)(n_ - vm_); vm_ = n_; } } while (0)
+#else
+#define VMSTAMP(i) do { } while (0)
+#endif
   // hmin and the magnitude behind delta in one interleaved reduction
   const double aq = alpha * qsrc;
   double hmin = h, mag = act ? fabs(h) + fabs(aq) + alpha * fabs(t) : 0.0;  // inactive lanes hold h = +inf
@@ -1146,6 +1155,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
+      VMSTAMP(0);
 #define STEREO_SRC(J, HJ, QJ)                                                        \
   double HJ, QJ, HJ##u, HJ##v;                                                       \
   if (hq) { HJ = hq[4 * (J)]; QJ = hq[4 * (J) + 1]; HJ##u = hq[4 * (J) + 2]; HJ##v = hq[4 * (J) + 3]; } \
@@ -1221,6 +1231,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
       }
 #undef STEREO_SRC
 #undef STEREO_ACC
+      VMSTAMP(1);
       bad = bad || (m1 < vtrunc && !(m2 - m1 > delta && vtrunc - m1 > delta));
       need_serial = UNI(act && bad);
       MSTAMP(8);
@@ -1258,6 +1269,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
       out = m1 < vtrunc ? m1 : vtrunc;
       if (need_serial && lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
     }
+    VMSTAMP(2);
     if (need_serial) {
       const int idx = act ? perm[lane] : lane;
       const double hs = __shfl(h, idx, kWave), qs = __shfl(qsrc, idx, kWave);
@@ -1274,6 +1286,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
       out = envelope_value<KERNEL>(p, alpha, t, vtrunc, sh, sq, zz, maxtop, lane, hq);
       MSTAMP(14);
     }
+    VMSTAMP(3);
 #undef MSTAMP
     // Smallest entry of the message.  With the same positions on both sides (lane k: source k and
     // destination k) a certified linear message has its minimum at min H exactly: destination t sees
@@ -1282,6 +1295,8 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
     if (KERNEL == 1 && p.certificate && !need_serial && !UNI(act && qsrc != t)) vmin = hmin;
     else vmin = wave_min_dpp(act ? out : inf);
   }
+  VMSTAMP(4);
+#undef VMSTAMP
   outmsg = out - vmin;
   return vmin;
 }

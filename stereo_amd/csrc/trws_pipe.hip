@@ -100,7 +100,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
     if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2] = wall_clock64();
     unsigned long long busy = 0;
 #ifdef STEREO_HIP_VISIT_PROFILE
-    unsigned long long vacc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long vacc[6] = {0, 0, 0, 0, 0, 0}, macc[5] = {0, 0, 0, 0, 0};
 #define VSTAMP(i) do { const long long n_ = (long long)__builtin_readcyclecounter(); vacc[i] += (unsigned long long)(n_ - vmark); vmark = n_; } while (0)
 #else
 #define VSTAMP(i) do { } while (0)
@@ -161,7 +161,11 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
               VSTAMP(2);
               double newm = 0;
               const double v = message_regs<KERNEL>(p, K, alpha, h, qsrc, qdst, perm, newm, lane,
-                                                    hqtab + wave * kPipeTab + 4 * kPipePad, (SHARED && p.win_ok) ? p.window : -1, &look_streak);
+                                                    hqtab + wave * kPipeTab + 4 * kPipePad, (SHARED && p.win_ok) ? p.window : -1, &look_streak
+#ifdef STEREO_HIP_VISIT_PROFILE
+                                                    , wave == 0 ? macc : nullptr
+#endif
+                                                    );
               VSTAMP(3);
               if (act) hcur[j * kWave + lane] = newm;
               if (BACKWARD && lane == 0) sc[j] = v;
@@ -322,6 +326,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
       atomicAdd(p.prof + 32 + wave, busy);  // every wave: cycles from barrier to barrier arrival
 #ifdef STEREO_HIP_VISIT_PROFILE
       if (wave == 0) for (int i = 0; i < 6; ++i) atomicAdd(p.prof + 48 + i, vacc[i]);
+      if (wave == 0) for (int i = 0; i < 5; ++i) atomicAdd(p.prof + 56 + i, macc[i]);
 #endif
       if (wave == 0) atomicAdd(p.prof + 6, (unsigned long long)(p1 - p0));
     }

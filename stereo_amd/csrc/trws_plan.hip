@@ -742,8 +742,12 @@ void stereo_trws_plan_destroy(stereo_trws_plan *plan) {
           std::fprintf(stderr, "[stereo_hip prof] wave 0 per visit: stage words %.0f | Di %.0f | H, positions %.0f | message %.0f | "
                                "hand-over %.0f | barrier %.0f\n", (double)v[48] / v[6], (double)v[49] / v[6], (double)v[50] / v[6],
                        (double)v[51] / v[6], (double)v[52] / v[6], (double)v[53] / v[6]);
+        if (v[48] | v[49] | v[50])
+          std::fprintf(stderr, "[stereo_hip prof] of the message: reduction + table %.0f | pair loop / flat path %.0f | margins + second look "
+                               "%.0f | serial construction + walk %.0f | minimum %.0f\n", (double)v[56] / v[6], (double)v[57] / v[6],
+                       (double)v[58] / v[6], (double)v[59] / v[6], (double)v[60] / v[6]);
       }
-      if (!plan->wide && (v[56] | v[57] | v[58] | v[59]))
+      if (!plan->wide && (v[56] | v[57] | v[58] | v[59]) && !(v[48] | v[49] | v[50]))
         std::fprintf(stderr, "[stereo_hip prof messages] useful sources per message: <= 8: %llu, <= 16: %llu, <= 32: %llu, more (flat path): %llu\n", v[56], v[57], v[58], v[59]);
       if (!plan->wide && v[9])
         std::fprintf(stderr, "[stereo_hip prof messages] certified attempt %.0f cycles x %llu | second look %.0f x %llu | "
