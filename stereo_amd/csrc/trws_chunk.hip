@@ -334,7 +334,7 @@ __device__ __forceinline__ void chunk_body(DevParams p, int epoch) {
             for (int j = 0; j < 8; ++j)
               if (lane == j) { xn = nx.xn[j]; sl = nx.slot[j]; }
           }
-          wait_for_dependencies(p, nx, epoch, lane, L.ctl + 1);
+          wait_for_dependencies(p, nx.ndep, nx.dep[0], nx.dep[1], nx.dep[2], nx.dep[3], nx.rank, epoch, lane, L.ctl + 1);
           double mv[8][4];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {

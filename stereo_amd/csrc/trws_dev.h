@@ -930,14 +930,12 @@ __device__ __forceinline__ bool wait_flag(const DevParams &p, int rank, int epoc
 // The loaders' wait for a node's foreign dependencies: lane j watches the completion flag of
 // dependency j (all flags polled together), bounded by the wall clock (keep_waiting); a wait that
 // gives up reports what it waited for and raises the workgroup's abort word.
-__device__ __forceinline__ void wait_for_dependencies(const DevParams &p, const NodeDesc &nx, int epoch, int lane,
-                                                      int *abort_word) {
-  if (nx.ndep <= 0) return;
-  int myrank = nx.dep[0];
-#pragma unroll
-  for (int j = 1; j < 4; ++j)
-    if (lane == j) myrank = nx.dep[j];
-  const bool watching = lane < nx.ndep;
+// (the descriptor's fields by value: a NodeDesc passed by reference is materialised in scratch memory)
+__device__ __forceinline__ void wait_for_dependencies(const DevParams &p, int ndep, int dep0, int dep1, int dep2, int dep3,
+                                                      int visiting_rank, int epoch, int lane, int *abort_word) {
+  if (ndep <= 0) return;
+  const int myrank = lane == 1 ? dep1 : lane == 2 ? dep2 : lane == 3 ? dep3 : dep0;
+  const bool watching = lane < ndep;
   int spins = 0;
   long long t0 = 0;
   for (;;) {
@@ -946,7 +944,7 @@ __device__ __forceinline__ void wait_for_dependencies(const DevParams &p, const 
     const unsigned long long late = __builtin_amdgcn_ballot_w64(v < epoch),
                              late_halo = __builtin_amdgcn_ballot_w64(v < epoch && myrank >= p.n_own);
     if (!keep_waiting(p, spins, t0, late_halo != 0)) {   // wall-clock bound, or somebody else gave up
-      if (lane == __builtin_ctzll(late_halo ? late_halo : late)) report_give_up(p, nx.rank, myrank, v, epoch);
+      if (lane == __builtin_ctzll(late_halo ? late_halo : late)) report_give_up(p, visiting_rank, myrank, v, epoch);
       if (lane == 0) *abort_word = 1;
       return;
     }

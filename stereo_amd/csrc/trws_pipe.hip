@@ -209,7 +209,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           }
           // the completion flags of the foreign neighbours, then their data
           // (all flags are polled together: lane j watches dependency j)
-          wait_for_dependencies(p, nx, epoch, lane, ctl + 1);
+          wait_for_dependencies(p, nx.ndep, nx.dep[0], nx.dep[1], nx.dep[2], nx.dep[3], nx.rank, epoch, lane, ctl + 1);
 #pragma unroll
           for (int j = 0; j < 8; ++j)
             if (UPDATE && j >= nx.nout && j < ntot && nx.slot[j] < 0 && act)

@@ -65,7 +65,9 @@ __device__ __forceinline__ void pipe2_body(DevParams p, int epoch) {
     if (wave == kPipeCompute) wnext = desc[(size_t)p0 * DW + lane];
     if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2] = wall_clock64();
 
+    unsigned long long busy = 0;  // development profile (STEREO_HIP_TRWS_PROF): cycles from barrier to barrier arrival
     for (int pos = p0 - 1; pos <= p1; ++pos) {
+      const long long tstart = p.prof ? (long long)__builtin_readcyclecounter() : 0;
       double *st = stage0 + (pos & 1) * k2Stage;
       double *stn = stage0 + ((pos + 1) & 1) * k2Stage;
       double *hcur = hand + (pos & 3) * 8 * k2W, *hprev = hand + ((pos - 1) & 3) * 8 * k2W;
@@ -278,7 +280,7 @@ __device__ __forceinline__ void pipe2_body(DevParams p, int epoch) {
               if (lane == j) { ej = nx.e[j]; xn = nx.xn[j]; sl = nx.slot[j]; }
             av = p.alpha[ej];
           }
-          wait_for_dependencies(p, nx, epoch, lane, ctl + 1);
+          wait_for_dependencies(p, nx.ndep, nx.dep[0], nx.dep[1], nx.dep[2], nx.dep[3], nx.rank, epoch, lane, ctl + 1);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             if (UPDATE && j >= nx.nout && j < ntot && nx.slot[j] < 0) {
@@ -387,6 +389,7 @@ __device__ __forceinline__ void pipe2_body(DevParams p, int epoch) {
           if (lane == 0) { sc[9] = eb; ((int *)(sc + 10))[0] = bi; }
         }
       }
+      if (p.prof) busy += (unsigned long long)((long long)__builtin_readcyclecounter() - tstart);
       __syncthreads();
       if (ctl[1]) {
         if (tid == 0) st_sc1(p.abort_flag, 1);
@@ -394,6 +397,10 @@ __device__ __forceinline__ void pipe2_body(DevParams p, int epoch) {
       }
     }
     if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2 + 1] = wall_clock64();
+    if (p.prof && lane == 0 && (p.prof_run < 0 || run == p.prof_run)) {
+      atomicAdd(p.prof + 32 + wave, busy);
+      if (wave == 0) atomicAdd(p.prof + 6, (unsigned long long)(p1 - p0));
+    }
   }
 }
 

@@ -718,7 +718,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                   \
             if (lane == j) { xn = rq.xn[j]; sl = rq.slot[j]; }                                            \
         }                                                                                                 \
-        wait_for_dependencies(p, rq, epoch, lane, L.ctl + 1);                                             \
+        wait_for_dependencies(p, rq.ndep, rq.dep[0], rq.dep[1], rq.dep[2], rq.dep[3], rq.rank, epoch, lane, L.ctl + 1);                                             \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
           if (UPDATE && j >= rq.nout && j < rtot && rq.slot[j] < 0) {                                     \
             const double *mb = p.msg + (size_t)rq.e[j] * K + 2 * lane;                                    \
@@ -769,7 +769,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
             for (int j = 0; j < 8; ++j)
               if (lane == j) { xn = nx.xn[j]; sl = nx.slot[j]; }
           }
-          wait_for_dependencies(p, nx, epoch, lane, L.ctl + 1);
+          wait_for_dependencies(p, nx.ndep, nx.dep[0], nx.dep[1], nx.dep[2], nx.dep[3], nx.rank, epoch, lane, L.ctl + 1);
           double mv[8][4];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
