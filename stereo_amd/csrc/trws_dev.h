@@ -940,7 +940,7 @@ __device__ __forceinline__ void wait_for_dependencies(const DevParams &p, int nd
   long long t0 = 0;
   for (;;) {
     const int v = watching ? ld_sc1(p.done + myrank) : epoch;
-    if (!UNI(v < epoch)) return;
+    if (!UNI(v < epoch)) break;
     const unsigned long long late = __builtin_amdgcn_ballot_w64(v < epoch),
                              late_halo = __builtin_amdgcn_ballot_w64(v < epoch && myrank >= p.n_own);
     if (!keep_waiting(p, spins, t0, late_halo != 0)) {   // wall-clock bound, or somebody else gave up
@@ -949,6 +949,12 @@ __device__ __forceinline__ void wait_for_dependencies(const DevParams &p, int nd
       return;
     }
   }
+  // The flags are up: what the caller reads next (the neighbours' messages and labels, sc1 loads that
+  // go to memory) must not be moved in front of the flag loads by the compiler.  The hardware issues a
+  // wave's loads in order and the branch above has waited for the flags' values, so a wavefront-scope
+  // acquire -- a compiler barrier, no cache operation -- completes the hand-over's consumer side; the
+  // producer drains its write-through stores (s_waitcnt vmcnt(0)) before it stores the flag.
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // ---- lane exchange lane ^ S without an address register where the hardware offers one
