@@ -39,7 +39,7 @@ namespace {
 // completion flags -- and both run two visits ahead with their requests parked in registers, so
 // that no HBM round trip lies inside a visit.  One hardware barrier per visit.
 // Kernel 1 (truncated linear) only; kernel 2 above K = 64 stays on the generic kernel.
-// (Round-3 history, DESIGN.md 4.7: three waves per message with separate closest-pair waves, then
+// (Round-3 history, DESIGN.md 4.4: three waves per message with separate closest-pair waves, then
 // three / two waves sharing the destinations of a message, were all slower than one wave per message:
 // a visit is bound by the instructions its SIMDs issue, and every split repeats Di, H and the
 // reductions.)
