@@ -288,6 +288,62 @@ def simulate_schedule(sched, workgroups, visit=1.0, handover=0.0):
     return float(done_t.max()), finished == R
 
 
+def look_ahead_allowed(sched, direction):
+    """Bit 12 of descriptor word 2 (trws_graph.cpp), restated from the schedule: by rank, may a loader
+    wait for the node's foreign dependencies two visits ahead?  True if every dependency comes before
+    the node visited two steps earlier in the same run (one step, or the node itself, at the start of
+    a run) in this sweep's order."""
+    rank_at, run_ptr = sched["rank_at"], sched["run_ptr"]
+    dep_ptr, dep_rank = sched["dep_ptr"], sched["dep_rank"]
+    N = len(rank_at)
+    before = (lambda x, b: x < b) if direction == 0 else (lambda x, b: x > b)
+    ok = np.ones(N, bool)
+    for k in range(len(run_ptr) - 1):
+        a, b = int(run_ptr[k]), int(run_ptr[k + 1])
+        for pos in range(a, b):
+            r = int(rank_at[pos])
+            bound = int(rank_at[pos - 2]) if pos - 2 >= a else int(rank_at[pos - 1]) if pos - 1 >= a else r
+            ok[r] = all(before(int(x), bound) for x in dep_rank[dep_ptr[r]:dep_ptr[r + 1]])
+    return ok
+
+
+def simulate_look_ahead(sched, allowed):
+    """Does the sweep kernels' loader protocol terminate when the loader of the data behind flags works
+    two visits ahead on the nodes `allowed` (by rank) names?  Every run has its own workgroup.  The
+    visit that computes position i of a run can end only when (a) the dependencies of position i + 1
+    are visible (its data is staged during visit i at the latest) and (b) those of position i + 2 are,
+    if that node is allowed (the loader waits for them during visit i); a node becomes visible to other
+    runs when the visit that computed it has ended (the storer works during the next one, whatever
+    the loader waits for).  Returns True if every run finishes, False on a deadlock."""
+    rank_at, run_ptr = sched["rank_at"], sched["run_ptr"]
+    dep_ptr, dep_rank = sched["dep_ptr"], sched["dep_rank"]
+    N = len(rank_at)
+    R = len(run_ptr) - 1
+    visible = np.zeros(N, bool)
+
+    def deps_visible(pos):
+        r = int(rank_at[pos])
+        return all(visible[int(x)] for x in dep_rank[dep_ptr[r]:dep_ptr[r + 1]])
+
+    ended = [0] * R   # visits ended per run: 1 = the lead-in visit, 1 + j = the visit computing the run's j-th node
+    progress = True
+    while progress:
+        progress = False
+        for k in range(R):
+            a, b = int(run_ptr[k]), int(run_ptr[k + 1])
+            while ended[k] < b - a + 1:
+                i = a + ended[k] - 1           # position computed by the visit about to end (a - 1: lead-in, nothing computed)
+                if i + 1 < b and not deps_visible(i + 1):
+                    break                       # node i + 1 cannot be staged yet
+                if i + 2 < b and allowed[int(rank_at[i + 2])] and not deps_visible(i + 2):
+                    break                       # the loader waits two visits ahead
+                ended[k] += 1
+                if i >= a:
+                    visible[int(rank_at[i])] = True
+                progress = True
+    return all(ended[k] == int(run_ptr[k + 1]) - int(run_ptr[k]) + 1 for k in range(R))
+
+
 def messages(kernel, Di, gamma, msg_in, q_source, q_dest, alpha, lam, certificate=True, window=-1,
              shared_positions=None):
     """M message updates on the device (stereo_trws_messages): arrays are M x K (row = message),

@@ -126,6 +126,31 @@ def _check_schedule(H, W, capacity):
     return out
 
 
+def test_loader_look_ahead_rule_cannot_deadlock():
+    """The sweep kernels' second loader waits for a node's foreign dependencies two visits ahead where
+    descriptor bit 12 allows it (trws_graph.cpp).  Protocol simulation on the host: with the rule the
+    sweep finishes on every grid, both directions; looking ahead EVERYWHERE deadlocks on the two
+    interleaved last rows (each feeds the other) -- which is what the rule is for; never looking ahead
+    is the old protocol."""
+    from stereo_amd.trws import schedule, look_ahead_allowed, simulate_look_ahead
+    saw_deadlock = False
+    for H, W in [(2, 2), (3, 3), (4, 5), (5, 5), (6, 8), (7, 9), (12, 14), (1, 9), (9, 1), (2, 7), (20, 17)]:
+        conn = grid_conn(H, W)
+        N = H * W
+        for d in (0, 1):
+            s = schedule(N, conn.T, d, 0)
+            rule = look_ahead_allowed(s, d)
+            assert simulate_look_ahead(s, np.zeros(N, bool)), (H, W, d, "one visit ahead")
+            assert simulate_look_ahead(s, rule), (H, W, d, "descriptor rule")
+            if not simulate_look_ahead(s, np.ones(N, bool)):
+                saw_deadlock = True
+                assert not rule.all()           # the rule forbids at least one node there
+            # most nodes may be looked ahead at (the point of the exercise)
+            if H >= 5 and W >= 5:
+                assert rule.mean() > 0.7, (H, W, d, rule.mean())
+    assert saw_deadlock, "the negative control never deadlocked: the simulation does not model the hazard"
+
+
 def test_chain_schedule_small_grids():
     for H, W in [(2, 2), (3, 3), (5, 5), (6, 8), (7, 9), (12, 14), (1, 9), (9, 1), (2, 7)]:
         _check_schedule(H, W, 0)

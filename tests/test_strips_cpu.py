@@ -74,6 +74,33 @@ def test_strip_schedule_structure(shape, G):
         assert ok and ok0 and depth == depth0
 
 
+@pytest.mark.parametrize("shape,G", [((20, 24), 2), ((9, 30), 3), ((12, 5), 4)])
+def test_descriptor_look_ahead_bit_is_the_rule_and_cannot_deadlock(shape, G):
+    """Bit 12 of descriptor word 2 as the library writes it (read back through the strips' host-side
+    layout) equals the rule restated in stereo_amd.trws.look_ahead_allowed, and the loader protocol
+    with it terminates on the strip-aware schedule (halo dependencies included)."""
+    from stereo_amd.strips import schedule_strips, strip_layout_host, row_strip_owner
+    from stereo_amd.trws import analyze, look_ahead_allowed, simulate_look_ahead
+    H, W = shape
+    N = H * W
+    conn = grid_conn(H, W)
+    own = row_strip_owner(H, W, G)
+    rank = analyze(N, conn.T)["rank"]
+    for d in (0, 1):
+        s = schedule_strips(N, conn.T, d, own, G)
+        rule = look_ahead_allowed(s, d)
+        assert simulate_look_ahead(s, rule)
+        seen = 0
+        for g in range(G):
+            lay = strip_layout_host(N, conn.T, own, G, g, d)
+            for v in range(lay["desc"].shape[0]):
+                node = int(lay["nodes"][lay["desc"][v, 0]])
+                bit = (int(lay["desc"][v, 2]) >> 12) & 1
+                assert bit == int(rule[rank[node]]), (d, g, v, node)
+                seen += 1
+        assert seen == N
+
+
 def test_strips_must_be_a_chain():
     from stereo_amd import StereoHipError
     from stereo_amd.strips import schedule_strips
