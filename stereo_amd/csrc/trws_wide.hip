@@ -324,7 +324,8 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                   hlo = min_raw(hlo, WVALID(c) ? h[c] : inf); hhi = max_raw(hhi, WVALID(c) ? h[c] : -inf);
                   h[c] = WVALID(c) ? h[c] : inf;
                 }
-                hmin = wave_min_dpp(hlo); hmax = wave_max_dpp(hhi);
+                wave_min_max_dpp(hlo, hhi);  // both reductions in one interleaved pass (two independent chains)
+                hmin = hlo; hmax = hhi;
               }
               const double vtrunc = hmin + alpha * p.lambda;
               const double ap0 = alpha * pos_first, ap1 = alpha * pos_last;
