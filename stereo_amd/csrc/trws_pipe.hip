@@ -100,7 +100,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
     if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2] = wall_clock64();
     unsigned long long busy = 0;
 #ifdef STEREO_HIP_VISIT_PROFILE
-    unsigned long long vacc[6] = {0, 0, 0, 0, 0, 0}, macc[5] = {0, 0, 0, 0, 0};
+    unsigned long long vacc[6] = {0, 0, 0, 0, 0, 0}, macc[5] = {0, 0, 0, 0, 0}, lacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define VSTAMP(i) do { const long long n_ = (long long)__builtin_readcyclecounter(); vacc[i] += (unsigned long long)(n_ - vmark); vmark = n_; } while (0)
 #else
 #define VSTAMP(i) do { } while (0)
@@ -209,7 +209,13 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           }
           // the completion flags of the foreign neighbours, then their data
           // (all flags are polled together: lane j watches dependency j)
+#ifdef STEREO_HIP_VISIT_PROFILE
+          const long long lb0 = (long long)__builtin_readcyclecounter();
+#endif
           wait_for_dependencies(p, nx.ndep, nx.dep[0], nx.dep[1], nx.dep[2], nx.dep[3], nx.rank, epoch, lane, ctl + 1);
+#ifdef STEREO_HIP_VISIT_PROFILE
+          const long long lb1 = (long long)__builtin_readcyclecounter();
+#endif
 #pragma unroll
           for (int j = 0; j < 8; ++j)
             if (UPDATE && j >= nx.nout && j < ntot && nx.slot[j] < 0 && act)
@@ -219,6 +225,14 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           for (int j = 0; j < 8; ++j)
             if (j >= nx.nout && j < ntot && act) stn[kStM + j * kWave + lane] = mv[j];
           if (lane < 8) stni[64 + lane] = pxv;
+#ifdef STEREO_HIP_VISIT_PROFILE
+          if (pos > p0 + 3) {  // steady state only: the first visits of a run wait for the wavefront to arrive
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const long long lb2 = (long long)__builtin_readcyclecounter();
+            lacc[0] += (unsigned long long)(lb0 - vmark); lacc[1] += (unsigned long long)(lb1 - lb0);
+            lacc[2] += (unsigned long long)(lb2 - lb1); lacc[3] += 1;
+          }
+#endif
         }
       } else if (wave == kPipeCompute + 2) {
         // ------------------------------------------------------------ loader A: own data of node pos + 1
@@ -269,7 +283,16 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
             if (pd.remote & (1 << 17)) st_sc1(p.peer_x1 + pd.pn[1], xi);
             p.eterms[pd.epos] = scp[9];
           }
+#ifdef STEREO_HIP_VISIT_PROFILE
+          const long long sb0 = (long long)__builtin_readcyclecounter();
+#endif
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef STEREO_HIP_VISIT_PROFILE
+          if (pos > p0 + 3) {
+            const long long sb1 = (long long)__builtin_readcyclecounter();
+            lacc[4] += (unsigned long long)(sb0 - vmark); lacc[5] += (unsigned long long)(sb1 - sb0); lacc[6] += 1;
+          }
+#endif
           if (lane == 0) {
             st_sc1(p.done + pd.rank, epoch);
             if (pd.remote & (1 << 16)) st_sc1(p.peer_done0 + pd.pn[0], epoch);
@@ -327,6 +350,8 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
 #ifdef STEREO_HIP_VISIT_PROFILE
       if (wave == 0) for (int i = 0; i < 6; ++i) atomicAdd(p.prof + 48 + i, vacc[i]);
       if (wave == 0) for (int i = 0; i < 5; ++i) atomicAdd(p.prof + 56 + i, macc[i]);
+      if (wave == kPipeCompute) for (int i = 0; i < 4; ++i) atomicAdd(p.prof + 16 + i, lacc[i]);
+      if (wave == kPipeCompute + 1) for (int i = 4; i < 7; ++i) atomicAdd(p.prof + 16 + i, lacc[i]);
 #endif
       if (wave == 0) atomicAdd(p.prof + 6, (unsigned long long)(p1 - p0));
     }

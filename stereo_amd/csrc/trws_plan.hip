@@ -742,6 +742,10 @@ void stereo_trws_plan_destroy(stereo_trws_plan *plan) {
           std::fprintf(stderr, "[stereo_hip prof] wave 0 per visit: stage words %.0f | Di %.0f | H, positions %.0f | message %.0f | "
                                "hand-over %.0f | barrier %.0f\n", (double)v[48] / v[6], (double)v[49] / v[6], (double)v[50] / v[6],
                        (double)v[51] / v[6], (double)v[52] / v[6], (double)v[53] / v[6]);
+        if ((v[48] | v[49] | v[50]) && v[19] && v[22])
+          std::fprintf(stderr, "[stereo_hip prof] loader (steady state, per visit): until it polls %.0f | flags %.0f | fetch + stage %.0f; "
+                               "storer: until the drain %.0f | drain %.0f\n", (double)v[16] / v[19], (double)v[17] / v[19],
+                       (double)v[18] / v[19], (double)v[20] / v[22], (double)v[21] / v[22]);
         if (v[48] | v[49] | v[50])
           std::fprintf(stderr, "[stereo_hip prof] of the message: reduction + table %.0f | pair loop / flat path %.0f | margins + second look "
                                "%.0f | serial construction + walk %.0f | minimum %.0f\n", (double)v[56] / v[6], (double)v[57] / v[6],
