@@ -80,8 +80,8 @@ typedef struct stereo_trws_plan stereo_trws_plan;
 #define STEREO_TRWS_MESSAGES_MINPLUS 1 /* plain min-plus messages, no certificate / envelope construction:
                                          the reference's bits unless a message's certificate would have
                                          failed (exact or near ties), the brute-force O(K^2) result always.
-                                         With 64 < K <= 256 and shared ascending positions it runs
-                                         trws_chunk_kernel (1.6x the exact kernel at 3000x2000x256) */
+                                         With 64 < K <= 256 and shared ascending positions it is a branch of
+                                         trws_wide_kernel (1.4x the exact messages at 3000x2000x256) */
 /* OR-ed into message_mode: visit the nodes in index order -- MRFEnergy's order when the gateway
  * does NOT call SetAutomaticOrdering (trws_mex.cpp:121; nodes keep the order of AddNode,
  * MRFEnergy.cpp:37-76).  On an image grid the dependency DAG then has H + W - 1 anti-diagonal

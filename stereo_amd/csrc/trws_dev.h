@@ -44,7 +44,7 @@ struct DevParams {
   int N;
   unsigned long long *fallbacks;  // messages that needed the serial envelope (diagnostics)
   int certificate;                // 0: always run the serial envelope
-  int lean;                       // STEREO_TRWS_MESSAGES_MINPLUS in the wide-label regime (trws_chunk_kernel)
+  int lean;                       // STEREO_TRWS_MESSAGES_MINPLUS in the wide-label regime (trws_wide_kernel's plain min-plus branch)
   unsigned long long *prof;       // optional: 8 phase-cycle accumulators (development)
   const int32_t *desc[2];         // packed node descriptors of the pipelined kernels
   int prof_run;

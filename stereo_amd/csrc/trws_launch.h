@@ -30,9 +30,5 @@ void wide_set_attributes();
 void launch_wide(int what, int blocks, hipStream_t s, const DevParams &p, int epoch);
 void launch_wide_group(int what, int blocks, hipStream_t s, const GroupArgs &ga, int epoch);
 
-size_t chunk_lds_bytes();
-void chunk_set_attributes();
-void launch_chunk(int what, int blocks, hipStream_t s, const DevParams &p, int epoch);
-void launch_chunk_group(int what, int blocks, hipStream_t s, const GroupArgs &ga, int epoch);
 
 }  // namespace stereo

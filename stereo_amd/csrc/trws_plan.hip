@@ -276,7 +276,7 @@ DevParams make_params(stereo_trws_plan *P) {
   p.spin_ticks = P->spin_ticks;
   p.n_own = P->layout ? (int)P->layout->n_own : (int)P->Nl;
   p.fallbacks = P->d_fallbacks.p; p.certificate = P->certificate ? 1 : 0;
-  // MINPLUS in the wide-label regime runs the chunk-parallel kernel (trws_chunk.hip)
+  // MINPLUS in the wide-label regime: the wide kernel's plain min-plus branch
   p.lean = (P->wide && P->mode == STEREO_TRWS_MESSAGES_MINPLUS) ? 1 : 0;
   p.prof = P->d_prof.p;
   p.timeline = P->d_timeline.p;
@@ -298,8 +298,7 @@ DevParams make_params(stereo_trws_plan *P) {
 void launch_persistent(stereo_trws_plan *P, const DevParams &p, int what, hipStream_t s) {
   const int epoch = ++P->epoch;
   STEREO_HIP_CHECK(hipMemsetAsync(P->d_ctl.p, 0, sizeof(int32_t), s));  // ticket = 0
-  if (P->wide && p.lean) launch_chunk(what, std::min(P->grid_blocks, P->cus), s, p, epoch);
-  else if (P->wide) launch_wide(what, std::min(P->grid_blocks, P->cus), s, p, epoch);
+  if (P->wide) launch_wide(what, std::min(P->grid_blocks, P->cus), s, p, epoch);
   else if (P->fast2) launch_pipe2(P->pos != nullptr, what, std::min(P->grid_blocks, P->cus), s, p, epoch);
   else if (P->fast) launch_pipe(P->kernel, P->pos != nullptr, what, P->grid_blocks, s, p, epoch);
   else launch_generic(P->kernel, P->mode, what, P->grid_blocks, persistent_lds_bytes(P->Kp), s, p, epoch);
@@ -689,7 +688,7 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
     generic_set_attributes(plds);
     if (P->fast || strip_api) pipe_set_attributes();
     if (P->fast2) pipe2_set_attributes();
-    if (P->wide_allowed || strip_api) { wide_set_attributes(); chunk_set_attributes(); }
+    if (P->wide_allowed || strip_api) wide_set_attributes();
     *plan = P.release();
     return 0;
   } catch (const HipError &e) {
@@ -1013,8 +1012,7 @@ static void launch_group(stereo_trws_plan *const *G, int n, int what, hipStream_
     if (what != 3) P->sweep_launches += 1;
   }
   ga.first[n] = total;
-  if (P0->wide && P0->mode == STEREO_TRWS_MESSAGES_MINPLUS) launch_chunk_group(what, total, s, ga, epoch);
-  else if (P0->wide) launch_wide_group(what, total, s, ga, epoch);
+  if (P0->wide) launch_wide_group(what, total, s, ga, epoch);
   else if (P0->fast2) launch_pipe2_group(P0->pos != nullptr, what, total, s, ga, epoch);
   else launch_pipe_group(P0->kernel, P0->pos != nullptr, what, total, s, ga, epoch);
   STEREO_HIP_CHECK(hipGetLastError());

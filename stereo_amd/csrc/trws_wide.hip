@@ -342,6 +342,74 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) out[c] = hmin;
                 vmin = hmin;
+              } else if (p.lean) {
+                // ---- STEREO_TRWS_MESSAGES_MINPLUS: the message is the plain min-plus, nothing else -------
+                // (min over ALL sources = min over the useful ones, truncated: every other source costs
+                //  >= vTrunc; no margins, no tangency test, no serial construction)
+                serial = false;
+                const int w = p.window;
+                unsigned long long um[4];
+                int nuse = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                  um[c] = __builtin_amdgcn_ballot_w64(WVALID(c) && h[c] < vtrunc);
+                  nuse += __builtin_popcountll(um[c]);
+                }
+                double pq[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) pq[c] = WPOS(c);
+                double m1[4] = {inf, inf, inf, inf};
+                if (nuse <= kWideSparse) {
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) {
+                    unsigned long long mk = um[c];
+                    while (mk) {
+                      const int l = __builtin_ctzll(mk);
+                      mk &= mk - 1;
+                      const double hi = readlane_f64(h[c], l), qi = readlane_f64(pq[c], l);
+#pragma unroll
+                      for (int cc = 0; cc < 4; ++cc) m1[cc] = min_raw(m1[cc], pair_cost<1>(alpha, pq[cc] - qi, hi));
+                    }
+                  }
+                } else {
+                  double2 *mtab = (double2 *)scr + kWPad;
+                  double *htab = scr + kWPad;
+                  if (lane < 2 * kWPad) {
+                    if (uniform) scr[lane < kWPad ? lane : K + lane] = inf;
+                    else ((double2 *)scr)[lane < kWPad ? lane : K + lane] = make_double2(inf, 0.0);
+                  }
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) {
+                    if (WVALID(c)) {
+                      if (uniform) htab[c * kWave + lane] = h[c];
+                      else mtab[c * kWave + lane] = make_double2(h[c], pq[c]);
+                    }
+                  }
+                  WSYNC();
+                  if (uniform && w <= kWPad) {
+                    for (int d = -w; d <= w; ++d) {
+                      const double ad = alpha * fabs((double)d * ustep);  // == alpha |t - q| exactly
+#pragma unroll
+                      for (int c = 0; c < 4; ++c) m1[c] = min_raw(m1[c], ad + htab[c * kWave + lane + d]);
+                    }
+                  } else {
+                    for (int d = -w; d <= w; ++d) {
+#pragma unroll
+                      for (int c = 0; c < 4; ++c) {
+                        const int i = c * kWave + lane + d;
+                        const double2 sv = mtab[w <= kWPad ? i : i < 0 ? 0 : i > K - 1 ? K - 1 : i];
+                        double cst = pair_cost<1>(alpha, pq[c] - sv.y, sv.x);
+                        if (w > kWPad) cst = (i >= 0 && i < K) ? cst : inf;
+                        m1[c] = min_raw(m1[c], cst);
+                      }
+                    }
+                  }
+                  WSYNC();
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) out[c] = m1[c] < vtrunc ? m1[c] : vtrunc;
+                vmin = hmin;  // (destination t sees source t at distance 0, vTrunc >= min H)
+                WSTAMP(3);
               } else if (fast_msg) {
                 // ---- the certified path ---------------------------------------------------------------
                 // Only USEFUL cones (h < vTrunc; bit masks um) can give a destination a cost below

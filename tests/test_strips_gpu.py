@@ -287,8 +287,8 @@ def test_a_strip_stores_its_own_rows_only(hip, oracle):
     assert done == 3 and np.array_equal(lab, lab_o) and _close(en, en_o) and _close(lb, lb_o)
 
 
-def test_strips_in_the_minplus_mode_on_the_chunk_kernel(hip, oracle):
-    """MINPLUS messages with K = 200 run the chunk-parallel kernel; as two strips (group launch)
+def test_strips_in_the_minplus_mode(hip, oracle):
+    """MINPLUS messages with K = 200 run the wide kernel's plain min-plus branch; as two strips (group launch)
     they still give the brute-force oracle's labels."""
     from stereo_amd.strips import make_strips
     from stereo_amd.trws import MESSAGES_MINPLUS
