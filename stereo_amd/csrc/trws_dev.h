@@ -1103,7 +1103,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
                                                double qsrc, double t, const uint16_t *perm,
                                                double &outmsg, int lane, double *hq = nullptr,
                                                int window = -1, int *look_streak = nullptr,
-                                               unsigned long long *vprof = nullptr) {
+                                               unsigned long long *vprof = nullptr, int perm_here = -1) {
   const double inf = __builtin_huge_val();
   const bool act = lane < K;
 #ifdef STEREO_HIP_VISIT_PROFILE
@@ -1275,7 +1275,9 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
     }
     VMSTAMP(2);
     if (need_serial) {
-      const int idx = act ? perm[lane] : lane;
+      // (perm_here >= 0: the caller holds perm[lane] in a register -- shared positions, the same for every
+      //  message: no load on the serial path)
+      const int idx = perm_here >= 0 ? perm_here : act ? perm[lane] : lane;
       const double hs = __shfl(h, idx, kWave), qs = __shfl(qsrc, idx, kWave);
       double sh = 0, sq = 0, zz = 0;
       int maxtop = 0;

@@ -45,6 +45,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
   const bool act = lane < K;
   const double posk = (SHARED && act) ? p.pos[lane] : 0.0;
   int look_streak = 0;  // failed second looks in a row (this compute wave): see message_regs
+  const int perm_shared = (SHARED && wave < kPipeCompute) ? (act ? (int)p.perm_pos[lane] : lane) : -1;  // source order by position, once
   if (tid == 0) ctl[1] = 0;
   if (wave < kPipeCompute && lane < 2 * kPipePad) {
     // padding of the source tables (entries -16 .. -1 and 64 .. 79): never overwritten afterwards
@@ -164,8 +165,10 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
                                                     hqtab + wave * kPipeTab + 4 * kPipePad, (SHARED && p.win_ok) ? p.window : -1, &look_streak
 #ifdef STEREO_HIP_VISIT_PROFILE
                                                     , wave == 0 ? macc : nullptr
+#else
+                                                    , nullptr
 #endif
-                                                    );
+                                                    , perm_shared);
               VSTAMP(3);
               if (act) hcur[j * kWave + lane] = newm;
               if (BACKWARD && lane == 0) sc[j] = v;
