@@ -906,11 +906,12 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           const int *sti = (const int *)(st + kWStI);
           const int f = __builtin_amdgcn_readfirstlane(sti[2]);
           const int nout = f & 15, nin = (f >> 4) & 15, md = (f >> 16) & 255, ntot = nout + nin;
-          double db[4], di[4];
+          double db[4], di[4], pq[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const int k = c * kWave + lane;
             db[c] = (c < C && k < K) ? st[k] : inf;
+            pq[c] = WPOS(c);
           }
 #pragma unroll
           for (int jj = 0; jj < 8; ++jj) {
@@ -922,9 +923,9 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
 #pragma unroll
               for (int c = 0; c < 4; ++c) {
                 if (c < C) {
-                  const double d = fwd ? pks - WPOS(c) : WPOS(c) - pks;
+                  const double d = fwd ? pks - pq[c] : pq[c] - pks;
                   const double v = KERNEL == 1 ? fabs(d) : d * d;
-                  db[c] += aj * (v < p.lambda ? v : p.lambda);
+                  db[c] += aj * min_raw(v, p.lambda);  // (v, lambda >= 0: the same value as v < lambda ? v : lambda)
                 }
               }
             }
@@ -941,15 +942,24 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
               }
             }
           }
-          double bestv = inf, bestdb = 0;
-          int besti = 0x7fffffff;
+          // first minimum over the labels (AddColumn's vectorMin): the minimum itself by a plain reduction,
+          // then the lowest label k = 64 c + lane that attains it -- lowest chunk with a hit, lowest lane in it
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {  // ascending k per lane: strict '<' keeps the first minimum
-            const int k = c * kWave + lane;
-            if (c < C && k < K && di[c] < bestv) { bestv = di[c]; besti = k; bestdb = db[c]; }
+          for (int c = 0; c < 4; ++c) di[c] = (c < C && c * kWave + lane < K) ? di[c] : inf;
+          const double vbest = wave_min_dpp(min_raw(min_raw(di[0], di[1]), min_raw(di[2], di[3])));
+          int bi = 0;
+          double eb = 0;
+          bool found = false;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const unsigned long long hit = __builtin_amdgcn_ballot_w64(di[c] == vbest);
+            if (!found && hit) {
+              const int l = __builtin_ctzll(hit);
+              bi = c * kWave + l;
+              eb = readlane_f64(db[c], l);
+              found = true;
+            }
           }
-          const int bi = wave_argmin_dpp(bestv, besti);
-          const double eb = readlane_f64(bestdb, bi & (kWave - 1));  // the lane owning label bi
           xprev2 = xprev; xprev = bi;
           if (lane == 0) { sc[9] = eb; ((int *)(sc + 10))[0] = bi; }
         }
