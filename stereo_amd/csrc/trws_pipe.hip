@@ -325,14 +325,17 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
                 d = mdj == 0 ? readlane_f64(qpj, ks) - qvj : qpj - readlane_f64(qvj, ks);
               }
               const double v = KERNEL == 1 ? fabs(d) : d * d;
-              db += st[kStA + j] * (v < p.lambda ? v : p.lambda);
+              db += st[kStA + j] * min_raw(v, p.lambda);  // (v, lambda >= 0: the value of v < lambda ? v : lambda)
             }
           }
           double di = db;
 #pragma unroll
           for (int j = 0; j < 8; ++j)
             if (j < nout) di += st[kStM + j * kWave + lane];
-          const int bi = wave_argmin_dpp(act ? di : inf, act ? lane : 0x7fffffff);
+          // first minimum (AddColumn's vectorMin): the minimum by a plain reduction, then the lowest lane that has it
+          const double dim = act ? di : inf;
+          const double vbest = wave_min_dpp(dim);
+          const int bi = __builtin_ctzll(__builtin_amdgcn_ballot_w64(dim == vbest));
           xprev2 = xprev; xprev = bi;
           const double eb = readlane_f64(db, bi);
           if (lane == 0) { sc[9] = eb; ((int *)(sc + 10))[0] = bi; }
