@@ -8,8 +8,15 @@ SURVEY.md 8(d) "Config 2").  A "step" is one
 TRW-S iteration (forward sweep, backward sweep with lower bound, primal
 labelling + energy, stop test), exactly what Minimize_TRW_S does per iteration
 (cpp/trw-s/minimize.cpp:31-113).  Inputs are resident in HBM before the timed
-region.  With --gpus N every rank solves its own image pair (independent
-objects, no data-path collective): weak scaling, value = total iterations/s.
+region.
+
+With --gpus N > 1 the top-level line is the north star's scaling figure instead: ONE synthetic
+3000 x 2000 x 256-label image (BASELINE.json configs[3]) tiled into N row strips, one per GPU
+(stereo_amd.strips: peer stores over xGMI, RCCL only for two doubles per iteration), strong
+scaling, `value` = iterations/s of that one image over exactly --steps timed iterations.  Before
+anything is timed a PREFLIGHT runs two small strip problems across the N real devices and compares
+them with the single plan on rank 0 (`preflight`).  The one-Teddy-pair-per-GPU replica figure is a
+labelled extra (`replicas`), never `value`.  At N = 1 the same configs[3] figure is the `scale` object.
 
 One JSON line is printed by rank 0.
 """
@@ -91,7 +98,7 @@ def algorithmic_bytes_per_sweep_pair(info_deg, K):
     return float(fwd.sum() + bwd.sum())
 
 
-def scale_leg(args, rank, local_rank, world, dist, dev, index_order=False, minplus=False):
+def scale_leg(args, rank, local_rank, world, dist, dev, index_order=False, minplus=False, steps=None, warmup=None):
     """Strong scaling of ONE large image (BASELINE.json configs[3]: synthetic 3000 x 2000 x 256-label
     volume) over the `world` GPUs: rank g owns band g of the rows (stereo_amd.strips), boundary
     messages / flags / labels go to the neighbour GPU as peer stores over xGMI, energy and bound are
@@ -106,6 +113,8 @@ def scale_leg(args, rank, local_rank, world, dist, dev, index_order=False, minpl
     _cus = _lib.lib().stereo_hip_device_cus
     H, W, K = args.scale_height, args.scale_width, args.scale_labels
     N = H * W
+    steps = args.scale_steps if steps is None else steps
+    warmup = args.scale_warmup if warmup is None else warmup
     t_setup = time.perf_counter()
     conn = grid_conn(H, W)
     E = conn.shape[0]
@@ -140,13 +149,13 @@ def scale_leg(args, rank, local_rank, world, dist, dev, index_order=False, minpl
     plan.stats(reset=True)
     setup_s = time.perf_counter() - t_setup
     NEVER = -1e300
-    solver.iterate(args.scale_warmup, max_relgap=NEVER)
+    solver.iterate(warmup, max_relgap=NEVER)
     plan.stats(reset=True)
     plan.serial_messages(reset=True)
     D.barrier(dist, dev)
     t0 = time.perf_counter()
-    done, _ = solver.iterate(args.scale_steps, max_relgap=NEVER)
-    assert done == args.scale_steps
+    done, _ = solver.iterate(steps, max_relgap=NEVER)
+    assert done == steps
     D.barrier(dist, dev)
     dt = D.max_over_ranks(dist, time.perf_counter() - t0, dev)
     sweep_ms, launches = plan.stats()
@@ -182,7 +191,7 @@ def scale_leg(args, rank, local_rank, world, dist, dev, index_order=False, minpl
     # N = 1 results of the default scale workload (driver-run BENCH_r02 / BENCH_r03, 1 warm-up + 3 timed
     # iterations): labels are the same at any N, energy and bound agree to 1e-12 relative
     ref1 = None
-    if (H, W, K, args.scale_warmup + args.scale_steps, index_order, minplus) == (2000, 3000, 256, 4, False, False):
+    if (H, W, K, warmup + steps, index_order, minplus) == (2000, 3000, 256, 4, False, False):
         ref1 = {"label_sum": 624442294, "energy": 47220100.82134177, "lower_bound": 47214056.1673238}
     n1 = None
     if ref1 is not None:
@@ -192,8 +201,9 @@ def scale_leg(args, rank, local_rank, world, dist, dev, index_order=False, minpl
                   source="committed constants of the N = 1 run (BENCH_r02.json scale object)")
     return {"workload": "configs[3]: synthetic %dx%dx%d-label cost volume, TRW-S, kernel 1, tol 8, ONE image tiled "
                         "into %d row strips" % (W, H, K, world),
-            "n_gpus": world, "scaling": "strong", "value": args.scale_steps / dt, "unit": "iterations/s",
-            "ms_per_iteration": dt / args.scale_steps * 1e3, "steps": args.scale_steps, "warmup": args.scale_warmup,
+            "n_gpus": world, "scaling": "strong", "value": steps / dt, "unit": "iterations/s",
+            "ms_per_iteration": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+            "bytes_per_launch_per_gpu": bytes_launch,
             "hbm_frac_per_gpu": [frac_min, frac_max], "sweep_launch_ms_rank0": avg_launch_s * 1e3,
             "serial_envelope_messages": serial, "energy": energy, "lower_bound": lb, "label_sum": crc,
             "transport": "none (one GPU)" if world == 1 else "peer stores over xGMI into HIP-IPC-mapped neighbour arrays + flag; "
@@ -204,8 +214,95 @@ def scale_leg(args, rank, local_rank, world, dist, dev, index_order=False, minpl
             "ranks": ranks, "distinct_devices": len({(r["host"], r["device"]) for r in ranks}),
             "collective_backend": (dist.get_backend() if dist is not None and world > 1 else "none"),
             "n1_reference": n1,
-            "note": "THIS object is the north star's 1 -> N scaling curve (one image, strong scaling); the top-level "
-                    "`value` is N independent Teddy problems (weak scaling)"}
+            "note": "the north star's 1 -> N scaling curve (one image, strong scaling): at N > 1 this object IS the "
+                    "top-level value; at N = 1 the top-level value is the Teddy headline and this is the curve's first point"}
+
+
+def preflight(rank, world, dist, dev, one_gpu):
+    """Before anything is timed at N > 1: two small problems solved by `world` row strips on the `world`
+    REAL devices (the same TrwsStripRank path as the scale leg: HIP-IPC mappings, peer stores, flags,
+    the 2-double all_gather) against the single plan on rank 0 -- K = 16 with per-edge positions on the
+    K <= 64 kernel and K = 256 fronto-parallel labels on the wide kernel, 2 iterations each.  Returns
+    the `preflight` object on rank 0: ok, and per case labels_equal / energy / bound differences."""
+    import torch
+    from stereo_amd import _lib
+    from stereo_amd.strips import TrwsStripRank
+    from stereo_amd.trws import TrwsPlan
+    from helpers import trws_problem
+    cases = []
+    ok = True
+    for (H, W, K) in ((64, 96, 16), (max(32, 4 * world), 24, 256)):
+        case = {"grid": "%dx%dx%d" % (W, H, K), "strips": world}
+        try:
+            kind = "fronto" if K > 64 else "general"
+            p = trws_problem(7, H, W, K, kind=kind)
+            cus = int(_lib.lib().stereo_hip_device_cus()) or 256
+            s = TrwsStripRank(1, K, H, W, p["conn"].T, rank, world, dist, dev,
+                              max_workgroups=max(2, cus // world) if one_gpu else 0)
+            pos = np.arange(K, dtype=np.float64)
+            if kind == "fronto":
+                s.upload(p["unary"].T, p["alphas"], 8.0, positions=pos)
+            else:
+                s.upload(p["unary"].T, p["alphas"], 3.0, q=p["q"].T, qprim=p["qprim"].T)
+            done, _ = s.iterate(2, max_relgap=-1e300)
+            idx, lab = s.own_labels()
+            parts = [None] * world
+            dist.all_gather_object(parts, (idx, lab))
+            if rank == 0:
+                full = np.zeros(H * W)
+                for i, l in parts:
+                    full[i] = l
+                one = TrwsPlan(1, K, H * W, p["conn"].T)
+                if kind == "fronto":
+                    one.upload(p["unary"].T, p["alphas"], 8.0, positions=pos)
+                else:
+                    one.upload(p["unary"].T, p["alphas"], 3.0, q=p["q"].T, qprim=p["qprim"].T)
+                one.iterate(2, max_relgap=-1e300)
+                lab1, en1, lb1, _ = one.result()
+                one.close()
+                case.update(kernel_path=int(s.plan.path()), labels_equal=bool(np.array_equal(full, lab1)),
+                            label_sum=int(full.sum()), label_sum_single_plan=int(np.asarray(lab1).sum()),
+                            energy=s.energy, energy_single_plan=en1, lower_bound=s.lb, lower_bound_single_plan=lb1,
+                            energy_rel_diff=abs(s.energy - en1) / max(abs(en1), 1e-300),
+                            lower_bound_rel_diff=abs(s.lb - lb1) / max(abs(lb1), 1e-300))
+                case["ok"] = bool(case["labels_equal"] and case["energy_rel_diff"] <= 1e-12 and case["lower_bound_rel_diff"] <= 1e-12)
+            s.close()
+        except Exception as exc:
+            case.update(ok=False, error="%s: %s" % (type(exc).__name__, exc))
+        ok = ok and bool(case.get("ok", rank != 0))
+        cases.append(case)
+    return {"ok": ok, "cases": cases,
+            "what": "row strips on the N devices of this run vs the single plan on rank 0, 2 iterations, before any timing; "
+                    "labels bit-exact, energy / bound to 1e-12 relative (strip-ordered partial sums)"} if rank == 0 else None
+
+
+def cpu_all_cores(unary, conn, K, iters):
+    """The oracle (oracle/trws_oracle.c, 1 thread per problem -- the reference is single-threaded) on
+    C independent copies of the same Teddy-sized problem at once, one per host core up to 32 (each copy
+    holds ~1 GB of messages and positions): iterations/s of all copies together.  Reported baseline."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import pyoracle
+    E = conn.shape[0]
+    host = os.cpu_count() or 1
+    try:
+        host_avail = len(os.sched_getaffinity(0))
+    except Exception:
+        host_avail = host
+    C_ = max(1, min(host_avail, 32))
+    q = np.tile(np.arange(K, dtype=np.float64), (E, 1))
+    ones = np.ones(E)
+
+    def one(_):
+        r = pyoracle.trws(1, unary, conn, q, q, ones, 8.0, maxiter=iters, max_relgap=-1e300, mode=1, want_trace=True)
+        return float(r[4][-1, 2])
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(C_) as ex:
+        secs = list(ex.map(one, range(C_)))
+    wall = time.perf_counter() - t0
+    return {"value": C_ * iters / max(secs), "unit": "iterations/s", "cores": C_, "host_cores": host,
+            "host_cores_available": host_avail, "kind": "port",
+            "sample": "%d independent copies of the problem x %d iterations, one oracle thread each (ctypes releases the "
+                      "GIL), slowest copy's iteration time; %.1f s wall incl. every copy's setup" % (C_, iters, wall)}
 
 
 def main():
@@ -221,6 +318,7 @@ def main():
                     help="skip the labelled index-order extra (profiling: its launches are the same kernel and "
                          "would be averaged into the headline kernel's rocprofv3 statistics)")
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-cores leg of the CPU baseline")
     ap.add_argument("--message-mode", choices=["exact", "minplus"], default="exact")
     ap.add_argument("--volume", choices=["ncc", "noise"], default="ncc",
                     help="ncc: NCC cost volume of an image pair (the named workload); noise: planted signal + noise")
@@ -233,6 +331,12 @@ def main():
     ap.add_argument("--scale-labels", type=int, default=256)
     ap.add_argument("--scale-steps", type=int, default=3)
     ap.add_argument("--scale-warmup", type=int, default=1)
+    ap.add_argument("--scale-options", action="store_true",
+                    help="N > 1: also time the labelled min-plus / index-order options of the scale leg (at N = 1 they always run)")
+    ap.add_argument("--scale-n1-steps", type=int, default=2,
+                    help="N > 1: rank 0 alone also times this many iterations of the same image on ONE GPU after the strips "
+                         "(the curve's first point measured in the same job); 0 skips it")
+    ap.add_argument("--no-preflight", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -258,6 +362,18 @@ def main():
     conn = grid_conn(H, W)
     E = conn.shape[0]
     dev = torch.device("cuda", local_rank)
+    # who is here: one entry per rank as the collective backend sees it (host, device index, device name, uuid-ish bus id)
+    import socket
+    props = torch.cuda.get_device_properties(local_rank)
+    me = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(), "device": local_rank, "name": props.name,
+          "pci_bus_id": getattr(props, "pci_bus_id", None), "cus": getattr(props, "multi_processor_count", None)}
+    ranks_seen = [me]
+    if dist is not None and world > 1:
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, me)
+    pre = None
+    if world > 1 and not args.no_preflight:
+        pre = preflight(rank, world, dist, dev, one_gpu)
     big = N * K > (1 << 28)
     volume = args.volume if not big else "noise"
     if volume == "ncc":
@@ -339,13 +455,15 @@ def main():
         # HBM traffic per launch from the committed PMC passes of this same workload (profiles/),
         # corrected as MI355X_MICROARCH.md prescribes; null if the workload differs from them
         traffic = None
-        pmc = {(375, 450, 60, "ncc", "teddy"): "r03_trws_teddy60_pmc_hbm.json",
+        pmc = {(375, 450, 60, "ncc", "teddy"): ("r04_trws_teddy60_pmc_hbm.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_trws_teddy60_pmc_hbm.json")) else "r03_trws_teddy60_pmc_hbm.json"),
                (375, 450, 60, "ncc", "synthetic"): "r02_trws_teddy60_ncc_pmc_hbm.json",
                (375, 450, 60, "noise", "none"): "r01_trws_teddy60_pmc_hbm.json",
                (1000, 1500, 256, "noise", "none"): "r01_trws_wide256_1500x1000_pmc_hbm.json",
                (2000, 3000, 256, "noise", "none"): "r03_trws_wide256_3000x2000_pmc_hbm.json"}.get((H, W, K, volume, pair))
+        traffic_source = None
         if pmc and os.path.exists(os.path.join(ROOT, "profiles", pmc)):
             traffic = json.load(open(os.path.join(ROOT, "profiles", pmc)))["per_launch"]["hbm_bytes_corrected"]
+            traffic_source = "profiles/%s (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; NOT measured in this run)" % pmc
         out = {
             "metric": "TRW-S fusion iterations/sec, 450x375x60 labels",
             "value": rate,
@@ -367,6 +485,8 @@ def main():
                                        else "synthetic cost volume (planted signal + noise)", W, H, K),
                        "nodes": N, "directed_edges": E, "message_mode": "exact (reference envelope)" if args.message_mode == "exact" else "minplus",
                        "parallelism": "independent image pair per GPU" if world > 1 else "1 GPU"},
+            "ranks_seen": ranks_seen, "distinct_devices": len({(r["host"], r["device"]) for r in ranks_seen}),
+            "collective_backend": (dist.get_backend() if dist is not None and world > 1 else "none"),
             "serial_envelope_messages": serial_msgs,
             "serial_envelope_fraction": serial_msgs / (2.0 * E * max(args.steps, 1)),  # 2E message updates per iteration
             "final_energy": energy, "final_lower_bound": lb, "iterations_done": iters,
@@ -376,7 +496,7 @@ def main():
                                            "SetAutomaticOrdering), H+W-1 dependency levels; NOT the gateway's labels -- "
                                            "reported next to the headline, never as `value`"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": {4: "trws_pipe2_kernel", 3: "trws_wide_kernel", 2: "trws_pipe_kernel", 1: "trws_persistent_kernel", 0: "trws_sweep_kernel (per level)"}[plan.path()]
                                    + " (one persistent launch per sweep)", "bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches_per_iter},
@@ -401,9 +521,14 @@ def main():
                                     "energy": g_en, "energy_ref": float(r[1]), "lower_bound": g_lb,
                                     "lower_bound_ref": float(r[2]), "ref": "oracle/trws_oracle.c (envelope messages)"}
             out["cpu_baseline"] = {"value": ci / secs, "unit": "iterations/s", "cores": 1,
-                                   "kind": "port",
+                                   "kind": "port", "host_cores": os.cpu_count(),
                                    "sample": "%d iterations of the same %dx%dx%d volume, oracle/trws_oracle.c "
                                              "(envelope messages), setup excluded" % (ci, W, H, K)}
+            if not args.no_cpu_all_cores:
+                try:
+                    out["cpu_baseline"]["all_cores"] = cpu_all_cores(unary, conn, K, ci)
+                except Exception as exc:
+                    out["cpu_baseline"]["all_cores"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if world == 1 and not args.no_cpu_baseline:
             # secondary figure: QPBO binary fusion moves/s on a Teddy-sized move (host arrays in,
             # labels out -- PCIe inclusive), next to the reference QPBO library where it travelled
@@ -461,9 +586,26 @@ def main():
         del plan, d_unary, d_alpha, d_pos
         torch.cuda.empty_cache()
         try:
-            scale = scale_leg(args, rank, local_rank, world, dist, dev)
+            if world > 1:   # the top-level figure at N > 1: exactly --steps timed iterations after --warmup
+                scale = scale_leg(args, rank, local_rank, world, dist, dev, steps=args.steps, warmup=args.warmup)
+            else:
+                scale = scale_leg(args, rank, local_rank, world, dist, dev)
         except Exception as exc:  # the headline line must not depend on the scaling leg
             scale = {"error": "%s: %s" % (type(exc).__name__, exc), "n_gpus": world}
+        if world > 1 and args.scale_n1_steps > 0:
+            # the curve's first point in the same job: rank 0 alone, the plain single-GPU plan on the same image
+            n1 = None
+            if rank == 0:
+                try:
+                    torch.cuda.empty_cache()
+                    r1 = scale_leg(args, 0, local_rank, 1, None, dev, steps=args.scale_n1_steps, warmup=1)
+                    n1 = {k: r1[k] for k in ("value", "unit", "ms_per_iteration", "steps", "warmup", "hbm_frac_per_gpu",
+                                             "energy", "lower_bound", "label_sum")}
+                except Exception as exc:
+                    n1 = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                if isinstance(scale, dict):
+                    scale["n1_same_run"] = n1
+            D.barrier(dist, dev)
         # the same image and strips under the two labelled options (and both): not the reference's bits
         notes = {"minplus_option": "STEREO_TRWS_MESSAGES_MINPLUS: windowed min-plus messages, no certificate / envelope "
                                    "construction (equal to the reference unless a certificate would have failed)",
@@ -471,6 +613,8 @@ def main():
                  "index_order_minplus_option": "both options"}
         for key, io, mp in (("minplus_option", False, True), ("index_order_option", True, False),
                             ("index_order_minplus_option", True, True)):
+            if world > 1 and not args.scale_options:
+                break
             try:
                 torch.cuda.empty_cache()
                 alt_scale = scale_leg(args, rank, local_rank, world, dist, dev, index_order=io, minplus=mp)
@@ -488,6 +632,40 @@ def main():
     if rank == 0:
         if scale is not None:
             out["scale"] = scale
+        if pre is not None:
+            out["preflight"] = pre
+        if world > 1:
+            # N > 1: the line IS the strong-scaling figure of configs[3]; the one-pair-per-GPU Teddy figure moves to `replicas`
+            rep = {k: out[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "data", "config", "roofline",
+                                       "final_energy", "final_lower_bound", "serial_envelope_fraction") if k in out}
+            rep["scaling"] = "weak"
+            rep["note"] = "N INDEPENDENT Teddy problems, one per GPU (no communication): replica throughput, not the scaling curve"
+            out["replicas"] = rep
+            for k in ("index_order_option", "final_energy", "final_lower_bound", "iterations_done", "serial_envelope_messages",
+                      "serial_envelope_fraction"):
+                out.pop(k, None)
+            sc = scale if isinstance(scale, dict) else {}
+            good = "value" in sc
+            Hs, Ws, Ks = args.scale_height, args.scale_width, args.scale_labels
+            out.update({
+                "metric": "TRW-S iterations/sec, ONE %dx%dx%d-label image tiled over %d GPUs (configs[3])" % (Ws, Hs, Ks, world),
+                "value": sc.get("value") if good else None, "unit": "iterations/s",
+                "ms_per_step": sc.get("ms_per_iteration") if good else None,
+                "scaling": "strong", "data": "synthetic",
+                "config": {"workload": sc.get("workload", "configs[3]"), "nodes": Hs * Ws, "directed_edges": 4 * Hs * Ws - 2 * (Hs + Ws),
+                           "message_mode": "exact (reference envelope)", "parallelism": "%d row strips, one per GPU" % world},
+                "preflight_ok": bool(pre and pre.get("ok")),
+            })
+            if good:
+                fr = sc["hbm_frac_per_gpu"]
+                out["roofline"] = {"bound": "hbm", "achieved": fr[0] * HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": fr[0], "traffic": None, "traffic_source": None,
+                                   "kernel": "trws_wide_kernel (one persistent launch per sweep and GPU)",
+                                   "per_gpu": True, "frac_min_max_over_gpus": fr,
+                                   "bytes_per_launch": sc.get("bytes_per_launch_per_gpu"),
+                                   "avg_launch_us": sc.get("sweep_launch_ms_rank0", 0.0) * 1e3, "launches_per_step": 2.0}
+            else:
+                out["scale_error"] = sc.get("error", "scale leg skipped (--no-scale)")
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -299,3 +299,87 @@ def globalstereo_unary_cost(im0, im1, P2, d_min, d_step, col_thresh, assignment,
     for c in range(Cn):
         ssd = ssd + M[:, c] ** 2
     return np.log(2.0) - np.log(np.exp(ssd * (-1.0 / (col_thresh * Cn))) + 1.0)
+
+
+# ----------------------------------------------- globalstereo: construction from the raw arguments
+# ojw_default_options('cvpr08') as dispmap_globalstereo uses it (imrender/ojw/ojw_default_options.m:58-80)
+GLOBALSTEREO_DEFAULTS = dict(disp_thresh=0.02, col_thresh=30.0, lambda_l=9.0, lambda_h=108.0, connect=4, improve=1)
+
+
+def globalstereo_setup(P, disp_range, disparity_factor, segment, n_images, kernel, options=None):
+    """dispmap_globalstereo.m:29-57 + preprocess (:377-414), from the RAW constructor arguments:
+      P2      = self.P(:,:,2) after `permute(P, [2 1 3])` (:43): 4 x 3;
+      disps   = disp_range(1)*f : disp_range(2)*f, sorted descending (:48-49) -- a MATLAB colon with
+                unit step, lo + (0 : floor(hi - lo));  d_min = disps(end), d_step = disps(1) - d_min (:51-52);
+      weights = EW * (num_in / ((connect == 8) + 1)) with EW = lambda_h where the two pixels of a
+                neighbourhood edge lie in the same segment, lambda_l otherwise (:397-403), edges in
+                construct_neighborhood order;
+      kernel 2: weights /= tol, tol = tol^2 (:410-413);  tol = options.disp_thresh (:32);
+      improve = options.improve > 0 (:393).
+    `segment` (H, W) stands for vgg_segment_ms' label image (:391; the segmenter is out of scope)."""
+    opt = dict(GLOBALSTEREO_DEFAULTS)
+    opt.update(options or {})
+    P = np.asarray(P, np.float64)
+    first = P[:, :, 0].reshape(-1, order="F")[[0, 1, 2, 3, 4, 5, 8]]        # P([1:6 9]), column-major linear index
+    if np.max(np.abs(first - np.array([1, 0, 0, 0, 1, 0, 1.0]))) > 1e-12:
+        raise ValueError("First image must be reference image")
+    P2 = np.ascontiguousarray(P[:, :, 1].T)                                 # 4 x 3
+    lo, hi = disp_range[0] * disparity_factor, disp_range[1] * disparity_factor
+    n = int(np.floor(hi - lo + 1e-10)) + 1                                  # colon: lo, lo+1, ..., <= hi
+    disps = np.sort(lo + np.arange(n, dtype=np.float64))[::-1]
+    d_min = float(disps[-1])
+    d_step = float(disps[0] - d_min)
+    seg = np.asarray(segment)
+    H, W = seg.shape
+    ind1, ind2 = construct_neighborhood(H, W)
+    s = seg.T.reshape(-1)                                                   # column-major pixel order
+    same = s[ind1] == s[ind2]
+    ew = same * float(opt["lambda_h"]) + (~same) * float(opt["lambda_l"])
+    ew = ew * (n_images / ((opt["connect"] == 8) + 1))
+    tol = float(opt["disp_thresh"])
+    if kernel == 2:
+        ew = ew / tol
+        tol = tol ** 2
+    return dict(P2=P2, d_min=d_min, d_step=d_step, weights=ew, tol=tol, improve=bool(opt["improve"] > 0),
+                col_thresh=float(opt["col_thresh"]))
+
+
+# ----------------------------------------------------- dispmap_ncc: local plane proposals (SURVEY 8(f1))
+def fit_plane_to_points(points, kernel):
+    """dispmap_ncc.m:67-92.  points (3, n) = [x; y; disparity].  Kernel 1: 20 rounds of iteratively
+    reweighted least squares, each the last right singular vector of w .* cost_func with
+    w = sqrt(|cost_func * v|) of the previous round (ones first); kernel 2: one SVD.
+    p(4) = -(p(1:3)' * mean(points, 2)), p = p / p(3).  (MATLAB's svd is outside the reference tree:
+    LAPACK's here; a singular vector's sign cancels in p / p(3).)"""
+    points = np.asarray(points, np.float64)
+    c = points.mean(axis=1, keepdims=True)
+    cost = -(points - c).T                                                  # n x 3
+    p = np.zeros(4)
+    if kernel == 1:
+        w = np.ones((cost.shape[0], 1))
+        for _ in range(20):
+            v = np.linalg.svd(w * cost, full_matrices=False)[2][-1]
+            p[:3] = v
+            w = np.sqrt(np.abs(cost @ v)).reshape(-1, 1)
+    else:
+        p[:3] = np.linalg.svd(cost, full_matrices=False)[2][-1]
+    p[3] = -(p[:3] @ points.mean(axis=1))
+    return p / p[2]
+
+
+def plane_from_neighbourhood(best_disp, x, y, r, kernel):
+    """dispmap_ncc.m:48-66 (generate_new_plane_RANSAC): the plane fitted to the winner-takes-all
+    disparities of the pixels STRICTLY closer than r to (x, y) (1-based, x = column).  best_disp (H, W).
+    Returns (plane (4,), number of points)."""
+    best = np.asarray(best_disp, np.float64)
+    H, W = best.shape
+    pts = get_points(H, W)
+    ids = np.sqrt((pts[0] - x) ** 2 + (pts[1] - y) ** 2) < r
+    return fit_plane_to_points(np.vstack([pts[:, ids], best.T.reshape(-1)[ids]]), kernel), int(ids.sum())
+
+
+def plane_lattice(best_disp, kernel, radius=5, first=10, step=50):
+    """example_ncc.m:24-32: `for x = 10:50:W, for y = 10:50:H` one local fit each, in that order."""
+    H, W = np.asarray(best_disp).shape
+    return [plane_from_neighbourhood(best_disp, x, y, radius, kernel)[0]
+            for x in range(first, W + 1, step) for y in range(first, H + 1, step)]

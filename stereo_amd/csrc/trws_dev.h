@@ -1098,7 +1098,10 @@ __device__ __forceinline__ double envelope_value(const DevParams &p, double alph
 // Message update with everything in registers (K <= 64): h = gamma*Di - old message,
 // qsrc / t = source / destination positions, perm = ascending order of the sources
 // (only touched by the serial fallback).  Returns the normalised message in `out`.
-template <int KERNEL>
+// SHAREDPOS: source and destination positions are the same shared vector (lane k: qsrc == t ==
+// position k) and `hq` is given; where it is strictly ascending (p.pos_gap > 0) the certified path
+// walks a COMPACTED table of the useful sources (below).
+template <int KERNEL, bool SHAREDPOS = false>
 __device__ __forceinline__ double message_regs(const DevParams &p, int K, double alpha, double h,
                                                double qsrc, double t, const uint16_t *perm,
                                                double &outmsg, int lane, double *hq = nullptr,
@@ -1150,6 +1153,56 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
       unsigned long long mask = __builtin_amdgcn_ballot_w64(useful);
       double m1 = inf, m2 = inf;
       bool bad = !(delta < inf);
+      if (SHAREDPOS && p.pos_gap > 0 && !(window >= 0 && __builtin_popcountll(mask) > 32)) {
+        // Shared strictly ascending positions, at most 32 useful sources (or no window): the useful
+        // sources' (h, q) are COMPACTED into the wave's table -- a useful lane writes entry number
+        // "useful lanes below me" -- and walked four per trip with uniform reads at constant offsets:
+        // no mask arithmetic, no per-source address, nothing in scalar registers inside the loop (a
+        // v_cmp whose mask an s_and / s_or consumes stalls the wave for the VALU's latency; the trip of
+        // the masked loop below is 20 scalar + 30 vector instructions for two sources, this one ~13
+        // vector instructions per source).  The table ends with three inert entries (h = +inf: cost
+        // +inf, changes neither minimum, matches nothing), so a trip never has to be cut short.
+        // Tangency as in the wide kernel (4.4): with destination t = position of lane t, the cost
+        // c_j(t) = alpha |t - q_j| + h_j of useful source j equals u_j - u_t + h_t right of j and
+        // v_j - v_t + h_t left of it, so |c_j(t) - h_t| <= delta IS "cone t lies within delta of an arm
+        // of cone j"; lane t counts its matches, and a useful cone matches itself exactly once
+        // (distance 0: c = h_t bit for bit), so "count != [t useful]" means a near tangency.  The pair
+        // test the masked loop makes in addition -- the apex of a USEFUL cone j on an arm of a useless
+        // cone t -- needs h_j >= h_t + alpha |q_t - q_j| - delta >= vTrunc + alpha gap - delta, which
+        // h_j < vTrunc rules out as soon as alpha gap > 2 delta: checked (uniform), serial path otherwise.
+        const int nuse = __builtin_popcountll(mask);
+        bad = bad || !(alpha * p.pos_gap > 2 * delta);
+        {
+          const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+          if (useful) { hq[2 * slot] = h; hq[2 * slot + 1] = qsrc; }
+          if (lane < 3) { hq[2 * (nuse + lane)] = inf; hq[2 * (nuse + lane) + 1] = 0; }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+        VMSTAMP(0);
+        int cnt = 0;
+        // (the match count as compare + add-with-carry; left to itself the compiler packs the four
+        //  compare results of a trip into a bit field and counts its bits: 14 instructions instead of 8.
+        //  s_nop 1: an fp64 v_cmp's VCC needs two wait states before a VALU reads it as a carry)
+#define STEREO_ACC_C(HJ, QJ)                                                         \
+  {                                                                                  \
+    const double c = pair_cost<1>(alpha, t - (QJ), (HJ));                            \
+    const double lo = min_raw(m1, c), hi = max_raw(m1, c);                           \
+    const double dc = c - h;                                                         \
+    m2 = min_raw_if(hi > lo, m2, hi);                                                \
+    m1 = lo;                                                                         \
+    asm("v_cmp_le_f64_e64 vcc, |%1|, %2\n\ts_nop 1\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc" \
+        : "+v"(cnt) : "v"(dc), "v"(delta) : "vcc");                                  \
+  }
+        for (int i = 0; i < nuse; i += 4) {
+          const double h0 = hq[2 * i], q0 = hq[2 * i + 1], h1 = hq[2 * i + 2], q1 = hq[2 * i + 3];
+          const double h2 = hq[2 * i + 4], q2 = hq[2 * i + 5], h3 = hq[2 * i + 6], q3 = hq[2 * i + 7];
+          STEREO_ACC_C(h0, q0) STEREO_ACC_C(h1, q1) STEREO_ACC_C(h2, q2) STEREO_ACC_C(h3, q3)
+        }
+#undef STEREO_ACC_C
+        bad = bad || cnt != (useful ? 1 : 0);
+        VMSTAMP(1);
+      } else {
       // The sources are broadcast from a per-wave LDS table (one ds_read_b128 per source instead of
       // eight v_readlane); two sources per trip keep two independent dependency chains in flight.
       // m1 / m2 = smallest and second smallest DISTINCT cost seen so far.
@@ -1236,6 +1289,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
 #undef STEREO_SRC
 #undef STEREO_ACC
       VMSTAMP(1);
+      }
       bad = bad || (m1 < vtrunc && !(m2 - m1 > delta && vtrunc - m1 > delta));
       need_serial = UNI(act && bad);
       MSTAMP(8);
@@ -1298,7 +1352,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
     // destination k) a certified linear message has its minimum at min H exactly: destination t sees
     // its own source at distance 0 (h_t + alpha 0 = h_t), every other term is some h_s plus a
     // non-negative cost, and vTrunc = min H + alpha lambda is no smaller -- no reduction needed.
-    if (KERNEL == 1 && p.certificate && !need_serial && !UNI(act && qsrc != t)) vmin = hmin;
+    if (KERNEL == 1 && p.certificate && !need_serial && (SHAREDPOS || !UNI(act && qsrc != t))) vmin = hmin;
     else vmin = wave_min_dpp(act ? out : inf);
   }
   VMSTAMP(4);

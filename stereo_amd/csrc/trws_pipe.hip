@@ -35,6 +35,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
   double *hqtab = scal + 2 * kScalDoubles;                // per compute wave: 64 x (h, q, u, v)
   int *ctl = (int *)(hqtab + kPipeCompute * kPipeTab);    // [0] run, [1] abort
   int *dring = ctl + 4;                                   // the last three descriptors (the storer's comes from here, not from HBM)
+  double *zrow = (double *)(dring + 3 * kWave);           // 64 zeros: where the Di loop finds the message rows a node does not have
   const int K = p.K;
   const double inf = __builtin_huge_val();
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -47,6 +48,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
   int look_streak = 0;  // failed second looks in a row (this compute wave): see message_regs
   const int perm_shared = (SHARED && wave < kPipeCompute) ? (act ? (int)p.perm_pos[lane] : lane) : -1;  // source order by position, once
   if (tid == 0) ctl[1] = 0;
+  if (tid < kWave) zrow[tid] = 0.0;
   if (wave < kPipeCompute && lane < 2 * kPipePad) {
     // padding of the source tables (entries -16 .. -1 and 64 .. 79): never overwritten afterwards
     double *e = hqtab + wave * kPipeTab + 4 * (lane < kPipePad ? lane : kWave + lane);
@@ -123,7 +125,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
         if (UPDATE && have_node) {
           const int *sti = (const int *)(st + kStI);
           const int f = __builtin_amdgcn_readfirstlane(sti[2]);
-          const int nout = f & 15, nin = (f >> 4) & 15, md = (f >> 16) & 255, ntot = nout + nin;
+          const int nout = f & 15, md = (f >> 16) & 255;
           const int myrow = sti[72 + (lane & 7)];  // LDS offsets (doubles) of the node's message rows, from the loader
           VSTAMP(0);
           if (wave < nout || (BACKWARD && wave == 0)) {  // waves without a message stay out of the way
@@ -131,9 +133,15 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           // (this wave's own old message is one of the rows; it is read once more below rather than
           //  picked out of the loop with eight selects)
           const double mown = st[kStM + (wave < nout ? wave : 0) * kWave + lane];
+          // (all eight rows are requested together and added in list order; a row the node does not have
+          //  is the zero row -- x + 0.0 == x --, so nothing here branches on the node's degree and the
+          //  reads share one LDS latency instead of paying one each)
+          {
+            double rowv[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if (j < ntot) Di += lds[__builtin_amdgcn_readlane(myrow, j) + lane];
+            for (int j = 0; j < 8; ++j) rowv[j] = lds[__builtin_amdgcn_readlane(myrow, j) + lane];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Di += rowv[j];
           }
           double node_vmin = 0;
           if (BACKWARD) {
@@ -161,7 +169,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
               const double alpha = st[kStA + j];
               VSTAMP(2);
               double newm = 0;
-              const double v = message_regs<KERNEL>(p, K, alpha, h, qsrc, qdst, perm, newm, lane,
+              const double v = message_regs<KERNEL, SHARED>(p, K, alpha, h, qsrc, qdst, perm, newm, lane,
                                                     hqtab + wave * kPipeTab + 4 * kPipePad, (SHARED && p.win_ok) ? p.window : -1, &look_streak
 #ifdef STEREO_HIP_VISIT_PROFILE
                                                     , wave == 0 ? macc : nullptr
@@ -193,7 +201,8 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
               if (lane == j) slr = j >= nx.nout ? nx.slot[j] : -1;
-            const int row = slr >= 8 ? (int)(hand - lds) + ((pos - 1) & 3) * 8 * kWave + (slr - 8) * kWave
+            const int row = lane >= nx.nout + nx.nin ? (int)(zrow - lds)
+                          : slr >= 8 ? (int)(hand - lds) + ((pos - 1) & 3) * 8 * kWave + (slr - 8) * kWave
                           : slr >= 0 ? (int)(hand - lds) + (pos & 3) * 8 * kWave + slr * kWave
                                      : (int)(stn - lds) + kStM + lane * kWave;
             if (lane < 8) stni[72 + lane] = row;
@@ -381,7 +390,7 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_group_kernel(GroupArgs
 }  // namespace
 
 size_t pipe_lds_bytes() {
-  return sizeof(double) * (2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * kPipeTab + 2 + 3 * kWave / 2);
+  return sizeof(double) * (2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * kPipeTab + 2 + 3 * kWave / 2 + kWave);
 }
 int pipe_threads() { return kPipeThreads; }
 

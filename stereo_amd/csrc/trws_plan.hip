@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void scatter_perm_kernel(const uint16_t *in
 // One wave per message through message_regs -- the routine the pipelined sweep kernel computes
 // its messages with (certified fast path, second look, serial construction), table in LDS as
 // there -- so that the certificate can be attacked with hand-placed near-tangent cones.
-template <int KERNEL>
+template <int KERNEL, bool SHAREDPOS>
 __global__ __launch_bounds__(kWave) void trws_messages_kernel(DevParams p, int K, int64_t M, const double *Di,
                                                              const double *gamma, const double *msg_in,
                                                              const double *qsrc, const double *qdst,
@@ -141,8 +141,8 @@ __global__ __launch_bounds__(kWave) void trws_messages_kernel(DevParams p, int K
     if (lane == 0) before = *p.fallbacks;
     before = __shfl(before, 0, kWave);
     double out = 0;
-    const double v = message_regs<KERNEL>(p, K, alpha[m], h, qs, qt, perm + (size_t)m * K, out, lane,
-                                          tab + 4 * kPipePad, window);
+    const double v = message_regs<KERNEL, SHAREDPOS>(p, K, alpha[m], h, qs, qt, perm + (size_t)m * K, out, lane,
+                                                     tab + 4 * kPipePad, window);
     __threadfence();
     if (act) msg_out[o] = out;
     if (lane == 0) { vmin[m] = v; serial[m] = (int32_t)(*p.fallbacks - before); }
@@ -1258,18 +1258,24 @@ int stereo_trws_messages(int kernel, int K, int64_t M, const double *Di, const d
     p.K = K; p.Kp = (K + 1) & ~1; p.kernel = kernel; p.lambda = lambda; p.certificate = certificate ? 1 : 0;
     p.fallbacks = dfb.p;
     if (shared_positions) { p.pos_first = shared_positions[0]; p.pos_last = shared_positions[K - 1]; }
-    if (kernel == 2 && shared_positions) {
+    // shared_positions: every message's q_source and q_dest ARE this vector (the caller's promise, as the
+    // sweep kernels have it with fronto-parallel labels); strictly ascending ones take the compacted
+    // certified loop of message_regs<.., true>
+    bool shared_asc = false;
+    if (shared_positions) {
       p.pos_gap = std::numeric_limits<double>::infinity();
       for (int k = 1; k < K; ++k) p.pos_gap = std::min(p.pos_gap, shared_positions[k] - shared_positions[k - 1]);
+      shared_asc = K > 1 && p.pos_gap > 0 && std::isfinite(shared_positions[0]) && std::isfinite(shared_positions[K - 1]);
+      if (!shared_asc && kernel == 1) p.pos_gap = 0;
     }
     if (const char *dbg = std::getenv("STEREO_HIP_TRWS_DEBUG")) p.debug = std::atoi(dbg);
     const unsigned grid = (unsigned)std::min<int64_t>(M, 4096);
-    if (kernel == 1)
-      hipLaunchKernelGGL(trws_messages_kernel<1>, dim3(grid), dim3(kWave), 0, 0, p, K, M, dD.p, dg.p, dm.p, dqs.p, dqd.p,
-                         da.p, dperm.p, shared_positions ? window : -1, dout.p, dv.p, dser.p, dfb.p);
-    else
-      hipLaunchKernelGGL(trws_messages_kernel<2>, dim3(grid), dim3(kWave), 0, 0, p, K, M, dD.p, dg.p, dm.p, dqs.p, dqd.p,
-                         da.p, dperm.p, shared_positions ? window : -1, dout.p, dv.p, dser.p, dfb.p);
+#define STEREO_MSG_LAUNCH(KER, SH)                                                                                              \
+    hipLaunchKernelGGL((trws_messages_kernel<KER, SH>), dim3(grid), dim3(kWave), 0, 0, p, K, M, dD.p, dg.p, dm.p, dqs.p, dqd.p, \
+                       da.p, dperm.p, shared_positions ? window : -1, dout.p, dv.p, dser.p, dfb.p)
+    if (kernel == 1) { if (shared_asc) STEREO_MSG_LAUNCH(1, true); else STEREO_MSG_LAUNCH(1, false); }
+    else STEREO_MSG_LAUNCH(2, false);
+#undef STEREO_MSG_LAUNCH
     STEREO_HIP_CHECK(hipGetLastError());
     STEREO_HIP_CHECK(hipDeviceSynchronize());
     STEREO_HIP_CHECK(hipMemcpy(msg_out, dout.p, sizeof(double) * MK, hipMemcpyDeviceToHost));

@@ -163,14 +163,20 @@ def test_plane_lattice_in_one_launch(hip):
     from stereo_amd import PlaneProposal
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "teddy_pair.npz"))
     im0, im1 = g["im0"][100:260, 150:330].astype(np.float64), g["im1"][100:260, 150:330].astype(np.float64)   # 160 x 180
+    from oracle import terms as ot
     for kernel in (1, 2):
         dm = hip.dispmap_ncc([im0, im1], np.arange(0, 32.0), kernel, 40.0, 8.0)
         dev = dm.generate_plane_lattice(radius=5)
         host = dm.generate_plane_lattice(radius=5, on_device=False)
-        assert len(dev) == len(host) == 4 * 4                 # x = 10, 60, 110, 160; y = 10, 60, 110, 160
-        for k, (d, h) in enumerate(zip(dev, host)):
+        # the ORACLE's restatement of dispmap_ncc.m:48-92 (oracle/terms.py: plane_lattice) on the oracle's own
+        # winner-takes-all disparities (best_disp_from_ncc of the NumPy NCC volume): nothing of the product in it
+        ncc_o = ot.compute_ncc(im0, im1, np.arange(0, 32.0), 2)
+        want = ot.plane_lattice(ot.best_disp_from_ncc(ncc_o, np.arange(0, 32.0)), kernel, radius=5)
+        assert len(dev) == len(host) == len(want) == 4 * 4    # x = 10, 60, 110, 160; y = 10, 60, 110, 160
+        for k, (d, h, o) in enumerate(zip(dev, host, want)):
             assert isinstance(d, PlaneProposal)
-            assert np.allclose(d.planes[:, 0], h[:, 0], rtol=1e-6, atol=1e-6), (kernel, k, d.planes[:, 0], h[:, 0])
+            assert np.allclose(d.planes[:, 0], o, rtol=1e-6, atol=1e-6), (kernel, k, d.planes[:, 0], o)
+            assert np.allclose(h[:, 0], o, rtol=1e-9, atol=1e-9), (kernel, k, h[:, 0], o)
         # one call, many centres == many calls, one centre (bit for bit)
         ctx = dm._context()
         one = [ctx.fit_plane(x, y, 5)[0] for x in (10, 60) for y in (10, 110)]

@@ -66,8 +66,15 @@ def _run(hip, oracle, im0, im1, disp_range, factor, seg, cells, seed0, kernel=1)
     gs = hip.dispmap_globalstereo([im0, im1], P, disp_range, factor, segment=seg, rng=rng,
                                   options=dict(smoothness_kernel=kernel))
     assert gs.improve                                                                   # ojw_default_options.m:72
-    ref = OracleGlobal(oracle, hip, im0, im1, gs.P2, gs.d_min, gs.d_step, gs.options["col_thresh"], gs.smooth_weights,
-                       gs.tol, kernel, gs.start_disparity)
+    # the oracle side is built from the RAW constructor arguments (oracle/terms.py: dispmap_globalstereo.m:29-57,
+    # preprocess :377-414 -- edge weights from the segment image, kernel-2 rescale, d_min / d_step, P(:,:,2)),
+    # never from the fields of the object under test; the product's fields must equal them exactly
+    su = ot.globalstereo_setup(P, disp_range, factor, seg, 2, kernel)
+    assert su["improve"] and gs.d_min == su["d_min"] and gs.d_step == su["d_step"] and gs.tol == su["tol"]
+    assert np.array_equal(np.asarray(gs.P2), su["P2"]) and np.array_equal(gs.smooth_weights, su["weights"])
+    assert gs.options["col_thresh"] == su["col_thresh"]
+    ref = OracleGlobal(oracle, hip, im0, im1, su["P2"], su["d_min"], su["d_step"], su["col_thresh"], su["weights"],
+                       su["tol"], kernel, gs.start_disparity)
     assert np.array_equal(gs.assignment, ref.a)
     u = ref.unary(ref.a)
     assert np.max(np.abs(u - ref.unary_numpy(ref.a))) < 1e-11                          # device unary vs NumPy restatement
@@ -121,17 +128,28 @@ def test_globalstereo_moves_with_improve_on_the_teddy_crop(hip, oracle):
     _run(hip, oracle, im0, im1, [0, 15], 4, seg, cells=(4, 6, 8, 8, 12, 16, 24, 32), seed0=3)
 
 
-def test_globalstereo_moves_with_improve_full_size(hip, oracle):
-    """375 x 450 (the size of example_global.m's Teddy pair), synthetic textured pair, the example's
-    constants: disp_range [0 59], factor 4, P(1,4,2) = -0.25, lambda 9 / 108, improve on."""
+@pytest.mark.parametrize("pair", ["teddy", "synthetic"])
+def test_globalstereo_moves_with_improve_full_size(pair, hip, oracle):
+    """375 x 450 with the example's constants (example_global.m:17-20: disp_range [0 59], factor 4,
+    P(1,4,2) = -0.25, lambda 9 / 108, improve on): on the reference's own Teddy pair (data/teddy/im2.png,
+    im6.png = tests/golden/teddy_pair.npz), whose segment image here is a colour-quantisation stand-in for
+    the mean-shift segmenter (out of scope), and on the synthetic textured pair."""
     if not oracle.have_ref_qpbo():
         pytest.skip("oracle/_ref/libref_qpbo.so not present")
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from bench import synthetic_pair
     H, W = 375, 450
-    im0, im1 = synthetic_pair(H, W, 60)
-    seg = (np.arange(H)[:, None] // 25) * 100 + (np.arange(W)[None, :] // 30)
+    if pair == "teddy":
+        g = np.load(os.path.join(GOLD, "teddy_pair.npz"))
+        im0, im1 = g["im0"].astype(np.float64), g["im1"].astype(np.float64)
+        assert im0.shape[:2] == (H, W)
+        # segments = 32 x 32-pixel cells split by coarse colour (3 bits per channel of the cell-smoothed image)
+        q = (im0 // 32).astype(np.int64)
+        seg = ((np.arange(H)[:, None] // 32) * 64 + (np.arange(W)[None, :] // 32)) * 512 + q[:, :, 0] * 64 + q[:, :, 1] * 8 + q[:, :, 2]
+    else:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import synthetic_pair
+        im0, im1 = synthetic_pair(H, W, 60)
+        seg = (np.arange(H)[:, None] // 25) * 100 + (np.arange(W)[None, :] // 30)
     unl, _ = _run(hip, oracle, im0, im1, [0, 59], 4, seg, cells=(8, 12, 16, 24, 32, 48), seed0=5)
     assert unl > 0, "no move left nodes unlabelled: Improve was not exercised"
 

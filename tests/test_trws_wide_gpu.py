@@ -230,6 +230,99 @@ def test_wide_kernel_matches_oracle_at_300x400x256(hip, oracle):
     assert abs(en2 - en_o) <= 1e-12 * abs(en_o) and abs(lb2 - lb_o) <= 1e-12 * abs(lb_o)
 
 
+def test_wide_kernel_matches_oracle_at_750x500x256(hip, oracle):
+    """configs[3] at the largest size the CPU oracle runs in about a minute (a sixteenth of the 3000 x 2000
+    grid, the same 256 labels and generator as bench.py's volume): 2 iterations, single plan and two row
+    strips against oracle/trws_oracle.c -- labels, energy, bound, iteration count bit for bit (strips:
+    scalars to 1e-12, they are partial sums added in strip order)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synthetic_volume
+    from helpers import grid_conn
+    from stereo_amd.trws import TrwsPlan
+    from stereo_amd.strips import make_strips
+    H, W, K = 500, 750, 256
+    conn = grid_conn(H, W)
+    E = conn.shape[0]
+    unary = synthetic_volume(H, W, K, seed=1)
+    alphas = np.ones(E)
+    pos = np.arange(K, dtype=np.float64)
+    q = np.ascontiguousarray(np.broadcast_to(pos, (E, K)))
+    lab_o, en_o, lb_o, it_o = oracle.trws(1, unary, conn, q, q, alphas, 8.0, 2, -1e300, mode=1)
+    del q
+    plan = TrwsPlan(1, K, H * W, conn.T)
+    plan.upload(unary.T, alphas, 8.0, positions=pos)
+    assert plan.path() == 3
+    plan.iterate(2, max_relgap=-1e300)
+    lab, en, lb, it = plan.result()
+    plan.close()
+    assert it == it_o and np.array_equal(lab, lab_o) and en == en_o and lb == lb_o
+    s = make_strips(1, K, H, W, conn.T, 2)
+    s.upload(unary.T, alphas, 8.0, positions=pos)
+    s.iterate(2, max_relgap=-1e300)
+    lab2, en2, lb2, _ = s.result()
+    s.close()
+    assert np.array_equal(lab2, lab_o)
+    assert abs(en2 - en_o) <= 1e-12 * abs(en_o) and abs(lb2 - lb_o) <= 1e-12 * abs(lb_o)
+
+
+def test_full_size_3000x2000x256_properties(hip):
+    """configs[3] at FULL size, where no CPU oracle fits the test budget: size-independent properties of
+    the exact path on bench.py's 3000 x 2000 x 256 volume (61 GB resident) -- (i) the lower bound does not
+    decrease over the iterations and stays below the energy (this volume has no exact ties: the envelope
+    quirk of DESIGN.md section 2 does not fire), energy of the labelling is finite and falls from the first
+    to the third iteration; (ii) reset() reproduces labels, energy and bound bit for bit (nothing of a
+    previous solve survives in messages, flags or labels); (iii) two row strips give the single plan's
+    labels bit for bit and its scalars to 1e-12."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synthetic_volume_device
+    from helpers import grid_conn
+    from stereo_amd.trws import TrwsPlan
+    from stereo_amd.strips import make_strips
+    if torch.cuda.get_device_properties(0).total_memory < 150e9:
+        pytest.skip("needs ~125 GB of HBM")
+    H, W, K = 2000, 3000, 256
+    dev = torch.device("cuda", 0)
+    conn = grid_conn(H, W)
+    E = conn.shape[0]
+    d_unary = synthetic_volume_device(H, W, K, 1, dev)
+    d_alpha = torch.ones(E, dtype=torch.float64, device=dev)
+    d_pos = torch.arange(K, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    plan = TrwsPlan(1, K, H * W, conn.T)
+    plan.bind_device(d_unary.data_ptr(), d_alpha.data_ptr(), 8.0, d_positions=d_pos.data_ptr(), keepalive=(d_unary, d_alpha, d_pos))
+    assert plan.path() == 3
+    trace = []
+    for _ in range(3):
+        plan.iterate(1, max_relgap=-1e300)
+        _, en, lb, _ = plan.result(want_labels=False)
+        trace.append((en, lb))
+    lab, en, lb, it = plan.result()
+    assert it == 3 and all(np.isfinite(v) for t in trace for v in t)
+    assert trace[0][1] <= trace[1][1] <= trace[2][1], trace          # the bound does not decrease
+    assert all(l <= e for e, l in trace), trace                        # ... and stays below the energy
+    assert trace[2][0] < trace[0][0], trace
+    assert lab.min() >= 1 and lab.max() <= K
+    plan.reset()
+    plan.iterate(3, max_relgap=-1e300)
+    lab_b, en_b, lb_b, _ = plan.result()
+    assert np.array_equal(lab, lab_b) and en == en_b and lb == lb_b
+    plan.close()
+    del plan
+    torch.cuda.empty_cache()
+    s = make_strips(1, K, H, W, conn.T, 2)
+    s.bind_device(d_unary.data_ptr(), d_alpha.data_ptr(), 8.0, d_positions=d_pos.data_ptr(), keepalive=(d_unary, d_alpha, d_pos))
+    s.iterate(3, max_relgap=-1e300)
+    lab2, en2, lb2, _ = s.result()
+    s.close()
+    assert np.array_equal(lab2, lab)
+    assert abs(en2 - en) <= 1e-12 * abs(en) and abs(lb2 - lb) <= 1e-12 * abs(lb)
+
+
 LEAN = [
     # seed, H, W, K, positions, integer, tol, maxiter
     (71, 9, 11, 256, "grid", False, 8.0, 4),
