@@ -333,9 +333,9 @@ def main():
     ap.add_argument("--scale-warmup", type=int, default=1)
     ap.add_argument("--scale-options", action="store_true",
                     help="N > 1: also time the labelled min-plus / index-order options of the scale leg (at N = 1 they always run)")
-    ap.add_argument("--scale-n1-steps", type=int, default=2,
-                    help="N > 1: rank 0 alone also times this many iterations of the same image on ONE GPU after the strips "
-                         "(the curve's first point measured in the same job); 0 skips it")
+    ap.add_argument("--no-scale-n1", action="store_true",
+                    help="N > 1: skip rank 0's own single-GPU run of the same image, same --steps / --warmup, after the strips "
+                         "(the curve's first point measured in the same job, and a label / energy cross-check of the strips)")
     ap.add_argument("--no-preflight", action="store_true")
     args = ap.parse_args()
 
@@ -592,15 +592,20 @@ def main():
                 scale = scale_leg(args, rank, local_rank, world, dist, dev)
         except Exception as exc:  # the headline line must not depend on the scaling leg
             scale = {"error": "%s: %s" % (type(exc).__name__, exc), "n_gpus": world}
-        if world > 1 and args.scale_n1_steps > 0:
+        if world > 1 and not args.no_scale_n1:
             # the curve's first point in the same job: rank 0 alone, the plain single-GPU plan on the same image
             n1 = None
             if rank == 0:
                 try:
                     torch.cuda.empty_cache()
-                    r1 = scale_leg(args, 0, local_rank, 1, None, dev, steps=args.scale_n1_steps, warmup=1)
+                    r1 = scale_leg(args, 0, local_rank, 1, None, dev, steps=args.steps, warmup=args.warmup)
                     n1 = {k: r1[k] for k in ("value", "unit", "ms_per_iteration", "steps", "warmup", "hbm_frac_per_gpu",
                                              "energy", "lower_bound", "label_sum")}
+                    if isinstance(scale, dict) and "value" in scale:   # same image, same iteration count: the strips' answer
+                        n1["strips_label_sum_equal"] = bool(scale["label_sum"] == r1["label_sum"])
+                        n1["strips_energy_rel_diff"] = abs(scale["energy"] - r1["energy"]) / abs(r1["energy"])
+                        n1["strips_lower_bound_rel_diff"] = abs(scale["lower_bound"] - r1["lower_bound"]) / abs(r1["lower_bound"])
+                        n1["speedup_over_one_gpu"] = scale["value"] / r1["value"]
                 except Exception as exc:
                     n1 = {"error": "%s: %s" % (type(exc).__name__, exc)}
                 if isinstance(scale, dict):

@@ -92,6 +92,28 @@ struct DevBuf {
   }
 };
 
+// Scratch that lives for a few launches on ONE stream: allocated and released in stream order
+// (hipMallocAsync / hipFreeAsync), so releasing it neither waits for the kernels that use it nor
+// synchronises the device the way hipFree does.
+template <class T>
+struct StreamBuf {
+  T *p = nullptr;
+  hipStream_t s = nullptr;
+  StreamBuf() = default;
+  StreamBuf(const StreamBuf &) = delete;
+  StreamBuf &operator=(const StreamBuf &) = delete;
+  ~StreamBuf() {
+    if (p) (void)hipFreeAsync(p, s);
+  }
+  void alloc(size_t count, hipStream_t stream = nullptr) {
+    if (p) (void)hipFreeAsync(p, s);
+    p = nullptr;
+    s = stream;
+    if (count == 0) count = 1;
+    STEREO_HIP_CHECK(hipMallocAsync((void **)&p, count * sizeof(T), stream));
+  }
+};
+
 template <class T>
 struct PinnedBuf {
   T *p = nullptr;

@@ -221,8 +221,10 @@ __global__ __launch_bounds__(kTB) void ncc_stats_kernel(const double *im, int H,
   //  NumPy restatement is unaffected.  A zero norm gives +-inf and, as with the division, a non-finite
   //  value that becomes 0, dispmap_ncc.m:190)
   const double rnorm = 1.0 / sqrt(fabs(var));
-  st[px] = b[0]; st[Npx + px] = b[1]; st[2 * Npx + px] = b[2]; st[3 * Npx + px] = mean;
-  st[4 * Npx + px] = var < 0 ? -rnorm : rnorm;
+  if (st) {    // column-major planes (ncc_cross_kernel); the label-fastest path only wants the row-major ones
+    st[px] = b[0]; st[Npx + px] = b[1]; st[2 * Npx + px] = b[2]; st[3 * Npx + px] = mean;
+    st[4 * Npx + px] = var < 0 ? -rnorm : rnorm;
+  }
   if (stT) {   // the same five planes row-major, for ncc_lane_kernel
     const int64_t t = (int64_t)row * W + col;
     stT[t] = b[0]; stT[Npx + t] = b[1]; stT[2 * Npx + t] = b[2]; stT[3 * Npx + t] = mean;
@@ -837,8 +839,6 @@ void launch_ncc_volume(const double *d_im0, const double *d_im1, int H, int W, c
     hipLaunchKernelGGL(ncc_volume_kernel, dim3(blocks((int64_t)npx * D)), dim3(kTB), 0, 0, p);
     return;
   }
-  DevBuf<double> st0, st1;
-  st0.alloc(5 * npx); st1.alloc(5 * npx);
   // (ncc_lane_kernel stages 96 columns of the right image per row: the disparities of every 64-label
   //  chunk must span less than that minus the workgroup's own columns)
   bool lanes_ok = layout == 1 && !std::getenv("STEREO_HIP_NCC_ROWLANES");
@@ -851,13 +851,15 @@ void launch_ncc_volume(const double *d_im0, const double *d_im1, int H, int W, c
   lanes_ok = lanes_ok && span + 5 + 8 <= kNlSeg1;
   if (lanes_ok) {
     // label-fastest volume: lane = disparity (ncc_lane_kernel) over row-major copies of images and statistics
-    DevBuf<double> s0T, s1T, i0T, i1T;
+    // (row-major staging copies only, in stream-ordered scratch: released behind the kernel without a
+    //  device-wide synchronisation; the column-major statistics are the other path's)
+    StreamBuf<double> s0T, s1T, i0T, i1T;
     s0T.alloc(5 * npx); s1T.alloc(5 * npx); i0T.alloc(3 * npx); i1T.alloc(3 * npx);
     const dim3 tg((H + 15) / 16, (W + 15) / 16, 3);
     hipLaunchKernelGGL(ncc_transpose_kernel, tg, dim3(kTB), 0, 0, d_im0, H, W, i0T.p);
     hipLaunchKernelGGL(ncc_transpose_kernel, tg, dim3(kTB), 0, 0, d_im1, H, W, i1T.p);
-    hipLaunchKernelGGL(ncc_stats_kernel, dim3(blocks(npx)), dim3(kTB), 0, 0, d_im0, H, W, patchsize, st0.p, s0T.p);
-    hipLaunchKernelGGL(ncc_stats_kernel, dim3(blocks(npx)), dim3(kTB), 0, 0, d_im1, H, W, patchsize, st1.p, s1T.p);
+    hipLaunchKernelGGL(ncc_stats_kernel, dim3(blocks(npx)), dim3(kTB), 0, 0, d_im0, H, W, patchsize, (double *)nullptr, s0T.p);
+    hipLaunchKernelGGL(ncc_stats_kernel, dim3(blocks(npx)), dim3(kTB), 0, 0, d_im1, H, W, patchsize, (double *)nullptr, s1T.p);
     // enough workgroups for every CU: the columns are cut so that row tiles x column chunks x 64-label
     // chunks reach ~2 workgroups per CU (each chunk re-computes four columns of products)
     int cus = 256, dev = 0;
@@ -869,12 +871,17 @@ void launch_ncc_volume(const double *d_im0, const double *d_im1, int H, int W, c
     chunks = (W + cols - 1) / cols;
     NccLane f{H, W, D, d_im1, i0T.p, i1T.p, s0T.p, s1T.p, d_disp, d_out, cols};
     const size_t lds = sizeof(double) * kNlLdsDoubles;
-    STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)ncc_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static thread_local int lds_set_on = -1;   // the attribute is per device: set once per device and thread
+    if (lds_set_on != dev) {
+      STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)ncc_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      lds_set_on = dev;
+    }
     hipLaunchKernelGGL(ncc_lane_kernel, dim3(rt, dc, chunks), dim3(kNlWaves * 64), lds, 0, f);
     STEREO_HIP_CHECK(hipGetLastError());
-    STEREO_HIP_CHECK(hipDeviceSynchronize());  // the staging buffers are released on return
-    return;
+    return;   // (the staging buffers are freed in stream order behind the kernel)
   }
+  DevBuf<double> st0, st1;
+  st0.alloc(5 * npx); st1.alloc(5 * npx);
   hipLaunchKernelGGL(ncc_stats_kernel, dim3(blocks(npx)), dim3(kTB), 0, 0, d_im0, H, W, patchsize, st0.p, (double *)nullptr);
   hipLaunchKernelGGL(ncc_stats_kernel, dim3(blocks(npx)), dim3(kTB), 0, 0, d_im1, H, W, patchsize, st1.p, (double *)nullptr);
   NccFast f{H, W, D, d_im0, d_im1, st0.p, st1.p, d_disp, d_out, layout};
@@ -1228,14 +1235,27 @@ int stereo_fusion_fuse_until_convergence(stereo_fusion *F, const double *proposa
     if (ids[i] < 1 || ids[i] > n) return fail("stereo_fusion_fuse_until_convergence: proposal id out of range", err, errcap);
   return guarded("stereo_fusion_fuse_until_convergence", err, errcap, [&] {
     const int64_t N = F->N;
-    DevBuf<double> all;   // the proposals, resident for the whole schedule
-    all.alloc((size_t)4 * N * n);
+    // Where a move's proposal comes from: a single plane is expanded on the device when its move comes
+    // (32 bytes of input, no storage); 4 x N arrays stay resident for the whole schedule only while all
+    // n of them fit a budget (STEREO_HIP_FUSION_RESIDENT_MB, default 4096 MB and never more than a quarter
+    // of the free device memory) -- beyond that each move uploads its own proposal from the caller's
+    // buffer, as the per-move entry point does (a 3000 x 2000 image is 192 MB per proposal: a schedule
+    // over a few dozen proposals must not need tens of GB up front).
+    DevBuf<double> all;
+    bool resident = false;
     if (proposals) {
       check_planes(proposals, N * n);
-      STEREO_HIP_CHECK(hipMemcpy(all.p, proposals, sizeof(double) * 4 * N * n, hipMemcpyHostToDevice));
+      size_t budget = (size_t)4096 << 20, free_b = 0, total_b = 0;
+      if (const char *mb = std::getenv("STEREO_HIP_FUSION_RESIDENT_MB")) budget = (size_t)std::max(0L, std::atol(mb)) << 20;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, free_b / 4);
+      const size_t need = sizeof(double) * 4 * (size_t)N * (size_t)n;
+      resident = need <= budget;
+      if (resident) {
+        all.alloc((size_t)4 * N * n);
+        STEREO_HIP_CHECK(hipMemcpy(all.p, proposals, need, hipMemcpyHostToDevice));
+      }
     } else {
       check_planes(planes, n);
-      for (int k = 0; k < n; ++k) fusion_build_proposal(F, planes + 4 * k, 1, nullptr, all.p + (size_t)4 * N * k);
     }
     std::vector<double> E(1, F->energy);
     std::vector<char> visited((size_t)n, 0);
@@ -1244,7 +1264,9 @@ int stereo_fusion_fuse_until_convergence(stereo_fusion *F, const double *proposa
       if (it1 > n_ids) break;
       const int64_t pid = ids[it1 - 1];
       if (visited[pid - 1]) continue;
-      STEREO_HIP_CHECK(hipMemcpyAsync(F->prop.p, all.p + (size_t)4 * N * (pid - 1), sizeof(double) * 4 * N, hipMemcpyDeviceToDevice, 0));
+      if (!proposals) fusion_build_proposal(F, planes + 4 * (pid - 1), 1, nullptr, F->prop.p);
+      else if (resident) STEREO_HIP_CHECK(hipMemcpyAsync(F->prop.p, all.p + (size_t)4 * N * (pid - 1), sizeof(double) * 4 * N, hipMemcpyDeviceToDevice, 0));
+      else F->prop.upload(proposals + (size_t)4 * N * (pid - 1), 4 * N);
       fusion_binary_core(F, improve, nullptr, nullptr, nullptr, nullptr, wall_ms());
       E.push_back(F->energy);
       if (E[E.size() - 2] != E.back()) std::fill(visited.begin(), visited.end(), 0);   // E(end-1) ~= E(end)

@@ -855,12 +855,16 @@ constexpr int kSpinLimit = 1 << 22;  // polls before a wait INSIDE a workgroup (
 // `halo`: the wait is for a node of a neighbouring strip.  Waits for the strip's own nodes get twice the
 // time: when a neighbour is missing, the visit that waits for IT gives up first and names the cause,
 // the visits queued up behind it inside the strip see the abort flag and leave quietly.
+// (the poll counter wraps inside [0, 1024): nothing that could overflow however long the bound is; the
+//  clock is read at every wrap, the first reading -- t0 == 0: not started -- starts the bound, so the
+//  first 1024 polls, about a millisecond, come on top of it and a wait that ends earlier never reads it)
 __device__ __forceinline__ bool keep_waiting(const DevParams &p, int &spins, long long &t0, bool halo) {
   __builtin_amdgcn_s_sleep(1);
-  if ((++spins & 1023) != 0) return true;
+  spins = (spins + 1) & 1023;
+  if (spins != 0) return true;
   if (ld_sc1(p.abort_flag)) return false;
   const long long now = (long long)wall_clock64();
-  if (spins == 1024) { t0 = now; return true; }
+  if (t0 == 0) { t0 = now | 1; return true; }
   return now - t0 < (halo ? p.spin_ticks : 2 * p.spin_ticks);
 }
 // The first visit that gives up says what it was waiting for (the host turns it into the error text):
@@ -954,6 +958,15 @@ __device__ __forceinline__ void wait_for_dependencies(const DevParams &p, int nd
   // wave's loads in order and the branch above has waited for the flags' values, so a wavefront-scope
   // acquire -- a compiler barrier, no cache operation -- completes the hand-over's consumer side; the
   // producer drains its write-through stores (s_waitcnt vmcnt(0)) before it stores the flag.
+  // CONTRACT (this is weaker than the memory model's agent- / system-scope acquire, which would emit a
+  // buffer_inv sc1 -- ~1.7 us per wait on this part, MI355X_MICROARCH.md -- on every visit of every row):
+  // every load of data ANOTHER workgroup / GPU wrote during this launch goes through ld_sc1 (sc0 sc1:
+  // served from memory, never from this CU's L1 or a non-coherent L2 line).  The loaders keep to it by
+  // construction -- loader B (this routine's only caller besides wait_flag) reads nothing but foreign
+  // rows and labels, all with ld_sc1; loader A reads only data no other workgroup writes in the launch
+  // (unary, positions, weights, the node's OWN previous-sweep rows) with plain loads -- and
+  // tools/stress_trws.py / the strips tests compare whole solves bit for bit on every commit that
+  // touches a loader.  A new post-wait read of handed-over data with a plain load would break it silently.
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 

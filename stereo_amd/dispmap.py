@@ -23,6 +23,7 @@ class dispmap_super:
         self.images = [np.asarray(im, dtype=np.float64) for im in images]
         self.sz = self.images[0].shape[:2]
         self.maxiter = 1000          # dispmap_super.m:9
+        self.host_stack_budget_bytes = 8 << 30   # binary_fuse_until_convergence: largest 4 x N x n host array built for the native call
         self._max_relgap = 1e-4      # dispmap_super.m:10
         self._improve = False        # dispmap_super.m:13
         self._assignment = None
@@ -206,6 +207,10 @@ class dispmap_super:
         ids = ids[(ids >= 1) & (ids <= n)]
         # (a subclass with its own binary_fusion keeps the loop below, which calls it)
         native = device_loop and type(self).binary_fusion is dispmap_super.binary_fusion and hasattr(self, "tol")
+        single = n > 0 and all(isinstance(p, PlaneProposal) and p.segments is None for p in proposal_cell)
+        if native and not single and 32.0 * self.sz[0] * self.sz[1] * n > self.host_stack_budget_bytes:
+            native = False   # the native call takes ONE contiguous 4 x N x n host array: beyond the budget keep the
+                             # loop here, one proposal uploaded per move (the same moves, the same energies)
         ctx = self._context() if native else None
         if ctx is not None and n > 0:
             # the whole schedule in one native call on the resident state (stereo_fusion_fuse_until_convergence):
@@ -214,16 +219,29 @@ class dispmap_super:
             if not self._ctx_has_assignment:
                 ctx.set_assignment(self._assignment)
                 self._ctx_has_assignment = True
-            single = all(isinstance(p, PlaneProposal) and p.segments is None for p in proposal_cell)
-            if single:
-                E = ctx.fuse_until_convergence(ids, self.maxiter, planes=np.concatenate([p.planes for p in proposal_cell], axis=1),
-                                               improve=self._improve)
-            else:
+            props = None
+            if not single:
                 props = [p.expand(N) if isinstance(p, PlaneProposal) else np.asfortranarray(p, dtype=np.float64) for p in proposal_cell]
                 for p in props:
                     if p.shape != (4, N):
                         raise StereoHipError("Binary fusion: Proposals is of wrong size")
-                E = ctx.fuse_until_convergence(ids, self.maxiter, proposals=props, improve=self._improve)
+            try:
+                if single:
+                    E = ctx.fuse_until_convergence(ids, self.maxiter, planes=np.concatenate([p.planes for p in proposal_cell], axis=1),
+                                                   improve=self._improve)
+                else:
+                    E = ctx.fuse_until_convergence(ids, self.maxiter, proposals=props, improve=self._improve)
+            except Exception:
+                # a schedule that fails half way (a solver bound, out of memory) has already moved the RESIDENT
+                # assignment and energy: the host copies are stale from here on, and the stored energy is whatever
+                # the context holds now -- the object stays consistent with the device, then the error goes up
+                self._host_stale = True
+                try:
+                    self.stored_energy = float(ctx.get_assignment()[1])
+                except Exception:
+                    self._ctx_has_assignment = False     # not even that: re-upload the host assignment before the next move
+                    self._host_stale = False
+                raise
             self.stored_energy = float(E[-1])
             self._host_stale = True
             self.fusion_energies = [float(e) for e in E]

@@ -57,7 +57,7 @@ class OracleGlobal:
         return e, lb, nu
 
 
-def _run(hip, oracle, im0, im1, disp_range, factor, seg, cells, seed0, kernel=1):
+def _run(hip, oracle, im0, im1, disp_range, factor, seg, cells, seed0, kernel=1, tie_allowance=1e-4):
     H, W = im0.shape[:2]
     N = H * W
     P = np.tile(np.hstack([np.eye(3), np.zeros((3, 1))])[:, :, None], (1, 1, 2))      # example_global.m:17-18
@@ -104,17 +104,20 @@ def _run(hip, oracle, im0, im1, disp_range, factor, seg, cells, seed0, kernel=1)
             assert np.all(U0[differ] == U1[differ]), "move %d: %d pixels differ outside exact ties" % (k, int((U0[differ] != U1[differ]).sum()))
             # ... and few of them, PER MOVE (a regression inside a summed allowance would be invisible):
             # at most 1e-4 of the pixels and never more than a tenth of the exact ties of the move
+            # (on the real Teddy pair a quarter of the pixels are exact ties in every move -- ~39 000 of 168 750:
+            #  both planes leave the right image -- and ~50 of them land on the other side per move; the synthetic
+            #  pairs have a few hundred ties and 0-2 such pixels)
             n_diff, n_ties = int(differ.sum()), int((U0 == U1).sum())
             resync.append((k, n_diff, n_ties))
-            assert n_diff <= max(1, 1e-4 * N), "move %d: %d tie pixels took the other plane (%d exact ties)" % (k, n_diff, n_ties)
-            assert n_diff <= max(1, 0.1 * n_ties), (k, n_diff, n_ties)
+            assert n_diff <= max(1, tie_allowance * N), "move %d: %d tie pixels took the other plane (%d exact ties)" % (k, n_diff, n_ties)
+            assert n_diff <= max(1, 0.1 * n_ties if tie_allowance <= 1e-4 else 0.005 * n_ties), (k, n_diff, n_ties)
             tie_pixels += n_diff
             gs.assignment = ref.a.copy()      # same state on both sides for the next move
         total_unlabelled += nu_r
     # (shown with pytest -s / in the failure report: move, resynchronised pixels, exact ties of that move)
     print("globalstereo parity: %d moves, %d pixels of %d resynchronised at exact ties, per move %s" % (
         len(cells), tie_pixels, N, resync))
-    assert tie_pixels <= 1e-4 * N * len(cells), tie_pixels
+    assert tie_pixels <= tie_allowance * N * len(cells), tie_pixels
     return total_unlabelled, gs.energy()
 
 
@@ -150,7 +153,10 @@ def test_globalstereo_moves_with_improve_full_size(pair, hip, oracle):
         from bench import synthetic_pair
         im0, im1 = synthetic_pair(H, W, 60)
         seg = (np.arange(H)[:, None] // 25) * 100 + (np.arange(W)[None, :] // 30)
-    unl, _ = _run(hip, oracle, im0, im1, [0, 59], 4, seg, cells=(8, 12, 16, 24, 32, 48), seed0=5)
+    # tie allowance: 1e-4 of the pixels per move on the synthetic pair; on the Teddy pair, where 23 % of the pixels
+    # are exact ties in every move, 5e-4 of the pixels and at most 0.5 % of the move's exact ties
+    unl, _ = _run(hip, oracle, im0, im1, [0, 59], 4, seg, cells=(8, 12, 16, 24, 32, 48), seed0=5,
+                  tie_allowance=5e-4 if pair == "teddy" else 1e-4)
     assert unl > 0, "no move left nodes unlabelled: Improve was not exercised"
 
 
