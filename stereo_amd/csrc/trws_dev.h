@@ -970,6 +970,28 @@ __device__ __forceinline__ void wait_for_dependencies(const DevParams &p, int nd
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The same wait with the lane's own dependency already in the lane (`myrank`: lane j < ndep watches
+// dependency j -- the caller takes it from the descriptor word with one ds_bpermute instead of four scalar
+// reads and a chain of selects).
+__device__ __forceinline__ void wait_for_dependencies_w(const DevParams &p, int ndep, int myrank, int visiting_rank, int epoch,
+                                                        int lane, int *abort_word) {
+  const bool watching = lane < ndep;
+  int spins = 0;
+  long long t0 = 0;
+  for (;;) {
+    const int v = watching ? ld_sc1(p.done + myrank) : epoch;
+    if (!UNI(v < epoch)) break;
+    const unsigned long long late = __builtin_amdgcn_ballot_w64(v < epoch),
+                             late_halo = __builtin_amdgcn_ballot_w64(v < epoch && myrank >= p.n_own);
+    if (!keep_waiting(p, spins, t0, late_halo != 0)) {   // wall-clock bound, or somebody else gave up
+      if (lane == __builtin_ctzll(late_halo ? late_halo : late)) report_give_up(p, visiting_rank, myrank, v, epoch);
+      if (lane == 0) *abort_word = 1;
+      return;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (contract: see wait_for_dependencies)
+}
+
 // ---- lane exchange lane ^ S without an address register where the hardware offers one
 template <int S>
 __device__ __forceinline__ unsigned xor_lane_u32(unsigned v) {
@@ -1173,7 +1195,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
         // no mask arithmetic, no per-source address, nothing in scalar registers inside the loop (a
         // v_cmp whose mask an s_and / s_or consumes stalls the wave for the VALU's latency; the trip of
         // the masked loop below is 20 scalar + 30 vector instructions for two sources, this one ~13
-        // vector instructions per source).  The table ends with three inert entries (h = +inf: cost
+        // vector instructions per source).  The table ends with seven inert entries (h = +inf: cost
         // +inf, changes neither minimum, matches nothing), so a trip never has to be cut short.
         // Tangency as in the wide kernel (4.4): with destination t = position of lane t, the cost
         // c_j(t) = alpha |t - q_j| + h_j of useful source j equals u_j - u_t + h_t right of j and
@@ -1188,7 +1210,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
         {
           const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
           if (useful) { hq[2 * slot] = h; hq[2 * slot + 1] = qsrc; }
-          if (lane < 3) { hq[2 * (nuse + lane)] = inf; hq[2 * (nuse + lane) + 1] = 0; }
+          if (lane < 7) { hq[2 * (nuse + lane)] = inf; hq[2 * (nuse + lane) + 1] = 0; }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
         }
@@ -1207,13 +1229,22 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
     asm("v_cmp_le_f64_e64 vcc, |%1|, %2\n\ts_nop 1\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc" \
         : "+v"(cnt) : "v"(dc), "v"(delta) : "vcc");                                  \
   }
-        for (int i = 0; i < nuse; i += 4) {
-          const double h0 = hq[2 * i], q0 = hq[2 * i + 1], h1 = hq[2 * i + 2], q1 = hq[2 * i + 3];
-          const double h2 = hq[2 * i + 4], q2 = hq[2 * i + 5], h3 = hq[2 * i + 6], q3 = hq[2 * i + 7];
+        if (nuse <= 8) {
+          // (up to eight sources -- nearly every message of a noisy volume --: all eight entries are
+          //  requested together, one LDS latency instead of one per trip)
+          const double h0 = hq[0], q0 = hq[1], h1 = hq[2], q1 = hq[3], h2 = hq[4], q2 = hq[5], h3 = hq[6], q3 = hq[7];
+          const double h4 = hq[8], q4 = hq[9], h5 = hq[10], q5 = hq[11], h6 = hq[12], q6 = hq[13], h7 = hq[14], q7 = hq[15];
           STEREO_ACC_C(h0, q0) STEREO_ACC_C(h1, q1) STEREO_ACC_C(h2, q2) STEREO_ACC_C(h3, q3)
+          if (nuse > 4) { STEREO_ACC_C(h4, q4) STEREO_ACC_C(h5, q5) STEREO_ACC_C(h6, q6) STEREO_ACC_C(h7, q7) }
+        } else {
+          for (int i = 0; i < nuse; i += 4) {
+            const double h0 = hq[2 * i], q0 = hq[2 * i + 1], h1 = hq[2 * i + 2], q1 = hq[2 * i + 3];
+            const double h2 = hq[2 * i + 4], q2 = hq[2 * i + 5], h3 = hq[2 * i + 6], q3 = hq[2 * i + 7];
+            STEREO_ACC_C(h0, q0) STEREO_ACC_C(h1, q1) STEREO_ACC_C(h2, q2) STEREO_ACC_C(h3, q3)
+          }
         }
 #undef STEREO_ACC_C
-        bad = bad || cnt != (useful ? 1 : 0);
+        bad = bad | (cnt != (useful ? 1 : 0));
         VMSTAMP(1);
       } else {
       // The sources are broadcast from a per-wave LDS table (one ds_read_b128 per source instead of
@@ -1303,8 +1334,9 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
 #undef STEREO_ACC
       VMSTAMP(1);
       }
-      bad = bad || (m1 < vtrunc && !(m2 - m1 > delta && vtrunc - m1 > delta));
-      need_serial = UNI(act && bad);
+      // (| and &, not || and &&: short-circuit conditions on per-lane fp64 tests become nested exec-mask regions)
+      bad = bad | ((m1 < vtrunc) & !((m2 - m1 > delta) & (vtrunc - m1 > delta)));
+      need_serial = UNI(act & bad);
       MSTAMP(8);
       // The second look (8.6 k cycles) rescues messages whose useful cones are merely close; on volumes
       // with exact ties (the flat columns of an NCC volume: 442 k failed certificates per 10 iterations
@@ -1326,7 +1358,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
       } else if (look_streak) {
         *look_streak = 0;
       }
-      out = m1 < vtrunc ? m1 : vtrunc;
+      out = min_raw(m1, vtrunc);   // m1 < vtrunc ? m1 : vtrunc (no NaN on either side)
       if (need_serial && lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
     }
     if (KERNEL == 2 && p.certificate) {

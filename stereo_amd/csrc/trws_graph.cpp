@@ -487,6 +487,10 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
         uint32_t pk[2] = {0, 0};
         for (int k = 0; k < 8; ++k) pk[k >> 2] |= (uint32_t)(uint8_t)(int8_t)D[12 + k] << (8 * (k & 3));
         D[41] = (int32_t)pk[0]; D[42] = (int32_t)pk[1];
+        uint32_t fetch = 0;
+        for (int k = nout; k < nout + nin && k < 8; ++k)
+          if (D[12 + k] < 0) fetch |= 1u << k;
+        D[kDescFetch] = (int32_t)fetch;
       }
       };
       {

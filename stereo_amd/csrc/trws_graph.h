@@ -107,6 +107,10 @@ constexpr int kDescRemote = 43, kDescEpos = 44;
 //            numbering (valid where bit k of word 43 is set)
 //   words 53, 54: the node's id in the previous / next strip's numbering (bits 16 / 17 of word 43)
 constexpr int kDescPeerEdge = 45, kDescPeerNode = 53;
+//   word 55: bits 0-7: edge k of the node's list (k >= n_out: an incoming edge) brings its message from GLOBAL memory --
+//            the other end was not visited one or two steps earlier in the same run, so a loader fetches the row (and
+//            that node's label) behind the node's completion flag
+constexpr int kDescFetch = 55;
 
 // Strip-local storage.  A strip keeps arrays only for what it touches: its own nodes, the nodes
 // one edge away (whose flags it waits on and whose labels its primal pass reads), and the edges

@@ -12,6 +12,8 @@
 namespace stereo {
 namespace {
 
+#define RLI(v, i) __builtin_amdgcn_readlane((v), (i))
+
 // ---- pipelined persistent sweep (K <= 64): role-specialised waves ---------------------
 // Same dataflow schedule and arithmetic as trws_persistent_kernel, but the global-memory traffic
 // of a visit is taken off the critical path by dedicated waves of the workgroup:
@@ -36,6 +38,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
   int *ctl = (int *)(hqtab + kPipeCompute * kPipeTab);    // [0] run, [1] abort
   int *dring = ctl + 4;                                   // the last three descriptors (the storer's comes from here, not from HBM)
   double *zrow = (double *)(dring + 3 * kWave);           // 64 zeros: where the Di loop finds the message rows a node does not have
+  double *gtab = zrow + kWave;                            // gtab[k] = (double)1 / (double)k, k = 1 .. 8 (MRFEnergy.cpp:207-228), divided once
   const int K = p.K;
   const double inf = __builtin_huge_val();
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -49,6 +52,16 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
   const int perm_shared = (SHARED && wave < kPipeCompute) ? (act ? (int)p.perm_pos[lane] : lane) : -1;  // source order by position, once
   if (tid == 0) ctl[1] = 0;
   if (tid < kWave) zrow[tid] = 0.0;
+  if (tid < 16) gtab[tid] = (double)1 / (double)(tid > 0 ? tid : 1);
+  // A visit is bound by the instructions the CU's four SIMDs issue for all twelve waves (~4400 per visit
+  // before round 4, 45 % of them scalar), so the service waves are written branch-poor: no exec-mask region
+  // per row -- a lane beyond the last label works on label K - 1 again (loads read an element that exists,
+  // stores repeat lane K - 1's value at lane K - 1's address), a row the node does not have is skipped by
+  // ONE scalar branch on a uniform count or on a mask the host put into the descriptor (word 55: which
+  // incoming rows come from global memory), row addresses are one unsigned 32 x 32 -> 64 multiply and one
+  // shift-add on a per-lane base, and values one lane needs from another lane's descriptor word come by
+  // ds_bpermute instead of chains of eight compares and selects.
+#define PIPE_ROW(BASE, E) ((BASE) + (size_t)((unsigned long long)(unsigned)(E) * (unsigned long long)(unsigned)Kv))
   if (wave < kPipeCompute && lane < 2 * kPipePad) {
     // padding of the source tables (entries -16 .. -1 and 64 .. 79): never overwritten afterwards
     double *e = hqtab + wave * kPipeTab + 4 * (lane < kPipePad ? lane : kWave + lane);
@@ -73,32 +86,25 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
 #define PIPE_LOAD8(DST, PTR) DST = *(PTR)   /* plain loads: the compiler keeps them in flight across the barrier and waits at the first use */
 #define PIPE_REQUEST_OWN(W)                                                                          \
     do {                                                                                             \
-      const NodeDesc rq = decode_desc(W);                                                            \
-      const int rtot = rq.nout + rq.nin;                                                             \
-      if (act) { const double *a_ = p.unary + (size_t)rq.node * K + lane; PIPE_LOAD8(rdk, a_); }     \
+      const int rf_ = RLI((W), 2);                                                                   \
+      const int rnout = rf_ & 15, rtot = rnout + ((rf_ >> 4) & 15);                                  \
+      { const double *a_ = PIPE_ROW(p.unary + lkv, RLI((W), 0)); PIPE_LOAD8(rdk, a_); }                   \
       _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                \
-        if (j < rtot && act) {                                                                       \
-          const size_t off = (size_t)rq.e[j] * K + lane;                                             \
-          if (j < rq.nout && (UPDATE || PRIMAL)) { const double *a_ = p.msg + off; PIPE_LOAD8(rmv[j], a_); } \
-          if (!SHARED) {                                                                             \
-            const double *a_ = p.q + off, *b_ = p.qprim + off;                                       \
-            PIPE_LOAD8(rqv[j], a_); PIPE_LOAD8(rqpv[j], b_);                                         \
-          }                                                                                          \
+        if (j < rnout && (UPDATE || PRIMAL)) { const double *a_ = PIPE_ROW((p.msg + lkv), RLI((W), 4 + j)); PIPE_LOAD8(rmv[j], a_); } \
+        if (!SHARED && j < rtot) {                                                                   \
+          const double *a_ = PIPE_ROW(p.q + lkv, RLI((W), 4 + j)), *b_ = PIPE_ROW(p.qprim + lkv, RLI((W), 4 + j)); \
+          PIPE_LOAD8(rqv[j], a_); PIPE_LOAD8(rqpv[j], b_);                                           \
         }                                                                                            \
       }                                                                                              \
-      rav = 0;                                                                                       \
-      if (lane < rtot) {                                                                             \
-        int ej = 0;                                                                                  \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                \
-          if (lane == j) ej = rq.e[j];                                                               \
-        rav = p.alpha[ej];                                                                           \
-      }                                                                                              \
+      rav = p.alpha[__shfl((W), 4 + (lane & 7), kWave)];  /* lane j: weight of the node's edge j (words of absent edges hold 0) */ \
     } while (0)
+    // storer: node pos's descriptor word (per lane), fetched during visit pos and used right behind the barrier that ends it
+    int sw = 0;
     if (wave == kPipeCompute + 2) {
       wa1 = desc[(size_t)p0 * DW + lane];
       if (p0 + 1 < p1) wa2 = desc[(size_t)(p0 + 1) * DW + lane];
       if (p0 + 2 < p1) wa3 = desc[(size_t)(p0 + 2) * DW + lane];
-      PIPE_REQUEST_OWN(wa1);
+      { const int Kv = K, lkv = lane < K ? lane : K - 1; PIPE_REQUEST_OWN(wa1); }
     }
     if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2] = wall_clock64();
     unsigned long long busy = 0;
@@ -119,6 +125,13 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
       double *hcur = hand + (pos & 3) * 8 * kWave, *hprev = hand + ((pos - 1) & 3) * 8 * kWave;
       double *sc = scal + (pos & 1) * kScalDoubles;
       const bool have_node = pos >= p0 && pos < p1;
+      // (opaque copies, renewed every visit: what is derived from them -- per-lane row bases, the label-count
+      //  tests of the envelope code, ... -- is recomputed where it is used, one instruction each; left visible as
+      //  loop invariants, the compiler hoists dozens of such values out of the visit loop and keeps them in
+      //  spilled registers, scalar ones in VGPR lanes, vector ones in scratch memory)
+      int Kv = K;
+      asm volatile("" : "+s"(Kv));
+      const int lkv = lane < Kv ? lane : Kv - 1;
 
       if (wave < kPipeCompute) {
         // ------------------------------------------------------------ compute
@@ -136,12 +149,14 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           // (all eight rows are requested together and added in list order; a row the node does not have
           //  is the zero row -- x + 0.0 == x --, so nothing here branches on the node's degree and the
           //  reads share one LDS latency instead of paying one each)
-          {
+          //  (per-edge positions: two batches of four -- that kernel has no registers to spare)
+#pragma unroll
+          for (int b = 0; b < 8; b += (SHARED ? 8 : 4)) {
             double rowv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) rowv[j] = lds[__builtin_amdgcn_readlane(myrow, j) + lane];
+            for (int j = 0; j < (SHARED ? 8 : 4); ++j) rowv[j] = lds[__builtin_amdgcn_readlane(myrow, b + j) + lane];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) Di += rowv[j];
+            for (int j = 0; j < (SHARED ? 8 : 4); ++j) Di += rowv[j];
           }
           double node_vmin = 0;
           if (BACKWARD) {
@@ -164,12 +179,12 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
                 qsrc = src_is_qprim ? b_ : a_;
                 qdst = src_is_qprim ? a_ : b_;
                 const int e = __builtin_amdgcn_readfirstlane(sti[4 + j]);
-                perm = (src_is_qprim ? p.perm_qp : p.perm_q) + (size_t)e * K;
+                perm = (src_is_qprim ? p.perm_qp : p.perm_q) + (size_t)e * Kv;
               }
               const double alpha = st[kStA + j];
               VSTAMP(2);
               double newm = 0;
-              const double v = message_regs<KERNEL, SHARED>(p, K, alpha, h, qsrc, qdst, perm, newm, lane,
+              const double v = message_regs<KERNEL, SHARED>(p, Kv, alpha, h, qsrc, qdst, perm, newm, lane,
                                                     hqtab + wave * kPipeTab + 4 * kPipePad, (SHARED && p.win_ok) ? p.window : -1, &look_streak
 #ifdef STEREO_HIP_VISIT_PROFILE
                                                     , wave == 0 ? macc : nullptr
@@ -178,7 +193,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
 #endif
                                                     , perm_shared);
               VSTAMP(3);
-              if (act) hcur[j * kWave + lane] = newm;
+              hcur[j * kWave + lane] = newm;   // (lanes beyond K fill the row's padding)
               if (BACKWARD && lane == 0) sc[j] = v;
             }
           }
@@ -189,53 +204,55 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
         if (pos + 1 >= p0 && pos + 1 < p1) {
           const int w = wnext;
           if (pos + 2 < p1) wnext = desc[(size_t)(pos + 2) * DW + lane];
-          const NodeDesc nx = decode_desc(w);
           int *stni = (int *)(stn + kStI);
           stni[lane] = w;
           dring[((pos + 1) % 3) * kWave + lane] = w;
+          const int f = RLI(w, 2);
+          const int nout = f & 15, ntot = nout + ((f >> 4) & 15), ndep = (f >> 8) & 15;
+          const int fm = RLI(w, kDescFetch) & 255;   // incoming rows that come from global memory (behind flags)
+          const int j8 = lane & 7;
+          const int sl = __shfl(w, 12 + j8, kWave);  // lane j: hand-over slot of the node's edge j, label source
+          const int xn = __shfl(w, 32 + j8, kWave);
           {
             // where the compute waves find the node's message rows at visit pos + 1: a message handed
             // over inside the run sits in the ring of the last two visits, everything else in this
-            // stage -- decided once here instead of by every compute wave in scalar code
-            int slr = -1;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (lane == j) slr = j >= nx.nout ? nx.slot[j] : -1;
-            const int row = lane >= nx.nout + nx.nin ? (int)(zrow - lds)
-                          : slr >= 8 ? (int)(hand - lds) + ((pos - 1) & 3) * 8 * kWave + (slr - 8) * kWave
-                          : slr >= 0 ? (int)(hand - lds) + (pos & 3) * 8 * kWave + slr * kWave
-                                     : (int)(stn - lds) + kStM + lane * kWave;
+            // stage, a row the node does not have is the zero row -- decided once here instead of by
+            // every compute wave in scalar code
+            const int row = j8 >= ntot ? (int)(zrow - lds)
+                          : (j8 < nout || sl < 0) ? (int)(stn - lds) + kStM + j8 * kWave
+                          : sl >= 8 ? (int)(hand - lds) + ((pos - 1) & 3) * 8 * kWave + (sl - 8) * kWave
+                                    : (int)(hand - lds) + (pos & 3) * 8 * kWave + sl * kWave;
             if (lane < 8) stni[72 + lane] = row;
           }
-          const int ntot = nx.nout + nx.nin;
           // (everything that does not depend on other workgroups -- unary, previous-sweep messages,
           //  positions, weights -- is loader A's, below, two visits ahead)
-          double mv[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) mv[j] = 0;
-          int pxv = 0, xn = 0, sl = 0;
-          if (lane < ntot) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (lane == j) { xn = nx.xn[j]; sl = nx.slot[j]; }
-          }
           // the completion flags of the foreign neighbours, then their data
           // (all flags are polled together: lane j watches dependency j)
 #ifdef STEREO_HIP_VISIT_PROFILE
           const long long lb0 = (long long)__builtin_readcyclecounter();
 #endif
-          wait_for_dependencies(p, nx.ndep, nx.dep[0], nx.dep[1], nx.dep[2], nx.dep[3], nx.rank, epoch, lane, ctl + 1);
+          if (ndep > 0) wait_for_dependencies_w(p, ndep, __shfl(w, 20 + (lane & 3), kWave), RLI(w, 1), epoch, lane, ctl + 1);
 #ifdef STEREO_HIP_VISIT_PROFILE
           const long long lb1 = (long long)__builtin_readcyclecounter();
 #endif
+          // (at most four rows come from global memory -- a node has at most four foreign dependencies --: the
+          //  set bits of the mask are walked, row number and edge id of the k-th one are scalars)
+          double mv[4];
+          int jr[4];
+          {
+            int m = UPDATE ? fm : 0;
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (UPDATE && j >= nx.nout && j < ntot && nx.slot[j] < 0 && act)
-              mv[j] = ld_sc1(p.msg + (size_t)nx.e[j] * K + lane);
-          if (PRIMAL && lane < ntot && lane >= nx.nout && sl < 0) pxv = ld_sc1(p.x + xn);
+            for (int k = 0; k < 4; ++k) {
+              jr[k] = m ? __builtin_ctz(m) : -1;
+              m &= m - 1;
+              if (jr[k] >= 0) mv[k] = ld_sc1(PIPE_ROW((p.msg + lkv), __builtin_amdgcn_readlane(w, 4 + jr[k])));
+            }
+          }
+          int pxv = 0;
+          if (PRIMAL && ((fm >> j8) & 1)) pxv = ld_sc1(p.x + xn);
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (j >= nx.nout && j < ntot && act) stn[kStM + j * kWave + lane] = mv[j];
+          for (int k = 0; k < 4; ++k)
+            if (jr[k] >= 0) stn[kStM + jr[k] * kWave + lane] = mv[k];
           if (lane < 8) stni[64 + lane] = pxv;
 #ifdef STEREO_HIP_VISIT_PROFILE
           if (pos > p0 + 3) {  // steady state only: the first visits of a run wait for the wavefront to arrive
@@ -254,18 +271,16 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
         // go out and stay in flight across the barrier (plain loads: the compiler waits at their first use,
         // which is in the next visit).
         if (pos + 1 >= p0 && pos + 1 < p1) {
-          const NodeDesc nx = decode_desc(wa1);
-          const int ntot = nx.nout + nx.nin;
-          if (act) stn[kStD + lane] = rdk;
+          const int f = RLI(wa1, 2);
+          const int nout = f & 15, nin = (f >> 4) & 15;
+          stn[kStD + lane] = rdk;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            if (j < ntot && act) {
-              if (j < nx.nout) stn[kStM + j * kWave + lane] = rmv[j];
-              if (!SHARED) { stn[kStQ + j * kWave + lane] = rqv[j]; stn[kStQP + j * kWave + lane] = rqpv[j]; }
-            }
+            if (j < nout) stn[kStM + j * kWave + lane] = rmv[j];
+            if (!SHARED && j < nout + nin) { stn[kStQ + j * kWave + lane] = rqv[j]; stn[kStQP + j * kWave + lane] = rqpv[j]; }
           }
           if (lane < 8) stn[kStA + lane] = rav;
-          if (lane == 0) stn[kStG] = (double)1 / (double)(nx.nout > nx.nin ? nx.nout : nx.nin);
+          if (lane == 0) stn[kStG] = gtab[nout > nin ? nout : nin];
           int wa4 = 0;
           if (pos + 4 < p1) wa4 = desc[(size_t)(pos + 4) * DW + lane];  // three nodes ahead: waited for at the top of the next visit
           wa1 = wa2; wa2 = wa3; wa3 = wa4;
@@ -273,28 +288,43 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
         }
       } else if (wave == kPipeCompute + 1) {
         // ------------------------------------------------------------ storer: node pos - 1
+        // The node's descriptor word is in a register since the previous visit (below) and nothing but the
+        // fields the stores need is read from it, each row address being a scalar multiply and a shift-add:
+        // the flag a row below waits for used to rise ~3 k cycles into this visit, 2.2 k of them the
+        // decoding of all 55 descriptor fields and an exec-mask region per row.
         if (pos - 1 >= p0) {
-          const NodeDesc pd = decode_desc(dring[((pos - 1) % 3) * kWave + lane]);
           const double *scp = scal + ((pos + 1) & 1) * kScalDoubles;  // parity of pos - 1
+          const int s_nout = RLI(sw, 2) & 15;
+          const int s_remote = RLI(sw, kDescRemote), s_pn0 = RLI(sw, kDescPeerNode), s_pn1 = RLI(sw, kDescPeerNode + 1);
           if (UPDATE) {
+            if (s_remote & 255) {   // strips: some rows go to a neighbour's array, under the neighbour's edge numbers
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              if (j < pd.nout) {
-                double *mb = ((pd.remote >> j) & 1) ? (((pd.remote >> (8 + j)) & 1) ? p.peer_msg1 : p.peer_msg0) : p.msg;
-                const int ej = ((pd.remote >> j) & 1) ? pd.re[j] : pd.e[j];  // the neighbour numbers the edge itself
-                if (act) st_sc1(mb + (size_t)ej * K + lane, hprev[j * kWave + lane]);
-                if (BACKWARD && lane == 0) p.lbterms[pd.lbe[j]] = scp[j];
+              for (int j = 0; j < 8; ++j) {
+                if (j < s_nout) {
+                  double *mb = ((s_remote >> j) & 1) ? (((s_remote >> (8 + j)) & 1) ? p.peer_msg1 : p.peer_msg0) : p.msg;
+                  const int ej = ((s_remote >> j) & 1) ? RLI(sw, kDescPeerEdge + j) : RLI(sw, 4 + j);
+                  st_sc1(PIPE_ROW(mb + lkv, ej), hprev[j * kWave + lkv]);
+                }
               }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if (j < s_nout) st_sc1(PIPE_ROW((p.msg + lkv), RLI(sw, 4 + j)), hprev[j * kWave + lkv]);
             }
-            if (BACKWARD && lane == 0) p.lbterms[pd.lbn] = scp[8];
+            if (BACKWARD) {
+              const int s_lbe = __shfl(sw, 24 + (lane & 7), kWave);   // lane j: position of message j's lower-bound term
+              if (lane < s_nout) p.lbterms[s_lbe] = scp[lane];
+              if (lane == 0) p.lbterms[RLI(sw, 3)] = scp[8];
+            }
           }
           if (PRIMAL && lane == 0) {
             const int xi = ((const int *)(scp + 10))[0];
-            st_sc1(p.x + pd.node, xi);
-            if (pd.remote & (1 << 16)) st_sc1(p.peer_x0 + pd.pn[0], xi);
-            if (pd.remote & (1 << 17)) st_sc1(p.peer_x1 + pd.pn[1], xi);
-            p.eterms[pd.epos] = scp[9];
+            st_sc1(p.x + RLI(sw, 0), xi);
+            if (s_remote & (1 << 16)) st_sc1(p.peer_x0 + s_pn0, xi);
+            if (s_remote & (1 << 17)) st_sc1(p.peer_x1 + s_pn1, xi);
+            p.eterms[RLI(sw, kDescEpos)] = scp[9];
           }
+          const int s_rank = RLI(sw, 1);
 #ifdef STEREO_HIP_VISIT_PROFILE
           const long long sb0 = (long long)__builtin_readcyclecounter();
 #endif
@@ -306,10 +336,14 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           }
 #endif
           if (lane == 0) {
-            st_sc1(p.done + pd.rank, epoch);
-            if (pd.remote & (1 << 16)) st_sc1(p.peer_done0 + pd.pn[0], epoch);
-            if (pd.remote & (1 << 17)) st_sc1(p.peer_done1 + pd.pn[1], epoch);
+            st_sc1(p.done + s_rank, epoch);
+            if (s_remote & (1 << 16)) st_sc1(p.peer_done0 + s_pn0, epoch);
+            if (s_remote & (1 << 17)) st_sc1(p.peer_done1 + s_pn1, epoch);
           }
+        }
+        if (have_node) {
+          // node pos's descriptor (it reached dring during visit pos - 1)
+          sw = dring[(pos % 3) * kWave + lane];
         }
       } else if (wave == kPipeCompute + 3) {
         // ------------------------------------------------------------ primal of node pos
@@ -386,11 +420,13 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_group_kernel(GroupArgs
 #undef PIPE_REQUEST_OWN
 #undef PIPE_LOAD8
 #undef VSTAMP
+#undef PIPE_ROW
+#undef RLI
 
 }  // namespace
 
 size_t pipe_lds_bytes() {
-  return sizeof(double) * (2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * kPipeTab + 2 + 3 * kWave / 2 + kWave);
+  return sizeof(double) * (2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * kPipeTab + 2 + 3 * kWave / 2 + kWave + 16);
 }
 int pipe_threads() { return kPipeThreads; }
 
