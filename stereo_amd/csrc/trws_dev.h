@@ -1235,7 +1235,10 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
           const double h0 = hq[0], q0 = hq[1], h1 = hq[2], q1 = hq[3], h2 = hq[4], q2 = hq[5], h3 = hq[6], q3 = hq[7];
           const double h4 = hq[8], q4 = hq[9], h5 = hq[10], q5 = hq[11], h6 = hq[12], q6 = hq[13], h7 = hq[14], q7 = hq[15];
           STEREO_ACC_C(h0, q0) STEREO_ACC_C(h1, q1) STEREO_ACC_C(h2, q2) STEREO_ACC_C(h3, q3)
-          if (nuse > 4) { STEREO_ACC_C(h4, q4) STEREO_ACC_C(h5, q5) STEREO_ACC_C(h6, q6) STEREO_ACC_C(h7, q7) }
+          if (nuse > 4) {
+            STEREO_ACC_C(h4, q4) STEREO_ACC_C(h5, q5)
+            if (nuse > 6) { STEREO_ACC_C(h6, q6) STEREO_ACC_C(h7, q7) }
+          }
         } else {
           for (int i = 0; i < nuse; i += 4) {
             const double h0 = hq[2 * i], q0 = hq[2 * i + 1], h1 = hq[2 * i + 2], q1 = hq[2 * i + 3];

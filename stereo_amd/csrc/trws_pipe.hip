@@ -125,6 +125,10 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
       double *hcur = hand + (pos & 3) * 8 * kWave, *hprev = hand + ((pos - 1) & 3) * 8 * kWave;
       double *sc = scal + (pos & 1) * kScalDoubles;
       const bool have_node = pos >= p0 && pos < p1;
+      // (the workgroup's abort word -- a loader's wait gave up during the PREVIOUS visit -- is requested here and
+      //  looked at in front of the barrier that ends this visit: read behind that barrier, as it used to be, its
+      //  LDS round trip was the first thing on every wave's path into the next visit)
+      const int aborted = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       // (opaque copies, renewed every visit: what is derived from them -- per-lane row bases, the label-count
       //  tests of the envelope code, ... -- is recomputed where it is used, one instruction each; left visible as
       //  loop invariants, the compiler hoists dozens of such values out of the visit loop and keeps them in
@@ -228,6 +232,21 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           //  positions, weights -- is loader A's, below, two visits ahead)
           // the completion flags of the foreign neighbours, then their data
           // (all flags are polled together: lane j watches dependency j)
+          // (the rows that come from global memory -- two per foreign dependency, four on an ordinary row or
+          //  chain node, up to eight where a node hangs on four other runs -- are the set bits of the mask, walked
+          //  four at a time: row number and edge id of the k-th one are scalars; the addresses of the first four are
+          //  formed BEFORE the wait, so that behind the flags nothing but the loads themselves is left)
+          double mv[4];
+          const double *fa[4];
+          int jr[4];
+          int mrest = UPDATE ? fm : 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            jr[k] = mrest ? __builtin_ctz(mrest) : -1;
+            mrest &= mrest - 1;
+            fa[k] = PIPE_ROW((p.msg + lkv), __builtin_amdgcn_readlane(w, 4 + (jr[k] >= 0 ? jr[k] : 0)));
+          }
+          const int32_t *xa = p.x + xn;
 #ifdef STEREO_HIP_VISIT_PROFILE
           const long long lb0 = (long long)__builtin_readcyclecounter();
 #endif
@@ -235,24 +254,19 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
 #ifdef STEREO_HIP_VISIT_PROFILE
           const long long lb1 = (long long)__builtin_readcyclecounter();
 #endif
-          // (at most four rows come from global memory -- a node has at most four foreign dependencies --: the
-          //  set bits of the mask are walked, row number and edge id of the k-th one are scalars)
-          double mv[4];
-          int jr[4];
-          {
-            int m = UPDATE ? fm : 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              jr[k] = m ? __builtin_ctz(m) : -1;
-              m &= m - 1;
-              if (jr[k] >= 0) mv[k] = ld_sc1(PIPE_ROW((p.msg + lkv), __builtin_amdgcn_readlane(w, 4 + jr[k])));
-            }
-          }
+          for (int k = 0; k < 4; ++k)
+            if (jr[k] >= 0) mv[k] = ld_sc1(fa[k]);
           int pxv = 0;
-          if (PRIMAL && ((fm >> j8) & 1)) pxv = ld_sc1(p.x + xn);
+          if (PRIMAL && ((fm >> j8) & 1)) pxv = ld_sc1(xa);
 #pragma unroll
           for (int k = 0; k < 4; ++k)
             if (jr[k] >= 0) stn[kStM + jr[k] * kWave + lane] = mv[k];
+          while (mrest) {   // rows five to eight (rare)
+            const int jx = __builtin_ctz(mrest);
+            mrest &= mrest - 1;
+            stn[kStM + jx * kWave + lane] = ld_sc1(PIPE_ROW((p.msg + lkv), __builtin_amdgcn_readlane(w, 4 + jx)));
+          }
           if (lane < 8) stni[64 + lane] = pxv;
 #ifdef STEREO_HIP_VISIT_PROFILE
           if (pos > p0 + 3) {  // steady state only: the first visits of a run wait for the wavefront to arrive
@@ -386,9 +400,9 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
       }
       if (p.prof) busy += (unsigned long long)((long long)__builtin_readcyclecounter() - tstart);
       VSTAMP(4);
+      if (aborted) return;  // a dependency wait gave up (bounded spin); host reports it
       __syncthreads();
       VSTAMP(5);
-      if (ctl[1]) return;  // a dependency wait gave up (bounded spin); host reports it
     }
     if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2 + 1] = wall_clock64();
     if (p.prof && lane == 0 && (p.prof_run < 0 || run == p.prof_run)) {

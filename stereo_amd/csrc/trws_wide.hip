@@ -359,26 +359,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) pq[c] = WPOS(c);
                 double m1[4] = {inf, inf, inf, inf};
-                if (nuse <= kWideSparse && w <= 64) {
-                  // (a cone only reaches the destinations within w labels of it, see the certified path below:
-                  //  the chunks beyond get nothing from it -- and plain min-plus owes them no test either)
-#pragma unroll
-                  for (int c = 0; c < 4; ++c) {
-                    unsigned long long mk = um[c];
-                    while (mk) {
-                      const int l = __builtin_ctzll(mk);
-                      mk &= mk - 1;
-                      const double hi = readlane_f64(h[c], l), qi = readlane_f64(pq[c], l);
-                      if (l >= w && l < kWave - w) {
-                        m1[c] = min_raw(m1[c], pair_cost<1>(alpha, pq[c] - qi, hi));
-                      } else {
-#pragma unroll
-                        for (int cc = 0; cc < 4; ++cc)
-                          if (cc >= c - 1 && cc <= c + 1) m1[cc] = min_raw(m1[cc], pair_cost<1>(alpha, pq[cc] - qi, hi));
-                      }
-                    }
-                  }
-                } else if (nuse <= kWideSparse) {
+                if (nuse <= kWideSparse) {
 #pragma unroll
                   for (int c = 0; c < 4; ++c) {
                     unsigned long long mk = um[c];
@@ -455,68 +436,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                 double m1[4] = {inf, inf, inf, inf}, m2[4] = {inf, inf, inf, inf};
                 bool bad = false;
                 if (!(delta < inf)) bad = true;  // no finite scale: the serial construction decides
-                else if (nuse <= kWideSparse && w <= 64) {
-                  // A cone only REACHES the destinations within `w` labels of it -- farther away its cost is
-                  // >= vTrunc bit for bit (window) and neither minimum can use it -- so of the
-                  // four 64-label chunks a lane holds it touches its own, and a neighbouring one only from
-                  // the first or last w lanes of its chunk.  What EVERY destination still owes the cone is
-                  // the tangency test (cone t on an arm of cone i, however far: the reference's construction
-                  // drops a cone that passes exactly through the apex on top of its stack), and for a whole
-                  // chunk on one side of the cone that is one subtraction on keys formed once per message:
-                  // u_t - u_i right of it, v_t - v_i left of it (u = h - alpha q, v = h + alpha q; the cost's
-                  // own c_i(t) - h_t equals them up to rounding, 1e-16 against a delta of 1e-9).  So a visit
-                  // of a cone costs ~10 instructions for each chunk it reaches and 3 for the others, chosen
-                  // by ONE uniform branch per cone on its lane (bodies specialised per source chunk), instead
-                  // of ~12 for all four.  Matches are counted per lane (compare + add-with-carry), the lane's
-                  // own useful cones match themselves exactly once each: any other count is a near tangency.
-                  double uu[4], vv[4];
-#pragma unroll
-                  for (int c = 0; c < 4; ++c) {
-                    const double aq = alpha * pq[c];
-                    uu[c] = h[c] - aq; vv[c] = h[c] + aq;
-                  }
-                  int cnt = 0;
-#define WIDE_COUNT(X) asm("v_cmp_le_f64_e64 vcc, |%1|, %2\n\ts_nop 1\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc" : "+v"(cnt) : "v"(X), "v"(delta) : "vcc")
-#define WIDE_NEAR(cc)                                                                  \
-  {                                                                                    \
-    const double cst = pair_cost<1>(alpha, pq[cc] - qi, hi);                           \
-    const double lo_ = min_raw(m1[cc], cst), hi_ = max_raw(m1[cc], cst);               \
-    const double dc_ = cst - h[cc];                                                    \
-    m2[cc] = min_raw(m2[cc], hi_);                                                     \
-    m1[cc] = lo_;                                                                      \
-    WIDE_COUNT(dc_);                                                                   \
-  }
-#define WIDE_FAR(cc, c) { const double dk_ = (cc) > (c) ? uu[cc] - ui : vv[cc] - vi; WIDE_COUNT(dk_); }
-#pragma unroll
-                  for (int c = 0; c < 4; ++c) {
-                    unsigned long long mk = um[c];
-                    while (mk) {
-                      const int l = __builtin_ctzll(mk);
-                      mk &= mk - 1;
-                      const double hi = readlane_f64(h[c], l), qi = readlane_f64(pq[c], l);
-                      const double aqi = alpha * qi;                 // (the lane's own expressions: same bits as uu / vv of lane l)
-                      const double ui = hi - aqi, vi = hi + aqi;
-                      if (l >= w && l < kWave - w) {                 // reaches its own chunk only
-#pragma unroll
-                        for (int cc = 0; cc < 4; ++cc) {
-                          if (cc == c) WIDE_NEAR(cc) else WIDE_FAR(cc, c)
-                        }
-                      } else {                                       // ... and (at most) the neighbouring chunks
-#pragma unroll
-                        for (int cc = 0; cc < 4; ++cc) {
-                          if (cc >= c - 1 && cc <= c + 1) WIDE_NEAR(cc) else WIDE_FAR(cc, c)
-                        }
-                      }
-                    }
-                  }
-#undef WIDE_FAR
-#undef WIDE_NEAR
-#undef WIDE_COUNT
-                  int expect = 0;
-#pragma unroll
-                  for (int c = 0; c < 4; ++c) expect += (int)((um[c] >> lane) & 1ull);
-                  bad = cnt != expect;
-                } else if (nuse <= kWideSparse) {
+                else if (nuse <= kWideSparse) {
                   int matches = 0;
 #pragma unroll
                   for (int c = 0; c < 4; ++c) {
