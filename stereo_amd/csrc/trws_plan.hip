@@ -773,6 +773,12 @@ void stereo_trws_plan_destroy(stereo_trws_plan *plan) {
                      (double)v[21] / v[22], v[22]);
         std::fprintf(stderr, "[stereo_hip prof wide] cycles from barrier to barrier arrival, per wave:");
         for (int i = 0; i < 16; ++i) std::fprintf(stderr, " %.0f", (double)v[32 + i] / v[22]);
+        if (v[28] | v[29])
+          std::fprintf(stderr, "\n[stereo_hip prof wide] loader B: request inside the node's own visit %.0f cycles x %llu | staging (incl. wait for "
+                               "parked loads) %.0f per visit | request two visits ahead %.0f x %llu",
+                       v[28] ? (double)v[24] / v[28] : 0.0, v[28], (double)v[25] / v[22], v[29] ? (double)v[26] / v[29] : 0.0, v[29]);
+        std::fprintf(stderr, "\n[stereo_hip prof wide] visits with more than 8000 cycles to the barrier, per wave:");
+        for (int i = 0; i < 12; ++i) std::fprintf(stderr, " %llu", v[48 + i]);
         std::fprintf(stderr, "\n");
       }
     }

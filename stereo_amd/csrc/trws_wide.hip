@@ -39,6 +39,12 @@ namespace {
 // completion flags -- and both run two visits ahead with their requests parked in registers, so
 // that no HBM round trip lies inside a visit.  One hardware barrier per visit.
 // Kernel 1 (truncated linear) only; kernel 2 above K = 64 stays on the generic kernel.
+// (Round 4: a "reach-aware" useful-cone loop -- the ~10-instruction update only for the label chunks within the
+// truncation window of a cone, a 4-instruction key test u_t - u_i / v_t - v_i for the chunks beyond, one uniform
+// branch per cone choosing a body specialised per source chunk -- executes 30 % fewer instructions per cone and was
+// measured 8-11 % SLOWER in two variants (per-lane add-with-carry counts; scalar popcounts): 77 -> 83 / 86 ms per
+// iteration at 1500x1000x256.  The short dependent compare -> mask -> count chains of the far test stall where the
+// uniform body's four interleaved chunks cover each other's latency, and every cone pays a taken branch.)
 // (Round-3 history, DESIGN.md 4.4: three waves per message with separate closest-pair waves, then
 // three / two waves sharing the destinations of a message, were all slower than one wave per message:
 // a visit is bound by the instructions its SIMDs issue, and every split repeats Di, H and the
@@ -225,7 +231,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
   const double pos_first = p.pos[0], pos_last = p.pos[K - 1];
   // development profile (STEREO_HIP_TRWS_PROF): cycles of wave 0 per phase [0..15], busy cycles of
   // loader / storer / primal [16..18], hardware-barrier wait of wave 0 [19], visits [20]
-  unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pbusy = 0, pwait = 0, pvis = 0;
+  unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pbusy = 0, pwait = 0, pvis = 0, plate = 0;
 #define WSTAMP(i) do { if (wprof) { const long long now_ = (long long)__builtin_readcyclecounter(); pacc[i] += (unsigned long long)(now_ - tmark); tmark = now_; } } while (0)
   __syncthreads();
 
@@ -256,6 +262,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
         const long long now_ = (long long)__builtin_readcyclecounter(); \
         if (wave == 0) pvis += have_node ? 1 : 0; \
         pbusy += (unsigned long long)(now_ - tvisit); \
+        if (now_ - tvisit > 8000) plate += 1; \
         tmark = now_; \
       } \
       BARRIER; \
@@ -798,9 +805,20 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
         pxv = 0;                                                                                          \
         if (PRIMAL && lane < rtot && lane >= rq.nout && sl < 0) pxv = ld_sc1(p.x + xn);                   \
       } while (0)
+#ifdef STEREO_HIP_MESSAGE_PROFILE
+      unsigned long long lbacc[6] = {0, 0, 0, 0, 0, 0};
+#define LBSTAMP(i) do { if (wprof) { const long long n_ = (long long)__builtin_readcyclecounter(); lbacc[i] += (unsigned long long)(n_ - lbm); lbm = n_; } } while (0)
+#define LBCOUNT(i) do { if (wprof) lbacc[i] += 1; } while (0)
+#else
+#define LBSTAMP(i) do { } while (0)
+#define LBCOUNT(i) do { } while (0)
+#endif
       WIDE_VISITS_BEGIN
+#ifdef STEREO_HIP_MESSAGE_PROFILE
+        long long lbm = (long long)__builtin_readcyclecounter();
+#endif
         if (pos + 1 >= p0 && pos + 1 < p1) {
-          if (!parked) WIDE_REQUEST_FOREIGN(w1);
+          if (!parked) { WIDE_REQUEST_FOREIGN(w1); LBSTAMP(0); LBCOUNT(4); }
           const NodeDesc nx = decode_desc(w1);
           int *stni = (int *)(stn + kWStI);
           const int ntot = nx.nout + nx.nin;
@@ -812,13 +830,22 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
             }
           }
           if (lane < 8) stni[64 + lane] = pxv;
+#ifdef STEREO_HIP_MESSAGE_PROFILE
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+          LBSTAMP(1);
           int w4 = 0;
           if (pos + 4 < p1) w4 = desc[(size_t)(pos + 4) * DW + lane];
           w1 = w2; w2 = w3; w3 = w4;
           parked = pos + 2 < p1 && ((__builtin_amdgcn_readlane(w1, 2) >> 12) & 1) != 0;
-          if (parked) WIDE_REQUEST_FOREIGN(w1);
+          if (parked) { WIDE_REQUEST_FOREIGN(w1); LBSTAMP(2); LBCOUNT(5); }
         }
       WIDE_VISITS_END
+#ifdef STEREO_HIP_MESSAGE_PROFILE
+      if (wprof && lane == 0) for (int i = 0; i < 6; ++i) atomicAdd(p.prof + 24 + i, lbacc[i]);
+#endif
+#undef LBSTAMP
+#undef LBCOUNT
 #undef WIDE_REQUEST_FOREIGN
 #undef WIDE_LOAD16_SC1
     } else if (wave == kWideCompute + 1) {
@@ -981,6 +1008,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
     }
     if (wave >= kWideCompute) atomicAdd(p.prof + 16 + (wave - kWideCompute), pbusy);
     atomicAdd(p.prof + 32 + wave, pbusy);
+    atomicAdd(p.prof + 48 + wave, plate);   // visits in which this wave needed more than 8000 cycles to reach the barrier
   }
 }
 template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE>
