@@ -445,6 +445,37 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                 if (!(delta < inf)) bad = true;  // no finite scale: the serial construction decides
                 else if (nuse <= kWideSparse) {
                   int matches = 0;
+#ifdef STEREO_WIDE_FP32_CONES
+                  // MEASUREMENT FLAVOUR ONLY (tools/gpu_fp32_cones.sh): the useful-cone loop in fp32 --
+                  // costs, both minima and the match test on single-precision copies of H and the positions
+                  // (SURVEY 8(d) configs 4 / 5 allow fp32 messages).  Not the reference's bits and not a product mode:
+                  // built into its own library to put a number on "would fp32 messages be faster here".
+                  float hf[4], pf[4], m1f[4], m2f[4];
+                  const float af = (float)alpha, df = (float)delta + 1e-6f * ((float)mag + 1.0f);
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) { hf[c] = (float)h[c]; pf[c] = (float)pq[c]; m1f[c] = __builtin_huge_valf(); m2f[c] = __builtin_huge_valf(); }
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) {
+                    unsigned long long mk = um[c];
+                    while (mk) {
+                      const int l = __builtin_ctzll(mk);
+                      mk &= mk - 1;
+                      const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hf[c]), l));
+                      const float qi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pf[c]), l));
+#pragma unroll
+                      for (int cc = 0; cc < 4; ++cc) {
+                        const float cst = af * __builtin_fabsf(pf[cc] - qi) + hi;
+                        const float lo_ = __builtin_fminf(m1f[cc], cst), hi_ = __builtin_fmaxf(m1f[cc], cst);
+                        m2f[cc] = __builtin_fminf(m2f[cc], hi_);
+                        m1f[cc] = lo_;
+                        matches += __builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_fabsf(cst - hf[cc]) <= df));
+                      }
+                    }
+                  }
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) { m1[c] = (double)m1f[c]; m2[c] = (double)m2f[c] + (double)df * 4; }
+                  bad = false; (void)matches;   // (no serial fallbacks in the measurement: fp32 cannot decide the certificate)
+#else
 #pragma unroll
                   for (int c = 0; c < 4; ++c) {
                     unsigned long long mk = um[c];
@@ -463,6 +494,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                     }
                   }
                   bad = matches != nuse;
+#endif
                 } else {
                   bool crowded = false;
                   {
@@ -547,6 +579,9 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                     out[c] = m1[c] < vtrunc ? m1[c] : vtrunc;
                   }
                 }
+#ifdef STEREO_WIDE_FP32_CONES
+                if (nuse <= kWideSparse) bad = false;   // (measurement flavour: margins of 1e-9 mean nothing in fp32)
+#endif
                 // the smallest entry of a min-plus message on shared positions is min H itself
                 // (destination t sees source t at distance 0; vTrunc >= min H): no reduction
                 vmin = hmin;
