@@ -41,6 +41,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("images", nargs="*")
     ap.add_argument("--size", type=int, nargs=2, default=[375, 450])
+    ap.add_argument("--segpln", action="store_true",
+                    help="proposals = the class's SegPln proposals (dispmap_globalstereo.m:60-201: window matching, LO-RANSAC "
+                         "plane per segment, on the device) over 14 colour / block segmentations standing in for the "
+                         "mean-shift / Felzenszwalb maps of :122-137, instead of the random piecewise-planar stand-ins")
     args = ap.parse_args()
     import stereo_amd
     from stereo_amd import terms as T
@@ -64,7 +68,20 @@ def main():
     dm = stereo_amd.dispmap_globalstereo(images, P, disp_range, disparity_factor, smooth_weights=weights, rng=rng)
     print("object + random start: %.2f s, energy %.6f" % (time.time() - t0, dm.energy()))
     d_lo, d_hi = dm.d_min, dm.d_min + dm.d_step
-    proposals = [piecewise_planar(H, W, cell, rng, d_lo, d_hi) for cell in (8, 12, 16, 24, 32, 48, 64) for _ in range(2)]
+    if args.segpln:
+        # 14 segmentation maps at the scales of `mults` (:122): blocks of growing size, split by coarse colour
+        t1 = time.time()
+        maps = []
+        for m in (1, 2, 3, 4, 5, 6, 7, 3, 5, 8, 12, 24, 50, 100):
+            cell = 4 + 2 * min(m, 30)
+            q = (images[0] // (256 // max(2, 8 - min(m, 6)))).astype(np.int64)
+            lab = ((np.arange(H)[:, None] // cell) * 4096 + (np.arange(W)[None, :] // cell)) * 512 + q[:, :, 0] * 64 + q[:, :, 1] * 8 + q[:, :, 2]
+            maps.append(np.unique(lab, return_inverse=True)[1].reshape(H, W) + 1)
+        proposals = dm.segpln(maps, seed=0)
+        print("SegPln: window matching + %d maps (%d .. %d segments), %.2f s" % (
+            len(maps), min(int(m.max()) for m in maps), max(int(m.max()) for m in maps), time.time() - t1))
+    else:
+        proposals = [piecewise_planar(H, W, cell, rng, d_lo, d_hi) for cell in (8, 12, 16, 24, 32, 48, 64) for _ in range(2)]
     t0 = time.time()
     for k, p in enumerate(proposals):
         e, lb, unl = dm.binary_fusion(p)

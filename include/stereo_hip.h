@@ -25,8 +25,8 @@ extern "C" {
 /* Bumped whenever an entry point is added or a signature changes; the Python binding refuses a
  * library that reports another version (a stale libstereo_hip.so).  3: stereo_hip_device_cus, plan
  * entry points select their plan's device, wall-clock bound on cross-workgroup waits.  4: stereo_fusion_fit_planes,
- * stereo_fusion_fuse_until_convergence. */
-#define STEREO_HIP_ABI_VERSION 4
+ * stereo_fusion_fuse_until_convergence.  5: stereo_segpln_wta, stereo_segpln_planes. */
+#define STEREO_HIP_ABI_VERSION 5
 
 /* ---- library ---------------------------------------------------------- */
 
@@ -435,6 +435,30 @@ int stereo_fusion_simultaneous_planes(stereo_fusion *ctx, const double *planes, 
 int stereo_fusion_simultaneous(stereo_fusion *ctx, const double *proposals, int K, double maxiter,
                                double max_relgap, double *energy, double *trws_energy,
                                double *lower_bound, double *iterations, char *err, size_t errcap);
+
+/* ---- SegPln proposals (dispmap_globalstereo.m:60-201) -------------------------------------
+ * The winner-takes-all disparity map by window matching (:72-113): for every image and every disparity of
+ * `disps` (the class's self.disps: descending, :49) the reference image's pixels are projected, the image is
+ * sampled bilinearly (vgg_interp2, oobv -1000), ephoto of the colour difference (:405) is averaged over the
+ * (2 window + 1)^2 box ('valid') and summed over the images; normalised score, first maximum, disparities with
+ * a score below min_corr (0.07, :112) set to 0, mirrored back to H x W.  images: n_images blocks of H x W x C
+ * doubles (MATLAB layout), the first one the reference image; P: 3 x 4 x n_images column major (the argument
+ * of the class constructor, :67).  wta: H x W column major. */
+int stereo_segpln_wta(const double *images, int n_images, int H, int W, int C, const double *P, const double *disps,
+                      int nd, double col_thresh, int window, double min_corr, double *wta, char *err, size_t errcap);
+/* One proposal of segpln (:140-197) from a segmentation the CALLER supplies (labels 1 .. S, 0 = none; the
+ * mean-shift / Felzenszwalb segmenters of :124-137 are out of scope): per segment the LO-RANSAC of :417-450
+ * (threshold rt = 0.1 at :163, at most max_samples = 500 trials, confidence 0.95) over the world coordinates
+ * [x y 1] / d, then the least-squares plane of the inliers; proposal (4 x N) = [N1 N2 1 N3] on the segment's
+ * pixels, [0 0 1 0] where nothing was fitted, NaN / Inf -> 1e-100.  The reference draws its triples with
+ * randperm; here trial t of segment s takes the three distinct indices splitmix64(seed, s, t, attempt) mod n
+ * (oracle/terms.py:segpln_sample -- the draw is an input of the parity test), the 3 x 3 systems are solved by
+ * Cramer's rule and the least-squares planes through the normal equations in a fixed summation order (MATLAB's
+ * mldivide is outside the reference tree; oracle/terms.py:segpln_planes is the definition, matched bit for
+ * bit).  planes (3 x S) / inliers (S) may be NULL. */
+int stereo_segpln_planes(const double *wta, const int32_t *segments, int H, int W, double rt, uint64_t seed,
+                         int max_samples, double *proposal, int S, double *planes, int32_t *inliers, char *err,
+                         size_t errcap);
 
 #ifdef __cplusplus
 }

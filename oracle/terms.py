@@ -383,3 +383,207 @@ def plane_lattice(best_disp, kernel, radius=5, first=10, step=50):
     H, W = np.asarray(best_disp).shape
     return [plane_from_neighbourhood(best_disp, x, y, radius, kernel)[0]
             for x in range(first, W + 1, step) for y in range(first, H + 1, step)]
+
+
+# ------------------------------------------------------- dispmap_globalstereo.segpln (second half)
+def _interp2_linear_vec(A, X, Y, oobv):
+    """vgg_interp2_linear (above) for many points at once: the same expressions per point, NumPy arrays."""
+    A = np.asarray(A, np.float64)
+    if A.ndim == 2:
+        A = A[:, :, None]
+    h, w, col = A.shape
+    X = np.asarray(X, np.float64); Y = np.asarray(Y, np.float64)
+    out = np.full((X.shape[0], col), float(oobv))
+    with np.errstate(invalid="ignore"):
+        ok = (X >= 1) & (Y >= 1) & (X <= w) & (Y <= h)          # (NaN coordinates fail every comparison: oobv)
+    xi = np.where(ok, X, 1.0).astype(np.int64); yi = np.where(ok, Y, 1.0).astype(np.int64)
+    u = np.where(ok, X, 1.0) - xi; v = np.where(ok, Y, 1.0) - yi
+    x1 = np.minimum(xi, w - 1); y1 = np.minimum(yi, h - 1)      # index of the "+1" sample; unused (weight 0) on the last column / row
+    for c in range(col):
+        a00 = A[yi - 1, xi - 1, c]; a01 = A[yi - 1, x1, c]; a10 = A[y1, xi - 1, c]; a11 = A[y1, x1, c]
+        inner = a00 + (a01 - a00) * u
+        inner = inner + ((a10 - inner) + (a11 - a10) * u) * v
+        lastrow = a00 + (a01 - a00) * u                          # yy == h
+        lastcol = a00 + (a10 - a00) * v                          # xx == w
+        val = np.where(xi == w, np.where(yi == h, a00, lastcol), np.where(yi == h, lastrow, inner))
+        out[:, c] = np.where(ok, val, float(oobv))
+    return out
+
+
+def segpln_wta(images, P, disps, col_thresh=30.0, window=2, min_corr=0.07):
+    """dispmap_globalstereo.m:60-122: the winner-takes-all disparity map behind the SegPln proposals.
+    For every image a and every disparity of `disps` (descending, :49) the reference image's pixels are
+    projected (X = WC P(:,1:3,a)', d = disps(b) P(:,4,a), :83-91), the image sampled bilinearly with oobv
+    -1000 (:94), ephoto of the colour difference (:98, :405) averaged over the (2 window + 1)^2 box
+    ('valid', :99) and accumulated; normalised with the FIRST pixel's out-of-range value (:105-106),
+    first maximum over the disparities (:110), disparity of the winner, 0 where the score is below
+    `min_corr` (:111-112), mirrored back to full size (:113).  images: list of (H, W, C); P (3, 4, n).
+    Returns (H, W) disparities."""
+    ims = [np.asarray(im, np.float64) for im in images]
+    R = np.clip(np.round(ims[0]), 0, 255)                         # R = uint8(images{1}) (:69)
+    H, W, C = R.shape
+    Rvec = R.transpose(1, 0, 2).reshape(H * W, C)
+    Xg, Yg = np.meshgrid(np.arange(1, W + 1, dtype=np.float64), np.arange(1, H + 1, dtype=np.float64))
+    WC = np.stack([Xg.T.reshape(-1), Yg.T.reshape(-1), np.ones(H * W)], 1)   # column-major pixel order
+    P = np.asarray(P, np.float64)
+    disps = np.asarray(disps, np.float64)
+    wn = 2 * window + 1
+    Hv, Wv = H - 2 * window, W - 2 * window
+    ephoto = lambda F: np.log(2.0) - np.log(np.exp(np.sum(F ** 2, 1) * (-1.0 / (col_thresh * C))) + 1.0)
+    corr = np.zeros((Hv, Wv, len(disps)))
+    for a in range(len(ims)):
+        # X = WC * P(:,1:3,a)' (:83), every entry as the explicit sum (x P(k,1) + y P(k,2)) + 1 P(k,3)
+        X = np.stack([(WC[:, 0] * P[k, 0, a] + WC[:, 1] * P[k, 1, a]) + 1.0 * P[k, 2, a] for k in range(3)], 1)
+        P_ = P[:, 3, a]
+        for b, dv in enumerate(disps):
+            d = dv * P_
+            with np.errstate(divide="ignore", invalid="ignore"):
+                Z = 1.0 / (X[:, 2] + d[2])
+                Y = _interp2_linear_vec(ims[a], (X[:, 0] + d[0]) * Z, (X[:, 1] + d[1]) * Z, -1000.0)
+            Y = ephoto(Y - Rvec).reshape(W, H).T                  # (H, W)
+            t = np.zeros((Hv, W))
+            for i in range(wn):                                   # conv2(filt, filt', ., 'valid'): columns, then rows
+                t = t + (1.0 / wn) * Y[i:i + Hv, :]
+            o = np.zeros((Hv, Wv))
+            for j in range(wn):
+                o = o + (1.0 / wn) * t[:, j:j + Wv]
+            corr[:, :, b] += o
+    X1 = ephoto((-1000.0 - Rvec)[:1])[0] * len(ims)
+    corr = (X1 - corr) / X1
+    best = np.argmax(corr, axis=2)                                # first maximum
+    score = np.max(corr, axis=2)
+    out = disps[best]
+    out[score < min_corr] = 0.0
+    return np.pad(out, window, mode="symmetric")
+
+
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
+def segpln_sample(seed, segment, trial, n):
+    """Three distinct indices in [0, n): what `sam = randperm(len); sam = sam(1:3)` (:429-430) draws, from a
+    counter-based generator (MATLAB's stream cannot be reproduced: the draw is an INPUT of the parity test,
+    and both sides take it from this function): k-th index = splitmix64(seed, segment, trial, attempt) mod n,
+    redrawn while it repeats an earlier one."""
+    out = []
+    attempt = 0
+    while len(out) < 3:
+        v = _splitmix64((int(seed) * 0x100000001B3 + int(segment) * 0x1000193 + int(trial) * 64 + attempt) & 0xFFFFFFFFFFFFFFFF) % int(n)
+        attempt += 1
+        if v not in out:
+            out.append(int(v))
+    return out
+
+
+def _solve3(a, b):
+    """3 x 3 solve by Cramer's rule, every product and sum in this fixed association (the device kernel makes
+    the same operations in the same order, no contraction): a (3, 3) rows, b (3,)."""
+    a11, a12, a13 = a[0]; a21, a22, a23 = a[1]; a31, a32, a33 = a[2]
+    c11 = a22 * a33 - a23 * a32; c12 = a21 * a33 - a23 * a31; c13 = a21 * a32 - a22 * a31
+    det = (a11 * c11 - a12 * c12) + a13 * c13
+    b1, b2, b3 = b
+    d1 = (b1 * c11 - a12 * (b2 * a33 - a23 * b3)) + a13 * (b2 * a32 - a22 * b3)
+    d2 = (a11 * (b2 * a33 - a23 * b3) - b1 * c12) + a13 * (a21 * b3 - b2 * a31)
+    d3 = (a11 * (a22 * b3 - b2 * a32) - a12 * (a21 * b3 - b2 * a31)) + b1 * c13
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.array([np.float64(d1) / np.float64(det), np.float64(d2) / np.float64(det), np.float64(d3) / np.float64(det)])
+
+
+def _lstsq3(pts, mask):
+    """pts(mask, :) \\ -1 for an n x 3 system, as the normal equations A'A x = A'(-1) solved by _solve3, the six
+    moments and three right-hand sides summed as the device's wave does: lane l of 64 adds its points
+    l, l + 64, ... in index order, then the lanes are folded 32, 16, 8, 4, 2, 1 apart (lane l += lane l + s).
+    (MATLAB's mldivide works by QR and is outside the reference tree: this restatement IS the definition.)"""
+    n = pts.shape[0]
+    acc = np.zeros((64, 9))
+    for l in range(64):
+        for i in range(l, n, 64):
+            if mask[i]:
+                x, y, z = pts[i]
+                acc[l] += np.array([x * x, x * y, x * z, y * y, y * z, z * z, -x, -y, -z])
+    s = 32
+    while s >= 1:
+        acc[:s] = acc[:s] + acc[s:2 * s]
+        s //= 2
+    xx, xy, xz, yy, yz, zz, bx, by, bz = acc[0]
+    return _solve3(np.array([[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]]), np.array([bx, by, bz]))
+
+
+def _segpln_nsamples(ni, n, pf=3, conf=0.95):
+    q = 1.0
+    for k in range(pf):
+        q = q * ((ni - pf + 1 + k) / (n - pf + 1 + k))       # prod([(ni-pf+1):ni] ./ [(ptNum-pf+1):ptNum])
+    if (1 - q) < np.finfo(np.float64).eps:
+        return 1.0
+    with np.errstate(divide="ignore"):
+        cnt = np.log(1 - conf) / np.log(1 - q)
+    return max(cnt, 1.0)
+
+
+def segpln_rplane(pts, th, seed, segment, max_sam=500):
+    """LO-RANSAC of dispmap_globalstereo.m:417-450 on pts (n, 3): returns the inlier mask."""
+    n = pts.shape[0]
+    inls = np.zeros(n, bool)
+    max_i, no_sam = 3, 0
+    max_sam = float(max_sam)
+    div = np.array([-1.0, -1.0, -1.0])
+    with np.errstate(invalid="ignore", over="ignore"):
+        while no_sam < max_sam:
+            no_sam += 1
+            sam = segpln_sample(seed, segment, no_sam, n)
+            N = _solve3(pts[sam], div)
+            dist = np.abs(((pts[:, 0] * N[0] + pts[:, 1] * N[1]) + pts[:, 2] * N[2]) + 1.0)
+            v = dist < th
+            no_i = int(v.sum())
+            if max_i < no_i:
+                N = _lstsq3(pts, v)
+                dist = np.abs(((pts[:, 0] * N[0] + pts[:, 1] * N[1]) + pts[:, 2] * N[2]) + 1.0)
+                v = dist < th
+                if int(v.sum()) > int(inls.sum()):
+                    inls = v
+                    max_i = no_i
+                    max_sam = min(max_sam, _segpln_nsamples(int(inls.sum()), n))
+    return inls
+
+
+def segpln_planes(wta, segments, seed=0, rt=0.1):
+    """dispmap_globalstereo.m:140-197 for ONE segmentation map: wta (H, W) winner-takes-all disparities,
+    segments (H, W) labels 1 .. S (0: no segment).  World coordinates [x y 1] / d (:141-145), per segment the
+    points with WC(:,3) ~= 0 (:168), LO-RANSAC when more than three (:171-175), the least-squares plane of
+    the inliers when more than two (:177-186): proposal columns [N1 N2 1 N3] for the segment's pixels,
+    [0 0 1 0] elsewhere (:157-161); NaN / Inf -> 1e-100 (:193-196).  Returns (proposal (4, N), planes (S, 3),
+    inlier counts (S,))."""
+    wta = np.asarray(wta, np.float64)
+    seg = np.asarray(segments).astype(np.int64)
+    H, W = wta.shape
+    d = wta.T.reshape(-1)
+    s = seg.T.reshape(-1)
+    pts2 = get_points(H, W)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        z = 1.0 / d
+        WC = np.stack([z * pts2[0], z * pts2[1], z], 1)
+    S = int(s.max()) if s.size else 0
+    prop = np.zeros((4, H * W)); prop[2] = 1.0
+    planes = np.zeros((S, 3)); ninl = np.zeros(S, np.int64)
+    for a in range(1, S + 1):
+        idx = np.nonzero(s == a)[0]
+        if idx.size == 0:
+            continue
+        N = WC[idx]
+        N = N[N[:, 2] != 0]
+        keep = np.ones(N.shape[0], bool)
+        if N.shape[0] > 3:
+            keep = segpln_rplane(N, rt, seed, a)
+        ninl[a - 1] = int(keep.sum())
+        if int(keep.sum()) > 2:
+            with np.errstate(invalid="ignore", over="ignore"):
+                N_ = _lstsq3(N, keep)
+            planes[a - 1] = N_
+            prop[0, idx] = N_[0]; prop[1, idx] = N_[1]; prop[2, idx] = 1.0; prop[3, idx] = N_[2]
+    prop[~np.isfinite(prop)] = 1e-100
+    return prop, planes, ninl

@@ -434,10 +434,12 @@ class dispmap_globalstereo(dispmap_super):
         if np.max(np.abs(P[:, :, 0].T.reshape(-1)[[0, 1, 2, 3, 4, 5, 8]] - np.array([1, 0, 0, 0, 1, 0, 1.0]))) > 1e-12:
             raise StereoHipError("First image must be reference image")
         self.P2 = np.asfortranarray(P[:, :, 1].T)          # self.P = permute(P, [2 1 3]); a = 2
+        self._P = np.array(P[:, :, :len(self.images)], dtype=np.float64)   # the constructor's 3 x 4 x n (segpln projects with it, :67)
         # MATLAB colon lo*f : hi*f (dispmap_globalstereo.m:48): lo*f + (0 : floor(hi*f - lo*f)), also
         # for a fractional span (np.arange(lo*f, hi*f + 1) would append one element then)
         lo_f, hi_f = disp_range[0] * disparity_factor, disp_range[1] * disparity_factor
         disps = (lo_f + np.arange(np.floor(hi_f - lo_f + 1e-10) + 1))[::-1]
+        self.disps = disps                                 # sorted descending (:49)
         self.d_min = float(disps[-1])
         self.d_step = float(disps[0] - self.d_min)
         self._tol = opt["disp_thresh"]
@@ -482,5 +484,22 @@ class dispmap_globalstereo(dispmap_super):
 
     def init_solution(self):
         self.set_disparity(self.start_disparity)
+
+    # ---- proposals (dispmap_globalstereo.m:60-201)
+    def segpln_wta(self):
+        """The winner-takes-all disparity map of segpln (:72-113), computed on the device once per object."""
+        if getattr(self, "_segpln_wta", None) is None:
+            self._segpln_wta = T.segpln_wta(self.images, self._P, self.disps, col_thresh=self.options["col_thresh"],
+                                            window=self.options.get("window", 2))
+        return self._segpln_wta
+
+    def segpln(self, segment_maps, seed=0):
+        """dispmap_globalstereo.m:60-201: one piecewise-planar proposal (4 x N) per segmentation map -- the
+        reference makes 14 of them with mean-shift / Felzenszwalb segmentations at the scales `mults` (:122-137);
+        the segmenters are out of scope, so the maps (H x W labels 1 .. S, 0 = no segment) are the
+        caller's.  Window matching, LO-RANSAC and the plane fits run on the device (stereo_segpln_wta /
+        stereo_segpln_planes); `seed` stands for MATLAB's random stream (map b uses seed + b)."""
+        wta = self.segpln_wta()
+        return [T.segpln_planes(wta, seg, seed=int(seed) + b)[0] for b, seg in enumerate(segment_maps)]
 
     restart = init_solution

@@ -116,3 +116,38 @@ def globalstereo_unary(im0, im1, P2, d_min, d_step, col_thresh, assignment):
           _p(_f(np.asarray(P2, np.float64))), C.c_double(d_min), C.c_double(d_step), C.c_double(col_thresh),
           _p(_f(assignment)), _p(U))
     return U
+
+
+def segpln_wta(images, P, disps, col_thresh=30.0, window=2, min_corr=0.07):
+    """dispmap_globalstereo.m:72-113 on the device (stereo_segpln_wta): the winner-takes-all disparity map behind
+    the SegPln proposals.  images: list of (H, W, C) arrays, the first one the reference image; P (3, 4, n);
+    disps: the class's self.disps (descending).  -> (H, W) array."""
+    ims = [np.asarray(im, np.float64) for im in images]
+    ims = [im[:, :, None] if im.ndim == 2 else im for im in ims]
+    H, W, Cn = ims[0].shape
+    stack = np.concatenate([_f(im).reshape(-1, order="F") for im in ims])
+    Pm = _f(np.asarray(P, np.float64).reshape(3, 4, len(ims)))
+    d = _f(np.asarray(disps, np.float64).reshape(-1))
+    out = np.zeros((H, W), order="F")
+    _call(_lib.lib().stereo_segpln_wta, _p(stack), C.c_int(len(ims)), C.c_int(H), C.c_int(W), C.c_int(Cn), _p(Pm), _p(d),
+          C.c_int(d.shape[0]), C.c_double(float(col_thresh)), C.c_int(int(window)), C.c_double(float(min_corr)), _p(out))
+    return out
+
+
+def segpln_planes(wta, segments, seed=0, rt=0.1, max_samples=500):
+    """One SegPln proposal (dispmap_globalstereo.m:140-197) over a caller-supplied segmentation (labels 1 .. S,
+    0 = no segment), LO-RANSAC + least-squares plane per segment on the device (stereo_segpln_planes).
+    -> (proposal 4 x N Fortran order, planes S x 3, inlier counts S)."""
+    wta = _f(np.asarray(wta, np.float64))
+    H, W = wta.shape
+    seg = np.asfortranarray(np.asarray(segments).astype(np.int32))
+    if seg.shape != (H, W):
+        raise StereoHipError("segpln_planes: segments must have the image's shape")
+    S = int(seg.max()) if seg.size else 0
+    prop = np.zeros((4, H * W), order="F")
+    planes = np.zeros((3, max(S, 1)), order="F")
+    ninl = np.zeros(max(S, 1), np.int32)
+    _call(_lib.lib().stereo_segpln_planes, _p(wta), _p(seg, C.c_int32), C.c_int(H), C.c_int(W), C.c_double(float(rt)),
+          C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), C.c_int(int(max_samples)), _p(prop), C.c_int(S), _p(planes),
+          _p(ninl, C.c_int32))
+    return prop, planes[:, :S].T.copy(), ninl[:S].copy()
