@@ -711,8 +711,10 @@ __device__ __forceinline__ bool build_envelope_parallel(int K, double alpha, dou
     const bool tested = (kw >> (js & 31)) & 1, drops = (dw >> (js & 31)) & 1;
     // a source meets a cone it has not been tested against (its higher candidates were all dropped):
     // that one and the next two that are still in P, which is where the following rounds tend to land
-    if (UNI(act & !empty & !tested)) { test3(B_lo, B_hi); ++late_tests; continue; }
+    // (both masks are formed before either is looked at: one trip of the vector results to the scalar side per round)
+    const unsigned long long late = __builtin_amdgcn_ballot_w64(act & !empty & !tested);
     const unsigned long long np = __builtin_amdgcn_ballot_w64(act & (empty | !drops)) | 1ull;
+    if (late) { test3(B_lo, B_hi); ++late_tests; continue; }
     if (np == P) { settled = true; break; }
     P = np;
     ++extra_rounds;
@@ -1102,11 +1104,13 @@ __device__ __forceinline__ double envelope_value(const DevParams &p, double alph
       tab[4 * lane] = zm; tab[4 * lane + 1] = sh; tab[4 * lane + 2] = sq;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      // (three probes per round, requested together: 64 -> 16 -> 4 -> 1 candidates in three LDS latencies instead
+      //  of six; the running maximum is non-decreasing, so "how many of the three probes lie below t" is the step)
       slot = 0;
 #pragma unroll
-      for (int step = kWave / 2; step >= 1; step >>= 1) {
-        const double probe = tab[4 * (slot + step - 1)];
-        slot = probe < t ? slot + step : slot;
+      for (int step = kWave / 4; step >= 1; step >>= 2) {
+        const double pr1 = tab[4 * (slot + step - 1)], pr2 = tab[4 * (slot + 2 * step - 1)], pr3 = tab[4 * (slot + 3 * step - 1)];
+        slot += ((pr1 < t ? 1 : 0) + (pr2 < t ? 1 : 0) + (pr3 < t ? 1 : 0)) * step;
       }
       ch = tab[4 * slot + 1]; cq = tab[4 * slot + 2];
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1171,6 +1175,9 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
     long long tm0 = p.prof ? (long long)__builtin_readcyclecounter() : 0;  // development profile: slots 8..15
 #define MSTAMP(slot) do { if (p.prof) { const long long n_ = (long long)__builtin_readcyclecounter(); if (lane == 0) { atomicAdd(p.prof + (slot), (unsigned long long)(n_ - tm0)); atomicAdd(p.prof + (slot) + 1, 1ull); } tm0 = n_; } } while (0)
 #endif
+    // (Going straight to the serial construction after four failures in a row, with a look at the certificate at
+    //  every eighth message, was measured in round 4: 23-41 % more serial constructions -- the failures of a wave do
+    //  not come in runs long enough -- and 14.21 -> 14.31 ms per iteration on the Teddy pair.  Not kept.)
     if (KERNEL == 1 && p.certificate) {
       // Fast path (DESIGN.md "message certificate").  Only "useful" sources, those with
       // h < vTrunc, can produce a value below the truncation level: cost >= h for every
