@@ -278,8 +278,8 @@ def preflight(rank, world, dist, dev, one_gpu):
 
 def cpu_all_cores(unary, conn, K, iters):
     """The oracle (oracle/trws_oracle.c, 1 thread per problem -- the reference is single-threaded) on
-    C independent copies of the same Teddy-sized problem at once, one per host core up to 32 (each copy
-    holds ~1 GB of messages and positions): iterations/s of all copies together.  Reported baseline."""
+    C independent copies of the same Teddy-sized problem at once, one per host core up to 64 (each copy
+    holds ~0.5 GB of messages): iterations/s of all copies together.  Reported baseline."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import pyoracle
     E = conn.shape[0]
@@ -288,7 +288,7 @@ def cpu_all_cores(unary, conn, K, iters):
         host_avail = len(os.sched_getaffinity(0))
     except Exception:
         host_avail = host
-    C_ = max(1, min(host_avail, 32))
+    C_ = max(1, min(host_avail, 64))
     q = np.tile(np.arange(K, dtype=np.float64), (E, 1))
     ones = np.ones(E)
 

@@ -59,12 +59,12 @@ constexpr int kWBuckets = 512;
 constexpr int kWideSparse = 32;  // up to this many useful cones are evaluated one by one, more by the dense window loop
 constexpr int kWStG = kWS + 8 * kWS + 8;            // gamma = 1 / max(n_out, n_in) of the node (the loader's division)
 constexpr int kWStI = kWS + 8 * kWS + 10;           // int area of a stage (in doubles)
-constexpr int kWStS = kWStI + 40;                   // S = D + the node's own (previous-sweep) message rows, added in list order by loader A
-constexpr int kWStage = kWStS + kWS;  // ints: desc[64] px[8] row[8]
+constexpr int kWStS = kWStI + 44;                   // S = D + the node's own (previous-sweep) message rows, added in list order by loader A
+constexpr int kWStage = kWStS + kWS;  // ints: desc[64] px[8] row[8] inrow[8] (inrow[k]: where the k-th INCOMING row lives, the zero row beyond the last)
 // stage: D[kWS] m[8][kWS] a[8] | ints desc[64] px[8] row[8] (row: where Di's k-th message row lives in LDS, in doubles) | S[kWS]
 
 struct WidePtrs {
-  double *stage0, *hand, *scr, *fb, *pos, *scal;
+  double *stage0, *hand, *scr, *fb, *pos, *scal, *zrow;
   int *dring, *ctl;
 };
 __device__ __forceinline__ WidePtrs wide_carve(double *lds) {
@@ -77,9 +77,10 @@ __device__ __forceinline__ WidePtrs wide_carve(double *lds) {
   w.scal = w.pos + kWS;                      // 2 * kScalDoubles
   w.dring = (int *)(w.scal + 2 * kScalDoubles);  // 3 * 64 descriptor words (for the storer)
   w.ctl = w.dring + 3 * 64;                  // [0] run, [1] abort, [2] lock of the serial scratch
+  w.zrow = (double *)(w.ctl + 4);            // kWS zeros: the incoming rows a node does not have
   return w;
 }
-constexpr int kWideLdsDoubles = 2 * kWStage + 3 * 8 * kWS + kWideCompute * kWScr + 4 * kWS + kWS + 2 * kScalDoubles + 96 + 2;
+constexpr int kWideLdsDoubles = 2 * kWStage + 3 * 8 * kWS + kWideCompute * kWScr + 4 * kWS + kWS + 2 * kScalDoubles + 96 + 2 + kWS;
 static_assert(kWideLdsDoubles * 8 <= 160 * 1024, "wide kernel LDS");
 
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
@@ -226,6 +227,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
   const double ustep = p.uniform_step;
   const bool uniform = ustep != 0;
   if (tid == 0) { L.ctl[1] = 0; L.ctl[2] = 0; }
+  for (int k = tid; k < kWS; k += kWideThreads) L.zrow[k] = 0.0;
 #define WPOS(c) (L.pos[(c) * kWave + lane])        // this lane's four label positions (+inf beyond K)
 #define WVALID(c) ((c) * kWave + lane < K)
   const double pos_first = p.pos[0], pos_last = p.pos[K - 1];
@@ -255,6 +257,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
       double *hcur = L.hand + hb * 8 * kWS, *hprev = L.hand + hb1 * 8 * kWS, *hprev2 = L.hand + hb2 * 8 * kWS; \
       double *sc = L.scal + (pos & 1) * kScalDoubles; \
       const bool have_node = pos >= p0 && pos < p1; \
+      const int aborted_ = __hip_atomic_load(L.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); /* a loader's wait gave up during the previous visit */ \
       long long tmark = wprof ? (long long)__builtin_readcyclecounter() : 0; \
       const long long tvisit = tmark; \
       (void)st; (void)stn; (void)hcur; (void)hprev; (void)hprev2; (void)sc; (void)have_node; (void)tvisit;
@@ -265,12 +268,12 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
         if (now_ - tvisit > 8000) plate += 1; \
         tmark = now_; \
       } \
-      BARRIER; \
-      if (wprof && wave == 0) pwait += (unsigned long long)((long long)__builtin_readcyclecounter() - tmark); \
-      if (L.ctl[1]) { \
+      if (aborted_) { /* (looked at in front of the barrier: behind it the LDS round trip was every wave's first step into the next visit) */ \
         if (tid == 0) st_sc1(p.abort_flag, 1); \
         return; \
       } \
+      BARRIER; \
+      if (wprof && wave == 0) pwait += (unsigned long long)((long long)__builtin_readcyclecounter() - tmark); \
     }
 #define WIDE_VISITS_END WIDE_VISITS_END_(__syncthreads())
     if (wave < kWideCompute) {
@@ -291,19 +294,35 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           if (working || (BACKWARD && wave == 0)) {
             double di[4] = {inf, inf, inf, inf};
             {
-            const int myrow = sti[72 + (lane & 7)];  // LDS offsets of the message rows (written by loader A)
+            const int inrow = sti[80 + (lane & 7)];  // LDS offsets of the INCOMING message rows (written by loader A)
             // Di = D + messages in list order (from the ring where the neighbour was one of
-            // the last two visits of this run); the prefix D + rows 0 .. nout - 1 comes from loader A
-            // (reads are unconditional -- rows are padded to 256 -- and masked afterwards, so that
-            // all of them are in flight together)
+            // the last two visits of this run); the prefix D + rows 0 .. nout - 1 comes from loader A.
+            // The first four incoming rows -- all an ordinary node has -- are requested together, without a
+            // branch on the node's degree: a row the node does not have is the zero row (x + 0.0 == x), so
+            // the sixteen reads share one LDS latency instead of one per row; rows five to eight as before.
 #pragma unroll
             for (int c = 0; c < 4; ++c) di[c] = st[kWStS + c * kWave + lane];
+            {
+              double rin[4][4];
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-              if (jj >= nout && jj < ntot) {
-                const double *src = lds + __builtin_amdgcn_readlane(myrow, jj);
+              for (int k = 0; k < 4; ++k) {
+                const double *src = lds + __builtin_amdgcn_readlane(inrow, k);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) di[c] += src[c * kWave + lane];
+                for (int c = 0; c < 4; ++c) rin[k][c] = src[c * kWave + lane];
+              }
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) di[c] += rin[k][c];
+            }
+            if (nin > 4) {
+#pragma unroll
+              for (int k = 4; k < 8; ++k) {
+                if (k < nin) {
+                  const double *src = lds + __builtin_amdgcn_readlane(inrow, k);
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) di[c] += src[c * kWave + lane];
+                }
               }
             }
 #pragma unroll
@@ -697,6 +716,11 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                           : sl >= 0 ? (int)(L.hand - lds) + hb1n * 8 * kWS + sl * kWS
                                     : (int)(stn - lds) + kWS + lane * kWS;
             if (lane < 8) stni[72 + lane] = row;
+            {
+              const int kin = nx.nout + (lane & 7);
+              const int rk = __shfl(row, kin & 7, kWave);
+              if (lane < 8) stni[80 + lane] = (kin < nx.nout + nx.nin && kin < 8) ? rk : (int)(L.zrow - lds);
+            }
           }
           L.dring[((pos + 1) % 3) * 64 + lane] = w;
           if (ok0) *(wide_v4i *)(stn + 2 * lane) = rd0;
@@ -750,6 +774,11 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                           : sl >= 0 ? (int)(L.hand - lds) + hb1n * 8 * kWS + sl * kWS
                                     : (int)(stn - lds) + kWS + lane * kWS;
             if (lane < 8) stni[72 + lane] = row;
+            {
+              const int kin = nx.nout + (lane & 7);
+              const int rk = __shfl(row, kin & 7, kWave);
+              if (lane < 8) stni[80 + lane] = (kin < nx.nout + nx.nin && kin < 8) ? rk : (int)(L.zrow - lds);
+            }
           }
           L.dring[((pos + 1) % 3) * 64 + lane] = w;
           const int ntot = nx.nout + nx.nin;
