@@ -27,8 +27,8 @@ void launch_pipe2_group(bool shared, int what, int blocks, hipStream_t s, const 
 
 size_t wide_lds_bytes();
 void wide_set_attributes();
-void launch_wide(int what, int blocks, hipStream_t s, const DevParams &p, int epoch);
-void launch_wide_group(int what, int blocks, hipStream_t s, const GroupArgs &ga, int epoch);
+void launch_wide(int kernel, int what, int blocks, hipStream_t s, const DevParams &p, int epoch);
+void launch_wide_group(int kernel, int what, int blocks, hipStream_t s, const GroupArgs &ga, int epoch);
 
 
 }  // namespace stereo

@@ -298,7 +298,7 @@ DevParams make_params(stereo_trws_plan *P) {
 void launch_persistent(stereo_trws_plan *P, const DevParams &p, int what, hipStream_t s) {
   const int epoch = ++P->epoch;
   STEREO_HIP_CHECK(hipMemsetAsync(P->d_ctl.p, 0, sizeof(int32_t), s));  // ticket = 0
-  if (P->wide) launch_wide(what, std::min(P->grid_blocks, P->cus), s, p, epoch);
+  if (P->wide) launch_wide(P->kernel, what, std::min(P->grid_blocks, P->cus), s, p, epoch);
   else if (P->fast2) launch_pipe2(P->pos != nullptr, what, std::min(P->grid_blocks, P->cus), s, p, epoch);
   else if (P->fast) launch_pipe(P->kernel, P->pos != nullptr, what, P->grid_blocks, s, p, epoch);
   else launch_generic(P->kernel, P->mode, what, P->grid_blocks, persistent_lds_bytes(P->Kp), s, p, epoch);
@@ -538,7 +538,8 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
       STEREO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, P->device));
       P->cus = std::max(cus, 1);
     }
-    const bool wide_candidate = kernel == 1 && K > kWave && K <= 256;  // (either message mode: MINPLUS runs it lean)
+    // (kernel 1 in either message mode -- MINPLUS runs it lean --, kernel 2 with exact messages)
+    const bool wide_candidate = (kernel == 1 || message_mode == STEREO_TRWS_MESSAGES_EXACT) && K > kWave && K <= 256;
     const int64_t per_cu = std::min<int64_t>(std::max<int64_t>(1, (int64_t)(160 * 1024) / (int64_t)persistent_lds_bytes(P->Kp)), 4);
     const int64_t capacity = wide_candidate ? P->cus : P->cus * per_cu;
     // The analysis depends on the connectivity only (ordering, lists, schedules: 0.2-0.6 s at Teddy
@@ -620,7 +621,7 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
     }
     }
     P->fast = g.fast_ok && K <= kWave && message_mode == STEREO_TRWS_MESSAGES_EXACT;
-    P->wide_allowed = g.fast_ok && kernel == 1 && K > kWave && K <= 256;
+    P->wide_allowed = g.fast_ok && (kernel == 1 || message_mode == STEREO_TRWS_MESSAGES_EXACT) && K > kWave && K <= 256;
     P->fast2 = g.fast_ok && kernel == 1 && K > kWave && K <= 2 * kWave && message_mode == STEREO_TRWS_MESSAGES_EXACT;
     if (const char *f = std::getenv("STEREO_HIP_TRWS_FAST")) {
       P->fast = P->fast && std::string(f) != "0";
@@ -1018,7 +1019,7 @@ static void launch_group(stereo_trws_plan *const *G, int n, int what, hipStream_
     if (what != 3) P->sweep_launches += 1;
   }
   ga.first[n] = total;
-  if (P0->wide) launch_wide_group(what, total, s, ga, epoch);
+  if (P0->wide) launch_wide_group(P0->kernel, what, total, s, ga, epoch);
   else if (P0->fast2) launch_pipe2_group(P0->pos != nullptr, what, total, s, ga, epoch);
   else launch_pipe_group(P0->kernel, P0->pos != nullptr, what, total, s, ga, epoch);
   STEREO_HIP_CHECK(hipGetLastError());

@@ -38,7 +38,8 @@ namespace {
 // trws_pipe_kernel; the loader is split in two -- data nobody else writes, and data behind
 // completion flags -- and both run two visits ahead with their requests parked in registers, so
 // that no HBM round trip lies inside a visit.  One hardware barrier per visit.
-// Kernel 1 (truncated linear) only; kernel 2 above K = 64 stays on the generic kernel.
+// Kernel 1 (truncated linear) and, since round 4, kernel 2 (truncated quadratic: the hull-slope certificate of
+// message_quad_fast on four labels per lane; exact messages only -- the MINPLUS option stays kernel 1).
 // (Round 4: a "reach-aware" useful-cone loop -- the ~10-instruction update only for the label chunks within the
 // truncation window of a cone, a 4-instruction key test u_t - u_i / v_t - v_i for the chunks beyond, one uniform
 // branch per cone choosing a body specialised per source chunk -- executes 30 % fewer instructions per cone and was
@@ -289,7 +290,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           const int *sti = (const int *)(st + kWStI);
           const int f = __builtin_amdgcn_readfirstlane(sti[2]);
           const int nout = f & 15, nin = (f >> 4) & 15, ntot = nout + nin;
-          const bool fast_msg = KERNEL == 1 && p.certificate != 0;
+          const bool fast_msg = p.certificate != 0;
           const bool working = j0 < nout;
           if (working || (BACKWARD && wave == 0)) {
             double di[4] = {inf, inf, inf, inf};
@@ -368,7 +369,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) out[c] = hmin;
                 vmin = hmin;
-              } else if (p.lean) {
+              } else if (p.lean && KERNEL == 1) {
                 // ---- STEREO_TRWS_MESSAGES_MINPLUS: the message is the plain min-plus, nothing else -------
                 // (min over ALL sources = min over the useful ones, truncated: every other source costs
                 //  >= vTrunc; no margins, no tangency test, no serial construction)
@@ -435,6 +436,86 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) out[c] = m1[c] < vtrunc ? m1[c] : vtrunc;
                 vmin = hmin;  // (destination t sees source t at distance 0, vTrunc >= min H)
+                WSTAMP(3);
+              } else if (fast_msg && KERNEL == 2) {
+                // ---- truncated QUADRATIC kernel (typeStereoQuadratic.h:329-501), round 4 ------------------
+                // The certificate of message_quad_fast (trws_dev.h) on four labels per lane: plain min-plus
+                // over the useful parabolas (h < vTrunc), smallest and second smallest cost per destination;
+                // if the smallest is delta-separated from every other cost and from vTrunc, and the rounding
+                // of a breakpoint that involves it (<= ~7 eps G / (alpha gap)) stays below the slope margin
+                // delta / (2 alpha Q), the reference's hull construction returns exactly that parabola's value.
+                // No tangency test.  Shared strictly ascending positions: gap = the smallest distance of two
+                // neighbouring positions, Q = their span, G bounded by max |h| + 2 alpha max pos^2 (a larger
+                // scale only makes delta, and with it the certificate, more conservative).
+                const int w = p.window;   // sources farther than sqrt(lambda (1 + 1e-9)) cost >= vTrunc bit for bit
+                unsigned long long um[4];
+                int nuse = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                  um[c] = __builtin_amdgcn_ballot_w64(WVALID(c) && h[c] < vtrunc);
+                  nuse += __builtin_popcountll(um[c]);
+                }
+                double pq[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) pq[c] = WPOS(c);
+                const double pmax = max_raw(fabs(pos_first), fabs(pos_last));
+                const double scale = max_raw(fabs(hmin), fabs(hmax)) + 2 * (alpha * pmax * pmax);
+                const double qdelta = 1e-9 * (scale + fabs(alpha * p.lambda) + fabs(vtrunc));
+                double m1[4] = {inf, inf, inf, inf}, m2[4] = {inf, inf, inf, inf};
+                if (nuse <= kWideSparse) {
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) {
+                    unsigned long long mk = um[c];
+                    while (mk) {
+                      const int l = __builtin_ctzll(mk);
+                      mk &= mk - 1;
+                      const double hi = readlane_f64(h[c], l), qi = readlane_f64(pq[c], l);
+#pragma unroll
+                      for (int cc = 0; cc < 4; ++cc) {
+                        const double cst = pair_cost<2>(alpha, pq[cc] - qi, hi);
+                        const double lo_ = min_raw(m1[cc], cst), hi_ = max_raw(m1[cc], cst);
+                        m2[cc] = min_raw(m2[cc], hi_);   // second smallest; equal costs of two sources count
+                        m1[cc] = lo_;
+                      }
+                    }
+                  }
+                } else {
+                  double2 *mtab = (double2 *)scr + kWPad;
+                  if (lane < 2 * kWPad) ((double2 *)scr)[lane < kWPad ? lane : K + lane] = make_double2(inf, 0.0);
+#pragma unroll
+                  for (int c = 0; c < 4; ++c)
+                    if (WVALID(c)) mtab[c * kWave + lane] = make_double2(h[c], pq[c]);
+                  WSYNC();
+                  for (int d = -w; d <= w; ++d) {
+                    double2 sv[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                      const int i = c * kWave + lane + d;
+                      sv[c] = mtab[w <= kWPad ? i : i < 0 ? 0 : i > K - 1 ? K - 1 : i];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                      const int i = c * kWave + lane + d;
+                      double cst = pair_cost<2>(alpha, pq[c] - sv[c].y, sv[c].x);
+                      if (w > kWPad) cst = (i >= 0 && i < K) ? cst : inf;
+                      const double lo_ = min_raw(m1[c], cst), hi_ = max_raw(m1[c], cst);
+                      m2[c] = min_raw(m2[c], hi_);
+                      m1[c] = lo_;
+                    }
+                  }
+                  WSYNC();
+                }
+                bool bad = !(qdelta < inf) || !(alpha > 0) || !(p.pos_gap > 4e-8);
+                bad = bad || !(1e-13 * scale * (pos_last - pos_first) < qdelta * p.pos_gap);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                  if (WVALID(c)) {
+                    bad = bad || (m1[c] < vtrunc && !(m2[c] - m1[c] > qdelta && vtrunc - m1[c] > qdelta));
+                    out[c] = m1[c] < vtrunc ? m1[c] : vtrunc;
+                  }
+                }
+                vmin = hmin;  // (destination t sees source t at distance 0; every other cost is some h plus a square)
+                serial = UNI(bad);
                 WSTAMP(3);
               } else if (fast_msg) {
                 // ---- the certified path ---------------------------------------------------------------
@@ -1098,21 +1179,37 @@ void wide_set_attributes() {
   STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<1, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, wlds))
   SET_W(trws_wide_kernel); SET_W(trws_wide_group_kernel);
 #undef SET_W
+#define SET_W(NAME)                                                                                                             \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<2, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wlds)); \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<2, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wlds));  \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<2, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wlds));  \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<2, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, wlds))
+  SET_W(trws_wide_kernel); SET_W(trws_wide_group_kernel);
+#undef SET_W
 }
 
 #define WIDE_SWITCH(NAME, ARG)                                                                                     \
   const size_t wlds = wide_lds_bytes();                                                                            \
   const dim3 wgrid(blocks), wblock(kWideThreads);                                                                  \
-  switch (what) {                                                                                                  \
-    case 0: hipLaunchKernelGGL((NAME<1, false, false, true>), wgrid, wblock, wlds, s, ARG, epoch); break;          \
-    case 1: hipLaunchKernelGGL((NAME<1, true, false, true>), wgrid, wblock, wlds, s, ARG, epoch); break;           \
-    case 2: hipLaunchKernelGGL((NAME<1, false, true, true>), wgrid, wblock, wlds, s, ARG, epoch); break;           \
-    default: hipLaunchKernelGGL((NAME<1, false, true, false>), wgrid, wblock, wlds, s, ARG, epoch); break;         \
+  if (kernel == 2) {                                                                                               \
+    switch (what) {                                                                                                \
+      case 0: hipLaunchKernelGGL((NAME<2, false, false, true>), wgrid, wblock, wlds, s, ARG, epoch); break;        \
+      case 1: hipLaunchKernelGGL((NAME<2, true, false, true>), wgrid, wblock, wlds, s, ARG, epoch); break;         \
+      case 2: hipLaunchKernelGGL((NAME<2, false, true, true>), wgrid, wblock, wlds, s, ARG, epoch); break;         \
+      default: hipLaunchKernelGGL((NAME<2, false, true, false>), wgrid, wblock, wlds, s, ARG, epoch); break;       \
+    }                                                                                                              \
+  } else {                                                                                                         \
+    switch (what) {                                                                                                \
+      case 0: hipLaunchKernelGGL((NAME<1, false, false, true>), wgrid, wblock, wlds, s, ARG, epoch); break;        \
+      case 1: hipLaunchKernelGGL((NAME<1, true, false, true>), wgrid, wblock, wlds, s, ARG, epoch); break;         \
+      case 2: hipLaunchKernelGGL((NAME<1, false, true, true>), wgrid, wblock, wlds, s, ARG, epoch); break;         \
+      default: hipLaunchKernelGGL((NAME<1, false, true, false>), wgrid, wblock, wlds, s, ARG, epoch); break;       \
+    }                                                                                                              \
   }                                                                                                                \
   STEREO_HIP_CHECK(hipGetLastError());
 
-void launch_wide(int what, int blocks, hipStream_t s, const DevParams &p, int epoch) { WIDE_SWITCH(trws_wide_kernel, p) }
-void launch_wide_group(int what, int blocks, hipStream_t s, const GroupArgs &ga, int epoch) { WIDE_SWITCH(trws_wide_group_kernel, ga) }
+void launch_wide(int kernel, int what, int blocks, hipStream_t s, const DevParams &p, int epoch) { WIDE_SWITCH(trws_wide_kernel, p) }
+void launch_wide_group(int kernel, int what, int blocks, hipStream_t s, const GroupArgs &ga, int epoch) { WIDE_SWITCH(trws_wide_group_kernel, ga) }
 #undef WIDE_SWITCH
 
 }  // namespace stereo

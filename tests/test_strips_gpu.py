@@ -100,6 +100,13 @@ def test_wide_kernel_strips_k256(G, hip, oracle):
     (lab, en, lb, _), path, _ = _run_strips(p, 1, K, H, W, G, 8.0, 3, shared_pos=pos)
     assert path == 3
     assert np.array_equal(lab, lab1) and _close(en, en1) and _close(lb, lb1)
+    # the truncated quadratic kernel on the same layout (round 4)
+    H, W = 12, 14
+    p = trws_problem(109, H, W, K, kind="fronto")
+    lab_o, en_o, lb_o, _ = oracle.trws(2, p["unary"], p["conn"], p["q"], p["qprim"], p["alphas"], 64.0, 2, -1e300, mode=1)
+    (lab, en, lb, _), path, _ = _run_strips(p, 2, K, H, W, G, 64.0, 2, shared_pos=pos)
+    assert path == 3
+    assert np.array_equal(lab, lab_o) and _close(en, en_o) and _close(lb, lb_o)
 
 
 @pytest.mark.parametrize("G", [2, 3])

@@ -19,7 +19,7 @@ def _run_shared(hip, oracle, seed, H, W, K, pos, tol, maxiter, integer=False, al
     ref = oracle.trws(2, p["unary"], p["conn"], q, q, p["alphas"], tol, maxiter, -1e300, mode=1)
     plan = TrwsPlan(2, K, H * W, p["conn"].T)
     plan.upload(p["unary"].T, p["alphas"], tol, positions=pos)
-    assert plan.path() == (2 if K <= 64 else 1)
+    assert plan.path() == (2 if K <= 64 else 3 if K <= 256 else 1)   # (round 4: 64 < K <= 256 on shared ascending positions runs on the wide kernel)
     plan.iterate(maxiter, max_relgap=-1e300)
     lab, en, lb, it = plan.result()
     assert it == ref[3]
@@ -38,7 +38,7 @@ SHARED = [
     (76, 8, 8, 48, "offset", 16.0, 3),     # positions around 1e3: g = h + alpha q^2 is large, the margin scales with it
     (77, 7, 9, 20, "grid", 0.0, 3),        # lambda = 0
     (78, 6, 7, 40, "grid", 1e9, 3),        # no truncation
-    (79, 7, 8, 100, "grid", 64.0, 3),      # K > 64: generic kernel, up to four labels per lane
+    (79, 7, 8, 100, "grid", 64.0, 3),      # K > 64: the wide kernel, four labels per lane
     (80, 6, 7, 256, "irregular", 30.0, 3),
     (83, 5, 6, 200, "half", 16.0, 3),
 ]
