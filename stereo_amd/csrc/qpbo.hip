@@ -49,6 +49,8 @@ struct QpboDev {
   const int32_t *aptr, *head, *rev;  // arcs grouped by tail; rev[a] = reverse arc
   double *r, *delta, *ex, *snk;
   int32_t *h, *h2;
+  // Improve launch only (else nullptr): the exact heights at the moment the current node was fixed
+  int32_t *keep;
   int32_t *counters;  // [0] active nodes, [1] frontier size (next), [2] changed flag
   // tiling for the block-local relabelling: tile T owns positions [T * 1024, (T + 1) * 1024);
   // perm[pos] = node or -1, pos_of[node] = pos.  A tile holds nodes that are close in the graph
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
   // done when no tile changed.  The fixpoint is the BFS distance whatever the schedule, so the
   // result is deterministic, and a front crosses a whole tile per barrier instead of one level.
   int relabels_done = 0;
+  bool keep_valid = false;   // g.keep holds the exact heights of the flow the current Improve step started from
   auto global_relabel = [&](int &active) -> bool {
     constexpr int kArcRegs = 8;
     const long long t_in = wall_clock64();
@@ -141,9 +144,17 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     // labelling (every residual arc still sees at most one level down once the relaxation has
     // converged, sink arcs are re-seeded), which is all the push phase needs; far fewer passes.)
     const bool warm = incremental != 0 && relabels_done == 0;
+    // (`confined`: a later relabelling of the same Improve step.  Fixing node i hands excess to i alone,
+    // and i had no path to the sink: the excess moves only through nodes that had none either, so no
+    // residual arc changes on the old shortest path of a node that had one -- its distance can only have
+    // gone down (a shorter way through i's mate).  The snapshot of the exact heights at the moment of
+    // the fix is therefore an upper bound of the distances for those nodes, n for all others, and the
+    // label correction started from ANY upper bound ends in the same fixpoint, the BFS distances: the
+    // same heights as the search from scratch, but the front only crosses the region the fix touched.)
+    const bool confined = !warm && keep_valid;
     ++relabels_done;
     for (int v = first; v < n; v += stride) {
-      const int old_h = warm ? ldc(h + v) : n;
+      const int old_h = warm ? ldc(h + v) : (confined ? ldc(g.keep + v) : n);
       stc(h + v, ldc(g.snk + v) > 0 ? 1 : (old_h < n ? old_h : n));
     }
     // A tile is relaxed again only if a height next to it went down in the last step (every tile in
@@ -602,6 +613,10 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     int32_t *word = ctl + (improve_steps & 1 ? 10 : 15), *other = ctl + (improve_steps & 1 ? 15 : 10);
     if (improve_steps == 0 && blockIdx.x == 0 && threadIdx.x == 0) { stc(word, N); stc(other, N); }   // both start at "none"
     if (!grid_sync(ctl, gen)) return;   // (every workgroup's final heights and terminal capacities are in memory)
+    if (g.keep) {   // the starting point of this step's later relabellings (global_relabel, `confined`)
+      for (int v = first; v < n; v += stride) stc(g.keep + v, ldc(g.h + v));
+      keep_valid = true;
+    }
     int mine = N;
     for (int j = improve_from + first; j < N; j += stride) {
       const int i = improve_perm[j];
@@ -899,7 +914,7 @@ namespace {
 struct QpboSolver {
   QpboProblem P;
   int n = 0, m = 0;
-  DevBuf<int32_t> d_aptr, d_head, d_rev, d_h, d_h2, d_cnt, d_flags, d_ctl, d_perm, d_posof, d_dirty;
+  DevBuf<int32_t> d_aptr, d_head, d_rev, d_h, d_h2, d_cnt, d_flags, d_ctl, d_perm, d_posof, d_dirty, d_keep;
   DevBuf<double> d_r, d_delta, d_ex, d_snk;
   std::vector<double> snk0;
   QpboDev g{};
@@ -981,7 +996,20 @@ struct QpboSolver {
     DevBuf<int32_t> d_perm;
     d_perm.upload(perm.data(), perm.size());
     if (!std::getenv("STEREO_HIP_QPBO_IMPROVE_HOST")) {
-      maxflow(true, d_perm.p);
+      // the relabellings inside an Improve step start from the heights of the flow the step began with
+      // (qpbo_maxflow_kernel, `confined`); STEREO_HIP_QPBO_CONFINED=0: every one of them from scratch (round 3)
+      const char *e = std::getenv("STEREO_HIP_QPBO_CONFINED");
+      if (!e || std::atoi(e) != 0) {
+        if (d_keep.n < (size_t)n) d_keep.alloc(n);
+        g.keep = d_keep.p;
+      }
+      try {
+        maxflow(true, d_perm.p);
+      } catch (...) {
+        g.keep = nullptr;
+        throw;
+      }
+      g.keep = nullptr;
     } else {
       const int N = (int)P.N;
       DevBuf<int32_t> d_next;

@@ -289,7 +289,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
         if (UPDATE && have_node) {
           const int *sti = (const int *)(st + kWStI);
           const int f = __builtin_amdgcn_readfirstlane(sti[2]);
-          const int nout = f & 15, nin = (f >> 4) & 15, ntot = nout + nin;
+          const int nout = f & 15, nin = (f >> 4) & 15;
           const bool fast_msg = p.certificate != 0;
           const bool working = j0 < nout;
           if (working || (BACKWARD && wave == 0)) {
