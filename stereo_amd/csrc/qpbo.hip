@@ -134,6 +134,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
   // done when no tile changed.  The fixpoint is the BFS distance whatever the schedule, so the
   // result is deterministic, and a front crosses a whole tile per barrier instead of one level.
   int relabels_done = 0;
+  [[maybe_unused]] int improve_steps_dbg = 0;   // (STEREO_HIP_QPBO_CHECK_CONFINED)
   bool keep_valid = false;   // g.keep holds the exact heights of the flow the current Improve step started from
   auto global_relabel = [&](int &active) -> bool {
     constexpr int kArcRegs = 8;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     // converged, sink arcs are re-seeded), which is all the push phase needs; far fewer passes.)
     const bool warm = incremental != 0 && relabels_done == 0;
     // (`confined`: a later relabelling of the same Improve step.  Fixing node i hands excess to i alone,
-    // and i had no path to the sink: the excess moves only through nodes that had none either, so no
+    // and i had no path to the sink (keep_valid is only set then): the excess moves only through nodes that had none either, so no
     // residual arc changes on the old shortest path of a node that had one -- its distance can only have
     // gone down (a shorter way through i's mate).  The snapshot of the exact heights at the moment of
     // the fix is therefore an upper bound of the distances for those nodes, n for all others, and the
@@ -234,6 +235,22 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
       if (!grid_sync(ctl, gen)) return false;
       if (!ld(QpboCtl::kChanged + slotC)) break;
     }
+#ifdef STEREO_HIP_QPBO_CHECK_CONFINED
+    // development check: exact distances are tight (a node below n without a sink arc has a residual arc one
+    // level down); a start that was NOT an upper bound leaves nodes that hang in the air
+    if (confined && g.counters) {
+      for (int v = first; v < n; v += stride) {
+        const int hv = ldc(h + v);
+        if (hv >= n || ldc(g.snk + v) > 0) continue;
+        bool sup = false;
+        for (int a = g.aptr[v]; a < g.aptr[v + 1]; ++a) sup = sup || (ldc(g.r + a) > 0 && ldc(h + g.head[a]) == hv - 1);
+        if (!sup && atomicAdd(g.counters + 1100, 1) == 0) {
+          g.counters[1101] = v; g.counters[1102] = hv; g.counters[1103] = ldc(g.keep + v);
+          g.counters[1104] = ldc(g.ex + v) > 0; g.counters[1105] = relabels_done; g.counters[1106] = improve_steps_dbg;
+        }
+      }
+    }
+#endif
     slotA = (slotA + 1) % 3;
     clear_next(QpboCtl::kActive, slotA);
     int cnt = 0;
@@ -615,7 +632,6 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     if (!grid_sync(ctl, gen)) return;   // (every workgroup's final heights and terminal capacities are in memory)
     if (g.keep) {   // the starting point of this step's later relabellings (global_relabel, `confined`)
       for (int v = first; v < n; v += stride) stc(g.keep + v, ldc(g.h + v));
-      keep_valid = true;
     }
     int mine = N;
     for (int j = improve_from + first; j < N; j += stride) {
@@ -630,6 +646,10 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     if (!grid_sync(ctl, gen)) return;
     const int next = ldc(word);
     if (next >= N) break;
+    // (the argument for `confined` needs the node that receives the excess to be cut off from the sink: "neither
+    // side connected".  The other ambiguous case, both sides connected, sends the new excess through nodes that
+    // do have a path and lengthens distances there: those steps relabel from scratch.)
+    keep_valid = g.keep != nullptr && ldc(g.keep + improve_perm[next]) >= n;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       stc(other, N);
       // AddUnaryTerm(i, 0, INFTY), INFTY = max(-t_i + sum of outgoing residuals, t_i + sum of incoming) + 1
@@ -646,6 +666,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     }
     improve_from = next + 1;
     ++improve_steps;
+    improve_steps_dbg = improve_steps;
     incremental = 1;   // the heights stay a valid labelling when a unary term changes: warm search
     solve = true;
     if (!grid_sync(ctl, gen)) return;
@@ -1075,6 +1096,15 @@ struct QpboSolver {
     STEREO_HIP_CHECK(hipLaunchCooperativeKernel((const void *)qpbo_maxflow_kernel, dim3(blocks), dim3(kMB), args, dyn, 0));
     int32_t host_ctl[QpboCtl::kWords];
     STEREO_HIP_CHECK(hipMemcpy(host_ctl, d_ctl.p, sizeof(host_ctl), hipMemcpyDeviceToHost));
+#ifdef STEREO_HIP_QPBO_CHECK_CONFINED
+    {
+      int32_t dbg[8];
+      STEREO_HIP_CHECK(hipMemcpy(dbg, d_cnt.p + 1100, sizeof(dbg), hipMemcpyDeviceToHost));
+      if (dbg[0]) std::fprintf(stderr, "[stereo_hip qpbo] confined check: %d unsupported nodes; first v=%d (N=%d) h=%d keep=%d excess=%d relabel#%d step %d\n",
+                               dbg[0], dbg[1], (int)P.N, dbg[2], dbg[3], dbg[4], dbg[5], dbg[6]);
+      STEREO_HIP_CHECK(hipMemset(d_cnt.p + 1100, 0, sizeof(dbg)));
+    }
+#endif
     if (host_ctl[QpboCtl::kAbort] == 1) throw HipError{"stereo_rd: grid barrier gave up (device-side spin bound)"};
     if (host_ctl[QpboCtl::kAbort] == 2) throw HipError{"stereo_rd: push-relabel did not converge within the round bound"};
     if (std::getenv("STEREO_HIP_QPBO_VERBOSE"))
