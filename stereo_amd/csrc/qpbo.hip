@@ -153,16 +153,40 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     // label correction started from ANY upper bound ends in the same fixpoint, the BFS distances: the
     // same heights as the search from scratch, but the front only crosses the region the fix touched.)
     const bool confined = !warm && keep_valid;
+    // (`local`: inside such a step only the tiles the step has touched are looked at.  The step's first, warm
+    // relabelling lowers the nodes that can reach the new sink arc at i's mate -- the tiles where that happened are
+    // recorded in `touched` --, and from then on distances only grow (pushes along admissible arcs never shorten a
+    // path), for nodes of that set alone: every other node keeps the height it has.  So the first pass relaxes the
+    // tiles whose input changed instead of all of them; the dirty marks carry the rest as before.  Both mark
+    // arrays are all zero when a relabelling ends, so nothing has to be cleared here.)
+    const bool local = keep_valid && (warm || confined);
+    int32_t *touched = g.keep ? g.keep + n : nullptr;
     ++relabels_done;
     for (int v = first; v < n; v += stride) {
-      const int old_h = warm ? ldc(h + v) : (confined ? ldc(g.keep + v) : n);
-      stc(h + v, ldc(g.snk + v) > 0 ? 1 : (old_h < n ? old_h : n));
+      const int cur_h = (warm || local) ? ldc(h + v) : n;
+      const int old_h = warm ? cur_h : (confined ? ldc(g.keep + v) : n);
+      const int new_h = ldc(g.snk + v) > 0 ? 1 : (old_h < n ? old_h : n);
+      stc(h + v, new_h);
+#ifdef STEREO_HIP_QPBO_CHECK_CONFINED
+      // development check: outside the touched tiles a confined relabelling starts from the heights that are there
+      if (local && confined && g.counters && new_h != cur_h && !ldc(touched + g.pos_of[v] / kMB)) atomicAdd(g.counters + 1107, 1);
+#endif
+      if (local && warm && new_h < cur_h) {   // a new sink arc: this node's tile and the tiles of its neighbours
+        const int T = g.pos_of[v] / kMB;
+        stc(touched + T, 1); stc(g.rdirty + T, 1);
+        for (int a = g.aptr[v]; a < g.aptr[v + 1]; ++a) stc(g.rdirty + g.pos_of[g.head[a]] / kMB, 1);
+      }
     }
     // A tile is relaxed again only if a height next to it went down in the last step (every tile in
     // the first): once a tile has reached its fixpoint it stays there until an input changes.  The
     // search front crosses the image, the warm search of an Improve step touches a small region.
     int rpar = 0;
-    for (int T = first; T < g.ntiles; T += stride) { stc(g.rdirty + T, 1); stc(g.rdirty + g.ntiles + T, 0); }
+    if (!local) {
+      for (int T = first; T < g.ntiles; T += stride) { stc(g.rdirty + T, 1); stc(g.rdirty + g.ntiles + T, 0); }
+    } else if (confined) {
+      for (int T = first; T < g.ntiles; T += stride)
+        if (ldc(touched + T)) stc(g.rdirty + T, 1);
+    }
     // residuals do not change during the relabelling: after this invalidate plain loads of r see
     // what the (write-through, sc1) pushes stored
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -219,6 +243,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         } while (__syncthreads_or(ch));
         if (my < start) {
           stc(h + v, my); any_changed = true;
+          if (local) stc(touched + T, 1);
           // whoever has a residual arc INTO v may come down now: the tiles of v's neighbours
 #pragma unroll
           for (int k = 0; k < kArcRegs; ++k)
@@ -238,7 +263,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
 #ifdef STEREO_HIP_QPBO_CHECK_CONFINED
     // development check: exact distances are tight (a node below n without a sink arc has a residual arc one
     // level down); a start that was NOT an upper bound leaves nodes that hang in the air
-    if (confined && g.counters) {
+    if ((confined || local) && g.counters) {
       for (int v = first; v < n; v += stride) {
         const int hv = ldc(h + v);
         if (hv >= n || ldc(g.snk + v) > 0) continue;
@@ -632,6 +657,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     if (!grid_sync(ctl, gen)) return;   // (every workgroup's final heights and terminal capacities are in memory)
     if (g.keep) {   // the starting point of this step's later relabellings (global_relabel, `confined`)
       for (int v = first; v < n; v += stride) stc(g.keep + v, ldc(g.h + v));
+      for (int T = first; T < g.ntiles; T += stride) stc(g.keep + n + T, 0);   // `touched`, global_relabel
     }
     int mine = N;
     for (int j = improve_from + first; j < N; j += stride) {
@@ -1021,7 +1047,7 @@ struct QpboSolver {
       // (qpbo_maxflow_kernel, `confined`); STEREO_HIP_QPBO_CONFINED=0: every one of them from scratch (round 3)
       const char *e = std::getenv("STEREO_HIP_QPBO_CONFINED");
       if (!e || std::atoi(e) != 0) {
-        if (d_keep.n < (size_t)n) d_keep.alloc(n);
+        if (d_keep.n < (size_t)n + (size_t)std::max(g.ntiles, 1)) d_keep.alloc((size_t)n + (size_t)std::max(g.ntiles, 1));   // heights + one mark per tile
         g.keep = d_keep.p;
       }
       try {
@@ -1100,8 +1126,9 @@ struct QpboSolver {
     {
       int32_t dbg[8];
       STEREO_HIP_CHECK(hipMemcpy(dbg, d_cnt.p + 1100, sizeof(dbg), hipMemcpyDeviceToHost));
-      if (dbg[0]) std::fprintf(stderr, "[stereo_hip qpbo] confined check: %d unsupported nodes; first v=%d (N=%d) h=%d keep=%d excess=%d relabel#%d step %d\n",
-                               dbg[0], dbg[1], (int)P.N, dbg[2], dbg[3], dbg[4], dbg[5], dbg[6]);
+      if (dbg[0] || dbg[7])
+        std::fprintf(stderr, "[stereo_hip qpbo] confined check: %d unsupported nodes, %d heights outside the touched tiles changed; first v=%d (N=%d) h=%d keep=%d excess=%d relabel#%d step %d\n",
+                     dbg[0], dbg[7], dbg[1], (int)P.N, dbg[2], dbg[3], dbg[4], dbg[5], dbg[6]);
       STEREO_HIP_CHECK(hipMemset(d_cnt.p + 1100, 0, sizeof(dbg)));
     }
 #endif
