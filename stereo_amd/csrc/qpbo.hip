@@ -80,10 +80,35 @@ constexpr int kMB = 1024;
 // [8] rounds done, [9] global relabels done
 struct QpboCtl { enum { kBar = 0, kAbort = 1, kChanged = 2, kActive = 5, kRounds = 8, kRelabels = 9, kWords = 16 }; };
 constexpr int kGridSpinLimit = 1 << 24;
+// -DSTEREO_HIP_QPBO_PROFILE: workgroup 0 adds up where its time goes (10 ns ticks and event counts in
+// counters[1200 ..], printed with STEREO_HIP_QPBO_VERBOSE): relabelling = init pass | tile set-up | tile
+// relaxation | grid barriers; tiled rounds = tile load | local rounds | store | grid barriers
+#ifdef STEREO_HIP_QPBO_PROFILE
+#define QPROF_T(var) const long long var = wall_clock64()
+#define QPROF_ADD(slot, val) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g.counters) g.counters[1200 + (slot)] += (int)(val); } while (0)
+#else
+#define QPROF_T(var) do {} while (0)
+#define QPROF_ADD(slot, val) do {} while (0)
+#endif
 __device__ __forceinline__ int ldc(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void stc(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ldc(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void stc(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// "Did any thread of the workgroup say yes" on the barrier the caller needs anyway: a wave with a yes stores a
+// flag, one s_barrier, everybody reads it.  Three flags in turn -- the next one is cleared while this one is in
+// use (its last readers passed the previous call's barrier) -- instead of __syncthreads_or's workgroup reduction,
+// which costs several times the relaxation step it guards (0.93 us per step measured, 16 waves).
+// Called by all threads; s_any[0..2] zero before the first call.
+__device__ __forceinline__ bool wg_any(bool pred, int *s_any, int &slot) {
+  if (__builtin_amdgcn_ballot_w64(pred) != 0 && (threadIdx.x & 63) == 0) s_any[slot] = 1;
+  const int nxt = slot == 2 ? 0 : slot + 1;
+  if (threadIdx.x == 0) s_any[nxt] = 0;
+  __syncthreads();
+  const bool r = s_any[slot] != 0;
+  slot = nxt;
+  return r;
+}
 
 __device__ __forceinline__ bool grid_sync(int32_t *ctl, unsigned &gen) {
   __syncthreads();
@@ -114,7 +139,12 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
                                                             int adaptive, const int32_t *improve_perm, int improve_N) {
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // tile state of the tiled rounds
   __shared__ int s_red;
-  __shared__ int s_h[kMB];
+  __shared__ int s_h[kMB + 1];   // [kMB]: n, the height an arc without residual capacity leads to
+  __shared__ int s_any[3];
+  int any_slot = 0;
+  if (threadIdx.x < 3) s_any[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_h[kMB] = g.n;
+  __syncthreads();
   unsigned gen = 0;
   const int n = g.n;
   const int first = blockIdx.x * kMB + threadIdx.x, stride = gridDim.x * kMB;
@@ -162,6 +192,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     const bool local = keep_valid && (warm || confined);
     int32_t *touched = g.keep ? g.keep + n : nullptr;
     ++relabels_done;
+    QPROF_T(qp0);
     for (int v = first; v < n; v += stride) {
       const int cur_h = (warm || local) ? ldc(h + v) : n;
       const int old_h = warm ? cur_h : (confined ? ldc(g.keep + v) : n);
@@ -190,7 +221,10 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     // residuals do not change during the relabelling: after this invalidate plain loads of r see
     // what the (write-through, sc1) pushes stored
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    QPROF_T(qp1);
+    QPROF_ADD(0, qp1 - qp0);
     if (!grid_sync(ctl, gen)) return false;
+    QPROF_ADD(3, wall_clock64() - qp1);
     for (;;) {
       slotC = (slotC + 1) % 3;
       clear_next(QpboCtl::kChanged, slotC);
@@ -201,46 +235,80 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         const int is_dirty = ldc(rd_in + T);
         __syncthreads();  // every thread has read the flag before it is cleared
         if (!is_dirty) continue;
+        QPROF_T(qp2);
         if (threadIdx.x == 0) stc(rd_in + T, 0);
         const int v = g.perm[T * kMB + threadIdx.x];
-        int my = n, winfo[kArcRegs], exth[kArcRegs], a0 = 0, a1 = 0;
+        int my = n, a0 = 0, a1 = 0;
+        int lidx[kArcRegs];  // residual arc to a node of this tile: its slot in s_h; every other arc: the slot that holds n
         int extT[kArcRegs];  // tile of the arc's head if it is another tile (whatever the residual), else -1
+        int ext_best = n;    // what the residual arcs that leave the tile allow (their heads do not move during this step)
         if (v >= 0) {
           my = ldc(h + v);
           a0 = g.aptr[v]; a1 = g.aptr[v + 1];
         }
         s_h[threadIdx.x] = my;
+        {
+          // heads, then everything that hangs on them, requested together: three dependent round trips per tile
+          int wk[kArcRegs], pwk[kArcRegs], hwk[kArcRegs];
+          double rk[kArcRegs];
 #pragma unroll
-        for (int k = 0; k < kArcRegs; ++k) {
-          winfo[k] = -1; exth[k] = n; extT[k] = -1;
-          if (a0 + k < a1) {
-            const int w = g.head[a0 + k], pw = g.pos_of[w];
-            if (pw / kMB != T) extT[k] = pw / kMB;
-            if (g.r[a0 + k] > 0) {
-              if (pw / kMB == T) winfo[k] = pw % kMB;
-              else { winfo[k] = -2; exth[k] = ldc(h + w); }
+          for (int k = 0; k < kArcRegs; ++k) wk[k] = a0 + k < a1 ? g.head[a0 + k] : 0;
+#pragma unroll
+          for (int k = 0; k < kArcRegs; ++k) {
+            pwk[k] = g.pos_of[wk[k]];
+            hwk[k] = ldc(h + wk[k]);
+            rk[k] = a0 + k < a1 ? g.r[a0 + k] : 0.0;
+          }
+#pragma unroll
+          for (int k = 0; k < kArcRegs; ++k) {
+            lidx[k] = kMB; extT[k] = -1;
+            if (a0 + k < a1) {
+              const bool inside = pwk[k] / kMB == T;
+              if (!inside) extT[k] = pwk[k] / kMB;
+              if (rk[k] > 0) {
+                if (inside) lidx[k] = pwk[k] % kMB;
+                else ext_best = hwk[k] + 1 < ext_best ? hwk[k] + 1 : ext_best;
+              }
             }
           }
         }
         __syncthreads();
+        QPROF_T(qp3);
+        QPROF_ADD(1, qp3 - qp2); QPROF_ADD(4, 1);
         const int start = my;
         bool ch;
-        do {
-          int best = my;
+        if (tiled > 0) {
+          // (tiled rounds are only switched on for graphs with at most four arcs per node: the 4-connected grid)
+          do {
+            QPROF_ADD(5, 1);
+            int best = ext_best < my ? ext_best : my;
 #pragma unroll
-          for (int k = 0; k < kArcRegs; ++k) {
-            const int hw = winfo[k] >= 0 ? s_h[winfo[k]] : exth[k];
-            best = (winfo[k] != -1 && hw + 1 < best) ? hw + 1 : best;
-          }
-          for (int a = a0 + kArcRegs; a < a1; ++a) {  // nodes of higher degree: the rest from memory
-            if (!(g.r[a] > 0)) continue;
-            const int w = g.head[a], pw = g.pos_of[w];
-            const int hw = pw / kMB == T ? s_h[pw % kMB] : ldc(h + w);
-            best = hw + 1 < best ? hw + 1 : best;
-          }
-          ch = best < my;
-          if (ch) { my = best; s_h[threadIdx.x] = my; }  // heights only decrease: racing readers are harmless
-        } while (__syncthreads_or(ch));
+            for (int k = 0; k < 4; ++k) {
+              const int hw = s_h[lidx[k]] + 1;
+              best = hw < best ? hw : best;
+            }
+            ch = best < my;
+            if (ch) { my = best; s_h[threadIdx.x] = my; }  // heights only decrease: racing readers are harmless
+          } while (wg_any(ch, s_any, any_slot));
+        } else {
+          do {
+            QPROF_ADD(5, 1);
+            int best = ext_best < my ? ext_best : my;
+#pragma unroll
+            for (int k = 0; k < kArcRegs; ++k) {
+              const int hw = s_h[lidx[k]] + 1;
+              best = hw < best ? hw : best;
+            }
+            for (int a = a0 + kArcRegs; a < a1; ++a) {  // nodes of higher degree: the rest from memory
+              if (!(g.r[a] > 0)) continue;
+              const int w = g.head[a], pw = g.pos_of[w];
+              const int hw = pw / kMB == T ? s_h[pw % kMB] : ldc(h + w);
+              best = hw + 1 < best ? hw + 1 : best;
+            }
+            ch = best < my;
+            if (ch) { my = best; s_h[threadIdx.x] = my; }
+          } while (wg_any(ch, s_any, any_slot));
+        }
         if (my < start) {
           stc(h + v, my); any_changed = true;
           if (local) stc(touched + T, 1);
@@ -254,10 +322,13 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
           }
         }
         __syncthreads();
+        QPROF_ADD(2, wall_clock64() - qp3);
       }
-      if (__syncthreads_or(any_changed) && threadIdx.x == 0)
+      if (wg_any(any_changed, s_any, any_slot) && threadIdx.x == 0)
         __hip_atomic_store(ctl + QpboCtl::kChanged + slotC, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      QPROF_T(qp4);
       if (!grid_sync(ctl, gen)) return false;
+      QPROF_ADD(3, wall_clock64() - qp4); QPROF_ADD(6, 1);
       if (!ld(QpboCtl::kChanged + slotC)) break;
     }
 #ifdef STEREO_HIP_QPBO_CHECK_CONFINED
@@ -280,7 +351,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     clear_next(QpboCtl::kActive, slotA);
     int cnt = 0;
     for (int v = first; v < n; v += stride) cnt += (ldc(g.ex + v) > 0 && ldc(h + v) < n) ? 1 : 0;
-    cnt = __syncthreads_count(cnt > 0 ? 1 : 0) > 0 ? cnt : 0;
+    cnt = wg_any(cnt > 0, s_any, any_slot) ? cnt : 0;
     if (threadIdx.x == 0) s_red = 0;
     __syncthreads();
     if (cnt) atomicAdd(&s_red, cnt);
@@ -478,6 +549,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         const int is_dirty = ldc(dirty_in + T);
         __syncthreads();  // every thread has read the flag before it is cleared
         if (!is_dirty) continue;
+        QPROF_T(qt0);
         if (threadIdx.x == 0) stc(dirty_in + T, 0);
         const int v = g.perm[T * kMB + threadIdx.x];
         const bool valid = v >= 0;
@@ -518,7 +590,10 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         s_h[threadIdx.x] = hv;
         const int h0 = hv;  // height at the barrier
         __syncthreads();
+        QPROF_T(qt1);
+        QPROF_ADD(8, qt1 - qt0); QPROF_ADD(12, 1);
         for (int l = 0; l < L; ++l) {
+          QPROF_ADD(13, 1);
           // push (a pair of arcs is only modified by the endpoint that is higher)
           if (valid) {
             e = s_ex[threadIdx.x]; hv = s_h[threadIdx.x];
@@ -583,8 +658,10 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
           }
           __syncthreads();  // every old height has been read
           if (valid) s_h[threadIdx.x] = newh;
-          if (!__syncthreads_or(valid && s_ex[threadIdx.x] > 0 && newh < n)) break;
+          if (!wg_any(valid && s_ex[threadIdx.x] > 0 && newh < n, s_any, any_slot)) break;
         }
+        QPROF_T(qt2);
+        QPROF_ADD(9, qt2 - qt1);
         if (valid) {
           stc(g.ex + v, s_ex[threadIdx.x]); stc(g.snk + v, s_snk[threadIdx.x]);  // read by other workgroups in the relabelling
           const int hnew = s_h[threadIdx.x];
@@ -595,9 +672,11 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
           if (s_ex[threadIdx.x] > 0 && hnew < n) ++cnt;
         }
         // (also the barrier before the tile buffers are reused)
-        const int left = __syncthreads_or(valid && s_ex[threadIdx.x] > 0 && s_h[threadIdx.x] < n);
+        const int left = wg_any(valid && s_ex[threadIdx.x] > 0 && s_h[threadIdx.x] < n, s_any, any_slot);
         if (left && threadIdx.x == 0) stc(dirty_out + T, 1);
+        QPROF_ADD(10, wall_clock64() - qt2);
       }
+      QPROF_T(qt3);
       if (threadIdx.x == 0) s_red = 0;
       __syncthreads();
       if (cnt) atomicAdd(&s_red, cnt);
@@ -607,6 +686,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         __hip_atomic_fetch_add(ctl + QpboCtl::kActive + slotA, (s_red & ((1 << 30) - 1)) + (s_red >> 30), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
       if (!grid_sync(ctl, gen)) return false;
+      QPROF_ADD(11, wall_clock64() - qt3); QPROF_ADD(14, 1);
       active = ld(QpboCtl::kActive + slotA);
       return true;
     };
@@ -1137,6 +1217,16 @@ struct QpboSolver {
     if (std::getenv("STEREO_HIP_QPBO_VERBOSE"))
       std::fprintf(stderr, "[stereo_hip qpbo] relabels: %.3f ms, %d barriers; tiled section: %.3f ms, %d rounds\n", host_ctl[11] * 1e-5,
                    host_ctl[12], host_ctl[13] * 1e-5, host_ctl[14]);
+#ifdef STEREO_HIP_QPBO_PROFILE
+    if (std::getenv("STEREO_HIP_QPBO_VERBOSE")) {
+      int32_t q[16];
+      STEREO_HIP_CHECK(hipMemcpy(q, d_cnt.p + 1200, sizeof(q), hipMemcpyDeviceToHost));
+      STEREO_HIP_CHECK(hipMemset(d_cnt.p + 1200, 0, sizeof(q)));
+      std::fprintf(stderr, "[stereo_hip qpbo] workgroup 0, relabelling: init %.3f ms, tile set-up %.3f ms (%d tiles), relaxation %.3f ms (%d iterations), "
+                   "grid barriers %.3f ms (%d steps); tiled rounds: load %.3f ms (%d tiles), local rounds %.3f ms (%d), store %.3f ms, reduction + grid barrier %.3f ms (%d rounds)\n",
+                   q[0] * 1e-5, q[1] * 1e-5, q[4], q[2] * 1e-5, q[5], q[3] * 1e-5, q[6], q[8] * 1e-5, q[12], q[9] * 1e-5, q[13], q[10] * 1e-5, q[11] * 1e-5, q[14]);
+    }
+#endif
     if (std::getenv("STEREO_HIP_QPBO_VERBOSE")) { std::vector<int32_t> tr(1040); (void)hipMemcpy(tr.data(), d_cnt.p, sizeof(int32_t) * 1040, hipMemcpyDeviceToHost); std::fprintf(stderr, "[stereo_hip qpbo] active per round:"); for (int i = 0; i < host_ctl[QpboCtl::kRounds] && i < 1024; i += (i < 32 ? 1 : 8)) std::fprintf(stderr, " %d", tr[16 + i]); std::fprintf(stderr, "\n"); }
     iterations += host_ctl[QpboCtl::kRounds];
     relabels += host_ctl[QpboCtl::kRelabels];
