@@ -140,6 +140,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // tile state of the tiled rounds
   __shared__ int s_red;
   __shared__ int s_h[kMB + 1];   // [kMB]: n, the height an arc without residual capacity leads to
+  __shared__ int s_h2[kMB];      // tiled rounds: the heights being written while s_h is read, and the other way round
   __shared__ int s_any[3];
   int any_slot = 0;
   if (threadIdx.x < 3) s_any[threadIdx.x] = 0;
@@ -251,13 +252,17 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
           // heads, then everything that hangs on them, requested together: three dependent round trips per tile
           int wk[kArcRegs], pwk[kArcRegs], hwk[kArcRegs];
           double rk[kArcRegs];
+          const int nk = tiled > 0 ? 4 : kArcRegs;   // (tiled rounds: at most four arcs per node)
 #pragma unroll
-          for (int k = 0; k < kArcRegs; ++k) wk[k] = a0 + k < a1 ? g.head[a0 + k] : 0;
+          for (int k = 0; k < kArcRegs; ++k) wk[k] = (k < nk && a0 + k < a1) ? g.head[a0 + k] : 0;
 #pragma unroll
           for (int k = 0; k < kArcRegs; ++k) {
-            pwk[k] = g.pos_of[wk[k]];
-            hwk[k] = ldc(h + wk[k]);
-            rk[k] = a0 + k < a1 ? g.r[a0 + k] : 0.0;
+            pwk[k] = 0; hwk[k] = n; rk[k] = 0.0;
+            if (k < nk) {
+              pwk[k] = g.pos_of[wk[k]];
+              hwk[k] = ldc(h + wk[k]);
+              rk[k] = a0 + k < a1 ? g.r[a0 + k] : 0.0;
+            }
           }
 #pragma unroll
           for (int k = 0; k < kArcRegs; ++k) {
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     };
     mark_all_dirty();
     if (!grid_sync(ctl, gen)) return;
-    double *s_ex = dyn_lds, *s_snk = dyn_lds + kMB, *s_r = dyn_lds + 2 * kMB, *s_d = dyn_lds + 6 * kMB;
+    double *s_d = dyn_lds;   // [thread][arc]: what a neighbour inside the tile pushed over the reverse of that arc
     // L local rounds (L == 0: only take in what was pushed across tile borders); counts the active
     // nodes and one more per workgroup that pushed across a border (that flow is still in transit)
     auto tile_round = [&](int L) -> bool {
@@ -556,22 +561,35 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         int loc[4] = {-1, -1, -1, -1}, rvk[4] = {0, 0, 0, 0}, exth[4] = {n, n, n, n}, extT[4] = {0, 0, 0, 0}, a0 = 0, deg = 0;
         double e = 0;
         int hv = n;
+        double sk = 0, rk[4] = {0, 0, 0, 0};
         if (valid) {
+          // four dependent round trips per tile: node | its terminals and arc range | heads, reverse arcs,
+          // residuals | what hangs on the heads -- each level requested as a whole before any of it is used
           e = ldc(g.ex + v); hv = ldc(h + v);
           a0 = g.aptr[v]; deg = g.aptr[v + 1] - a0;
-          s_snk[threadIdx.x] = ldc(g.snk + v);
-          double rk[4], din_k[4];
-          int rvs[4];
+          sk = ldc(g.snk + v);
+          double din_k[4];
+          int rvs[4], wk[4], pwk[4], awk[4], hwk[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            rk[k] = 0; din_k[k] = 0; rvs[k] = 0;
+            const int a = k < deg ? a0 + k : 0;
+            const int w = g.head[a], rv = g.rev[a];
+            wk[k] = k < deg ? w : 0; rvs[k] = k < deg ? rv : 0;
+            rk[k] = ldc(g.r + a);
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            pwk[k] = g.pos_of[wk[k]]; awk[k] = g.aptr[wk[k]];
+            hwk[k] = ldc(h + wk[k]); din_k[k] = ldc(din + rvs[k]);
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
             if (k < deg) {
-              const int a = a0 + k, w = g.head[a], pw = g.pos_of[w];
-              rvs[k] = g.rev[a];
-              rvk[k] = rvs[k] - g.aptr[w];
-              rk[k] = ldc(g.r + a);
-              if (pw / kMB == T) loc[k] = pw % kMB;
-              else { exth[k] = ldc(h + w); din_k[k] = ldc(din + rvs[k]); extT[k] = pw / kMB; }
+              rvk[k] = rvs[k] - awk[k];
+              if (pwk[k] / kMB == T) { loc[k] = pwk[k] % kMB; din_k[k] = 0; }
+              else { exth[k] = hwk[k]; extT[k] = pwk[k] / kMB; }
+            } else {
+              rk[k] = 0; din_k[k] = 0;
             }
           }
 #pragma unroll
@@ -580,14 +598,15 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
               e += din_k[k]; rk[k] += din_k[k];
               stc(din + rvs[k], 0.0);
             }
-            s_r[threadIdx.x * 4 + k] = rk[k];
-            s_d[threadIdx.x * 4 + k] = 0;
           }
-        } else {
-          s_snk[threadIdx.x] = 0;
         }
-        s_ex[threadIdx.x] = e;
-        s_h[threadIdx.x] = hv;
+        // A node's excess, sink capacity and residuals are only ever changed by its own thread: they stay in
+        // registers for the local rounds.  LDS holds what neighbours read (heights, two buffers in turn: a round
+        // writes the new ones where nobody is reading) and what they write (the amounts pushed over a local arc).
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_d[threadIdx.x * 4 + k] = 0;
+        int *hcur = s_h, *hnext = s_h2;
+        hcur[threadIdx.x] = hv;
         const int h0 = hv;  // height at the barrier
         __syncthreads();
         QPROF_T(qt1);
@@ -595,84 +614,70 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         for (int l = 0; l < L; ++l) {
           QPROF_ADD(13, 1);
           // push (a pair of arcs is only modified by the endpoint that is higher)
-          if (valid) {
-            e = s_ex[threadIdx.x]; hv = s_h[threadIdx.x];
-            if (e > 0 && hv < n) {
-              if (hv == 1) {
-                const double sk = s_snk[threadIdx.x];
-                if (sk > 0) {
-                  const double d = e < sk ? e : sk;
-                  s_snk[threadIdx.x] = sk - d;
+          if (valid && e > 0 && hv < n) {
+            if (hv == 1 && sk > 0) {
+              const double d = e < sk ? e : sk;
+              sk -= d;
+              e -= d;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (k < deg && e > 0 && rk[k] > 0) {
+                const bool local = loc[k] >= 0;
+                const int hw = local ? hcur[loc[k]] : exth[k];
+                if ((local || l == 0) && hv == hw + 1) {
+                  const double d = e < rk[k] ? e : rk[k];
+                  rk[k] -= d;
+                  if (local) s_d[loc[k] * 4 + rvk[k]] = d;
+                  else { stc(dout + a0 + k, d); stc(dirty_out + extT[k], 1); crossed = true; }
                   e -= d;
                 }
               }
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                if (k < deg && e > 0) {
-                  const double ra = s_r[threadIdx.x * 4 + k];
-                  if (ra > 0) {
-                    const bool local = loc[k] >= 0;
-                    const int hw = local ? s_h[loc[k]] : exth[k];
-                    if ((local || l == 0) && hv == hw + 1) {
-                      const double d = e < ra ? e : ra;
-                      s_r[threadIdx.x * 4 + k] = ra - d;
-                      if (local) s_d[loc[k] * 4 + rvk[k]] = d;
-                      else { stc(dout + a0 + k, d); stc(dirty_out + extT[k], 1); crossed = true; }
-                      e -= d;
-                    }
-                  }
-                }
-              }
-              s_ex[threadIdx.x] = e;
             }
           }
           __syncthreads();
           // gather in the node's own arc order, relabel from the post-push residual graph
-          int newh = n;
+          int newh = hv;
           if (valid) {
-            e = s_ex[threadIdx.x];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               if (k < deg) {
                 const double d = s_d[threadIdx.x * 4 + k];
-                if (d != 0) { e += d; s_r[threadIdx.x * 4 + k] += d; s_d[threadIdx.x * 4 + k] = 0; }
+                if (d != 0) { e += d; rk[k] += d; s_d[threadIdx.x * 4 + k] = 0; }
               }
             }
-            s_ex[threadIdx.x] = e;
-            hv = s_h[threadIdx.x];
-            newh = hv;
             if (e > 0 && hv < n) {
-              int hmin = s_snk[threadIdx.x] > 0 ? 0 : n;
+              int hmin = sk > 0 ? 0 : n;
 #pragma unroll
               for (int k = 0; k < 4; ++k) {
                 // outside heights are lower bounds.  An outside neighbour that stood exactly one above
                 // this node at the barrier may have pushed to it in this round; the residual that gives
                 // this node's arc arrives with the next round, so the arc counts as open until then.
-                if (k < deg && (s_r[threadIdx.x * 4 + k] > 0 || (loc[k] < 0 && exth[k] == h0 + 1))) {
-                  const int hw = loc[k] >= 0 ? s_h[loc[k]] : exth[k];
+                if (k < deg && (rk[k] > 0 || (loc[k] < 0 && exth[k] == h0 + 1))) {
+                  const int hw = loc[k] >= 0 ? hcur[loc[k]] : exth[k];
                   hmin = hw < hmin ? hw : hmin;
                 }
               }
               if (hmin + 1 > hv) newh = hmin + 1 < n ? hmin + 1 : n;
             }
           }
-          __syncthreads();  // every old height has been read
-          if (valid) s_h[threadIdx.x] = newh;
-          if (!wg_any(valid && s_ex[threadIdx.x] > 0 && newh < n, s_any, any_slot)) break;
+          hnext[threadIdx.x] = newh;   // (the other buffer: the old heights are still being read)
+          hv = newh;
+          { int *t = hcur; hcur = hnext; hnext = t; }
+          if (!wg_any(valid && e > 0 && hv < n, s_any, any_slot)) break;
         }
         QPROF_T(qt2);
         QPROF_ADD(9, qt2 - qt1);
         if (valid) {
-          stc(g.ex + v, s_ex[threadIdx.x]); stc(g.snk + v, s_snk[threadIdx.x]);  // read by other workgroups in the relabelling
-          const int hnew = s_h[threadIdx.x];
-          stc(h + v, hnew);
+          stc(g.ex + v, e); stc(g.snk + v, sk);  // read by other workgroups in the relabelling
+          stc(h + v, hv);
 #pragma unroll
           for (int k = 0; k < 4; ++k)
-            if (k < deg) stc(g.r + a0 + k, s_r[threadIdx.x * 4 + k]);
-          if (s_ex[threadIdx.x] > 0 && hnew < n) ++cnt;
+            if (k < deg) stc(g.r + a0 + k, rk[k]);
+          if (e > 0 && hv < n) ++cnt;
         }
         // (also the barrier before the tile buffers are reused)
-        const int left = wg_any(valid && s_ex[threadIdx.x] > 0 && s_h[threadIdx.x] < n, s_any, any_slot);
+        const int left = wg_any(valid && e > 0 && hv < n, s_any, any_slot);
         if (left && threadIdx.x == 0) stc(dirty_out + T, 1);
         QPROF_ADD(10, wall_clock64() - qt2);
       }
@@ -1173,8 +1178,8 @@ struct QpboSolver {
     if (dev != cached_dev) {
       int c = 0, pc = 0;
       STEREO_HIP_CHECK(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
-      STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)qpbo_maxflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 10 * kMB)));
-      STEREO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, qpbo_maxflow_kernel, kMB, sizeof(double) * 10 * kMB));
+      STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)qpbo_maxflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 4 * kMB)));
+      STEREO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, qpbo_maxflow_kernel, kMB, sizeof(double) * 4 * kMB));
       cached_cus = c; cached_per_cu = pc; cached_dev = dev;
     }
     const int cus = cached_cus, per_cu = cached_per_cu;
@@ -1187,7 +1192,7 @@ struct QpboSolver {
     // tiled rounds: every node has at most four arcs and the pushed-amount buffer has two halves
     int tiled = (max_degree <= 4 && d_delta.n >= (size_t)2 * std::max(m, 1)) ? 16 : 0;
     if (const char *e = std::getenv("STEREO_HIP_QPBO_TILED")) tiled = tiled ? std::max(0, std::atoi(e)) : 0;
-    const size_t dyn = tiled ? sizeof(double) * 10 * kMB : 0;
+    const size_t dyn = tiled ? sizeof(double) * 4 * kMB : 0;
     int switch_at = 16;  // plain rounds first: most moves end within a dozen of them
     if (const char *e = std::getenv("STEREO_HIP_QPBO_SWITCH")) switch_at = std::max(0, std::atoi(e));
     int incremental = warm ? 1 : 0;
