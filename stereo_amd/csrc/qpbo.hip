@@ -57,8 +57,10 @@ struct QpboDev {
   // (a 16 x 32 pixel patch and its mates when the grid shape is known).
   const int32_t *perm, *pos_of;
   int ntiles;
-  // tiled rounds: dirty[parity][tile] = the tile holds excess that can still move, or flow was
-  // pushed into it across its border in the last round; other tiles are skipped
+  // tiled rounds: dirty[parity][tile] == number of the round = the tile holds excess that can still move, or
+  // flow was pushed into it across its border in the round before; other tiles are skipped.  (Round numbers
+  // instead of flags that are cleared: every workgroup reads ALL marks of a round to find its share of the
+  // marked tiles, see `collect`, so nothing may change them while the round runs.)
   int32_t *dirty;
   // the same idea for the label-correcting relabelling: rdirty[parity][tile] = a height next to
   // the tile (or inside it) went down in the last step
@@ -146,6 +148,42 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
   if (threadIdx.x < 3) s_any[threadIdx.x] = 0;
   if (threadIdx.x == 0) s_h[kMB] = g.n;
   __syncthreads();
+  // The marked tiles of a round / relabelling step, dealt out evenly: every workgroup reads all marks, ranks the
+  // marked tiles (ballot + wave counts, the same list everywhere, no atomics) and takes ranks b, b + #workgroups, ...
+  // With the fixed tile -> workgroup map a step lasted as long as the workgroup that happened to own two or three
+  // marked tiles (some 190 of 658 are marked in a round of the hard globalstereo moves: 73 us per round against
+  // ~35 for one tile); results do not depend on who processes a tile.
+  constexpr int kMaxMine = 64;
+  __shared__ int s_mine[kMaxMine];
+  __shared__ int s_wcnt[kMB / 64];
+  const bool dealt = g.ntiles <= kMaxMine * (int)gridDim.x;
+  auto collect = [&](const int32_t *marks, int tag) -> int {
+    if (!dealt) return (g.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // candidates of the fixed map
+    int total = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < g.ntiles; base += kMB) {
+      const int T = base + threadIdx.x;
+      const bool f = T < g.ntiles && ldc(marks + T) == tag;
+      const unsigned long long b = __builtin_amdgcn_ballot_w64(f);
+      if (lane == 0) s_wcnt[wave] = __builtin_popcountll(b);
+      __syncthreads();
+      int before = total, chunk = 0;
+#pragma unroll
+      for (int w = 0; w < kMB / 64; ++w) {
+        const int c = s_wcnt[w];
+        before += w < wave ? c : 0;
+        chunk += c;
+      }
+      if (f) {
+        const int rank = before + __builtin_popcountll(b & ((1ull << lane) - 1ull));
+        if (rank % (int)gridDim.x == (int)blockIdx.x) s_mine[rank / (int)gridDim.x] = T;
+      }
+      total += chunk;
+      __syncthreads();
+    }
+    return total > (int)blockIdx.x ? (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  };
+  int RG = 0;   // relabelling steps so far in this launch: the marks of step RG are rdirty[RG & 1][tile] == RG
   unsigned gen = 0;
   const int n = g.n;
   const int first = blockIdx.x * kMB + threadIdx.x, stride = gridDim.x * kMB;
@@ -188,10 +226,10 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     // relabelling lowers the nodes that can reach the new sink arc at i's mate -- the tiles where that happened are
     // recorded in `touched` --, and from then on distances only grow (pushes along admissible arcs never shorten a
     // path), for nodes of that set alone: every other node keeps the height it has.  So the first pass relaxes the
-    // tiles whose input changed instead of all of them; the dirty marks carry the rest as before.  Both mark
-    // arrays are all zero when a relabelling ends, so nothing has to be cleared here.)
+    // tiles whose input changed instead of all of them; the dirty marks carry the rest as before.)
     const bool local = keep_valid && (warm || confined);
     int32_t *touched = g.keep ? g.keep + n : nullptr;
+    int32_t *rd_first = g.rdirty + (size_t)((RG + 1) & 1) * g.ntiles;   // marks of the first step
     ++relabels_done;
     QPROF_T(qp0);
     for (int v = first; v < n; v += stride) {
@@ -205,19 +243,18 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
 #endif
       if (local && warm && new_h < cur_h) {   // a new sink arc: this node's tile and the tiles of its neighbours
         const int T = g.pos_of[v] / kMB;
-        stc(touched + T, 1); stc(g.rdirty + T, 1);
-        for (int a = g.aptr[v]; a < g.aptr[v + 1]; ++a) stc(g.rdirty + g.pos_of[g.head[a]] / kMB, 1);
+        stc(touched + T, 1); stc(rd_first + T, RG + 1);
+        for (int a = g.aptr[v]; a < g.aptr[v + 1]; ++a) stc(rd_first + g.pos_of[g.head[a]] / kMB, RG + 1);
       }
     }
     // A tile is relaxed again only if a height next to it went down in the last step (every tile in
     // the first): once a tile has reached its fixpoint it stays there until an input changes.  The
     // search front crosses the image, the warm search of an Improve step touches a small region.
-    int rpar = 0;
     if (!local) {
-      for (int T = first; T < g.ntiles; T += stride) { stc(g.rdirty + T, 1); stc(g.rdirty + g.ntiles + T, 0); }
+      for (int T = first; T < g.ntiles; T += stride) stc(rd_first + T, RG + 1);
     } else if (confined) {
       for (int T = first; T < g.ntiles; T += stride)
-        if (ldc(touched + T)) stc(g.rdirty + T, 1);
+        if (ldc(touched + T)) stc(rd_first + T, RG + 1);
     }
     // residuals do not change during the relabelling: after this invalidate plain loads of r see
     // what the (write-through, sc1) pushes stored
@@ -230,14 +267,17 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
       slotC = (slotC + 1) % 3;
       clear_next(QpboCtl::kChanged, slotC);
       bool any_changed = false;
-      int32_t *rd_in = g.rdirty + (size_t)rpar * g.ntiles, *rd_out = g.rdirty + (size_t)(rpar ^ 1) * g.ntiles;
-      rpar ^= 1;
-      for (int T = blockIdx.x; T < g.ntiles; T += gridDim.x) {
-        const int is_dirty = ldc(rd_in + T);
-        __syncthreads();  // every thread has read the flag before it is cleared
-        if (!is_dirty) continue;
+      ++RG;
+      int32_t *rd_in = g.rdirty + (size_t)(RG & 1) * g.ntiles, *rd_out = g.rdirty + (size_t)((RG + 1) & 1) * g.ntiles;
+      const int mine = collect(rd_in, RG);
+      for (int j = 0; j < mine; ++j) {
+        int T;
+        if (dealt) T = s_mine[j];
+        else {
+          T = blockIdx.x + j * gridDim.x;
+          if (ldc(rd_in + T) != RG) continue;
+        }
         QPROF_T(qp2);
-        if (threadIdx.x == 0) stc(rd_in + T, 0);
         const int v = g.perm[T * kMB + threadIdx.x];
         int my = n, a0 = 0, a1 = 0;
         int lidx[kArcRegs];  // residual arc to a node of this tile: its slot in s_h; every other arc: the slot that holds n
@@ -320,10 +360,10 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
           // whoever has a residual arc INTO v may come down now: the tiles of v's neighbours
 #pragma unroll
           for (int k = 0; k < kArcRegs; ++k)
-            if (extT[k] >= 0) stc(rd_out + extT[k], 1);
+            if (extT[k] >= 0) stc(rd_out + extT[k], RG + 1);
           for (int a = a0 + kArcRegs; a < a1; ++a) {
             const int tw = g.pos_of[g.head[a]] / kMB;
-            if (tw != T) stc(rd_out + tw, 1);
+            if (tw != T) stc(rd_out + tw, RG + 1);
           }
         }
         __syncthreads();
@@ -535,7 +575,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     // over its border does not change in a round, so it is skipped -- exactly, not heuristically.
     // After an exact relabelling every tile is looked at once (nodes may have become active again).
     auto mark_all_dirty = [&]() {
-      for (int T = first; T < g.ntiles; T += stride) stc(g.dirty + (size_t)((G + 1) & 1) * g.ntiles + T, 1);
+      for (int T = first; T < g.ntiles; T += stride) stc(g.dirty + (size_t)((G + 1) & 1) * g.ntiles + T, G + 1);
     };
     mark_all_dirty();
     if (!grid_sync(ctl, gen)) return;
@@ -550,12 +590,15 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
       clear_next(QpboCtl::kActive, slotA);
       int cnt = 0;
       bool crossed = false;
-      for (int T = blockIdx.x; T < g.ntiles; T += gridDim.x) {
-        const int is_dirty = ldc(dirty_in + T);
-        __syncthreads();  // every thread has read the flag before it is cleared
-        if (!is_dirty) continue;
+      const int mine = collect(dirty_in, G);
+      for (int j = 0; j < mine; ++j) {
+        int T;
+        if (dealt) T = s_mine[j];
+        else {
+          T = blockIdx.x + j * gridDim.x;
+          if (ldc(dirty_in + T) != G) continue;
+        }
         QPROF_T(qt0);
-        if (threadIdx.x == 0) stc(dirty_in + T, 0);
         const int v = g.perm[T * kMB + threadIdx.x];
         const bool valid = v >= 0;
         int loc[4] = {-1, -1, -1, -1}, rvk[4] = {0, 0, 0, 0}, exth[4] = {n, n, n, n}, extT[4] = {0, 0, 0, 0}, a0 = 0, deg = 0;
@@ -629,7 +672,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
                   const double d = e < rk[k] ? e : rk[k];
                   rk[k] -= d;
                   if (local) s_d[loc[k] * 4 + rvk[k]] = d;
-                  else { stc(dout + a0 + k, d); stc(dirty_out + extT[k], 1); crossed = true; }
+                  else { stc(dout + a0 + k, d); stc(dirty_out + extT[k], G + 1); crossed = true; }
                   e -= d;
                 }
               }
@@ -678,7 +721,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         }
         // (also the barrier before the tile buffers are reused)
         const int left = wg_any(valid && e > 0 && hv < n, s_any, any_slot);
-        if (left && threadIdx.x == 0) stc(dirty_out + T, 1);
+        if (left && threadIdx.x == 0) stc(dirty_out + T, G + 1);
         QPROF_ADD(10, wall_clock64() - qt2);
       }
       QPROF_T(qt3);
@@ -1168,6 +1211,8 @@ struct QpboSolver {
     if (const char *e = std::getenv("STEREO_HIP_QPBO_RELABEL_EVERY")) relabel_every = std::max(1, std::atoi(e));
     if (d_ctl.n < (size_t)QpboCtl::kWords) d_ctl.alloc(QpboCtl::kWords);
     STEREO_HIP_CHECK(hipMemsetAsync(d_ctl.p, 0, sizeof(int32_t) * QpboCtl::kWords, 0));
+    // tile marks are round numbers counted from the start of a launch: none left over from the last one
+    if (d_dirty.p) STEREO_HIP_CHECK(hipMemsetAsync(d_dirty.p, 0, sizeof(int32_t) * d_dirty.n, 0));
     // (device properties and the occupancy of the kernel are asked once per process and device:
     // an Improve pass calls this function hundreds of times)
     // (thread local: stereo_hip_set_device selects a device per host thread, and two threads
