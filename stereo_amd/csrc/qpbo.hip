@@ -204,6 +204,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
   // result is deterministic, and a front crosses a whole tile per barrier instead of one level.
   int relabels_done = 0;
   [[maybe_unused]] int improve_steps_dbg = 0;   // (STEREO_HIP_QPBO_CHECK_CONFINED)
+  int fixed_node = 0;        // the node the current Improve step fixed
   bool keep_valid = false;   // g.keep holds the exact heights of the flow the current Improve step started from
   auto global_relabel = [&](int &active) -> bool {
     constexpr int kArcRegs = 8;
@@ -232,10 +233,9 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     int32_t *rd_first = g.rdirty + (size_t)((RG + 1) & 1) * g.ntiles;   // marks of the first step
     ++relabels_done;
     QPROF_T(qp0);
-    for (int v = first; v < n; v += stride) {
-      const int cur_h = (warm || local) ? ldc(h + v) : n;
-      const int old_h = warm ? cur_h : (confined ? ldc(g.keep + v) : n);
-      const int new_h = ldc(g.snk + v) > 0 ? 1 : (old_h < n ? old_h : n);
+    auto start_height = [&](int v, double snk_v, int cur_h, int keep_h) {
+      const int old_h = warm ? cur_h : (confined ? keep_h : n);
+      const int new_h = snk_v > 0 ? 1 : (old_h < n ? old_h : n);
       stc(h + v, new_h);
 #ifdef STEREO_HIP_QPBO_CHECK_CONFINED
       // development check: outside the touched tiles a confined relabelling starts from the heights that are there
@@ -246,7 +246,56 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         stc(touched + T, 1); stc(rd_first + T, RG + 1);
         for (int a = g.aptr[v]; a < g.aptr[v + 1]; ++a) stc(rd_first + g.pos_of[g.head[a]] / kMB, RG + 1);
       }
+    };
+    constexpr bool kLocalPasses = true;
+    if (local && kLocalPasses) {
+      // Only what the step can have changed: its first relabelling starts from heights that are exact but for the
+      // new sink arc at the fixed node's mate (and the fixed node itself); a later one resets the touched tiles,
+      // every other node has the height it started the step with (the check build verifies exactly that).
+      if (warm) {
+        if (blockIdx.x == 0 && threadIdx.x < 2) {
+          const int v = fixed_node + (threadIdx.x ? improve_N : 0);
+          start_height(v, ldc(g.snk + v), ldc(h + v), n);
+        }
+      } else {
+        for (int T = blockIdx.x; T < g.ntiles; T += gridDim.x) {
+          if (!ldc(touched + T)) continue;
+          const int v = g.perm[T * kMB + threadIdx.x];
+          if (v >= 0) start_height(v, ldc(g.snk + v), ldc(h + v), ldc(g.keep + v));
+        }
+      }
+    } else {
+      // (four nodes per thread requested together: the loads are agent-scope and would otherwise go one by one)
+      for (int v0 = first; v0 < n; v0 += 4 * stride) {
+        double sk4[4];
+        int ch4[4], kh4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int v = v0 + u * stride < n ? v0 + u * stride : v0;
+          sk4[u] = ldc(g.snk + v);
+          ch4[u] = (warm || local) ? ldc(h + v) : n;
+          kh4[u] = confined ? ldc(g.keep + v) : n;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (v0 + u * stride < n) start_height(v0 + u * stride, sk4[u], ch4[u], kh4[u]);
+      }
     }
+#ifdef STEREO_HIP_QPBO_CHECK_CONFINED
+    // development check: the local pass left every node where the pass over all nodes would have put it
+    if (local && kLocalPasses && g.counters) {
+      __syncthreads();
+      for (int v = first; v < n; v += stride) {
+        const int cur_h = ldc(h + v);
+        const int old_h = warm ? cur_h : ldc(g.keep + v);
+        const int want = ldc(g.snk + v) > 0 ? 1 : (old_h < n ? old_h : n);
+        const bool mine_to_write = warm ? (v == fixed_node || v == fixed_node + improve_N) : ldc(touched + g.pos_of[v] / kMB) != 0;
+        if (!mine_to_write && want != cur_h && atomicAdd(g.counters + 1108, 1) == 0) {
+          g.counters[1110] = v; g.counters[1111] = cur_h; g.counters[1112] = want; g.counters[1113] = warm ? 1 : 0;
+        }
+      }
+    }
+#endif
     // A tile is relaxed again only if a height next to it went down in the last step (every tile in
     // the first): once a tile has reached its fixpoint it stays there until an input changes.  The
     // search front crosses the image, the warm search of an Improve step touches a small region.
@@ -395,7 +444,37 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     slotA = (slotA + 1) % 3;
     clear_next(QpboCtl::kActive, slotA);
     int cnt = 0;
-    for (int v = first; v < n; v += stride) cnt += (ldc(g.ex + v) > 0 && ldc(h + v) < n) ? 1 : 0;
+    if (local && kLocalPasses) {
+      // (a node that can move excess inside such a step was lowered by the step: it lies in a touched tile)
+      for (int T = blockIdx.x; T < g.ntiles; T += gridDim.x) {
+        if (!ldc(touched + T)) continue;
+        const int v = g.perm[T * kMB + threadIdx.x];
+        if (v >= 0) cnt += (ldc(g.ex + v) > 0 && ldc(h + v) < n) ? 1 : 0;
+      }
+    } else {
+      for (int v0 = first; v0 < n; v0 += 4 * stride) {
+        double e4[4];
+        int h4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int v = v0 + u * stride < n ? v0 + u * stride : v0;
+          e4[u] = ldc(g.ex + v); h4[u] = ldc(h + v);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cnt += (v0 + u * stride < n && e4[u] > 0 && h4[u] < n) ? 1 : 0;
+#ifdef STEREO_HIP_QPBO_CHECK_CONFINED
+#pragma unroll
+        for (int u = 0; u < 4; ++u)   // development check: inside a local step excess only moves in touched tiles
+          if (local && g.counters && v0 + u * stride < n && e4[u] > 0 && h4[u] < n && !ldc(touched + g.pos_of[v0 + u * stride] / kMB))
+            atomicAdd(g.counters + 1107, 1);
+#endif
+      }
+    }
+#ifdef STEREO_HIP_QPBO_CHECK_CONFINED
+    if (local && kLocalPasses && g.counters)   // development check: nothing that can move excess outside the touched tiles
+      for (int v = first; v < n; v += stride)
+        if (ldc(g.ex + v) > 0 && ldc(h + v) < n && !ldc(touched + g.pos_of[v] / kMB)) atomicAdd(g.counters + 1109, 1);
+#endif
     cnt = wg_any(cnt > 0, s_any, any_slot) ? cnt : 0;
     if (threadIdx.x == 0) s_red = 0;
     __syncthreads();
@@ -438,7 +517,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         const double sk = g.snk[v];
         if (sk > 0) {
           const double d = e < sk ? e : sk;
-          g.snk[v] = sk - d;
+          stc(g.snk + v, sk - d);   // (written through: the local passes of an Improve step read it from another workgroup)
           e -= d;
         }
       }
@@ -477,7 +556,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
           e -= d;
         }
       }
-      g.ex[v] = e;
+      stc(g.ex + v, e);
     }
     if (!grid_sync(ctl, gen)) return;
     // ---- gather the pushed flow in the node's own arc order, relabel from the post-push residual graph
@@ -502,7 +581,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         const double d = ldc(g.delta + b);
         if (d != 0) { e += d; stc(g.delta + b, 0.0); }
       }
-      g.ex[v] = e;
+      stc(g.ex + v, e);
       int hv = ldc(h + v);
       if (e > 0 && hv < n) {
         int hmin = n;
@@ -803,7 +882,8 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     // (the argument for `confined` needs the node that receives the excess to be cut off from the sink: "neither
     // side connected".  The other ambiguous case, both sides connected, sends the new excess through nodes that
     // do have a path and lengthens distances there: those steps relabel from scratch.)
-    keep_valid = g.keep != nullptr && ldc(g.keep + improve_perm[next]) >= n;
+    fixed_node = improve_perm[next];
+    keep_valid = g.keep != nullptr && ldc(g.keep + fixed_node) >= n;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       stc(other, N);
       // AddUnaryTerm(i, 0, INFTY), INFTY = max(-t_i + sum of outgoing residuals, t_i + sum of incoming) + 1
@@ -1254,8 +1334,11 @@ struct QpboSolver {
     STEREO_HIP_CHECK(hipMemcpy(host_ctl, d_ctl.p, sizeof(host_ctl), hipMemcpyDeviceToHost));
 #ifdef STEREO_HIP_QPBO_CHECK_CONFINED
     {
-      int32_t dbg[8];
+      int32_t dbg[16];
       STEREO_HIP_CHECK(hipMemcpy(dbg, d_cnt.p + 1100, sizeof(dbg), hipMemcpyDeviceToHost));
+      if (dbg[8] || dbg[9])
+        std::fprintf(stderr, "[stereo_hip qpbo] confined check: local passes: %d nodes left at another height than the full pass (first v=%d has %d wants %d, warm %d), %d active nodes outside the touched tiles\n",
+                     dbg[8], dbg[10], dbg[11], dbg[12], dbg[13], dbg[9]);
       if (dbg[0] || dbg[7])
         std::fprintf(stderr, "[stereo_hip qpbo] confined check: %d unsupported nodes, %d heights outside the touched tiles changed; first v=%d (N=%d) h=%d keep=%d excess=%d relabel#%d step %d\n",
                      dbg[0], dbg[7], dbg[1], (int)P.N, dbg[2], dbg[3], dbg[4], dbg[5], dbg[6]);
