@@ -57,6 +57,13 @@ struct QpboDev {
   // (a 16 x 32 pixel patch and its mates when the grid shape is known).
   const int32_t *perm, *pos_of;
   int ntiles;
+  // graphs with at most four arcs per node: what a tile needs to know about its arcs, by tile position, so that
+  // a tile is loaded in two dependent round trips (this table | the state it points to) instead of four
+  // (node -> arc range -> heads -> their positions).  13 words per position, one array per word:
+  // [0] first arc | degree << 28, [1 + k] head of arc k, [5 + k] slot of the head in this tile | index of the
+  // reverse arc among the head's arcs << 10, or -1 - (the head's tile), [9 + k] reverse arc.  Filled at the
+  // start of a launch (the heads depend on the move), kept for the Improve launch of the same move.
+  int32_t *tab;
   // tiled rounds: dirty[parity][tile] == number of the round = the tile holds excess that can still move, or
   // flow was pushed into it across its border in the round before; other tiles are skipped.  (Round numbers
   // instead of flags that are cleared: every workgroup reads ALL marks of a round to find its share of the
@@ -196,6 +203,36 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     if (blockIdx.x == 0 && threadIdx.x == 0)
       __hip_atomic_store(ctl + base + (slot + 1) % 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
+  const bool tabbed = g.tab != nullptr && tiled > 0;
+  const size_t tabn = (size_t)g.ntiles * kMB;
+  if (tabbed && improve_perm == nullptr) {
+    for (int T = blockIdx.x; T < g.ntiles; T += gridDim.x) {
+      const size_t p = (size_t)T * kMB + threadIdx.x;
+      const int v = g.perm[p];
+      int a0 = 0, deg = 0;
+      if (v >= 0) { a0 = g.aptr[v]; deg = g.aptr[v + 1] - a0; }
+      int w4[4], rv4[4], pw4[4], aw4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int a = k < deg ? a0 + k : 0;
+        const int w = g.head[a], rv = g.rev[a];
+        w4[k] = k < deg ? w : 0; rv4[k] = k < deg ? rv : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { pw4[k] = g.pos_of[w4[k]]; aw4[k] = g.aptr[w4[k]]; }
+      g.tab[p] = a0 | (deg << 28);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        g.tab[(1 + k) * tabn + p] = w4[k];
+        g.tab[(5 + k) * tabn + p] = pw4[k] / kMB == T ? ((pw4[k] % kMB) | ((rv4[k] - aw4[k]) << 10)) : -1 - pw4[k] / kMB;
+        g.tab[(9 + k) * tabn + p] = rv4[k];
+      }
+    }
+    // (plain stores, read by whichever workgroup is dealt the tile: written back before the barrier, and the
+    // relabelling every solve starts with invalidates before anybody reads)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (!grid_sync(ctl, gen)) return;
+  }
   // Exact distances to the sink in the residual graph, then #active nodes.  Label correcting
   // instead of one grid barrier per BFS level: every workgroup relaxes h[v] = min(h[v], h[w] + 1)
   // over the residual arcs of its tile (heights in LDS, arc status in registers) until nothing
@@ -332,12 +369,41 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         int lidx[kArcRegs];  // residual arc to a node of this tile: its slot in s_h; every other arc: the slot that holds n
         int extT[kArcRegs];  // tile of the arc's head if it is another tile (whatever the residual), else -1
         int ext_best = n;    // what the residual arcs that leave the tile allow (their heads do not move during this step)
-        if (v >= 0) {
-          my = ldc(h + v);
-          a0 = g.aptr[v]; a1 = g.aptr[v + 1];
-        }
-        s_h[threadIdx.x] = my;
-        {
+        if (tabbed) {
+          // the arc table of the tile position, then the state it points to: two dependent round trips
+          const size_t p = (size_t)T * kMB + threadIdx.x;
+          const int ta = g.tab[p];
+          int tw[4], tl[4], hwk[4];
+          double rk[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { tw[k] = g.tab[(1 + k) * tabn + p]; tl[k] = g.tab[(5 + k) * tabn + p]; }
+          a0 = ta & 0x0fffffff; a1 = a0 + (int)((unsigned)ta >> 28);
+          my = v >= 0 ? ldc(h + v) : n;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            hwk[k] = ldc(h + tw[k]);
+            rk[k] = g.r[a0 + k < a1 ? a0 + k : 0];
+          }
+#pragma unroll
+          for (int k = 0; k < kArcRegs; ++k) { lidx[k] = kMB; extT[k] = -1; }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (a0 + k < a1) {
+              const bool inside = tl[k] >= 0;
+              if (!inside) extT[k] = -1 - tl[k];
+              if (rk[k] > 0) {
+                if (inside) lidx[k] = tl[k] & (kMB - 1);
+                else ext_best = hwk[k] + 1 < ext_best ? hwk[k] + 1 : ext_best;
+              }
+            }
+          }
+          s_h[threadIdx.x] = my;
+        } else {
+          if (v >= 0) {
+            my = ldc(h + v);
+            a0 = g.aptr[v]; a1 = g.aptr[v + 1];
+          }
+          s_h[threadIdx.x] = my;
           // heads, then everything that hangs on them, requested together: three dependent round trips per tile
           int wk[kArcRegs], pwk[kArcRegs], hwk[kArcRegs];
           double rk[kArcRegs];
@@ -684,7 +750,42 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         double e = 0;
         int hv = n;
         double sk = 0, rk[4] = {0, 0, 0, 0};
-        if (valid) {
+        if (tabbed) {
+          // the arc table of the tile position, then the state it points to: two dependent round trips
+          const size_t p = (size_t)T * kMB + threadIdx.x;
+          const int ta = g.tab[p];
+          int tw[4], tl[4], rvs[4], hwk[4];
+          double din_k[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            tw[k] = g.tab[(1 + k) * tabn + p]; tl[k] = g.tab[(5 + k) * tabn + p]; rvs[k] = g.tab[(9 + k) * tabn + p];
+          }
+          a0 = ta & 0x0fffffff; deg = (int)((unsigned)ta >> 28);
+          const int vv = valid ? v : 0;
+          e = ldc(g.ex + vv); hv = ldc(h + vv); sk = ldc(g.snk + vv);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            rk[k] = ldc(g.r + (k < deg ? a0 + k : 0));
+            hwk[k] = ldc(h + tw[k]); din_k[k] = ldc(din + rvs[k]);
+          }
+          if (!valid) { e = 0; hv = n; sk = 0; }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (k < deg) {
+              if (tl[k] >= 0) { loc[k] = tl[k] & (kMB - 1); rvk[k] = tl[k] >> 10; din_k[k] = 0; }
+              else { exth[k] = hwk[k]; extT[k] = -1 - tl[k]; }
+            } else {
+              rk[k] = 0; din_k[k] = 0;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (k < deg && din_k[k] != 0) {  // flow that arrived over this arc's reverse during the last round
+              e += din_k[k]; rk[k] += din_k[k];
+              stc(din + rvs[k], 0.0);
+            }
+          }
+        } else if (valid) {
           // four dependent round trips per tile: node | its terminals and arc range | heads, reverse arcs,
           // residuals | what hangs on the heads -- each level requested as a whole before any of it is used
           e = ldc(g.ex + v); hv = ldc(h + v);
@@ -735,6 +836,13 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         QPROF_ADD(8, qt1 - qt0); QPROF_ADD(12, 1);
         for (int l = 0; l < L; ++l) {
           QPROF_ADD(13, 1);
+          // the neighbours' heights of this round, requested together (the buffer being read does not change
+          // before the round's last barrier: the push and the relabel below see the same values)
+          int hw4[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) hw4[k] = hcur[loc[k] >= 0 ? loc[k] : threadIdx.x];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) hw4[k] = loc[k] >= 0 ? hw4[k] : exth[k];
           // push (a pair of arcs is only modified by the endpoint that is higher)
           if (valid && e > 0 && hv < n) {
             if (hv == 1 && sk > 0) {
@@ -746,7 +854,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
             for (int k = 0; k < 4; ++k) {
               if (k < deg && e > 0 && rk[k] > 0) {
                 const bool local = loc[k] >= 0;
-                const int hw = local ? hcur[loc[k]] : exth[k];
+                const int hw = hw4[k];
                 if ((local || l == 0) && hv == hw + 1) {
                   const double d = e < rk[k] ? e : rk[k];
                   rk[k] -= d;
@@ -775,10 +883,8 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
                 // outside heights are lower bounds.  An outside neighbour that stood exactly one above
                 // this node at the barrier may have pushed to it in this round; the residual that gives
                 // this node's arc arrives with the next round, so the arc counts as open until then.
-                if (k < deg && (rk[k] > 0 || (loc[k] < 0 && exth[k] == h0 + 1))) {
-                  const int hw = loc[k] >= 0 ? hcur[loc[k]] : exth[k];
-                  hmin = hw < hmin ? hw : hmin;
-                }
+                if (k < deg && (rk[k] > 0 || (loc[k] < 0 && exth[k] == h0 + 1)))
+                  hmin = hw4[k] < hmin ? hw4[k] : hmin;
               }
               if (hmin + 1 > hv) newh = hmin + 1 < n ? hmin + 1 : n;
             }
@@ -1169,7 +1275,7 @@ namespace {
 struct QpboSolver {
   QpboProblem P;
   int n = 0, m = 0;
-  DevBuf<int32_t> d_aptr, d_head, d_rev, d_h, d_h2, d_cnt, d_flags, d_ctl, d_perm, d_posof, d_dirty, d_keep;
+  DevBuf<int32_t> d_aptr, d_head, d_rev, d_h, d_h2, d_cnt, d_flags, d_ctl, d_perm, d_posof, d_dirty, d_keep, d_tab;
   DevBuf<double> d_r, d_delta, d_ex, d_snk;
   std::vector<double> snk0;
   QpboDev g{};
@@ -1232,6 +1338,12 @@ struct QpboSolver {
     d_dirty.alloc((size_t)4 * std::max(g.ntiles, 1));
     STEREO_HIP_CHECK(hipMemset(d_dirty.p, 0, sizeof(int32_t) * 4 * std::max(g.ntiles, 1)));
     g.dirty = d_dirty.p; g.rdirty = d_dirty.p + (size_t)2 * std::max(g.ntiles, 1);
+    // the arc table of the tiled rounds (QpboDev::tab): graphs with at most four arcs per node
+    g.tab = nullptr;
+    if (max_degree <= 4 && !std::getenv("STEREO_HIP_QPBO_NO_TABLE")) {
+      d_tab.alloc((size_t)13 * perm.size());
+      g.tab = d_tab.p;
+    }
   }
 
   // AddUnaryTerm(i, 0, INFTY) with INFTY = 1 + max over the two saturation sums of node i

@@ -107,6 +107,29 @@ def test_improve_matches_reference(hip, oracle):
     assert ran > 0, "no case exercised Improve"
 
 
+def test_improve_confined_relabelling_changes_nothing(hip, oracle, monkeypatch):
+    """The relabellings inside an Improve step start from the heights of the step's starting flow and only
+    look at the tiles the step touched (qpbo.hip, `confined` / `local`); STEREO_HIP_QPBO_CONFINED=0 keeps the
+    search from scratch over all nodes.  Same fixpoint: labels, energy and bound bit for bit, on problems
+    with both kinds of ambiguous node (neither / both sides connected) and on one with several tiles."""
+    if not oracle.have_ref_qpbo():
+        pytest.skip("oracle/_ref/libref_qpbo.so not present")
+    ran = 0
+    for seed, H, W in [(40, 8, 9), (43, 8, 9), (13, 30, 41), (14, 70, 90)]:
+        p = glass_problem(seed, H, W, field=3.0, integer=(seed % 2 == 0))
+        args = (p["U0"], p["U1"], p["E00"], p["E01"], p["E10"], p["E11"])
+        out = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("STEREO_HIP_QPBO_CONFINED", mode)
+            oracle.ref_qpbo().ref_srand(seed)
+            out[mode] = hip.rd(*args, p["conn"].T + 1, {"improve": True})
+        monkeypatch.delenv("STEREO_HIP_QPBO_CONFINED")
+        assert np.array_equal(out["1"][0], out["0"][0]), "seed %d" % seed
+        assert out["1"][1] == out["0"][1] and out["1"][2] == out["0"][2] and out["1"][3] == out["0"][3]
+        ran += int(out["1"][3] > 0)
+    assert ran > 0, "no case exercised Improve"
+
+
 def test_rd_golden_vectors(hip):
     """Committed reference outputs (tests/golden/rd_runs.npz): no oracle/_ref needed."""
     import ctypes

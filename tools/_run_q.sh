@@ -1,6 +1,6 @@
-bash tools/gpu_qpbo.sh r04s
+bash tools/gpu_qpbo.sh r04u
+echo "=== no table"
+STEREO_HIP_QPBO_NO_TABLE=1 timeout 600 python examples/example_global.py 2>&1 | tail -1
+STEREO_HIP_QPBO_NO_TABLE=1 timeout 600 python examples/example_global.py 2>&1 | tail -1
 echo "=== check build"
-for seed in 13 4135; do
-STEREO_HIP_LIB=stereo_amd/libstereo_hip_chk.so timeout 300 python tools/stress_improve.py 40 $seed > gpurun_out/r04s_chk.log 2>&1; grep -c "confined check" gpurun_out/r04s_chk.log; grep "confined check" gpurun_out/r04s_chk.log | head -4; tail -1 gpurun_out/r04s_chk.log
-done
-STEREO_HIP_LIB=stereo_amd/libstereo_hip_chk.so timeout 600 python examples/example_global.py 2>&1 | grep -E "confined check|moves/s" | tail -3
+STEREO_HIP_LIB=stereo_amd/libstereo_hip_chk.so timeout 300 python tools/stress_improve.py 40 13 > gpurun_out/r04u_chk.log 2>&1; grep -c "confined check" gpurun_out/r04u_chk.log; tail -1 gpurun_out/r04u_chk.log
