@@ -64,6 +64,7 @@ struct QpboDev {
   // reverse arc among the head's arcs << 10, or -1 - (the head's tile), [9 + k] reverse arc.  Filled at the
   // start of a launch (the heads depend on the move), kept for the Improve launch of the same move.
   int32_t *tab;
+  unsigned long long *hx;   // tiled rounds: hx_pack word per node (nullptr: no tiled rounds)
   // tiled rounds: dirty[parity][tile] == number of the round = the tile holds excess that can still move, or
   // flow was pushed into it across its border in the round before; other tiles are skipped.  (Round numbers
   // instead of flags that are cleared: every workgroup reads ALL marks of a round to find its share of the
@@ -101,6 +102,20 @@ constexpr int kGridSpinLimit = 1 << 24;
 #endif
 __device__ __forceinline__ int ldc(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void stc(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ldc(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stc(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// One word per node for the tiled rounds: height | height at the last grid barrier << 24 | round of the store << 48.
+// A tile reads its outside neighbours' heights AS OF THE BARRIER (only then does exactly the higher endpoint of an
+// arc pair push), but tiles are stored while others are still being loaded -- a workgroup's second tile of a round
+// starts when its neighbours' first tiles are done.  The owner stores all three in one word, the reader takes the
+// old height if the word was written in the running round: the same result whatever the timing.
+__device__ __forceinline__ unsigned long long hx_pack(int cur, int prev, int round) {
+  return (unsigned long long)(unsigned)cur | ((unsigned long long)(unsigned)prev << 24) | ((unsigned long long)(round & 0xffff) << 48);
+}
+__device__ __forceinline__ int hx_at_barrier(unsigned long long w, int round) {
+  const int cur = (int)(w & 0xffffffu), prev = (int)((w >> 24) & 0xffffffu);
+  return (int)(w >> 48) == (round & 0xffff) ? prev : cur;
+}
 __device__ __forceinline__ double ldc(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void stc(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -203,6 +218,8 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     if (blockIdx.x == 0 && threadIdx.x == 0)
       __hip_atomic_store(ctl + base + (slot + 1) % 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
+  int G = 0;   // tiled rounds of this launch so far (marks, pushed-amount buffers and hx words are numbered by it)
+  bool hx_refresh_all = false;
   const bool tabbed = g.tab != nullptr && tiled > 0;
   const size_t tabn = (size_t)g.ntiles * kMB;
   if (tabbed && improve_perm == nullptr) {
@@ -515,8 +532,14 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
       for (int T = blockIdx.x; T < g.ntiles; T += gridDim.x) {
         if (!ldc(touched + T)) continue;
         const int v = g.perm[T * kMB + threadIdx.x];
-        if (v >= 0) cnt += (ldc(g.ex + v) > 0 && ldc(h + v) < n) ? 1 : 0;
+        if (v >= 0) {
+          const int hh = ldc(h + v);
+          cnt += (ldc(g.ex + v) > 0 && hh < n) ? 1 : 0;
+          if (g.hx) stc(g.hx + v, hx_pack(hh, hh, 0));   // (the heights the next tiled round reads)
+        }
       }
+      if (hx_refresh_all && g.hx)
+        for (int v = first; v < n; v += stride) { const int hh = ldc(h + v); stc(g.hx + v, hx_pack(hh, hh, 0)); }
     } else {
       for (int v0 = first; v0 < n; v0 += 4 * stride) {
         double e4[4];
@@ -528,6 +551,11 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) cnt += (v0 + u * stride < n && e4[u] > 0 && h4[u] < n) ? 1 : 0;
+        if (g.hx) {   // (the heights the next tiled round reads)
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (v0 + u * stride < n) stc(g.hx + v0 + u * stride, hx_pack(h4[u], h4[u], 0));
+        }
 #ifdef STEREO_HIP_QPBO_CHECK_CONFINED
 #pragma unroll
         for (int u = 0; u < 4; ++u)   // development check: inside a local step excess only moves in touched tiles
@@ -541,6 +569,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
       for (int v = first; v < n; v += stride)
         if (ldc(g.ex + v) > 0 && ldc(h + v) < n && !ldc(touched + g.pos_of[v] / kMB)) atomicAdd(g.counters + 1109, 1);
 #endif
+    hx_refresh_all = false;
     cnt = wg_any(cnt > 0, s_any, any_slot) ? cnt : 0;
     if (threadIdx.x == 0) s_red = 0;
     __syncthreads();
@@ -710,16 +739,21 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     // hand-over from the plain rounds: heights into g.h, excess and sink capacities written through
     // (from here on the workgroup that owns a node's tile reads and writes them)
     for (int v = first; v < n; v += stride) {
-      if (h != g.h) stc(g.h + v, ldc(h + v));
+      const int hh = ldc(h + v);
+      if (h != g.h) stc(g.h + v, hh);
+      if (g.hx) stc(g.hx + v, hx_pack(hh, hh, 0));
       stc(g.ex + v, g.ex[v]); stc(g.snk + v, g.snk[v]);
     }
     h = g.h; h2 = g.h2;
-    int G = 0;  // global round number: pushes of round G land in delta buffer G & 1
+    // (G, the round number: pushes of round G land in delta buffer G & 1)
     // Few tiles hold excess after the plain rounds (7k active nodes in some dozens of 660 tiles on
     // the long globalstereo moves): a tile without excess that can move and without flow arriving
     // over its border does not change in a round, so it is skipped -- exactly, not heuristically.
     // After an exact relabelling every tile is looked at once (nodes may have become active again).
     auto mark_all_dirty = [&]() {
+      // (hx words carry 16 bits of the round number: long before they wrap, start again from 0 and have the
+      // relabelling that follows every call rewrite all words as "not stored in any round"; nothing is in transit here)
+      if (G > 60000) { G = 0; hx_refresh_all = true; }
       for (int T = first; T < g.ntiles; T += stride) stc(g.dirty + (size_t)((G + 1) & 1) * g.ntiles + T, G + 1);
     };
     mark_all_dirty();
@@ -766,7 +800,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             rk[k] = ldc(g.r + (k < deg ? a0 + k : 0));
-            hwk[k] = ldc(h + tw[k]); din_k[k] = ldc(din + rvs[k]);
+            hwk[k] = hx_at_barrier(ldc(g.hx + tw[k]), G); din_k[k] = ldc(din + rvs[k]);
           }
           if (!valid) { e = 0; hv = n; sk = 0; }
 #pragma unroll
@@ -803,7 +837,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             pwk[k] = g.pos_of[wk[k]]; awk[k] = g.aptr[wk[k]];
-            hwk[k] = ldc(h + wk[k]); din_k[k] = ldc(din + rvs[k]);
+            hwk[k] = hx_at_barrier(ldc(g.hx + wk[k]), G); din_k[k] = ldc(din + rvs[k]);
           }
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -899,6 +933,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         if (valid) {
           stc(g.ex + v, e); stc(g.snk + v, sk);  // read by other workgroups in the relabelling
           stc(h + v, hv);
+          stc(g.hx + v, hx_pack(hv, h0, G));
 #pragma unroll
           for (int k = 0; k < 4; ++k)
             if (k < deg) stc(g.r + a0 + k, rk[k]);
@@ -1277,6 +1312,7 @@ struct QpboSolver {
   int n = 0, m = 0;
   DevBuf<int32_t> d_aptr, d_head, d_rev, d_h, d_h2, d_cnt, d_flags, d_ctl, d_perm, d_posof, d_dirty, d_keep, d_tab;
   DevBuf<double> d_r, d_delta, d_ex, d_snk;
+  DevBuf<unsigned long long> d_hx;
   std::vector<double> snk0;
   QpboDev g{};
   int64_t iterations = 0, relabels = 0;
@@ -1339,6 +1375,11 @@ struct QpboSolver {
     STEREO_HIP_CHECK(hipMemset(d_dirty.p, 0, sizeof(int32_t) * 4 * std::max(g.ntiles, 1)));
     g.dirty = d_dirty.p; g.rdirty = d_dirty.p + (size_t)2 * std::max(g.ntiles, 1);
     // the arc table of the tiled rounds (QpboDev::tab): graphs with at most four arcs per node
+    g.hx = nullptr;
+    if (max_degree <= 4 && 2 * Nn < (1 << 24)) {   // tiled rounds (heights fit the 24-bit fields of an hx word)
+      d_hx.alloc((size_t)2 * Nn);
+      g.hx = d_hx.p;
+    }
     g.tab = nullptr;
     if (max_degree <= 4 && !std::getenv("STEREO_HIP_QPBO_NO_TABLE")) {
       d_tab.alloc((size_t)13 * perm.size());
@@ -1427,7 +1468,7 @@ struct QpboSolver {
     int32_t *ctl = d_ctl.p;
     int max_rounds = 1 << 21;
     // tiled rounds: every node has at most four arcs and the pushed-amount buffer has two halves
-    int tiled = (max_degree <= 4 && d_delta.n >= (size_t)2 * std::max(m, 1)) ? 16 : 0;
+    int tiled = (max_degree <= 4 && g.hx != nullptr && d_delta.n >= (size_t)2 * std::max(m, 1)) ? 16 : 0;
     if (const char *e = std::getenv("STEREO_HIP_QPBO_TILED")) tiled = tiled ? std::max(0, std::atoi(e)) : 0;
     const size_t dyn = tiled ? sizeof(double) * 4 * kMB : 0;
     int switch_at = 16;  // plain rounds first: most moves end within a dozen of them
