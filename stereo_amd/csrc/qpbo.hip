@@ -359,9 +359,9 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
       for (int T = first; T < g.ntiles; T += stride)
         if (ldc(touched + T)) stc(rd_first + T, RG + 1);
     }
-    // residuals do not change during the relabelling: after this invalidate plain loads of r see
-    // what the (write-through, sc1) pushes stored
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // (everything another workgroup may have written inside the launch -- heights, residuals, excess, sink
+    // capacities -- is read with agent-scope loads; an acquire fence here, i.e. an invalidate of the whole L2 per
+    // relabelling, cost more than those loads: STEREO_HIP_QPBO_PROFILE, `init`)
     QPROF_T(qp1);
     QPROF_ADD(0, qp1 - qp0);
     if (!grid_sync(ctl, gen)) return false;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             hwk[k] = ldc(h + tw[k]);
-            rk[k] = g.r[a0 + k < a1 ? a0 + k : 0];
+            rk[k] = ldc(g.r + (a0 + k < a1 ? a0 + k : 0));
           }
 #pragma unroll
           for (int k = 0; k < kArcRegs; ++k) { lidx[k] = kMB; extT[k] = -1; }
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
             if (k < nk) {
               pwk[k] = g.pos_of[wk[k]];
               hwk[k] = ldc(h + wk[k]);
-              rk[k] = a0 + k < a1 ? g.r[a0 + k] : 0.0;
+              rk[k] = a0 + k < a1 ? ldc(g.r + a0 + k) : 0.0;
             }
           }
 #pragma unroll
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
               best = hw < best ? hw : best;
             }
             for (int a = a0 + kArcRegs; a < a1; ++a) {  // nodes of higher degree: the rest from memory
-              if (!(g.r[a] > 0)) continue;
+              if (!(ldc(g.r + a) > 0)) continue;
               const int w = g.head[a], pw = g.pos_of[w];
               const int hw = pw / kMB == T ? s_h[pw % kMB] : ldc(h + w);
               best = hw + 1 < best ? hw + 1 : best;
@@ -605,11 +605,11 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
   while (active > 0 && rounds < max_rounds && (tiled <= 0 || (rounds < switch_at && !slow_tail))) {
     // ---- push (old heights; a pair of arcs is only modified by the endpoint that is higher)
     for (int v = first; v < n; v += stride) {
-      double e = g.ex[v];
+      double e = ldc(g.ex + v);
       const int hv = ldc(h + v);
       if (!(e > 0) || hv >= n) continue;
       if (hv == 1) {
-        const double sk = g.snk[v];
+        const double sk = ldc(g.snk + v);
         if (sk > 0) {
           const double d = e < sk ? e : sk;
           stc(g.snk + v, sk - d);   // (written through: the local passes of an Improve step read it from another workgroup)
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     clear_next(QpboCtl::kActive, slotA);
     int cnt = 0;
     for (int v = first; v < n; v += stride) {
-      double e = g.ex[v];
+      double e = ldc(g.ex + v);
       const int a0 = g.aptr[v], a1 = g.aptr[v + 1];
       constexpr int kB = 8;
       int bb[kB];
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
       int hv = ldc(h + v);
       if (e > 0 && hv < n) {
         int hmin = n;
-        if (g.snk[v] > 0) hmin = 0;
+        if (ldc(g.snk + v) > 0) hmin = 0;
         double rb[kB];
         int hw8[kB];
 #pragma unroll
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
       const int hh = ldc(h + v);
       if (h != g.h) stc(g.h + v, hh);
       if (g.hx) stc(g.hx + v, hx_pack(hh, hh, 0));
-      stc(g.ex + v, g.ex[v]); stc(g.snk + v, g.snk[v]);
+      stc(g.ex + v, ldc(g.ex + v)); stc(g.snk + v, ldc(g.snk + v));
     }
     h = g.h; h2 = g.h2;
     // (G, the round number: pushes of round G land in delta buffer G & 1)
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         int loc[4] = {-1, -1, -1, -1}, rvk[4] = {0, 0, 0, 0}, exth[4] = {n, n, n, n}, extT[4] = {0, 0, 0, 0}, a0 = 0, deg = 0;
         double e = 0;
         int hv = n;
-        double sk = 0, rk[4] = {0, 0, 0, 0};
+        double sk = 0, rk[4] = {0, 0, 0, 0}, e0_in = 0;
         if (tabbed) {
           // the arc table of the tile position, then the state it points to: two dependent round trips
           const size_t p = (size_t)T * kMB + threadIdx.x;
@@ -803,6 +803,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
             hwk[k] = hx_at_barrier(ldc(g.hx + tw[k]), G); din_k[k] = ldc(din + rvs[k]);
           }
           if (!valid) { e = 0; hv = n; sk = 0; }
+          e0_in = e;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             if (k < deg) {
@@ -825,6 +826,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
           e = ldc(g.ex + v); hv = ldc(h + v);
           a0 = g.aptr[v]; deg = g.aptr[v + 1] - a0;
           sk = ldc(g.snk + v);
+          e0_in = e;
           double din_k[4];
           int rvs[4], wk[4], pwk[4], awk[4], hwk[4];
 #pragma unroll
@@ -865,6 +867,9 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         int *hcur = s_h, *hnext = s_h2;
         hcur[threadIdx.x] = hv;
         const int h0 = hv;  // height at the barrier
+        // what this thread has to write back: bit 0 excess, bit 1 sink capacity, bits 2 .. 5 the residuals
+        // (most nodes of a tile do not move in a round; a store that is written through costs what a load does)
+        int wrote = (e0_in != e) ? 0x3d : 0;   // flow taken in over the border: excess and residuals changed
         __syncthreads();
         QPROF_T(qt1);
         QPROF_ADD(8, qt1 - qt0); QPROF_ADD(12, 1);
@@ -883,6 +888,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
               const double d = e < sk ? e : sk;
               sk -= d;
               e -= d;
+              wrote |= 3;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -892,6 +898,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
                 if ((local || l == 0) && hv == hw + 1) {
                   const double d = e < rk[k] ? e : rk[k];
                   rk[k] -= d;
+                  wrote |= 1 | (4 << k);
                   if (local) s_d[loc[k] * 4 + rvk[k]] = d;
                   else { stc(dout + a0 + k, d); stc(dirty_out + extT[k], G + 1); crossed = true; }
                   e -= d;
@@ -907,7 +914,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
             for (int k = 0; k < 4; ++k) {
               if (k < deg) {
                 const double d = s_d[threadIdx.x * 4 + k];
-                if (d != 0) { e += d; rk[k] += d; s_d[threadIdx.x * 4 + k] = 0; }
+                if (d != 0) { e += d; rk[k] += d; s_d[threadIdx.x * 4 + k] = 0; wrote |= 1 | (4 << k); }
               }
             }
             if (e > 0 && hv < n) {
@@ -931,12 +938,15 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
         QPROF_T(qt2);
         QPROF_ADD(9, qt2 - qt1);
         if (valid) {
-          stc(g.ex + v, e); stc(g.snk + v, sk);  // read by other workgroups in the relabelling
-          stc(h + v, hv);
-          stc(g.hx + v, hx_pack(hv, h0, G));
+          if (wrote & 1) stc(g.ex + v, e);   // (written through: read by other workgroups)
+          if (wrote & 2) stc(g.snk + v, sk);
+          if (hv != h0) {   // (an unchanged height leaves a word whose current-height field is right whatever its round)
+            stc(h + v, hv);
+            stc(g.hx + v, hx_pack(hv, h0, G));
+          }
 #pragma unroll
           for (int k = 0; k < 4; ++k)
-            if (k < deg) stc(g.r + a0 + k, rk[k]);
+            if (k < deg && (wrote & (4 << k))) stc(g.r + a0 + k, rk[k]);
           if (e > 0 && hv < n) ++cnt;
         }
         // (also the barrier before the tile buffers are reused)
@@ -996,9 +1006,8 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
   // sink (not strongly labelled).  Two result words used in turn (one is cleared while the other is in
   // use), heights in g.h are exact and written through.
   {
-    // what the plain rounds stored with ordinary stores (excess, sink capacities) must be in memory
-    // before another workgroup's thread rewrites a node's terminal capacities below
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // (excess and sink capacities are written through wherever they are stored: nothing to write back
+    // before another workgroup's thread rewrites a node's terminal capacities below)
     const int N = improve_N;
     int32_t *word = ctl + (improve_steps & 1 ? 10 : 15), *other = ctl + (improve_steps & 1 ? 15 : 10);
     if (improve_steps == 0 && blockIdx.x == 0 && threadIdx.x == 0) { stc(word, N); stc(other, N); }   // both start at "none"
