@@ -193,3 +193,36 @@ def test_grid_hint_does_not_change_results(hip):
         a, b = plain.solve(*args), hinted.solve(*args)
         assert np.array_equal(a[0], b[0]) and a[3] == b[3]
         assert _rel(a[1], b[1]) < 1e-12 and _rel(a[2], b[2]) < 1e-12
+
+
+def test_large_grid_move_matches_reference(hip, oracle):
+    """A 1000 x 1500 move (2930 tiles: several per workgroup and round, dealt out; heights beyond 16 bits) and a
+    frustrated 120 x 160 problem with Improve on the image-patch tiling, against the reference library."""
+    import ctypes
+    from stereo_amd.rd import RdPlan
+    if not oracle.have_ref_qpbo():
+        pytest.skip("oracle/_ref/libref_qpbo.so not present")
+    H, W = 1000, 1500
+    p = fusion_problem(321, H, W, nonsub_boost=3.0)
+    args = (p["U0"], p["U1"], p["E00"], p["E01"], p["E10"], p["E11"])
+    ref = oracle.ref_rd(*args, p["conn"])
+    plan = RdPlan(H * W, p["conn"].T, grid=(H, W))
+    for _ in range(2):   # (the second move runs on the buffers, marks and tables the first left behind)
+        lab, en, lb, nu = plan.solve(*args)
+        if np.array_equal(lab, ref[0]):
+            assert nu == ref[3] and _rel(en, ref[1]) < 1e-9
+        else:   # weak labels may differ between incomparable components only: never a worse energy
+            assert en <= ref[1] + 1e-9 * max(1.0, abs(ref[1]))
+            assert np.mean(lab != ref[0]) < 1e-3
+        assert _rel(lb, ref[2]) < 1e-9
+    plan.close()
+    H, W = 120, 160
+    p = glass_problem(322, H, W, 3.0, True)
+    args = (p["U0"], p["U1"], p["E00"], p["E01"], p["E10"], p["E11"])
+    r = oracle.ref_rd(*args, p["conn"], improve=True, seed=7)
+    plan = RdPlan(H * W, p["conn"].T, grid=(H, W))
+    ctypes.CDLL(None).srand(7)
+    b = plan.solve(*args, improve=True)
+    assert b[3] == r[3] and b[3] > 0
+    assert np.array_equal(b[0], r[0])
+    assert _rel(b[1], r[1]) < 1e-9
