@@ -1702,6 +1702,36 @@ double det_sum(const double *x, int64_t n, DevBuf<double> &partial) {
   return s;
 }
 
+
+// Several fixed-shape sums whose results the host only needs later: the kernels are queued as they become
+// possible, one copy brings all block partials back (a synchronous copy per sum was eight host round trips per move).
+struct DetSums {
+  DevBuf<double> &buf;
+  std::vector<std::pair<size_t, int64_t>> slots;   // (offset, #partials)
+  std::vector<double> host;
+  size_t used = 0;
+  static int64_t blocks(int64_t n) { return n > 0 ? (n + kQB * 8 - 1) / (kQB * 8) : 0; }
+  DetSums(DevBuf<double> &b, int64_t capacity) : buf(b) {
+    if (buf.n < (size_t)std::max<int64_t>(capacity, 1)) buf.alloc((size_t)std::max<int64_t>(capacity, 1));
+  }
+  int queue(const double *x, int64_t n) {
+    const int64_t nb = blocks(n);
+    if (used + (size_t)nb > buf.n) throw HipError{"DetSums: capacity"};
+    if (nb > 0) hipLaunchKernelGGL(det_sum_kernel, dim3((unsigned)nb), dim3(kQB), 0, 0, x, n, buf.p + used);
+    slots.push_back({used, nb});
+    used += (size_t)nb;
+    return (int)slots.size() - 1;
+  }
+  void fetch() {
+    host.resize(used);
+    if (used) STEREO_HIP_CHECK(hipMemcpy(host.data(), buf.p, sizeof(double) * used, hipMemcpyDeviceToHost));
+  }
+  double get(int slot) const {
+    double s = 0;
+    for (int64_t k = 0; k < slots[slot].second; ++k) s += host[slots[slot].first + k];  // fixed order
+    return s;
+  }
+};
 }  // namespace
 
 extern "C" int stereo_rd_plan_create(int64_t N, int64_t E, const uint32_t *conn, stereo_rd_plan **plan, char *err,
@@ -1802,11 +1832,12 @@ static int rd_plan_solve_device(stereo_rd_plan *P, const double *const in[6], in
     if (np > 0) hipLaunchKernelGGL(rd_pairs_kernel, dim3((unsigned)((np + kQB - 1) / kQB)), dim3(kQB), 0, 0, d);
     hipLaunchKernelGGL(rd_nodes_kernel, dim3((unsigned)((N + kQB - 1) / kQB)), dim3(kQB), 0, 0, d);
     STEREO_HIP_CHECK(hipMemcpyAsync(P->d_snk0.p, S.d_snk.p, sizeof(double) * n, hipMemcpyDeviceToDevice, 0));
-    // constant of the normal form and sum_i min(0, tr_i): fixed-shape reductions
-    const double konst = det_sum(P->d_konst.p, np, P->d_partial) + det_sum(in[0], N, P->d_partial);
-    const double cap_in = det_sum(P->d_snk0.p, n, P->d_partial);
-    // sum_i min(0, tr_i) = -(sink capacity of the unprimed half)
-    const double neg = -det_sum(P->d_snk0.p, N, P->d_partial);
+    // constant of the normal form and sum_i min(0, tr_i): fixed-shape reductions, queued now and read back
+    // together with the sums that follow the max-flow
+    DetSums sums(P->d_partial, DetSums::blocks(np) + 2 * DetSums::blocks(N) + 2 * DetSums::blocks(n) + DetSums::blocks(N + E));
+    const int s_konst = sums.queue(P->d_konst.p, np), s_u0 = sums.queue(in[0], N);
+    const int s_cap = sums.queue(P->d_snk0.p, n);
+    const int s_neg = sums.queue(P->d_snk0.p, N);   // sum_i min(0, tr_i) = -(sink capacity of the unprimed half)
     S.iterations = 0; S.relabels = 0;
     const bool verbose = std::getenv("STEREO_HIP_QPBO_VERBOSE") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1817,15 +1848,21 @@ static int rd_plan_solve_device(stereo_rd_plan *P, const double *const in[6], in
       STEREO_HIP_CHECK(hipDeviceSynchronize());
       std::fprintf(stderr, "[stereo_hip qpbo plan] maxflow %.3f ms\n", now() - tm0);
     }
-    const double left = det_sum(S.d_snk.p, n, P->d_partial);
-    *lower_bound = konst + neg + (cap_in - left) / 2;
+    const int s_left = sums.queue(S.d_snk.p, n);
     // labels on the device; the host only sees the number of unlabelled nodes
     if ((int64_t)P->d_label.n < N) P->d_label.alloc(N);
     STEREO_HIP_CHECK(hipMemsetAsync(S.d_cnt.p + 3, 0, sizeof(int32_t), 0));
     hipLaunchKernelGGL(rd_labels_kernel, dim3((unsigned)((N + kQB - 1) / kQB)), dim3(kQB), 0, 0, N, n, S.g.h,
                        P->d_label.p, S.d_cnt.p + 3);
+    // the energy of the strong labels, on the bet that no node stays unlabelled (otherwise it is summed again below)
+    hipLaunchKernelGGL(rd_energy_terms_kernel, dim3((unsigned)((N + E + kQB - 1) / kQB)), dim3(kQB), 0, 0, N, E,
+                       P->d_conn.p, S.g.h, n, in[0], in[1], in[2], in[3], in[4], in[5], P->d_label.p, P->d_terms.p);
+    const int s_energy = sums.queue(P->d_terms.p, N + E);
+    sums.fetch();
     int32_t unl32 = 0;
     STEREO_HIP_CHECK(hipMemcpy(&unl32, S.d_cnt.p + 3, sizeof(unl32), hipMemcpyDeviceToHost));
+    const double konst = sums.get(s_konst) + sums.get(s_u0), cap_in = sums.get(s_cap), neg = -sums.get(s_neg);
+    *lower_bound = konst + neg + (cap_in - sums.get(s_left)) / 2;
     double unl = unl32;
     if (unl > 0) {
       // rare: heights and the residual network go to the host for the two-pass DFS / Improve
@@ -1865,9 +1902,13 @@ static int rd_plan_solve_device(stereo_rd_plan *P, const double *const in[6], in
       STEREO_HIP_CHECK(hipMemcpy(l8.data(), P->d_label.p, N, hipMemcpyDeviceToHost));
       for (int64_t i = 0; i < N; ++i) labelling[i] = l8[i];
     }
-    hipLaunchKernelGGL(rd_energy_terms_kernel, dim3((unsigned)((N + E + kQB - 1) / kQB)), dim3(kQB), 0, 0, N, E,
-                       P->d_conn.p, S.g.h, n, in[0], in[1], in[2], in[3], in[4], in[5], P->d_label.p, P->d_terms.p);
-    *energy = det_sum(P->d_terms.p, N + E, P->d_partial);
+    if (unl32 > 0) {   // labels changed on the host (weak persistency, Improve): the energy of the final labelling
+      hipLaunchKernelGGL(rd_energy_terms_kernel, dim3((unsigned)((N + E + kQB - 1) / kQB)), dim3(kQB), 0, 0, N, E,
+                         P->d_conn.p, S.g.h, n, in[0], in[1], in[2], in[3], in[4], in[5], P->d_label.p, P->d_terms.p);
+      *energy = det_sum(P->d_terms.p, N + E, P->d_partial);
+    } else {
+      *energy = sums.get(s_energy);
+    }
     STEREO_HIP_CHECK(hipGetLastError());
     return 0;
   } catch (const HipError &e) {

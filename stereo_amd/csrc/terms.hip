@@ -1060,7 +1060,18 @@ void fusion_update_energy(stereo_fusion *F) {
   hipLaunchKernelGGL(pairwise_terms_kernel, dim3(blocks(F->E)), dim3(kTB), 0, 0, F->kernel, F->E, F->conn.p,
                      F->points.p, F->cur.p, (const double *)nullptr, F->weights.p, F->tol, F->d_min, F->d_step,
                      F->E00.p, F->E01.p, F->E10.p, F->E11.p);
-  F->energy = fusion_sum(F, F->Ucur.p, F->N) + fusion_sum(F, F->E00.p, F->E);
+  // both sums with one copy back (same block partials, same order of addition as two fusion_sum calls)
+  const int64_t N = F->N, E = F->E;
+  const int64_t nbN = N > 0 ? (N + kTB * 8 - 1) / (kTB * 8) : 0, nbE = E > 0 ? (E + kTB * 8 - 1) / (kTB * 8) : 0;
+  if ((int64_t)F->partial.n < nbN + nbE) F->partial.alloc((size_t)(nbN + nbE));
+  if (nbN) hipLaunchKernelGGL(fusion_sum_kernel, dim3((unsigned)nbN), dim3(kTB), 0, 0, F->Ucur.p, N, F->partial.p);
+  if (nbE) hipLaunchKernelGGL(fusion_sum_kernel, dim3((unsigned)nbE), dim3(kTB), 0, 0, F->E00.p, E, F->partial.p + nbN);
+  std::vector<double> h((size_t)(nbN + nbE));
+  if (!h.empty()) STEREO_HIP_CHECK(hipMemcpy(h.data(), F->partial.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+  double tu = 0, te = 0;
+  for (int64_t i = 0; i < nbN; ++i) tu += h[i];
+  for (int64_t i = 0; i < nbE; ++i) te += h[nbN + i];
+  F->energy = tu + te;
 }
 
 }  // namespace
