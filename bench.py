@@ -317,7 +317,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the labelled index-order extra (profiling: its launches are the same kernel and "
                          "would be averaged into the headline kernel's rocprofv3 statistics)")
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-iters", type=int, default=10)
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-cores leg of the CPU baseline")
     ap.add_argument("--message-mode", choices=["exact", "minplus"], default="exact")
     ap.add_argument("--volume", choices=["ncc", "noise"], default="ncc",
@@ -526,7 +526,7 @@ def main():
                                              "(envelope messages), setup excluded" % (ci, W, H, K)}
             if not args.no_cpu_all_cores:
                 try:
-                    out["cpu_baseline"]["all_cores"] = cpu_all_cores(unary, conn, K, ci)
+                    out["cpu_baseline"]["all_cores"] = cpu_all_cores(unary, conn, K, min(ci, 3))
                 except Exception as exc:
                     out["cpu_baseline"]["all_cores"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if world == 1 and not args.no_cpu_baseline:
