@@ -1148,13 +1148,44 @@ __global__ __launch_bounds__(kQB) void rd_nodes_kernel(RdPlanDev d) {
 // strong persistency on the device (QPBO.cpp:840-844): x_i = 1 iff i reaches the sink, 0 iff its
 // mate does, -1 if both or neither; counts the -1s
 __global__ __launch_bounds__(kQB) void rd_labels_kernel(int64_t N, int n, const int32_t *h, int8_t *label,
-                                                       int32_t *unlabelled) {
+                                                       int32_t *unlabelled, int32_t *free_list = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * kQB + threadIdx.x;
   if (i >= N) return;
   const int li = h[i] < n ? 1 : 0, lm = h[i + N] < n ? 1 : 0;
   const int l = li == lm ? -1 : li;
   label[i] = (int8_t)l;
-  if (l < 0) atomicAdd(unlabelled, 1);
+  if (l < 0) {
+    const int slot = atomicAdd(unlabelled, 1);
+    if (free_list) free_list[slot] = (int32_t)i;   // (in no particular order: the host sorts the few there are)
+  }
+}
+
+// The residual arcs of the free nodes (both nodes of every unlabelled variable, ids ascending), for the weak
+// persistency pass on the host: per node its arcs in list order -- head and two bits, residual capacity on the arc
+// and on its reverse.  Only this travels, not the residual network.
+__global__ __launch_bounds__(kQB) void rd_free_arcs_kernel(int cnt, int N, const int32_t *ids, const int32_t *aptr,
+                                                          const int32_t *head, const int32_t *rev, const double *r,
+                                                          int maxdeg, int32_t *out_head, uint8_t *out_flag) {
+  const int t = blockIdx.x * kQB + threadIdx.x;
+  if (t >= 2 * cnt) return;
+  const int v = t < cnt ? ids[t] : ids[t - cnt] + N;
+  const int a0 = aptr[v], deg = aptr[v + 1] - a0;
+  for (int k = 0; k < maxdeg; ++k) {
+    int w = -1;
+    uint8_t f = 0;
+    if (k < deg) {
+      const int a = a0 + k;
+      w = head[a];
+      f = (uint8_t)((r[a] > 0 ? 1 : 0) | (r[rev[a]] > 0 ? 2 : 0));
+    }
+    out_head[(size_t)t * maxdeg + k] = w;
+    out_flag[(size_t)t * maxdeg + k] = f;
+  }
+}
+
+__global__ __launch_bounds__(kQB) void rd_set_labels_kernel(int cnt, const int32_t *ids, const int8_t *lab, int8_t *label) {
+  const int t = blockIdx.x * kQB + threadIdx.x;
+  if (t < cnt) label[ids[t]] = lab[t];
 }
 
 // fixed-shape reduction (same tree for every run): partial[b] = sum of a 2048-element chunk
@@ -1581,6 +1612,68 @@ void weak_persistencies(const QpboProblem &P, const std::vector<double> &r, std:
     }
 }
 
+// The same pass on the free subgraph alone (rd_free_arcs_kernel): local node t < cnt is variable ids[t], t >= cnt its
+// mate; arcs in the order of the arc lists, a head that is not free ends nowhere.  Visiting order, arc order and
+// numbering are those of weak_persistencies, so the labels are the same.  lab[t]: new label of variable ids[t].
+void weak_persistencies_compact(int cnt, int N, const std::vector<int32_t> &ids, int maxdeg,
+                                const std::vector<int32_t> &heads, const std::vector<uint8_t> &flags,
+                                std::vector<int8_t> &lab) {
+  const int M = 2 * cnt;
+  std::vector<int32_t> loc((size_t)M * maxdeg, -1);   // local index of every arc's head, -1: not free / no arc
+  for (int t = 0; t < M; ++t)
+    for (int k = 0; k < maxdeg; ++k) {
+      const int32_t w = heads[(size_t)t * maxdeg + k];
+      if (w < 0) continue;
+      const int32_t var = w >= N ? w - N : w;
+      const auto it = std::lower_bound(ids.begin(), ids.end(), var);
+      if (it != ids.end() && *it == var) loc[(size_t)t * maxdeg + k] = (int32_t)(it - ids.begin()) + (w >= N ? cnt : 0);
+    }
+  std::vector<int32_t> region(M, -1), parent(M, 0), cursor(M, 0), stack;
+  std::vector<uint8_t> seen(M, 0);
+  stack.reserve(M);
+  for (int s0 = 0; s0 < M; ++s0) {
+    if (seen[s0]) continue;
+    int i = s0;
+    seen[i] = 1; parent[i] = i; cursor[i] = 0;
+    for (;;) {
+      if (cursor[i] == maxdeg) {
+        stack.push_back(i);
+        if (parent[i] == i) break;
+        i = parent[i];
+        ++cursor[i];
+        continue;
+      }
+      const size_t a = (size_t)i * maxdeg + cursor[i];
+      const int j = loc[a];
+      if (j < 0 || !(flags[a] & 1) || seen[j]) { ++cursor[i]; continue; }
+      seen[j] = 1; parent[j] = i; i = j; cursor[i] = 0;
+    }
+  }
+  int component = 0;
+  for (int k = (int)stack.size() - 1; k >= 0; --k) {
+    int i = stack[k];
+    if (region[i] > 0) continue;
+    region[i] = ++component; parent[i] = i; cursor[i] = 0;
+    for (;;) {
+      if (cursor[i] == maxdeg) {
+        if (parent[i] == i) break;
+        i = parent[i];
+        ++cursor[i];
+        continue;
+      }
+      const size_t a = (size_t)i * maxdeg + cursor[i];
+      const int j = loc[a];
+      if (j < 0 || !(flags[a] & 2) || region[j] >= 0) { ++cursor[i]; continue; }
+      parent[j] = i; i = j; cursor[i] = 0; region[i] = component;
+    }
+  }
+  lab.assign(cnt, -1);
+  for (int t = 0; t < cnt; ++t) {
+    if (region[t] > region[t + cnt]) lab[t] = 0;
+    else if (region[t] < region[t + cnt]) lab[t] = 1;
+  }
+}
+
 // The permutation of QPBO::Improve (QPBO_extra.cpp:13-27), drawn from libc rand() like the
 // reference's.  Note for callers that seed rand() to reproduce the reference: the HIP runtime draws
 // from the same generator during its one-time initialisation (measured), so initialise it first
@@ -1684,7 +1777,9 @@ struct stereo_rd_plan {
   DevBuf<int32_t> d_pair_i, d_pair_j, d_pe_ptr, d_pe_edge, d_slots, d_slot_pair;
   DevBuf<uint32_t> d_conn;
   DevBuf<double> d_ci, d_cjs, d_konst, d_trv, d_terms, d_partial, d_in[6], d_snk0;
-  DevBuf<int8_t> d_label;
+  DevBuf<int8_t> d_label, d_flab;
+  DevBuf<int32_t> d_free, d_fids, d_fhead;   // unlabelled variables (unordered | sorted), heads of the free nodes' arcs
+  DevBuf<uint8_t> d_fflag;
   QpboSolver S;
 };
 
@@ -1852,8 +1947,9 @@ static int rd_plan_solve_device(stereo_rd_plan *P, const double *const in[6], in
     // labels on the device; the host only sees the number of unlabelled nodes
     if ((int64_t)P->d_label.n < N) P->d_label.alloc(N);
     STEREO_HIP_CHECK(hipMemsetAsync(S.d_cnt.p + 3, 0, sizeof(int32_t), 0));
+    if ((int64_t)P->d_free.n < N) P->d_free.alloc(N);
     hipLaunchKernelGGL(rd_labels_kernel, dim3((unsigned)((N + kQB - 1) / kQB)), dim3(kQB), 0, 0, N, n, S.g.h,
-                       P->d_label.p, S.d_cnt.p + 3);
+                       P->d_label.p, S.d_cnt.p + 3, P->d_free.p);
     // the energy of the strong labels, on the bet that no node stays unlabelled (otherwise it is summed again below)
     hipLaunchKernelGGL(rd_energy_terms_kernel, dim3((unsigned)((N + E + kQB - 1) / kQB)), dim3(kQB), 0, 0, N, E,
                        P->d_conn.p, S.g.h, n, in[0], in[1], in[2], in[3], in[4], in[5], P->d_label.p, P->d_terms.p);
@@ -1865,33 +1961,74 @@ static int rd_plan_solve_device(stereo_rd_plan *P, const double *const in[6], in
     *lower_bound = konst + neg + (cap_in - sums.get(s_left)) / 2;
     double unl = unl32;
     if (unl > 0) {
-      // rare: heights and the residual network go to the host for the two-pass DFS / Improve
-      std::vector<int32_t> h(n);
-      STEREO_HIP_CHECK(hipMemcpy(h.data(), S.g.h, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-      std::vector<int> label(N);
-      for (int64_t i = 0; i < N; ++i) {
-        const int li = h[i] < n ? 1 : 0, lm = h[i + N] < n ? 1 : 0;
-        label[i] = li == lm ? -1 : li;
-      }
-      S.P.head.resize(S.m); S.P.rev.resize(S.m);
-      std::vector<double> r(S.m);
-      STEREO_HIP_CHECK(hipMemcpy(S.P.head.data(), S.d_head.p, sizeof(int32_t) * S.m, hipMemcpyDeviceToHost));
-      STEREO_HIP_CHECK(hipMemcpy(S.P.rev.data(), S.d_rev.p, sizeof(int32_t) * S.m, hipMemcpyDeviceToHost));
-      STEREO_HIP_CHECK(hipMemcpy(r.data(), S.d_r.p, sizeof(double) * S.m, hipMemcpyDeviceToHost));
-      weak_persistencies(S.P, r, label);
-      unl = 0;
-      for (int64_t i = 0; i < N; ++i) if (label[i] < 0) unl += 1;
-      *num_unlabelled = unl;  // rd_mex.cpp:83-88: counted before Improve
-      if (improve && unl > 0) {
-        S.improve(improve_permutation(N), h);
+      const double tw0 = now();
+      std::vector<int32_t> h;
+      const int maxdeg = S.max_degree;
+      const bool compact = maxdeg >= 1 && maxdeg <= 16 && !std::getenv("STEREO_HIP_QPBO_WEAK_FULL");
+      if (compact) {
+        // Weak persistency (QPBO_postprocessing.cpp:10-120) is a two-pass DFS over the FREE nodes only: their ids
+        // come back, the arcs of exactly those nodes are gathered on the device, the pass runs on the host on that
+        // small graph, and the new labels go back by id -- instead of the heights and the whole residual network.
+        const int cnt = unl32;
+        std::vector<int32_t> ids(cnt);
+        STEREO_HIP_CHECK(hipMemcpy(ids.data(), P->d_free.p, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost));
+        std::sort(ids.begin(), ids.end());
+        const size_t na = (size_t)2 * cnt * maxdeg;
+        if (P->d_fids.n < (size_t)cnt) P->d_fids.alloc((size_t)cnt + cnt / 2 + 64);
+        if (P->d_fhead.n < na) { P->d_fhead.alloc(na + na / 2 + 64); P->d_fflag.alloc(na + na / 2 + 64); }
+        if (P->d_flab.n < (size_t)cnt) P->d_flab.alloc((size_t)cnt + cnt / 2 + 64);
+        STEREO_HIP_CHECK(hipMemcpyAsync(P->d_fids.p, ids.data(), sizeof(int32_t) * cnt, hipMemcpyHostToDevice, 0));
+        hipLaunchKernelGGL(rd_free_arcs_kernel, dim3((unsigned)((2 * cnt + kQB - 1) / kQB)), dim3(kQB), 0, 0, cnt, (int)N,
+                           P->d_fids.p, S.d_aptr.p, S.d_head.p, S.d_rev.p, S.d_r.p, maxdeg, P->d_fhead.p, P->d_fflag.p);
+        std::vector<int32_t> heads(na);
+        std::vector<uint8_t> flags(na);
+        STEREO_HIP_CHECK(hipMemcpy(heads.data(), P->d_fhead.p, sizeof(int32_t) * na, hipMemcpyDeviceToHost));
+        STEREO_HIP_CHECK(hipMemcpy(flags.data(), P->d_fflag.p, na, hipMemcpyDeviceToHost));
+        const double tw1 = now();
+        std::vector<int8_t> lab;
+        weak_persistencies_compact(cnt, (int)N, ids, maxdeg, heads, flags, lab);
+        unl = 0;
+        for (int t = 0; t < cnt; ++t) if (lab[t] < 0) unl += 1;
+        STEREO_HIP_CHECK(hipMemcpyAsync(P->d_flab.p, lab.data(), cnt, hipMemcpyHostToDevice, 0));
+        hipLaunchKernelGGL(rd_set_labels_kernel, dim3((unsigned)((cnt + kQB - 1) / kQB)), dim3(kQB), 0, 0, cnt, P->d_fids.p,
+                           P->d_flab.p, P->d_label.p);
+        STEREO_HIP_CHECK(hipStreamSynchronize(0));   // (the host vectors of the two asynchronous copies go out of scope)
+        if (verbose) std::fprintf(stderr, "[stereo_hip qpbo plan] weak persistency: %d free variables, %.3f ms to fetch their arcs, %.3f ms on the host\n", cnt, tw1 - tw0, now() - tw1);
+      } else {
+        // (graphs with long arc lists: heights and the whole residual network go to the host)
+        h.resize(n);
+        STEREO_HIP_CHECK(hipMemcpy(h.data(), S.g.h, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+        std::vector<int> label(N);
         for (int64_t i = 0; i < N; ++i) {
           const int li = h[i] < n ? 1 : 0, lm = h[i + N] < n ? 1 : 0;
-          label[i] = li == lm ? 0 : li;
+          label[i] = li == lm ? -1 : li;
         }
+        S.P.head.resize(S.m); S.P.rev.resize(S.m);
+        std::vector<double> r(S.m);
+        STEREO_HIP_CHECK(hipMemcpy(S.P.head.data(), S.d_head.p, sizeof(int32_t) * S.m, hipMemcpyDeviceToHost));
+        STEREO_HIP_CHECK(hipMemcpy(S.P.rev.data(), S.d_rev.p, sizeof(int32_t) * S.m, hipMemcpyDeviceToHost));
+        STEREO_HIP_CHECK(hipMemcpy(r.data(), S.d_r.p, sizeof(double) * S.m, hipMemcpyDeviceToHost));
+        const double tw1 = now();
+        weak_persistencies(S.P, r, label);
+        unl = 0;
+        for (int64_t i = 0; i < N; ++i) if (label[i] < 0) unl += 1;
+        std::vector<int8_t> l8(N);
+        for (int64_t i = 0; i < N; ++i) l8[i] = (int8_t)label[i];
+        P->d_label.upload(l8.data(), N);
+        if (verbose) std::fprintf(stderr, "[stereo_hip qpbo plan] weak persistency: %.3f ms to fetch the residual network, %.3f ms on the host\n", tw1 - tw0, now() - tw1);
       }
-      std::vector<int8_t> l8(N);
-      for (int64_t i = 0; i < N; ++i) l8[i] = (int8_t)label[i];
-      P->d_label.upload(l8.data(), N);
+      *num_unlabelled = unl;  // rd_mex.cpp:83-88: counted before Improve
+      if (improve && unl > 0) {
+        const double ti0 = now();
+        S.improve(improve_permutation(N), h);   // (returns the final heights)
+        std::vector<int8_t> l8(N);
+        for (int64_t i = 0; i < N; ++i) {
+          const int li = h[i] < n ? 1 : 0, lm = h[i + N] < n ? 1 : 0;
+          l8[i] = (int8_t)(li == lm ? 0 : li);   // QPBO_extra.cpp:1210-1219: ambiguous -> user label (0)
+        }
+        P->d_label.upload(l8.data(), N);
+        if (verbose) std::fprintf(stderr, "[stereo_hip qpbo plan] Improve: %.3f ms\n", now() - ti0);
+      }
     }
     *num_unlabelled = unl;
     if (std::getenv("STEREO_HIP_QPBO_VERBOSE"))
