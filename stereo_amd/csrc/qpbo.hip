@@ -588,6 +588,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
   };
 
   int improve_from = 0, improve_steps = 0;
+  bool heights_copied = false;   // the solve that just ended wrote g.h after its last grid barrier
   bool solve = improve_perm == nullptr;   // the Improve launch starts from a maximal flow: first find a node to fix
   for (;;) {
   if (solve) {
@@ -992,6 +993,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
 
   // heights may be stale lower bounds: one exact BFS defines T; leave it in g.h
   if (!exact && !global_relabel(active)) return;
+  heights_copied = h != g.h;
   if (h != g.h) {
     for (int v = first; v < n; v += stride) stc(g.h + v, ldc(h + v));
   }
@@ -1011,7 +1013,12 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     const int N = improve_N;
     int32_t *word = ctl + (improve_steps & 1 ? 10 : 15), *other = ctl + (improve_steps & 1 ? 15 : 10);
     if (improve_steps == 0 && blockIdx.x == 0 && threadIdx.x == 0) { stc(word, N); stc(other, N); }   // both start at "none"
-    if (!grid_sync(ctl, gen)) return;   // (every workgroup's final heights and terminal capacities are in memory)
+    // (every workgroup's final heights and terminal capacities are in memory: a solve ends with the grid barriers of
+    // its last relabelling, so the barrier is only needed if heights were copied after them -- and in the first step,
+    // between the initialisation of the two result words and their use)
+    if (improve_steps == 0 || heights_copied) {
+      if (!grid_sync(ctl, gen)) return;
+    }
     if (g.keep) {   // the starting point of this step's later relabellings (global_relabel, `confined`)
       for (int v = first; v < n; v += stride) stc(g.keep + v, ldc(g.h + v));
       for (int T = first; T < g.ntiles; T += stride) stc(g.keep + n + T, 0);   // `touched`, global_relabel
@@ -1053,7 +1060,11 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     improve_steps_dbg = improve_steps;
     incremental = 1;   // the heights stay a valid labelling when a unary term changes: warm search
     solve = true;
-    if (!grid_sync(ctl, gen)) return;
+    // the new terminal capacities of the fixed node and its mate: the first reader is the relabelling's start pass --
+    // all workgroups in general, workgroup 0 alone in a `local` step (everybody else meets them behind that
+    // relabelling's own grid barriers)
+    if (keep_valid) __syncthreads();
+    else if (!grid_sync(ctl, gen)) return;
   }
   }  // for (;;)
 }
