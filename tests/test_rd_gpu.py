@@ -155,11 +155,13 @@ def test_rd_golden_vectors(hip):
         assert _rel(en2, en_i) < 1e-9, name
 
 
-def test_plan_equals_stateless_and_reference(hip, oracle):
+def test_plan_equals_stateless_and_reference(hip, oracle, monkeypatch):
     """stereo_rd_plan_* (capacities built on the device, buffers reused across moves) must give
-    what stereo_rd gives, move after move, including after a move that left nodes unlabelled."""
+    what the stateless stereo_rd gives (graph built on the host per call: STEREO_HIP_RD_CACHE=0), move
+    after move, including after a move that left nodes unlabelled."""
     import ctypes
     from stereo_amd.rd import RdPlan
+    monkeypatch.setenv("STEREO_HIP_RD_CACHE", "0")
     libc = ctypes.CDLL(None)
     H, W = 20, 24
     probs = [fusion_problem(301, H, W), glass_problem(302, H, W, 3.0, True), fusion_problem(303, H, W, nonsub_boost=5.0),
@@ -226,3 +228,25 @@ def test_large_grid_move_matches_reference(hip, oracle):
     assert b[3] == r[3] and b[3] > 0
     assert np.array_equal(b[0], r[0])
     assert _rel(b[1], r[1]) < 1e-9
+
+
+def test_gateway_keeps_the_plan_of_the_last_connectivity(hip, oracle, monkeypatch):
+    """stereo_rd (what rd_mex calls) keeps the plan of the last connectivity it saw: same results as the
+    stateless path on repeated moves, on a change of connectivity and back, with and without Improve."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    pa = [fusion_problem(401, 30, 40), glass_problem(402, 30, 40, 3.0, True), fusion_problem(403, 30, 40, nonsub_boost=4.0)]
+    pb = [glass_problem(404, 24, 50, 3.0, False), fusion_problem(405, 24, 50)]   # same N, another grid
+    seq = [pa[0], pa[1], pb[0], pa[2], pb[1], pa[1]]
+    for k, p in enumerate(seq):
+        args = (p["U0"], p["U1"], p["E00"], p["E01"], p["E10"], p["E11"])
+        for improve in (False, True):
+            out = {}
+            for mode in ("1", "0"):
+                monkeypatch.setenv("STEREO_HIP_RD_CACHE", mode)
+                libc.srand(k)
+                out[mode] = hip.rd(*args, p["conn"].T + 1, {"improve": improve})
+            assert np.array_equal(out["1"][0], out["0"][0]), (k, improve)
+            assert out["1"][3] == out["0"][3]
+            assert _rel(out["1"][1], out["0"][1]) < 1e-12 and _rel(out["1"][2], out["0"][2]) < 1e-12
+    monkeypatch.delenv("STEREO_HIP_RD_CACHE")
