@@ -1043,6 +1043,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     // do have a path and lengthens distances there: those steps relabel from scratch.)
     fixed_node = improve_perm[next];
     keep_valid = g.keep != nullptr && ldc(g.keep + fixed_node) >= n;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g.counters) g.counters[keep_valid ? 1300 : 1301] += 1;   // (statistics: steps of either kind)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       stc(other, N);
       // AddUnaryTerm(i, 0, INFTY), INFTY = max(-t_i + sum of outgoing residuals, t_i + sum of incoming) + 1
@@ -1553,9 +1554,16 @@ struct QpboSolver {
 #endif
     if (host_ctl[QpboCtl::kAbort] == 1) throw HipError{"stereo_rd: grid barrier gave up (device-side spin bound)"};
     if (host_ctl[QpboCtl::kAbort] == 2) throw HipError{"stereo_rd: push-relabel did not converge within the round bound"};
-    if (std::getenv("STEREO_HIP_QPBO_VERBOSE"))
+    if (std::getenv("STEREO_HIP_QPBO_VERBOSE")) {
       std::fprintf(stderr, "[stereo_hip qpbo] relabels: %.3f ms, %d barriers; tiled section: %.3f ms, %d rounds\n", host_ctl[11] * 1e-5,
                    host_ctl[12], host_ctl[13] * 1e-5, host_ctl[14]);
+      if (improve_perm) {
+        int32_t st[2] = {0, 0};
+        STEREO_HIP_CHECK(hipMemcpy(st, d_cnt.p + 1300, sizeof(st), hipMemcpyDeviceToHost));
+        STEREO_HIP_CHECK(hipMemset(d_cnt.p + 1300, 0, sizeof(st)));
+        std::fprintf(stderr, "[stereo_hip qpbo] Improve steps: %d with the fixed node cut off from the sink (confined relabellings), %d with both sides connected\n", st[0], st[1]);
+      }
+    }
 #ifdef STEREO_HIP_QPBO_PROFILE
     if (std::getenv("STEREO_HIP_QPBO_VERBOSE")) {
       int32_t q[16];
