@@ -577,6 +577,32 @@ def main():
                 tm2 = (time.perf_counter() - t1) / (len(pps) - 1)
                 extra["end_to_end_device_proposals"] = {"moves_per_s": 1.0 / tm2, "ms_per_move": tm2 * 1e3, "energy": dm.energy(),
                                                         "energy_equal_to_end_to_end": bool(dm.energy() == extra["end_to_end"]["energy"])}
+                # hard moves: examples/example_global.py's workload -- dispmap_globalstereo on the synthetic pair,
+                # 14 block-wise piecewise-planar proposals, QPBO with Improve (most moves leave nodes unlabelled)
+                try:
+                    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "examples"))
+                    from example_global import piecewise_planar
+                    from stereo_amd import terms as T
+                    P34 = np.tile(np.hstack([np.eye(3), np.zeros((3, 1))])[:, :, None], (1, 1, 2))
+                    P34[0, 3, 1] = -0.25
+                    gconn = T.construct_neighborhood(H, W)
+                    gimg = im0.transpose(1, 0, 2).reshape(H * W, -1)
+                    same = np.abs(gimg[gconn[0]] - gimg[gconn[1]]).sum(axis=1) < 30.0
+                    grng = np.random.default_rng(0)
+                    gs = stereo_amd.dispmap_globalstereo([im0, im1], P34, (0, 59), 4,
+                                                         smooth_weights=np.where(same, 108.0, 9.0) * 2.0, rng=grng)
+                    props = [piecewise_planar(H, W, cell, grng, gs.d_min, gs.d_min + gs.d_step)
+                             for cell in (8, 12, 16, 24, 32, 48, 64) for _ in range(2)]
+                    t1 = time.perf_counter()
+                    for pl in props:
+                        gs.binary_fusion(pl)
+                    tg = time.perf_counter() - t1
+                    extra["hard_moves"] = {"moves_per_s": len(props) / tg, "ms_per_move": tg / len(props) * 1e3, "energy": gs.energy(),
+                                           "what": "examples/example_global.py: dispmap_globalstereo on the synthetic %dx%d pair, %d "
+                                                   "piecewise-planar proposals, binary fusion with QPBO + weak persistency + Improve"
+                                                   % (W, H, len(props))}
+                except Exception as exc:
+                    extra["hard_moves"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
                 out["binary_fusion"] = extra
             except Exception as exc:  # the headline number must not depend on the secondary one
                 out["binary_fusion"] = {"error": str(exc)}
