@@ -45,6 +45,11 @@ int stereo_hip_device_cus(void);
  * rand() for QPBO Improve (QPBO_extra.cpp:13-27 draws its permutation from it): the runtime
  * consumes rand() values during that initialisation.  Returns 0, or non-zero without a device. */
 int stereo_hip_warm_up(void);
+
+/* Test hook (host only, no device needed): the node permutation QPBO::Improve walks
+ * (QPBO_extra.cpp:13-27, :1224-1232), drawn from libc rand() exactly as the reference draws it --
+ * N - 1 values consumed, the generator left where N - 1 calls of rand() leave it.  out: N int32. */
+int stereo_hip_improve_permutation(int64_t N, int32_t *out);
 /* Last error message of the calling thread ("" if none). */
 const char *stereo_hip_last_error(void);
 

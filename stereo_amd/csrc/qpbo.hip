@@ -1368,7 +1368,7 @@ namespace {
 struct QpboSolver {
   QpboProblem P;
   int n = 0, m = 0;
-  DevBuf<int32_t> d_aptr, d_head, d_rev, d_h, d_h2, d_cnt, d_flags, d_ctl, d_perm, d_posof, d_dirty, d_keep, d_tab;
+  DevBuf<int32_t> d_aptr, d_head, d_rev, d_h, d_h2, d_cnt, d_flags, d_ctl, d_perm, d_posof, d_dirty, d_keep, d_tab, d_iperm;
   DevBuf<double> d_r, d_delta, d_ex, d_snk;
   DevBuf<unsigned long long> d_hx;
   std::vector<double> snk0;
@@ -1459,8 +1459,10 @@ struct QpboSolver {
   void improve(const std::vector<int32_t> &perm, std::vector<int32_t> &h) {
     // one cooperative launch walks the whole permutation (qpbo_maxflow_kernel, improve_perm);
     // STEREO_HIP_QPBO_IMPROVE_HOST=1 keeps round 2's host loop (one launch per fixed node) for comparison
-    DevBuf<int32_t> d_perm;
-    d_perm.upload(perm.data(), perm.size());
+    // (kept across calls: hipMalloc / hipFree per Improve call cost more than the upload)
+    if (d_iperm.n < perm.size()) d_iperm.alloc(perm.size());
+    STEREO_HIP_CHECK(hipMemcpy(d_iperm.p, perm.data(), sizeof(int32_t) * perm.size(), hipMemcpyHostToDevice));
+    DevBuf<int32_t> &d_perm = d_iperm;
     if (!std::getenv("STEREO_HIP_QPBO_IMPROVE_HOST")) {
       // the relabellings inside an Improve step start from the heights of the flow the step began with
       // (qpbo_maxflow_kernel, `confined`); STEREO_HIP_QPBO_CONFINED=0: every one of them from scratch (round 3)
@@ -1709,11 +1711,72 @@ void weak_persistencies_compact(int cnt, int N, const std::vector<int32_t> &ids,
 // reference's.  Note for callers that seed rand() to reproduce the reference: the HIP runtime draws
 // from the same generator during its one-time initialisation (measured), so initialise it first
 // (stereo_hip_warm_up; the Python package does so when it loads the library).
+// `count` values of rand(), in order, from the process-wide generator -- the same values and the same generator
+// state afterwards as `count` calls of rand(), without glibc's lock per call (2.7 ms of a 3.0 ms permutation at
+// 450 x 375; an Improve move pays it on the host).  POSIX semantics only: initstate() parks the generator on a
+// scratch array and hands back the array it was running on, position included; random_r() runs on that array
+// through a random_data of our own; parking that one writes the advanced position back; setstate() resumes.
+// The first use checks itself against rand() on a saved copy of the state (nothing is consumed by the check) and
+// falls back to rand() for good if anything differs.  STEREO_HIP_FAST_RAND=0: always rand().
+bool draw_rand_fast(int32_t *out, int64_t count) {
+  static char park[256], park_r[256], scratch[256];
+  char *old = initstate(1u, park, sizeof(park));
+  if (!old) return false;
+  struct random_data rd;
+  std::memset(&rd, 0, sizeof(rd));
+  bool ok = initstate_r(1u, scratch, sizeof(scratch), &rd) == 0 && setstate_r(old, &rd) == 0;
+  if (ok) {
+    for (int64_t i = 0; i < count; ++i) { int32_t v; random_r(&rd, &v); out[i] = v; }
+    ok = initstate_r(1u, park_r, sizeof(park_r), &rd) == 0;   // (parks rd: the position goes back into `old`)
+  }
+  setstate(old);
+  return ok;
+}
+
+bool fast_rand_usable() {
+  static int state = -1;   // -1 unknown, 0 no, 1 yes
+  if (state >= 0) return state == 1;
+  state = 0;
+  if (const char *e = std::getenv("STEREO_HIP_FAST_RAND")) if (std::atoi(e) == 0) return false;
+  // a copy of the generator's state while it is parked, to undo what the check draws
+  static char park[256];
+  static const size_t bytes_of_type[5] = {8, 32, 64, 128, 256};   // TYPE_0 .. TYPE_4 arrays incl. the info word
+  char *old = initstate(1u, park, sizeof(park));
+  if (!old) return false;
+  int32_t info;
+  std::memcpy(&info, old, sizeof(info));
+  const int type = (int)(((info % 5) + 5) % 5);
+  const size_t bytes = bytes_of_type[type];
+  char saved[256];
+  std::memcpy(saved, old, bytes);
+  setstate(old);
+  int32_t slow[8], fast[8];
+  for (int i = 0; i < 8; ++i) slow[i] = rand();
+  const int32_t slow_next = rand();
+  auto restore = [&]() -> bool {
+    char *cur = initstate(1u, park, sizeof(park));
+    if (cur != old) { if (cur) setstate(cur); return false; }
+    std::memcpy(old, saved, bytes);
+    setstate(old);
+    return true;
+  };
+  if (!restore()) return false;
+  const bool drew = draw_rand_fast(fast, 8);
+  const int32_t fast_next = rand();
+  if (!restore()) return false;
+  if (drew && std::memcmp(slow, fast, sizeof(slow)) == 0 && slow_next == fast_next) state = 1;
+  return state == 1;
+}
+
 std::vector<int32_t> improve_permutation(int64_t N) {
   std::vector<int32_t> perm((size_t)N);
   for (int64_t i = 0; i < N; ++i) perm[i] = (int32_t)i;
+  if (N < 2) return perm;
+  std::vector<int32_t> r((size_t)(N - 1));
+  if (!(fast_rand_usable() && draw_rand_fast(r.data(), N - 1)))
+    for (int64_t i = 0; i < N - 1; ++i) r[i] = rand();   // (draw_rand_fast either drew everything or nothing)
   for (int64_t i = 0; i < N - 1; ++i) {
-    int64_t j = i + (int64_t)((rand() / (1.0 + (double)RAND_MAX)) * (double)(N - i));
+    int64_t j = i + (int64_t)((r[i] / (1.0 + (double)RAND_MAX)) * (double)(N - i));
     if (j > N - 1) j = N - 1;
     std::swap(perm[i], perm[j]);
   }
@@ -1777,6 +1840,13 @@ int rd_through_cached_plan(const double *U0, const double *U1, const double *E00
 }
 
 }  // namespace
+
+extern "C" int stereo_hip_improve_permutation(int64_t N, int32_t *out) {
+  if (N < 0 || (N > 0 && !out)) return 1;
+  const std::vector<int32_t> perm = improve_permutation(N);
+  if (N > 0) std::memcpy(out, perm.data(), sizeof(int32_t) * (size_t)N);
+  return 0;
+}
 
 extern "C" int stereo_rd(const double *U0, const double *U1, const double *E00, const double *E01,
                          const double *E10, const double *E11, const uint32_t *conn, int64_t N, int64_t E,
@@ -2116,7 +2186,9 @@ static int rd_plan_solve_device(stereo_rd_plan *P, const double *const in[6], in
       *num_unlabelled = unl;  // rd_mex.cpp:83-88: counted before Improve
       if (improve && unl > 0) {
         const double ti0 = now();
-        S.improve(improve_permutation(N), h);   // (returns the final heights)
+        const std::vector<int32_t> perm = improve_permutation(N);
+        if (verbose) std::fprintf(stderr, "[stereo_hip qpbo plan] Improve: permutation %.3f ms\n", now() - ti0);
+        S.improve(perm, h);   // (returns the final heights)
         std::vector<int8_t> l8(N);
         for (int64_t i = 0; i < N; ++i) {
           const int li = h[i] < n ? 1 : 0, lm = h[i + N] < n ? 1 : 0;

@@ -172,3 +172,38 @@ def test_chain_schedule_splits_the_interleaved_rows():
 def test_chain_schedule_more_rows_than_workgroups():
     slow = _check_schedule(120, 90, 16)
     assert max(slow.values()) < 8.0
+
+
+def test_improve_permutation_is_the_rand_loop():
+    """QPBO_extra.cpp:13-27: perm[i] <-> perm[i + floor(rand() / (RAND_MAX + 1) * (N - i))], N - 1 draws of libc
+    rand().  The library draws them without glibc's per-call lock (initstate / random_r / setstate on the
+    generator's own state array): same permutation, and rand() continues where N - 1 calls would leave it --
+    also after a first use (the self-check of the fast path consumes nothing) and twice in a row."""
+    import ctypes
+    from stereo_amd import _lib
+    L = _lib.lib()
+    L.stereo_hip_improve_permutation.argtypes = [ctypes.c_int64, ctypes.c_void_p]
+    libc = ctypes.CDLL(None)
+    libc.rand.restype = ctypes.c_int
+    RAND_MAX = 2147483647
+
+    def slow(N):
+        perm = list(range(N))
+        for i in range(N - 1):
+            j = i + int((libc.rand() / (1.0 + RAND_MAX)) * (N - i))
+            j = min(j, N - 1)
+            perm[i], perm[j] = perm[j], perm[i]
+        return np.array(perm, dtype=np.int32)
+
+    for seed, N in [(3, 1), (3, 2), (5, 17), (7, 5000), (11, 20000)]:
+        libc.srand(seed)
+        want = [slow(N), slow(N)]
+        want_next = libc.rand()
+        libc.srand(seed)
+        got = []
+        for _ in range(2):
+            out = np.empty(N, dtype=np.int32)
+            assert L.stereo_hip_improve_permutation(N, out.ctypes.data) == 0
+            got.append(out)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (seed, N)
+        assert libc.rand() == want_next, (seed, N)
