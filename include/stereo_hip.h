@@ -65,11 +65,20 @@ const char *stereo_hip_last_error(void);
  *             defaults 1000 and 0 are applied by the caller / gateway).
  * labelling   N doubles, ONE based (trws_mex.cpp:137).
  */
+/* Repeated calls with the same (kernel, K, connectivity) -- one per simultaneous_fusion of an object,
+ * dispmap_super.m:153-198 -- reuse the plan of the last problem seen: graph analysis, descriptors and
+ * device buffers are kept, a call costs the upload of its inputs, the iterations and the labels back.
+ * If every column of q and qprim is bitwise the same vector (fronto-parallel proposals, :177-183) only
+ * that vector is uploaded and the shared-position kernels run; same bits as the K x E form.
+ * STEREO_HIP_TRWS_CACHE=0: a fresh plan per call and the K x E arrays always.  The cached plan keeps its
+ * device memory (messages: 8 K E bytes) until the next different problem or stereo_trws_cache_clear(). */
 int stereo_trws(int kernel, const double *unary, const uint32_t *conn, const double *q,
                 const double *qprim, const double *alphas, double tol, double maxiter,
                 double max_relgap, int K, int64_t N, int64_t E, double *labelling,
                 double *energy, double *lower_bound, double *iterations, char *err,
                 size_t errcap);
+void stereo_trws_cache_clear(void);
+
 
 /* Device-resident form of the same solver: graph analysis (SetAutomaticOrdering,
  * ordering.cpp:7-157; CompleteGraphConstruction, MRFEnergy.cpp:137-229) is done
@@ -303,6 +312,9 @@ int stereo_rd(const double *U0, const double *U1, const double *E00, const doubl
               const double *E10, const double *E11, const uint32_t *conn, int64_t N,
               int64_t E, int improve, double *labelling, double *energy,
               double *lower_bound, double *num_unlabelled, char *err, size_t errcap);
+/* Frees the plan stereo_rd keeps for the last connectivity (its device buffers stay allocated until
+ * the next different problem otherwise). */
+void stereo_rd_cache_clear(void);
 
 /* Device-resident form of stereo_rd for repeated fusion moves on one connectivity
  * (dispmap_super.m:61-84 is called once per proposal): edge grouping, the doubled-graph

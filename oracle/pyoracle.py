@@ -30,6 +30,7 @@ def _load(path):
 _lib = None
 _ref_qpbo = None
 _ref_types = None
+_ref_segment = None
 
 
 def lib():
@@ -60,6 +61,27 @@ def ref_types():
             _ref_types.ref_update_message.restype = C.c_double
             _ref_types.ref_vec_min.restype = C.c_double
     return _ref_types or None
+
+
+def ref_segment():
+    global _ref_segment
+    if _ref_segment is None:
+        _ref_segment = _load(os.path.join(_HERE, "_ref", "libref_segment_ms.so")) or False
+    return _ref_segment or None
+
+
+def have_ref_segment():
+    return ref_segment() is not None
+
+
+_ref_segment_gb = None
+
+
+def ref_segment_gb_lib():
+    global _ref_segment_gb
+    if _ref_segment_gb is None:
+        _ref_segment_gb = _load(os.path.join(_HERE, "_ref", "libref_segment_gb.so")) or False
+    return _ref_segment_gb or None
 
 
 def have_ref_qpbo():
@@ -218,3 +240,59 @@ def rd(U0, U1, E00, E01, E10, E11, conn, improve=False, stage=0, seed=None):
     if rc:
         raise RuntimeError("oracle_rd failed rc=%d" % rc)
     return lab, en.value, lb.value, nu.value
+
+
+# --------------------------------------------------------------------- segmentation
+
+def ref_segment_ms(image, h_s=4, h_r=5.0, min_sz=0):
+    """The REFERENCE mean-shift segmenter (imrender/vgg/seg_ms through oracle/_ref) behind the
+    restated vgg_segment_ms gateway: image H x W x 3 uint8 -> H x W uint32 segment ids from 1
+    (dispmap_globalstereo.m:391-392 with ojw_default_options.m:68 seg_params = [4 5 0])."""
+    L = ref_segment()
+    if L is None:
+        raise RuntimeError("oracle/_ref/libref_segment_ms.so not available")
+    im = np.asarray(image)
+    if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+        raise ValueError("A must be an HxWx3 uint8 array.")     # vgg_segment_ms.cxx:26-27
+    H, W, _ = im.shape
+    A = np.asfortranarray(im)                                    # MATLAB's H x W x 3 column-major
+    out = np.zeros((H, W), dtype=np.uint32, order="F")
+    err = C.create_string_buffer(512)
+    rc = L.ref_segment_ms(A.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(H), C.c_int(W),
+                          C.c_int(int(h_s)), C.c_float(float(h_r)), C.c_int(int(min_sz)),
+                          out.ctypes.data_as(_u32p), err, C.c_size_t(512))
+    if rc:
+        raise RuntimeError("ref_segment_ms: %s" % err.value.decode())
+    return np.ascontiguousarray(out)
+
+
+def ref_segment_gb(image, sigma, k, min_sz, compress=1):
+    """The REFERENCE graph-based segmenter (imrender/vgg/seg_gb) behind the restated vgg_segment_gb
+    gateway: image H x W x 3 uint8 -> H x W uint32 (dispmap_globalstereo.m:132)."""
+    L = ref_segment_gb_lib()
+    if L is None:
+        raise RuntimeError("oracle/_ref/libref_segment_gb.so not available")
+    im = np.asarray(image)
+    if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+        raise ValueError("A must be an HxWx3 uint8 array.")     # vgg_segment_gb.cxx:29-30
+    H, W, _ = im.shape
+    A = np.asfortranarray(im)
+    out = np.zeros((H, W), dtype=np.uint32, order="F")
+    L.ref_segment_gb(A.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(H), C.c_int(W), C.c_float(float(sigma)),
+                     C.c_float(float(k)), C.c_int(int(min_sz)), C.c_int(int(compress)), out.ctypes.data_as(_u32p))
+    return np.ascontiguousarray(out)
+
+
+def ref_segpln_segments(image):
+    """The 14 segmentation maps of segpln (dispmap_globalstereo.m:121-134): mean shift at seven scales,
+    then the graph-based segmenter at seven scales -> H x W x 14 uint32."""
+    segment_params = np.array([1, 1.5, 10, 100.0])
+    mults = [1, 2, 3, 4, 5, 6, 7, 3, 5, 8, 12, 24, 50, 100]
+    maps = []
+    for b, m in enumerate(mults):
+        sp = segment_params * m
+        if b < 7:
+            maps.append(ref_segment_ms(image, sp[0], sp[1], sp[2]))
+        else:
+            maps.append(ref_segment_gb(image, 0, sp[3], sp[2], 1))
+    return np.stack(maps, axis=2)

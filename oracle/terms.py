@@ -420,7 +420,7 @@ def segpln_wta(images, P, disps, col_thresh=30.0, window=2, min_corr=0.07):
     `min_corr` (:111-112), mirrored back to full size (:113).  images: list of (H, W, C); P (3, 4, n).
     Returns (H, W) disparities."""
     ims = [np.asarray(im, np.float64) for im in images]
-    R = np.clip(np.round(ims[0]), 0, 255)                         # R = uint8(images{1}) (:69)
+    R = np.clip(np.floor(ims[0] + 0.5), 0, 255)                   # R = uint8(images{1}) (:69): MATLAB rounds half away from zero
     H, W, C = R.shape
     Rvec = R.transpose(1, 0, 2).reshape(H * W, C)
     Xg, Yg = np.meshgrid(np.arange(1, W + 1, dtype=np.float64), np.arange(1, H + 1, dtype=np.float64))

@@ -46,6 +46,8 @@ def lib():
         L.stereo_trws_plan_destroy.restype = None
         L.stereo_rd_plan_destroy.restype = None
         L.stereo_fusion_destroy.restype = None
+        L.stereo_trws_cache_clear.restype = None
+        L.stereo_rd_cache_clear.restype = None
         _lib = L
         # one-time runtime initialisation now, not inside the first solver call: it consumes libc
         # rand() values, which QPBO Improve draws its permutation from (see stereo_hip_warm_up)

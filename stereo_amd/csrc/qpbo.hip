@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -760,8 +761,19 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
     auto mark_all_dirty = [&]() {
       // (hx words carry 16 bits of the round number: long before they wrap, start again from 0 and have the
       // relabelling that follows every call rewrite all words as "not stored in any round"; nothing is in transit here)
-      if (G > 60000) { G = 0; hx_refresh_all = true; }
-      for (int T = first; T < g.ntiles; T += stride) stc(g.dirty + (size_t)((G + 1) & 1) * g.ntiles + T, G + 1);
+      // The dirty marks are raw round numbers too: at the wrap both planes are cleared (by the thread that
+      // then writes the tile's new mark, so the two stores are ordered), or marks left from the launch's
+      // first rounds 2, 3, ... would compare equal to the restarted round numbers.
+      // -DSTEREO_HIP_QPBO_WRAP_AT=<n>: debug flavour that wraps early (tools/gpu_qpbo_wrap.sh).
+#ifndef STEREO_HIP_QPBO_WRAP_AT
+#define STEREO_HIP_QPBO_WRAP_AT 60000
+#endif
+      const bool wrap = G > STEREO_HIP_QPBO_WRAP_AT;
+      if (wrap) { G = 0; hx_refresh_all = true; }
+      for (int T = first; T < g.ntiles; T += stride) {
+        if (wrap) { stc(g.dirty + T, 0); stc(g.dirty + (size_t)g.ntiles + T, 0); }
+        stc(g.dirty + (size_t)((G + 1) & 1) * g.ntiles + T, G + 1);
+      }
     };
     mark_all_dirty();
     if (!grid_sync(ctl, gen)) return;
@@ -1718,8 +1730,22 @@ void weak_persistencies_compact(int cnt, int N, const std::vector<int32_t> &ids,
 // through a random_data of our own; parking that one writes the advanced position back; setstate() resumes.
 // The first use checks itself against rand() on a saved copy of the state (nothing is consumed by the check) and
 // falls back to rand() for good if anything differs.  STEREO_HIP_FAST_RAND=0: always rand().
+// Threads: the park / resume window swaps the PROCESS-WIDE generator state, so every window of this
+// library is serialised by rand_window_mutex() (two host threads running Improve moves would otherwise
+// hand each other's park buffers around and leave the generator on a static array for good).  A
+// foreign thread that calls rand() inside a window draws from the parked stream (seeded 1) instead of
+// the process stream -- the same hazard class as any unsynchronised rand() user, documented in
+// INTEGRATION.md.
+std::mutex &rand_window_mutex() {
+  static std::mutex m;
+  return m;
+}
+
+// (callers hold rand_window_mutex())
 bool draw_rand_fast(int32_t *out, int64_t count) {
-  static char park[256], park_r[256], scratch[256];
+  alignas(int32_t) static char park[256];
+  alignas(int32_t) static char park_r[256];
+  alignas(int32_t) static char scratch[256];
   char *old = initstate(1u, park, sizeof(park));
   if (!old) return false;
   struct random_data rd;
@@ -1733,13 +1759,14 @@ bool draw_rand_fast(int32_t *out, int64_t count) {
   return ok;
 }
 
+// (callers hold rand_window_mutex())
 bool fast_rand_usable() {
-  static int state = -1;   // -1 unknown, 0 no, 1 yes
-  if (state >= 0) return state == 1;
-  state = 0;
+  static std::atomic<int> state{-1};   // -1 unknown, 0 no, 1 yes
+  if (state.load() >= 0) return state.load() == 1;
+  state.store(0);
   if (const char *e = std::getenv("STEREO_HIP_FAST_RAND")) if (std::atoi(e) == 0) return false;
   // a copy of the generator's state while it is parked, to undo what the check draws
-  static char park[256];
+  alignas(int32_t) static char park[256];
   static const size_t bytes_of_type[5] = {8, 32, 64, 128, 256};   // TYPE_0 .. TYPE_4 arrays incl. the info word
   char *old = initstate(1u, park, sizeof(park));
   if (!old) return false;
@@ -1764,8 +1791,8 @@ bool fast_rand_usable() {
   const bool drew = draw_rand_fast(fast, 8);
   const int32_t fast_next = rand();
   if (!restore()) return false;
-  if (drew && std::memcmp(slow, fast, sizeof(slow)) == 0 && slow_next == fast_next) state = 1;
-  return state == 1;
+  if (drew && std::memcmp(slow, fast, sizeof(slow)) == 0 && slow_next == fast_next) state.store(1);
+  return state.load() == 1;
 }
 
 std::vector<int32_t> improve_permutation(int64_t N) {
@@ -1773,8 +1800,11 @@ std::vector<int32_t> improve_permutation(int64_t N) {
   for (int64_t i = 0; i < N; ++i) perm[i] = (int32_t)i;
   if (N < 2) return perm;
   std::vector<int32_t> r((size_t)(N - 1));
-  if (!(fast_rand_usable() && draw_rand_fast(r.data(), N - 1)))
-    for (int64_t i = 0; i < N - 1; ++i) r[i] = rand();   // (draw_rand_fast either drew everything or nothing)
+  {
+    std::lock_guard<std::mutex> window(rand_window_mutex());   // one permutation's draws are contiguous in the stream
+    if (!(fast_rand_usable() && draw_rand_fast(r.data(), N - 1)))
+      for (int64_t i = 0; i < N - 1; ++i) r[i] = rand();   // (draw_rand_fast either drew everything or nothing)
+  }
   for (int64_t i = 0; i < N - 1; ++i) {
     int64_t j = i + (int64_t)((r[i] / (1.0 + (double)RAND_MAX)) * (double)(N - i));
     if (j > N - 1) j = N - 1;
@@ -1813,10 +1843,15 @@ struct RdPlanCache {
   std::vector<uint32_t> conn;
 };
 
+RdPlanCache &rd_plan_cache() {
+  static RdPlanCache *C = new RdPlanCache;   // (never destroyed: the HIP runtime may be gone before static destructors run)
+  return *C;
+}
+
 int rd_through_cached_plan(const double *U0, const double *U1, const double *E00, const double *E01, const double *E10,
                            const double *E11, const uint32_t *conn, int64_t N, int64_t E, int improve, double *labelling,
                            double *energy, double *lower_bound, double *num_unlabelled, char *err, size_t errcap) {
-  static RdPlanCache *C = new RdPlanCache;   // (never destroyed: the HIP runtime may be gone before static destructors run)
+  RdPlanCache *C = &rd_plan_cache();
   std::lock_guard<std::mutex> lock(C->mu);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return fail("stereo_rd: hipGetDevice failed", err, errcap);
@@ -1840,6 +1875,13 @@ int rd_through_cached_plan(const double *U0, const double *U1, const double *E00
 }
 
 }  // namespace
+
+extern "C" void stereo_rd_cache_clear(void) {
+  RdPlanCache &C = rd_plan_cache();
+  std::lock_guard<std::mutex> lock(C.mu);
+  if (C.plan) { stereo_rd_plan_destroy(C.plan); C.plan = nullptr; }
+  C.conn.clear(); C.conn.shrink_to_fit();
+}
 
 extern "C" int stereo_hip_improve_permutation(int64_t N, int32_t *out) {
   if (N < 0 || (N > 0 && !out)) return 1;

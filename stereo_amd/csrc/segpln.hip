@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kTile * kTile) void segpln_wta_kernel(WtaArgs a) {
   {
     double s = 0;
     for (int c = 0; c < a.C; ++c) {
-      const double r = fmin(fmax(rint(a.images[(size_t)c * Npx]), 0.0), 255.0);
+      const double r = fmin(fmax(floor(a.images[(size_t)c * Npx] + 0.5), 0.0), 255.0);
       const double f = -1000.0 - r;
       s = s + f * f;
     }
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kTile * kTile) void segpln_wta_kernel(WtaArgs a) {
           double s = 0;
           for (int c = 0; c < a.C; ++c) {
             const double v = interp2_linear(img + (size_t)c * Npx, a.H, a.W, sx, sy, -1000.0);
-            const double r = fmin(fmax(rint(a.images[(size_t)c * Npx + (size_t)cc * a.H + rr]), 0.0), 255.0);  // uint8(images{1})
+            const double r = fmin(fmax(floor(a.images[(size_t)c * Npx + (size_t)cc * a.H + rr] + 0.5), 0.0), 255.0);  // uint8(images{1}): half away from zero
             const double f = v - r;
             s = s + f * f;
           }

@@ -1299,6 +1299,85 @@ int stereo_trws_plan_path(stereo_trws_plan *P) {
   return P->wide ? 3 : P->fast2 ? 4 : P->fast ? 2 : 1;
 }
 
+}  // extern "C"
+
+// ---- the gateway entry: what trws_mex reaches ------------------------------------------------------------
+// A simultaneous fusion through trws.m:33 calls the gateway once per move with the SAME connectivity
+// (dispmap_super.m:153-198: the neighbourhood of the object), and fronto-parallel proposals make every column
+// of q and qprim one and the same vector (:177-183 evaluates each plane at every edge: [0 0 1 -d] gives d).
+// So the gateway (i) keeps the plan of the last (kernel, K, N, E, connectivity, message mode, device) -- graph
+// analysis, descriptors and device buffers survive the call -- and (ii) looks at q / qprim on the host before
+// uploading anything: if all 2 E columns are bitwise one vector, that vector goes up as the plan's shared
+// positions (8 K bytes instead of 16 K E) and the shared-position kernels run; results are the K x E form's bit
+// for bit (tests/test_trws_gpu.py).  STEREO_HIP_TRWS_CACHE=0: a plan per call, K x E arrays always uploaded.
+namespace {
+
+struct TrwsPlanCache {
+  std::mutex mu;
+  stereo_trws_plan *plan = nullptr;
+  int kernel = 0, K = 0, mode = 0, device = -1;
+  int64_t N = 0, E = 0;
+  std::vector<uint32_t> conn;
+};
+
+TrwsPlanCache &trws_plan_cache() {
+  static TrwsPlanCache *C = new TrwsPlanCache;   // (never destroyed: the HIP runtime may be gone before static destructors run)
+  return *C;
+}
+
+// true iff every column of q and of qprim (K x E, column-major) equals q's first column bit for bit
+bool columns_are_one_vector(const double *q, const double *qprim, int K, int64_t E) {
+  if (E < 1) return false;
+  const size_t row = sizeof(double) * (size_t)K;
+  if (std::memcmp(q, qprim, row) != 0) return false;
+  // a quick look at a few columns first: general planes differ on the first edge already
+  for (int64_t e : {E / 2, E - 1})
+    if (std::memcmp(q, q + (size_t)e * K, row) != 0 || std::memcmp(q, qprim + (size_t)e * K, row) != 0) return false;
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = std::max(1u, std::min(nt ? nt : 1u, 16u));
+  if ((size_t)E * K < (1u << 20)) nt = 1;
+  std::vector<char> same(nt, 1);
+  auto scan = [&](unsigned t) {
+    const int64_t a = E * t / nt, b = E * (t + 1) / nt;
+    for (int64_t e = a; e < b; ++e)
+      if (std::memcmp(q, q + (size_t)e * K, row) != 0 || std::memcmp(q, qprim + (size_t)e * K, row) != 0) { same[t] = 0; return; }
+  };
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nt; ++t) th.emplace_back(scan, t);
+  scan(0);
+  for (auto &x : th) x.join();
+  for (char c : same) if (!c) return false;
+  return true;
+}
+
+int trws_solve_on(stereo_trws_plan *P, const double *unary, const double *q, const double *qprim, const double *alphas,
+                  double tol, double maxiter, double max_relgap, bool look_for_shared, double *labelling, double *energy,
+                  double *lower_bound, double *iterations, char *err, size_t errcap) {
+  int rc;
+  if (look_for_shared && columns_are_one_vector(q, qprim, P->K, P->E))
+    rc = stereo_trws_plan_upload(P, unary, nullptr, nullptr, q, alphas, tol, err, errcap);
+  else
+    rc = stereo_trws_plan_upload(P, unary, q, qprim, nullptr, alphas, tol, err, errcap);
+  if (rc) return rc;
+  // Minimize_TRW_S always runs at least one iteration (minimize.cpp:31,100-101)
+  int itmax = (int)maxiter;  // trws_mex.cpp:125
+  if (itmax < 1) itmax = 1;
+  rc = stereo_trws_plan_iterate(P, itmax, max_relgap, nullptr, nullptr, nullptr, err, errcap);
+  if (rc) return rc;
+  return stereo_trws_plan_result(P, labelling, energy, lower_bound, iterations, err, errcap);
+}
+
+}  // namespace
+
+extern "C" {
+
+void stereo_trws_cache_clear(void) {
+  TrwsPlanCache &C = trws_plan_cache();
+  std::lock_guard<std::mutex> lock(C.mu);
+  if (C.plan) { stereo_trws_plan_destroy(C.plan); C.plan = nullptr; }
+  C.conn.clear(); C.conn.shrink_to_fit();
+}
+
 int stereo_trws(int kernel, const double *unary, const uint32_t *conn, const double *q,
                 const double *qprim, const double *alphas, double tol, double maxiter,
                 double max_relgap, int K, int64_t N, int64_t E, double *labelling, double *energy,
@@ -1306,21 +1385,37 @@ int stereo_trws(int kernel, const double *unary, const uint32_t *conn, const dou
   if (kernel != 1 && kernel != 2) return fail("Unsupported kernel", err, errcap);  // trws_mex.cpp:162
   if (!unary || !conn || !q || !qprim || !alphas || !labelling || !energy || !lower_bound || !iterations)
     return fail("stereo_trws: NULL argument", err, errcap);
-  stereo_trws_plan *P = nullptr;
   int mode = STEREO_TRWS_MESSAGES_EXACT;
   if (const char *m = std::getenv("STEREO_HIP_TRWS_MESSAGES"))
     if (std::string(m) == "minplus") mode = STEREO_TRWS_MESSAGES_MINPLUS;
-  int rc = stereo_trws_plan_create(kernel, K, N, E, conn, mode, &P, err, errcap);
-  if (rc) return rc;
-  rc = stereo_trws_plan_upload(P, unary, q, qprim, nullptr, alphas, tol, err, errcap);
-  if (!rc) {
-    // Minimize_TRW_S always runs at least one iteration (minimize.cpp:31,100-101)
-    int itmax = (int)maxiter;  // trws_mex.cpp:125
-    if (itmax < 1) itmax = 1;
-    rc = stereo_trws_plan_iterate(P, itmax, max_relgap, nullptr, nullptr, nullptr, err, errcap);
+  const char *ce = std::getenv("STEREO_HIP_TRWS_CACHE");
+  const bool cached = (!ce || std::atoi(ce) != 0) && E > 0 && N > 0;
+  if (!cached) {
+    stereo_trws_plan *P = nullptr;
+    int rc = stereo_trws_plan_create(kernel, K, N, E, conn, mode, &P, err, errcap);
+    if (rc) return rc;
+    rc = trws_solve_on(P, unary, q, qprim, alphas, tol, maxiter, max_relgap, false, labelling, energy, lower_bound, iterations,
+                       err, errcap);
+    stereo_trws_plan_destroy(P);
+    return rc;
   }
-  if (!rc) rc = stereo_trws_plan_result(P, labelling, energy, lower_bound, iterations, err, errcap);
-  stereo_trws_plan_destroy(P);
+  TrwsPlanCache &C = trws_plan_cache();
+  std::lock_guard<std::mutex> lock(C.mu);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail("stereo_trws: no HIP device available (the HIP path has no CPU fallback)", err, errcap);
+  const bool hit = C.plan && C.kernel == kernel && C.K == K && C.N == N && C.E == E && C.mode == mode && C.device == dev &&
+                   std::memcmp(C.conn.data(), conn, sizeof(uint32_t) * 2 * (size_t)E) == 0;
+  if (!hit) {
+    if (C.plan) { stereo_trws_plan_destroy(C.plan); C.plan = nullptr; }
+    stereo_trws_plan *P = nullptr;
+    const int rc = stereo_trws_plan_create(kernel, K, N, E, conn, mode, &P, err, errcap);
+    if (rc) return rc;
+    C.plan = P; C.kernel = kernel; C.K = K; C.N = N; C.E = E; C.mode = mode; C.device = dev;
+    C.conn.assign(conn, conn + 2 * (size_t)E);
+  }
+  const int rc = trws_solve_on(C.plan, unary, q, qprim, alphas, tol, maxiter, max_relgap, true, labelling, energy, lower_bound,
+                               iterations, err, errcap);
+  if (rc) { stereo_trws_plan_destroy(C.plan); C.plan = nullptr; }   // never keep a plan an error went through
   return rc;
 }
 

@@ -125,6 +125,10 @@ def segpln_wta(images, P, disps, col_thresh=30.0, window=2, min_corr=0.07):
     ims = [np.asarray(im, np.float64) for im in images]
     ims = [im[:, :, None] if im.ndim == 2 else im for im in ims]
     H, W, Cn = ims[0].shape
+    if any(im.shape != ims[0].shape for im in ims):
+        raise StereoHipError("segpln_wta: every image must have the reference image's H x W x C")
+    if np.asarray(P).size != 12 * len(ims):
+        raise StereoHipError("segpln_wta: P must be 3 x 4 x (number of images)")
     stack = np.concatenate([_f(im).reshape(-1, order="F") for im in ims])
     Pm = _f(np.asarray(P, np.float64).reshape(3, 4, len(ims)))
     d = _f(np.asarray(disps, np.float64).reshape(-1))

@@ -207,3 +207,47 @@ def test_improve_permutation_is_the_rand_loop():
             got.append(out)
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (seed, N)
         assert libc.rand() == want_next, (seed, N)
+
+
+def test_improve_permutation_from_four_threads_leaves_rand_intact():
+    """The park / resume window swaps the process-wide generator state; concurrent Improve moves on
+    several host threads (ctypes releases the GIL) must not leave rand() on one of the library's
+    static arrays: after the threads are done, srand(7) gives the sequence it gave before."""
+    import ctypes
+    import threading
+    from stereo_amd import _lib
+    L = _lib.lib()
+    L.stereo_hip_improve_permutation.argtypes = [ctypes.c_int64, ctypes.c_void_p]
+    libc = ctypes.CDLL(None)
+    libc.rand.restype = ctypes.c_int
+    libc.srand(7)
+    before = [libc.rand() for _ in range(16)]
+    bad = []
+
+    def work():
+        out = np.empty(30000, dtype=np.int32)
+        for _ in range(40):
+            if L.stereo_hip_improve_permutation(30000, out.ctypes.data) != 0:
+                bad.append("rc")
+            if not np.array_equal(np.sort(out), np.arange(30000)):
+                bad.append("not a permutation")
+
+    threads = [threading.Thread(target=work) for _ in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not bad, bad
+    libc.srand(7)
+    assert [libc.rand() for _ in range(16)] == before
+    # ... and a seeded permutation is still the rand() loop's
+    libc.srand(5)
+    r = [libc.rand() for _ in range(16)]
+    perm = list(range(17))
+    for i in range(16):
+        j = min(i + int((r[i] / 2147483648.0) * (17 - i)), 16)
+        perm[i], perm[j] = perm[j], perm[i]
+    libc.srand(5)
+    out = np.empty(17, dtype=np.int32)
+    assert L.stereo_hip_improve_permutation(17, out.ctypes.data) == 0
+    assert out.tolist() == perm

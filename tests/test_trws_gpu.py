@@ -234,3 +234,44 @@ def test_index_order_option_matches_oracle_in_that_order(case, hip, oracle):
     assert it == it_o and np.array_equal(lab, lab_o) and en == en_o and lb == lb_o
     ref = oracle.trws(kernel, p["unary"], p["conn"], p["q"], p["qprim"], p["alphas"], tol, iters, -1e300, mode=1)
     assert ref[2] != lb_o     # (the gateway's order gives another bound after the same iterations)
+
+
+def test_gateway_keeps_the_plan_and_finds_shared_positions(hip, oracle, monkeypatch):
+    """stereo_trws (what trws_mex reaches) keeps the plan of the last problem and uploads one
+    vector when every column of q / qprim is that vector: first call, cached call, a call with
+    other inputs on the same plan, a different problem (cache miss) and the uncached path
+    (STEREO_HIP_TRWS_CACHE=0) all give the oracle's bits -- like test_rd_gpu's cached plan test."""
+    from stereo_amd import _lib
+    _lib.lib().stereo_trws_cache_clear()
+    fr = trws_problem(31, 14, 17, 20, kind="fronto")            # K x E columns all 0..19
+    fr2 = trws_problem(32, 14, 17, 20, kind="fronto")           # same graph, other unaries / weights
+    ge = trws_problem(33, 14, 17, 20, kind="general")           # same graph and K, general planes
+    other = trws_problem(34, 9, 11, 7, kind="general")          # another graph
+    # a fronto problem whose LAST edge alone differs: must not be taken for shared positions
+    odd = {k: np.array(v) for k, v in fr.items()}
+    odd["q"][-1, 3] += 0.25
+
+    def both(p, kernel=1, tol=3.0, it=6):
+        want = oracle.trws(kernel, p["unary"], p["conn"], p["q"], p["qprim"], p["alphas"], tol, it, 0.0, mode=1)
+        got = hip.trws(kernel, p["unary"].T, p["conn"].T + 1, p["q"].T, p["qprim"].T, p["alphas"], tol,
+                       dict(maxiter=it, max_relgap=0))
+        assert np.array_equal(got[0], want[0]) and got[1:] == want[1:], (got[1:], want[1:])
+        return got
+
+    a = both(fr)            # miss: plan built, shared positions
+    b = both(fr)            # hit
+    assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+    both(fr2)               # hit, new inputs
+    both(ge)                # hit, K x E positions on the plan that ran shared positions before
+    both(fr)                # ... and back
+    both(odd)
+    both(fr, kernel=2, tol=9.0)   # miss: the kernel is part of the key
+    both(other)             # miss
+    both(fr)                # miss again
+    monkeypatch.setenv("STEREO_HIP_TRWS_CACHE", "0")
+    c = both(fr)
+    assert np.array_equal(a[0], c[0]) and a[1:] == c[1:]
+    monkeypatch.delenv("STEREO_HIP_TRWS_CACHE")
+    _lib.lib().stereo_trws_cache_clear()
+    both(ge)
+    _lib.lib().stereo_trws_cache_clear()
