@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+PROFILE_ROUND = "r05"    # roofline.traffic is read from THIS round's committed PMC passes only (profiles/r05_*), never older ones
 
 
 def synthetic_volume(H, W, K, seed):
@@ -305,6 +306,91 @@ def cpu_all_cores(unary, conn, K, iters):
                       "GIL), slowest copy's iteration time; %.1f s wall incl. every copy's setup" % (C_, iters, wall)}
 
 
+def hard_moves_leg(which, H, W, im0_synth):
+    """QPBO hard moves/s through the mirrored class (state resident in HBM, one proposal uploaded per move), then --
+    outside the timed region -- the SAME moves through the reference's QPBO library on the host (oracle/_ref, srand()
+    before every move as tests/test_globalstereo_gpu.py does): `cpu_reference` with `labels_equal`."""
+    import ctypes
+    import stereo_amd
+    from stereo_amd import terms as T
+    P34 = np.tile(np.hstack([np.eye(3), np.zeros((3, 1))])[:, :, None], (1, 1, 2))
+    P34[0, 3, 1] = -0.25
+    gold = os.path.join(ROOT, "tests", "golden")
+    grng = np.random.default_rng(0)
+    if which == "teddy":
+        g = np.load(os.path.join(gold, "teddy_pair.npz"))
+        im0, im1 = g["im0"].astype(np.float64), g["im1"].astype(np.float64)
+        H, W = im0.shape[:2]
+        sg = np.load(os.path.join(gold, "teddy_segments.npz"))
+        gs = stereo_amd.dispmap_globalstereo([im0, im1], P34, (0, 59), 4, segment=sg["segment"], rng=grng)
+        t1 = time.perf_counter()
+        props = gs.segpln([sg["segments"][:, :, b] for b in range(14)], seed=0)     # window matching + LO-RANSAC on the device
+        t_props = time.perf_counter() - t1
+        what = ("example_global.m on the Teddy pair: edge weights from the reference's mean-shift segmentation, the 14 SegPln "
+                "proposals on the reference's 14 segmentation maps (planes fitted on the device)")
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "examples"))
+        from example_global import piecewise_planar
+        im0, im1 = synthetic_pair(H, W, 60)
+        gconn = T.construct_neighborhood(H, W)
+        gimg = im0.transpose(1, 0, 2).reshape(H * W, -1)
+        same = np.abs(gimg[gconn[0]] - gimg[gconn[1]]).sum(axis=1) < 30.0
+        gs = stereo_amd.dispmap_globalstereo([im0, im1], P34, (0, 59), 4, smooth_weights=np.where(same, 108.0, 9.0) * 2.0, rng=grng)
+        props = [piecewise_planar(H, W, cell, grng, gs.d_min, gs.d_min + gs.d_step) for cell in (8, 12, 16, 24, 32, 48, 64) for _ in range(2)]
+        t_props = None
+        what = "examples/example_global.py on the synthetic pair: 14 block-wise random-plane proposals, colour-difference edge weights"
+    N = H * W
+    start = np.array(gs.assignment)
+    libc = ctypes.CDLL(None)
+    unl = []
+    t1 = time.perf_counter()
+    for k, pl in enumerate(props):
+        libc.srand(1000 + k)
+        unl.append(gs.binary_fusion(pl)[2])
+    tg = time.perf_counter() - t1
+    res = {"moves_per_s": len(props) / tg, "ms_per_move": tg / len(props) * 1e3, "energy": gs.energy(), "moves": len(props),
+           "grid": "%dx%d" % (W, H), "moves_with_unlabelled_nodes": int(sum(1 for u in unl if u > 0)),
+           "what": what + "; binary fusion with QPBO + weak persistency + Improve"}
+    if t_props is not None:
+        res["proposals_s"] = t_props
+    from oracle import pyoracle, terms as ot
+    if pyoracle.have_ref_qpbo():
+        # the same moves on the host: NumPy pairwise terms, the device's unaries (exp / log differ in the last bit between
+        # libm and the device), the reference library with Improve.  Only the library call is timed.
+        i1, i2 = ot.construct_neighborhood(H, W)
+        conn = np.stack([i1, i2], 1)
+        pts = ot.get_points(H, W)
+        disp = lambda a, p: ot.globalstereo_rescale(ot.disparity_from_assignment(a, p), gs.d_min, gs.d_step)
+        un = lambda a: T.globalstereo_unary(im0, im1, gs.P2, gs.d_min, gs.d_step, gs.options["col_thresh"], np.asfortranarray(a))
+        a = start.copy()
+        gs.assignment = start.copy()
+        t_ref = 0.0
+        differ_total, ties_only, unl_equal = 0, True, True
+        for k, pl in enumerate(props):
+            pl = np.asarray(pl.expand(N) if hasattr(pl, "expand") else pl)
+            U0, U1 = un(a), un(pl)
+            E = ot.all_pairwise_costs(1, np.asarray(gs.smooth_weights), gs.tol, a, pl, i1, i2, pts, disp_fn=disp)
+            t1 = time.perf_counter()
+            lab, e_r, lb_r, nu_r = pyoracle.ref_rd(U0, U1, *E, conn, improve=True, seed=1000 + k)
+            t_ref += time.perf_counter() - t1
+            a[:, lab == 1] = pl[:, lab == 1]
+            libc.srand(1000 + k)
+            nu = gs.binary_fusion(pl)[2]
+            unl_equal = unl_equal and nu == nu_r
+            d = (gs.assignment != a).any(0)
+            if d.any():
+                differ_total += int(d.sum())
+                ties_only = ties_only and bool(np.all(U0[d] == U1[d]))
+                gs.assignment = a.copy()      # the same state on both sides for the next move
+        res["cpu_reference"] = {"moves_per_s": len(props) / t_ref, "ms_per_move": t_ref / len(props) * 1e3, "kind": "reference",
+                                "cores": 1, "what": "the reference's QPBO v1.3 library (oracle/_ref), Solve + weak persistency + "
+                                "Improve, library call only (terms excluded)",
+                                "labels_equal": bool(differ_total == 0),
+                                "pixels_differing_over_all_moves": differ_total, "differences_only_at_exact_unary_ties": ties_only,
+                                "num_unlabelled_equal": bool(unl_equal), "energy": float(e_r)}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -454,16 +540,16 @@ def main():
         achieved = bytes_per_launch / avg_launch_s / 1e9
         # HBM traffic per launch from the committed PMC passes of this same workload (profiles/),
         # corrected as MI355X_MICROARCH.md prescribes; null if the workload differs from them
+        # (only this round's passes count: a shape or volume without one reports null and says why)
         traffic = None
-        pmc = {(375, 450, 60, "ncc", "teddy"): ("r04_trws_teddy60_pmc_hbm.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_trws_teddy60_pmc_hbm.json")) else "r03_trws_teddy60_pmc_hbm.json"),
-               (375, 450, 60, "ncc", "synthetic"): "r02_trws_teddy60_ncc_pmc_hbm.json",
-               (375, 450, 60, "noise", "none"): "r01_trws_teddy60_pmc_hbm.json",
-               (1000, 1500, 256, "noise", "none"): "r01_trws_wide256_1500x1000_pmc_hbm.json",
-               (2000, 3000, 256, "noise", "none"): "r03_trws_wide256_3000x2000_pmc_hbm.json"}.get((H, W, K, volume, pair))
-        traffic_source = None
+        pmc = {(375, 450, 60, "ncc", "teddy"): "%s_trws_teddy60_pmc_hbm.json" % PROFILE_ROUND,
+               (2000, 3000, 256, "noise", "none"): "%s_trws_wide256_3000x2000_pmc_hbm.json" % PROFILE_ROUND}.get((H, W, K, volume, pair))
+        traffic_source = "no PMC pass of this workload (%dx%dx%d, %s volume, %s pair) is committed for %s" % (W, H, K, volume, pair, PROFILE_ROUND)
         if pmc and os.path.exists(os.path.join(ROOT, "profiles", pmc)):
             traffic = json.load(open(os.path.join(ROOT, "profiles", pmc)))["per_launch"]["hbm_bytes_corrected"]
             traffic_source = "profiles/%s (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; NOT measured in this run)" % pmc
+        elif pmc:
+            traffic_source = "profiles/%s not committed yet" % pmc
         out = {
             "metric": "TRW-S fusion iterations/sec, 450x375x60 labels",
             "value": rate,
@@ -523,13 +609,51 @@ def main():
             out["cpu_baseline"] = {"value": ci / secs, "unit": "iterations/s", "cores": 1,
                                    "kind": "port", "host_cores": os.cpu_count(),
                                    "sample": "%d iterations of the same %dx%dx%d volume, oracle/trws_oracle.c "
-                                             "(envelope messages), setup excluded" % (ci, W, H, K)}
+                                             "(envelope messages), setup excluded" % (ci, W, H, K),
+                                   "note": "the port is ~3x faster than the reference mex it stands for (BASELINE.md section 2: "
+                                           "the real trws_mex probed at ~0.25 it/s on this workload) -- value / cpu_baseline is "
+                                           "NOT the speed-up over the reference"}
             if not args.no_cpu_all_cores:
                 try:
                     out["cpu_baseline"]["all_cores"] = cpu_all_cores(unary, conn, K, min(ci, 3))
                 except Exception as exc:
                     out["cpu_baseline"]["all_cores"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        out["fp32_variant"] = ("not offered: SURVEY 8(d) allows fp32 messages for configs[3]/[4]; measured in round 4 "
+                               "(profiles/r04_fp32_cones.txt: -9 % per iteration at 3000x2000x256, bound moves by 4e-10, and no "
+                               "exactness certificate exists in fp32, so every message would take the serial construction); "
+                               "one exact f64 path is kept instead of a second inexact one")
         if world == 1 and not args.no_cpu_baseline:
+            # the drop-in call itself: stereo_trws / stereo_rd exactly as trws.m:33 / rd.m:21 hand the
+            # arrays over -- HOST K x E q and qprim, K x N unary, labels back -- set-up, transfers and everything included
+            try:
+                h_un = np.asfortranarray(d_unary.cpu().numpy().T)                       # K x N
+                h_q = np.asfortranarray(np.tile(np.arange(K, dtype=np.float64)[:, None], (1, E)))   # K x E, as dispmap_super.m:177-183 builds it
+                conn1 = conn.T + 1
+                _lib.lib().stereo_trws_cache_clear()
+                tb = []
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    bl, be, bb, bi = stereo_amd.trws(1, h_un, conn1, h_q, h_q, np.ones(E), 8.0, dict(maxiter=args.steps, max_relgap=NEVER))
+                    tb.append(time.perf_counter() - t1)
+                _lib.lib().stereo_trws_cache_clear()
+                os.environ["STEREO_HIP_TRWS_CACHE"] = "0"
+                t1 = time.perf_counter()
+                ul, ue, ub, ui = stereo_amd.trws(1, h_un, conn1, h_q, h_q, np.ones(E), 8.0, dict(maxiter=args.steps, max_relgap=NEVER))
+                t_unc = time.perf_counter() - t1
+                del os.environ["STEREO_HIP_TRWS_CACHE"]
+                resident_s = dt
+                out["trws_boundary"] = {
+                    "what": "stereo_trws (what trws_mex reaches) with HOST arrays as trws.m:33 hands them: unary K x N (%.0f MB), q and "
+                            "qprim K x E (%.0f MB each), %d iterations, labels back; python-side checks of the binding included"
+                            % (h_un.nbytes / 1e6, h_q.nbytes / 1e6, args.steps),
+                    "first_call_s": tb[0], "second_call_s": tb[1], "third_call_s": tb[2],
+                    "uncached_call_s": t_unc, "uncached_what": "STEREO_HIP_TRWS_CACHE=0: plan per call, K x E arrays uploaded (round 4's path)",
+                    "resident_plan_s_for_the_same_iterations": resident_s,
+                    "second_call_over_resident": tb[1] / resident_s,
+                    "iterations_per_s_second_call": args.steps / tb[1],
+                    "equal_to_uncached": bool(np.array_equal(bl, ul) and be == ue and bb == ub and bi == ui)}
+            except Exception as exc:
+                out["trws_boundary"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
             # secondary figure: QPBO binary fusion moves/s on a Teddy-sized move (host arrays in,
             # labels out -- PCIe inclusive), next to the reference QPBO library where it travelled
             try:
@@ -545,6 +669,19 @@ def main():
                 tf = (time.perf_counter() - t1) / 10
                 extra = {"moves_per_s": 1.0 / tf, "ms_per_move": tf * 1e3, "grid": "%dx%d" % (W, H),
                          "energy": fen, "lower_bound": flb, "unlabelled": fnu, "includes": "H2D of the six term arrays + D2H of labels"}
+                # ... and the gateway entry stereo_rd itself (rd.m:21): first call builds the plan, later calls reuse it
+                try:
+                    _lib.lib().stereo_rd_cache_clear()
+                    trd = []
+                    for _ in range(4):
+                        t1 = time.perf_counter()
+                        glab = stereo_amd.rd(*fargs, fp["conn"].T + 1, {})[0]
+                        trd.append(time.perf_counter() - t1)
+                    extra["rd_boundary"] = {"what": "stereo_rd (what rd_mex reaches) with host arrays as rd.m:21 hands them, labels back",
+                                            "first_call_ms": trd[0] * 1e3, "cached_call_ms": min(trd[1:]) * 1e3,
+                                            "labels_equal_to_plan": bool(np.array_equal(glab, flab))}
+                except Exception as exc:
+                    extra["rd_boundary"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
                 from oracle import pyoracle
                 if pyoracle.have_ref_qpbo():
                     t1 = time.perf_counter()
@@ -577,32 +714,15 @@ def main():
                 tm2 = (time.perf_counter() - t1) / (len(pps) - 1)
                 extra["end_to_end_device_proposals"] = {"moves_per_s": 1.0 / tm2, "ms_per_move": tm2 * 1e3, "energy": dm.energy(),
                                                         "energy_equal_to_end_to_end": bool(dm.energy() == extra["end_to_end"]["energy"])}
-                # hard moves: examples/example_global.py's workload -- dispmap_globalstereo on the synthetic pair,
-                # 14 block-wise piecewise-planar proposals, QPBO with Improve (most moves leave nodes unlabelled)
-                try:
-                    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "examples"))
-                    from example_global import piecewise_planar
-                    from stereo_amd import terms as T
-                    P34 = np.tile(np.hstack([np.eye(3), np.zeros((3, 1))])[:, :, None], (1, 1, 2))
-                    P34[0, 3, 1] = -0.25
-                    gconn = T.construct_neighborhood(H, W)
-                    gimg = im0.transpose(1, 0, 2).reshape(H * W, -1)
-                    same = np.abs(gimg[gconn[0]] - gimg[gconn[1]]).sum(axis=1) < 30.0
-                    grng = np.random.default_rng(0)
-                    gs = stereo_amd.dispmap_globalstereo([im0, im1], P34, (0, 59), 4,
-                                                         smooth_weights=np.where(same, 108.0, 9.0) * 2.0, rng=grng)
-                    props = [piecewise_planar(H, W, cell, grng, gs.d_min, gs.d_min + gs.d_step)
-                             for cell in (8, 12, 16, 24, 32, 48, 64) for _ in range(2)]
-                    t1 = time.perf_counter()
-                    for pl in props:
-                        gs.binary_fusion(pl)
-                    tg = time.perf_counter() - t1
-                    extra["hard_moves"] = {"moves_per_s": len(props) / tg, "ms_per_move": tg / len(props) * 1e3, "energy": gs.energy(),
-                                           "what": "examples/example_global.py: dispmap_globalstereo on the synthetic %dx%d pair, %d "
-                                                   "piecewise-planar proposals, binary fusion with QPBO + weak persistency + Improve"
-                                                   % (W, H, len(props))}
-                except Exception as exc:
-                    extra["hard_moves"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                # hard moves: example_global.m's workload -- dispmap_globalstereo, 14 piecewise-planar proposals, QPBO with
+                # weak persistency + Improve (most moves leave nodes unlabelled) -- on the synthetic pair (block-wise random
+                # planes, colour-difference edge weights) and on the reference's own Teddy pair with the inputs a MATLAB user
+                # has (mean-shift edge weights and SegPln proposals on the reference's own segmentation maps, tests/golden/)
+                for key, which in (("hard_moves", "synthetic"), ("hard_moves_teddy", "teddy")):
+                    try:
+                        extra[key] = hard_moves_leg(which, H, W, im0)
+                    except Exception as exc:
+                        extra[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
                 out["binary_fusion"] = extra
             except Exception as exc:  # the headline number must not depend on the secondary one
                 out["binary_fusion"] = {"error": str(exc)}

@@ -1,7 +1,9 @@
-"""Inputs of BASELINE.json configs[4] -- example_simultaneous.m on the Baby2 pair -- assembled on the
-CPU from committed data and the oracle's NumPy restatement only, so that the golden run
-(tests/golden/make_golden_full.py, build container) and the -m gpu test (GPU box) feed the solver
-the same bits:
+"""Inputs of the reference's examples on its own image pairs, assembled on the CPU from committed data
+and the oracle's NumPy restatement only (test infrastructure).
+
+baby2_problem(): BASELINE.json configs[4] -- example_simultaneous.m on the Baby2 pair -- so that the
+golden run (tests/golden/make_golden_full.py, build container) and the -m gpu test (GPU box) feed the
+solver the same bits:
 
   images      tests/golden/baby2_pair.npz (data/baby2/im2.png, im6.png)
   weights     lambda_h / lambda_l by the reference's own mean-shift segmentation
@@ -18,6 +20,11 @@ the same bits:
               ties between labels, which is the harder case for the message envelope)
   q, qprim    K x E positions of trws.m:33 (dispmap_super.m:177-183), disparities rescaled to
               the search range (:336-345); general planes: q != qprim.
+
+teddy_global(): BASELINE.json configs[2] -- example_global.m on the Teddy pair: the constructor's
+fields from the raw arguments, the 14 SegPln proposals, a seeded start, and a generator of the
+fusion moves' QPBO inputs (U0, U1, E00 .. E11) with NumPy unaries, for the CPU-side experiments on
+what the reference's labels depend on (tests/test_oracle_qpbo.py).
 """
 import os
 
@@ -65,3 +72,42 @@ def baby2_problem(seed=13):
     q, qp = ot.trws_positions(props, i1, i2, pts, disp_fn=disp)
     return dict(kernel=1, unary=np.ascontiguousarray(unary), conn=np.stack([i1, i2], 1), q=q, qprim=qp,
                 alphas=np.asarray(su["weights"], np.float64), tol=su["tol"], props=props, H=H, W=W)
+
+
+class TeddyGlobal:
+    """example_global.m:10-31 from the raw arguments (oracle/terms.py), Teddy pair, real segmentation."""
+
+    def __init__(self, seed=5):
+        g = np.load(os.path.join(GOLD, "teddy_pair.npz"))
+        sg = np.load(os.path.join(GOLD, "teddy_segments.npz"))
+        pl = np.load(os.path.join(GOLD, "teddy_segpln_planes.npz"))
+        self.im0, self.im1 = g["im0"].astype(np.float64), g["im1"].astype(np.float64)
+        self.H, self.W = self.im0.shape[:2]
+        self.N = self.H * self.W
+        self.P = example_P()                                                           # example_global.m:17-18
+        self.segment = sg["segment"]
+        self.su = ot.globalstereo_setup(self.P, [0, 59], 4, self.segment, 2, 1)        # :19-20
+        self.i1, self.i2 = ot.construct_neighborhood(self.H, self.W)
+        self.conn = np.stack([self.i1, self.i2], 1)
+        self.pts = ot.get_points(self.H, self.W)
+        self.proposals = proposals_from_planes(sg["segments"], [pl["planes_%d" % b] for b in range(14)])
+        rng = np.random.default_rng(seed)
+        self.start = rng.random((self.H, self.W)) * self.su["d_step"] + self.su["d_min"]   # dispmap_globalstereo.m:56
+        self.a = np.zeros((4, self.N)); self.a[2] = 1.0; self.a[3] = -self.start.T.reshape(-1)
+
+    def disp(self, asg, p):
+        return ot.globalstereo_rescale(ot.disparity_from_assignment(asg, p), self.su["d_min"], self.su["d_step"])
+
+    def unary(self, asg):
+        su = self.su
+        return ot.globalstereo_unary_cost(self.im0, self.im1, su["P2"], su["d_min"], su["d_step"], su["col_thresh"], asg, self.pts)
+
+    def move_terms(self, prop, unary=None):
+        """-> U0, U1, (E00, E01, E10, E11) of fusing `prop` into the current assignment (dispmap_super.m:61-84)."""
+        un = unary or self.unary
+        E = ot.all_pairwise_costs(1, self.su["weights"], self.su["tol"], self.a, prop, self.i1, self.i2, self.pts, disp_fn=self.disp)
+        return un(self.a), un(prop), E
+
+    def accept(self, prop, labelling):
+        m = np.asarray(labelling) == 1                                                 # dispmap_super.m:83
+        self.a[:, m] = prop[:, m]

@@ -68,7 +68,7 @@ def run_config1():
 
 def run_config4():
     from oracle import pyoracle
-    from simultaneous_inputs import baby2_problem
+    from example_inputs import baby2_problem
     p = baby2_problem()
     t0 = time.time()
     lab, en, lb, it = pyoracle.trws(p["kernel"], p["unary"], p["conn"], p["q"], p["qprim"], p["alphas"],

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import terms as ot  # noqa: E402
-from simultaneous_inputs import example_P  # noqa: E402
+from example_inputs import example_P  # noqa: E402
 
 for name, disp_range, factor in (("baby2", [0, 85], 3), ("teddy", [0, 59], 4)):
     g = np.load(os.path.join(HERE, "%s_pair.npz" % name))

@@ -57,7 +57,27 @@ class OracleGlobal:
         return e, lb, nu
 
 
-def _run(hip, oracle, im0, im1, disp_range, factor, seg, cells, seed0, kernel=1, tie_allowance=1e-4):
+def _grid_leg(hip, oracle, ref, prop, U0, U1, seed):
+    """The same move with every input rounded to a 2^-30 grid: capacities, sums and flows are exact in
+    double precision then, so the roof-dual labelling does not depend on the order of any operation --
+    the HIP path (through the rd.m boundary, hip.rd -> stereo_rd) must give the reference library's
+    labels at EVERY pixel, exact ties included, with Improve; energy and bound equal as numbers."""
+    Q = 2.0 ** 30
+    grid = lambda x: np.round(np.asarray(x) * Q) / Q
+    E = [grid(x) for x in ot.all_pairwise_costs(ref.kernel, ref.w, ref.tol, ref.a, prop, ref.i1, ref.i2, ref.pts, disp_fn=ref.disp)]
+    U0g, U1g = grid(U0), grid(U1)
+    lab_r, e_r, lb_r, nu_r = ref.o.ref_rd(U0g, U1g, *E, ref.conn, improve=True, seed=seed)
+    ctypes.CDLL(None).srand(seed)
+    lab, e, lb, nu = hip.rd(U0g, U1g, *E, ref.conn.T + 1, dict(improve=True))
+    n_ties = int((U0g == U1g).sum())
+    assert nu == nu_r, (nu, nu_r)
+    assert np.array_equal(lab, lab_r), "exact grid: %d labels differ (%d exact ties)" % (int((lab != lab_r).sum()), n_ties)
+    assert e == e_r, (e, e_r)
+    return n_ties, nu_r
+
+
+def _run(hip, oracle, im0, im1, disp_range, factor, seg, cells, seed0, kernel=1, tie_allowance=1e-4, proposals=None,
+         grid_moves=()):
     H, W = im0.shape[:2]
     N = H * W
     P = np.tile(np.hstack([np.eye(3), np.zeros((3, 1))])[:, :, None], (1, 1, 2))      # example_global.m:17-18
@@ -84,9 +104,12 @@ def _run(hip, oracle, im0, im1, disp_range, factor, seg, cells, seed0, kernel=1,
     total_unlabelled = 0
     tie_pixels = 0
     resync = []
-    for k, cell in enumerate(cells):
-        prop = piecewise_planar(H, W, cell, rng, d_lo, d_hi)
+    grid_ties = 0
+    for k, cell in enumerate(cells if proposals is None else range(len(proposals))):
+        prop = piecewise_planar(H, W, cell, rng, d_lo, d_hi) if proposals is None else proposals[k]
         U0, U1 = ref.unary(ref.a), ref.unary(prop)
+        if k in grid_moves:
+            grid_ties += _grid_leg(hip, oracle, ref, prop, U0, U1, 2000 + k)[0]
         e_r, lb_r, nu_r = ref.binary_fusion(prop, seed=1000 + k)
         libc.srand(1000 + k)
         e, lb, nu = gs.binary_fusion(prop)
@@ -115,9 +138,10 @@ def _run(hip, oracle, im0, im1, disp_range, factor, seg, cells, seed0, kernel=1,
             gs.assignment = ref.a.copy()      # same state on both sides for the next move
         total_unlabelled += nu_r
     # (shown with pytest -s / in the failure report: move, resynchronised pixels, exact ties of that move)
-    print("globalstereo parity: %d moves, %d pixels of %d resynchronised at exact ties, per move %s" % (
-        len(cells), tie_pixels, N, resync))
-    assert tie_pixels <= tie_allowance * N * len(cells), tie_pixels
+    n_moves = len(cells) if proposals is None else len(proposals)
+    print("globalstereo parity: %d moves, %d pixels of %d resynchronised at exact ties, per move %s; exact-grid legs: %d moves, "
+          "%d exact ties, all labels equal" % (n_moves, tie_pixels, N, resync, len(grid_moves), grid_ties))
+    assert tie_pixels <= tie_allowance * N * n_moves, tie_pixels
     return total_unlabelled, gs.energy()
 
 
@@ -127,7 +151,8 @@ def test_globalstereo_moves_with_improve_on_the_teddy_crop(hip, oracle):
     g = np.load(os.path.join(GOLD, "teddy_crop.npz"))
     im0, im1 = g["im0"].astype(np.float64), g["im1"].astype(np.float64)
     H, W = im0.shape[:2]
-    seg = (np.arange(H)[:, None] // 16) * 10 + (np.arange(W)[None, :] // 24)
+    r0, c0 = (int(v) for v in g["origin"])      # the reference's own mean-shift segments of the full image, cut to the crop
+    seg = np.load(os.path.join(GOLD, "teddy_segments.npz"))["segment"][r0:r0 + H, c0:c0 + W]
     _run(hip, oracle, im0, im1, [0, 15], 4, seg, cells=(4, 6, 8, 8, 12, 16, 24, 32), seed0=3)
 
 
@@ -135,8 +160,10 @@ def test_globalstereo_moves_with_improve_on_the_teddy_crop(hip, oracle):
 def test_globalstereo_moves_with_improve_full_size(pair, hip, oracle):
     """375 x 450 with the example's constants (example_global.m:17-20: disp_range [0 59], factor 4,
     P(1,4,2) = -0.25, lambda 9 / 108, improve on): on the reference's own Teddy pair (data/teddy/im2.png,
-    im6.png = tests/golden/teddy_pair.npz), whose segment image here is a colour-quantisation stand-in for
-    the mean-shift segmenter (out of scope), and on the synthetic textured pair."""
+    im6.png = tests/golden/teddy_pair.npz) with the segment image of the reference's own mean-shift segmenter
+    (tests/golden/teddy_segments.npz, made by oracle/_ref/libref_segment_ms.so), and on the synthetic textured
+    pair.  Proposals: block-wise random planes, the hard case for ties (a quarter of the pixels leave the right
+    image under both planes).  Moves 1 and 3 are also run on the exact 2^-30 grid (_grid_leg): every label equal."""
     if not oracle.have_ref_qpbo():
         pytest.skip("oracle/_ref/libref_qpbo.so not present")
     H, W = 375, 450
@@ -144,9 +171,7 @@ def test_globalstereo_moves_with_improve_full_size(pair, hip, oracle):
         g = np.load(os.path.join(GOLD, "teddy_pair.npz"))
         im0, im1 = g["im0"].astype(np.float64), g["im1"].astype(np.float64)
         assert im0.shape[:2] == (H, W)
-        # segments = 32 x 32-pixel cells split by coarse colour (3 bits per channel of the cell-smoothed image)
-        q = (im0 // 32).astype(np.int64)
-        seg = ((np.arange(H)[:, None] // 32) * 64 + (np.arange(W)[None, :] // 32)) * 512 + q[:, :, 0] * 64 + q[:, :, 1] * 8 + q[:, :, 2]
+        seg = np.load(os.path.join(GOLD, "teddy_segments.npz"))["segment"]       # vgg_segment_ms(R, 4, 5, 0), :391-392
     else:
         import sys
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -156,9 +181,31 @@ def test_globalstereo_moves_with_improve_full_size(pair, hip, oracle):
     # tie allowance: 1e-4 of the pixels per move on the synthetic pair; on the Teddy pair, where 23 % of the pixels
     # are exact ties in every move, 5e-4 of the pixels and at most 0.5 % of the move's exact ties
     unl, _ = _run(hip, oracle, im0, im1, [0, 59], 4, seg, cells=(8, 12, 16, 24, 32, 48), seed0=5,
-                  tie_allowance=5e-4 if pair == "teddy" else 1e-4)
+                  tie_allowance=5e-4 if pair == "teddy" else 1e-4, grid_moves=(1, 3))
     if pair == "synthetic":   # (the Teddy pair's six moves happen to label every node: Improve is exercised on the synthetic pair)
         assert unl > 0, "no move left nodes unlabelled: Improve was not exercised"
+
+
+def test_example_global_on_the_teddy_pair(hip, oracle):
+    """BASELINE.json configs[2] = example_global.m:10-39 with the inputs a MATLAB user has: the Teddy pair, the
+    constructor's defaults (ojw_default_options('cvpr08')), edge weights from the reference's own mean-shift
+    segmentation, and the 14 SegPln proposals on the reference's own 14 segmentation maps (mean shift and
+    graph-based at seven scales each, dispmap_globalstereo.m:121-134; planes per segment from the committed
+    fixture, tests/golden/teddy_segpln_planes.npz), fused one after the other with QPBO + Improve.  The start
+    (rand, :56) is seeded.  Bar as in _run: assignment bit-equal after every move except at exact ties U0 == U1
+    (a handful per move here: the proposals follow the scene), unlabelled count equal, energy within 1e-9;
+    three of the moves repeated on the exact grid with every label equal."""
+    if not oracle.have_ref_qpbo():
+        pytest.skip("oracle/_ref/libref_qpbo.so not present")
+    from example_inputs import proposals_from_planes
+    g = np.load(os.path.join(GOLD, "teddy_pair.npz"))
+    im0, im1 = g["im0"].astype(np.float64), g["im1"].astype(np.float64)
+    sg = np.load(os.path.join(GOLD, "teddy_segments.npz"))
+    pl = np.load(os.path.join(GOLD, "teddy_segpln_planes.npz"))
+    props = proposals_from_planes(sg["segments"], [pl["planes_%d" % b] for b in range(14)])
+    unl, _ = _run(hip, oracle, im0, im1, [0, 59], 4, sg["segment"], cells=None, seed0=5, tie_allowance=1e-4,
+                  proposals=props, grid_moves=(1, 6, 12))
+    assert unl > 0, "no move left nodes unlabelled: Improve was not exercised"
 
 
 def test_globalstereo_quadratic_kernel_moves(hip, oracle):

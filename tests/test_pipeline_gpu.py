@@ -119,3 +119,41 @@ def test_fuse_until_convergence_and_globalstereo(hip, oracle):
     assert gs.energy() < e_start
     with pytest.raises(hip.StereoHipError, match="wrong size"):
         gs.binary_fusion(np.zeros((4, 3)))
+
+
+def test_example_ncc_on_the_teddy_pair_full_size(hip, oracle):
+    """BASELINE.json configs[0] = example_ncc.m at full size on the reference's own Teddy pair
+    (tests/golden/teddy_pair.npz = data/teddy/im2.png, im6.png, 375 x 450): 60 disparities (BASELINE's
+    label count; the script ships 0:1:50), tol 8, unary weight 40, kernel 1 (:13-16); proposals = the
+    local plane fits on the 10:50:W x 10:50:H lattice with radius 5 (:24-32, 72 of them, fitted by the
+    product and handed to both sides: proposals are inputs) followed by the fronto-parallel planes
+    d = 0:10:max(disparities) (:35-41); one binary_fusion per proposal in that order (:45-49).  After
+    EVERY move the whole 4 x N assignment is bit-equal to the pipeline driven by the reference's QPBO
+    library, num_unlabelled equal, energy and bound within 1e-9."""
+    if not oracle.have_ref_qpbo():
+        pytest.skip("oracle/_ref/libref_qpbo.so not present")
+    g = np.load(os.path.join(GOLD, "teddy_pair.npz"))
+    im0, im1 = g["im0"].astype(np.float64), g["im1"].astype(np.float64)
+    H, W = im0.shape[:2]
+    N = H * W
+    disps = np.arange(0, 60.0)
+    dm = hip.dispmap_ncc([im0, im1], disps, 1, 40.0, 8.0)
+    ref = OraclePipeline(oracle, im0, im1, disps, 1, 40.0, 8.0, ncc=dm.ncc)
+    assert np.array_equal(dm.assignment, ref.a)
+    lattice = dm.generate_plane_lattice(radius=5, first=10, step=50)
+    assert len(lattice) == 9 * 8
+    props = [np.asarray(p.expand(N) if hasattr(p, "expand") else p) for p in lattice]
+    props += [ot.fronto_parallel(d, N) for d in np.arange(0, disps.max() + 1e-9, 10.0)]
+    assert len(props) == 78
+    accepted = 0
+    for k, (pl, P) in enumerate(zip(list(lattice) + props[72:], props)):
+        before = ref.a.copy()
+        e, lb, nu = dm.binary_fusion(pl)
+        e_r, lb_r, nu_r = ref.binary_fusion(P)
+        assert nu == nu_r, (k, nu, nu_r)
+        assert np.array_equal(dm.assignment, ref.a), "move %d: %d pixels took another plane" % (
+            k, int((dm.assignment != ref.a).any(0).sum()))
+        assert abs(e - e_r) <= 1e-9 * abs(e_r) and abs(lb - lb_r) <= 1e-9 * abs(lb_r), (k, e, e_r, lb, lb_r)
+        accepted += int((ref.a != before).any(0).sum())
+    assert abs(dm.energy() - ref.energy()) <= 1e-9 * abs(ref.energy())
+    assert accepted > N // 2          # the sweep actually rewrites the disparity map

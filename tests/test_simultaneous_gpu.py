@@ -63,23 +63,28 @@ class OracleGlobalSimultaneous:
         return e, lb, it, L
 
 
-def _run(hip, oracle, im0, im1, disp_range, factor, weights, seed, maxiter, relgap, kernel=1):
+def _run(hip, oracle, im0, im1, disp_range, factor, seg, seed, maxiter, relgap, kernel=1, proposals=None):
     H, W = im0.shape[:2]
     P = np.tile(np.hstack([np.eye(3), np.zeros((3, 1))])[:, :, None], (1, 1, 2))      # example_simultaneous.m:15-16
     P[0, 3, 1] = -0.25
     rng = np.random.default_rng(seed)
-    gs = hip.dispmap_globalstereo([im0, im1], P, disp_range, factor, smooth_weights=weights, rng=rng,
+    gs = hip.dispmap_globalstereo([im0, im1], P, disp_range, factor, segment=seg, rng=rng,
                                   options=dict(smoothness_kernel=kernel))
+    su = ot.globalstereo_setup(P, disp_range, factor, seg, 2, kernel)              # from the RAW arguments (:377-414)
+    assert np.array_equal(gs.smooth_weights, su["weights"]) and gs.tol == su["tol"]
     ref = OracleGlobalSimultaneous(oracle, gs, im0, im1)
     assert np.max(np.abs(ref.unary(ref.a) - ref.unary_numpy(ref.a))) < 1e-11       # device unary vs NumPy restatement
     assert _rel(gs.energy(), ref.energy()) < 1e-9
     # proposals that follow the scene (block-wise planes around the winner-takes-all disparities of
     # the pair's NCC volume, in globalstereo units = pixels x disparity_factor), so that many of the
     # 15 labels win somewhere; the reference's SegPln generator is out of scope
-    px = -P[0, 3, 1]                                   # pixels per disparity unit (T = [x y 1 disp] P2, :357-358)
-    d_px = np.arange(0.0, np.ceil((gs.d_min + gs.d_step) * px) + 1)
-    wta = hip.dispmap_ncc([im0, im1], d_px, 1, 40.0, 8.0).best_disp_from_ncc()
-    props = [piecewise_planar_from_disparity(H, W, cell, rng, np.asarray(wta) / px) for cell in CELLS for _ in range(2)]
+    if proposals is None:
+        px = -P[0, 3, 1]                               # pixels per disparity unit (T = [x y 1 disp] P2, :357-358)
+        d_px = np.arange(0.0, np.ceil((gs.d_min + gs.d_step) * px) + 1)
+        wta = hip.dispmap_ncc([im0, im1], d_px, 1, 40.0, 8.0).best_disp_from_ncc()
+        props = [piecewise_planar_from_disparity(H, W, cell, rng, np.asarray(wta) / px) for cell in CELLS for _ in range(2)]
+    else:
+        props = proposals
     assert len(props) == 14
     gs.maxiter, gs.max_relgap = maxiter, relgap
     e, lb, it = gs.simultaneous_fusion(props)
@@ -93,14 +98,14 @@ def _run(hip, oracle, im0, im1, disp_range, factor, weights, seed, maxiter, relg
     return it, e, lb
 
 
-def _weights(im0):
-    """Edge weights (9 | 108) * 2 from a colour-difference rule standing in for the mean-shift
-    segments (dispmap_globalstereo.m:391-403; the segmenter is out of scope)."""
-    H, W = im0.shape[:2]
-    i1, i2 = ot.construct_neighborhood(H, W)
-    img = im0.transpose(1, 0, 2).reshape(H * W, -1)
-    same = np.abs(img[i1] - img[i2]).sum(axis=1) < 30.0
-    return np.where(same, 108.0, 9.0) * 2.0
+def _crop_segment():
+    """The reference's own mean-shift segmentation of the Teddy reference image (tests/golden/teddy_segments.npz,
+    vgg_segment_ms(R, 4, 5, 0), dispmap_globalstereo.m:391-392), cut to the 64 x 96 crop: the edge weights are
+    lambda_h inside a segment and lambda_l across a boundary (:397-403), so only same / different matters."""
+    g = np.load(os.path.join(GOLD, "teddy_crop.npz"))
+    r0, c0 = (int(v) for v in g["origin"])
+    H, W = g["im0"].shape[:2]
+    return np.load(os.path.join(GOLD, "teddy_segments.npz"))["segment"][r0:r0 + H, c0:c0 + W]
 
 
 def test_simultaneous_fusion_on_the_teddy_crop_with_the_examples_settings(hip, oracle):
@@ -108,7 +113,7 @@ def test_simultaneous_fusion_on_the_teddy_crop_with_the_examples_settings(hip, o
     sets them: the run ends on the gap test, so the iteration count itself is under test."""
     g = np.load(os.path.join(GOLD, "teddy_crop.npz"))
     im0, im1 = g["im0"].astype(np.float64), g["im1"].astype(np.float64)
-    it, e, lb = _run(hip, oracle, im0, im1, [0, 15], 4, _weights(im0), seed=11, maxiter=3000, relgap=1e-5)
+    it, e, lb = _run(hip, oracle, im0, im1, [0, 15], 4, _crop_segment(), seed=11, maxiter=3000, relgap=1e-5)
     assert 1 < it < 3000 and (e - lb) / e < 1e-5
 
 
@@ -116,18 +121,26 @@ def test_simultaneous_fusion_quadratic_kernel_on_the_crop(hip, oracle):
     """Kernel 2: w <- w / tol, tol <- tol^2 (dispmap_globalstereo.m:410-413), typeStereoQuadratic.h messages."""
     g = np.load(os.path.join(GOLD, "teddy_crop.npz"))
     im0, im1 = g["im0"].astype(np.float64), g["im1"].astype(np.float64)
-    _run(hip, oracle, im0, im1, [0, 15], 4, _weights(im0), seed=12, maxiter=40, relgap=1e-5, kernel=2)
+    _run(hip, oracle, im0, im1, [0, 15], 4, _crop_segment(), seed=12, maxiter=40, relgap=1e-5, kernel=2)
 
 
 def test_simultaneous_fusion_baby2(hip, oracle):
     """The example's own input: the Baby2 pair (tests/golden/baby2_pair.npz = data/baby2/im2.png,
     im6.png, 370 x 413), disp_range [0 85], factor 3 (example_simultaneous.m:9-18), K = 15.  The
-    oracle needs ~1.2 s per iteration at this size, so the iteration cap is 40 instead of the
-    example's 3000 (same code path; the gap test is exercised on the crop)."""
+    edge weights come from the reference's own mean-shift segmentation (tests/golden/baby2_segments.npz) and the
+    proposals are the 14 SegPln proposals on the reference's own 14 segmentation maps
+    (tests/golden/baby2_segpln_planes.npz, dispmap_globalstereo.m:121-197) -- what `dm.segpln()` hands
+    simultaneous_fusion in the example (:30,52).  The oracle needs ~1.5 s per iteration at this size, so the
+    iteration cap is 40 here instead of the example's 3000; the run to the example's stop is
+    tests/test_full_runs_gpu.py (golden checksums of the oracle run made once in the build container)."""
+    from example_inputs import proposals_from_planes
     g = np.load(os.path.join(GOLD, "baby2_pair.npz"))
     im0, im1 = g["im0"].astype(np.float64), g["im1"].astype(np.float64)
     assert im0.shape == (370, 413, 3)
-    it, _, _ = _run(hip, oracle, im0, im1, [0, 85], 3, _weights(im0), seed=13, maxiter=40, relgap=1e-5)
+    sg = np.load(os.path.join(GOLD, "baby2_segments.npz"))
+    pl = np.load(os.path.join(GOLD, "baby2_segpln_planes.npz"))
+    props = proposals_from_planes(sg["segments"], [pl["planes_%d" % b] for b in range(14)])
+    it, _, _ = _run(hip, oracle, im0, im1, [0, 85], 3, sg["segment"], seed=13, maxiter=40, relgap=1e-5, proposals=props)
     assert it == 40
 
 
@@ -138,7 +151,7 @@ def test_simultaneous_fusion_degenerate_inputs(hip):
     g = np.load(os.path.join(GOLD, "teddy_crop.npz"))
     im0, im1 = g["im0"].astype(np.float64), g["im1"].astype(np.float64)
     P = np.tile(np.hstack([np.eye(3), np.zeros((3, 1))])[:, :, None], (1, 1, 2)); P[0, 3, 1] = -0.25
-    gs = hip.dispmap_globalstereo([im0, im1], P, [0, 15], 4, smooth_weights=_weights(im0), rng=np.random.default_rng(0))
+    gs = hip.dispmap_globalstereo([im0, im1], P, [0, 15], 4, segment=_crop_segment(), rng=np.random.default_rng(0))
     before, e0 = np.array(gs.assignment), gs.energy()
     gs.maxiter = 3
     e, lb, it = gs.simultaneous_fusion([])
