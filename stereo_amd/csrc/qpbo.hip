@@ -1236,6 +1236,12 @@ __global__ __launch_bounds__(kQB) void det_sum_kernel(const double *x, int64_t n
   if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
 }
 
+// flow absorbed by every node's sink arc: initial minus residual capacity
+__global__ __launch_bounds__(kQB) void rd_absorbed_kernel(int n, const double *snk0, const double *snk, double *out) {
+  const int v = blockIdx.x * kQB + threadIdx.x;
+  if (v < n) out[v] = snk0[v] - snk[v];
+}
+
 // energy of a labelling from the caller's tables: per-node and per-edge terms
 __global__ __launch_bounds__(kQB) void rd_energy_terms_kernel(int64_t N, int64_t E, const uint32_t *conn,
                                                               const int32_t *h, int n, const double *U0,
@@ -2089,7 +2095,7 @@ extern "C" int stereo_rd_plan_create(int64_t N, int64_t E, const uint32_t *conn,
     P->d_slots.upload(slots.data(), slots.size()); P->d_slot_pair.upload(slot_pair.data(), slot_pair.size());
     P->d_conn.upload(conn, 2 * E);
     P->d_ci.alloc(np); P->d_cjs.alloc(np); P->d_konst.alloc(np); P->d_trv.alloc(N);
-    P->d_terms.alloc(N + E); P->d_label.alloc(N); P->d_snk0.alloc(n);
+    P->d_terms.alloc(std::max<int64_t>(N + E, n)); P->d_label.alloc(N); P->d_snk0.alloc(n);
     QpboSolver &S = P->S;
     S.P.N = N; S.P.aptr = aptr;
     S.n = (int)n; S.m = (int)m;
@@ -2139,7 +2145,6 @@ static int rd_plan_solve_device(stereo_rd_plan *P, const double *const in[6], in
     // together with the sums that follow the max-flow
     DetSums sums(P->d_partial, DetSums::blocks(np) + 2 * DetSums::blocks(N) + 2 * DetSums::blocks(n) + DetSums::blocks(N + E));
     const int s_konst = sums.queue(P->d_konst.p, np), s_u0 = sums.queue(in[0], N);
-    const int s_cap = sums.queue(P->d_snk0.p, n);
     const int s_neg = sums.queue(P->d_snk0.p, N);   // sum_i min(0, tr_i) = -(sink capacity of the unprimed half)
     S.iterations = 0; S.relabels = 0;
     const bool verbose = std::getenv("STEREO_HIP_QPBO_VERBOSE") != nullptr;
@@ -2151,7 +2156,12 @@ static int rd_plan_solve_device(stereo_rd_plan *P, const double *const in[6], in
       STEREO_HIP_CHECK(hipDeviceSynchronize());
       std::fprintf(stderr, "[stereo_hip qpbo plan] maxflow %.3f ms\n", now() - tm0);
     }
-    const int s_left = sums.queue(S.d_snk.p, n);
+    // what reached the sink, node by node (snk0 - snk is exact for a node whose capacity barely moved -- an
+    // out-of-range plane makes unaries of 4e7, dispmap_ncc.m:245 -- where the difference of the two totals
+    // loses everything below ulp(1e12): 1e-3 on example_ncc.m's first move)
+    hipLaunchKernelGGL(rd_absorbed_kernel, dim3((unsigned)((n + kQB - 1) / kQB)), dim3(kQB), 0, 0, n, P->d_snk0.p, S.d_snk.p,
+                       P->d_terms.p);
+    const int s_flow = sums.queue(P->d_terms.p, n);   // (d_terms, max(N + E, 2 N) doubles, is free until the energy terms below)
     // labels on the device; the host only sees the number of unlabelled nodes
     if ((int64_t)P->d_label.n < N) P->d_label.alloc(N);
     STEREO_HIP_CHECK(hipMemsetAsync(S.d_cnt.p + 3, 0, sizeof(int32_t), 0));
@@ -2165,8 +2175,8 @@ static int rd_plan_solve_device(stereo_rd_plan *P, const double *const in[6], in
     sums.fetch();
     int32_t unl32 = 0;
     STEREO_HIP_CHECK(hipMemcpy(&unl32, S.d_cnt.p + 3, sizeof(unl32), hipMemcpyDeviceToHost));
-    const double konst = sums.get(s_konst) + sums.get(s_u0), cap_in = sums.get(s_cap), neg = -sums.get(s_neg);
-    *lower_bound = konst + neg + (cap_in - sums.get(s_left)) / 2;
+    const double konst = sums.get(s_konst) + sums.get(s_u0), neg = -sums.get(s_neg);
+    *lower_bound = konst + neg + sums.get(s_flow) / 2;
     double unl = unl32;
     if (unl > 0) {
       const double tw0 = now();

@@ -10,8 +10,10 @@ handed to both sides (checked against the NumPy restatement to 1e-11 on their ow
 in the last bit between libm and the device, and a parity test of the solver must not hinge on
 that.  Bar: the accepted planes -- the whole 4 x N assignment -- bit-exact after
 every move, num_unlabelled equal, energy within 1e-9.  One documented exception: pixels with
-EXACTLY equal unaries for both planes (see _run) -- there the reference's own label is an
-artefact of floating-point residues in its max-flow, and at most 1e-4 of the pixels may differ."""
+EXACTLY equal unaries for both planes (see _run) -- there the reference's own label is an artefact of
+rounding in its capacities and flows (it changes with the order of its input edges,
+tests/test_oracle_qpbo.py): at most 3 % of a move's exact ties may take the other plane, and every
+move where that happens is repeated on an exact 2^-30 grid of inputs, where all labels must be equal."""
 import ctypes
 import os
 
@@ -22,6 +24,7 @@ from helpers import piecewise_planar
 from oracle import terms as ot
 
 pytestmark = pytest.mark.gpu
+NEAR_TIE = 1e-14      # |U0 - U1| at or below this: both planes' photo-consistency saturates at log 2 (to the last bits)
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -57,14 +60,14 @@ class OracleGlobal:
         return e, lb, nu
 
 
-def _grid_leg(hip, oracle, ref, prop, U0, U1, seed):
+def _grid_leg(hip, oracle, ref, a, prop, U0, U1, seed):
     """The same move with every input rounded to a 2^-30 grid: capacities, sums and flows are exact in
     double precision then, so the roof-dual labelling does not depend on the order of any operation --
     the HIP path (through the rd.m boundary, hip.rd -> stereo_rd) must give the reference library's
     labels at EVERY pixel, exact ties included, with Improve; energy and bound equal as numbers."""
     Q = 2.0 ** 30
     grid = lambda x: np.round(np.asarray(x) * Q) / Q
-    E = [grid(x) for x in ot.all_pairwise_costs(ref.kernel, ref.w, ref.tol, ref.a, prop, ref.i1, ref.i2, ref.pts, disp_fn=ref.disp)]
+    E = [grid(x) for x in ot.all_pairwise_costs(ref.kernel, ref.w, ref.tol, a, prop, ref.i1, ref.i2, ref.pts, disp_fn=ref.disp)]
     U0g, U1g = grid(U0), grid(U1)
     lab_r, e_r, lb_r, nu_r = ref.o.ref_rd(U0g, U1g, *E, ref.conn, improve=True, seed=seed)
     ctypes.CDLL(None).srand(seed)
@@ -76,7 +79,7 @@ def _grid_leg(hip, oracle, ref, prop, U0, U1, seed):
     return n_ties, nu_r
 
 
-def _run(hip, oracle, im0, im1, disp_range, factor, seg, cells, seed0, kernel=1, tie_allowance=1e-4, proposals=None,
+def _run(hip, oracle, im0, im1, disp_range, factor, seg, cells, seed0, kernel=1, tie_allowance=0.03, proposals=None,
          grid_moves=()):
     H, W = im0.shape[:2]
     N = H * W
@@ -104,12 +107,14 @@ def _run(hip, oracle, im0, im1, disp_range, factor, seg, cells, seed0, kernel=1,
     total_unlabelled = 0
     tie_pixels = 0
     resync = []
-    grid_ties = 0
+    grid_ties = grid_extra = 0
     for k, cell in enumerate(cells if proposals is None else range(len(proposals))):
         prop = piecewise_planar(H, W, cell, rng, d_lo, d_hi) if proposals is None else proposals[k]
         U0, U1 = ref.unary(ref.a), ref.unary(prop)
-        if k in grid_moves:
-            grid_ties += _grid_leg(hip, oracle, ref, prop, U0, U1, 2000 + k)[0]
+        a_before = ref.a.copy()
+        on_grid = k in grid_moves
+        if on_grid:
+            grid_ties += _grid_leg(hip, oracle, ref, a_before, prop, U0, U1, 2000 + k)[0]
         e_r, lb_r, nu_r = ref.binary_fusion(prop, seed=1000 + k)
         libc.srand(1000 + k)
         e, lb, nu = gs.binary_fusion(prop)
@@ -120,28 +125,30 @@ def _run(hip, oracle, im0, im1, disp_range, factor, seg, cells, seed0, kernel=1,
         if differ.any():
             # The only pixels where the accepted planes may differ: exact ties U0 == U1 (both planes
             # leave the right image there: the photo-consistency saturates at log 2,
-            # dispmap_globalstereo.m:371,405).  Which side of the cut such a node lands on is decided
-            # by last-bit residues of the max-flow algorithm IN THE REFERENCE ITSELF (QPBO.h:127-128
-            # warns about it); both labellings have the same energy (asserted above to 1e-9, and
-            # the two solvers' energies agree to ~1e-11 here).
-            assert np.all(U0[differ] == U1[differ]), "move %d: %d pixels differ outside exact ties" % (k, int((U0[differ] != U1[differ]).sum()))
-            # ... and few of them, PER MOVE (a regression inside a summed allowance would be invisible):
-            # at most 1e-4 of the pixels and never more than a tenth of the exact ties of the move
-            # (on the real Teddy pair a quarter of the pixels are exact ties in every move -- ~39 000 of 168 750:
-            #  both planes leave the right image -- and ~50 of them land on the other side per move; the synthetic
-            #  pairs have a few hundred ties and 0-2 such pixels)
+            # dispmap_globalstereo.m:371,405).  Which side of the cut such a node lands on is decided by
+            # last-bit rounding of capacities and flows IN THE REFERENCE ITSELF: its own labels there change when
+            # it is handed the same energy with the edges in another order (tests/test_oracle_qpbo.py,
+            # test_tie_labels_of_the_reference_depend_on_its_own_edge_order; QPBO.h:127-128 warns about it); both
+            # labellings have the same energy (asserted above to 1e-9).
+            # (or ties to the last bit: |U0 - U1| of one or two ulp of log 2 occurs a few times per thousand differing pixels)
+            near = np.abs(U0 - U1) <= NEAR_TIE
+            assert np.all(near[differ]), "move %d: %d pixels differ outside (near) ties" % (k, int((~near[differ]).sum()))
+            # ... a small part of the move's exact ties (whole zero-capacity components flip together: dozens of
+            # pixels; measured <= 2 % of the ties of a move; a regression inside a summed allowance would be invisible)
             n_diff, n_ties = int(differ.sum()), int((U0 == U1).sum())
             resync.append((k, n_diff, n_ties))
-            assert n_diff <= max(1, tie_allowance * N), "move %d: %d tie pixels took the other plane (%d exact ties)" % (k, n_diff, n_ties)
-            assert n_diff <= max(1, 0.1 * n_ties if tie_allowance <= 1e-4 else 0.005 * n_ties), (k, n_diff, n_ties)
+            assert n_diff <= max(1, tie_allowance * n_ties), "move %d: %d tie pixels took the other plane (%d exact ties)" % (k, n_diff, n_ties)
+            # ... and the SAME move on the exact 2^-30 grid, where no rounding is left, must not differ anywhere
+            if not on_grid:
+                grid_ties += _grid_leg(hip, oracle, ref, a_before, prop, U0, U1, 2000 + k)[0]
+                grid_extra += 1
             tie_pixels += n_diff
             gs.assignment = ref.a.copy()      # same state on both sides for the next move
         total_unlabelled += nu_r
     # (shown with pytest -s / in the failure report: move, resynchronised pixels, exact ties of that move)
     n_moves = len(cells) if proposals is None else len(proposals)
     print("globalstereo parity: %d moves, %d pixels of %d resynchronised at exact ties, per move %s; exact-grid legs: %d moves, "
-          "%d exact ties, all labels equal" % (n_moves, tie_pixels, N, resync, len(grid_moves), grid_ties))
-    assert tie_pixels <= tie_allowance * N * n_moves, tie_pixels
+          "%d exact ties, all labels equal" % (n_moves, tie_pixels, N, resync, len(grid_moves) + grid_extra, grid_ties))
     return total_unlabelled, gs.energy()
 
 
@@ -178,10 +185,8 @@ def test_globalstereo_moves_with_improve_full_size(pair, hip, oracle):
         from bench import synthetic_pair
         im0, im1 = synthetic_pair(H, W, 60)
         seg = (np.arange(H)[:, None] // 25) * 100 + (np.arange(W)[None, :] // 30)
-    # tie allowance: 1e-4 of the pixels per move on the synthetic pair; on the Teddy pair, where 23 % of the pixels
-    # are exact ties in every move, 5e-4 of the pixels and at most 0.5 % of the move's exact ties
-    unl, _ = _run(hip, oracle, im0, im1, [0, 59], 4, seg, cells=(8, 12, 16, 24, 32, 48), seed0=5,
-                  tie_allowance=5e-4 if pair == "teddy" else 1e-4, grid_moves=(1, 3))
+    # tie allowance per move: 3 % of the move's exact ties (Teddy pair: 23 % of the pixels are exact ties in every move)
+    unl, _ = _run(hip, oracle, im0, im1, [0, 59], 4, seg, cells=(8, 12, 16, 24, 32, 48), seed0=5, grid_moves=(1, 3))
     if pair == "synthetic":   # (the Teddy pair's six moves happen to label every node: Improve is exercised on the synthetic pair)
         assert unl > 0, "no move left nodes unlabelled: Improve was not exercised"
 
@@ -203,8 +208,7 @@ def test_example_global_on_the_teddy_pair(hip, oracle):
     sg = np.load(os.path.join(GOLD, "teddy_segments.npz"))
     pl = np.load(os.path.join(GOLD, "teddy_segpln_planes.npz"))
     props = proposals_from_planes(sg["segments"], [pl["planes_%d" % b] for b in range(14)])
-    unl, _ = _run(hip, oracle, im0, im1, [0, 59], 4, sg["segment"], cells=None, seed0=5, tie_allowance=1e-4,
-                  proposals=props, grid_moves=(1, 6, 12))
+    unl, _ = _run(hip, oracle, im0, im1, [0, 59], 4, sg["segment"], cells=None, seed0=5, proposals=props, grid_moves=(1, 6, 12))
     assert unl > 0, "no move left nodes unlabelled: Improve was not exercised"
 
 
