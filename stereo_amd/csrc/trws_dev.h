@@ -1134,6 +1134,41 @@ __device__ __forceinline__ double envelope_value(const DevParams &p, double alph
   return c < vtrunc ? c : vtrunc;
 }
 
+// Second look at a certificate whose tangency test found a cone within delta of an arm of a useful cone j
+// (shared strictly ascending positions: lane t = destination t = cone t).  One kind of tangency is decided, not
+// ambiguous: cone t's apex EXACTLY on the RIGHT arm of an earlier cone j -- fl(alpha |t - q_j| + h_j) == h_t, the
+// very expression of the reference's test `dist + hj <= hk` (typeStereoLinear.h:432-435), which therefore holds and
+// drops cone t whenever t meets j, while `dist + hk < hj` (:417) cannot: the trace of the serial construction is that
+// of the same input with h_t raised by an infinitesimal amount, where cone t is strictly dominated by j and
+// contributes nothing.  Whether the two cones give the same BITS where they coincide is the margin test's business
+// (equal costs count once; costs one ulp apart fail it).  The mirror image -- an apex exactly on a LEFT arm -- is the
+// reference's "s <= q_j" quirk (:444-449: the new cone is dropped although it wins to its right) and stays a failure,
+// like every inexact near-tangency.  The masked columns of an NCC volume (dispmap_ncc.m:190-191) produce such exact
+// right-arm ramps by the thousand: messages there are truncated cones, so the next node's H carries arms of slope
+// exactly alpha (84 % of the Teddy volume's failed certificates, none of them with a result other than min-plus).
+// Table: entry i at hq[stride * i] (h) and hq[stride * i + 1] (q): the first `count` entries (compacted table), or
+// the entries named by `mask` (count == 0).  Returns "still tangent" per lane.
+__device__ __forceinline__ bool harmless_ties_only(double alpha, double h, double t, double delta, bool useful, const double *hq,
+                                                   int stride, int count, unsigned long long mask) {
+  int cnt = 0;
+  if (count > 0) {
+    for (int i = 0; i < count; ++i) {
+      const double hj = hq[stride * i], qj = hq[stride * i + 1];
+      const double dc = (alpha * fabs(t - qj) + hj) - h;
+      cnt += ((fabs(dc) <= delta) & !((dc == 0) & (qj < t))) ? 1 : 0;
+    }
+  } else {
+    while (mask) {
+      const int j = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const double hj = hq[stride * j], qj = hq[stride * j + 1];
+      const double dc = (alpha * fabs(t - qj) + hj) - h;
+      cnt += ((fabs(dc) <= delta) & !((dc == 0) & (qj < t))) ? 1 : 0;
+    }
+  }
+  return cnt != (useful ? 1 : 0);
+}
+
 // Message update with everything in registers (K <= 64): h = gamma*Di - old message,
 // qsrc / t = source / destination positions, perm = ascending order of the sources
 // (only touched by the serial fallback).  Returns the normalised message in `out`.
@@ -1254,7 +1289,9 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
           }
         }
 #undef STEREO_ACC_C
-        bad = bad | (cnt != (useful ? 1 : 0));
+        bool tangent = cnt != (useful ? 1 : 0);
+        if (UNI(act & tangent) && !UNI(act & bad)) tangent = harmless_ties_only(alpha, h, t, delta, useful, hq, 2, nuse, 0ull);
+        bad = bad | tangent;
         VMSTAMP(1);
       } else {
       // The sources are broadcast from a per-wave LDS table (one ds_read_b128 per source instead of
@@ -1309,7 +1346,13 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
         wave_sort2(ku, kv, lane);
         const unsigned un = (unsigned)__shfl_down((int)ku, 1, kWave), vn = (unsigned)__shfl_down((int)kv, 1, kWave);
         const unsigned thr = bad ? 0u : (unsigned)(delta * scale) + 2u;
-        bad = bad || (lane + 1 < K && (un - ku <= thr || vn - kv <= thr));
+        bool tangent = lane + 1 < K && (un - ku <= thr || vn - kv <= thr);
+        // (the sorted keys see ALL pairs and cannot tell an exact tie from a near one: a hit is looked at again pair by pair)
+        //  -- the pairs with a USEFUL member, which is all the certificate asks for; the one pair kind that loop cannot see,
+        //  a useful apex on an arm of a useless cone, is excluded by alpha gap > 2 delta as in the compacted loop above)
+        if (UNI(act & tangent) && !UNI(act & bad) && alpha * p.pos_gap > 2 * delta)
+          tangent = harmless_ties_only(alpha, h, t, delta, useful, hq, 4, 0, mask);
+        bad = bad || tangent;
         for (int d = -window; d <= window; ++d) {
           const double hj = hq[4 * (lane + d)], qj = hq[4 * (lane + d) + 1];
           const double c = pair_cost<1>(alpha, t - qj, hj);

@@ -60,6 +60,9 @@ def heights(rng, q, alpha, lam, kind):
             h[k] = h[k - 1] + sgn * alpha * (q[k] - q[k - 1])   # accumulated: ulp noise along the ramp
         h[a:b] += eps * rng.integers(0, 2, b - a)
         h[a:b] -= min(0.0, h[a:b].min())           # keep it low enough to matter
+        if rng.random() < 0.5:                      # exact ties next to ties that are off by an ulp or two (the masked
+            for k in rng.choice(np.arange(a, b), max(1, (b - a) // 4), replace=False):   # columns of an NCC volume)
+                h[k] = _ulps(h[k], int(rng.integers(-2, 3)))
     elif kind == "vtrunc":
         s = int(rng.integers(0, K)); h[s] = 0.0; h[np.arange(K) != s] += 1.0
         t = int(rng.integers(0, K))
