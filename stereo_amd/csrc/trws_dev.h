@@ -849,6 +849,8 @@ __device__ __forceinline__ bool message_quad_fast(double lambda, int K, double a
 
 constexpr int kMaxSlots = TrwsGraph::kMaxSlots;
 constexpr int kSpinLimit = 1 << 22;  // polls before a wait INSIDE a workgroup (LDS flags) gives up
+constexpr int kCoopSpinLimit = 1 << 24;  // ... before a wave stops waiting for its partner's half of a message (a bug, not a state: the
+                                         // partner runs the same code on the same inputs); the result is then wrong and the parity tests say so
 
 // Waiting for ANOTHER workgroup -- with row strips possibly another process on another GPU, whose
 // launch may start late -- is bounded by wall-clock time (DevParams::spin_ticks of the 100 MHz
@@ -1134,6 +1136,40 @@ __device__ __forceinline__ double envelope_value(const DevParams &p, double alph
   return c < vtrunc ? c : vtrunc;
 }
 
+// Two waves, one message (trws_pipe_kernel, shared positions).  The reference's neighbourhood holds every pair of
+// pixels as TWO directed edges; with equal weights and one positions vector both carry the same message (same Di,
+// same gamma, same old message by induction from zero), so the second wave of such a pair -- on another SIMD --
+// takes half of the useful-source loop (or the window loop while the first sorts the tangency keys) instead of
+// computing the same message again.  Everything up to the loop is computed by both (same inputs: same bits, same
+// decisions, hence no coordination), the second wave leaves its partial minima / match counts in LDS behind a flag,
+// the first combines, judges the certificate, falls back to the serial construction if it must, and writes both rows.
+// The visit's barrier separates one exchange from the next.
+struct CoopPart {
+  int part = 0;             // 0: the wave that finishes the message, 1: its helper
+  int nparts = 1;           // 1: no cooperation
+  double *xd = nullptr;     // exchange area in LDS of the PAIR: [0..63] m1, [64..127] m2, then 64 ints of match counts
+  int *flag = nullptr;      // the helper's flag word
+  int seq = 0;              // what the flag must show for this exchange
+};
+__device__ __forceinline__ void coop_publish(const CoopPart &c, double m1, double m2, int cnt, int lane) {
+  c.xd[lane] = m1; c.xd[kWave + lane] = m2; ((int *)(c.xd + 2 * kWave))[lane] = cnt;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_store(c.flag, c.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// (the second smallest DISTINCT cost of the union: the part whose minimum is the overall minimum contributes its
+//  second smallest, the other its minimum)
+__device__ __forceinline__ void coop_collect(const CoopPart &c, double &m1, double &m2, int &cnt, int lane) {
+  int spins = 0;
+  while (__hip_atomic_load(c.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != c.seq && ++spins < kCoopSpinLimit) { }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const double b1 = c.xd[lane], b2 = c.xd[kWave + lane];
+  cnt += ((const int *)(c.xd + 2 * kWave))[lane];
+  const double lo = min_raw(m1, b1);
+  const double ca = m1 > lo ? m1 : m2, cb = b1 > lo ? b1 : b2;
+  m2 = min_raw(ca, cb);
+  m1 = lo;
+}
+
 // Second look at a certificate whose tangency test found a cone within delta of an arm of a useful cone j
 // (shared strictly ascending positions: lane t = destination t = cone t).  One kind of tangency is decided, not
 // ambiguous: cone t's apex EXACTLY on the RIGHT arm of an earlier cone j -- fl(alpha |t - q_j| + h_j) == h_t, the
@@ -1180,7 +1216,8 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
                                                double qsrc, double t, const uint16_t *perm,
                                                double &outmsg, int lane, double *hq = nullptr,
                                                int window = -1, int *look_streak = nullptr,
-                                               unsigned long long *vprof = nullptr, int perm_here = -1) {
+                                               unsigned long long *vprof = nullptr, int perm_here = -1,
+                                               const CoopPart coop = CoopPart()) {
   const double inf = __builtin_huge_val();
   const bool act = lane < K;
 #ifdef STEREO_HIP_VISIT_PROFILE
@@ -1196,6 +1233,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
   double hmin = h, mag = act ? fabs(h) + fabs(aq) + alpha * fabs(t) : 0.0;  // inactive lanes hold h = +inf
   wave_min_max_dpp(hmin, mag);
   double out, vmin;
+  if (coop.part && (UNI(alpha == 0) || KERNEL != 1 || !p.certificate)) { outmsg = 0; return 0; }   // (nothing there is shared)
   if (UNI(alpha == 0)) {
     out = hmin; vmin = hmin;  // typeStereoLinear.h:390-396
   } else {
@@ -1271,6 +1309,21 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
     asm("v_cmp_le_f64_e64 vcc, |%1|, %2\n\ts_nop 1\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc" \
         : "+v"(cnt) : "v"(dc), "v"(delta) : "vcc");                                  \
   }
+        // (two waves: only worth the exchange with more than eight sources; the helper takes the upper half)
+        const bool split = coop.nparts > 1 && nuse > 8;
+        if (split) {
+          const int half = ((nuse + 7) >> 3) << 2;   // a multiple of four >= nuse / 2
+          const int i0 = coop.part ? half : 0, i1 = coop.part ? nuse : half;
+          for (int i = i0; i < i1; i += 4) {
+            const double h0 = hq[2 * i], q0 = hq[2 * i + 1], h1 = hq[2 * i + 2], q1 = hq[2 * i + 3];
+            const double h2 = hq[2 * i + 4], q2 = hq[2 * i + 5], h3 = hq[2 * i + 6], q3 = hq[2 * i + 7];
+            STEREO_ACC_C(h0, q0) STEREO_ACC_C(h1, q1) STEREO_ACC_C(h2, q2) STEREO_ACC_C(h3, q3)
+          }
+          if (coop.part) { coop_publish(coop, m1, m2, cnt, lane); outmsg = 0; return 0; }
+          coop_collect(coop, m1, m2, cnt, lane);
+        } else if (coop.part) {
+          outmsg = 0; return 0;   // (nothing to share: the first wave does it alone)
+        } else
         if (nuse <= 8) {
           // (up to eight sources -- nearly every message of a noisy volume --: all eight entries are
           //  requested together, one LDS latency instead of one per trip)
@@ -1298,6 +1351,8 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
       // eight v_readlane); two sources per trip keep two independent dependency chains in flight.
       // m1 / m2 = smallest and second smallest DISTINCT cost seen so far.
       // table entry of a source: (h, q, u, v) -- the tangency test then needs no arithmetic on the source
+      const bool flat = window >= 0 && __builtin_popcountll(mask) > 32;
+      if (coop.part && !flat) { outmsg = 0; return 0; }   // (the masked loop is not shared: the first wave does it alone)
       if (hq) {
         hq[4 * lane] = h; hq[4 * lane + 1] = qsrc; hq[4 * lane + 2] = ui; hq[4 * lane + 3] = vi;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1324,7 +1379,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
 #ifdef STEREO_HIP_MESSAGE_PROFILE
       if (p.prof && lane == 0) { const int nu_ = __builtin_popcountll(mask); atomicAdd(p.prof + 56 + (nu_ > 32 ? 3 : nu_ > 16 ? 2 : nu_ > 8 ? 1 : 0), 1ull); }
 #endif
-      if (window >= 0 && __builtin_popcountll(mask) > 32) {
+      if (flat) {
         // Flat h (the zig-zag rows: gamma = 1/6 .. 1/8 makes almost every source useful) on shared
         // strictly ascending positions.  The pair loop below would be K^2; instead
         //  * tangency for ALL pairs by sorting u and v (conservative superset of the useful pairs):
@@ -1332,6 +1387,19 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
         //    tested as "within delta / resolution + 2 units";
         //  * min-plus only over the sources inside the truncation window of each destination (a source
         //    farther than lambda costs >= vTrunc exactly); the table is padded with +inf entries.
+        // (two waves: the helper walks the window while the first wave sorts the keys)
+        if (coop.part) {
+          for (int d = -window; d <= window; ++d) {
+            const double hj = hq[4 * (lane + d)], qj = hq[4 * (lane + d) + 1];
+            const double c = pair_cost<1>(alpha, t - qj, hj);
+            const double lo = min_raw(m1, c), hi = max_raw(m1, c);
+            m2 = min_raw_if(hi > lo, m2, hi);
+            m1 = lo;
+          }
+          coop_publish(coop, m1, m2, 0, lane);
+          outmsg = 0;
+          return 0;
+        }
         const double hmax = wave_max_dpp(act ? h : -inf);
         const double ap0 = alpha * p.pos_first, ap1 = alpha * p.pos_last;
         const double aplo = min_raw(ap0, ap1), aphi = max_raw(ap0, ap1);
@@ -1353,6 +1421,10 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
         if (UNI(act & tangent) && !UNI(act & bad) && alpha * p.pos_gap > 2 * delta)
           tangent = harmless_ties_only(alpha, h, t, delta, useful, hq, 4, 0, mask);
         bad = bad || tangent;
+        if (coop.nparts > 1) {
+          int none = 0;
+          coop_collect(coop, m1, m2, none, lane);
+        } else
         for (int d = -window; d <= window; ++d) {
           const double hj = hq[4 * (lane + d)], qj = hq[4 * (lane + d) + 1];
           const double c = pair_cost<1>(alpha, t - qj, hj);
@@ -1474,6 +1546,7 @@ constexpr int kScalDoubles = 16;                  // newv[8], node_vmin, prim_e,
 constexpr int kPipePad = 16;                      // source tables are padded by this many (+inf) entries on both sides
 constexpr int kPipeScr = 66;                      // doubles of scratch behind a wave's table: 129 ints of build_envelope_parallel
 constexpr int kPipeTab = 4 * (kWave + 2 * kPipePad) + kPipeScr;  // doubles per compute wave: (h, q, u, v) x 96 + scratch
+constexpr int kPipeXchg = 2 * kWave + kWave / 2;  // doubles of a helper's exchange area: m1[64], m2[64], 64 ints (CoopPart)
 
 __device__ __forceinline__ int group_strip(const GroupArgs &ga) {
   int s = 0;

@@ -491,6 +491,26 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
         for (int k = nout; k < nout + nin && k < 8; ++k)
           if (D[12 + k] < 0) fetch |= 1u << k;
         D[kDescFetch] = (int32_t)fetch;
+        // twins: outgoing messages k and k' that go to the SAME neighbour (the reference's neighbourhood holds every
+        // pair of pixels as two directed edges, dispmap_super.m:279-302, and the orientation step turns both the same
+        // way): nibble k of word 56 = k' (k itself without a twin).  Pairs only, mutual; what makes twins carry the same
+        // message -- equal weights, shared positions, equal old messages -- is the kernel's to check at run time.
+        uint32_t twin = 0;
+        {
+          int tw[8];
+          for (int k = 0; k < 8; ++k) tw[k] = k;
+          for (int k = 0; k < nout && k < 8; ++k) {
+            if (tw[k] != k) continue;
+            const int32_t ek = oidx[optr[r] + k];
+            const int32_t to_k = d == 0 ? g.head[ek] : g.tail[ek];
+            for (int k2 = k + 1; k2 < nout && k2 < 8; ++k2) {
+              const int32_t e2 = oidx[optr[r] + k2];
+              if (tw[k2] == k2 && (d == 0 ? g.head[e2] : g.tail[e2]) == to_k) { tw[k] = k2; tw[k2] = k; break; }
+            }
+          }
+          for (int k = 0; k < 8; ++k) twin |= (uint32_t)tw[k] << (4 * k);
+        }
+        D[kDescTwin] = (int32_t)twin;
       }
       };
       {

@@ -111,6 +111,8 @@ constexpr int kDescPeerEdge = 45, kDescPeerNode = 53;
 //            the other end was not visited one or two steps earlier in the same run, so a loader fetches the row (and
 //            that node's label) behind the node's completion flag
 constexpr int kDescFetch = 55;
+//   word 56: nibble k: the outgoing message that goes to the same neighbour as outgoing message k (k itself: none)
+constexpr int kDescTwin = 56;
 
 // Strip-local storage.  A strip keeps arrays only for what it touches: its own nodes, the nodes
 // one edge away (whose flags it waits on and whose labels its primal pass reads), and the edges

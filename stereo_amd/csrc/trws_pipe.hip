@@ -39,6 +39,8 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
   int *dring = ctl + 4;                                   // the last three descriptors (the storer's comes from here, not from HBM)
   double *zrow = (double *)(dring + 3 * kWave);           // 64 zeros: where the Di loop finds the message rows a node does not have
   double *gtab = zrow + kWave;                            // gtab[k] = (double)1 / (double)k, k = 1 .. 8 (MRFEnergy.cpp:207-228), divided once
+  double *xchg = gtab + 16;                               // per compute wave (as helper): partial minima and match counts of a shared message
+  int *xflag = (int *)(xchg + kPipeCompute * kPipeXchg);  // ... and the flag behind them (CoopPart, trws_dev.h)
   const int K = p.K;
   const double inf = __builtin_huge_val();
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -53,6 +55,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
   if (tid == 0) ctl[1] = 0;
   if (tid < kWave) zrow[tid] = 0.0;
   if (tid < 16) gtab[tid] = (double)1 / (double)(tid > 0 ? tid : 1);
+  if (tid < kPipeCompute) xflag[tid] = 0;
   // A visit is bound by the instructions the CU's four SIMDs issue for all twelve waves (~4400 per visit
   // before round 4, 45 % of them scalar), so the service waves are written branch-poor: no exec-mask region
   // per row -- a lane beyond the last label works on label K - 1 again (loads read an element that exists,
@@ -144,12 +147,17 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           const int f = __builtin_amdgcn_readfirstlane(sti[2]);
           const int nout = f & 15, md = (f >> 16) & 255;
           const int myrow = sti[72 + (lane & 7)];  // LDS offsets (doubles) of the node's message rows, from the loader
+          const unsigned twins = SHARED ? (unsigned)__builtin_amdgcn_readfirstlane(sti[kDescTwin]) : 0x76543210u;
           VSTAMP(0);
           if (wave < nout || (BACKWARD && wave == 0)) {  // waves without a message stay out of the way
           double Di = act ? st[kStD + lane] : 0.0;
           // (this wave's own old message is one of the rows; it is read once more below rather than
           //  picked out of the loop with eight selects)
           const double mown = st[kStM + (wave < nout ? wave : 0) * kWave + lane];
+          // (the twin's old message and the two weights are requested here, with the rows below: one LDS latency)
+          const int partner = wave < nout ? (int)((twins >> (4 * wave)) & 15u) : wave;
+          const double m_tw = st[kStM + (partner < 8 ? partner : 0) * kWave + lane];
+          const double alpha_me = st[kStA + (wave < nout ? wave : 0)], alpha_tw = st[kStA + (partner < 8 ? partner : 0)];
           // (all eight rows are requested together and added in list order; a row the node does not have
           //  is the zero row -- x + 0.0 == x --, so nothing here branches on the node's degree and the
           //  reads share one LDS latency instead of paying one each)
@@ -185,7 +193,17 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
                 const int e = __builtin_amdgcn_readfirstlane(sti[4 + j]);
                 perm = (src_is_qprim ? p.perm_qp : p.perm_q) + (size_t)e * Kv;
               }
-              const double alpha = st[kStA + j];
+              const double alpha = alpha_me;
+              // a twin -- the node's other message to the same neighbour -- with the same weight and the same old
+              // message is the same message: one wave finishes it, the other takes half of its loop (CoopPart)
+              CoopPart cp;
+              if (SHARED && KERNEL == 1 && partner != j) {
+                if (alpha_tw == alpha && !UNI(act && mown != m_tw)) {
+                  const int helper = j > partner ? j : partner;
+                  cp.nparts = 2; cp.part = j > partner ? 1 : 0;
+                  cp.xd = xchg + helper * kPipeXchg; cp.flag = xflag + helper; cp.seq = pos + 1;
+                }
+              }
               VSTAMP(2);
               double newm = 0;
               const double v = message_regs<KERNEL, SHARED>(p, Kv, alpha, h, qsrc, qdst, perm, newm, lane,
@@ -195,10 +213,16 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
 #else
                                                     , nullptr
 #endif
-                                                    , perm_shared);
+                                                    , perm_shared, cp);
               VSTAMP(3);
-              hcur[j * kWave + lane] = newm;   // (lanes beyond K fill the row's padding)
-              if (BACKWARD && lane == 0) sc[j] = v;
+              if (!cp.part) {
+                hcur[j * kWave + lane] = newm;   // (lanes beyond K fill the row's padding)
+                if (BACKWARD && lane == 0) sc[j] = v;
+                if (cp.nparts > 1) {
+                  hcur[partner * kWave + lane] = newm;
+                  if (BACKWARD && lane == 0) sc[partner] = v;
+                }
+              }
             }
           }
           }
@@ -440,7 +464,8 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_group_kernel(GroupArgs
 }  // namespace
 
 size_t pipe_lds_bytes() {
-  return sizeof(double) * (2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * kPipeTab + 2 + 3 * kWave / 2 + kWave + 16);
+  return sizeof(double) * (2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * kPipeTab + 2 + 3 * kWave / 2 + kWave + 16 +
+                         kPipeCompute * kPipeXchg + kPipeCompute / 2);
 }
 int pipe_threads() { return kPipeThreads; }
 

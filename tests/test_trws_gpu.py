@@ -198,7 +198,7 @@ def test_named_workload_ncc_volume_full_size_matches_oracle(source, hip, oracle)
     q = np.tile(pos, (E, 1))
     ref = oracle.trws(1, unary, conn, q, q, np.ones(E), 8.0, iters, -1e300, mode=1)
     assert plan.path() == 2
-    assert serial > 0.001 * 2 * E * iters, "only %d messages took the serial construction" % serial   # (1 % of them before round 5's exact-tie rule, 0.17 % since)
+    assert serial > 0.0005 * 2 * E * iters, "only %d messages took the serial construction" % serial   # (1 % of them before round 5's exact-tie rule, 0.17 % since -- counted once per pair of twin messages)
     assert np.array_equal(lab, ref[0]), "labels differ at %d nodes" % int((lab != ref[0]).sum())
     assert en == ref[1] and lb == ref[2] and it == ref[3]
 
