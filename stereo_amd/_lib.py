@@ -46,8 +46,9 @@ def lib():
         L.stereo_trws_plan_destroy.restype = None
         L.stereo_rd_plan_destroy.restype = None
         L.stereo_fusion_destroy.restype = None
-        L.stereo_trws_cache_clear.restype = None
-        L.stereo_rd_cache_clear.restype = None
+        for name in ("stereo_trws_cache_clear", "stereo_rd_cache_clear"):
+            if hasattr(L, name):   # (an older build loaded through STEREO_HIP_LIB for an A/B timing lacks them)
+                getattr(L, name).restype = None
         _lib = L
         # one-time runtime initialisation now, not inside the first solver call: it consumes libc
         # rand() values, which QPBO Improve draws its permutation from (see stereo_hip_warm_up)

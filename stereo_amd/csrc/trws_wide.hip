@@ -66,7 +66,7 @@ constexpr int kWStage = kWStS + kWS;  // ints: desc[64] px[8] row[8] inrow[8] (i
 
 struct WidePtrs {
   double *stage0, *hand, *scr, *fb, *pos, *scal, *zrow;
-  int *dring, *ctl;
+  int *dring, *ctl, *xflag;
 };
 __device__ __forceinline__ WidePtrs wide_carve(double *lds) {
   WidePtrs w;
@@ -78,10 +78,11 @@ __device__ __forceinline__ WidePtrs wide_carve(double *lds) {
   w.scal = w.pos + kWS;                      // 2 * kScalDoubles
   w.dring = (int *)(w.scal + 2 * kScalDoubles);  // 3 * 64 descriptor words (for the storer)
   w.ctl = w.dring + 3 * 64;                  // [0] run, [1] abort, [2] lock of the serial scratch
-  w.zrow = (double *)(w.ctl + 4);            // kWS zeros: the incoming rows a node does not have
+  w.xflag = w.ctl + 4;                       // kWideCompute flag words of the twin exchange (CoopPart, trws_dev.h)
+  w.zrow = (double *)(w.ctl + 4 + kWideCompute);   // kWS zeros: the incoming rows a node does not have
   return w;
 }
-constexpr int kWideLdsDoubles = 2 * kWStage + 3 * 8 * kWS + kWideCompute * kWScr + 4 * kWS + kWS + 2 * kScalDoubles + 96 + 2 + kWS;
+constexpr int kWideLdsDoubles = 2 * kWStage + 3 * 8 * kWS + kWideCompute * kWScr + 4 * kWS + kWS + 2 * kScalDoubles + 96 + 2 + kWideCompute / 2 + kWS;
 static_assert(kWideLdsDoubles * 8 <= 160 * 1024, "wide kernel LDS");
 
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
@@ -210,6 +211,33 @@ __device__ __forceinline__ bool useful_cone_ties(const unsigned long long (&um)[
   return matches != 2 * mine;
 }
 
+// Exchange of a twin pair (CoopPart in trws_dev.h, four labels per lane here): the helper leaves its partial minima,
+// second minima (equal costs of two cones count twice in this kernel) and match count in ITS OWN scratch behind a flag.
+__device__ __forceinline__ void wide_publish(double *xd, int *flag, int seq, const double (&m1)[4], const double (&m2)[4],
+                                             int matches, int lane) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { xd[c * kWave + lane] = m1[c]; xd[(4 + c) * kWave + lane] = m2[c]; }
+  if (lane == 0) ((int *)(xd + 8 * kWave))[0] = matches;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void wide_collect(const double *xd, int *flag, int seq, double (&m1)[4], double (&m2)[4], int &matches,
+                                             int lane) {
+  int spins = 0;
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != seq && ++spins < kCoopSpinLimit) { }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  double b1[4], b2[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { b1[c] = xd[c * kWave + lane]; b2[c] = xd[(4 + c) * kWave + lane]; }
+  matches += __builtin_amdgcn_readfirstlane(((const int *)(xd + 8 * kWave))[0]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const double lo = min_raw(m1[c], b1[c]), hi = max_raw(m1[c], b1[c]);
+    m2[c] = min_raw(hi, min_raw(m2[c], b2[c]));
+    m1[c] = lo;
+  }
+}
+
 template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE>
 __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -228,6 +256,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
   const double ustep = p.uniform_step;
   const bool uniform = ustep != 0;
   if (tid == 0) { L.ctl[1] = 0; L.ctl[2] = 0; }
+  if (tid < kWideCompute) L.xflag[tid] = 0;
   for (int k = tid; k < kWS; k += kWideThreads) L.zrow[k] = 0.0;
 #define WPOS(c) (L.pos[(c) * kWave + lane])        // this lane's four label positions (+inf beyond K)
 #define WVALID(c) ((c) * kWave + lane < K)
@@ -292,6 +321,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           const int nout = f & 15, nin = (f >> 4) & 15;
           const bool fast_msg = p.certificate != 0;
           const bool working = j0 < nout;
+          const unsigned twins = (unsigned)__builtin_amdgcn_readfirstlane(sti[kDescTwin]);
           if (working || (BACKWARD && wave == 0)) {
             double di[4] = {inf, inf, inf, inf};
             {
@@ -341,11 +371,37 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
               const double gamma = st[kWStG];  // (double)1 / (double)max(n_out, n_in)
               const double alpha = st[kWS + 8 * kWS + j];
               const bool constant = UNI(alpha == 0);
+              // Twin messages (trws_dev.h CoopPart): the node's other message to the same neighbour, with the same weight
+              // and the same old message, IS this message -- the lower-numbered wave finishes it and writes both rows,
+              // the other one takes every second useful cone (or the window loop while the first tests the keys).
+              // (one scalar word: bit 0 sharing, bit 1 this wave is the helper, bits 4-7 the twin's number -- everything else
+              //  is derived where it is used: more live scalars across this routine end up spilled into VGPR lanes)
+              int coopw = (int)((twins >> (4 * j)) & 15u) << 4;
+              // (this message's old row and its twin's are requested together, compared without branches, and the old row
+              //  is used for H below: one LDS latency, a dozen instructions)
+              double mold[4];
+              {
+                const int tw = (coopw >> 4) < kWideCompute ? (coopw >> 4) : j;
+                double mtw[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { mold[c] = st[kWS + j * kWS + c * kWave + lane]; mtw[c] = st[kWS + tw * kWS + c * kWave + lane]; }
+                const double alpha_tw = st[kWS + 8 * kWS + tw];
+                bool differ = alpha_tw != alpha;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) differ = differ | (WVALID(c) & (mtw[c] != mold[c]));
+                const bool may = KERNEL == 1 && fast_msg && !p.lean && !constant && tw != j && nout <= kWideCompute && !(p.debug & 8192);   // (development switch 8192: no twins)
+                if (may && !UNI(differ)) coopw |= 1 | (j > tw ? 2 : 0);
+              }
+#define coop_n ((coopw & 1) + 1)
+#define coop_part ((coopw >> 1) & 1)
+#define partner (coopw >> 4)
+#define xd (L.scr + (j > partner ? j : partner) * kWScr)      /* the helper's own scratch: m1[4][64], m2[4][64], one int */
+#define xfl (L.xflag + (j > partner ? j : partner))
               double h[4], hmin, hmax;
               {
                 double hlo = inf, hhi = -inf;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) h[c] = gamma * di[c] - st[kWS + j * kWS + c * kWave + lane];
+                for (int c = 0; c < 4; ++c) h[c] = gamma * di[c] - mold[c];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                   hlo = min_raw(hlo, WVALID(c) ? h[c] : inf); hhi = max_raw(hhi, WVALID(c) ? h[c] : -inf);
@@ -576,6 +632,36 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                   for (int c = 0; c < 4; ++c) { m1[c] = (double)m1f[c]; m2[c] = (double)m2f[c] + (double)df * 4; }
                   bad = false; (void)matches;   // (no serial fallbacks in the measurement: fp32 cannot decide the certificate)
 #else
+                  // (two waves: every second cone each, from three cones on -- an exchange costs about one cone)
+                  const bool split = coop_n > 1 && nuse > ((p.debug & 4096) ? 1000 : 2);   // (development switch 4096: twins found, nothing shared)
+                  if (wprof) { pacc[6] += split ? 1000 : 0; pacc[7] += coop_n > 1 ? 1000 : 0; pacc[8] += 1000ull * nuse; }   // (development profile: per mille of wave 0's messages)
+                  if (coop_part && !split) continue;   // (nothing to share: the first wave does it alone)
+                  if (split) {
+                    // (its own copy of the loop: the one below keeps the shape the compiler schedules best)
+                    int turn = 0;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                      unsigned long long mk = um[c];
+                      while (mk) {
+                        const int l = __builtin_ctzll(mk);
+                        mk &= mk - 1;
+                        const bool skip = turn != coop_part;
+                        turn ^= 1;
+                        if (skip) continue;
+                        const double hi = readlane_f64(h[c], l), qi = readlane_f64(pq[c], l);
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) {
+                          const double cst = pair_cost<1>(alpha, pq[cc] - qi, hi);
+                          const double lo_ = min_raw(m1[cc], cst), hi_ = max_raw(m1[cc], cst);
+                          m2[cc] = min_raw(m2[cc], hi_);
+                          m1[cc] = lo_;
+                          matches += __builtin_popcountll(__builtin_amdgcn_ballot_w64(fabs(cst - h[cc]) <= delta));
+                        }
+                      }
+                    }
+                    if (coop_part) { wide_publish(xd, xfl, pos + 1, m1, m2, matches, lane); continue; }
+                    wide_collect(xd, xfl, pos + 1, m1, m2, matches, lane);
+                  } else {
 #pragma unroll
                   for (int c = 0; c < 4; ++c) {
                     unsigned long long mk = um[c];
@@ -593,11 +679,12 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                       }
                     }
                   }
+                  }
                   bad = matches != nuse;
 #endif
                 } else {
                   bool crowded = false;
-                  {
+                  if (!coop_part) {
                     double r[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) r[c] = h[c] - alpha * pq[c];
@@ -621,6 +708,11 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                     }
                     bad = nuse > 64 || useful_cone_ties(um, 1, 0, uu, vv, delta);
                   }
+                  // (two waves: the first tests the keys, above; the helper walks the window, below)
+                  if (coop_n > 1 && !coop_part) {
+                    int none = 0;
+                    wide_collect(xd, xfl, pos + 1, m1, m2, none, lane);
+                  } else {
                   // source table (the scratch again): (h, q) pairs at index kWPad + k -- h only on uniform
                   // positions --, (+inf, 0) padding on both sides
                   double2 *mtab = (double2 *)scr + kWPad;
@@ -671,6 +763,8 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                     }
                   }
                   WSYNC();
+                  if (coop_part) { wide_publish(xd, xfl, pos + 1, m1, m2, 0, lane); continue; }
+                  }
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -727,9 +821,17 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
 #pragma unroll
               for (int c = 0; c < 4; ++c) {
                 const int k = c * kWave + lane;
-                if (c < C && k < K) hcur[j * kWS + k] = out[c] - vmin;
+                if (c < C && k < K) {
+                  hcur[j * kWS + k] = out[c] - vmin;
+                  if (coop_n > 1) hcur[partner * kWS + k] = out[c] - vmin;
+                }
               }
-              if (BACKWARD && lane == 0) sc[j] = vmin;
+              if (BACKWARD && lane == 0) { sc[j] = vmin; if (coop_n > 1) sc[partner] = vmin; }
+#undef coop_n
+#undef coop_part
+#undef partner
+#undef xd
+#undef xfl
               WSTAMP(5);
             }
           }
