@@ -93,6 +93,7 @@ constexpr int kMB = 1024;
 // [8] rounds done, [9] global relabels done
 struct QpboCtl { enum { kBar = 0, kAbort = 1, kChanged = 2, kActive = 5, kRounds = 8, kRelabels = 9, kWords = 16 }; };
 constexpr int kGridSpinLimit = 1 << 24;
+constexpr int kImproveBlocks = 64;    // workgroups of an Improve launch (see QpboSolver::maxflow)
 // -DSTEREO_HIP_QPBO_PROFILE: workgroup 0 adds up where its time goes (10 ns ticks and event counts in
 // counters[1200 ..], printed with STEREO_HIP_QPBO_VERBOSE): relabelling = init pass | tile set-up | tile
 // relaxation | grid barriers; tiled rounds = tile load | local rounds | store | grid barriers
@@ -1542,6 +1543,14 @@ struct QpboSolver {
     if (per_cu < 1) throw HipError{"qpbo_maxflow_kernel does not fit on a CU"};
     int blocks = std::min(cus * std::min(per_cu, 2), std::max(g.ntiles, 1));
     blocks = std::max(blocks, 1);
+    // The Improve loop is thousands of tiny steps, each a handful of grid barriers over a few touched tiles: its cost is
+    // the barrier, which grows with the number of workgroups that meet there (swept on the Teddy pair's example_global
+    // moves, tools/sweep_qpbo.sh).  STEREO_HIP_QPBO_IMPROVE_BLOCKS overrides.
+    if (improve_perm) {
+      int ib = kImproveBlocks;
+      if (const char *e = std::getenv("STEREO_HIP_QPBO_IMPROVE_BLOCKS")) ib = std::max(1, std::atoi(e));
+      blocks = std::min(blocks, ib);
+    }
     QpboDev gg = g;
     int32_t *ctl = d_ctl.p;
     int max_rounds = 1 << 21;
