@@ -22,8 +22,8 @@ void launch_pipe_group(int kernel, bool shared, int what, int blocks, hipStream_
 
 size_t pipe2_lds_bytes();
 void pipe2_set_attributes();
-void launch_pipe2(bool shared, int what, int blocks, hipStream_t s, const DevParams &p, int epoch);
-void launch_pipe2_group(bool shared, int what, int blocks, hipStream_t s, const GroupArgs &ga, int epoch);
+void launch_pipe2(int kernel, bool shared, int what, int blocks, hipStream_t s, const DevParams &p, int epoch);
+void launch_pipe2_group(int kernel, bool shared, int what, int blocks, hipStream_t s, const GroupArgs &ga, int epoch);
 
 size_t wide_lds_bytes();
 void wide_set_attributes();

@@ -1,5 +1,5 @@
-// TRW-S pipelined sweep kernel for 64 < K <= 128 with per-edge positions (two labels per lane), linear
-// kernel.  Part of libstereo_hip.so; overview in trws_plan.hip.
+// TRW-S pipelined sweep kernel for 64 < K <= 128 with per-edge positions (two labels per lane), both smoothness
+// kernels (the quadratic one since round 5).  Part of libstereo_hip.so; overview in trws_plan.hip.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -28,7 +28,7 @@ constexpr int k2Fb = 5 * (k2W + 2);                 // serial scratch per comput
 constexpr int k2LdsDoubles = 2 * k2Stage + 4 * 8 * k2W + 2 * kScalDoubles + kPipeCompute * 4 * k2W + kPipeCompute * k2Fb + 2;
 static_assert(k2LdsDoubles * 8 <= 160 * 1024, "pipe2 kernel LDS");
 
-template <bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
+template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
 __device__ __forceinline__ void pipe2_body(DevParams p, int epoch) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double *stage0 = lds;                                   // 2 stages
@@ -131,7 +131,59 @@ __device__ __forceinline__ void pipe2_body(DevParams p, int epoch) {
                   const double vtrunc = hmin + alpha * p.lambda;
                   bool need_serial = p.certificate == 0;
                   out[0] = out[1] = vtrunc;
-                  if (!need_serial) {
+                  if (!need_serial && KERNEL == 2) {
+                    // ---- truncated QUADRATIC kernel (typeStereoQuadratic.h:329-501): the hull-slope certificate of
+                    // message_quad_fast (trws_dev.h) on two labels per lane, per-edge positions -- plain min-plus over the
+                    // useful parabolas, smallest and second smallest cost per destination (equal costs of two sources count),
+                    // gap = distance from a useful source to the nearest other source, Q = span of the source positions.
+                    double sc2 = 0, qlo = inf, qhi = -inf;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                      if (act[c]) {
+                        sc2 = max_raw(sc2, fabs(h[c]) + alpha * qsrc[c] * qsrc[c] + alpha * qdst[c] * qdst[c]);
+                        qlo = min_raw(qlo, qsrc[c]); qhi = max_raw(qhi, qsrc[c]);
+                      }
+                    }
+                    sc2 = wave_max_dpp(sc2);
+                    wave_min_max_dpp(qlo, qhi);
+                    const double delta = 1e-9 * (sc2 + fabs(alpha * p.lambda) + fabs(vtrunc));
+                    double *tab = tabs + wave * 4 * k2W;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) { tab[4 * kk[c]] = h[c]; tab[4 * kk[c] + 1] = qsrc[c]; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    double m1[2] = {inf, inf}, m2[2] = {inf, inf};
+                    double gap = inf;
+                    asm volatile("" : "+v"(gap));   // (not a wave-uniform constant: see message_quad_fast)
+#pragma unroll
+                    for (int cs = 0; cs < 2; ++cs) {
+                      unsigned long long mask = __builtin_amdgcn_ballot_w64(act[cs] && h[cs] < vtrunc);
+                      while (mask) {
+                        const int js = __builtin_ctzll(mask) + cs * kWave;
+                        mask &= mask - 1;
+                        const double hj = tab[4 * js], qj = tab[4 * js + 1];
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                          const double cst = pair_cost<2>(alpha, qdst[c] - qj, hj);
+                          const double lo = min_raw(m1[c], cst), hi = max_raw(m1[c], cst);
+                          m2[c] = min_raw(m2[c], hi);
+                          m1[c] = lo;
+                          gap = min_raw_if(act[c] && kk[c] != js, gap, fabs(qsrc[c] - qj));
+                        }
+                      }
+                    }
+                    gap = wave_min_dpp(gap);
+                    bool bad = !(delta < inf) || !(alpha > 0) || !(gap > 4e-8);
+                    bad = bad || !(1e-13 * sc2 * (qhi - qlo) < delta * gap);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                      bad = bad || (act[c] && m1[c] < vtrunc && !(m2[c] - m1[c] > delta && vtrunc - m1[c] > delta));
+                      out[c] = m1[c] < vtrunc ? m1[c] : vtrunc;
+                    }
+                    need_serial = UNI(bad);
+                    if (need_serial && lane == 0 && p.fallbacks) atomicAdd(p.fallbacks, 1);
+                  }
+                  if (!need_serial && KERNEL == 1) {
                     double ui[2], vi[2], mg = 0;
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
@@ -212,7 +264,7 @@ __device__ __forceinline__ void pipe2_body(DevParams p, int epoch) {
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    if (lane == 0) build_envelope<1>(K, alpha, A, B, sh, sq, z);
+                    if (lane == 0) build_envelope<KERNEL>(K, alpha, A, B, sh, sq, z);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -220,7 +272,7 @@ __device__ __forceinline__ void pipe2_body(DevParams p, int epoch) {
                       if (act[c]) {
                         int jj = 0;
                         while (z[jj + 1] < qdst[c]) ++jj;
-                        const double cst = pair_cost<1>(alpha, qdst[c] - sq[jj], sh[jj]);
+                        const double cst = pair_cost<KERNEL>(alpha, qdst[c] - sq[jj], sh[jj]);
                         out[c] = cst < vtrunc ? cst : vtrunc;
                       }
                     }
@@ -363,7 +415,7 @@ __device__ __forceinline__ void pipe2_body(DevParams p, int epoch) {
                     const double qvk = st[k2StQ + j * k2W + kk[c]], qpk = st[k2StQP + j * k2W + kk[c]];
                     d = mdj == 0 ? st[k2StQP + j * k2W + ks] - qvk : qpk - st[k2StQ + j * k2W + ks];
                   }
-                  const double v = fabs(d);
+                  const double v = KERNEL == 1 ? fabs(d) : d * d;
                   db[c] += aj * (v < p.lambda ? v : p.lambda);
                 }
               }
@@ -404,15 +456,15 @@ __device__ __forceinline__ void pipe2_body(DevParams p, int epoch) {
   }
 }
 
-template <bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
+template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
 __global__ __launch_bounds__(kPipeThreads) void trws_pipe2_kernel(DevParams p, int epoch) {
-  pipe2_body<BACKWARD, PRIMAL, UPDATE, SHARED>(p, epoch);
+  pipe2_body<KERNEL, BACKWARD, PRIMAL, UPDATE, SHARED>(p, epoch);
 }
 
 // row strips that share a device: one launch, workgroup b works for the strip group_strip() names
-template <bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
+template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
 __global__ __launch_bounds__(kPipeThreads) void trws_pipe2_group_kernel(GroupArgs ga, int epoch) {
-  pipe2_body<BACKWARD, PRIMAL, UPDATE, SHARED>(ga.pp[group_strip(ga)], epoch);
+  pipe2_body<KERNEL, BACKWARD, PRIMAL, UPDATE, SHARED>(ga.pp[group_strip(ga)], epoch);
 }
 
 }  // namespace
@@ -421,38 +473,43 @@ size_t pipe2_lds_bytes() { return sizeof(double) * k2LdsDoubles; }
 
 void pipe2_set_attributes() {
   const int lds2 = (int)pipe2_lds_bytes();
-#define SET_LDS2(NAME, SH)                                                                                                            \
-  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<false, false, true, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2)); \
-  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<true, false, true, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));  \
-  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<false, true, true, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));  \
-  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<false, true, false, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2))
-  SET_LDS2(trws_pipe2_kernel, true); SET_LDS2(trws_pipe2_kernel, false);
-  SET_LDS2(trws_pipe2_group_kernel, true); SET_LDS2(trws_pipe2_group_kernel, false);
+#define SET_LDS2(NAME, KER, SH)                                                                                                            \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<KER, false, false, true, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2)); \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<KER, true, false, true, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));  \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<KER, false, true, true, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));  \
+  STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<KER, false, true, false, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2))
+  SET_LDS2(trws_pipe2_kernel, 1, true); SET_LDS2(trws_pipe2_kernel, 1, false);
+  SET_LDS2(trws_pipe2_group_kernel, 1, true); SET_LDS2(trws_pipe2_group_kernel, 1, false);
+  SET_LDS2(trws_pipe2_kernel, 2, true); SET_LDS2(trws_pipe2_kernel, 2, false);
+  SET_LDS2(trws_pipe2_group_kernel, 2, true); SET_LDS2(trws_pipe2_group_kernel, 2, false);
 #undef SET_LDS2
 }
 
 #define PIPE2_SWITCH(NAME, ARG)                                                                   \
   const size_t lds2 = pipe2_lds_bytes();                                                          \
   const dim3 grid2(blocks), block2(kPipeThreads);                                                 \
-  switch (what) {                                                                                 \
-    case 0: PIPE2(NAME, false, false, true, ARG); break;                                          \
-    case 1: PIPE2(NAME, true, false, true, ARG); break;                                           \
-    case 2: PIPE2(NAME, false, true, true, ARG); break;                                           \
-    default: PIPE2(NAME, false, true, false, ARG); break;                                         \
-  }                                                                                               \
+  if (kernel == 1) { PIPE2_4(NAME, 1, ARG) } else { PIPE2_4(NAME, 2, ARG) }                       \
   STEREO_HIP_CHECK(hipGetLastError());
-#define PIPE2(NAME, BW, PR, UP, ARG)                                                              \
+#define PIPE2_4(NAME, KER, ARG)                                                                   \
+  switch (what) {                                                                                 \
+    case 0: PIPE2(NAME, KER, false, false, true, ARG); break;                                     \
+    case 1: PIPE2(NAME, KER, true, false, true, ARG); break;                                      \
+    case 2: PIPE2(NAME, KER, false, true, true, ARG); break;                                      \
+    default: PIPE2(NAME, KER, false, true, false, ARG); break;                                    \
+  }
+#define PIPE2(NAME, KER, BW, PR, UP, ARG)                                                         \
   do {                                                                                            \
-    if (shared) hipLaunchKernelGGL((NAME<BW, PR, UP, true>), grid2, block2, lds2, s, ARG, epoch);  \
-    else hipLaunchKernelGGL((NAME<BW, PR, UP, false>), grid2, block2, lds2, s, ARG, epoch);        \
+    if (shared) hipLaunchKernelGGL((NAME<KER, BW, PR, UP, true>), grid2, block2, lds2, s, ARG, epoch);  \
+    else hipLaunchKernelGGL((NAME<KER, BW, PR, UP, false>), grid2, block2, lds2, s, ARG, epoch);        \
   } while (0)
 
-void launch_pipe2(bool shared, int what, int blocks, hipStream_t s, const DevParams &p, int epoch) {
+void launch_pipe2(int kernel, bool shared, int what, int blocks, hipStream_t s, const DevParams &p, int epoch) {
   PIPE2_SWITCH(trws_pipe2_kernel, p)
 }
-void launch_pipe2_group(bool shared, int what, int blocks, hipStream_t s, const GroupArgs &ga, int epoch) {
+void launch_pipe2_group(int kernel, bool shared, int what, int blocks, hipStream_t s, const GroupArgs &ga, int epoch) {
   PIPE2_SWITCH(trws_pipe2_group_kernel, ga)
 }
+#undef PIPE2_4
 #undef PIPE2
 #undef PIPE2_SWITCH
 

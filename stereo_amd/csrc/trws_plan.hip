@@ -171,7 +171,7 @@ struct stereo_trws_plan {
   DevBuf<int32_t> d_desc[2];
   bool fast = false;
   bool wide = false;  // 64 < K <= 256 with shared strictly ascending positions: trws_wide_kernel
-  bool fast2 = false; // 64 < K <= 128, linear kernel, any positions: trws_pipe2_kernel (when not wide)
+  bool fast2 = false; // 64 < K <= 128, any positions, both smoothness kernels: trws_pipe2_kernel (when not wide)
   bool wide_allowed = false;
   bool pos_ascending = false;  // shared positions finite and strictly ascending
   double pos_first = 0, pos_last = 0, pos_gap = 0;
@@ -299,7 +299,7 @@ void launch_persistent(stereo_trws_plan *P, const DevParams &p, int what, hipStr
   const int epoch = ++P->epoch;
   STEREO_HIP_CHECK(hipMemsetAsync(P->d_ctl.p, 0, sizeof(int32_t), s));  // ticket = 0
   if (P->wide) launch_wide(P->kernel, what, std::min(P->grid_blocks, P->cus), s, p, epoch);
-  else if (P->fast2) launch_pipe2(P->pos != nullptr, what, std::min(P->grid_blocks, P->cus), s, p, epoch);
+  else if (P->fast2) launch_pipe2(P->kernel, P->pos != nullptr, what, std::min(P->grid_blocks, P->cus), s, p, epoch);
   else if (P->fast) launch_pipe(P->kernel, P->pos != nullptr, what, P->grid_blocks, s, p, epoch);
   else launch_generic(P->kernel, P->mode, what, P->grid_blocks, persistent_lds_bytes(P->Kp), s, p, epoch);
   if (what != 3) P->sweep_launches += 1;
@@ -622,7 +622,7 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
     }
     P->fast = g.fast_ok && K <= kWave && message_mode == STEREO_TRWS_MESSAGES_EXACT;
     P->wide_allowed = g.fast_ok && (kernel == 1 || message_mode == STEREO_TRWS_MESSAGES_EXACT) && K > kWave && K <= 256;
-    P->fast2 = g.fast_ok && kernel == 1 && K > kWave && K <= 2 * kWave && message_mode == STEREO_TRWS_MESSAGES_EXACT;
+    P->fast2 = g.fast_ok && K > kWave && K <= 2 * kWave && message_mode == STEREO_TRWS_MESSAGES_EXACT;   // (both smoothness kernels since round 5)
     if (const char *f = std::getenv("STEREO_HIP_TRWS_FAST")) {
       P->fast = P->fast && std::string(f) != "0";
       P->wide_allowed = P->wide_allowed && std::string(f) != "0";
@@ -1020,7 +1020,7 @@ static void launch_group(stereo_trws_plan *const *G, int n, int what, hipStream_
   }
   ga.first[n] = total;
   if (P0->wide) launch_wide_group(P0->kernel, what, total, s, ga, epoch);
-  else if (P0->fast2) launch_pipe2_group(P0->pos != nullptr, what, total, s, ga, epoch);
+  else if (P0->fast2) launch_pipe2_group(P0->kernel, P0->pos != nullptr, what, total, s, ga, epoch);
   else launch_pipe_group(P0->kernel, P0->pos != nullptr, what, total, s, ga, epoch);
   STEREO_HIP_CHECK(hipGetLastError());
 }

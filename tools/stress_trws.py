@@ -16,9 +16,13 @@ modes = {}
 while time.time() - t0 < budget:
     H, W = int(rng.integers(1, 70)), int(rng.integers(2, 70))
     K = int(rng.choice([2, 3, 5, 8, 16, 31, 60, 64, 65, 100, 200, 256]))
+    if os.environ.get("STRESS_TRWS_K"):    # e.g. STRESS_TRWS_K=65,100,128: one kernel family only
+        K = int(rng.choice([int(x) for x in os.environ["STRESS_TRWS_K"].split(",")]))
     if K > 64 and H * W > 1500:
         H, W = min(H, 30), min(W, 40)
     kernel = int(rng.choice([1, 1, 1, 2]))
+    if os.environ.get("STRESS_TRWS_KERNEL"):
+        kernel = int(os.environ["STRESS_TRWS_KERNEL"])
     shared = bool(rng.integers(0, 2))
     integer = bool(rng.integers(0, 4) == 0)
     tol = float(rng.choice([0.0, 1.5, 3.0, 8.0, 40.0]))
