@@ -91,7 +91,7 @@ struct QpboDev {
 constexpr int kMB = 1024;
 // ctl words: [0] barrier counter, [1] abort, [2..4] "changed" slots, [5..7] active-count slots,
 // [8] rounds done, [9] global relabels done
-struct QpboCtl { enum { kBar = 0, kAbort = 1, kChanged = 2, kActive = 5, kRounds = 8, kRelabels = 9, kWords = 16 }; };
+struct QpboCtl { enum { kBar = 0, kAbort = 1, kChanged = 2, kActive = 5, kRounds = 8, kRelabels = 9, kNext = 16, kWords = 20 }; };   // [16..18]: result words of the Improve search, used in turn
 constexpr int kGridSpinLimit = 1 << 24;
 constexpr int kImproveBlocks = 64;    // workgroups of an Improve launch (see QpboSolver::maxflow)
 // -DSTEREO_HIP_QPBO_PROFILE: workgroup 0 adds up where its time goes (10 ns ticks and event counts in
@@ -213,7 +213,8 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
   unsigned gen = 0;
   // (`adaptive`: bit 0 = the slow-tail test below; bits 8.. = progress, in thousandths of the active nodes per round,
   //  below which a round counts as stagnant)
-  const int stall_permille = adaptive >> 8;
+  const int adaptive_in = adaptive;
+  const int stall_permille = (adaptive >> 8) & 0x3ff;
   adaptive &= 1;
   const int n = g.n;
   const int first = blockIdx.x * kMB + threadIdx.x, stride = gridDim.x * kMB;
@@ -596,6 +597,7 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
   };
 
   int improve_from = 0, improve_steps = 0;
+  const bool no_skip_relabel = (adaptive_in >> 30) & 1;   // (development switch STEREO_HIP_QPBO_FINAL_RELABEL=1: always run the final relabelling)
   bool heights_copied = false;   // the solve that just ended wrote g.h after its last grid barrier
   bool solve = improve_perm == nullptr;   // the Improve launch starts from a maximal flow: first find a node to fix
   for (;;) {
@@ -1011,6 +1013,11 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
   }
 
   // heights may be stale lower bounds: one exact BFS defines T; leave it in g.h
+  // (unless nothing has been pushed since the last relabelling and that one was exact -- from scratch, confined, or
+  //  the warm one of an Improve step whose fixed node was cut off from the sink, where the old heights are upper
+  //  bounds: most Improve steps find nothing to push after their warm relabelling, and this second one was three of
+  //  their seven grid barriers)
+  if (!exact && since_relabel == 0 && (relabels_done > 1 || incremental == 0 || keep_valid) && !no_skip_relabel) exact = true;
   if (!exact && !global_relabel(active)) return;
   heights_copied = h != g.h;
   if (h != g.h) {
@@ -1024,48 +1031,42 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
   }  // solve
   if (!improve_perm) break;
   // ---- Improve: the next node of the permutation whose two sides are both / neither connected to the
-  // sink (not strongly labelled).  Two result words used in turn (one is cleared while the other is in
-  // use), heights in g.h are exact and written through.
+  // sink (not strongly labelled).  Heights in g.h are exact and written through.
+  //
+  // A step is TRIVIAL if its node i is cut off from the sink (height n, and so is its mate's) and no residual arc
+  // leads into the mate: fixing i hands i excess that cannot move and gives the mate a sink arc that lowers nobody
+  // but the mate itself (height 1) -- no node becomes active, the flow stays maximal; the step's warm relabelling
+  // would find exactly that in three grid barriers.  Such a step changes the terminal capacities of i and its mate
+  // and the mate's height, nothing else: it does not change which other entries of the permutation are ambiguous,
+  // nor whether their steps are trivial (heights of other variables, residuals), nor the INFTY of another node
+  // (its own terminals and arcs).  So all trivial steps in front of the first non-trivial ambiguous entry commute
+  // with each other and are applied TOGETHER, each by the thread that owns the entry, behind the one barrier of the
+  // search -- which now looks for the first NON-TRIVIAL ambiguous entry.  (99 % of the Improve steps of the Teddy
+  // pair's example_global moves are trivial: 2045 of 2071 in the longest one, 114 ms of grid barriers before.)
   {
     // (excess and sink capacities are written through wherever they are stored: nothing to write back
     // before another workgroup's thread rewrites a node's terminal capacities below)
     const int N = improve_N;
-    int32_t *word = ctl + (improve_steps & 1 ? 10 : 15), *other = ctl + (improve_steps & 1 ? 15 : 10);
+    // (three result words in turn: the one of the NEXT step is cleared before this step's barrier -- its last readers
+    //  passed the barrier of the step before)
+    int32_t *word = ctl + QpboCtl::kNext + improve_steps % 3, *other = ctl + QpboCtl::kNext + (improve_steps + 1) % 3;
     if (improve_steps == 0 && blockIdx.x == 0 && threadIdx.x == 0) { stc(word, N); stc(other, N); }   // both start at "none"
     // (every workgroup's final heights and terminal capacities are in memory: a solve ends with the grid barriers of
     // its last relabelling, so the barrier is only needed if heights were copied after them -- and in the first step,
-    // between the initialisation of the two result words and their use)
+    // between the initialisation of the result words and their use)
     if (improve_steps == 0 || heights_copied) {
       if (!grid_sync(ctl, gen)) return;
     }
+    heights_copied = false;
+    if (improve_steps > 0 && blockIdx.x == 0 && threadIdx.x == 0) stc(other, N);
     if (g.keep) {   // the starting point of this step's later relabellings (global_relabel, `confined`)
       for (int v = first; v < n; v += stride) stc(g.keep + v, ldc(g.h + v));
       for (int T = first; T < g.ntiles; T += stride) stc(g.keep + n + T, 0);   // `touched`, global_relabel
     }
-    int mine = N;
-    for (int j = improve_from + first; j < N; j += stride) {
-      const int i = improve_perm[j];
-      if ((ldc(g.h + i) < n) == (ldc(g.h + i + N) < n)) { mine = j; break; }   // (ascending j: the first one is this thread's smallest)
-    }
-    if (threadIdx.x == 0) s_red = N;
-    __syncthreads();
-    if (mine < N) atomicMin(&s_red, mine);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_red < N) __hip_atomic_fetch_min(word, s_red, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!grid_sync(ctl, gen)) return;
-    const int next = ldc(word);
-    if (next >= N) break;
-    // (the argument for `confined` needs the node that receives the excess to be cut off from the sink: "neither
-    // side connected".  The other ambiguous case, both sides connected, sends the new excess through nodes that
-    // do have a path and lengthens distances there: those steps relabel from scratch.)
-    fixed_node = improve_perm[next];
-    keep_valid = g.keep != nullptr && ldc(g.keep + fixed_node) >= n;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && g.counters) g.counters[keep_valid ? 1300 : 1301] += 1;   // (statistics: steps of either kind)
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      stc(other, N);
-      // AddUnaryTerm(i, 0, INFTY), INFTY = max(-t_i + sum of outgoing residuals, t_i + sum of incoming) + 1
-      // evaluated on node i (QPBO_extra.cpp:241-254, :1177-1187), same summation order as the reference
-      const int i = improve_perm[next], im = i + N;
+    // AddUnaryTerm(i, 0, INFTY), INFTY = max(-t_i + sum of outgoing residuals, t_i + sum of incoming) + 1
+    // evaluated on node i (QPBO_extra.cpp:241-254, :1177-1187), same summation order as the reference
+    auto fix_to_zero = [&](int i, bool trivial_step) {
+      const int im = i + N;
       const double exi = ldc(g.ex + i), ski = ldc(g.snk + i), exm = ldc(g.ex + im), skm = ldc(g.snk + im);
       const double tcap = exi - ski;
       double c1 = -tcap, c2 = tcap;
@@ -1074,17 +1075,59 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
       const double t0 = exi - ski + INFTY, t1 = exm - skm - INFTY;
       stc(g.ex + i, t0 > 0 ? t0 : 0.0); stc(g.snk + i, t0 < 0 ? -t0 : 0.0);
       stc(g.ex + im, t1 > 0 ? t1 : 0.0); stc(g.snk + im, t1 < 0 ? -t1 : 0.0);
+      if (trivial_step) {   // what the step's relabelling would leave behind (t1 < 0: the mate has a sink arc now)
+        stc(g.h + i, n); stc(g.h + im, 1);
+        if (g.hx) { stc(g.hx + i, hx_pack(n, n, 0)); stc(g.hx + im, hx_pack(1, 1, 0)); }
+        if (g.keep) { stc(g.keep + i, n); stc(g.keep + im, 1); }
+      }
+    };
+    auto is_trivial = [&](int i) -> bool {   // (i ambiguous) cut off from the sink, no residual arc into the mate
+      if (no_skip_relabel || !g.keep || ldc(g.h + i) < n) return false;
+      const int im = i + N;
+      bool t = true;
+      for (int a = g.aptr[im]; a < g.aptr[im + 1]; ++a) t = t && !(ldc(g.r + g.rev[a]) > 0);
+      return t;
+    };
+    int mine = N;
+    for (int j = improve_from + first; j < N; j += stride) {
+      const int i = improve_perm[j];
+      if ((ldc(g.h + i) < n) != (ldc(g.h + i + N) < n)) continue;
+      if (!is_trivial(i)) { mine = j; break; }   // (ascending j: the first one is this thread's smallest)
     }
+    if (threadIdx.x == 0) s_red = N;
+    __syncthreads();
+    if (mine < N) atomicMin(&s_red, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_red < N) __hip_atomic_fetch_min(word, s_red, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!grid_sync(ctl, gen)) return;
+    const int next = ldc(word);
+    // the trivial steps in front of it, all at once
+    {
+      int done = 0;
+      for (int j = improve_from + first; j < (next < N ? next : N); j += stride) {
+        const int i = improve_perm[j];
+        if ((ldc(g.h + i) < n) != (ldc(g.h + i + N) < n)) continue;
+        fix_to_zero(i, true);
+        ++done;
+      }
+      if (done && g.counters) atomicAdd(g.counters + 1302, done);   // (statistics)
+    }
+    if (next >= N) break;
+    // (the argument for `confined` needs the node that receives the excess to be cut off from the sink: "neither
+    // side connected".  The other ambiguous case, both sides connected, sends the new excess through nodes that
+    // do have a path and lengthens distances there: those steps relabel from scratch.)
+    fixed_node = improve_perm[next];
+    keep_valid = g.keep != nullptr && ldc(g.keep + fixed_node) >= n;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g.counters) g.counters[keep_valid ? 1300 : 1301] += 1;   // (statistics: steps of either kind)
+    if (blockIdx.x == 0 && threadIdx.x == 0) fix_to_zero(fixed_node, false);
     improve_from = next + 1;
     ++improve_steps;
     improve_steps_dbg = improve_steps;
     incremental = 1;   // the heights stay a valid labelling when a unary term changes: warm search
     solve = true;
-    // the new terminal capacities of the fixed node and its mate: the first reader is the relabelling's start pass --
-    // all workgroups in general, workgroup 0 alone in a `local` step (everybody else meets them behind that
-    // relabelling's own grid barriers)
-    if (keep_valid) __syncthreads();
-    else if (!grid_sync(ctl, gen)) return;
+    // the new terminal capacities -- of the fixed node and its mate, and of the trivial steps in front of it, whose
+    // mates' heights other workgroups wrote as well: everybody meets them behind a grid barrier
+    if (!grid_sync(ctl, gen)) return;
   }
   }  // for (;;)
 }
@@ -1572,6 +1615,7 @@ struct QpboSolver {
     int stall = 10;
     if (const char *e = std::getenv("STEREO_HIP_QPBO_STALL_PERMILLE")) stall = std::min(999, std::max(0, std::atoi(e)));
     adaptive |= stall << 8;
+    if (const char *e = std::getenv("STEREO_HIP_QPBO_FINAL_RELABEL")) if (std::atoi(e) != 0) adaptive |= 1 << 30;
     int improve_N = (int)P.N;
     void *args[] = {&gg, &ctl, &relabel_every, &max_rounds, &tiled, &switch_at, &incremental, &first_interval, &adaptive,
                     &improve_perm, &improve_N};
@@ -1597,10 +1641,11 @@ struct QpboSolver {
       std::fprintf(stderr, "[stereo_hip qpbo] relabels: %.3f ms, %d barriers; tiled section: %.3f ms, %d rounds\n", host_ctl[11] * 1e-5,
                    host_ctl[12], host_ctl[13] * 1e-5, host_ctl[14]);
       if (improve_perm) {
-        int32_t st[2] = {0, 0};
+        int32_t st[3] = {0, 0, 0};
         STEREO_HIP_CHECK(hipMemcpy(st, d_cnt.p + 1300, sizeof(st), hipMemcpyDeviceToHost));
         STEREO_HIP_CHECK(hipMemset(d_cnt.p + 1300, 0, sizeof(st)));
-        std::fprintf(stderr, "[stereo_hip qpbo] Improve steps: %d with the fixed node cut off from the sink (confined relabellings), %d with both sides connected\n", st[0], st[1]);
+        std::fprintf(stderr, "[stereo_hip qpbo] Improve steps: %d trivial (no residual arc into the fixed node's mate: no solve), %d with the fixed node cut off "
+                             "from the sink (confined relabellings), %d with both sides connected\n", st[2], st[0], st[1]);
       }
     }
 #ifdef STEREO_HIP_QPBO_PROFILE
