@@ -3,12 +3,14 @@
 smoothness with segment-dependent weights, QPBO with Improve) and a sweep of binary fusions over
 piecewise-planar proposals.
 
-    python examples/example_global.py [im_left.png im_right.png] [--size H W]
+    python examples/example_global.py [im_left.png im_right.png] [--size H W] [--teddy]
 
-Out of scope here: the reference's SegPln proposals come from a mean-shift
-segmentation + plane fits and its edge weights from the same segmentation; this script uses its own
-deterministic stand-ins -- block-wise random planes at several block sizes, and "same segment" =
-small colour difference across the edge.  Without images a synthetic textured pair is used.
+--teddy: the example's own input -- the Teddy pair with the edge weights of the reference's mean-shift
+segmentation and the 14 SegPln proposals on the reference's 14 segmentation maps (all from committed
+fixtures, tests/golden/teddy_pair.npz / teddy_segments.npz; the segmenters themselves stay on the host,
+SURVEY.md 8(f3)), planes fitted on the device.  Otherwise the script uses deterministic stand-ins --
+block-wise random planes at several block sizes, and "same segment" = small colour difference across
+the edge -- on the given images or, without images, on a synthetic textured pair.
 """
 import argparse
 import os
@@ -45,9 +47,28 @@ def main():
                     help="proposals = the class's SegPln proposals (dispmap_globalstereo.m:60-201: window matching, LO-RANSAC "
                          "plane per segment, on the device) over 14 colour / block segmentations standing in for the "
                          "mean-shift / Felzenszwalb maps of :122-137, instead of the random piecewise-planar stand-ins")
+    ap.add_argument("--teddy", action="store_true", help="example_global.m's own input from the committed fixtures")
     args = ap.parse_args()
     import stereo_amd
     from stereo_amd import terms as T
+    if args.teddy:
+        gold = os.path.join(ROOT, "tests", "golden")
+        g = np.load(os.path.join(gold, "teddy_pair.npz")); sg = np.load(os.path.join(gold, "teddy_segments.npz"))
+        images = [g["im0"].astype(np.float64), g["im1"].astype(np.float64)]
+        P = np.tile(np.hstack([np.eye(3), np.zeros((3, 1))])[:, :, None], (1, 1, 2)); P[0, 3, 1] = -0.25
+        t0 = time.time()
+        dm = stereo_amd.dispmap_globalstereo(images, P, (0, 59), 4, segment=sg["segment"], rng=np.random.default_rng(0))
+        print("object + random start: %.2f s, energy %.6f" % (time.time() - t0, dm.energy()))
+        t1 = time.time()
+        proposals = dm.segpln([sg["segments"][:, :, b] for b in range(14)], seed=0)
+        print("SegPln: window matching + 14 maps, %.2f s" % (time.time() - t1))
+        t0 = time.time()
+        for p in proposals:
+            e, lb, unl = dm.binary_fusion(p)
+        dt = time.time() - t0
+        print("binary fusion of %d SegPln proposals: %.3f s (%.1f moves/s), energy %.6f, last move: %d unlabelled" % (
+            len(proposals), dt, len(proposals) / dt, dm.energy(), int(unl)))
+        return
     if len(args.images) == 2:
         from PIL import Image
         images = [np.asarray(Image.open(f).convert("RGB"), dtype=np.float64) for f in args.images]

@@ -1144,26 +1144,51 @@ __device__ __forceinline__ double envelope_value(const DevParams &p, double alph
 // decisions, hence no coordination), the second wave leaves its partial minima / match counts in LDS behind a flag,
 // the first combines, judges the certificate, falls back to the serial construction if it must, and writes both rows.
 // The visit's barrier separates one exchange from the next.
+constexpr int kPipeCompute = 8;  // one compute wave per outgoing message (<= 8 per node)
+constexpr int kPipeWaves = kPipeCompute + 4;  // loader (data behind flags), storer, loader A (own data, two visits
+                                              // deep; trws_pipe_kernel only), primal
+constexpr int kPipeThreads = kPipeWaves * kWave;
+// LDS stage layout (doubles): D[64] m[8][64] qv[8][64] qpv[8][64] | a[8] gamma pad | ints: desc[64] px[8] row[8]
+constexpr int kStD = 0, kStM = 64, kStQ = 64 + 512, kStQP = 64 + 1024, kStA = 64 + 1536;
+constexpr int kStG = kStA + 8;                    // gamma = 1 / max(n_out, n_in) of the node (the loader's division)
+constexpr int kStI = kStA + 10;                   // int area starts here (as doubles)
+constexpr int kStageDoubles = kStI + 40;          // ints: desc[64] px[8] row[8] (where Di's k-th message row lives in LDS)
+constexpr int kScalDoubles = 16;                  // newv[8], node_vmin, prim_e, x (as int)
+constexpr int kPipePad = 16;                      // source tables are padded by this many (+inf) entries on both sides
+constexpr int kPipeScr = 66;                      // doubles of scratch behind a wave's table: 129 ints of build_envelope_parallel
+constexpr int kPipeTab = 4 * (kWave + 2 * kPipePad) + kPipeScr;  // doubles per compute wave: (h, q, u, v) x 96 + scratch
+constexpr int kPipeXchg = 2 * kWave + kWave / 2;  // doubles of a helper's exchange area: m1[64], m2[64], 64 ints (CoopPart)
+
+// where the exchange areas and their flags live in trws_pipe_kernel's LDS (doubles from the start of the dynamic
+// allocation; pipe_body carves it in this order): the message routine forms the addresses from these constants and ONE
+// scalar word instead of carrying pointers through its whole length (scalar registers spilled into VGPR lanes cost an
+// instruction per use on the critical path of every visit)
+constexpr int kPipeXchgOff = 2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * kPipeTab + 2 + 3 * kWave / 2 + kWave + 16;
+constexpr int kPipeXflagOff = kPipeXchgOff + kPipeCompute * kPipeXchg;
+
 struct CoopPart {
-  int part = 0;             // 0: the wave that finishes the message, 1: its helper
-  int nparts = 1;           // 1: no cooperation
-  double *xd = nullptr;     // exchange area in LDS of the PAIR: [0..63] m1, [64..127] m2, then 64 ints of match counts
-  int *flag = nullptr;      // the helper's flag word
-  int seq = 0;              // what the flag must show for this exchange
+  int word = 0;   // bit 0: sharing; bit 1: this wave is the helper; bits 4-7: the helper's wave; bits 8-: what the flag must show
+  __device__ __forceinline__ bool active() const { return word & 1; }
+  __device__ __forceinline__ bool part() const { return (word >> 1) & 1; }
 };
 __device__ __forceinline__ void coop_publish(const CoopPart &c, double m1, double m2, int cnt, int lane) {
-  c.xd[lane] = m1; c.xd[kWave + lane] = m2; ((int *)(c.xd + 2 * kWave))[lane] = cnt;
+  extern __shared__ __attribute__((aligned(16))) double coop_lds[];
+  double *xd = coop_lds + kPipeXchgOff + ((c.word >> 4) & 15) * kPipeXchg;
+  xd[lane] = m1; xd[kWave + lane] = m2; ((int *)(xd + 2 * kWave))[lane] = cnt;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  if (lane == 0) __hip_atomic_store(c.flag, c.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (lane == 0) __hip_atomic_store((int *)(coop_lds + kPipeXflagOff) + ((c.word >> 4) & 15), c.word >> 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // (the second smallest DISTINCT cost of the union: the part whose minimum is the overall minimum contributes its
 //  second smallest, the other its minimum)
 __device__ __forceinline__ void coop_collect(const CoopPart &c, double &m1, double &m2, int &cnt, int lane) {
+  extern __shared__ __attribute__((aligned(16))) double coop_lds[];
+  const double *xd = coop_lds + kPipeXchgOff + ((c.word >> 4) & 15) * kPipeXchg;
+  int *flag = (int *)(coop_lds + kPipeXflagOff) + ((c.word >> 4) & 15);
   int spins = 0;
-  while (__hip_atomic_load(c.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != c.seq && ++spins < kCoopSpinLimit) { }
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (c.word >> 8) && ++spins < kCoopSpinLimit) { }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  const double b1 = c.xd[lane], b2 = c.xd[kWave + lane];
-  cnt += ((const int *)(c.xd + 2 * kWave))[lane];
+  const double b1 = xd[lane], b2 = xd[kWave + lane];
+  cnt += ((const int *)(xd + 2 * kWave))[lane];
   const double lo = min_raw(m1, b1);
   const double ca = m1 > lo ? m1 : m2, cb = b1 > lo ? b1 : b2;
   m2 = min_raw(ca, cb);
@@ -1233,7 +1258,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
   double hmin = h, mag = act ? fabs(h) + fabs(aq) + alpha * fabs(t) : 0.0;  // inactive lanes hold h = +inf
   wave_min_max_dpp(hmin, mag);
   double out, vmin;
-  if (coop.part && (UNI(alpha == 0) || KERNEL != 1 || !p.certificate)) { outmsg = 0; return 0; }   // (nothing there is shared)
+  if (coop.part() && (UNI(alpha == 0) || KERNEL != 1 || !p.certificate)) { outmsg = 0; return 0; }   // (nothing there is shared)
   if (UNI(alpha == 0)) {
     out = hmin; vmin = hmin;  // typeStereoLinear.h:390-396
   } else {
@@ -1310,23 +1335,11 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
         : "+v"(cnt) : "v"(dc), "v"(delta) : "vcc");                                  \
   }
         // (two waves: only worth the exchange with more than eight sources; the helper takes the upper half)
-        const bool split = coop.nparts > 1 && nuse > 8;
-        if (split) {
-          const int half = ((nuse + 7) >> 3) << 2;   // a multiple of four >= nuse / 2
-          const int i0 = coop.part ? half : 0, i1 = coop.part ? nuse : half;
-          for (int i = i0; i < i1; i += 4) {
-            const double h0 = hq[2 * i], q0 = hq[2 * i + 1], h1 = hq[2 * i + 2], q1 = hq[2 * i + 3];
-            const double h2 = hq[2 * i + 4], q2 = hq[2 * i + 5], h3 = hq[2 * i + 6], q3 = hq[2 * i + 7];
-            STEREO_ACC_C(h0, q0) STEREO_ACC_C(h1, q1) STEREO_ACC_C(h2, q2) STEREO_ACC_C(h3, q3)
-          }
-          if (coop.part) { coop_publish(coop, m1, m2, cnt, lane); outmsg = 0; return 0; }
-          coop_collect(coop, m1, m2, cnt, lane);
-        } else if (coop.part) {
-          outmsg = 0; return 0;   // (nothing to share: the first wave does it alone)
-        } else
+        const bool split = coop.active() && nuse > 8;
         if (nuse <= 8) {
+          if (coop.part()) { outmsg = 0; return 0; }   // (nothing to share: the first wave does it alone)
           // (up to eight sources -- nearly every message of a noisy volume --: all eight entries are
-          //  requested together, one LDS latency instead of one per trip)
+          //  requested together, one LDS latency instead of one per trip; first in the chain of cases: the common one)
           const double h0 = hq[0], q0 = hq[1], h1 = hq[2], q1 = hq[3], h2 = hq[4], q2 = hq[5], h3 = hq[6], q3 = hq[7];
           const double h4 = hq[8], q4 = hq[9], h5 = hq[10], q5 = hq[11], h6 = hq[12], q6 = hq[13], h7 = hq[14], q7 = hq[15];
           STEREO_ACC_C(h0, q0) STEREO_ACC_C(h1, q1) STEREO_ACC_C(h2, q2) STEREO_ACC_C(h3, q3)
@@ -1334,6 +1347,19 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
             STEREO_ACC_C(h4, q4) STEREO_ACC_C(h5, q5)
             if (nuse > 6) { STEREO_ACC_C(h6, q6) STEREO_ACC_C(h7, q7) }
           }
+        } else
+        if (split) {
+          const int half = ((nuse + 7) >> 3) << 2;   // a multiple of four >= nuse / 2
+          const int i0 = coop.part() ? half : 0, i1 = coop.part() ? nuse : half;
+          for (int i = i0; i < i1; i += 4) {
+            const double h0 = hq[2 * i], q0 = hq[2 * i + 1], h1 = hq[2 * i + 2], q1 = hq[2 * i + 3];
+            const double h2 = hq[2 * i + 4], q2 = hq[2 * i + 5], h3 = hq[2 * i + 6], q3 = hq[2 * i + 7];
+            STEREO_ACC_C(h0, q0) STEREO_ACC_C(h1, q1) STEREO_ACC_C(h2, q2) STEREO_ACC_C(h3, q3)
+          }
+          if (coop.part()) { coop_publish(coop, m1, m2, cnt, lane); outmsg = 0; return 0; }
+          coop_collect(coop, m1, m2, cnt, lane);
+        } else if (coop.part()) {
+          outmsg = 0; return 0;   // (nothing to share: the first wave does it alone)
         } else {
           for (int i = 0; i < nuse; i += 4) {
             const double h0 = hq[2 * i], q0 = hq[2 * i + 1], h1 = hq[2 * i + 2], q1 = hq[2 * i + 3];
@@ -1352,7 +1378,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
       // m1 / m2 = smallest and second smallest DISTINCT cost seen so far.
       // table entry of a source: (h, q, u, v) -- the tangency test then needs no arithmetic on the source
       const bool flat = window >= 0 && __builtin_popcountll(mask) > 32;
-      if (coop.part && !flat) { outmsg = 0; return 0; }   // (the masked loop is not shared: the first wave does it alone)
+      if (coop.part() && !flat) { outmsg = 0; return 0; }   // (the masked loop is not shared: the first wave does it alone)
       if (hq) {
         hq[4 * lane] = h; hq[4 * lane + 1] = qsrc; hq[4 * lane + 2] = ui; hq[4 * lane + 3] = vi;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1388,7 +1414,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
         //  * min-plus only over the sources inside the truncation window of each destination (a source
         //    farther than lambda costs >= vTrunc exactly); the table is padded with +inf entries.
         // (two waves: the helper walks the window while the first wave sorts the keys)
-        if (coop.part) {
+        if (coop.part()) {
           for (int d = -window; d <= window; ++d) {
             const double hj = hq[4 * (lane + d)], qj = hq[4 * (lane + d) + 1];
             const double c = pair_cost<1>(alpha, t - qj, hj);
@@ -1415,13 +1441,13 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
         const unsigned un = (unsigned)__shfl_down((int)ku, 1, kWave), vn = (unsigned)__shfl_down((int)kv, 1, kWave);
         const unsigned thr = bad ? 0u : (unsigned)(delta * scale) + 2u;
         bool tangent = lane + 1 < K && (un - ku <= thr || vn - kv <= thr);
-        // (the sorted keys see ALL pairs and cannot tell an exact tie from a near one: a hit is looked at again pair by pair)
+        // (the sorted keys see ALL pairs and cannot tell an exact tie from a near one: a hit is looked at again pair by pair
         //  -- the pairs with a USEFUL member, which is all the certificate asks for; the one pair kind that loop cannot see,
         //  a useful apex on an arm of a useless cone, is excluded by alpha gap > 2 delta as in the compacted loop above)
         if (UNI(act & tangent) && !UNI(act & bad) && alpha * p.pos_gap > 2 * delta)
           tangent = harmless_ties_only(alpha, h, t, delta, useful, hq, 4, 0, mask);
         bad = bad || tangent;
-        if (coop.nparts > 1) {
+        if (coop.active()) {
           int none = 0;
           coop_collect(coop, m1, m2, none, lane);
         } else
@@ -1532,21 +1558,6 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
 }
 
 #undef RLI
-
-constexpr int kPipeCompute = 8;  // one compute wave per outgoing message (<= 8 per node)
-constexpr int kPipeWaves = kPipeCompute + 4;  // loader (data behind flags), storer, loader A (own data, two visits
-                                              // deep; trws_pipe_kernel only), primal
-constexpr int kPipeThreads = kPipeWaves * kWave;
-// LDS stage layout (doubles): D[64] m[8][64] qv[8][64] qpv[8][64] | a[8] gamma pad | ints: desc[64] px[8] row[8]
-constexpr int kStD = 0, kStM = 64, kStQ = 64 + 512, kStQP = 64 + 1024, kStA = 64 + 1536;
-constexpr int kStG = kStA + 8;                    // gamma = 1 / max(n_out, n_in) of the node (the loader's division)
-constexpr int kStI = kStA + 10;                   // int area starts here (as doubles)
-constexpr int kStageDoubles = kStI + 40;          // ints: desc[64] px[8] row[8] (where Di's k-th message row lives in LDS)
-constexpr int kScalDoubles = 16;                  // newv[8], node_vmin, prim_e, x (as int)
-constexpr int kPipePad = 16;                      // source tables are padded by this many (+inf) entries on both sides
-constexpr int kPipeScr = 66;                      // doubles of scratch behind a wave's table: 129 ints of build_envelope_parallel
-constexpr int kPipeTab = 4 * (kWave + 2 * kPipePad) + kPipeScr;  // doubles per compute wave: (h, q, u, v) x 96 + scratch
-constexpr int kPipeXchg = 2 * kWave + kWave / 2;  // doubles of a helper's exchange area: m1[64], m2[64], 64 ints (CoopPart)
 
 __device__ __forceinline__ int group_strip(const GroupArgs &ga) {
   int s = 0;

@@ -154,10 +154,9 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           // (this wave's own old message is one of the rows; it is read once more below rather than
           //  picked out of the loop with eight selects)
           const double mown = st[kStM + (wave < nout ? wave : 0) * kWave + lane];
-          // (the twin's old message and the two weights are requested here, with the rows below: one LDS latency)
           const int partner = wave < nout ? (int)((twins >> (4 * wave)) & 15u) : wave;
-          const double m_tw = st[kStM + (partner < 8 ? partner : 0) * kWave + lane];
-          const double alpha_me = st[kStA + (wave < nout ? wave : 0)], alpha_tw = st[kStA + (partner < 8 ? partner : 0)];
+          const int twin_mask = (SHARED && KERNEL == 1) ? __builtin_amdgcn_readfirstlane((int)st[kStA + 9]) : 0;   // (loader A's verdict)
+          const double alpha_me = st[kStA + (wave < nout ? wave : 0)];
           // (all eight rows are requested together and added in list order; a row the node does not have
           //  is the zero row -- x + 0.0 == x --, so nothing here branches on the node's degree and the
           //  reads share one LDS latency instead of paying one each)
@@ -197,12 +196,9 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
               // a twin -- the node's other message to the same neighbour -- with the same weight and the same old
               // message is the same message: one wave finishes it, the other takes half of its loop (CoopPart)
               CoopPart cp;
-              if (SHARED && KERNEL == 1 && partner != j) {
-                if (alpha_tw == alpha && !UNI(act && mown != m_tw)) {
-                  const int helper = j > partner ? j : partner;
-                  cp.nparts = 2; cp.part = j > partner ? 1 : 0;
-                  cp.xd = xchg + helper * kPipeXchg; cp.flag = xflag + helper; cp.seq = pos + 1;
-                }
+              if (SHARED && KERNEL == 1 && ((twin_mask >> j) & 1)) {
+                const int helper = j > partner ? j : partner;
+                cp.word = 1 | (j > partner ? 2 : 0) | (helper << 4) | (((pos + 1) & 0x7fffff) << 8);
               }
               VSTAMP(2);
               double newm = 0;
@@ -215,10 +211,10 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
 #endif
                                                     , perm_shared, cp);
               VSTAMP(3);
-              if (!cp.part) {
+              if (!cp.part()) {
                 hcur[j * kWave + lane] = newm;   // (lanes beyond K fill the row's padding)
                 if (BACKWARD && lane == 0) sc[j] = v;
-                if (cp.nparts > 1) {
+                if (cp.active()) {
                   hcur[partner * kWave + lane] = newm;
                   if (BACKWARD && lane == 0) sc[partner] = v;
                 }
@@ -319,6 +315,27 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           }
           if (lane < 8) stn[kStA + lane] = rav;
           if (lane == 0) stn[kStG] = gtab[nout > nin ? nout : nin];
+          if (SHARED && KERNEL == 1 && UPDATE) {
+            // Which outgoing messages have a twin that IS the same message (word 56 names the candidates; equal weights,
+            // bitwise equal old rows -- this wave holds them in registers -- and shared positions make it so): decided
+            // here, off the compute waves' path, for ordinary nodes (up to four outgoing messages); bit j of the mask.
+            const unsigned tw = (unsigned)RLI(wa1, kDescTwin);
+            int mask = 0;
+            if (nout <= 4 && !(p.debug & 8192)) {   // (development switch 8192: no twins)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int k = j + 1; k < 4; ++k) {
+                  if (k < nout && (int)((tw >> (4 * j)) & 15u) == k) {
+                    const bool same = !UNI(act && rmv[j] != rmv[k]) && RLI(__double2hiint(rav), j) == RLI(__double2hiint(rav), k) &&
+                                      RLI(__double2loint(rav), j) == RLI(__double2loint(rav), k);
+                    if (same) mask |= (1 << j) | (1 << k);
+                  }
+                }
+              }
+            }
+            if (lane == 0) stn[kStA + 9] = (double)mask;
+          }
           int wa4 = 0;
           if (pos + 4 < p1) wa4 = desc[(size_t)(pos + 4) * DW + lane];  // three nodes ahead: waited for at the top of the next visit
           wa1 = wa2; wa2 = wa3; wa3 = wa4;
