@@ -4,10 +4,12 @@
 energy and (b) at once by simultaneous fusion (TRW-S over the 14 proposals and the current
 solution, maxiter 3000, max_relgap 1e-5 -- example_simultaneous.m:50-51).
 
-    python examples/example_simultaneous.py [im_left.png im_right.png] [--size H W]
+    python examples/example_simultaneous.py [im_left.png im_right.png] [--size H W] [--baby2]
 
-As in example_global.py the SegPln proposals and the segmentation behind the edge weights are out
-of scope; deterministic stand-ins are used, and a synthetic pair without images.
+--baby2: the example's own input -- the Baby2 pair with the edge weights of the reference's mean-shift segmentation
+and the 14 SegPln proposals on the reference's 14 segmentation maps (committed fixtures, tests/golden/baby2_pair.npz /
+baby2_segments.npz; the segmenters themselves stay on the host), planes fitted on the device.
+Otherwise deterministic stand-ins are used as in example_global.py, on the given images or a synthetic pair.
 """
 import argparse
 import os
@@ -25,11 +27,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("images", nargs="*")
     ap.add_argument("--size", type=int, nargs=2, default=[370, 413])      # Baby2 at third resolution
+    ap.add_argument("--baby2", action="store_true", help="example_simultaneous.m's own input from the committed fixtures")
     args = ap.parse_args()
     import stereo_amd
     from stereo_amd import terms as T
     from example_global import piecewise_planar
-    if len(args.images) == 2:
+    sg = None
+    if args.baby2:
+        gold = os.path.join(ROOT, "tests", "golden")
+        g = np.load(os.path.join(gold, "baby2_pair.npz")); sg = np.load(os.path.join(gold, "baby2_segments.npz"))
+        images = [g["im0"].astype(np.float64), g["im1"].astype(np.float64)]
+    elif len(args.images) == 2:
         from PIL import Image
         images = [np.asarray(Image.open(f).convert("RGB"), dtype=np.float64) for f in args.images]
     else:
@@ -44,10 +52,17 @@ def main():
     same = np.abs(img[conn[0]] - img[conn[1]]).sum(axis=1) < 30.0
     weights = np.where(same, 108.0, 9.0) * 2.0
     rng = np.random.default_rng(0)
-    dm = stereo_amd.dispmap_globalstereo(images, P, disp_range, disparity_factor, smooth_weights=weights, rng=rng)
-    print("start energy %.6f" % dm.energy())
-    d_lo, d_hi = dm.d_min, dm.d_min + dm.d_step
-    proposals = [piecewise_planar(H, W, cell, rng, d_lo, d_hi) for cell in (8, 12, 16, 24, 32, 48, 64) for _ in range(2)]
+    if sg is not None:
+        dm = stereo_amd.dispmap_globalstereo(images, P, disp_range, disparity_factor, segment=sg["segment"], rng=rng)
+        print("start energy %.6f" % dm.energy())
+        t0 = time.time()
+        proposals = dm.segpln([sg["segments"][:, :, b] for b in range(14)], seed=0)         # example_simultaneous.m:30
+        print("SegPln: window matching + 14 maps, %.2f s" % (time.time() - t0))
+    else:
+        dm = stereo_amd.dispmap_globalstereo(images, P, disp_range, disparity_factor, smooth_weights=weights, rng=rng)
+        print("start energy %.6f" % dm.energy())
+        d_lo, d_hi = dm.d_min, dm.d_min + dm.d_step
+        proposals = [piecewise_planar(H, W, cell, rng, d_lo, d_hi) for cell in (8, 12, 16, 24, 32, 48, 64) for _ in range(2)]
 
     t0 = time.time()
     moves = dm.binary_fuse_until_convergence(proposals, rng=np.random.default_rng(1))
