@@ -118,6 +118,13 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
 #define VSTAMP(i) do { } while (0)
 #endif
 
+    // Every role walks the run in its own loop -- the same visits, the same barrier at the end of each: the hardware
+    // barrier counts arrivals, whichever s_barrier instruction a wave arrives at -- so that what one role keeps across
+    // visits (the loaders' parked requests and descriptor words, the primal wave's labels) and the kernel parameters it
+    // uses are live in ITS loop only: in one loop for all roles the function sat at the scalar-register limit, ~300
+    // scalars spilled into VGPR lanes, and every edit anywhere moved spill code onto the compute waves' path.
+    if (wave < kPipeCompute) {
+    // ---- compute
     for (int pos = p0 - 1; pos <= p1; ++pos) {
       const long long tstart = p.prof ? (long long)__builtin_readcyclecounter() : 0;
 #ifdef STEREO_HIP_VISIT_PROFILE
@@ -139,8 +146,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
       int Kv = K;
       asm volatile("" : "+s"(Kv));
       const int lkv = lane < Kv ? lane : Kv - 1;
-
-      if (wave < kPipeCompute) {
+      {
         // ------------------------------------------------------------ compute
         if (UPDATE && have_node) {
           const int *sti = (const int *)(st + kStI);
@@ -223,7 +229,37 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           }
           }
         }
-      } else if (wave == kPipeCompute) {
+      }
+      if (p.prof) busy += (unsigned long long)((long long)__builtin_readcyclecounter() - tstart);
+      VSTAMP(4);
+      if (aborted) return;  // a dependency wait gave up (bounded spin); host reports it
+      __syncthreads();
+      VSTAMP(5);
+    }
+    } else if (wave == kPipeCompute) {
+    // ---- loader: stage node pos + 1
+    for (int pos = p0 - 1; pos <= p1; ++pos) {
+      const long long tstart = p.prof ? (long long)__builtin_readcyclecounter() : 0;
+#ifdef STEREO_HIP_VISIT_PROFILE
+      long long vmark = (long long)__builtin_readcyclecounter();
+#endif
+      double *st = stage0 + (pos & 1) * kStageDoubles;          // node `pos`
+      double *stn = stage0 + ((pos + 1) & 1) * kStageDoubles;   // node `pos + 1`
+      double *hcur = hand + (pos & 3) * 8 * kWave, *hprev = hand + ((pos - 1) & 3) * 8 * kWave;
+      double *sc = scal + (pos & 1) * kScalDoubles;
+      const bool have_node = pos >= p0 && pos < p1;
+      // (the workgroup's abort word -- a loader's wait gave up during the PREVIOUS visit -- is requested here and
+      //  looked at in front of the barrier that ends this visit: read behind that barrier, as it used to be, its
+      //  LDS round trip was the first thing on every wave's path into the next visit)
+      const int aborted = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // (opaque copies, renewed every visit: what is derived from them -- per-lane row bases, the label-count
+      //  tests of the envelope code, ... -- is recomputed where it is used, one instruction each; left visible as
+      //  loop invariants, the compiler hoists dozens of such values out of the visit loop and keeps them in
+      //  spilled registers, scalar ones in VGPR lanes, vector ones in scratch memory)
+      int Kv = K;
+      asm volatile("" : "+s"(Kv));
+      const int lkv = lane < Kv ? lane : Kv - 1;
+      {
         // ------------------------------------------------------------ loader: stage node pos + 1
         if (pos + 1 >= p0 && pos + 1 < p1) {
           const int w = wnext;
@@ -297,7 +333,37 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           }
 #endif
         }
-      } else if (wave == kPipeCompute + 2) {
+      }
+      if (p.prof) busy += (unsigned long long)((long long)__builtin_readcyclecounter() - tstart);
+      VSTAMP(4);
+      if (aborted) return;  // a dependency wait gave up (bounded spin); host reports it
+      __syncthreads();
+      VSTAMP(5);
+    }
+    } else if (wave == kPipeCompute + 2) {
+    // ---- loader A: own data of node pos + 1
+    for (int pos = p0 - 1; pos <= p1; ++pos) {
+      const long long tstart = p.prof ? (long long)__builtin_readcyclecounter() : 0;
+#ifdef STEREO_HIP_VISIT_PROFILE
+      long long vmark = (long long)__builtin_readcyclecounter();
+#endif
+      double *st = stage0 + (pos & 1) * kStageDoubles;          // node `pos`
+      double *stn = stage0 + ((pos + 1) & 1) * kStageDoubles;   // node `pos + 1`
+      double *hcur = hand + (pos & 3) * 8 * kWave, *hprev = hand + ((pos - 1) & 3) * 8 * kWave;
+      double *sc = scal + (pos & 1) * kScalDoubles;
+      const bool have_node = pos >= p0 && pos < p1;
+      // (the workgroup's abort word -- a loader's wait gave up during the PREVIOUS visit -- is requested here and
+      //  looked at in front of the barrier that ends this visit: read behind that barrier, as it used to be, its
+      //  LDS round trip was the first thing on every wave's path into the next visit)
+      const int aborted = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // (opaque copies, renewed every visit: what is derived from them -- per-lane row bases, the label-count
+      //  tests of the envelope code, ... -- is recomputed where it is used, one instruction each; left visible as
+      //  loop invariants, the compiler hoists dozens of such values out of the visit loop and keeps them in
+      //  spilled registers, scalar ones in VGPR lanes, vector ones in scratch memory)
+      int Kv = K;
+      asm volatile("" : "+s"(Kv));
+      const int lkv = lane < Kv ? lane : Kv - 1;
+      {
         // ------------------------------------------------------------ loader A: own data of node pos + 1
         // The registers hold what was requested during visit pos - 1 (its HBM latency lies behind a
         // whole visit, not inside one -- on the serial chains of the reference's node order the visit
@@ -341,7 +407,37 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           wa1 = wa2; wa2 = wa3; wa3 = wa4;
           if (pos + 2 < p1) PIPE_REQUEST_OWN(wa1);
         }
-      } else if (wave == kPipeCompute + 1) {
+      }
+      if (p.prof) busy += (unsigned long long)((long long)__builtin_readcyclecounter() - tstart);
+      VSTAMP(4);
+      if (aborted) return;  // a dependency wait gave up (bounded spin); host reports it
+      __syncthreads();
+      VSTAMP(5);
+    }
+    } else if (wave == kPipeCompute + 1) {
+    // ---- storer: node pos - 1
+    for (int pos = p0 - 1; pos <= p1; ++pos) {
+      const long long tstart = p.prof ? (long long)__builtin_readcyclecounter() : 0;
+#ifdef STEREO_HIP_VISIT_PROFILE
+      long long vmark = (long long)__builtin_readcyclecounter();
+#endif
+      double *st = stage0 + (pos & 1) * kStageDoubles;          // node `pos`
+      double *stn = stage0 + ((pos + 1) & 1) * kStageDoubles;   // node `pos + 1`
+      double *hcur = hand + (pos & 3) * 8 * kWave, *hprev = hand + ((pos - 1) & 3) * 8 * kWave;
+      double *sc = scal + (pos & 1) * kScalDoubles;
+      const bool have_node = pos >= p0 && pos < p1;
+      // (the workgroup's abort word -- a loader's wait gave up during the PREVIOUS visit -- is requested here and
+      //  looked at in front of the barrier that ends this visit: read behind that barrier, as it used to be, its
+      //  LDS round trip was the first thing on every wave's path into the next visit)
+      const int aborted = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // (opaque copies, renewed every visit: what is derived from them -- per-lane row bases, the label-count
+      //  tests of the envelope code, ... -- is recomputed where it is used, one instruction each; left visible as
+      //  loop invariants, the compiler hoists dozens of such values out of the visit loop and keeps them in
+      //  spilled registers, scalar ones in VGPR lanes, vector ones in scratch memory)
+      int Kv = K;
+      asm volatile("" : "+s"(Kv));
+      const int lkv = lane < Kv ? lane : Kv - 1;
+      {
         // ------------------------------------------------------------ storer: node pos - 1
         // The node's descriptor word is in a register since the previous visit (below) and nothing but the
         // fields the stores need is read from it, each row address being a scalar multiply and a shift-add:
@@ -400,7 +496,37 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           // node pos's descriptor (it reached dring during visit pos - 1)
           sw = dring[(pos % 3) * kWave + lane];
         }
-      } else if (wave == kPipeCompute + 3) {
+      }
+      if (p.prof) busy += (unsigned long long)((long long)__builtin_readcyclecounter() - tstart);
+      VSTAMP(4);
+      if (aborted) return;  // a dependency wait gave up (bounded spin); host reports it
+      __syncthreads();
+      VSTAMP(5);
+    }
+    } else {
+    // ---- primal of node pos
+    for (int pos = p0 - 1; pos <= p1; ++pos) {
+      const long long tstart = p.prof ? (long long)__builtin_readcyclecounter() : 0;
+#ifdef STEREO_HIP_VISIT_PROFILE
+      long long vmark = (long long)__builtin_readcyclecounter();
+#endif
+      double *st = stage0 + (pos & 1) * kStageDoubles;          // node `pos`
+      double *stn = stage0 + ((pos + 1) & 1) * kStageDoubles;   // node `pos + 1`
+      double *hcur = hand + (pos & 3) * 8 * kWave, *hprev = hand + ((pos - 1) & 3) * 8 * kWave;
+      double *sc = scal + (pos & 1) * kScalDoubles;
+      const bool have_node = pos >= p0 && pos < p1;
+      // (the workgroup's abort word -- a loader's wait gave up during the PREVIOUS visit -- is requested here and
+      //  looked at in front of the barrier that ends this visit: read behind that barrier, as it used to be, its
+      //  LDS round trip was the first thing on every wave's path into the next visit)
+      const int aborted = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // (opaque copies, renewed every visit: what is derived from them -- per-lane row bases, the label-count
+      //  tests of the envelope code, ... -- is recomputed where it is used, one instruction each; left visible as
+      //  loop invariants, the compiler hoists dozens of such values out of the visit loop and keeps them in
+      //  spilled registers, scalar ones in VGPR lanes, vector ones in scratch memory)
+      int Kv = K;
+      asm volatile("" : "+s"(Kv));
+      const int lkv = lane < Kv ? lane : Kv - 1;
+      {
         // ------------------------------------------------------------ primal of node pos
         if (PRIMAL && have_node) {
           const int *sti = (const int *)(st + kStI);
@@ -444,6 +570,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
       if (aborted) return;  // a dependency wait gave up (bounded spin); host reports it
       __syncthreads();
       VSTAMP(5);
+    }
     }
     if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2 + 1] = wall_clock64();
     if (p.prof && lane == 0 && (p.prof_run < 0 || run == p.prof_run)) {
