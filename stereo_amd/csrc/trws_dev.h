@@ -996,33 +996,56 @@ __device__ __forceinline__ void wait_for_dependencies_w(const DevParams &p, int 
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (contract: see wait_for_dependencies)
 }
 
-// ---- lane exchange lane ^ S without an address register where the hardware offers one
+// ---- lane exchange lane ^ S without an address register where the hardware offers one: a DPP move for 1, 2 and 8,
+// two of them for 4 (row_half_mirror is i -> i ^ 7 inside every eight lanes, the reversed quad i -> i ^ 3), the LDS
+// crossbar for 16 and 32.  (mov_dpp with bound_ctrl and all rows / banks enabled: one instruction, no copy of the source.)
 template <int S>
 __device__ __forceinline__ unsigned xor_lane_u32(unsigned v) {
-  if (S == 1) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
-  if (S == 2) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-  if (S == 8) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false);  // row_ror:8
-  if (S == 4 || S == 16) return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (S << 10));    // bit mode: xor S
+  if (S == 1) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  if (S == 2) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  if (S == 8) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);  // row_ror:8
+  if (S == 4) return (unsigned)__builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
+  if (S == 16) return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (S << 10));   // bit mode: xor S
   return (unsigned)__shfl_xor((int)v, S, kWave);
 }
 // Bitonic sort of two independent sets of 64 unsigned keys (one key of each per lane), ascending by lane.
-template <int SIZE, int STRIDE>
-__device__ __forceinline__ void bitonic_step2(unsigned &a, unsigned &b, int lane) {
-  const unsigned oa = xor_lane_u32<STRIDE>(a), ob = xor_lane_u32<STRIDE>(b);
-  const bool keep_min = ((lane & STRIDE) == 0) == ((lane & SIZE) == 0);
-  a = keep_min ? (a < oa ? a : oa) : (a > oa ? a : oa);
-  b = keep_min ? (b < ob ? b : ob) : (b > ob ? b : ob);
+// A compare-exchange keeps the smaller or the larger of (own, partner's) -- which one is a property of the lane and
+// the step -- and both are the MEDIAN of (own, partner's, c) with c = 0 resp. 0xffffffff: one v_med3_u32 per key (the
+// compiler matches max(min(a, b), min(max(a, b), c))) instead of min + max + select on a 64-bit lane mask per step
+// (21 masks: 42 scalar registers, spilled and read back lane by lane).  c comes out of one per-lane word of 21 bits,
+// one signed bit-field extract per step.  5 instructions per step and pair of keys, 12 before.
+__device__ __forceinline__ unsigned med3_u32(unsigned a, unsigned b, unsigned c) {
+  const unsigned lo = a < b ? a : b, hi = a < b ? b : a;
+  const unsigned t = hi < c ? hi : c;
+  return lo > t ? lo : t;
+}
+// bit k (k - 1) / 2 + j of the word: the step with blocks of 2^k and stride 2^j keeps the LARGER key in this lane
+__device__ __forceinline__ int bitonic_keep_bits(int lane) {
+  int km = 0;
+#pragma unroll
+  for (int k = 1; k <= 6; ++k) {
+    const int w = lane ^ -((lane >> k) & 1);   // bit j: lane bit j != lane bit k
+    km |= (w & ((1 << k) - 1)) << (k * (k - 1) / 2);
+  }
+  return km;
+}
+template <int LOG_SIZE, int LOG_STRIDE>
+__device__ __forceinline__ void bitonic_step2(unsigned &a, unsigned &b, int km) {
+  const unsigned oa = xor_lane_u32<(1 << LOG_STRIDE)>(a), ob = xor_lane_u32<(1 << LOG_STRIDE)>(b);
+  const unsigned c = (unsigned)__builtin_amdgcn_sbfe(km, LOG_SIZE * (LOG_SIZE - 1) / 2 + LOG_STRIDE, 1);
+  a = med3_u32(a, oa, c);
+  b = med3_u32(b, ob, c);
 }
 __device__ __forceinline__ void wave_sort2(unsigned &a, unsigned &b, int lane) {
-  bitonic_step2<2, 1>(a, b, lane);
-  bitonic_step2<4, 2>(a, b, lane); bitonic_step2<4, 1>(a, b, lane);
-  bitonic_step2<8, 4>(a, b, lane); bitonic_step2<8, 2>(a, b, lane); bitonic_step2<8, 1>(a, b, lane);
-  bitonic_step2<16, 8>(a, b, lane); bitonic_step2<16, 4>(a, b, lane); bitonic_step2<16, 2>(a, b, lane);
-  bitonic_step2<16, 1>(a, b, lane);
-  bitonic_step2<32, 16>(a, b, lane); bitonic_step2<32, 8>(a, b, lane); bitonic_step2<32, 4>(a, b, lane);
-  bitonic_step2<32, 2>(a, b, lane); bitonic_step2<32, 1>(a, b, lane);
-  bitonic_step2<64, 32>(a, b, lane); bitonic_step2<64, 16>(a, b, lane); bitonic_step2<64, 8>(a, b, lane);
-  bitonic_step2<64, 4>(a, b, lane); bitonic_step2<64, 2>(a, b, lane); bitonic_step2<64, 1>(a, b, lane);
+  const int km = bitonic_keep_bits(lane);
+  bitonic_step2<1, 0>(a, b, km);
+  bitonic_step2<2, 1>(a, b, km); bitonic_step2<2, 0>(a, b, km);
+  bitonic_step2<3, 2>(a, b, km); bitonic_step2<3, 1>(a, b, km); bitonic_step2<3, 0>(a, b, km);
+  bitonic_step2<4, 3>(a, b, km); bitonic_step2<4, 2>(a, b, km); bitonic_step2<4, 1>(a, b, km); bitonic_step2<4, 0>(a, b, km);
+  bitonic_step2<5, 4>(a, b, km); bitonic_step2<5, 3>(a, b, km); bitonic_step2<5, 2>(a, b, km); bitonic_step2<5, 1>(a, b, km);
+  bitonic_step2<5, 0>(a, b, km);
+  bitonic_step2<6, 5>(a, b, km); bitonic_step2<6, 4>(a, b, km); bitonic_step2<6, 3>(a, b, km); bitonic_step2<6, 2>(a, b, km);
+  bitonic_step2<6, 1>(a, b, km); bitonic_step2<6, 0>(a, b, km);
 }
 
 // Second look at a message whose certificate failed (cold path, kept out of line so that it costs the
@@ -1165,6 +1188,30 @@ constexpr int kPipeXchg = 2 * kWave + kWave / 2;  // doubles of a helper's excha
 // instruction per use on the critical path of every visit)
 constexpr int kPipeXchgOff = 2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * kPipeTab + 2 + 3 * kWave / 2 + kWave + 16;
 constexpr int kPipeXflagOff = kPipeXchgOff + kPipeCompute * kPipeXchg;
+
+// Min-plus of a destination over the table entries lane + d0 .. lane + d1 (the truncation window or a part of it; the
+// table is padded with +inf entries): four entries per trip, requested together -- one LDS latency per trip, not per entry.
+// m1 / m2: smallest and second smallest DISTINCT cost so far.
+__device__ __forceinline__ void window_minplus(const double *hq, double alpha, double t, int lane, int d0, int d1, double &m1, double &m2) {
+#define STEREO_WIN(HJ, QJ)                                         \
+  {                                                                \
+    const double c = pair_cost<1>(alpha, t - (QJ), (HJ));          \
+    const double lo = min_raw(m1, c), hi = max_raw(m1, c);         \
+    m2 = min_raw_if(hi > lo, m2, hi);                              \
+    m1 = lo;                                                       \
+  }
+  int d = d0;
+  for (; d + 3 <= d1; d += 4) {
+    const double *e = hq + 4 * (lane + d);
+    const double h0 = e[0], q0 = e[1], h1 = e[4], q1 = e[5], h2 = e[8], q2 = e[9], h3 = e[12], q3 = e[13];
+    STEREO_WIN(h0, q0) STEREO_WIN(h1, q1) STEREO_WIN(h2, q2) STEREO_WIN(h3, q3)
+  }
+  for (; d <= d1; ++d) {
+    const double hj = hq[4 * (lane + d)], qj = hq[4 * (lane + d) + 1];
+    STEREO_WIN(hj, qj)
+  }
+#undef STEREO_WIN
+}
 
 struct CoopPart {
   int word = 0;   // bit 0: sharing; bit 1: this wave is the helper; bits 4-7: the helper's wave; bits 8-: what the flag must show
@@ -1414,14 +1461,11 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
         //  * min-plus only over the sources inside the truncation window of each destination (a source
         //    farther than lambda costs >= vTrunc exactly); the table is padded with +inf entries.
         // (two waves: the helper walks the window while the first wave sorts the keys)
+        // (... all of it but the last kFlatOwn entries, which the first wave takes behind its sort)
+        constexpr int kFlatOwn = 3;
+        const int wsplit = window >= kFlatOwn ? window - kFlatOwn : window;
         if (coop.part()) {
-          for (int d = -window; d <= window; ++d) {
-            const double hj = hq[4 * (lane + d)], qj = hq[4 * (lane + d) + 1];
-            const double c = pair_cost<1>(alpha, t - qj, hj);
-            const double lo = min_raw(m1, c), hi = max_raw(m1, c);
-            m2 = min_raw_if(hi > lo, m2, hi);
-            m1 = lo;
-          }
+          window_minplus(hq, alpha, t, lane, -window, wsplit, m1, m2);
           coop_publish(coop, m1, m2, 0, lane);
           outmsg = 0;
           return 0;
@@ -1449,14 +1493,10 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
         bad = bad || tangent;
         if (coop.active()) {
           int none = 0;
+          window_minplus(hq, alpha, t, lane, wsplit + 1, window, m1, m2);
           coop_collect(coop, m1, m2, none, lane);
-        } else
-        for (int d = -window; d <= window; ++d) {
-          const double hj = hq[4 * (lane + d)], qj = hq[4 * (lane + d) + 1];
-          const double c = pair_cost<1>(alpha, t - qj, hj);
-          const double lo = min_raw(m1, c), hi = max_raw(m1, c);
-          m2 = min_raw_if(hi > lo, m2, hi);
-          m1 = lo;
+        } else {
+          window_minplus(hq, alpha, t, lane, -window, window, m1, m2);
         }
       } else {
       // (a wave whose last certificate failed checks after every trip whether this one has failed
