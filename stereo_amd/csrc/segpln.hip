@@ -183,18 +183,28 @@ struct FitArgs {
   double *proposal;         // 4 x N
   double *planes;           // 3 x S
   int32_t *ninl;            // S
+  const int32_t *list;      // the segments of this launch
 };
 
-// One wave per segment (dispmap_globalstereo.m:164-191 + rplane :417-450).  Control flow is uniform: every
-// decision is made on a count or on values every lane holds.
-__global__ __launch_bounds__(64) void segpln_fit_kernel(FitArgs a) {
-  const int s = blockIdx.x, lane = threadIdx.x;
+// One workgroup of T threads per segment (dispmap_globalstereo.m:164-191 + rplane :417-450).  Control flow is uniform:
+// every decision is made on a count or on values every thread holds.  The cost of a segment is its RANSAC trials, each
+// a pass over all of its points (`classify`: flags and an integer count, independent of who looks at which point) --
+// that pass is spread over all T threads (T = 1024 for the large segments of a coarse segmentation map: one of them on
+// ONE wave used to take 58 ms of the Teddy example's 119 ms of plane fitting); the least-squares sums, whose order of
+// addition is part of the definition (oracle/terms.py:_lstsq3: 64 strided partial sums, then a tree), stay with the
+// first wave, which hands the plane to the others through LDS.  They run a few times per segment, not once per trial.
+template <int T>
+__global__ __launch_bounds__(T) void segpln_fit_kernel(FitArgs a) {
+  __shared__ int s_cnt[T / 64 > 0 ? T / 64 : 1];
+  __shared__ double s_plane[3];
+  const int s = a.list[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p0 = a.seg_ptr[s], p1 = a.seg_ptr[s + 1];
-  if (p1 <= p0) { if (lane == 0) { a.ninl[s] = 0; a.planes[3 * s] = a.planes[3 * s + 1] = a.planes[3 * s + 2] = 0; } return; }
+  if (p1 <= p0) { if (tid == 0) { a.ninl[s] = 0; a.planes[3 * s] = a.planes[3 * s + 1] = a.planes[3 * s + 2] = 0; } return; }
   double *X = a.px + p0, *Y = a.py + p0, *Z = a.pz + p0;
   uint8_t *cur = a.cur + p0, *inl = a.inl + p0;
   // world coordinates [x y 1] / d of the segment's pixels (:141-145), those with WC(:,3) ~= 0 kept (:168), in order
   int n = 0;
+  if (wave == 0)
   for (int base = p0; base < p1; base += 64) {
     const int i = base + lane;
     double z = 0, x = 0, y = 0;
@@ -210,23 +220,42 @@ __global__ __launch_bounds__(64) void segpln_fit_kernel(FitArgs a) {
     if (keep) { X[at] = x; Y[at] = y; Z[at] = z; }
     n += __builtin_popcountll(m);
   }
+  if (T > 64) {
+    if (tid == 0) s_cnt[0] = n;
+    __threadfence_block();
+    __syncthreads();
+    n = s_cnt[0];
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   // distances of all points to the plane N . p = -1, flags into `dst`; returns the number of inliers
   auto classify = [&](const double N[3], uint8_t *dst) {
     int cnt = 0;
-    for (int i = lane; i < n; i += 64) {
+    for (int i = tid; i < n; i += T) {
       const double dist = fabs(((X[i] * N[0] + Y[i] * N[1]) + Z[i] * N[2]) + 1.0);
       const bool v = dist < a.rt;
       dst[i] = v ? 1 : 0;
       cnt += v ? 1 : 0;
     }
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (T > 64) {
+      __syncthreads();   // (the last reader of s_cnt is done)
+      if (lane == 0) s_cnt[wave] = cnt;
+      __syncthreads();
+      cnt = 0;
+      for (int w = 0; w < T / 64; ++w) cnt += s_cnt[w];
+    }
     __syncthreads();
     return cnt;
   };
   // least squares of the flagged points by the normal equations, summed as oracle/terms.py:_lstsq3 sums them
   auto lstsq = [&](const uint8_t *flags, double N[3]) {
+    if (T > 64 && wave != 0) {   // (the first wave sums, in the definition's order; the others take the plane from LDS)
+      __syncthreads();
+      N[0] = s_plane[0]; N[1] = s_plane[1]; N[2] = s_plane[2];
+      __syncthreads();
+      return;
+    }
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = lane; i < n; i += 64) {
       if (flags == nullptr || flags[i]) {
@@ -245,13 +274,18 @@ __global__ __launch_bounds__(64) void segpln_fit_kernel(FitArgs a) {
     m[0] = acc[0]; m[1] = acc[1]; m[2] = acc[2]; m[3] = acc[1]; m[4] = acc[3]; m[5] = acc[4]; m[6] = acc[2]; m[7] = acc[4]; m[8] = acc[5];
     b[0] = acc[6]; b[1] = acc[7]; b[2] = acc[8];
     solve3(m, b, N);
+    if (T > 64) {
+      if (lane == 0) { s_plane[0] = N[0]; s_plane[1] = N[1]; s_plane[2] = N[2]; }
+      __syncthreads();
+      __syncthreads();
+    }
   };
   int n_in = n;          // local_WC_points = N when there are too few points for RANSAC (:170)
   bool use_flags = false;
   if (n > 3) {
     int max_i = 3, no_sam = 0, best = 0;
     double max_sam = (double)a.max_samples;
-    for (int i = lane; i < n; i += 64) inl[i] = 0;
+    for (int i = tid; i < n; i += T) inl[i] = 0;
     __syncthreads();
     while ((double)no_sam < max_sam) {
       ++no_sam;
@@ -274,7 +308,7 @@ __global__ __launch_bounds__(64) void segpln_fit_kernel(FitArgs a) {
         __syncthreads();
         const int cnt = classify(N, cur);
         if (cnt > best) {
-          for (int i = lane; i < n; i += 64) inl[i] = cur[i];
+          for (int i = tid; i < n; i += T) inl[i] = cur[i];
           __syncthreads();
           best = cnt;
           max_i = no_i;
@@ -294,14 +328,14 @@ __global__ __launch_bounds__(64) void segpln_fit_kernel(FitArgs a) {
   double N_[3] = {0, 0, 0};
   const bool fitted = n_in > 2;
   if (fitted) lstsq(use_flags ? inl : nullptr, N_);
-  if (lane == 0) {
+  if (tid == 0) {
     a.ninl[s] = n_in;
     for (int k = 0; k < 3; ++k) a.planes[3 * s + k] = fitted ? N_[k] : 0.0;
   }
   if (fitted) {   // proposals{b}(:, M) = [N1 N2 1 N3]' for ALL pixels of the segment (:183-186), NaN / Inf -> 1e-100 (:193-196)
     double v[4] = {N_[0], N_[1], 1.0, N_[2]};
     for (int k = 0; k < 4; ++k) v[k] = (v[k] == v[k] && fabs(v[k]) != __builtin_huge_val()) ? v[k] : 1e-100;
-    for (int i = p0 + lane; i < p1; i += 64) {
+    for (int i = p0 + tid; i < p1; i += T) {
       double *c = a.proposal + 4 * (size_t)a.seg_idx[i];
       c[0] = v[0]; c[1] = v[1]; c[2] = v[2]; c[3] = v[3];
     }
@@ -378,8 +412,20 @@ int stereo_segpln_planes(const double *wta, const int32_t *segments, int H, int 
     dpl.alloc((size_t)3 * std::max(S, 1)); dn.alloc((size_t)std::max(S, 1));
     hipLaunchKernelGGL(segpln_init_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, N, dprop.p);
     if (S > 0) {
-      FitArgs a{dw.p, dptr.p, didx.p, H, W, S, max_samples, rt, seed, px.p, py.p, pz.p, cur.p, inl.p, dprop.p, dpl.p, dn.p};
-      hipLaunchKernelGGL(segpln_fit_kernel, dim3((unsigned)S), dim3(64), 0, 0, a);
+      // segments by size: a large one gets a workgroup of 1024 threads for its passes over the points, the others a wave
+      constexpr int kLargeSegment = 4096;
+      std::vector<int32_t> list[2];
+      for (int sg = 0; sg < S; ++sg) list[ptr[sg + 2] - ptr[sg + 1] > kLargeSegment ? 1 : 0].push_back(sg);
+      std::vector<int32_t> both(list[1]);
+      both.insert(both.end(), list[0].begin(), list[0].end());
+      DevBuf<int32_t> dlist;
+      dlist.upload(both.data(), both.size());
+      FitArgs a{dw.p, dptr.p, didx.p, H, W, S, max_samples, rt, seed, px.p, py.p, pz.p, cur.p, inl.p, dprop.p, dpl.p, dn.p, dlist.p};
+      if (!list[1].empty()) hipLaunchKernelGGL(segpln_fit_kernel<1024>, dim3((unsigned)list[1].size()), dim3(1024), 0, 0, a);
+      a.list = dlist.p + list[1].size();
+      if (!list[0].empty()) hipLaunchKernelGGL(segpln_fit_kernel<64>, dim3((unsigned)list[0].size()), dim3(64), 0, 0, a);
+      STEREO_HIP_CHECK(hipGetLastError());
+      STEREO_HIP_CHECK(hipDeviceSynchronize());   // (dlist lives until here)
     }
     STEREO_HIP_CHECK(hipGetLastError());
     STEREO_HIP_CHECK(hipMemcpy(proposal, dprop.p, sizeof(double) * 4 * N, hipMemcpyDeviceToHost));
