@@ -145,3 +145,24 @@ def test_segpln_through_the_class(hip):
         gs.binary_fusion(p)
         assert gs.energy() <= e * (1 + 1e-12)
         e = gs.energy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pair", ["teddy", "baby2"])
+def test_device_plane_fits_on_the_reference_segmentations_equal_the_golden_planes(hip, pair):
+    """The 14 segmentation maps the reference's own segmenters make of the example pairs (tests/golden/*_segments.npz)
+    hold segments from a handful of pixels to 150 000: the small ones are fitted by a wave, those above 4096 pixels by
+    a workgroup of 1024 threads (segpln.hip).  Both must give the oracle's planes -- the committed fixture
+    (tests/golden/make_golden_segpln.py: oracle/terms.py on the fixture's own winner-takes-all map) -- bit for bit."""
+    from example_inputs import proposals_from_planes
+    from stereo_amd import terms as T
+    sg = np.load(os.path.join(GOLD, "%s_segments.npz" % pair))
+    pl = np.load(os.path.join(GOLD, "%s_segpln_planes.npz" % pair))
+    want = proposals_from_planes(sg["segments"], [pl["planes_%d" % b] for b in range(14)])
+    largest = 0
+    for b in range(14):
+        seg = sg["segments"][:, :, b]
+        largest = max(largest, int(np.bincount(seg.ravel().astype(np.int64))[1:].max()))
+        got = T.segpln_planes(pl["wta"], seg, seed=b)[0]
+        assert np.array_equal(got, want[b], equal_nan=True), (pair, b, int((got != want[b]).any(axis=0).sum()))
+    assert largest > 4096   # (the large-segment kernel was exercised)
