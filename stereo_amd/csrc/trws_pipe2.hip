@@ -66,6 +66,9 @@ __device__ __forceinline__ void pipe2_body(DevParams p, int epoch) {
     if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2] = wall_clock64();
 
     unsigned long long busy = 0;  // development profile (STEREO_HIP_TRWS_PROF): cycles from barrier to barrier arrival
+    // (every role walks the run in its own loop, as in trws_pipe.hip: the same visits, the same barrier, registers per role)
+    if (wave < kPipeCompute) {
+    // ---- compute
     for (int pos = p0 - 1; pos <= p1; ++pos) {
       const long long tstart = p.prof ? (long long)__builtin_readcyclecounter() : 0;
       double *st = stage0 + (pos & 1) * k2Stage;
@@ -73,8 +76,7 @@ __device__ __forceinline__ void pipe2_body(DevParams p, int epoch) {
       double *hcur = hand + (pos & 3) * 8 * k2W, *hprev = hand + ((pos - 1) & 3) * 8 * k2W;
       double *sc = scal + (pos & 1) * kScalDoubles;
       const bool have_node = pos >= p0 && pos < p1;
-
-      if (wave < kPipeCompute) {
+      {
         // ------------------------------------------------------------ compute
         if (UPDATE && have_node) {
           const int *sti = (const int *)(st + k2StI);
@@ -287,7 +289,24 @@ __device__ __forceinline__ void pipe2_body(DevParams p, int epoch) {
             }
           }
         }
-      } else if (wave == kPipeCompute) {
+      }
+      if (p.prof) busy += (unsigned long long)((long long)__builtin_readcyclecounter() - tstart);
+      __syncthreads();
+      if (ctl[1]) {
+        if (tid == 0) st_sc1(p.abort_flag, 1);
+        return;
+      }
+    }
+    } else if (wave == kPipeCompute) {
+    // ---- loader: stage node pos + 1
+    for (int pos = p0 - 1; pos <= p1; ++pos) {
+      const long long tstart = p.prof ? (long long)__builtin_readcyclecounter() : 0;
+      double *st = stage0 + (pos & 1) * k2Stage;
+      double *stn = stage0 + ((pos + 1) & 1) * k2Stage;
+      double *hcur = hand + (pos & 3) * 8 * k2W, *hprev = hand + ((pos - 1) & 3) * 8 * k2W;
+      double *sc = scal + (pos & 1) * kScalDoubles;
+      const bool have_node = pos >= p0 && pos < p1;
+      {
         // ------------------------------------------------------------ loader: stage node pos + 1
         if (pos + 1 >= p0 && pos + 1 < p1) {
           const int w = wnext;
@@ -357,7 +376,24 @@ __device__ __forceinline__ void pipe2_body(DevParams p, int epoch) {
           }
           if (lane < 8) { stn[k2StA + lane] = av; stni[64 + lane] = pxv; }
         }
-      } else if (wave == kPipeCompute + 1) {
+      }
+      if (p.prof) busy += (unsigned long long)((long long)__builtin_readcyclecounter() - tstart);
+      __syncthreads();
+      if (ctl[1]) {
+        if (tid == 0) st_sc1(p.abort_flag, 1);
+        return;
+      }
+    }
+    } else if (wave == kPipeCompute + 1) {
+    // ---- storer: node pos - 1
+    for (int pos = p0 - 1; pos <= p1; ++pos) {
+      const long long tstart = p.prof ? (long long)__builtin_readcyclecounter() : 0;
+      double *st = stage0 + (pos & 1) * k2Stage;
+      double *stn = stage0 + ((pos + 1) & 1) * k2Stage;
+      double *hcur = hand + (pos & 3) * 8 * k2W, *hprev = hand + ((pos - 1) & 3) * 8 * k2W;
+      double *sc = scal + (pos & 1) * kScalDoubles;
+      const bool have_node = pos >= p0 && pos < p1;
+      {
         // ------------------------------------------------------------ storer: node pos - 1
         if (pos - 1 >= p0) {
           const NodeDesc pd = decode_desc(desc[(size_t)(pos - 1) * DW + lane]);
@@ -390,7 +426,24 @@ __device__ __forceinline__ void pipe2_body(DevParams p, int epoch) {
             if (pd.remote & (1 << 17)) st_sc1(p.peer_done1 + pd.pn[1], epoch);
           }
         }
-      } else if (wave == kPipeCompute + 3) {
+      }
+      if (p.prof) busy += (unsigned long long)((long long)__builtin_readcyclecounter() - tstart);
+      __syncthreads();
+      if (ctl[1]) {
+        if (tid == 0) st_sc1(p.abort_flag, 1);
+        return;
+      }
+    }
+    } else if (wave == kPipeCompute + 3) {
+    // ---- primal of node pos
+    for (int pos = p0 - 1; pos <= p1; ++pos) {
+      const long long tstart = p.prof ? (long long)__builtin_readcyclecounter() : 0;
+      double *st = stage0 + (pos & 1) * k2Stage;
+      double *stn = stage0 + ((pos + 1) & 1) * k2Stage;
+      double *hcur = hand + (pos & 3) * 8 * k2W, *hprev = hand + ((pos - 1) & 3) * 8 * k2W;
+      double *sc = scal + (pos & 1) * kScalDoubles;
+      const bool have_node = pos >= p0 && pos < p1;
+      {
         // ------------------------------------------------------------ primal of node pos
         if (PRIMAL && have_node) {
           const int *sti = (const int *)(st + k2StI);
@@ -447,6 +500,26 @@ __device__ __forceinline__ void pipe2_body(DevParams p, int epoch) {
         if (tid == 0) st_sc1(p.abort_flag, 1);
         return;
       }
+    }
+    } else {
+    // ---- (idle wave)
+    for (int pos = p0 - 1; pos <= p1; ++pos) {
+      const long long tstart = p.prof ? (long long)__builtin_readcyclecounter() : 0;
+      double *st = stage0 + (pos & 1) * k2Stage;
+      double *stn = stage0 + ((pos + 1) & 1) * k2Stage;
+      double *hcur = hand + (pos & 3) * 8 * k2W, *hprev = hand + ((pos - 1) & 3) * 8 * k2W;
+      double *sc = scal + (pos & 1) * kScalDoubles;
+      const bool have_node = pos >= p0 && pos < p1;
+      {
+        (void)0;
+      }
+      if (p.prof) busy += (unsigned long long)((long long)__builtin_readcyclecounter() - tstart);
+      __syncthreads();
+      if (ctl[1]) {
+        if (tid == 0) st_sc1(p.abort_flag, 1);
+        return;
+      }
+    }
     }
     if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2 + 1] = wall_clock64();
     if (p.prof && lane == 0 && (p.prof_run < 0 || run == p.prof_run)) {
