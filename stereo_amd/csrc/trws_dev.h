@@ -1213,6 +1213,14 @@ __device__ __forceinline__ void window_minplus(const double *hq, double alpha, d
 #undef STEREO_WIN
 }
 
+// more useful sources than this on shared ascending positions with a window: key sort + window loop instead of the pair loop
+#ifndef STEREO_FLAT_FROM
+#define STEREO_FLAT_FROM 32
+#endif
+#ifndef STEREO_FLAT_OWN
+#define STEREO_FLAT_OWN 0
+#endif
+constexpr int kFlatFrom = STEREO_FLAT_FROM;
 struct CoopPart {
   int word = 0;   // bit 0: sharing; bit 1: this wave is the helper; bits 4-7: the helper's wave; bits 8-: what the flag must show
   __device__ __forceinline__ bool active() const { return word & 1; }
@@ -1340,7 +1348,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
       unsigned long long mask = __builtin_amdgcn_ballot_w64(useful);
       double m1 = inf, m2 = inf;
       bool bad = !(delta < inf);
-      if (SHAREDPOS && p.pos_gap > 0 && !(window >= 0 && __builtin_popcountll(mask) > 32)) {
+      if (SHAREDPOS && p.pos_gap > 0 && !(window >= 0 && __builtin_popcountll(mask) > kFlatFrom)) {
         // Shared strictly ascending positions, at most 32 useful sources (or no window): the useful
         // sources' (h, q) are COMPACTED into the wave's table -- a useful lane writes entry number
         // "useful lanes below me" -- and walked four per trip with uniform reads at constant offsets:
@@ -1424,7 +1432,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
       // eight v_readlane); two sources per trip keep two independent dependency chains in flight.
       // m1 / m2 = smallest and second smallest DISTINCT cost seen so far.
       // table entry of a source: (h, q, u, v) -- the tangency test then needs no arithmetic on the source
-      const bool flat = window >= 0 && __builtin_popcountll(mask) > 32;
+      const bool flat = window >= 0 && __builtin_popcountll(mask) > kFlatFrom;
       if (coop.part() && !flat) { outmsg = 0; return 0; }   // (the masked loop is not shared: the first wave does it alone)
       if (hq) {
         hq[4 * lane] = h; hq[4 * lane + 1] = qsrc; hq[4 * lane + 2] = ui; hq[4 * lane + 3] = vi;
@@ -1462,7 +1470,7 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
         //    farther than lambda costs >= vTrunc exactly); the table is padded with +inf entries.
         // (two waves: the helper walks the window while the first wave sorts the keys)
         // (... all of it but the last kFlatOwn entries, which the first wave takes behind its sort)
-        constexpr int kFlatOwn = 3;
+        constexpr int kFlatOwn = STEREO_FLAT_OWN;
         const int wsplit = window >= kFlatOwn ? window - kFlatOwn : window;
         if (coop.part()) {
           window_minplus(hq, alpha, t, lane, -window, wsplit, m1, m2);
@@ -1470,19 +1478,28 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
           outmsg = 0;
           return 0;
         }
-        const double hmax = wave_max_dpp(act ? h : -inf);
+        // (keys of cones that cannot meet a useful one are taken at a CAP: a cone within delta of a useful cone's arm has
+        //  h <= vTrunc + |alpha| (position range) + delta, so whatever lies above the cap is out of every tangency a useful
+        //  cone takes part in; capped, the keys' range is known without a reduction for max H -- this wave is the one
+        //  the visit waits for -- and a capped key that happens to land next to another one only costs the second look,
+        //  which judges pairs by their true h.  The scale by v_rcp_f64 and a safety factor: any scale that keeps the keys
+        //  below 2^32 will do, the threshold is made with the same one.)
         const double ap0 = alpha * p.pos_first, ap1 = alpha * p.pos_last;
         const double aplo = min_raw(ap0, ap1), aphi = max_raw(ap0, ap1);
-        const double span = (hmax - hmin) + (aphi - aplo);  // >= max u - min u and >= max v - min v
-        const double scale = 4294967040.0 / span;           // (2^32 - 256) / span
+        const double hcap = vtrunc + 1.000001 * (aphi - aplo) + 4 * delta;
+        const double span = (hcap - hmin) + (aphi - aplo);  // >= max u - min u and >= max v - min v of the capped cones
+        const double scale = (4294967040.0 * 0.99999) * __builtin_amdgcn_rcp(span);   // <= (2^32 - 256) / span
         bad = bad || !(span < inf) || !(span > 0) || !(delta * scale < 1e9);
         unsigned ku = 0xFFFFFFFFu, kv = 0xFFFFFFFFu;
         if (act && !bad) {
-          ku = (unsigned)((ui - (hmin - aphi)) * scale);
-          kv = (unsigned)((vi - (hmin + aplo)) * scale);
+          const double hc = min_raw(h, hcap);
+          ku = (unsigned)(((hc - aq) - (hmin - aphi)) * scale);
+          kv = (unsigned)(((hc + aq) - (hmin + aplo)) * scale);
         }
         wave_sort2(ku, kv, lane);
-        const unsigned un = (unsigned)__shfl_down((int)ku, 1, kWave), vn = (unsigned)__shfl_down((int)kv, 1, kWave);
+        // (the key of the next lane: wave_shl:1, one DPP move each)
+        const unsigned un = (unsigned)__builtin_amdgcn_mov_dpp((int)ku, 0x130, 0xF, 0xF, true),
+                       vn = (unsigned)__builtin_amdgcn_mov_dpp((int)kv, 0x130, 0xF, 0xF, true);
         const unsigned thr = bad ? 0u : (unsigned)(delta * scale) + 2u;
         bool tangent = lane + 1 < K && (un - ku <= thr || vn - kv <= thr);
         // (the sorted keys see ALL pairs and cannot tell an exact tie from a near one: a hit is looked at again pair by pair
