@@ -1031,8 +1031,18 @@ __device__ __forceinline__ int bitonic_keep_bits(int lane) {
 }
 template <int LOG_SIZE, int LOG_STRIDE>
 __device__ __forceinline__ void bitonic_step2(unsigned &a, unsigned &b, int km) {
-  const unsigned oa = xor_lane_u32<(1 << LOG_STRIDE)>(a), ob = xor_lane_u32<(1 << LOG_STRIDE)>(b);
   const unsigned c = (unsigned)__builtin_amdgcn_sbfe(km, LOG_SIZE * (LOG_SIZE - 1) / 2 + LOG_STRIDE, 1);
+  if (LOG_STRIDE >= 4) {
+    // strides 16 and 32: gfx950's v_permlane16_swap / v_permlane32_swap exchange the odd rows (the upper half) of one
+    // register with the even rows (the lower half) of another; fed the key twice they leave (own, partner's) in every
+    // lane of the pair -- in which order does not matter to a median -- without the LDS crossbar's round trip
+    const auto ra = LOG_STRIDE == 4 ? __builtin_amdgcn_permlane16_swap(a, a, false, false) : __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    const auto rb = LOG_STRIDE == 4 ? __builtin_amdgcn_permlane16_swap(b, b, false, false) : __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    a = med3_u32(ra[0], ra[1], c);
+    b = med3_u32(rb[0], rb[1], c);
+    return;
+  }
+  const unsigned oa = xor_lane_u32<(1 << LOG_STRIDE)>(a), ob = xor_lane_u32<(1 << LOG_STRIDE)>(b);
   a = med3_u32(a, oa, c);
   b = med3_u32(b, ob, c);
 }
