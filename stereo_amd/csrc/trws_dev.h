@@ -1445,7 +1445,8 @@ __device__ __forceinline__ double message_regs(const DevParams &p, int K, double
       const bool flat = window >= 0 && __builtin_popcountll(mask) > kFlatFrom;
       if (coop.part() && !flat) { outmsg = 0; return 0; }   // (the masked loop is not shared: the first wave does it alone)
       if (hq) {
-        hq[4 * lane] = h; hq[4 * lane + 1] = qsrc; hq[4 * lane + 2] = ui; hq[4 * lane + 3] = vi;
+        hq[4 * lane] = h; hq[4 * lane + 1] = qsrc;
+        if (!flat) { hq[4 * lane + 2] = ui; hq[4 * lane + 3] = vi; }   // (the flat path reads (h, q) only)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
