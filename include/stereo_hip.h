@@ -155,6 +155,14 @@ int stereo_trws_plan_stats(stereo_trws_plan *plan, double *sweep_ms, int64_t *sw
  * construction and the serial construction was run instead. */
 int stereo_trws_plan_counters(stereo_trws_plan *plan, int64_t *serial_messages, int reset);
 
+/* The speculative schedule of the long serial run (the image grid's border chain): a runner computes the
+ * run's recurrence ahead with plain min-plus, segments of the run recompute every visit with the certified routine side
+ * by side, compare what they started from with what the segment in front produced, and walk again if it differs --
+ * results are the sequential sweep's either way.  out[0] = 1 if the plan's next sweeps use it (graph, kernel family,
+ * positions permitting; STEREO_HIP_TRWS_SPEC=0 turns it off at plan creation), out[1] = segments walked twice,
+ * out[2] = segments committed, out[3] = visits of the runner, since the plan was created.  No reference counterpart. */
+int stereo_trws_plan_spec_stats(stereo_trws_plan *plan, int64_t out[4]);
+
 /* Diagnostics / test hook: M independent message updates Edge::UpdateMessage
  * (typeStereoLinear.h:329-487, typeStereoQuadratic.h:329-501) on the device, one wavefront per
  * message, through the very routine the pipelined sweep kernel uses (certified min-plus fast

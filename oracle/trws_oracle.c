@@ -327,6 +327,10 @@ static double envelope_message(int kernel, int K, const double *H, double hmin, 
  * the brute-force min-plus and evaluate the "no near tangency + unique minimum"
  * certificate the HIP fast path uses to prove both are bitwise equal. */
 static int64_t g_diag[8];
+/* optional per-message record of mode 2 (census tools): byte n = bit 0 "envelope != brute-force
+ * min-plus", bit 1 "certificate fails", for the n-th message update since the buffer was set */
+static uint8_t *g_trace_buf; static int64_t g_trace_cap, g_trace_n;
+void oracle_trws_message_trace(uint8_t *buf, int64_t cap) { g_trace_buf = buf; g_trace_cap = cap; g_trace_n = 0; }
 void oracle_trws_diag(int64_t *out, int reset) {
   for (int i = 0; i < 8; ++i) { if (out) out[i] = g_diag[i]; if (reset) g_diag[i] = 0; }
 }
@@ -388,6 +392,7 @@ static double do_update(solver_t *S, int64_t e, const double *Di, double gamma, 
         for (int ks = 0; ks < K; ++ks) { double c = alpha * fabs(t[kd] - s[ks]) + S->H[ks]; if (c > m1 && c <= m1 + delta) { fail_margin = 1; break; } }
       }
       g_diag[2] += fail_nnt; g_diag[3] += fail_margin; g_diag[4] += (fail_nnt || fail_margin);
+      if (g_trace_buf && g_trace_n < g_trace_cap) g_trace_buf[g_trace_n] = (uint8_t)((fail_nnt || fail_margin) ? 2 : 0);
     }
   }
   for (int k = 0; k < K; ++k) msg[k] -= vmin;
@@ -396,6 +401,8 @@ static double do_update(solver_t *S, int64_t e, const double *Di, double gamma, 
     int neq = (vbrute != vmin);
     for (int k = 0; k < K && !neq; ++k) if (brute[k] != msg[k]) neq = 1;
     g_diag[1] += neq;
+    if (g_trace_buf && g_trace_n < g_trace_cap) g_trace_buf[g_trace_n] |= (uint8_t)neq;
+    ++g_trace_n;
     free(brute);
   }
   return vmin;

@@ -63,6 +63,19 @@ struct DevParams {
   // completion flag and the label of a boundary node -- straight into THEIR arrays (same index
   // space on every strip; over xGMI when the neighbour is another GPU).  [0] previous, [1] next strip.
   int ntickets[2];
+  // Speculative schedule of the long serial run (trws_graph.h: Sweep::Spec; trws_pipe_kernel, shared positions,
+  // linear kernel).  spec_kind == nullptr: the plain chain schedule.  Flags of the scheme live behind the nodes'
+  // own in `done`: done[N + s] = the runner's rows for segment s are there, done[N + nseg + s] = segment s - 1 has
+  // committed (its last node's rows and label are final).
+  const int32_t *spec_kind[2];        // per run: 0, or 1 + segment index
+  int spec_c0[2], spec_c1[2];         // schedule positions of the cut run
+  int spec_len, spec_nseg, spec_max_len;
+  double *spec_rows;                  // [nseg][8][K]: row j = what the first node of segment s finds as its j-th message
+  int32_t *spec_x;                    // [nseg]: label of the node in front of segment s (primal pass)
+  double *spec_undo;                  // [nseg][max_len][4][K]: the rows a segment's visits overwrite, for a second walk
+  unsigned long long *spec_stat;      // [0] segments walked twice, [1] segments committed, [2] runner visits
+  int tl_stride;                      // runs per direction in `timeline`
+  const DevParams *self;              // this block in global memory (what chain_runner reads its parameters from)
   double *peer_msg0, *peer_msg1;      // (scalars, not arrays: an index computed at run time would put
   int32_t *peer_done0, *peer_done1;   //  the whole parameter block into scratch memory)
   int32_t *peer_x0, *peer_x1;
@@ -1196,8 +1209,10 @@ constexpr int kPipeXchg = 2 * kWave + kWave / 2;  // doubles of a helper's excha
 // allocation; pipe_body carves it in this order): the message routine forms the addresses from these constants and ONE
 // scalar word instead of carrying pointers through its whole length (scalar registers spilled into VGPR lanes cost an
 // instruction per use on the critical path of every visit)
-constexpr int kPipeXchgOff = 2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * kPipeTab + 2 + 3 * kWave / 2 + kWave + 16;
+constexpr int kPipeCtlOff = 2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * kPipeTab;   // ctl words: [0] run, [1] abort, [2] verdict
+constexpr int kPipeXchgOff = kPipeCtlOff + 2 + 3 * kWave / 2 + kWave + 16;
 constexpr int kPipeXflagOff = kPipeXchgOff + kPipeCompute * kPipeXchg;
+constexpr int kPipeLdsDoubles = kPipeXflagOff + kPipeCompute / 2;   // (the runner of the speculative schedule, trws_spec.h, has its LDS behind)
 
 // Min-plus of a destination over the table entries lane + d0 .. lane + d1 (the truncation window or a part of it; the
 // table is padded with +inf entries): four entries per trip, requested together -- one LDS latency per trip, not per entry.

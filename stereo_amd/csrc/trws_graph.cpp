@@ -55,6 +55,12 @@ class Boundary {
 
 }  // namespace
 
+int spec_segment_length() {
+  int L = 16;
+  if (const char *e = std::getenv("STEREO_HIP_TRWS_SPEC_SEG")) L = std::atoi(e);
+  return std::max(4, std::min(L, 48));
+}
+
 #define TICK(name) do { if (std::getenv("STEREO_HIP_GRAPH_VERBOSE")) { auto now_ = std::chrono::steady_clock::now(); std::fprintf(stderr, "[graph] -> %s: %.1f ms\n", name, std::chrono::duration<double, std::milli>(now_ - tick_).count()); tick_ = now_; } } while (0)
 bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
                       std::string &err, int64_t max_resident_runs, const int32_t *owner_in, int nstrips,
@@ -541,6 +547,63 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
       S.chain_run_strip.clear();
       if (own)
         for (int64_t k = 0; k < RR; ++k) S.chain_run_strip.push_back(own[g.order[S.chain_rank[S.chain_run_ptr[k]]]]);
+      // ---- speculative schedule of the one long serial run (trws_graph.h: Sweep::Spec)
+      S.spec = TrwsGraph::Sweep::Spec();
+      if (ok && !own && RR >= 2) {
+        TrwsGraph::Sweep::Spec sp;
+        int64_t best = -1, len1 = 0, len2 = 0;
+        for (int64_t k = 0; k < RR; ++k) {
+          const int64_t len = S.chain_run_ptr[k + 1] - S.chain_run_ptr[k];
+          if (len > len1) { len2 = len1; len1 = len; best = k; } else if (len > len2) len2 = len;
+        }
+        const int L = spec_segment_length();
+        sp.run = (int32_t)best; sp.c0 = S.chain_run_ptr[best]; sp.c1 = S.chain_run_ptr[best + 1];
+        sp.seg_len = L; sp.nseg = (int32_t)(len1 / L); sp.max_len = (int32_t)(len1 - (int64_t)(sp.nseg - 1) * L);
+        bool fine = sp.nseg >= 8 && sp.nseg < (1 << 20) && len1 + 8 >= 2 * len2;
+        auto seg_of = [&](int64_t p) { return (int32_t)std::min<int64_t>((p - sp.c0) / L, sp.nseg - 1); };
+        std::vector<int64_t> pos_of;
+        if (fine) {
+          pos_of.assign(N, -1);
+          for (int64_t p = sp.c0; p < sp.c1; ++p) pos_of[S.chain_rank[p]] = p;
+        }
+        for (int64_t p = sp.c0; p < sp.c1 && fine; ++p) {
+          const int32_t *D = &S.desc[(size_t)p * W];
+          const int nout = D[2] & 15, nin = (D[2] >> 4) & 15, nd = (D[2] >> 8) & 15, ntot = nout + nin;
+          if (nout > 4 || nin > 4) { fine = false; break; }
+          int nfresh = 0, kfirst = ntot, slots[2] = {-1, -1};
+          for (int k = nout; k < ntot; ++k) {
+            const int sl = D[12 + k];
+            if (sl < 0) continue;
+            if (sl >= 4) { fine = false; break; }   // only what the node in front hands over, from its first four messages
+            if (nfresh == 0) kfirst = k;
+            ++nfresh;
+            if (slots[0] < 0 || slots[0] == sl) slots[0] = sl;
+            else if (slots[1] < 0 || slots[1] == sl) slots[1] = sl;
+            else fine = false;
+          }
+          if (p == sp.c0 ? nfresh != 0 : (nfresh < 1)) fine = false;
+          if (ntot - kfirst > 4 || (ntot - kfirst) - nfresh > 3) fine = false;
+          // a dependency inside the run must have committed before the runner gets here: an earlier segment
+          for (int k = 0; k < nd && fine; ++k) {
+            const int32_t x = D[20 + k];
+            if (pos_of[x] >= 0 && seg_of(pos_of[x]) >= seg_of(p)) fine = false;
+          }
+        }
+        if (fine) {
+          for (int64_t k = 0; k < RR; ++k) {
+            if (k == best) for (int32_t q = 0; q < sp.nseg; ++q) { sp.run_ptr.push_back(sp.c0 + q * L); sp.kind.push_back(1 + q); }
+            else { sp.run_ptr.push_back(S.chain_run_ptr[k]); sp.kind.push_back(0); }
+          }
+          sp.run_ptr.push_back(S.chain_run_ptr[RR]);
+          for (int64_t t = 0; t < RR; ++t) {
+            const int32_t k = S.chain_run_order.empty() ? (int32_t)t : S.chain_run_order[t];
+            if (k == best) { sp.run_order.push_back(-1); for (int32_t q = 0; q < sp.nseg; ++q) sp.run_order.push_back((int32_t)best + q); }
+            else sp.run_order.push_back(k < best ? k : k + sp.nseg - 1);
+          }
+          sp.ok = true;
+          S.spec = std::move(sp);
+        }
+      }
     };
 #undef DTICK
     std::thread backward([&] { build_direction(1); });

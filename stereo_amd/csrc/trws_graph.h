@@ -75,6 +75,27 @@ struct TrwsGraph {
     std::vector<int32_t> chain_rank, chain_run_ptr, chain_run_order;
     // strip that owns each run of the rank-contiguous / chain schedule (empty with one strip)
     std::vector<int32_t> run_strip, chain_run_strip;
+    // Speculative schedule.  The image grid's border chain is ONE run of 2(H+W)-4 strictly
+    // serial visits during most of which nothing else can run.  What makes it serial is a single row per
+    // visit -- the message a node hands to the next one -- and that row is plain min-plus of the previous
+    // one whenever the certificate holds.  So the run is cut into segments of `seg_len` visits; a RUNNER
+    // (one wave of one workgroup) walks the whole run computing nothing but that recurrence, uncertified,
+    // and leaves the row at every cut; the segments -- ordinary runs, every visit exact and certified --
+    // start from the runner's rows side by side on as many workgroups, hold their completion flags back,
+    // and COMMIT in order: a segment compares the rows it started from with what the segment in front
+    // really produced (bit for bit) and walks its visits a second time if they differ.  By induction every
+    // committed value is the sequential sweep's.  The schedule below is the chain schedule with that one
+    // run replaced by a runner ticket + its segments; descriptors are shared (the kernel treats the first
+    // visit of a segment differently, nothing in the descriptor says so).
+    struct Spec {
+      bool ok = false;
+      int32_t run = -1;                  // the run of the chain schedule that is cut
+      int32_t c0 = 0, c1 = 0;            // its schedule positions
+      int32_t seg_len = 0, nseg = 0, max_len = 0;
+      std::vector<int32_t> run_ptr;      // CSR over schedule positions, the cut run as nseg runs
+      std::vector<int32_t> run_order;    // ticket -> run; -1: the runner's ticket (just in front of segment 0)
+      std::vector<int32_t> kind;         // per run: 0, or 1 + segment index
+    } spec;
   } sweep[2];
   static constexpr int kDescWords = 64;
   // every node has <= 8 incident edges and <= 4 foreign dependencies per direction
@@ -92,6 +113,8 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
                       std::string &err, int64_t max_resident_runs = 0,
                       const int32_t *owner = nullptr, int nstrips = 1, int64_t certainly_resident = 256,
                       int ordering = 0);
+// visits per segment of the speculative schedule (STEREO_HIP_TRWS_SPEC_SEG, default 16)
+int spec_segment_length();
 // ordering: 0 = SetAutomaticOrdering (ordering.cpp:7-157, what the gateway calls, trws_mex.cpp:121);
 // 1 = node index order, MRFEnergy's order when SetAutomaticOrdering is not called (nodes in the
 // order they were added, MRFEnergy.cpp:37-76).  On the image grid: H + W - 1 anti-diagonal levels,

@@ -8,6 +8,7 @@
 #include "common.h"
 #include "trws_dev.h"
 #include "trws_launch.h"
+#include "trws_spec.h"
 
 namespace stereo {
 namespace {
@@ -52,7 +53,8 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
   const double posk = (SHARED && act) ? p.pos[lane] : 0.0;
   int look_streak = 0;  // failed second looks in a row (this compute wave): see message_regs
   const int perm_shared = (SHARED && wave < kPipeCompute) ? (act ? (int)p.perm_pos[lane] : lane) : -1;  // source order by position, once
-  if (tid == 0) ctl[1] = 0;
+  constexpr bool SPEC = SHARED && KERNEL == 1;   // instantiations the speculative schedule exists for
+  if (tid == 0) { ctl[1] = 0; ctl[2] = 0; ctl[3] = 0; }
   if (tid < kWave) zrow[tid] = 0.0;
   if (tid < 16) gtab[tid] = (double)1 / (double)(tid > 0 ? tid : 1);
   if (tid < kPipeCompute) xflag[tid] = 0;
@@ -74,12 +76,32 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
   if ((p.debug & 4) && BACKWARD) p.prof = nullptr;   // profile forward sweeps only
 
   for (;;) {
-    if (tid == 0) { const int t_ = atomicAdd(p.ticket, 1); ctl[0] = t_ < p.ntickets[D] ? (p.run_order[D] ? p.run_order[D][t_] : t_) : p.nruns[D]; }
+    // (ctl[3]: the workgroup walks the speculative segment it holds a second time -- no new ticket)
+    if (tid == 0 && !(SPEC && ctl[3])) { const int t_ = atomicAdd(p.ticket, 1); ctl[0] = t_ < p.ntickets[D] ? (p.run_order[D] ? p.run_order[D][t_] : t_) : p.nruns[D]; }
     __syncthreads();
     const int run = __builtin_amdgcn_readfirstlane(ctl[0]);
+    const int second_walk = SPEC ? __builtin_amdgcn_readfirstlane(ctl[3]) : 0;
     __syncthreads();
+    if (SPEC && tid == 0) ctl[3] = 0;
     if (run >= p.nruns[D]) break;
+    if (SPEC && run < 0) {   // the runner's ticket of the speculative schedule (trws_spec.h)
+#ifndef STEREO_X_NOCALL
+      chain_runner<BACKWARD, PRIMAL, UPDATE>(p.self, epoch, kPipeLdsDoubles, kPipeCtlOff);
+#endif
+      continue;
+    }
     const int p0 = p.run_ptr[D][run], p1 = p.run_ptr[D][run + 1];
+    // a segment of the speculative schedule (trws_graph.h: Sweep::Spec): its first visit takes what the node in front
+    // hands over from the runner's rows, its completion flags wait for the commit below the visit loops
+    const int seg = (SPEC && p.spec_kind[D]) ? __builtin_amdgcn_readfirstlane(p.spec_kind[D][run]) - 1 : -1;
+    unsigned long long busy = 0;
+#ifdef STEREO_HIP_VISIT_PROFILE
+    unsigned long long vacc[6] = {0, 0, 0, 0, 0, 0}, macc[5] = {0, 0, 0, 0, 0}, lacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define VSTAMP(i) do { const long long n_ = (long long)__builtin_readcyclecounter(); vacc[i] += (unsigned long long)(n_ - vmark); vmark = n_; } while (0)
+#else
+#define VSTAMP(i) do { } while (0)
+#endif
+    const bool spec_in = SPEC && seg > 0 && !second_walk;
     int xprev = 0, xprev2 = 0;  // primal wave: labels of the previous two nodes of the run
     int wnext = 0;              // loader: raw descriptor word of the node after next (prefetched)
     if (wave == kPipeCompute) wnext = desc[(size_t)p0 * DW + lane];
@@ -109,14 +131,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
       if (p0 + 2 < p1) wa3 = desc[(size_t)(p0 + 2) * DW + lane];
       { const int Kv = K, lkv = lane < K ? lane : K - 1; PIPE_REQUEST_OWN(wa1); }
     }
-    if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2] = wall_clock64();
-    unsigned long long busy = 0;
-#ifdef STEREO_HIP_VISIT_PROFILE
-    unsigned long long vacc[6] = {0, 0, 0, 0, 0, 0}, macc[5] = {0, 0, 0, 0, 0}, lacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define VSTAMP(i) do { const long long n_ = (long long)__builtin_readcyclecounter(); vacc[i] += (unsigned long long)(n_ - vmark); vmark = n_; } while (0)
-#else
-#define VSTAMP(i) do { } while (0)
-#endif
+    if (p.timeline && tid == 0) p.timeline[((size_t)D * p.tl_stride + run) * 2] = wall_clock64();
 
     // Every role walks the run in its own loop -- the same visits, the same barrier at the end of each: the hardware
     // barrier counts arrivals, whichever s_barrier instruction a wave arrives at -- so that what one role keeps across
@@ -265,14 +280,27 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           const int w = wnext;
           if (pos + 2 < p1) wnext = desc[(size_t)(pos + 2) * DW + lane];
           int *stni = (int *)(stn + kStI);
-          stni[lane] = w;
+          // (first visit of a speculative segment: the rows of the node in front come from the runner, behind the
+          //  segment's flag -- to everybody else in the workgroup they look like rows of another run)
+          //  (a second walk takes the same rows from the messages themselves: the segment in front has committed)
+          const bool sfirst = SPEC && seg > 0 && pos + 1 == p0;
+          stni[lane] = (sfirst && lane >= 12 && lane < 20 && w >= 0) ? -1 : w;
           dring[((pos + 1) % 3) * kWave + lane] = w;
           const int f = RLI(w, 2);
-          const int nout = f & 15, ntot = nout + ((f >> 4) & 15), ndep = (f >> 8) & 15;
-          const int fm = RLI(w, kDescFetch) & 255;   // incoming rows that come from global memory (behind flags)
+          const int nout = f & 15, ntot = nout + ((f >> 4) & 15);
+          int ndep = (f >> 8) & 15;
+          int fm = RLI(w, kDescFetch) & 255;   // incoming rows that come from global memory (behind flags)
           const int j8 = lane & 7;
-          const int sl = __shfl(w, 12 + j8, kWave);  // lane j: hand-over slot of the node's edge j, label source
+          int sl = __shfl(w, 12 + j8, kWave);  // lane j: hand-over slot of the node's edge j, label source
           const int xn = __shfl(w, 32 + j8, kWave);
+          int smask = 0, deprank = __shfl(w, 20 + (lane & 3), kWave);
+          if (sfirst) {
+            smask = (int)(__builtin_amdgcn_ballot_w64(lane < 8 && lane >= nout && lane < ntot && sl >= 0) & 255ull);
+            fm |= smask;
+            sl = -1;
+            deprank = lane == ndep ? p.N + seg : deprank;
+            ++ndep;
+          }
           {
             // where the compute waves find the node's message rows at visit pos + 1: a message handed
             // over inside the run sits in the ring of the last two visits, everything else in this
@@ -300,13 +328,17 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           for (int k = 0; k < 4; ++k) {
             jr[k] = mrest ? __builtin_ctz(mrest) : -1;
             mrest &= mrest - 1;
-            fa[k] = PIPE_ROW((p.msg + lkv), __builtin_amdgcn_readlane(w, 4 + (jr[k] >= 0 ? jr[k] : 0)));
+            const int jk = jr[k] >= 0 ? jr[k] : 0;
+            fa[k] = (SPEC && spec_in && ((smask >> jk) & 1)) ? PIPE_ROW((p.spec_rows + lkv), seg * 8 + jk)
+                                                 : PIPE_ROW((p.msg + lkv), __builtin_amdgcn_readlane(w, 4 + jk));
           }
-          const int32_t *xa = p.x + xn;
+          // (the label of the node in front of a speculative segment: the runner's, kept apart from p.x -- what the commit
+          //  compares must be what was read here)
+          const int32_t *xa = (SPEC && spec_in && ((smask >> j8) & 1)) ? p.spec_x + seg : p.x + xn;
 #ifdef STEREO_HIP_VISIT_PROFILE
           const long long lb0 = (long long)__builtin_readcyclecounter();
 #endif
-          if (ndep > 0) wait_for_dependencies_w(p, ndep, __shfl(w, 20 + (lane & 3), kWave), RLI(w, 1), epoch, lane, ctl + 1);
+          if (ndep > 0) wait_for_dependencies_w(p, ndep, deprank, RLI(w, 1), epoch, lane, ctl + 1);
 #ifdef STEREO_HIP_VISIT_PROFILE
           const long long lb1 = (long long)__builtin_readcyclecounter();
 #endif
@@ -321,7 +353,8 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           while (mrest) {   // rows five to eight (rare)
             const int jx = __builtin_ctz(mrest);
             mrest &= mrest - 1;
-            stn[kStM + jx * kWave + lane] = ld_sc1(PIPE_ROW((p.msg + lkv), __builtin_amdgcn_readlane(w, 4 + jx)));
+            stn[kStM + jx * kWave + lane] = ld_sc1((SPEC && spec_in && ((smask >> jx) & 1)) ? PIPE_ROW((p.spec_rows + lkv), seg * 8 + jx)
+                                                                                : PIPE_ROW((p.msg + lkv), __builtin_amdgcn_readlane(w, 4 + jx)));
           }
           if (lane < 8) stni[64 + lane] = pxv;
 #ifdef STEREO_HIP_VISIT_PROFILE
@@ -378,6 +411,12 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           for (int j = 0; j < 8; ++j) {
             if (j < nout) stn[kStM + j * kWave + lane] = rmv[j];
             if (!SHARED && j < nout + nin) { stn[kStQ + j * kWave + lane] = rqv[j]; stn[kStQP + j * kWave + lane] = rqpv[j]; }
+          }
+          if (SPEC && UPDATE && seg >= 0 && !second_walk) {
+            // a speculative segment keeps the rows its visits overwrite: a second walk starts from them (below)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (j < nout) st_sc1(PIPE_ROW(p.spec_undo + lkv, (seg * p.spec_max_len + (pos + 1 - p0)) * 4 + j), rmv[j]);
           }
           if (lane < 8) stn[kStA + lane] = rav;
           if (lane == 0) stn[kStG] = gtab[nout > nin ? nout : nin];
@@ -487,7 +526,7 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
           }
 #endif
           if (lane == 0) {
-            st_sc1(p.done + s_rank, epoch);
+            if (!(SPEC && seg >= 0)) st_sc1(p.done + s_rank, epoch);   // (a speculative segment raises its flags when it commits)
             if (s_remote & (1 << 16)) st_sc1(p.peer_done0 + s_pn0, epoch);
             if (s_remote & (1 << 17)) st_sc1(p.peer_done1 + s_pn1, epoch);
           }
@@ -572,7 +611,12 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
       VSTAMP(5);
     }
     }
-    if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2 + 1] = wall_clock64();
+    if (SPEC && seg >= 0) {
+      const int verdict = spec_commit<BACKWARD, PRIMAL, UPDATE>(p.self, epoch, p0, p1, seg, spec_in ? 1 : 0);
+      if (verdict == 2) return;
+      if (verdict == 1) continue;   // (ctl[3] is set: the same run once more)
+    }
+    if (p.timeline && tid == 0) p.timeline[((size_t)D * p.tl_stride + run) * 2 + 1] = wall_clock64();
     if (p.prof && lane == 0 && (p.prof_run < 0 || run == p.prof_run)) {
       // busy cycles before the barrier per role: compute (wave 0), loader, storer, primal; steps
       const int slot = wave == 0 ? 0 : wave == kPipeCompute ? 1 : wave == kPipeCompute + 1 ? 2 : wave == kPipeCompute + 3 ? 3 : -1;
@@ -608,13 +652,15 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_group_kernel(GroupArgs
 }  // namespace
 
 size_t pipe_lds_bytes() {
-  return sizeof(double) * (2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * kPipeTab + 2 + 3 * kWave / 2 + kWave + 16 +
-                         kPipeCompute * kPipeXchg + kPipeCompute / 2);
+  static_assert(kPipeLdsDoubles == 2 * kStageDoubles + 4 * 8 * kWave + 2 * kScalDoubles + kPipeCompute * kPipeTab + 2 + 3 * kWave / 2 + kWave + 16 +
+                                   kPipeCompute * kPipeXchg + kPipeCompute / 2, "LDS layout of pipe_body");
+  return sizeof(double) * kPipeLdsDoubles;
 }
+size_t pipe_spec_lds_bytes() { return sizeof(double) * (kPipeLdsDoubles + kRunDoubles); }   // ... with the runner's ring behind
 int pipe_threads() { return kPipeThreads; }
 
 void pipe_set_attributes() {
-  const int lds = (int)pipe_lds_bytes();
+  const int lds = (int)pipe_spec_lds_bytes();
 #define SET_P(KER, BW, PR, UP)                                                                                                          \
   STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_pipe_kernel<KER, BW, PR, UP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));        \
   STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_pipe_kernel<KER, BW, PR, UP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));       \
@@ -626,7 +672,7 @@ void pipe_set_attributes() {
 }
 
 #define PIPE_SWITCH(NAME, ARG)                                                                                          \
-  const size_t plds = pipe_lds_bytes();                                                                                 \
+  const size_t plds = spec ? pipe_spec_lds_bytes() : pipe_lds_bytes();                                                  \
   const dim3 grid(blocks), block(kPipeThreads);                                                                         \
   _Pragma("clang diagnostic push")                                                                                      \
   if (kernel == 1) { PIPE4(NAME, 1, ARG) } else { PIPE4(NAME, 2, ARG) }                                                 \
@@ -646,9 +692,11 @@ void pipe_set_attributes() {
   }
 
 void launch_pipe(int kernel, bool shared, int what, int blocks, hipStream_t s, const DevParams &p, int epoch) {
+  const bool spec = p.spec_kind[0] != nullptr || p.spec_kind[1] != nullptr;   // (the runner's LDS lies behind the visits')
   PIPE_SWITCH(trws_pipe_kernel, p)
 }
 void launch_pipe_group(int kernel, bool shared, int what, int blocks, hipStream_t s, const GroupArgs &ga, int epoch) {
+  const bool spec = false;   // (strips keep the plain chain schedule)
   PIPE_SWITCH(trws_pipe_group_kernel, ga)
 }
 #undef PIPE4

@@ -63,7 +63,7 @@ __device__ __forceinline__ void pipe2_body(DevParams p, int epoch) {
     int xprev = 0, xprev2 = 0;
     int wnext = 0;
     if (wave == kPipeCompute) wnext = desc[(size_t)p0 * DW + lane];
-    if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2] = wall_clock64();
+    if (p.timeline && tid == 0) p.timeline[((size_t)D * p.tl_stride + run) * 2] = wall_clock64();
 
     unsigned long long busy = 0;  // development profile (STEREO_HIP_TRWS_PROF): cycles from barrier to barrier arrival
     // (every role walks the run in its own loop, as in trws_pipe.hip: the same visits, the same barrier, registers per role)
@@ -521,7 +521,7 @@ __device__ __forceinline__ void pipe2_body(DevParams p, int epoch) {
       }
     }
     }
-    if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2 + 1] = wall_clock64();
+    if (p.timeline && tid == 0) p.timeline[((size_t)D * p.tl_stride + run) * 2 + 1] = wall_clock64();
     if (p.prof && lane == 0 && (p.prof_run < 0 || run == p.prof_run)) {
       atomicAdd(p.prof + 32 + wave, busy);
       if (wave == 0) atomicAdd(p.prof + 6, (unsigned long long)(p1 - p0));

@@ -223,6 +223,14 @@ struct stereo_trws_plan {
   hipStream_t own_stream = nullptr;  // strips launch concurrently: never on the NULL stream
   bool issued = false;
   int cus = 256;
+  // speculative schedule of the long serial run (trws_graph.h: Sweep::Spec; trws_spec.h)
+  DevBuf<int32_t> d_spec_run_ptr[2], d_spec_run_order[2], d_spec_kind[2], d_spec_x;
+  DevBuf<double> d_spec_rows, d_spec_undo;
+  DevBuf<unsigned long long> d_spec_stat;
+  DevBuf<DevParams> d_self;
+  PinnedBuf<DevParams> h_self;
+  bool spec_allowed = false;   // the graph has such a run in both directions and STEREO_HIP_TRWS_SPEC is not 0
+  bool spec_window = false;    // the positions are uniformly spaced over the window rounded up to four (finish_inputs)
   ~stereo_trws_plan() {
     for (int w = 0; w < 2; ++w)
       for (int k = 0; k < 3; ++k)
@@ -240,7 +248,15 @@ namespace {
 
 size_t persistent_lds_bytes(int Kp) { return generic_lds_bytes(Kp); }
 
-DevParams make_params(stereo_trws_plan *P) {
+// The speculative schedule runs where its runner's arithmetic is what message_regs returns under a passed certificate:
+// trws_pipe_kernel, linear kernel, certified messages, shared strictly ascending positions, uniformly spaced over the
+// truncation window (rounded up to a multiple of four entries).
+bool spec_active(const stereo_trws_plan *P) {
+  return P->spec_allowed && P->fast && !P->wide && !P->fast2 && P->nstrips == 1 && P->kernel == 1 && P->certificate && P->pos != nullptr &&
+         P->pos_ascending && P->window <= 16 && P->uniform_step != 0 && P->spec_window;
+}
+
+DevParams make_params(stereo_trws_plan *P, bool allow_spec = true) {
   DevParams p{};
   p.K = P->K; p.Kp = P->Kp; p.kernel = P->kernel; p.lambda = P->lambda;
   p.unary = P->unary; p.msg = P->d_msg.p; p.q = P->q; p.qprim = P->qprim; p.pos = P->pos;
@@ -287,6 +303,21 @@ DevParams make_params(stereo_trws_plan *P) {
   p.pos_first = P->pos_first; p.pos_last = P->pos_last;
   p.debug = 0;
   if (const char *dbg = std::getenv("STEREO_HIP_TRWS_DEBUG")) p.debug = std::atoi(dbg);
+  p.tl_stride = p.nruns[0];
+  p.self = P->d_self.p;
+  if (allow_spec && spec_active(P)) {
+    // the chain schedule with the long run cut into segments + the runner's ticket
+    for (int d = 0; d < 2; ++d) {
+      const TrwsGraph::Sweep::Spec &sp = P->graph->sweep[d].spec;
+      p.run_ptr[d] = P->d_spec_run_ptr[d].p; p.nruns[d] = (int)sp.kind.size();
+      p.run_order[d] = P->d_spec_run_order[d].p; p.ntickets[d] = (int)sp.run_order.size();
+      p.spec_kind[d] = P->d_spec_kind[d].p; p.spec_c0[d] = sp.c0; p.spec_c1[d] = sp.c1;
+    }
+    const TrwsGraph::Sweep::Spec &sp = P->graph->sweep[0].spec;
+    p.spec_len = sp.seg_len; p.spec_nseg = sp.nseg; p.spec_max_len = sp.max_len;
+    p.spec_rows = P->d_spec_rows.p; p.spec_x = P->d_spec_x.p; p.spec_undo = P->d_spec_undo.p; p.spec_stat = P->d_spec_stat.p;
+    p.tl_stride = std::max(p.nruns[0], p.nruns[1]);
+  }
   p.win_ok = (P->pos_ascending && P->window <= 16 && !(p.debug & 256)) ? 1 : 0;
   p.pos_gap = P->pos_gap;
   if (const char *pr = std::getenv("STEREO_HIP_TRWS_PROF_RUN")) p.prof_run = std::atoi(pr);
@@ -335,7 +366,7 @@ void run_argsort(const double *vals, uint16_t *perm, int K, int64_t count, hipSt
 void reset_state(stereo_trws_plan *P) {
   STEREO_HIP_CHECK(hipMemset(P->d_msg.p, 0, sizeof(double) * (size_t)P->El * P->K));
   STEREO_HIP_CHECK(hipMemset(P->d_x.p, 0, sizeof(int32_t) * P->Nl));
-  STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * P->Nl));
+  STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * P->d_done.n));
   STEREO_HIP_CHECK(hipMemset(P->d_ctl.p, 0, sizeof(int32_t) * kCtlWords));
   STEREO_HIP_CHECK(hipDeviceSynchronize());
   P->iterations = 0; P->energy = 0; P->lb = 0; P->epoch = 0; P->fwd_pending = false;
@@ -424,7 +455,7 @@ void finish_inputs(stereo_trws_plan *P) {
   STEREO_HIP_CHECK(hipDeviceSynchronize());
   // shared positions that are finite and strictly ascending: truncation window in index steps
   // (windowed min-plus of the pipelined kernel's flat-h path; the wide-label kernel requires it)
-  P->wide = false; P->uniform_step = 0; P->pos_ascending = false; P->window = 0;
+  P->wide = false; P->uniform_step = 0; P->pos_ascending = false; P->window = 0; P->spec_window = false;
   if (P->pos && P->lambda >= 0) {
     std::vector<double> hp(P->K);
     STEREO_HIP_CHECK(hipMemcpy(hp.data(), P->pos, sizeof(double) * P->K, hipMemcpyDeviceToHost));
@@ -455,6 +486,15 @@ void finish_inputs(stereo_trws_plan *P) {
         for (int d = 1; d <= w && uni; ++d)
           for (int k = 0; k + d < P->K && uni; ++k) uni = (hp[k + d] - hp[k]) == (double)d * step;
         if (uni) P->uniform_step = step;
+        // the runner of the speculative schedule (trws_spec.h) walks the window in groups of four entries: the
+        // spacing must hold for those too, and what lies beyond the window must cost >= vTrunc as an index distance
+        const int wr = (w + 3) & ~3;
+        bool spw = uni && P->kernel == 1;
+        for (int d = w + 1; d <= wr && spw; ++d) {
+          spw = (double)d * step > P->lambda;
+          for (int k = 0; k + d < P->K && spw; ++k) spw = (hp[k + d] - hp[k]) == (double)d * step;
+        }
+        P->spec_window = spw;
       }
     }
   }
@@ -620,6 +660,29 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
       }
     }
     }
+    {
+      const TrwsGraph::Sweep::Spec &s0 = g.sweep[0].spec, &s1 = g.sweep[1].spec;
+      bool on = g.fast_ok && nstrips == 1 && s0.ok && s1.ok && s0.nseg == s1.nseg && s0.seg_len == s1.seg_len && K <= kWave;
+      if (const char *e = std::getenv("STEREO_HIP_TRWS_SPEC")) on = on && std::atoi(e) != 0;
+      P->spec_allowed = on;
+      if (on) {
+        for (int d = 0; d < 2; ++d) {
+          const TrwsGraph::Sweep::Spec &sp = g.sweep[d].spec;
+          P->d_spec_run_ptr[d].upload(sp.run_ptr.data(), sp.run_ptr.size());
+          P->d_spec_run_order[d].upload(sp.run_order.data(), sp.run_order.size());
+          P->d_spec_kind[d].upload(sp.kind.data(), sp.kind.size());
+        }
+        const size_t ml = (size_t)std::max(s0.max_len, s1.max_len);
+        P->d_spec_rows.alloc((size_t)s0.nseg * 8 * K);
+        P->d_spec_undo.alloc((size_t)s0.nseg * ml * 4 * K);
+        P->d_spec_x.alloc(s0.nseg);
+        P->d_spec_stat.alloc(4);
+        STEREO_HIP_CHECK(hipMemset(P->d_spec_stat.p, 0, 4 * sizeof(unsigned long long)));
+        STEREO_HIP_CHECK(hipMemset(P->d_spec_rows.p, 0, sizeof(double) * (size_t)s0.nseg * 8 * K));
+        STEREO_HIP_CHECK(hipMemset(P->d_spec_x.p, 0, sizeof(int32_t) * s0.nseg));
+      }
+      P->d_self.alloc(1); P->h_self.alloc(1);
+    }
     P->fast = g.fast_ok && K <= kWave && message_mode == STEREO_TRWS_MESSAGES_EXACT;
     P->wide_allowed = g.fast_ok && (kernel == 1 || message_mode == STEREO_TRWS_MESSAGES_EXACT) && K > kWave && K <= 256;
     P->fast2 = g.fast_ok && K > kWave && K <= 2 * kWave && message_mode == STEREO_TRWS_MESSAGES_EXACT;   // (both smoothness kernels since round 5)
@@ -642,7 +705,9 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
     // device (logical strips, tests) stay in ordinary memory.  STEREO_HIP_STRIPS_FINEGRAINED=0/1 overrides.
     bool fine = nstrips > 1 && stereo_hip_device_count() > 1;
     if (const char *fg = std::getenv("STEREO_HIP_STRIPS_FINEGRAINED")) fine = nstrips > 1 && std::atoi(fg) != 0;
-    if (fine) P->d_done.alloc_fine_grained(P->Nl); else P->d_done.alloc(P->Nl);
+    // (behind the nodes' flags: the speculative schedule's, two per segment)
+    const size_t n_flags = (size_t)P->Nl + (P->spec_allowed ? 2 * (size_t)g.sweep[0].spec.nseg + 2 : 0);
+    if (fine) P->d_done.alloc_fine_grained(n_flags); else P->d_done.alloc(n_flags);
     P->d_ctl.alloc(kCtlWords);
     P->d_fallbacks.alloc(1);
     STEREO_HIP_CHECK(hipMemset(P->d_fallbacks.p, 0, sizeof(unsigned long long)));
@@ -657,8 +722,9 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
     }
     if (std::getenv("STEREO_HIP_TRWS_PROF")) { P->d_prof.alloc(64); STEREO_HIP_CHECK(hipMemset(P->d_prof.p, 0, 512)); }
     if (std::getenv("STEREO_HIP_TRWS_TIMELINE"))
-      P->d_timeline.alloc(4 * std::max({g.sweep[0].run_ptr.size(), g.sweep[0].chain_run_ptr.size(), g.sweep[1].chain_run_ptr.size()}) + 4);
-    STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * P->Nl));
+      P->d_timeline.alloc(4 * std::max({g.sweep[0].run_ptr.size(), g.sweep[0].chain_run_ptr.size(), g.sweep[1].chain_run_ptr.size(),
+                                         g.sweep[0].spec.kind.size() + 1, g.sweep[1].spec.kind.size() + 1}) + 8);
+    STEREO_HIP_CHECK(hipMemset(P->d_done.p, 0, sizeof(int32_t) * P->d_done.n));
     STEREO_HIP_CHECK(hipMemset(P->d_ctl.p, 0, sizeof(int32_t) * kCtlWords));
     {
       // one workgroup per concurrently active run, capped by what stays resident
@@ -666,6 +732,7 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
       if (g.fast_ok)
         runs = std::max<int64_t>({runs, (int64_t)g.sweep[0].chain_run_ptr.size() - 1, (int64_t)g.sweep[1].chain_run_ptr.size() - 1});
       if (nstrips > 1) runs = std::max<int64_t>({1, (int64_t)P->ntickets[0], (int64_t)P->ntickets[1]});
+      if (P->spec_allowed) runs = std::max<int64_t>({runs, (int64_t)g.sweep[0].spec.run_order.size(), (int64_t)g.sweep[1].spec.run_order.size()});
       P->grid_blocks = (int)std::min<int64_t>(runs, P->cus * per_cu);
       if (max_blocks > 0) P->grid_blocks = std::min(P->grid_blocks, max_blocks);
     }
@@ -716,9 +783,22 @@ void stereo_trws_plan_destroy(stereo_trws_plan *plan) {
   DeviceScope device_scope_(plan ? plan->device : -1);
   if (plan && plan->d_timeline.p) {
     const bool chain = plan->graph->fast_ok && (plan->wide || plan->fast2 || plan->fast);
-    const size_t R = (chain ? plan->graph->sweep[0].chain_run_ptr.size() : plan->graph->sweep[0].run_ptr.size()) - 1;
-    std::vector<unsigned long long> t(4 * (R + 1));
-    if (hipMemcpy(t.data(), plan->d_timeline.p, sizeof(unsigned long long) * 4 * R, hipMemcpyDeviceToHost) == hipSuccess) {
+    const bool spec = spec_active(plan);
+    const size_t R = spec ? std::max(plan->graph->sweep[0].spec.kind.size(), plan->graph->sweep[1].spec.kind.size())
+                          : (chain ? plan->graph->sweep[0].chain_run_ptr.size() : plan->graph->sweep[0].run_ptr.size()) - 1;
+    std::vector<unsigned long long> t(4 * (R + 1) + 8);
+    if (hipMemcpy(t.data(), plan->d_timeline.p, sizeof(unsigned long long) * (4 * R + 4), hipMemcpyDeviceToHost) == hipSuccess) {
+      if (spec)
+        for (int d = 0; d < 2; ++d) {
+          const auto &sp = plan->graph->sweep[d].spec;
+          const unsigned long long t0 = t[(2 * R + d) * 2];
+          std::fprintf(stderr, "[stereo_hip timeline] dir %d speculative: runner %.0f us; segments (us since the runner started, start..commit): ", d,
+                       (t[(2 * R + d) * 2 + 1] - t0) / 100.0);
+          for (int q = 0; q < sp.nseg; q += std::max(1, sp.nseg / 8))
+            std::fprintf(stderr, "seg%d[%.0f..%.0f] ", q, ((double)t[((size_t)d * R + sp.run + q) * 2] - (double)t0) / 100.0,
+                         ((double)t[((size_t)d * R + sp.run + q) * 2 + 1] - (double)t0) / 100.0);
+          std::fprintf(stderr, "last[..%.0f]\n", ((double)t[((size_t)d * R + sp.run + sp.nseg - 1) * 2 + 1] - (double)t0) / 100.0);
+        }
       for (int d = 0; d < 2; ++d) {
         const unsigned long long t0 = t[(size_t)d * R * 2];
         std::fprintf(stderr, "[stereo_hip timeline] dir %d (us since run 0 start): ", d);
@@ -985,6 +1065,8 @@ int stereo_trws_plan_iterate(stereo_trws_plan *P, int iters, double max_relgap, 
   hipStream_t s = (hipStream_t)stream;
   try {
     const DevParams p = make_params(P);
+    *P->h_self.p = p;   // (the block once more in global memory: chain_runner / spec_commit read their parameters there)
+    STEREO_HIP_CHECK(hipMemcpyAsync(P->d_self.p, P->h_self.p, sizeof(DevParams), hipMemcpyHostToDevice, s));
     for (int it = 0; it < iters; ++it) {
       issue_iteration(P, p, s);
       double lb = 0, en = 0;
@@ -1045,7 +1127,7 @@ int stereo_trws_plans_issue(stereo_trws_plan *const *plans, int n, void *stream,
     hipStream_t s = stream ? (hipStream_t)stream : P0->own_stream;
     if (!s) return fail("stereo_trws_plans_issue: a plain plan needs an explicit stream here", err, errcap);
     if (P0->d_group.n < (size_t)n) { P0->d_group.alloc(kMaxGroup); P0->h_group.alloc(kMaxGroup); }
-    for (int i = 0; i < n; ++i) P0->h_group.p[i] = make_params(plans[i]);
+    for (int i = 0; i < n; ++i) P0->h_group.p[i] = make_params(plans[i], false);   // (group launches keep the plain chain schedule)
     STEREO_HIP_CHECK(hipMemcpyAsync(P0->d_group.p, P0->h_group.p, sizeof(DevParams) * n, hipMemcpyHostToDevice, s));
     if (P0->time_sweeps) STEREO_HIP_CHECK(hipEventRecord(P0->ev0, s));
     if (!P0->fwd_pending) launch_group(plans, n, 0, s);
@@ -1238,6 +1320,18 @@ int stereo_trws_plan_counters(stereo_trws_plan *P, int64_t *serial_messages, int
   if (hipMemcpy(&v, P->d_fallbacks.p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 1;
   if (serial_messages) *serial_messages = (int64_t)v;
   if (reset && hipMemset(P->d_fallbacks.p, 0, sizeof(v)) != hipSuccess) return 1;
+  return 0;
+}
+
+int stereo_trws_plan_spec_stats(stereo_trws_plan *P, int64_t out[4]) {
+  DeviceScope device_scope_(P ? P->device : -1);
+  if (!P || !out) return 1;
+  out[0] = spec_active(P) ? 1 : 0; out[1] = out[2] = out[3] = 0;
+  if (P->d_spec_stat.p) {
+    unsigned long long v[4] = {0, 0, 0, 0};
+    if (hipMemcpy(v, P->d_spec_stat.p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    out[1] = (int64_t)v[0]; out[2] = (int64_t)v[1]; out[3] = (int64_t)v[2];
+  }
   return 0;
 }
 

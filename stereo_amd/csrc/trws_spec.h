@@ -1,0 +1,461 @@
+// The RUNNER of the speculative schedule (trws_graph.h: Sweep::Spec), for trws_pipe_kernel with shared
+// uniformly spaced positions and the linear kernel.  One workgroup draws the runner's ticket and walks the whole cut run
+// computing nothing but the recurrence that makes the run serial:
+//   wave 0      messages: Di of node i from the staged prefix sum and the row(s) node i - 1 handed over, H = gamma Di - m,
+//               plain windowed min-plus (what message_regs returns whenever its certificate holds), the row for node i + 1
+//               stays in registers -- no certificate, no tangency keys, no barrier, ~100 instructions per visit;
+//   wave 1      labels of the primal pass: x_i from x_(i-1), exact (the same operations as the primal wave of a visit);
+//   waves 2-9   loaders: descriptor of node i, its foreign flags, unary + message rows, prefix sum in list order, into a
+//               ring of kRunSlots staged nodes in LDS (node i belongs to loader i mod 8);
+//   wave 10     publisher: at every cut, the rows / label of the node in front go to p.spec_rows / p.spec_x, drained, then
+//               the segment's flag done[N + s].
+// Nothing here decides a result: the segments recompute every visit with the certified routine and compare what they
+// started from with what the segment in front produced (pipe_body's commit).  A wrong row costs a second walk of one or
+// more segments, never a wrong bit.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "trws_dev.h"
+
+namespace stereo {
+namespace {
+
+constexpr int kRunSlots = 12;
+constexpr int kRunLoaders = 8;
+// a staged node (doubles): prefix sum P | up to three staged rows of the tail | unary | the node's own (outgoing) rows | words
+constexpr int kRunRowP = 0, kRunRowS = 64, kRunRowTH = 256, kRunRowOUT = 320, kRunSc = 576;
+constexpr int kRunSlotDoubles = kRunSc + 16;
+constexpr int kRunTab = kRunSlots * kRunSlotDoubles;   // 16 + 64 + 16: H with +inf on both sides
+constexpr int kRunPub = kRunTab + 96;                  // 2 x (2 rows): what the publisher stores
+constexpr int kRunWords = kRunPub + 256;               // 64 ints (below)
+constexpr int kRunDoubles = kRunWords + 32;
+// words: ready[kRunSlots] | consumed by messages, by labels | publisher flags (rows x 2, labels x 2) | slots freed |
+//        label x 2 | node x 2 | row kinds x 2
+constexpr int kRwReady = 0, kRwConsM = 12, kRwConsP = 13, kRwPubM = 14, kRwPubP = 16, kRwFree = 18, kRwLabel = 20, kRwNode = 22,
+              kRwKinds = 24;
+// words of a staged node: tail length | tail kinds (a nibble each: 0-2 staged row, 8 / 9 first / second handed-over row)
+// | messages to compute (0, 1, 2) | their slots in the node's outgoing list x 2 | cut: segment that starts behind this
+// node (0: none) | kinds of that segment's first node's rows (a nibble per row) | n_out | incoming rows | their label
+// (-1: the node in front) x 4 | their direction bits | node id; doubles 8-15: alpha x 2, gamma, alpha of the incoming rows x 4
+constexpr int kRsNt = 0, kRsKinds = 1, kRsNmsg = 2, kRsS0 = 3, kRsS1 = 4, kRsCut = 5, kRsPubKinds = 6, kRsNout = 7, kRsNin = 8,
+              kRsSrc = 9, kRsMd = 13, kRsNode = 14;
+
+__device__ __forceinline__ int lds_load(const int *w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_store(int *w, int v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// Waits until *word >= want.  Everything the runner's waves wait for inside the workgroup ends with a loader's wait for
+// another workgroup, which is bounded by the wall clock and raises the abort word when it gives up; this wait looks at
+// that word (and, as a last resort against a hang, at the clock itself).
+__device__ __forceinline__ bool run_wait(const DevParams &p, const int *word, int want, int *abort_word) {
+  int spins = 0;
+  long long t0 = 0;
+  while (lds_load(word) < want) {
+    __builtin_amdgcn_s_sleep(1);
+    spins = (spins + 1) & 1023;
+    if (spins != 0) continue;
+    if (lds_load(abort_word) || ld_sc1(p.abort_flag)) return false;
+    const long long now = (long long)wall_clock64();
+    if (t0 == 0) { t0 = now | 1; continue; }
+    if (now - t0 > 4 * p.spin_ticks) { lds_store(abort_word, 1); return false; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return true;
+}
+
+#define RLI(v, i) __builtin_amdgcn_readlane((v), (i))
+
+// ---- wave 0: the message recurrence ------------------------------------------------------------------------------
+template <bool BACKWARD>
+__device__ __forceinline__ void run_messages(const DevParams &p, double *rb, int c0, int c1, int lane, int *abort_word) {
+  const double inf = __builtin_huge_val();
+  const int K = p.K;
+  const bool act = lane < K;
+  int *rw = (int *)(rb + kRunWords);
+  double *tabl = rb + kRunTab + 16 + lane;   // this lane's entry of the H table
+  const int wgroups = (p.window + 3) >> 2;   // the window in groups of four (entries beyond it cost >= vTrunc bit for bit)
+  double ad[16];
+  double alpha_have = 0;
+#pragma unroll
+  for (int d = 0; d < 16; ++d) ad[d] = 0;
+  bool have_ad = false;
+  double A0 = 0, A1 = 0;
+  for (int i = c0; i < c1; ++i) {
+    const int slot = (i - c0) % kRunSlots;
+    const double *sl = rb + slot * kRunSlotDoubles;
+    if (!run_wait(p, rw + kRwReady + slot, i + 1, abort_word)) return;
+    const int sw = ((const int *)(sl + kRunSc))[lane & 15];
+    const double sd = sl[kRunSc + 8 + (lane & 7)];
+    const int nt = RLI(sw, kRsNt), kinds = RLI(sw, kRsKinds), nmsg = RLI(sw, kRsNmsg), s0 = RLI(sw, kRsS0), s1 = RLI(sw, kRsS1);
+    const int cut = RLI(sw, kRsCut);
+    // (all rows are requested together: one LDS latency)
+    const double P = sl[kRunRowP + lane], S0 = sl[kRunRowS + lane], S1 = sl[kRunRowS + 64 + lane], S2 = sl[kRunRowS + 128 + lane];
+    const double m0 = sl[kRunRowOUT + (s0 < 0 ? 0 : s0) * 64 + lane], m1 = sl[kRunRowOUT + (s1 < 0 ? 0 : s1) * 64 + lane];
+    double Di = P;
+    // the tail of the node's list from the first handed-over row on, in list order (the order of the reference's additions)
+    switch (kinds | (nt << 16)) {
+      case 0x20098: Di += A0; Di += A1; break;                           // handed over, handed over (forward chain)
+      case 0x30908: Di += A0; Di += S0; Di += A1; break;                 // ... with a row of another run in between
+      case 0x30098: Di += A0; Di += A1; Di += S0; break;
+      case 0x41908: Di += A0; Di += S0; Di += A1; Di += S1; break;
+      default:
+        for (int t = 0; t < nt; ++t) {
+          const int kd = (kinds >> (4 * t)) & 15;
+          if (kd == 8) Di += A0; else if (kd == 9) Di += A1; else if (kd == 0) Di += S0; else if (kd == 1) Di += S1; else Di += S2;
+        }
+    }
+    if (BACKWARD) Di -= wave_min_dpp(act ? Di : inf);   // minimize.cpp:79-83 (the node's own lower-bound term)
+    const double gamma = readlane_f64(sd, 2);
+    double R0 = 0, R1 = 0;
+    for (int m = 0; m < nmsg; ++m) {
+      const double alpha = readlane_f64(sd, m);
+      const double mold = m == 0 ? m0 : m1;
+      const double h = act ? gamma * Di - mold : inf;
+      double out;
+      if (alpha == 0) {
+        out = 0;   // typeStereoLinear.h:390-396: a constant row, normalised
+      } else {
+        *tabl = h;
+        if (!(have_ad && alpha == alpha_have)) {
+#pragma unroll
+          for (int d = 0; d < 16; ++d) ad[d] = alpha * ((double)(d + 1) * p.uniform_step);
+          alpha_have = alpha; have_ad = true;
+        }
+        const double hmin = wave_min_dpp(h);
+        const double vtrunc = hmin + alpha * p.lambda;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double mm = h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (g < wgroups) {
+            double lo[4], hi[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) { lo[d] = tabl[-(4 * g + d + 1)]; hi[d] = tabl[4 * g + d + 1]; }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) { mm = min_raw(mm, lo[d] + ad[4 * g + d]); mm = min_raw(mm, hi[d] + ad[4 * g + d]); }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        out = min_raw(mm, vtrunc) - hmin;
+      }
+      if (m == 0) R0 = out; else R1 = out;
+    }
+    A0 = R0; A1 = nmsg == 2 ? R1 : R0;
+    if (cut) {
+      // the rows the segment behind this node starts from: to the publisher
+      const int ps = cut & 1;
+      if (!run_wait(p, rw + kRwFree, cut - 2, abort_word)) return;
+      double *pb = rb + kRunPub + ps * 128;
+      pb[lane] = A0; pb[64 + lane] = A1;
+      if (lane == 0) rw[kRwKinds + ps] = RLI(sw, kRsPubKinds);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) lds_store(rw + kRwPubM + ps, cut);
+    }
+    if (lane == 0) lds_store(rw + kRwConsM, i + 1 - c0);
+  }
+}
+
+// ---- wave 1: the labels of the primal pass (minimize.cpp:223-264, as the primal wave of a visit computes them) ------
+__device__ __forceinline__ void run_labels(const DevParams &p, double *rb, int c0, int c1, int lane, int *abort_word) {
+  const double inf = __builtin_huge_val();
+  const int K = p.K;
+  const bool act = lane < K;
+  int *rw = (int *)(rb + kRunWords);
+  const double posk = act ? p.pos[lane] : 0.0;
+  int xprev = 0;
+  for (int i = c0; i < c1; ++i) {
+    const int slot = (i - c0) % kRunSlots;
+    const double *sl = rb + slot * kRunSlotDoubles;
+    if (!run_wait(p, rw + kRwReady + slot, i + 1, abort_word)) return;
+    const int sw = ((const int *)(sl + kRunSc))[lane & 15];
+    const double sd = sl[kRunSc + 8 + (lane & 7)];
+    const int nout = RLI(sw, kRsNout), nin = RLI(sw, kRsNin), md = RLI(sw, kRsMd), cut = RLI(sw, kRsCut);
+    double db = act ? sl[kRunRowTH + lane] : 0.0;
+    const double o0 = sl[kRunRowOUT + lane], o1 = sl[kRunRowOUT + 64 + lane], o2 = sl[kRunRowOUT + 128 + lane], o3 = sl[kRunRowOUT + 192 + lane];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < nin) {
+        const int src = RLI(sw, kRsSrc + k);
+        const int ks = src < 0 ? xprev : src;
+        const double pks = readlane_f64(posk, ks);
+        const double d = ((md >> k) & 1) == 0 ? pks - posk : posk - pks;
+        db += readlane_f64(sd, 3 + k) * min_raw(fabs(d), p.lambda);
+      }
+    }
+    double di = db;
+    if (nout > 0) di += o0;
+    if (nout > 1) di += o1;
+    if (nout > 2) di += o2;
+    if (nout > 3) di += o3;
+    const double dim = act ? di : inf;
+    const double vbest = wave_min_dpp(dim);
+    xprev = __builtin_ctzll(__builtin_amdgcn_ballot_w64(dim == vbest));
+    if (cut) {
+      const int ps = cut & 1;
+      if (!run_wait(p, rw + kRwFree, cut - 2, abort_word)) return;
+      if (lane == 0) { rw[kRwLabel + ps] = xprev; rw[kRwNode + ps] = RLI(sw, kRsNode); }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) lds_store(rw + kRwPubP + ps, cut);
+    }
+    if (lane == 0) lds_store(rw + kRwConsP, i + 1 - c0);
+  }
+}
+
+// ---- waves 2-9: staging ---------------------------------------------------------------------------------------------
+template <bool BACKWARD, bool PRIMAL, bool UPDATE>
+__device__ __forceinline__ void run_loader(const DevParams &p, int epoch, double *rb, int c0, int c1, int lw, int lane, int *abort_word) {
+  constexpr int D = BACKWARD ? 1 : 0;
+  constexpr int DW = TrwsGraph::kDescWords;
+  const int32_t *desc = p.desc[D];
+  const int K = p.K;
+  const int lk = lane < K ? lane : K - 1;
+  int *rw = (int *)(rb + kRunWords);
+  const int L = p.spec_len, nseg = p.spec_nseg;
+  for (int i = c0 + lw; i < c1; i += kRunLoaders) {
+    const int w = desc[(size_t)i * DW + lane];
+    const int wn = i + 1 < c1 ? desc[(size_t)(i + 1) * DW + lane] : 0;
+    const int f = RLI(w, 2), fn = RLI(wn, 2);
+    const int nout = f & 15, nin = (f >> 4) & 15, ndep = (f >> 8) & 15, md = (f >> 16) & 255, ntot = nout + nin;
+    const int noutn = fn & 15, ntotn = noutn + ((fn >> 4) & 15);
+    const int j8 = lane & 7;
+    const int slw = __shfl(w, 12 + j8, kWave), sln = __shfl(wn, 12 + j8, kWave);
+    // rows the node in front hands over (this node's and, for the messages to compute here, the next node's)
+    const int fr = i > c0 ? (int)(__builtin_amdgcn_ballot_w64(lane < 8 && lane >= nout && lane < ntot && slw >= 0) & 255ull) : 0;
+    const int frn = i + 1 < c1 ? (int)(__builtin_amdgcn_ballot_w64(lane < 8 && lane >= noutn && lane < ntotn && sln >= 0) & 255ull) : 0;
+    const int kfirst = fr ? __builtin_ctz(fr) : ntot;
+    int s0 = -1, s1 = -1;
+    {
+      int rest = frn;
+      while (rest) {
+        const int k = __builtin_ctz(rest);
+        rest &= rest - 1;
+        const int s = __builtin_amdgcn_readlane(wn, 12 + k);
+        if (s0 < 0 || s0 == s) s0 = s; else s1 = s;
+      }
+    }
+    // the slots of the rows THIS node receives, in the numbering of the node in front (first distinct one: row "A0")
+    int p0s = -1;
+    if (fr) p0s = __builtin_amdgcn_readlane(w, 12 + kfirst);
+    int kinds = 0, nt = 0, nstaged = 0, stage_of[4] = {-1, -1, -1, -1};
+    for (int k = kfirst; k < ntot; ++k) {
+      int kd;
+      if ((fr >> k) & 1) kd = __builtin_amdgcn_readlane(w, 12 + k) == p0s ? 8 : 9;
+      else { kd = nstaged; if (nstaged < 4) stage_of[nstaged] = k; ++nstaged; }
+      kinds |= kd << (4 * nt);
+      ++nt;
+    }
+    // cut behind this node?
+    int cut = 0, pubkinds = 0;
+    if (i + 1 < c1 && (i + 1 - c0) % L == 0 && (i + 1 - c0) / L < nseg) {
+      cut = (i + 1 - c0) / L;
+      for (int k = noutn; k < ntotn; ++k)
+        if ((frn >> k) & 1) pubkinds |= (__builtin_amdgcn_readlane(wn, 12 + k) == s0 ? 8 : 9) << (4 * k);
+    }
+    // the ring slot: both recurrences are done with the node that had it
+    const int slot = (i - c0) % kRunSlots;
+    double *sl = rb + slot * kRunSlotDoubles;
+    if (UPDATE && !run_wait(p, rw + kRwConsM, i - c0 - kRunSlots + 1, abort_word)) return;
+    if (PRIMAL && !run_wait(p, rw + kRwConsP, i - c0 - kRunSlots + 1, abort_word)) return;
+    // foreign dependencies (everything but the node in front), then the rows
+    const int fm = RLI(w, kDescFetch) & 255;
+    const double *ua = p.unary + (size_t)((unsigned long long)(unsigned)RLI(w, 0) * (unsigned long long)(unsigned)K) + lk;
+    const double theta = *ua;
+    const double av = p.alpha[__shfl(w, 4 + j8, kWave)];
+    double r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      r[k] = 0;
+      if (k < nout && (UPDATE || PRIMAL)) r[k] = *(p.msg + (size_t)((unsigned long long)(unsigned)RLI(w, 4 + k) * (unsigned long long)(unsigned)K) + lk);
+    }
+    if (ndep > 0) wait_for_dependencies_w(p, ndep, __shfl(w, 20 + (lane & 3), kWave), RLI(w, 1), epoch, lane, abort_word);
+    if (lds_load(abort_word)) return;
+    int src = -1;   // lane k < nin: the label the k-th incoming row's pairwise term takes (-1: the node in front)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k >= nout && k < ntot && ((fm >> k) & 1) && !((fr >> k) & 1)) {
+        if (UPDATE) r[k] = ld_sc1(p.msg + (size_t)((unsigned long long)(unsigned)RLI(w, 4 + k) * (unsigned long long)(unsigned)K) + lk);
+        if (PRIMAL) { const int xv = ld_sc1(p.x + RLI(w, 32 + k)); if (lane == k - nout) src = xv; }
+      }
+    }
+    if (UPDATE) {
+      double P = theta;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k < kfirst) P += r[k];
+      sl[kRunRowP + lane] = P;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (stage_of[0] == k) sl[kRunRowS + lane] = r[k];
+        if (stage_of[1] == k) sl[kRunRowS + 64 + lane] = r[k];
+        if (stage_of[2] == k) sl[kRunRowS + 128 + lane] = r[k];
+      }
+    }
+    if (PRIMAL) sl[kRunRowTH + lane] = theta;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < nout) sl[kRunRowOUT + k * 64 + lane] = r[k];
+    // the two messages to the next node are ONE message if weights and old rows agree (positions are shared)
+    int nmsg = s0 < 0 ? 0 : 1;
+    if (UPDATE && s1 >= 0) {
+      bool same = RLI(__double2hiint(av), s0) == RLI(__double2hiint(av), s1) && RLI(__double2loint(av), s0) == RLI(__double2loint(av), s1);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (a != b && s0 == a && s1 == b) same = same && !UNI(lane < K && __double_as_longlong(r[a]) != __double_as_longlong(r[b]));
+      nmsg = same ? 1 : 2;
+    }
+    {
+      int word = 0;
+      word = lane == kRsNt ? nt : lane == kRsKinds ? kinds : lane == kRsNmsg ? nmsg : lane == kRsS0 ? s0 : lane == kRsS1 ? s1 : lane == kRsCut ? cut
+           : lane == kRsPubKinds ? pubkinds : lane == kRsNout ? nout : lane == kRsNin ? nin : lane == kRsMd ? (md >> nout) : lane == kRsNode ? RLI(w, 0) : 0;
+      const int srck = __shfl(src, lane - kRsSrc, kWave);
+      if (lane >= kRsSrc && lane < kRsSrc + 4) word = srck;
+      if (lane < 16) ((int *)(sl + kRunSc))[lane] = word;
+      // doubles 8-15: alpha of the two messages, gamma (MRFEnergy.cpp:207-228), alpha of the incoming rows
+      const double a0 = readlane_f64(av, s0 < 0 ? 0 : s0), a1 = readlane_f64(av, s1 < 0 ? (s0 < 0 ? 0 : s0) : s1);
+      const double ain = __shfl(av, nout + (lane - 3 < 0 ? 0 : lane - 3), kWave);
+      const double g = (double)1 / (double)(nout > nin ? nout : nin > 0 ? nin : 1);
+      if (lane < 8) sl[kRunSc + 8 + lane] = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? g : ain;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) lds_store(rw + kRwReady + slot, i + 1);
+  }
+}
+
+// ---- wave 10: what a segment starts from, to global memory ------------------------------------------------------------
+template <bool PRIMAL, bool UPDATE>
+__device__ __forceinline__ void run_publisher(const DevParams &p, int epoch, double *rb, int lane, int *abort_word) {
+  const int K = p.K;
+  const int lk = lane < K ? lane : K - 1;
+  int *rw = (int *)(rb + kRunWords);
+  for (int s = 1; s < p.spec_nseg; ++s) {
+    const int ps = s & 1;
+    if (UPDATE) {
+      if (!run_wait(p, rw + kRwPubM + ps, s, abort_word)) return;
+      const double *pb = rb + kRunPub + ps * 128;
+      double a0 = pb[lk], a1 = pb[64 + lk];
+      const int kinds = lds_load(rw + kRwKinds + ps);
+      if ((p.debug & 16384) && s % 3 == 1 && lane == 0) a0 = __longlong_as_double(__double_as_longlong(a0) ^ 1ll);   // (development: a wrong row)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int kd = (kinds >> (4 * k)) & 15;
+        if (kd) st_sc1(p.spec_rows + ((size_t)s * 8 + k) * K + lk, kd == 8 ? a0 : a1);
+      }
+    }
+    if (PRIMAL) {
+      if (!run_wait(p, rw + kRwPubP + ps, s, abort_word)) return;
+      int label = lds_load(rw + kRwLabel + ps);
+      const int node = lds_load(rw + kRwNode + ps);
+      if ((p.debug & 32768) && s % 5 == 2) label = label > 0 ? label - 1 : (K > 1 ? 1 : 0);                          // (development: a wrong label)
+      (void)node;
+      if (lane == 0) st_sc1(p.spec_x + s, label);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) { st_sc1(p.done + p.N + s, epoch); lds_store(rw + kRwFree, s); }
+  }
+}
+
+// (noinline, parameters through a pointer to their copy in global memory, LDS through the dynamic allocation's own
+//  symbol: nothing of this routine -- registers, scalars, the parameter block's address -- leaks into the kernel it is
+//  called from, whose visit loops sit at the register limits)
+template <bool BACKWARD, bool PRIMAL, bool UPDATE>
+__device__ __attribute__((noinline)) void chain_runner(const DevParams *pp, int epoch, int rb_off, int abort_off) {
+  extern __shared__ __attribute__((aligned(16))) double run_lds[];
+  const DevParams &p = *pp;
+  double *rb = run_lds + rb_off;
+  int *abort_word = (int *)(run_lds + abort_off) + 1;
+  constexpr int D = BACKWARD ? 1 : 0;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  const int c0 = p.spec_c0[D], c1 = p.spec_c1[D];
+  int *rw = (int *)(rb + kRunWords);
+  if (tid < 64) rw[tid] = 0;
+  if (tid < 16) { rb[kRunTab + tid] = __builtin_huge_val(); rb[kRunTab + 80 + tid] = __builtin_huge_val(); }
+  if (p.timeline && tid == 0) p.timeline[((size_t)2 * p.tl_stride + D) * 2] = wall_clock64();
+  __syncthreads();
+  if (wave == 0) { if (UPDATE) { __builtin_amdgcn_s_setprio(3); run_messages<BACKWARD>(p, rb, c0, c1, lane, abort_word); __builtin_amdgcn_s_setprio(0); } }
+  else if (wave == 1) { if (PRIMAL) { __builtin_amdgcn_s_setprio(3); run_labels(p, rb, c0, c1, lane, abort_word); __builtin_amdgcn_s_setprio(0); } }
+  else if (wave < 2 + kRunLoaders) run_loader<BACKWARD, PRIMAL, UPDATE>(p, epoch, rb, c0, c1, wave - 2, lane, abort_word);
+  else if (wave == 2 + kRunLoaders) run_publisher<PRIMAL, UPDATE>(p, epoch, rb, lane, abort_word);
+  __syncthreads();
+  if (p.timeline && tid == 0) p.timeline[((size_t)2 * p.tl_stride + D) * 2 + 1] = wall_clock64();
+  if (p.spec_stat && tid == 0) atomicAdd(p.spec_stat + 2, (unsigned long long)(c1 - c0));
+}
+
+// ---- commit of a speculative segment (called by all waves of the workgroup behind the barrier that ended the segment's
+// last visit: the storer has drained the last node's rows).  The segment in front commits first (its flag); then what
+// this segment started from is compared, bit for bit, with what that segment's last node really handed over: equal ->
+// every visit here saw the sequential sweep's inputs and the nodes' flags go up; different (the runner's plain min-plus
+// row was not the reference's envelope, or a row of the runner's was stale) -> the overwritten rows are put back and the
+// caller walks the visits again from the real rows.  Returns 0 committed, 1 walk again (ctl[3] set), 2 gave up.
+template <bool BACKWARD, bool PRIMAL, bool UPDATE>
+__device__ __attribute__((noinline)) int spec_commit(const DevParams *pp, int epoch, int p0, int p1, int seg, int compare) {
+  extern __shared__ __attribute__((aligned(16))) double run_lds[];
+  const DevParams &p = *pp;
+  constexpr int D = BACKWARD ? 1 : 0;
+  constexpr int DW = TrwsGraph::kDescWords;
+  const int32_t *desc = p.desc[D];
+  int *ctl = (int *)(run_lds + kPipeCtlOff);
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  const int K = p.K;
+  const int lkc = lane < K ? lane : K - 1;
+  if (compare) {
+    if (wave == 0) {
+      int differ = 0;
+      if (!wait_flag(p, p.N + p.spec_nseg + seg, epoch, -2)) { if (lane == 0) ctl[1] = 1; }
+      else {
+        const int w = desc[(size_t)p0 * DW + lane];
+        const int f = RLI(w, 2);
+        const int nout = f & 15, ntot = nout + ((f >> 4) & 15);
+        for (int j = nout; j < ntot; ++j) {
+          if (__builtin_amdgcn_readlane(w, 12 + j) < 0) continue;
+          if (UPDATE) {
+            const double a = ld_sc1(p.spec_rows + ((size_t)seg * 8 + j) * K + lkc);
+            const double b = ld_sc1(p.msg + (size_t)__builtin_amdgcn_readlane(w, 4 + j) * K + lkc);
+            differ |= UNI(__double_as_longlong(a) != __double_as_longlong(b)) ? 1 : 0;
+          }
+          if (PRIMAL) differ |= ld_sc1(p.spec_x + seg) != ld_sc1(p.x + __builtin_amdgcn_readlane(w, 32 + j)) ? 1 : 0;
+        }
+      }
+      if (lane == 0) ctl[2] = differ;
+    }
+    __syncthreads();
+    const int differ = __builtin_amdgcn_readfirstlane(ctl[2]);
+    const int gave_up = __builtin_amdgcn_readfirstlane(ctl[1]);
+    __syncthreads();
+    if (gave_up) return 2;
+    if (differ) {
+      if (UPDATE) {
+        for (int pos = p0 + wave; pos < p1; pos += kPipeWaves) {
+          const int w = desc[(size_t)pos * DW + lane];
+          const int nout = RLI(w, 2) & 15;
+          for (int j = 0; j < nout && j < 4; ++j)
+            st_sc1(p.msg + (size_t)__builtin_amdgcn_readlane(w, 4 + j) * K + lkc,
+                   ld_sc1(p.spec_undo + ((size_t)(seg * p.spec_max_len + (pos - p0)) * 4 + j) * K + lkc));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");   // (the second walk's plain loads must not find this CU's L1 holding anything of the first)
+      }
+      if (tid == 0) { ctl[3] = 1; if (p.spec_stat) atomicAdd(p.spec_stat, 1ull); }
+      __syncthreads();
+      return 1;
+    }
+  }
+  if (wave == 0) {
+    // the segment behind first (the commits are a serial chain), then the nodes' own flags
+    if (seg + 1 < p.spec_nseg && lane == 0) st_sc1(p.done + p.N + p.spec_nseg + seg + 1, epoch);
+    for (int pos = p0 + lane; pos < p1; pos += kWave) st_sc1(p.done + desc[(size_t)pos * DW + 1], epoch);
+    if (lane == 0 && p.spec_stat) atomicAdd(p.spec_stat + 1, 1ull);
+  }
+  return 0;
+}
+
+#undef RLI
+
+}  // namespace
+}  // namespace stereo

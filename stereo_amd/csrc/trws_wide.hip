@@ -276,7 +276,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
     const int p0 = p.run_ptr[D][run], p1 = p.run_ptr[D][run + 1];
     const bool wprof = WIDE_PROF(p) && (p.prof_run < 0 || run == p.prof_run);  // STEREO_HIP_TRWS_PROF_RUN: one run only
     (void)wprof;
-    if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2] = wall_clock64();
+    if (p.timeline && tid == 0) p.timeline[((size_t)D * p.tl_stride + run) * 2] = wall_clock64();
 
     // One visit loop per role (not one loop with a role switch inside): state carried from visit
     // to visit -- the loader's parked registers -- then occupies registers in that role only.
@@ -1242,7 +1242,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
 #undef WIDE_VISITS_BEGIN
 #undef WIDE_VISITS_END
 #undef WIDE_VISITS_END_
-    if (p.timeline && tid == 0) p.timeline[((size_t)D * p.nruns[0] + run) * 2 + 1] = wall_clock64();
+    if (p.timeline && tid == 0) p.timeline[((size_t)D * p.tl_stride + run) * 2 + 1] = wall_clock64();
   }
 #undef WSTAMP
 #undef WPOS

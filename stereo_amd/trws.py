@@ -180,6 +180,13 @@ class TrwsPlan:
         _lib.lib().stereo_trws_plan_counters(self._h, C.byref(n), C.c_int(int(reset)))
         return n.value
 
+    def spec_stats(self):
+        """Speculative schedule of the border chain (stereo_trws_plan_spec_stats): dict(active, second_walks, commits,
+        runner_visits)."""
+        out = (C.c_int64 * 4)()
+        _lib.lib().stereo_trws_plan_spec_stats(self._h, out)
+        return dict(active=bool(out[0]), second_walks=int(out[1]), commits=int(out[2]), runner_visits=int(out[3]))
+
     def stats(self, reset=False):
         ms, n = C.c_double(), C.c_int64()
         _lib.lib().stereo_trws_plan_stats(self._h, C.byref(ms), C.byref(n), C.c_int(int(reset)))
