@@ -29,8 +29,13 @@ namespace {
 //              wave 10 idles so that the primal wave shares a SIMD with one compute wave only
 // One s_barrier per visit.  The compute waves never touch global memory, so no load or
 // store latency is ever exposed on the chain of dependent visits.
-template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
+// SPEC: the instantiation that knows the speculative schedule (trws_graph.h: Sweep::Spec; trws_spec.h) -- a kernel of its
+// own, launched only when a plan's sweeps use it: everything it adds (the runner's ticket, a segment's first visit,
+// the held-back flags, the rows kept for a second walk, the commit) costs the visit loops registers, and the plain
+// schedule's kernels stay what they were.
+template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED, bool SPEC = false>
 __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
+  static_assert(!SPEC || (SHARED && KERNEL == 1), "the speculative schedule exists for shared positions and the linear kernel");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double *stage0 = lds;                                   // 2 stages
   double *hand = lds + 2 * kStageDoubles;                 // ring of 4 x 8 x 64: the last visits' new messages
@@ -53,7 +58,6 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
   const double posk = (SHARED && act) ? p.pos[lane] : 0.0;
   int look_streak = 0;  // failed second looks in a row (this compute wave): see message_regs
   const int perm_shared = (SHARED && wave < kPipeCompute) ? (act ? (int)p.perm_pos[lane] : lane) : -1;  // source order by position, once
-  constexpr bool SPEC = SHARED && KERNEL == 1;   // instantiations the speculative schedule exists for
   if (tid == 0) { ctl[1] = 0; ctl[2] = 0; ctl[3] = 0; }
   if (tid < kWave) zrow[tid] = 0.0;
   if (tid < 16) gtab[tid] = (double)1 / (double)(tid > 0 ? tid : 1);
@@ -638,6 +642,11 @@ __global__ __launch_bounds__(kPipeThreads) void trws_pipe_kernel(DevParams p, in
   pipe_body<KERNEL, BACKWARD, PRIMAL, UPDATE, SHARED>(p, epoch);
 }
 
+template <bool BACKWARD, bool PRIMAL, bool UPDATE>
+__global__ __launch_bounds__(kPipeThreads) void trws_pipe_spec_kernel(DevParams p, int epoch) {
+  pipe_body<1, BACKWARD, PRIMAL, UPDATE, true, true>(p, epoch);
+}
+
 template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE, bool SHARED>
 __global__ __launch_bounds__(kPipeThreads) void trws_pipe_group_kernel(GroupArgs ga, int epoch) {
   pipe_body<KERNEL, BACKWARD, PRIMAL, UPDATE, SHARED>(ga.pp[group_strip(ga)], epoch);
@@ -660,7 +669,10 @@ size_t pipe_spec_lds_bytes() { return sizeof(double) * (kPipeLdsDoubles + kRunDo
 int pipe_threads() { return kPipeThreads; }
 
 void pipe_set_attributes() {
-  const int lds = (int)pipe_spec_lds_bytes();
+  const int lds = (int)pipe_lds_bytes(), slds = (int)pipe_spec_lds_bytes();
+#define SET_S(BW, PR, UP) STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_pipe_spec_kernel<BW, PR, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, slds))
+  SET_S(false, false, true); SET_S(true, false, true); SET_S(false, true, true); SET_S(false, true, false);
+#undef SET_S
 #define SET_P(KER, BW, PR, UP)                                                                                                          \
   STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_pipe_kernel<KER, BW, PR, UP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));        \
   STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_pipe_kernel<KER, BW, PR, UP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));       \
@@ -672,7 +684,7 @@ void pipe_set_attributes() {
 }
 
 #define PIPE_SWITCH(NAME, ARG)                                                                                          \
-  const size_t plds = spec ? pipe_spec_lds_bytes() : pipe_lds_bytes();                                                  \
+  const size_t plds = pipe_lds_bytes();                                                                                 \
   const dim3 grid(blocks), block(kPipeThreads);                                                                         \
   _Pragma("clang diagnostic push")                                                                                      \
   if (kernel == 1) { PIPE4(NAME, 1, ARG) } else { PIPE4(NAME, 2, ARG) }                                                 \
@@ -692,12 +704,23 @@ void pipe_set_attributes() {
   }
 
 void launch_pipe(int kernel, bool shared, int what, int blocks, hipStream_t s, const DevParams &p, int epoch) {
-  const bool spec = p.spec_kind[0] != nullptr || p.spec_kind[1] != nullptr;   // (the runner's LDS lies behind the visits')
+  if (p.spec_kind[0] != nullptr && p.spec_kind[1] != nullptr && kernel == 1 && shared) {
+    // the speculative schedule's kernel (the runner's LDS lies behind the visits')
+    const size_t slds = pipe_spec_lds_bytes();
+    const dim3 grid(blocks), block(kPipeThreads);
+    switch (what) {
+      case 0: hipLaunchKernelGGL((trws_pipe_spec_kernel<false, false, true>), grid, block, slds, s, p, epoch); break;
+      case 1: hipLaunchKernelGGL((trws_pipe_spec_kernel<true, false, true>), grid, block, slds, s, p, epoch); break;
+      case 2: hipLaunchKernelGGL((trws_pipe_spec_kernel<false, true, true>), grid, block, slds, s, p, epoch); break;
+      default: hipLaunchKernelGGL((trws_pipe_spec_kernel<false, true, false>), grid, block, slds, s, p, epoch); break;
+    }
+    STEREO_HIP_CHECK(hipGetLastError());
+    return;
+  }
   PIPE_SWITCH(trws_pipe_kernel, p)
 }
 void launch_pipe_group(int kernel, bool shared, int what, int blocks, hipStream_t s, const GroupArgs &ga, int epoch) {
-  const bool spec = false;   // (strips keep the plain chain schedule)
-  PIPE_SWITCH(trws_pipe_group_kernel, ga)
+  PIPE_SWITCH(trws_pipe_group_kernel, ga)   // (strips keep the plain chain schedule)
 }
 #undef PIPE4
 #undef PIPE1

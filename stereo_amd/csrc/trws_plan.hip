@@ -676,8 +676,8 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
         P->d_spec_rows.alloc((size_t)s0.nseg * 8 * K);
         P->d_spec_undo.alloc((size_t)s0.nseg * ml * 4 * K);
         P->d_spec_x.alloc(s0.nseg);
-        P->d_spec_stat.alloc(4);
-        STEREO_HIP_CHECK(hipMemset(P->d_spec_stat.p, 0, 4 * sizeof(unsigned long long)));
+        P->d_spec_stat.alloc(8);
+        STEREO_HIP_CHECK(hipMemset(P->d_spec_stat.p, 0, 8 * sizeof(unsigned long long)));
         STEREO_HIP_CHECK(hipMemset(P->d_spec_rows.p, 0, sizeof(double) * (size_t)s0.nseg * 8 * K));
         STEREO_HIP_CHECK(hipMemset(P->d_spec_x.p, 0, sizeof(int32_t) * s0.nseg));
       }
@@ -1328,9 +1328,11 @@ int stereo_trws_plan_spec_stats(stereo_trws_plan *P, int64_t out[4]) {
   if (!P || !out) return 1;
   out[0] = spec_active(P) ? 1 : 0; out[1] = out[2] = out[3] = 0;
   if (P->d_spec_stat.p) {
-    unsigned long long v[4] = {0, 0, 0, 0};
+    unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpy(v, P->d_spec_stat.p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 1;
     out[1] = (int64_t)v[0]; out[2] = (int64_t)v[1]; out[3] = (int64_t)v[2];
+    if (std::getenv("STEREO_HIP_TRWS_TIMELINE"))   // (development: how often, and for how long, the message recurrence found its next node not staged yet)
+      std::fprintf(stderr, "[stereo_hip spec] runner visits %llu, of them waited for the loaders %llu, %.1f us in all\n", v[2], v[3], (double)v[4] / 100.0);
   }
   return 0;
 }

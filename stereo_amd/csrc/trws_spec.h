@@ -22,25 +22,26 @@
 namespace stereo {
 namespace {
 
-constexpr int kRunSlots = 12;
+constexpr int kRunSlots = 10;
 constexpr int kRunLoaders = 8;
-// a staged node (doubles): prefix sum P | up to three staged rows of the tail | unary | the node's own (outgoing) rows | words
-constexpr int kRunRowP = 0, kRunRowS = 64, kRunRowTH = 256, kRunRowOUT = 320, kRunSc = 576;
+// a staged node (doubles): prefix sum P | up to three staged rows of the tail | old rows of the (up to two) messages to
+// compute | unary | the node's own (outgoing) rows | words
+constexpr int kRunRowP = 0, kRunRowS = 64, kRunRowM = 256, kRunRowTH = 384, kRunRowOUT = 448, kRunSc = 704;
 constexpr int kRunSlotDoubles = kRunSc + 16;
 constexpr int kRunTab = kRunSlots * kRunSlotDoubles;   // 16 + 64 + 16: H with +inf on both sides
 constexpr int kRunPub = kRunTab + 96;                  // 2 x (2 rows): what the publisher stores
 constexpr int kRunWords = kRunPub + 256;               // 64 ints (below)
 constexpr int kRunDoubles = kRunWords + 32;
-// words: ready[kRunSlots] | consumed by messages, by labels | publisher flags (rows x 2, labels x 2) | slots freed |
-//        label x 2 | node x 2 | row kinds x 2
-constexpr int kRwReady = 0, kRwConsM = 12, kRwConsP = 13, kRwPubM = 14, kRwPubP = 16, kRwFree = 18, kRwLabel = 20, kRwNode = 22,
-              kRwKinds = 24;
+// words: consumed by messages, by labels | publisher flags (rows x 2, labels x 2) | slots freed | label x 2 | node x 2 |
+//        row kinds x 2
+constexpr int kRwConsM = 12, kRwConsP = 13, kRwPubM = 14, kRwPubP = 16, kRwFree = 18, kRwLabel = 20, kRwNode = 22, kRwKinds = 24;
 // words of a staged node: tail length | tail kinds (a nibble each: 0-2 staged row, 8 / 9 first / second handed-over row)
-// | messages to compute (0, 1, 2) | their slots in the node's outgoing list x 2 | cut: segment that starts behind this
-// node (0: none) | kinds of that segment's first node's rows (a nibble per row) | n_out | incoming rows | their label
-// (-1: the node in front) x 4 | their direction bits | node id; doubles 8-15: alpha x 2, gamma, alpha of the incoming rows x 4
-constexpr int kRsNt = 0, kRsKinds = 1, kRsNmsg = 2, kRsS0 = 3, kRsS1 = 4, kRsCut = 5, kRsPubKinds = 6, kRsNout = 7, kRsNin = 8,
-              kRsSrc = 9, kRsMd = 13, kRsNode = 14;
+// | messages to compute (0, 1, 2) | cut: segment that starts behind this node (0: none) | kinds of that segment's first
+// node's rows (a nibble per row) | n_out | incoming rows | their label (-1: the node in front) x 4 | their direction
+// bits | node id | word 15: the TAG, schedule position + 1, written last (behind a release fence): a reader that
+// finds it finds the node.  doubles 8-15: alpha x 2, gamma, alpha of the incoming rows x 4
+constexpr int kRsNt = 0, kRsKinds = 1, kRsNmsg = 2, kRsCut = 5, kRsPubKinds = 6, kRsNout = 7, kRsNin = 8, kRsSrc = 9, kRsMd = 13,
+              kRsNode = 14, kRsTag = 15;
 
 __device__ __forceinline__ int lds_load(const int *w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_store(int *w, int v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -66,7 +67,63 @@ __device__ __forceinline__ bool run_wait(const DevParams &p, const int *word, in
 
 #define RLI(v, i) __builtin_amdgcn_readlane((v), (i))
 
+// Arguments of a real (non-inlined) device function arrive in vector registers and the compiler must take them, and
+// everything loaded through them, for lane-varying: every branch on such a value becomes an exec-mask region, every loop
+// bound a mask loop.  They ARE uniform: the fields the runner and the commit use are read once and declared so.
+template <class T>
+__device__ __forceinline__ T uniform_value(T v) {
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "uniform_value");
+  if (sizeof(T) == 4) {
+    int w;
+    __builtin_memcpy(&w, &v, 4);
+    w = __builtin_amdgcn_readfirstlane(w);
+    __builtin_memcpy(&v, &w, 4);
+  } else {
+    int w[2];
+    __builtin_memcpy(w, &v, 8);
+    w[0] = __builtin_amdgcn_readfirstlane(w[0]); w[1] = __builtin_amdgcn_readfirstlane(w[1]);
+    __builtin_memcpy(&v, w, 8);
+  }
+  return v;
+}
+__device__ __forceinline__ DevParams uniform_params(const DevParams *pp) {
+  DevParams q;
+#define U(f) q.f = uniform_value(pp->f)
+  U(K); U(lambda); U(unary); U(msg); U(pos); U(alpha); U(x); U(done); U(abort_flag); U(spin_ticks); U(n_own); U(N);
+  U(desc[0]); U(desc[1]); U(window); U(uniform_step); U(spec_c0[0]); U(spec_c0[1]); U(spec_c1[0]); U(spec_c1[1]);
+  U(spec_len); U(spec_nseg); U(spec_max_len); U(spec_rows); U(spec_x); U(spec_undo); U(spec_stat); U(timeline); U(tl_stride); U(debug);
+#undef U
+  return q;
+}
+
 // ---- wave 0: the message recurrence ------------------------------------------------------------------------------
+// What a visit reads from its staged node, requested in one go and WITHOUT waiting for the node to be there: the words
+// first (tag included: one instruction, one snapshot), the rows behind a compiler barrier -- LDS serves a wave's
+// requests in order, so rows that follow a tag that was found are the node's.  The next node's requests go out while
+// this node's window is computed; a tag that was not there yet is waited for at the top of the next visit.
+struct RunNodeM {
+  int sw;
+  double sd, P, S0, S1, S2, M0, M1;
+};
+__device__ __forceinline__ void run_request_m(const double *sl, int lane, RunNodeM &n) {
+  n.sw = ((const int *)(sl + kRunSc))[lane & 15];
+  asm volatile("" ::: "memory");
+  n.sd = sl[kRunSc + 8 + (lane & 7)];
+  n.P = sl[kRunRowP + lane]; n.S0 = sl[kRunRowS + lane]; n.S1 = sl[kRunRowS + 64 + lane]; n.S2 = sl[kRunRowS + 128 + lane];
+  n.M0 = sl[kRunRowM + lane]; n.M1 = sl[kRunRowM + 64 + lane];
+}
+// min-plus over the table entries lane - 4 G .. lane + 4 G (all requested together), entry lane itself is `h`
+template <int G>
+__device__ __forceinline__ double run_window(const double *tabl, double h, const double (&ad)[16]) {
+  double lo[4 * G], hi[4 * G];
+#pragma unroll
+  for (int d = 0; d < 4 * G; ++d) { lo[d] = tabl[-(d + 1)]; hi[d] = tabl[d + 1]; }
+  double ma = h, mb = __builtin_huge_val();   // (two chains)
+#pragma unroll
+  for (int d = 0; d < 4 * G; ++d) { ma = min_raw(ma, lo[d] + ad[d]); mb = min_raw(mb, hi[d] + ad[d]); }
+  return min_raw(ma, mb);
+}
+
 template <bool BACKWARD>
 __device__ __forceinline__ void run_messages(const DevParams &p, double *rb, int c0, int c1, int lane, int *abort_word) {
   const double inf = __builtin_huge_val();
@@ -81,36 +138,40 @@ __device__ __forceinline__ void run_messages(const DevParams &p, double *rb, int
   for (int d = 0; d < 16; ++d) ad[d] = 0;
   bool have_ad = false;
   double A0 = 0, A1 = 0;
+  RunNodeM cur, nxt;
+  run_request_m(rb, lane, cur);
+  nxt = cur;
   for (int i = c0; i < c1; ++i) {
-    const int slot = (i - c0) % kRunSlots;
-    const double *sl = rb + slot * kRunSlotDoubles;
-    if (!run_wait(p, rw + kRwReady + slot, i + 1, abort_word)) return;
-    const int sw = ((const int *)(sl + kRunSc))[lane & 15];
-    const double sd = sl[kRunSc + 8 + (lane & 7)];
-    const int nt = RLI(sw, kRsNt), kinds = RLI(sw, kRsKinds), nmsg = RLI(sw, kRsNmsg), s0 = RLI(sw, kRsS0), s1 = RLI(sw, kRsS1);
-    const int cut = RLI(sw, kRsCut);
-    // (all rows are requested together: one LDS latency)
-    const double P = sl[kRunRowP + lane], S0 = sl[kRunRowS + lane], S1 = sl[kRunRowS + 64 + lane], S2 = sl[kRunRowS + 128 + lane];
-    const double m0 = sl[kRunRowOUT + (s0 < 0 ? 0 : s0) * 64 + lane], m1 = sl[kRunRowOUT + (s1 < 0 ? 0 : s1) * 64 + lane];
-    double Di = P;
+    const double *sl = rb + ((i - c0) % kRunSlots) * kRunSlotDoubles;
+    if (RLI(cur.sw, kRsTag) != i + 1) {   // (not there yet when it was asked for)
+      if (!run_wait(p, (const int *)(sl + kRunSc) + kRsTag, i + 1, abort_word)) return;
+      run_request_m(sl, lane, cur);
+    }
+    const int sw = cur.sw;
+    const int nt = RLI(sw, kRsNt), kinds = RLI(sw, kRsKinds), nmsg = RLI(sw, kRsNmsg), cut = RLI(sw, kRsCut);
+    double Di = cur.P;
     // the tail of the node's list from the first handed-over row on, in list order (the order of the reference's additions)
     switch (kinds | (nt << 16)) {
       case 0x20098: Di += A0; Di += A1; break;                           // handed over, handed over (forward chain)
-      case 0x30908: Di += A0; Di += S0; Di += A1; break;                 // ... with a row of another run in between
-      case 0x30098: Di += A0; Di += A1; Di += S0; break;
-      case 0x41908: Di += A0; Di += S0; Di += A1; Di += S1; break;
+      case 0x30908: Di += A0; Di += cur.S0; Di += A1; break;             // ... with a row of another run in between
+      case 0x30098: Di += A0; Di += A1; Di += cur.S0; break;
+      case 0x41908: Di += A0; Di += cur.S0; Di += A1; Di += cur.S1; break;
       default:
         for (int t = 0; t < nt; ++t) {
           const int kd = (kinds >> (4 * t)) & 15;
-          if (kd == 8) Di += A0; else if (kd == 9) Di += A1; else if (kd == 0) Di += S0; else if (kd == 1) Di += S1; else Di += S2;
+          if (kd == 8) Di += A0; else if (kd == 9) Di += A1; else if (kd == 0) Di += cur.S0; else if (kd == 1) Di += cur.S1; else Di += cur.S2;
         }
     }
     if (BACKWARD) Di -= wave_min_dpp(act ? Di : inf);   // minimize.cpp:79-83 (the node's own lower-bound term)
-    const double gamma = readlane_f64(sd, 2);
+    const double gamma = readlane_f64(cur.sd, 2);
+    const double mold0 = cur.M0, mold1 = cur.M1, sd = cur.sd;
+    // this node's words and rows are in registers: its place in the ring is free, and the next node's are asked for
+    if (lane == 0) lds_store(rw + kRwConsM, i + 1 - c0);
+    if (i + 1 < c1) run_request_m(rb + ((i + 1 - c0) % kRunSlots) * kRunSlotDoubles, lane, nxt);
     double R0 = 0, R1 = 0;
     for (int m = 0; m < nmsg; ++m) {
       const double alpha = readlane_f64(sd, m);
-      const double mold = m == 0 ? m0 : m1;
+      const double mold = m == 0 ? mold0 : mold1;
       const double h = act ? gamma * Di - mold : inf;
       double out;
       if (alpha == 0) {
@@ -126,17 +187,11 @@ __device__ __forceinline__ void run_messages(const DevParams &p, double *rb, int
         const double vtrunc = hmin + alpha * p.lambda;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        double mm = h;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          if (g < wgroups) {
-            double lo[4], hi[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) { lo[d] = tabl[-(4 * g + d + 1)]; hi[d] = tabl[4 * g + d + 1]; }
-#pragma unroll
-            for (int d = 0; d < 4; ++d) { mm = min_raw(mm, lo[d] + ad[4 * g + d]); mm = min_raw(mm, hi[d] + ad[4 * g + d]); }
-          }
-        }
+        double mm;
+        if (wgroups <= 1) mm = run_window<1>(tabl, h, ad);
+        else if (wgroups == 2) mm = run_window<2>(tabl, h, ad);
+        else if (wgroups == 3) mm = run_window<3>(tabl, h, ad);
+        else mm = run_window<4>(tabl, h, ad);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         out = min_raw(mm, vtrunc) - hmin;
@@ -154,11 +209,22 @@ __device__ __forceinline__ void run_messages(const DevParams &p, double *rb, int
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) lds_store(rw + kRwPubM + ps, cut);
     }
-    if (lane == 0) lds_store(rw + kRwConsM, i + 1 - c0);
+    cur = nxt;
   }
 }
 
 // ---- wave 1: the labels of the primal pass (minimize.cpp:223-264, as the primal wave of a visit computes them) ------
+struct RunNodeP {
+  int sw;
+  double sd, TH, O0, O1, O2, O3;
+};
+__device__ __forceinline__ void run_request_p(const double *sl, int lane, RunNodeP &n) {
+  n.sw = ((const int *)(sl + kRunSc))[lane & 15];
+  asm volatile("" ::: "memory");
+  n.sd = sl[kRunSc + 8 + (lane & 7)];
+  n.TH = sl[kRunRowTH + lane];
+  n.O0 = sl[kRunRowOUT + lane]; n.O1 = sl[kRunRowOUT + 64 + lane]; n.O2 = sl[kRunRowOUT + 128 + lane]; n.O3 = sl[kRunRowOUT + 192 + lane];
+}
 __device__ __forceinline__ void run_labels(const DevParams &p, double *rb, int c0, int c1, int lane, int *abort_word) {
   const double inf = __builtin_huge_val();
   const int K = p.K;
@@ -166,15 +232,22 @@ __device__ __forceinline__ void run_labels(const DevParams &p, double *rb, int c
   int *rw = (int *)(rb + kRunWords);
   const double posk = act ? p.pos[lane] : 0.0;
   int xprev = 0;
+  RunNodeP cur, nxt;
+  run_request_p(rb, lane, cur);
+  nxt = cur;
   for (int i = c0; i < c1; ++i) {
-    const int slot = (i - c0) % kRunSlots;
-    const double *sl = rb + slot * kRunSlotDoubles;
-    if (!run_wait(p, rw + kRwReady + slot, i + 1, abort_word)) return;
-    const int sw = ((const int *)(sl + kRunSc))[lane & 15];
-    const double sd = sl[kRunSc + 8 + (lane & 7)];
+    const double *sl = rb + ((i - c0) % kRunSlots) * kRunSlotDoubles;
+    if (RLI(cur.sw, kRsTag) != i + 1) {
+      if (!run_wait(p, (const int *)(sl + kRunSc) + kRsTag, i + 1, abort_word)) return;
+      run_request_p(sl, lane, cur);
+    }
+    const int sw = cur.sw;
+    const double sd = cur.sd;
     const int nout = RLI(sw, kRsNout), nin = RLI(sw, kRsNin), md = RLI(sw, kRsMd), cut = RLI(sw, kRsCut);
-    double db = act ? sl[kRunRowTH + lane] : 0.0;
-    const double o0 = sl[kRunRowOUT + lane], o1 = sl[kRunRowOUT + 64 + lane], o2 = sl[kRunRowOUT + 128 + lane], o3 = sl[kRunRowOUT + 192 + lane];
+    double db = act ? cur.TH : 0.0;
+    const double o0 = cur.O0, o1 = cur.O1, o2 = cur.O2, o3 = cur.O3;
+    if (lane == 0) lds_store(rw + kRwConsP, i + 1 - c0);
+    if (i + 1 < c1) run_request_p(rb + ((i + 1 - c0) % kRunSlots) * kRunSlotDoubles, lane, nxt);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (k < nin) {
@@ -200,7 +273,7 @@ __device__ __forceinline__ void run_labels(const DevParams &p, double *rb, int c
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) lds_store(rw + kRwPubP + ps, cut);
     }
-    if (lane == 0) lds_store(rw + kRwConsP, i + 1 - c0);
+    cur = nxt;
   }
 }
 
@@ -214,9 +287,15 @@ __device__ __forceinline__ void run_loader(const DevParams &p, int epoch, double
   const int lk = lane < K ? lane : K - 1;
   int *rw = (int *)(rb + kRunWords);
   const int L = p.spec_len, nseg = p.spec_nseg;
+  // (the descriptors of this wave's NEXT node are asked for before the current one is worked on)
+  int w2 = 0, wn2 = 0;
+  if (c0 + lw < c1) { w2 = desc[(size_t)(c0 + lw) * DW + lane]; wn2 = c0 + lw + 1 < c1 ? desc[(size_t)(c0 + lw + 1) * DW + lane] : 0; }
   for (int i = c0 + lw; i < c1; i += kRunLoaders) {
-    const int w = desc[(size_t)i * DW + lane];
-    const int wn = i + 1 < c1 ? desc[(size_t)(i + 1) * DW + lane] : 0;
+    const int w = w2, wn = wn2;
+    if (i + kRunLoaders < c1) {
+      w2 = desc[(size_t)(i + kRunLoaders) * DW + lane];
+      wn2 = i + kRunLoaders + 1 < c1 ? desc[(size_t)(i + kRunLoaders + 1) * DW + lane] : 0;
+    }
     const int f = RLI(w, 2), fn = RLI(wn, 2);
     const int nout = f & 15, nin = (f >> 4) & 15, ndep = (f >> 8) & 15, md = (f >> 16) & 255, ntot = nout + nin;
     const int noutn = fn & 15, ntotn = noutn + ((fn >> 4) & 15);
@@ -226,7 +305,7 @@ __device__ __forceinline__ void run_loader(const DevParams &p, int epoch, double
     const int fr = i > c0 ? (int)(__builtin_amdgcn_ballot_w64(lane < 8 && lane >= nout && lane < ntot && slw >= 0) & 255ull) : 0;
     const int frn = i + 1 < c1 ? (int)(__builtin_amdgcn_ballot_w64(lane < 8 && lane >= noutn && lane < ntotn && sln >= 0) & 255ull) : 0;
     const int kfirst = fr ? __builtin_ctz(fr) : ntot;
-    int s0 = -1, s1 = -1;
+    int s0 = -1, s1 = -1;   // slots, in this node's outgoing list, of the (up to two distinct) messages the next node takes from it
     {
       int rest = frn;
       while (rest) {
@@ -254,12 +333,7 @@ __device__ __forceinline__ void run_loader(const DevParams &p, int epoch, double
       for (int k = noutn; k < ntotn; ++k)
         if ((frn >> k) & 1) pubkinds |= (__builtin_amdgcn_readlane(wn, 12 + k) == s0 ? 8 : 9) << (4 * k);
     }
-    // the ring slot: both recurrences are done with the node that had it
-    const int slot = (i - c0) % kRunSlots;
-    double *sl = rb + slot * kRunSlotDoubles;
-    if (UPDATE && !run_wait(p, rw + kRwConsM, i - c0 - kRunSlots + 1, abort_word)) return;
-    if (PRIMAL && !run_wait(p, rw + kRwConsP, i - c0 - kRunSlots + 1, abort_word)) return;
-    // foreign dependencies (everything but the node in front), then the rows
+    // the node's own data (nobody writes it before the segment that holds the node walks it)
     const int fm = RLI(w, kDescFetch) & 255;
     const double *ua = p.unary + (size_t)((unsigned long long)(unsigned)RLI(w, 0) * (unsigned long long)(unsigned)K) + lk;
     const double theta = *ua;
@@ -268,8 +342,9 @@ __device__ __forceinline__ void run_loader(const DevParams &p, int epoch, double
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       r[k] = 0;
-      if (k < nout && (UPDATE || PRIMAL)) r[k] = *(p.msg + (size_t)((unsigned long long)(unsigned)RLI(w, 4 + k) * (unsigned long long)(unsigned)K) + lk);
+      if (k < nout) r[k] = *(p.msg + (size_t)((unsigned long long)(unsigned)RLI(w, 4 + k) * (unsigned long long)(unsigned)K) + lk);
     }
+    // foreign dependencies (everything but the node in front), then their rows and labels
     if (ndep > 0) wait_for_dependencies_w(p, ndep, __shfl(w, 20 + (lane & 3), kWave), RLI(w, 1), epoch, lane, abort_word);
     if (lds_load(abort_word)) return;
     int src = -1;   // lane k < nin: the label the k-th incoming row's pairwise term takes (-1: the node in front)
@@ -280,6 +355,10 @@ __device__ __forceinline__ void run_loader(const DevParams &p, int epoch, double
         if (PRIMAL) { const int xv = ld_sc1(p.x + RLI(w, 32 + k)); if (lane == k - nout) src = xv; }
       }
     }
+    // the ring slot: both recurrences have taken the node that had it into their registers
+    double *sl = rb + ((i - c0) % kRunSlots) * kRunSlotDoubles;
+    if (UPDATE && !run_wait(p, rw + kRwConsM, i - c0 - kRunSlots + 1, abort_word)) return;
+    if (PRIMAL && !run_wait(p, rw + kRwConsP, i - c0 - kRunSlots + 1, abort_word)) return;
     if (UPDATE) {
       double P = theta;
 #pragma unroll
@@ -292,11 +371,18 @@ __device__ __forceinline__ void run_loader(const DevParams &p, int epoch, double
         if (stage_of[1] == k) sl[kRunRowS + 64 + lane] = r[k];
         if (stage_of[2] == k) sl[kRunRowS + 128 + lane] = r[k];
       }
-    }
-    if (PRIMAL) sl[kRunRowTH + lane] = theta;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (k < nout) sl[kRunRowOUT + k * 64 + lane] = r[k];
+      for (int k = 0; k < 4; ++k) {
+        if (s0 == k) sl[kRunRowM + lane] = r[k];
+        if (s1 == k) sl[kRunRowM + 64 + lane] = r[k];
+      }
+    }
+    if (PRIMAL) {
+      sl[kRunRowTH + lane] = theta;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < nout) sl[kRunRowOUT + k * 64 + lane] = r[k];
+    }
     // the two messages to the next node are ONE message if weights and old rows agree (positions are shared)
     int nmsg = s0 < 0 ? 0 : 1;
     if (UPDATE && s1 >= 0) {
@@ -310,11 +396,11 @@ __device__ __forceinline__ void run_loader(const DevParams &p, int epoch, double
     }
     {
       int word = 0;
-      word = lane == kRsNt ? nt : lane == kRsKinds ? kinds : lane == kRsNmsg ? nmsg : lane == kRsS0 ? s0 : lane == kRsS1 ? s1 : lane == kRsCut ? cut
+      word = lane == kRsNt ? nt : lane == kRsKinds ? kinds : lane == kRsNmsg ? nmsg : lane == kRsCut ? cut
            : lane == kRsPubKinds ? pubkinds : lane == kRsNout ? nout : lane == kRsNin ? nin : lane == kRsMd ? (md >> nout) : lane == kRsNode ? RLI(w, 0) : 0;
       const int srck = __shfl(src, lane - kRsSrc, kWave);
       if (lane >= kRsSrc && lane < kRsSrc + 4) word = srck;
-      if (lane < 16) ((int *)(sl + kRunSc))[lane] = word;
+      if (lane < kRsTag) ((int *)(sl + kRunSc))[lane] = word;
       // doubles 8-15: alpha of the two messages, gamma (MRFEnergy.cpp:207-228), alpha of the incoming rows
       const double a0 = readlane_f64(av, s0 < 0 ? 0 : s0), a1 = readlane_f64(av, s1 < 0 ? (s0 < 0 ? 0 : s0) : s1);
       const double ain = __shfl(av, nout + (lane - 3 < 0 ? 0 : lane - 3), kWave);
@@ -322,7 +408,7 @@ __device__ __forceinline__ void run_loader(const DevParams &p, int epoch, double
       if (lane < 8) sl[kRunSc + 8 + lane] = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? g : ain;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) lds_store(rw + kRwReady + slot, i + 1);
+    if (lane == 0) lds_store((int *)(sl + kRunSc) + kRsTag, i + 1);
   }
 }
 
@@ -363,9 +449,10 @@ __device__ __forceinline__ void run_publisher(const DevParams &p, int epoch, dou
 //  symbol: nothing of this routine -- registers, scalars, the parameter block's address -- leaks into the kernel it is
 //  called from, whose visit loops sit at the register limits)
 template <bool BACKWARD, bool PRIMAL, bool UPDATE>
-__device__ __attribute__((noinline)) void chain_runner(const DevParams *pp, int epoch, int rb_off, int abort_off) {
+__device__ __attribute__((noinline)) void chain_runner(const DevParams *pp_, int epoch_, int rb_off_, int abort_off_) {
   extern __shared__ __attribute__((aligned(16))) double run_lds[];
-  const DevParams &p = *pp;
+  const DevParams &p = *pp_;
+  const int epoch = epoch_, rb_off = rb_off_, abort_off = abort_off_;
   double *rb = run_lds + rb_off;
   int *abort_word = (int *)(run_lds + abort_off) + 1;
   constexpr int D = BACKWARD ? 1 : 0;
@@ -374,6 +461,7 @@ __device__ __attribute__((noinline)) void chain_runner(const DevParams *pp, int 
   const int c0 = p.spec_c0[D], c1 = p.spec_c1[D];
   int *rw = (int *)(rb + kRunWords);
   if (tid < 64) rw[tid] = 0;
+  if (tid < kRunSlots) ((int *)(rb + tid * kRunSlotDoubles + kRunSc))[kRsTag] = 0;   // (no node staged)
   if (tid < 16) { rb[kRunTab + tid] = __builtin_huge_val(); rb[kRunTab + 80 + tid] = __builtin_huge_val(); }
   if (p.timeline && tid == 0) p.timeline[((size_t)2 * p.tl_stride + D) * 2] = wall_clock64();
   __syncthreads();
@@ -393,9 +481,10 @@ __device__ __attribute__((noinline)) void chain_runner(const DevParams *pp, int 
 // row was not the reference's envelope, or a row of the runner's was stale) -> the overwritten rows are put back and the
 // caller walks the visits again from the real rows.  Returns 0 committed, 1 walk again (ctl[3] set), 2 gave up.
 template <bool BACKWARD, bool PRIMAL, bool UPDATE>
-__device__ __attribute__((noinline)) int spec_commit(const DevParams *pp, int epoch, int p0, int p1, int seg, int compare) {
+__device__ __attribute__((noinline)) int spec_commit(const DevParams *pp_, int epoch_, int p0_, int p1_, int seg_, int compare_) {
   extern __shared__ __attribute__((aligned(16))) double run_lds[];
-  const DevParams &p = *pp;
+  const DevParams &p = *pp_;
+  const int epoch = epoch_, p0 = p0_, p1 = p1_, seg = seg_, compare = compare_;
   constexpr int D = BACKWARD ? 1 : 0;
   constexpr int DW = TrwsGraph::kDescWords;
   const int32_t *desc = p.desc[D];

@@ -52,4 +52,5 @@ dt = (time.perf_counter() - t) / iters
 _, en, lb, it = plan.result(want_labels=False)
 print("kernel %d %dx%dx%d tol %g: path %d, %.2f ms/iter (%.1f it/s), serial messages %d, energy %.6f lb %.6f" % (
     kernel, W, H, K, tol, plan.path(), dt * 1e3, 1 / dt, plan.serial_messages(), en, lb))
+if hasattr(plan, "spec_stats"): print("spec", plan.spec_stats())
 plan.close()
