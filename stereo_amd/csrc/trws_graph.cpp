@@ -772,6 +772,27 @@ extern "C" int stereo_trws_schedule_strips(int64_t N, int64_t E, const uint32_t 
                        pred_rank, dep_ptr, dep_rank, run_strip, remote, "stereo_trws_schedule_strips", err, errcap);
 }
 
+// Host-only view of the speculative schedule (trws_graph.h: Sweep::Spec), for CPU tests of its dependency structure.
+// info[0..5] = ok, cut run (index in the chain schedule), c0, c1, segment length, segments; the arrays (may be NULL)
+// take the schedule with the cut run as segments: run_ptr (runs + 1), kind (runs), ticket_run (tickets = runs + 1,
+// -1 = the runner); *nruns = runs.  Together with stereo_trws_schedule (positions, dependencies) that is everything
+// the kernels walk.
+extern "C" int stereo_trws_spec_schedule(int64_t N, int64_t E, const uint32_t *conn, int direction, int64_t *info,
+                                         int64_t *nruns, int64_t *run_ptr, int64_t *kind, int64_t *ticket_run, char *err,
+                                         size_t errcap) {
+  if (!conn || !info || (direction != 0 && direction != 1)) return stereo::fail("stereo_trws_spec_schedule: bad argument", err, errcap);
+  stereo::TrwsGraph g;
+  std::string gerr;
+  if (!stereo::build_trws_graph(N, E, conn, g, gerr)) return stereo::fail(gerr, err, errcap);
+  const stereo::TrwsGraph::Sweep::Spec &sp = g.sweep[direction].spec;
+  info[0] = sp.ok ? 1 : 0; info[1] = sp.run; info[2] = sp.c0; info[3] = sp.c1; info[4] = sp.seg_len; info[5] = sp.nseg;
+  if (nruns) *nruns = (int64_t)sp.kind.size();
+  for (size_t k = 0; run_ptr && k < sp.run_ptr.size(); ++k) run_ptr[k] = sp.run_ptr[k];
+  for (size_t k = 0; kind && k < sp.kind.size(); ++k) kind[k] = sp.kind[k];
+  for (size_t k = 0; ticket_run && k < sp.run_order.size(); ++k) ticket_run[k] = sp.run_order[k];
+  return 0;
+}
+
 // Host-only view of what one strip stores and of its renumbered descriptors (no device needed):
 // lets a CPU test check that the ids a strip writes into its neighbours' arrays are the ids the
 // neighbours use themselves.

@@ -252,7 +252,8 @@ size_t persistent_lds_bytes(int Kp) { return generic_lds_bytes(Kp); }
 // trws_pipe_kernel, linear kernel, certified messages, shared strictly ascending positions, uniformly spaced over the
 // truncation window (rounded up to a multiple of four entries).
 bool spec_active(const stereo_trws_plan *P) {
-  return P->spec_allowed && P->fast && !P->wide && !P->fast2 && P->nstrips == 1 && P->kernel == 1 && P->certificate && P->pos != nullptr &&
+  // (and a handful of resident workgroups: the runner, the segment that commits, the segments in between)
+  return P->spec_allowed && P->grid_blocks >= 8 && P->fast && !P->wide && !P->fast2 && P->nstrips == 1 && P->kernel == 1 && P->certificate && P->pos != nullptr &&
          P->pos_ascending && P->window <= 16 && P->uniform_step != 0 && P->spec_window;
 }
 
@@ -592,11 +593,11 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
       P->graph = share->graph;
     } else {
       static std::mutex cache_mutex;
-      static struct { int64_t N = -1, E = -1, capacity = -1, cus = -1; int nstrips = 1, ordering = 0; std::vector<uint32_t> conn; std::vector<int32_t> owner;
+      static struct { int64_t N = -1, E = -1, capacity = -1, cus = -1; int nstrips = 1, ordering = 0, seg = 0; std::vector<uint32_t> conn; std::vector<int32_t> owner;
                       std::shared_ptr<const TrwsGraph> g; } cache;
       std::lock_guard<std::mutex> lock(cache_mutex);
       const bool hit = cache.g && cache.N == N && cache.E == E && cache.capacity == capacity && cache.cus == P->cus &&
-                       cache.nstrips == nstrips && cache.ordering == ordering &&
+                       cache.nstrips == nstrips && cache.ordering == ordering && cache.seg == spec_segment_length() &&
                        std::memcmp(cache.conn.data(), conn, sizeof(uint32_t) * 2 * (size_t)E) == 0 &&
                        (nstrips == 1 || std::memcmp(cache.owner.data(), owner, sizeof(int32_t) * (size_t)N) == 0);
       if (hit) {
@@ -607,6 +608,7 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
         P->graph = fresh;
         if (N <= (1 << 23)) {  // (3000 x 2000: 3 GB of descriptors stay in host memory until the next connectivity)
           cache.N = N; cache.E = E; cache.capacity = capacity; cache.cus = P->cus; cache.nstrips = nstrips; cache.ordering = ordering;
+          cache.seg = spec_segment_length();
           cache.conn.assign(conn, conn + 2 * (size_t)E); cache.g = fresh;
           if (nstrips > 1) cache.owner.assign(owner, owner + N); else cache.owner.clear();
         } else {
@@ -1119,8 +1121,8 @@ int stereo_trws_plans_issue(stereo_trws_plan *const *plans, int n, void *stream,
         (P->pos == nullptr) != (P0->pos == nullptr) || P->mode != P0->mode)
       return fail("stereo_trws_plans_issue: the plans are not strips of one problem on one device in the same state", err, errcap);
     if (!(P->wide || P->fast || P->fast2))
-      return fail("stereo_trws_plans_issue: strips run on the pipelined kernels only (K <= 64; K <= 128 with the linear "
-                  "kernel; K <= 256 with shared ascending positions and the linear kernel)", err, errcap);
+      return fail("stereo_trws_plans_issue: strips run on the pipelined kernels only (K <= 64; K <= 128 with per-edge "
+                  "positions; K <= 256 with shared ascending positions)", err, errcap);
   }
   try {
     stereo_trws_plan *P0 = plans[0];
@@ -1408,9 +1410,22 @@ int stereo_trws_plan_path(stereo_trws_plan *P) {
 // for bit (tests/test_trws_gpu.py).  STEREO_HIP_TRWS_CACHE=0: a plan per call, K x E arrays always uploaded.
 namespace {
 
+// The environment switches a plan freezes at creation: part of the cache key (a cached plan must not outlive them).
+std::string trws_env_key() {
+  std::string k;
+  for (const char *name : {"STEREO_HIP_TRWS_CERTIFICATE", "STEREO_HIP_TRWS_FAST", "STEREO_HIP_TRWS_SPIN_SECONDS", "STEREO_HIP_TRWS_PROF",
+                           "STEREO_HIP_TRWS_TIMELINE", "STEREO_HIP_TRWS_SPEC", "STEREO_HIP_TRWS_SPEC_SEG", "STEREO_HIP_STRIPS_FINEGRAINED"}) {
+    const char *v = std::getenv(name);
+    k += v ? v : "-";
+    k += '|';
+  }
+  return k;
+}
+
 struct TrwsPlanCache {
   std::mutex mu;
   stereo_trws_plan *plan = nullptr;
+  std::string env;
   int kernel = 0, K = 0, mode = 0, device = -1;
   int64_t N = 0, E = 0;
   std::vector<uint32_t> conn;
@@ -1499,14 +1514,15 @@ int stereo_trws(int kernel, const double *unary, const uint32_t *conn, const dou
   std::lock_guard<std::mutex> lock(C.mu);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return fail("stereo_trws: no HIP device available (the HIP path has no CPU fallback)", err, errcap);
-  const bool hit = C.plan && C.kernel == kernel && C.K == K && C.N == N && C.E == E && C.mode == mode && C.device == dev &&
+  const std::string env = trws_env_key();
+  const bool hit = C.plan && C.kernel == kernel && C.K == K && C.N == N && C.E == E && C.mode == mode && C.device == dev && C.env == env &&
                    std::memcmp(C.conn.data(), conn, sizeof(uint32_t) * 2 * (size_t)E) == 0;
   if (!hit) {
     if (C.plan) { stereo_trws_plan_destroy(C.plan); C.plan = nullptr; }
     stereo_trws_plan *P = nullptr;
     const int rc = stereo_trws_plan_create(kernel, K, N, E, conn, mode, &P, err, errcap);
     if (rc) return rc;
-    C.plan = P; C.kernel = kernel; C.K = K; C.N = N; C.E = E; C.mode = mode; C.device = dev;
+    C.plan = P; C.kernel = kernel; C.K = K; C.N = N; C.E = E; C.mode = mode; C.device = dev; C.env = env;
     C.conn.assign(conn, conn + 2 * (size_t)E);
   }
   const int rc = trws_solve_on(C.plan, unary, q, qprim, alphas, tol, maxiter, max_relgap, true, labelling, energy, lower_bound,

@@ -295,6 +295,130 @@ def simulate_schedule(sched, workgroups, visit=1.0, handover=0.0):
     return float(done_t.max()), finished == R
 
 
+def spec_schedule(N, connectivity0, direction):
+    """Host-only inspection of the speculative schedule (stereo_trws_spec_schedule); connectivity zero based.
+    Returns None if the graph has no run to cut, else dict(run, c0, c1, seg_len, nseg, run_ptr, kind, ticket_run)."""
+    c = np.asarray(connectivity0)
+    if c.ndim != 2 or c.shape[0] != 2:
+        raise StereoHipError("connectivity must be 2 x E")
+    c = np.asfortranarray(c, dtype=np.uint32)
+    E = c.shape[1]
+    i64 = lambda n: np.zeros(n, np.int64)
+    info, run_ptr, kind, ticket_run = i64(6), i64(N + 2), i64(N + 1), i64(N + 2)
+    nruns = C.c_int64(0)
+    err = _lib.errbuf()
+    P = lambda a: _ptr(a, C.c_int64)
+    rc = _lib.lib().stereo_trws_spec_schedule(C.c_int64(N), C.c_int64(E), _ptr(c, C.c_uint32), C.c_int(direction), P(info),
+                                              C.byref(nruns), P(run_ptr), P(kind), P(ticket_run), err, C.c_size_t(len(err)))
+    _lib.check(rc, err)
+    if not info[0]:
+        return None
+    R = nruns.value
+    return dict(run=int(info[1]), c0=int(info[2]), c1=int(info[3]), seg_len=int(info[4]), nseg=int(info[5]),
+                run_ptr=run_ptr[:R + 1], kind=kind[:R], ticket_run=ticket_run[:R + 1])
+
+
+def simulate_spec_schedule(sched, spec, workgroups, visit=1.0, runner_visit=0.25, handover=0.0):
+    """Discrete simulation of a sweep on the speculative schedule with `workgroups` resident workgroups
+    that take tickets in order.  sched: schedule() of the same graph and direction (positions, dependencies);
+    spec: spec_schedule().  The runner (ticket -1) walks the cut run at `runner_visit` per node -- a node's foreign
+    dependencies must be done (a node of the cut run is done when its SEGMENT has committed) -- and publishes at every
+    cut; segment s starts behind the runner's cut s, walks its nodes at `visit`, and commits once segment s - 1 has
+    (+ `handover`): only then are its nodes done for everybody else.  Returns (makespan, finished_all, commit times)."""
+    import heapq
+    rank_at, dep_ptr, dep_rank = sched["rank_at"], sched["dep_ptr"], sched["dep_rank"]
+    run_ptr, kind, ticket_run = spec["run_ptr"], spec["kind"], spec["ticket_run"]
+    c0, c1, L, nseg = spec["c0"], spec["c1"], spec["seg_len"], spec["nseg"]
+    N = len(rank_at)
+    R = len(kind)
+    done_t = np.full(N, -1.0)
+    pub_t = np.full(nseg + 1, -1.0); pub_t[0] = 0.0
+    commit_t = np.full(nseg, -1.0)
+    waiting = {}                                   # event key -> tasks blocked on it
+    cur = {k: int(run_ptr[k]) for k in range(R)}   # next schedule position of each run
+    cur[-1] = c0
+    clock = {}
+    walked = {}                                    # segments: end of the walk
+    next_ticket = 0
+    free_at, events = [], []
+    T = len(ticket_run)
+    for _ in range(min(int(workgroups), T)):
+        heapq.heappush(free_at, 0.0)
+    finished = 0
+
+    def start_next():
+        nonlocal next_ticket
+        while free_at and next_ticket < T:
+            t0 = heapq.heappop(free_at)
+            k = int(ticket_run[next_ticket]); next_ticket += 1
+            clock[k] = t0
+            heapq.heappush(events, (t0, k))
+
+    def wait(key, k):
+        waiting.setdefault(key, []).append(k)
+
+    def fire(key, t):
+        for kk in waiting.pop(key, []):
+            heapq.heappush(events, (t, kk))
+
+    def deps_ready(r, k, now):
+        for x in dep_rank[dep_ptr[r]:dep_ptr[r + 1]]:
+            x = int(x)
+            if done_t[x] < 0:
+                wait(("rank", x), k)
+                return None
+            now = max(now, done_t[x] + handover)
+        return now
+
+    start_next()
+    while events:
+        t, k = heapq.heappop(events)
+        clock[k] = max(clock[k], t)
+        blocked = False
+        if k == -1:                                # the runner
+            while cur[-1] < c1:
+                ready = deps_ready(int(rank_at[cur[-1]]), k, clock[k])
+                if ready is None:
+                    blocked = True; break
+                clock[k] = ready + runner_visit
+                cur[-1] += 1
+                off = cur[-1] - c0
+                if cur[-1] < c1 and off % L == 0 and off // L < nseg:
+                    pub_t[off // L] = clock[k]
+                    fire(("pub", off // L), clock[k])
+        else:
+            seg = int(kind[k]) - 1
+            if seg > 0 and cur[k] == int(run_ptr[k]):
+                if pub_t[seg] < 0:
+                    wait(("pub", seg), k); continue
+                clock[k] = max(clock[k], pub_t[seg] + handover)
+            while cur[k] < run_ptr[k + 1]:
+                r = int(rank_at[cur[k]])
+                ready = deps_ready(r, k, clock[k])
+                if ready is None:
+                    blocked = True; break
+                clock[k] = ready + visit
+                if seg < 0:
+                    done_t[r] = clock[k]
+                    fire(("rank", r), clock[k])
+                cur[k] += 1
+            if not blocked and seg >= 0:
+                if seg > 0 and commit_t[seg - 1] < 0:
+                    wait(("commit", seg - 1), k); continue
+                if seg > 0:
+                    clock[k] = max(clock[k], commit_t[seg - 1] + handover)
+                commit_t[seg] = clock[k]
+                for pos in range(int(run_ptr[k]), int(run_ptr[k + 1])):
+                    done_t[int(rank_at[pos])] = clock[k]
+                    fire(("rank", int(rank_at[pos])), clock[k])
+                fire(("commit", seg), clock[k])
+        if not blocked:
+            finished += 1
+            heapq.heappush(free_at, clock[k])
+            start_next()
+    return float(done_t.max()), finished == T and bool((done_t >= 0).all()), commit_t
+
+
 def look_ahead_allowed(sched, direction):
     """Bit 12 of descriptor word 2 (trws_graph.cpp), restated from the schedule: by rank, may a loader
     wait for the node's foreign dependencies two visits ahead?  True if every dependency comes before
