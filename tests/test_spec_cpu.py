@@ -71,4 +71,4 @@ def test_the_protocol_terminates_and_pays(workgroups):
         # and a slow runner is no worse than none (it then paces the chain like the plain schedule)
         # (with a handful of workgroups the runner's own costs the rows a worker: no bound asked for there)
         depth2, ok2, _ = simulate_spec_schedule(s, sp, workgroups, visit=1.0, runner_visit=1.0)
-        assert ok2 and (workgroups < 256 or depth2 <= plain + sp["seg_len"] + 2)
+        assert ok2 and (workgroups < 256 or depth2 <= plain + 3 * sp["seg_len"])
