@@ -273,7 +273,7 @@ int stereo_trws_plan_debug_flags(stereo_trws_plan *plan, int32_t *done, int32_t 
  * stereo_trws_plan_spec_stats).  info[0..5] = exists, the run of stereo_trws_schedule that is cut, its first schedule
  * position, one past its last, visits per segment, segments.  The arrays (may be NULL) describe the schedule with that
  * run replaced by its segments: run_ptr (*nruns + 1 schedule positions), kind (*nruns: 0, or 1 + segment index),
- * ticket_run (*nruns + 1 tickets; -1 = the runner's ticket, just in front of segment 0).  No reference counterpart. */
+ * ticket_run (*nruns + 1 tickets; -1 = the runner's ticket, the first).  No reference counterpart. */
 int stereo_trws_spec_schedule(int64_t N, int64_t E, const uint32_t *connectivity0, int direction, int64_t *info,
                               int64_t *nruns, int64_t *run_ptr, int64_t *kind, int64_t *ticket_run, char *err,
                               size_t errcap);

@@ -595,9 +595,13 @@ bool build_trws_graph(int64_t N, int64_t E, const uint32_t *conn, TrwsGraph &g,
             else { sp.run_ptr.push_back(S.chain_run_ptr[k]); sp.kind.push_back(0); }
           }
           sp.run_ptr.push_back(S.chain_run_ptr[RR]);
+          // tickets: the runner's first, whatever the direction (the workgroup that draws it serves it before anything
+          // else, trws_pipe.hip; it waits for what it needs, holding one CU of 256), then the chain schedule's order
+          // with the cut run's ticket replaced by its segments'
+          sp.run_order.push_back(-1);
           for (int64_t t = 0; t < RR; ++t) {
             const int32_t k = S.chain_run_order.empty() ? (int32_t)t : S.chain_run_order[t];
-            if (k == best) { sp.run_order.push_back(-1); for (int32_t q = 0; q < sp.nseg; ++q) sp.run_order.push_back((int32_t)best + q); }
+            if (k == best) for (int32_t q = 0; q < sp.nseg; ++q) sp.run_order.push_back((int32_t)best + q);
             else sp.run_order.push_back(k < best ? k : k + sp.nseg - 1);
           }
           sp.ok = true;

@@ -93,7 +93,7 @@ struct TrwsGraph {
       int32_t c0 = 0, c1 = 0;            // its schedule positions
       int32_t seg_len = 0, nseg = 0, max_len = 0;
       std::vector<int32_t> run_ptr;      // CSR over schedule positions, the cut run as nseg runs
-      std::vector<int32_t> run_order;    // ticket -> run; -1: the runner's ticket (just in front of segment 0)
+      std::vector<int32_t> run_order;    // ticket -> run; -1: the runner's ticket (ticket 0)
       std::vector<int32_t> kind;         // per run: 0, or 1 + segment index
     } spec;
   } sweep[2];

@@ -47,18 +47,36 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
   double *gtab = zrow + kWave;                            // gtab[k] = (double)1 / (double)k, k = 1 .. 8 (MRFEnergy.cpp:207-228), divided once
   double *xchg = gtab + 16;                               // per compute wave (as helper): partial minima and match counts of a shared message
   int *xflag = (int *)(xchg + kPipeCompute * kPipeXchg);  // ... and the flag behind them (CoopPart, trws_dev.h)
+  constexpr int D = BACKWARD ? 1 : 0;
+  // The runner of the speculative schedule holds ticket 0 of either direction, and the workgroup that draws it calls
+  // it HERE, before anything the visit loops keep in registers exists: a call in the ticket loop has all of that live
+  // across it, the compiler spills what the callee touches over its whole live range -- reloads inside the visit
+  // loops -- and which registers the callee touches changed with every edit of the runner (measured: a fifth of an
+  // iteration either way).  At this point only the kernel arguments are live.
+  bool have_ticket = false;
+  if (SPEC) {
+    if (threadIdx.x == 0) {
+      const int t_ = atomicAdd(p.ticket, 1);
+      ctl[0] = t_ < p.ntickets[D] ? (p.run_order[D] ? p.run_order[D][t_] : t_) : p.nruns[D];
+      ctl[1] = 0; ctl[2] = 0; ctl[3] = 0;
+    }
+    __syncthreads();
+    const int first = __builtin_amdgcn_readfirstlane(ctl[0]);
+    __syncthreads();
+    if (first == -1) chain_runner<BACKWARD, PRIMAL, UPDATE>(p.self, epoch, kPipeLdsDoubles, kPipeCtlOff);
+    else have_ticket = true;
+  }
   const int K = p.K;
   const double inf = __builtin_huge_val();
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
-  constexpr int D = BACKWARD ? 1 : 0;
   constexpr int DW = TrwsGraph::kDescWords;
   const int32_t *desc = p.desc[D];
   const bool act = lane < K;
   const double posk = (SHARED && act) ? p.pos[lane] : 0.0;
   int look_streak = 0;  // failed second looks in a row (this compute wave): see message_regs
   const int perm_shared = (SHARED && wave < kPipeCompute) ? (act ? (int)p.perm_pos[lane] : lane) : -1;  // source order by position, once
-  if (tid == 0) { ctl[1] = 0; ctl[2] = 0; ctl[3] = 0; }
+  if (!SPEC && tid == 0) { ctl[1] = 0; ctl[2] = 0; ctl[3] = 0; }
   if (tid < kWave) zrow[tid] = 0.0;
   if (tid < 16) gtab[tid] = (double)1 / (double)(tid > 0 ? tid : 1);
   if (tid < kPipeCompute) xflag[tid] = 0;
@@ -81,19 +99,15 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
 
   for (;;) {
     // (ctl[3]: the workgroup walks the speculative segment it holds a second time -- no new ticket)
-    if (tid == 0 && !(SPEC && ctl[3])) { const int t_ = atomicAdd(p.ticket, 1); ctl[0] = t_ < p.ntickets[D] ? (p.run_order[D] ? p.run_order[D][t_] : t_) : p.nruns[D]; }
+    if (tid == 0 && !(SPEC && (ctl[3] || have_ticket))) { const int t_ = atomicAdd(p.ticket, 1); ctl[0] = t_ < p.ntickets[D] ? (p.run_order[D] ? p.run_order[D][t_] : t_) : p.nruns[D]; }
+    have_ticket = false;
     __syncthreads();
     const int run = __builtin_amdgcn_readfirstlane(ctl[0]);
     const int second_walk = SPEC ? __builtin_amdgcn_readfirstlane(ctl[3]) : 0;
     __syncthreads();
     if (SPEC && tid == 0) ctl[3] = 0;
     if (run >= p.nruns[D]) break;
-    if (SPEC && run < 0) {   // the runner's ticket of the speculative schedule (trws_spec.h)
-#ifndef STEREO_X_NOCALL
-      chain_runner<BACKWARD, PRIMAL, UPDATE>(p.self, epoch, kPipeLdsDoubles, kPipeCtlOff);
-#endif
-      continue;
-    }
+    if (SPEC && run < 0) continue;   // (the runner's ticket is ticket 0: drawn and served above)
     const int p0 = p.run_ptr[D][run], p1 = p.run_ptr[D][run + 1];
     // a segment of the speculative schedule (trws_graph.h: Sweep::Spec): its first visit takes what the node in front
     // hands over from the runner's rows, its completion flags wait for the commit below the visit loops

@@ -229,6 +229,7 @@ struct stereo_trws_plan {
   DevBuf<unsigned long long> d_spec_stat;
   DevBuf<DevParams> d_self;
   PinnedBuf<DevParams> h_self;
+  bool self_sent = false;
   bool spec_allowed = false;   // the graph has such a run in both directions and STEREO_HIP_TRWS_SPEC is not 0
   bool spec_window = false;    // the positions are uniformly spaced over the window rounded up to four (finish_inputs)
   ~stereo_trws_plan() {
@@ -332,7 +333,12 @@ void launch_persistent(stereo_trws_plan *P, const DevParams &p, int what, hipStr
   STEREO_HIP_CHECK(hipMemsetAsync(P->d_ctl.p, 0, sizeof(int32_t), s));  // ticket = 0
   if (P->wide) launch_wide(P->kernel, what, std::min(P->grid_blocks, P->cus), s, p, epoch);
   else if (P->fast2) launch_pipe2(P->kernel, P->pos != nullptr, what, std::min(P->grid_blocks, P->cus), s, p, epoch);
-  else if (P->fast) launch_pipe(P->kernel, P->pos != nullptr, what, P->grid_blocks, s, p, epoch);
+  else if (P->fast) {
+    int blocks = P->grid_blocks;
+    static const char *be = std::getenv("STEREO_HIP_TRWS_BLOCKS");   // (development: workgroups of a pipelined sweep launch)
+    if (be && std::atoi(be) > 0) blocks = std::min(blocks, std::atoi(be));
+    launch_pipe(P->kernel, P->pos != nullptr, what, blocks, s, p, epoch);
+  }
   else launch_generic(P->kernel, P->mode, what, P->grid_blocks, persistent_lds_bytes(P->Kp), s, p, epoch);
   if (what != 3) P->sweep_launches += 1;
 }
@@ -1067,8 +1073,12 @@ int stereo_trws_plan_iterate(stereo_trws_plan *P, int iters, double max_relgap, 
   hipStream_t s = (hipStream_t)stream;
   try {
     const DevParams p = make_params(P);
-    *P->h_self.p = p;   // (the block once more in global memory: chain_runner / spec_commit read their parameters there)
-    STEREO_HIP_CHECK(hipMemcpyAsync(P->d_self.p, P->h_self.p, sizeof(DevParams), hipMemcpyHostToDevice, s));
+    // (the block once more in global memory: chain_runner / spec_commit read their parameters there; sent when it changes)
+    if (!P->self_sent || std::memcmp(P->h_self.p, &p, sizeof(DevParams)) != 0) {
+      std::memcpy(P->h_self.p, &p, sizeof(DevParams));
+      STEREO_HIP_CHECK(hipMemcpy(P->d_self.p, P->h_self.p, sizeof(DevParams), hipMemcpyHostToDevice));
+      P->self_sent = true;
+    }
     for (int it = 0; it < iters; ++it) {
       issue_iteration(P, p, s);
       double lb = 0, en = 0;
