@@ -679,7 +679,7 @@ size_t pipe_lds_bytes() {
                                    kPipeCompute * kPipeXchg + kPipeCompute / 2, "LDS layout of pipe_body");
   return sizeof(double) * kPipeLdsDoubles;
 }
-size_t pipe_spec_lds_bytes() { return sizeof(double) * (kPipeLdsDoubles + kRunDoubles); }   // ... with the runner's ring behind
+size_t pipe_spec_lds_bytes() { return sizeof(double) * (kPipeLdsDoubles + kRunDoubles + kRunDummy); }   // ... with the runner's ring behind
 int pipe_threads() { return kPipeThreads; }
 
 void pipe_set_attributes() {

@@ -251,11 +251,11 @@ size_t persistent_lds_bytes(int Kp) { return generic_lds_bytes(Kp); }
 
 // The speculative schedule runs where its runner's arithmetic is what message_regs returns under a passed certificate:
 // trws_pipe_kernel, linear kernel, certified messages, shared strictly ascending positions, uniformly spaced over the
-// truncation window (rounded up to a multiple of four entries).
+// truncation window (rounded up to a multiple of four entries, at most eight: the runner keeps the window in registers).
 bool spec_active(const stereo_trws_plan *P) {
   // (and a handful of resident workgroups: the runner, the segment that commits, the segments in between)
   return P->spec_allowed && P->grid_blocks >= 8 && P->fast && !P->wide && !P->fast2 && P->nstrips == 1 && P->kernel == 1 && P->certificate && P->pos != nullptr &&
-         P->pos_ascending && P->window <= 16 && P->uniform_step != 0 && P->spec_window;
+         P->pos_ascending && P->window <= 8 && P->uniform_step != 0 && P->spec_window;
 }
 
 DevParams make_params(stereo_trws_plan *P, bool allow_spec = true) {
@@ -684,8 +684,8 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
         P->d_spec_rows.alloc((size_t)s0.nseg * 8 * K);
         P->d_spec_undo.alloc((size_t)s0.nseg * ml * 4 * K);
         P->d_spec_x.alloc(s0.nseg);
-        P->d_spec_stat.alloc(8);
-        STEREO_HIP_CHECK(hipMemset(P->d_spec_stat.p, 0, 8 * sizeof(unsigned long long)));
+        P->d_spec_stat.alloc(16);
+        STEREO_HIP_CHECK(hipMemset(P->d_spec_stat.p, 0, 16 * sizeof(unsigned long long)));
         STEREO_HIP_CHECK(hipMemset(P->d_spec_rows.p, 0, sizeof(double) * (size_t)s0.nseg * 8 * K));
         STEREO_HIP_CHECK(hipMemset(P->d_spec_x.p, 0, sizeof(int32_t) * s0.nseg));
       }
@@ -1340,8 +1340,12 @@ int stereo_trws_plan_spec_stats(stereo_trws_plan *P, int64_t out[4]) {
   if (!P || !out) return 1;
   out[0] = spec_active(P) ? 1 : 0; out[1] = out[2] = out[3] = 0;
   if (P->d_spec_stat.p) {
-    unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long v[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpy(v, P->d_spec_stat.p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    if (v[8] && v[2])   // (-DSTEREO_HIP_RUNNER_PROFILE)
+      std::fprintf(stderr, "[stereo_hip spec] message recurrence, cycles per visit: loop top %.0f | node in registers (incl. waits) %.0f | Di, next node asked for %.0f | "
+                           "H, table, min H %.0f | window + row %.0f | publish, turn %.0f\n", (double)v[13] / v[2], (double)v[8] / v[2], (double)v[9] / v[2],
+                   (double)v[10] / v[2], (double)v[11] / v[2], (double)v[12] / v[2]);
     out[1] = (int64_t)v[0]; out[2] = (int64_t)v[1]; out[3] = (int64_t)v[2];
     if (std::getenv("STEREO_HIP_TRWS_TIMELINE"))   // (development: how often, and for how long, the message recurrence found its next node not staged yet)
       std::fprintf(stderr, "[stereo_hip spec] runner visits %llu, of them waited for the loaders %llu, %.1f us in all\n", v[2], v[3], (double)v[4] / 100.0);

@@ -32,10 +32,12 @@ constexpr int kRunTab = kRunSlots * kRunSlotDoubles;   // 16 + 64 + 16: H with +
 constexpr int kRunPub = kRunTab + 96;                  // 2 x (2 rows): what the publisher stores
 constexpr int kRunWords = kRunPub + 256;               // 64 ints (below)
 constexpr int kRunDoubles = kRunWords + 32;
+constexpr int kRunDummy = 32;                           // 64 more words: where the lanes that have nothing to say store (run_visit_m)
 // words: consumed by messages, by labels | publisher flags (rows x 2, labels x 2) | slots freed | label x 2 | node x 2 |
 //        row kinds x 2
 constexpr int kRwConsM = 12, kRwConsP = 13, kRwPubM = 14, kRwPubP = 16, kRwFree = 18, kRwLabel = 20, kRwNode = 22, kRwKinds = 24;
-// words of a staged node: tail length | tail kinds (a nibble each: 0-2 staged row, 8 / 9 first / second handed-over row)
+// words of a staged node: tail length | tail kinds (a nibble each: 0-2 staged row, 8 / 9 first / second handed-over row;
+// the length once more in bits 16-)
 // | messages to compute (0, 1, 2) | cut: segment that starts behind this node (0: none) | kinds of that segment's first
 // node's rows (a nibble per row) | n_out | incoming rows | their label (-1: the node in front) x 4 | their direction
 // bits | node id | word 15: the TAG, schedule position + 1, written last (behind a release fence): a reader that
@@ -112,105 +114,147 @@ __device__ __forceinline__ void run_request_m(const double *sl, int lane, RunNod
   n.P = sl[kRunRowP + lane]; n.S0 = sl[kRunRowS + lane]; n.S1 = sl[kRunRowS + 64 + lane]; n.S2 = sl[kRunRowS + 128 + lane];
   n.M0 = sl[kRunRowM + lane]; n.M1 = sl[kRunRowM + 64 + lane];
 }
-// min-plus over the table entries lane - 4 G .. lane + 4 G (all requested together), entry lane itself is `h`
-template <int G>
-__device__ __forceinline__ double run_window(const double *tabl, double h, const double (&ad)[16]) {
-  double lo[4 * G], hi[4 * G];
+// What the routine needs of the launch parameters, as uniform values (read once by chain_runner).
+struct RunArgsM {
+  int K, window, c0, c1;
+  double lambda, step;
+  int32_t *abort_flag;
+  long long spin_ticks;
+  unsigned long long *stat;
+};
+
+// Waits until *word >= want (the slow path of a visit that found its node not staged yet).
+__device__ __attribute__((noinline)) bool run_wait_m(const int *word, int want, int *abort_word, int32_t *abort_flag, long long spin_ticks) {
+  int spins = 0;
+  long long t0 = 0;
+  while (lds_load(word) < want) {
+    __builtin_amdgcn_s_sleep(1);
+    spins = (spins + 1) & 1023;
+    if (spins != 0) continue;
+    if (lds_load(abort_word) || ld_sc1(abort_flag)) return false;
+    const long long now = (long long)wall_clock64();
+    if (t0 == 0) { t0 = now | 1; continue; }
+    if (now - t0 > 4 * spin_ticks) { lds_store(abort_word, 1); return false; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return true;
+}
+
+// One visit of the recurrence.  `cur`: the node's words and rows (asked for during the previous visit), `nxt`: where the
+// next node's go.  Everything that steers the visit is a scalar; the lanes only ever do the arithmetic.
+template <bool BACKWARD, int G>
+__device__ __forceinline__ bool run_visit_m(const RunArgsM &a, double *rb, int *rw, double *tabl, int *cons_word, int lane, bool act, int i, int &slot_off,
+                                            RunNodeM &cur, RunNodeM &nxt, double &A0, double &A1, double (&ad)[4 * G], double &alpha_have,
+                                            int *abort_word) {
+  const double inf = __builtin_huge_val();
+  if (__builtin_amdgcn_readlane(cur.sw, kRsTag) != i + 1) {   // (not there yet when it was asked for)
+    if (!run_wait_m((const int *)(rb + slot_off + kRunSc) + kRsTag, i + 1, abort_word, a.abort_flag, a.spin_ticks)) return false;
+    run_request_m(rb + slot_off, lane, cur);
+  }
+  const int sw = cur.sw;
+  const int key = __builtin_amdgcn_readlane(sw, kRsKinds), nmsg = __builtin_amdgcn_readlane(sw, kRsNmsg), cut = __builtin_amdgcn_readlane(sw, kRsCut);
+  double Di = cur.P;
+  // the tail of the node's list from the first handed-over row on, in list order (the order of the reference's additions)
+  if (key == 0x20098) { Di += A0; Di += A1; }                                   // handed over, handed over (forward chain)
+  else if (key == 0x30908) { Di += A0; Di += cur.S0; Di += A1; }                // ... with a row of another run in between
+  else if (key == 0x30098) { Di += A0; Di += A1; Di += cur.S0; }
+  else if (key == 0x41908) { Di += A0; Di += cur.S0; Di += A1; Di += cur.S1; }
+  else {
+    const int nt = key >> 16;
+    for (int t = 0; t < nt; ++t) {
+      const int kd = (key >> (4 * t)) & 15;
+      if (kd == 8) Di += A0; else if (kd == 9) Di += A1; else if (kd == 0) Di += cur.S0; else if (kd == 1) Di += cur.S1; else Di += cur.S2;
+    }
+  }
+  if (BACKWARD) Di -= wave_min_dpp(act ? Di : inf);   // minimize.cpp:79-83 (the node's own lower-bound term)
+  const double sd = cur.sd, mold0 = cur.M0, mold1 = cur.M1;
+  const double gamma = readlane_f64(sd, 2);
+  // this node's words and rows are in registers: its place in the ring is free (one store instruction without an
+  // exec-mask region: lane 0 hits the word, the other lanes words of their own nobody reads), and the next node's are
+  // asked for
+  lds_store(cons_word, i + 1 - a.c0);
+  slot_off += kRunSlotDoubles;
+  if (slot_off == kRunSlots * kRunSlotDoubles) slot_off = 0;
+  if (i + 1 < a.c1) run_request_m(rb + slot_off, lane, nxt);
+  double R0 = 0, R1 = 0;
+  for (int m = 0; m < nmsg; ++m) {
+    const double alpha = readlane_f64(sd, m);
+    const double h = act ? gamma * Di - (m == 0 ? mold0 : mold1) : inf;
+    double out = 0;   // (alpha == 0: typeStereoLinear.h:390-396, a constant row, normalised)
+    if (alpha != 0) {
+      *tabl = h;
+      if (alpha != alpha_have) {
 #pragma unroll
-  for (int d = 0; d < 4 * G; ++d) { lo[d] = tabl[-(d + 1)]; hi[d] = tabl[d + 1]; }
-  double ma = h, mb = __builtin_huge_val();   // (two chains)
+        for (int d = 0; d < 4 * G; ++d) ad[d] = alpha * ((double)(d + 1) * a.step);
+        alpha_have = alpha;
+      }
+      const double hmin = wave_min_dpp(h);
+      const double vtrunc = hmin + alpha * a.lambda;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      double lo[4 * G], hi[4 * G];
 #pragma unroll
-  for (int d = 0; d < 4 * G; ++d) { ma = min_raw(ma, lo[d] + ad[d]); mb = min_raw(mb, hi[d] + ad[d]); }
-  return min_raw(ma, mb);
+      for (int d = 0; d < 4 * G; ++d) { lo[d] = tabl[-(d + 1)]; hi[d] = tabl[d + 1]; }
+      double ma = h, mb = vtrunc;   // (two chains)
+#pragma unroll
+      for (int d = 0; d < 4 * G; ++d) { ma = min_raw(ma, lo[d] + ad[d]); mb = min_raw(mb, hi[d] + ad[d]); }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      out = min_raw(ma, mb) - hmin;
+    }
+    if (m == 0) R0 = out; else R1 = out;
+  }
+  A0 = R0; A1 = nmsg == 2 ? R1 : R0;
+  if (cut) {
+    // the rows the segment behind this node starts from: to the publisher
+    const int ps = cut & 1;
+    if (lds_load(rw + kRwFree) < cut - 2 && !run_wait_m(rw + kRwFree, cut - 2, abort_word, a.abort_flag, a.spin_ticks)) return false;
+    double *pb = rb + kRunPub + ps * 128;
+    pb[lane] = A0; pb[64 + lane] = A1;
+    if (lane == 0) lds_store(rw + kRwKinds + ps, __builtin_amdgcn_readlane(sw, kRsPubKinds));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) lds_store(rw + kRwPubM + ps, cut);
+  }
+  return true;
+}
+
+template <bool BACKWARD, int G>
+__device__ __forceinline__ void run_messages_g(const RunArgsM &a, double *rb, int lane, int *abort_word) {
+  const bool act = lane < a.K;
+  int *rw = (int *)(rb + kRunWords);
+  double *tabl = rb + kRunTab + 16 + lane;   // this lane's entry of the H table
+  int *cons_word = lane == 0 ? rw + kRwConsM : (int *)(rb + kRunDoubles) + lane;   // (kRunDummy words behind the runner's LDS)
+  double ad[4 * G];   // alpha |d step| of the window's index distances, for the weight seen last
+#pragma unroll
+  for (int d = 0; d < 4 * G; ++d) ad[d] = 0;
+  double alpha_have = 0;   // (never a weight that takes the window path)
+  double A0 = 0, A1 = 0;
+  RunNodeM na, nb;
+  run_request_m(rb, lane, na);
+  nb = na;
+  int slot_off = 0;
+  // (two visits per trip: the nodes' registers swap roles instead of being copied)
+  for (int i = a.c0; i < a.c1; i += 2) {
+    if (!run_visit_m<BACKWARD, G>(a, rb, rw, tabl, cons_word, lane, act, i, slot_off, na, nb, A0, A1, ad, alpha_have, abort_word)) return;
+    if (i + 1 < a.c1 && !run_visit_m<BACKWARD, G>(a, rb, rw, tabl, cons_word, lane, act, i + 1, slot_off, nb, na, A0, A1, ad, alpha_have, abort_word)) return;
+  }
 }
 
 template <bool BACKWARD>
-__device__ __forceinline__ void run_messages(const DevParams &p, double *rb, int c0, int c1, int lane, int *abort_word) {
-  const double inf = __builtin_huge_val();
-  const int K = p.K;
-  const bool act = lane < K;
-  int *rw = (int *)(rb + kRunWords);
-  double *tabl = rb + kRunTab + 16 + lane;   // this lane's entry of the H table
-  const int wgroups = (p.window + 3) >> 2;   // the window in groups of four (entries beyond it cost >= vTrunc bit for bit)
-  double ad[16];
-  double alpha_have = 0;
-#pragma unroll
-  for (int d = 0; d < 16; ++d) ad[d] = 0;
-  bool have_ad = false;
-  double A0 = 0, A1 = 0;
-  RunNodeM cur, nxt;
-  run_request_m(rb, lane, cur);
-  nxt = cur;
-  for (int i = c0; i < c1; ++i) {
-    const double *sl = rb + ((i - c0) % kRunSlots) * kRunSlotDoubles;
-    if (RLI(cur.sw, kRsTag) != i + 1) {   // (not there yet when it was asked for)
-      if (!run_wait(p, (const int *)(sl + kRunSc) + kRsTag, i + 1, abort_word)) return;
-      run_request_m(sl, lane, cur);
-    }
-    const int sw = cur.sw;
-    const int nt = RLI(sw, kRsNt), kinds = RLI(sw, kRsKinds), nmsg = RLI(sw, kRsNmsg), cut = RLI(sw, kRsCut);
-    double Di = cur.P;
-    // the tail of the node's list from the first handed-over row on, in list order (the order of the reference's additions)
-    switch (kinds | (nt << 16)) {
-      case 0x20098: Di += A0; Di += A1; break;                           // handed over, handed over (forward chain)
-      case 0x30908: Di += A0; Di += cur.S0; Di += A1; break;             // ... with a row of another run in between
-      case 0x30098: Di += A0; Di += A1; Di += cur.S0; break;
-      case 0x41908: Di += A0; Di += cur.S0; Di += A1; Di += cur.S1; break;
-      default:
-        for (int t = 0; t < nt; ++t) {
-          const int kd = (kinds >> (4 * t)) & 15;
-          if (kd == 8) Di += A0; else if (kd == 9) Di += A1; else if (kd == 0) Di += cur.S0; else if (kd == 1) Di += cur.S1; else Di += cur.S2;
-        }
-    }
-    if (BACKWARD) Di -= wave_min_dpp(act ? Di : inf);   // minimize.cpp:79-83 (the node's own lower-bound term)
-    const double gamma = readlane_f64(cur.sd, 2);
-    const double mold0 = cur.M0, mold1 = cur.M1, sd = cur.sd;
-    // this node's words and rows are in registers: its place in the ring is free, and the next node's are asked for
-    if (lane == 0) lds_store(rw + kRwConsM, i + 1 - c0);
-    if (i + 1 < c1) run_request_m(rb + ((i + 1 - c0) % kRunSlots) * kRunSlotDoubles, lane, nxt);
-    double R0 = 0, R1 = 0;
-    for (int m = 0; m < nmsg; ++m) {
-      const double alpha = readlane_f64(sd, m);
-      const double mold = m == 0 ? mold0 : mold1;
-      const double h = act ? gamma * Di - mold : inf;
-      double out;
-      if (alpha == 0) {
-        out = 0;   // typeStereoLinear.h:390-396: a constant row, normalised
-      } else {
-        *tabl = h;
-        if (!(have_ad && alpha == alpha_have)) {
-#pragma unroll
-          for (int d = 0; d < 16; ++d) ad[d] = alpha * ((double)(d + 1) * p.uniform_step);
-          alpha_have = alpha; have_ad = true;
-        }
-        const double hmin = wave_min_dpp(h);
-        const double vtrunc = hmin + alpha * p.lambda;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        double mm;
-        if (wgroups <= 1) mm = run_window<1>(tabl, h, ad);
-        else if (wgroups == 2) mm = run_window<2>(tabl, h, ad);
-        else if (wgroups == 3) mm = run_window<3>(tabl, h, ad);
-        else mm = run_window<4>(tabl, h, ad);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        out = min_raw(mm, vtrunc) - hmin;
-      }
-      if (m == 0) R0 = out; else R1 = out;
-    }
-    A0 = R0; A1 = nmsg == 2 ? R1 : R0;
-    if (cut) {
-      // the rows the segment behind this node starts from: to the publisher
-      const int ps = cut & 1;
-      if (!run_wait(p, rw + kRwFree, cut - 2, abort_word)) return;
-      double *pb = rb + kRunPub + ps * 128;
-      pb[lane] = A0; pb[64 + lane] = A1;
-      if (lane == 0) rw[kRwKinds + ps] = RLI(sw, kRsPubKinds);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) lds_store(rw + kRwPubM + ps, cut);
-    }
-    cur = nxt;
-  }
+__device__ __attribute__((noinline)) void run_messages(const DevParams *pp, int rb_off_, int abort_off_) {
+  extern __shared__ __attribute__((aligned(16))) double run_lds[];
+  constexpr int D = BACKWARD ? 1 : 0;
+  RunArgsM a;
+  a.K = uniform_value(pp->K); a.window = uniform_value(pp->window); a.c0 = uniform_value(pp->spec_c0[D]); a.c1 = uniform_value(pp->spec_c1[D]);
+  a.lambda = uniform_value(pp->lambda); a.step = uniform_value(pp->uniform_step);
+  a.abort_flag = uniform_value(pp->abort_flag); a.spin_ticks = uniform_value(pp->spin_ticks); a.stat = uniform_value(pp->spec_stat);
+  double *rb = run_lds + __builtin_amdgcn_readfirstlane(rb_off_);
+  int *abort_word = (int *)(run_lds + __builtin_amdgcn_readfirstlane(abort_off_)) + 1;
+  const int lane = threadIdx.x & (kWave - 1);
+  // the window in groups of four entries (entries beyond it cost >= vTrunc bit for bit, finish_inputs checks the spacing);
+  // windows of more than eight entries keep the plain schedule (spec_active, trws_plan.hip)
+  if (a.window <= 4) run_messages_g<BACKWARD, 1>(a, rb, lane, abort_word);
+  else run_messages_g<BACKWARD, 2>(a, rb, lane, abort_word);
 }
 
 // ---- wave 1: the labels of the primal pass (minimize.cpp:223-264, as the primal wave of a visit computes them) ------
@@ -396,7 +440,7 @@ __device__ __forceinline__ void run_loader(const DevParams &p, int epoch, double
     }
     {
       int word = 0;
-      word = lane == kRsNt ? nt : lane == kRsKinds ? kinds : lane == kRsNmsg ? nmsg : lane == kRsCut ? cut
+      word = lane == kRsNt ? nt : lane == kRsKinds ? (kinds | (nt << 16)) : lane == kRsNmsg ? nmsg : lane == kRsCut ? cut
            : lane == kRsPubKinds ? pubkinds : lane == kRsNout ? nout : lane == kRsNin ? nin : lane == kRsMd ? (md >> nout) : lane == kRsNode ? RLI(w, 0) : 0;
       const int srck = __shfl(src, lane - kRsSrc, kWave);
       if (lane >= kRsSrc && lane < kRsSrc + 4) word = srck;
@@ -465,7 +509,7 @@ __device__ __attribute__((noinline)) void chain_runner(const DevParams *pp_, int
   if (tid < 16) { rb[kRunTab + tid] = __builtin_huge_val(); rb[kRunTab + 80 + tid] = __builtin_huge_val(); }
   if (p.timeline && tid == 0) p.timeline[((size_t)2 * p.tl_stride + D) * 2] = wall_clock64();
   __syncthreads();
-  if (wave == 0) { if (UPDATE) { __builtin_amdgcn_s_setprio(3); run_messages<BACKWARD>(p, rb, c0, c1, lane, abort_word); __builtin_amdgcn_s_setprio(0); } }
+  if (wave == 0) { if (UPDATE) { __builtin_amdgcn_s_setprio(3); run_messages<BACKWARD>(pp_, rb_off, abort_off_); __builtin_amdgcn_s_setprio(0); } }
   else if (wave == 1) { if (PRIMAL) { __builtin_amdgcn_s_setprio(3); run_labels(p, rb, c0, c1, lane, abort_word); __builtin_amdgcn_s_setprio(0); } }
   else if (wave < 2 + kRunLoaders) run_loader<BACKWARD, PRIMAL, UPDATE>(p, epoch, rb, c0, c1, wave - 2, lane, abort_word);
   else if (wave == 2 + kRunLoaders) run_publisher<PRIMAL, UPDATE>(p, epoch, rb, lane, abort_word);

@@ -66,8 +66,8 @@ CASES = [
     (1, 30, 40, 16, 4.0, 1.0, "unit", None),
     (2, 36, 52, 60, 8.0, 0.5, "random", None),
     (3, 41, 33, 7, 2.0, 1.0, "zeros", None),
-    (4, 30, 40, 16, 10.0, 1.0, "pairs", "8"),      # window of ten entries: three groups of four; short segments
-    (5, 64, 64, 33, 15.0, 1.0, "unit", "24"),      # window of fifteen
+    (4, 30, 40, 16, 3.0, 1.0, "pairs", "8"),       # window of three entries: one group of four; short segments
+    (5, 64, 64, 33, 7.5, 1.0, "unit", "24"),       # window of seven; long segments
     (6, 35, 45, 64, 3.0, 0.25, "pairs", None),     # K = 64: no idle lane
 ]
 
@@ -104,7 +104,8 @@ def test_speculative_schedule_against_the_oracle(hip, oracle, monkeypatch):
 
 
 def test_where_the_speculative_schedule_stays_off(hip, oracle, monkeypatch):
-    """Positions that are not uniformly spaced, and the quadratic kernel, keep the plain schedule (and its results)."""
+    """Positions that are not uniformly spaced, windows of more than eight entries and the quadratic kernel keep the
+    plain schedule (and its results)."""
     H, W, K = 30, 40, 10
     unary, conn, alphas = _problem(11, H, W, K, "unit")
     uneven = np.cumsum(np.random.default_rng(3).uniform(0.5, 1.5, K))
@@ -113,6 +114,11 @@ def test_where_the_speculative_schedule_stays_off(hip, oracle, monkeypatch):
     q = np.tile(uneven, (conn.shape[0], 1))
     lab_o, en_o, lb_o, _ = oracle.trws(1, unary, conn, q, q, alphas, 3.0, 3, -1e300, mode=1)
     assert np.array_equal(got[-1][0], lab_o) and got[-1][1] == en_o and got[-1][2] == lb_o
+    wide, stw = _solve(monkeypatch, {}, 1, unary, conn, 9.5, 3, np.arange(K, dtype=np.float64), alphas)
+    assert not stw["active"]
+    qw = np.tile(np.arange(K, dtype=np.float64), (conn.shape[0], 1))
+    lab_o, en_o, lb_o, _ = oracle.trws(1, unary, conn, qw, qw, alphas, 9.5, 3, -1e300, mode=1)
+    assert np.array_equal(wide[-1][0], lab_o) and wide[-1][1] == en_o and wide[-1][2] == lb_o
     got2, st2 = _solve(monkeypatch, {}, 2, unary, conn, 9.0, 3, np.arange(K, dtype=np.float64), alphas)
     assert not st2["active"]
     q2 = np.tile(np.arange(K, dtype=np.float64), (conn.shape[0], 1))
