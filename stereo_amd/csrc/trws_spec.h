@@ -148,8 +148,11 @@ __device__ __forceinline__ bool run_visit_m(const RunArgsM &a, double *rb, int *
                                             int *abort_word) {
   const double inf = __builtin_huge_val();
   if (__builtin_amdgcn_readlane(cur.sw, kRsTag) != i + 1) {   // (not there yet when it was asked for)
-    if (!run_wait_m((const int *)(rb + slot_off + kRunSc) + kRsTag, i + 1, abort_word, a.abort_flag, a.spin_ticks)) return false;
+    const long long t0_ = (long long)wall_clock64();
+    // (a real call's result arrives in a vector register: say that it is uniform, or the loop gets exec-mask exits)
+    if (!__builtin_amdgcn_readfirstlane((int)run_wait_m((const int *)(rb + slot_off + kRunSc) + kRsTag, i + 1, abort_word, a.abort_flag, a.spin_ticks))) return false;
     run_request_m(rb + slot_off, lane, cur);
+    if (a.stat && lane == 0) { atomicAdd(a.stat + 3, 1ull); atomicAdd(a.stat + 4, (unsigned long long)((long long)wall_clock64() - t0_)); }
   }
   const int sw = cur.sw;
   const int key = __builtin_amdgcn_readlane(sw, kRsKinds), nmsg = __builtin_amdgcn_readlane(sw, kRsNmsg), cut = __builtin_amdgcn_readlane(sw, kRsCut);
@@ -208,7 +211,8 @@ __device__ __forceinline__ bool run_visit_m(const RunArgsM &a, double *rb, int *
   if (cut) {
     // the rows the segment behind this node starts from: to the publisher
     const int ps = cut & 1;
-    if (lds_load(rw + kRwFree) < cut - 2 && !run_wait_m(rw + kRwFree, cut - 2, abort_word, a.abort_flag, a.spin_ticks)) return false;
+    if (__builtin_amdgcn_readfirstlane(lds_load(rw + kRwFree)) < cut - 2 &&
+        !__builtin_amdgcn_readfirstlane((int)run_wait_m(rw + kRwFree, cut - 2, abort_word, a.abort_flag, a.spin_ticks))) return false;
     double *pb = rb + kRunPub + ps * 128;
     pb[lane] = A0; pb[64 + lane] = A1;
     if (lane == 0) lds_store(rw + kRwKinds + ps, __builtin_amdgcn_readlane(sw, kRsPubKinds));
@@ -269,12 +273,20 @@ __device__ __forceinline__ void run_request_p(const double *sl, int lane, RunNod
   n.TH = sl[kRunRowTH + lane];
   n.O0 = sl[kRunRowOUT + lane]; n.O1 = sl[kRunRowOUT + 64 + lane]; n.O2 = sl[kRunRowOUT + 128 + lane]; n.O3 = sl[kRunRowOUT + 192 + lane];
 }
-__device__ __forceinline__ void run_labels(const DevParams &p, double *rb, int c0, int c1, int lane, int *abort_word) {
+template <bool BACKWARD>
+__device__ __attribute__((noinline)) void run_labels(const DevParams *pp_, int rb_off_, int abort_off_) {
+  extern __shared__ __attribute__((aligned(16))) double run_lds[];
+  const DevParams p = uniform_params(pp_);
+  double *rb = run_lds + __builtin_amdgcn_readfirstlane(rb_off_);
+  int *abort_word = (int *)(run_lds + __builtin_amdgcn_readfirstlane(abort_off_)) + 1;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int c0 = p.spec_c0[BACKWARD ? 1 : 0], c1 = p.spec_c1[BACKWARD ? 1 : 0];
   const double inf = __builtin_huge_val();
   const int K = p.K;
   const bool act = lane < K;
   int *rw = (int *)(rb + kRunWords);
   const double posk = act ? p.pos[lane] : 0.0;
+  const double lambda = p.lambda;
   int xprev = 0;
   RunNodeP cur, nxt;
   run_request_p(rb, lane, cur);
@@ -299,7 +311,7 @@ __device__ __forceinline__ void run_labels(const DevParams &p, double *rb, int c
         const int ks = src < 0 ? xprev : src;
         const double pks = readlane_f64(posk, ks);
         const double d = ((md >> k) & 1) == 0 ? pks - posk : posk - pks;
-        db += readlane_f64(sd, 3 + k) * min_raw(fabs(d), p.lambda);
+        db += readlane_f64(sd, 3 + k) * min_raw(fabs(d), lambda);
       }
     }
     double di = db;
@@ -323,8 +335,15 @@ __device__ __forceinline__ void run_labels(const DevParams &p, double *rb, int c
 
 // ---- waves 2-9: staging ---------------------------------------------------------------------------------------------
 template <bool BACKWARD, bool PRIMAL, bool UPDATE>
-__device__ __forceinline__ void run_loader(const DevParams &p, int epoch, double *rb, int c0, int c1, int lw, int lane, int *abort_word) {
+__device__ __attribute__((noinline)) void run_loader(const DevParams *pp_, int epoch_, int rb_off_, int abort_off_, int lw_) {
+  extern __shared__ __attribute__((aligned(16))) double run_lds[];
+  const DevParams p = uniform_params(pp_);
+  double *rb = run_lds + __builtin_amdgcn_readfirstlane(rb_off_);
+  int *abort_word = (int *)(run_lds + __builtin_amdgcn_readfirstlane(abort_off_)) + 1;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int epoch = __builtin_amdgcn_readfirstlane(epoch_), lw = __builtin_amdgcn_readfirstlane(lw_);
   constexpr int D = BACKWARD ? 1 : 0;
+  const int c0 = p.spec_c0[D], c1 = p.spec_c1[D];
   constexpr int DW = TrwsGraph::kDescWords;
   const int32_t *desc = p.desc[D];
   const int K = p.K;
@@ -458,7 +477,13 @@ __device__ __forceinline__ void run_loader(const DevParams &p, int epoch, double
 
 // ---- wave 10: what a segment starts from, to global memory ------------------------------------------------------------
 template <bool PRIMAL, bool UPDATE>
-__device__ __forceinline__ void run_publisher(const DevParams &p, int epoch, double *rb, int lane, int *abort_word) {
+__device__ __attribute__((noinline)) void run_publisher(const DevParams *pp_, int epoch_, int rb_off_, int abort_off_) {
+  extern __shared__ __attribute__((aligned(16))) double run_lds[];
+  const DevParams p = uniform_params(pp_);
+  double *rb = run_lds + __builtin_amdgcn_readfirstlane(rb_off_);
+  int *abort_word = (int *)(run_lds + __builtin_amdgcn_readfirstlane(abort_off_)) + 1;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int epoch = __builtin_amdgcn_readfirstlane(epoch_);
   const int K = p.K;
   const int lk = lane < K ? lane : K - 1;
   int *rw = (int *)(rb + kRunWords);
@@ -510,9 +535,9 @@ __device__ __attribute__((noinline)) void chain_runner(const DevParams *pp_, int
   if (p.timeline && tid == 0) p.timeline[((size_t)2 * p.tl_stride + D) * 2] = wall_clock64();
   __syncthreads();
   if (wave == 0) { if (UPDATE) { __builtin_amdgcn_s_setprio(3); run_messages<BACKWARD>(pp_, rb_off, abort_off_); __builtin_amdgcn_s_setprio(0); } }
-  else if (wave == 1) { if (PRIMAL) { __builtin_amdgcn_s_setprio(3); run_labels(p, rb, c0, c1, lane, abort_word); __builtin_amdgcn_s_setprio(0); } }
-  else if (wave < 2 + kRunLoaders) run_loader<BACKWARD, PRIMAL, UPDATE>(p, epoch, rb, c0, c1, wave - 2, lane, abort_word);
-  else if (wave == 2 + kRunLoaders) run_publisher<PRIMAL, UPDATE>(p, epoch, rb, lane, abort_word);
+  else if (wave == 1) { if (PRIMAL) { __builtin_amdgcn_s_setprio(3); run_labels<BACKWARD>(pp_, rb_off, abort_off_); __builtin_amdgcn_s_setprio(0); } }
+  else if (wave < 2 + kRunLoaders) run_loader<BACKWARD, PRIMAL, UPDATE>(pp_, epoch, rb_off, abort_off_, wave - 2);
+  else if (wave == 2 + kRunLoaders) run_publisher<PRIMAL, UPDATE>(pp_, epoch, rb_off, abort_off_);
   __syncthreads();
   if (p.timeline && tid == 0) p.timeline[((size_t)2 * p.tl_stride + D) * 2 + 1] = wall_clock64();
   if (p.spec_stat && tid == 0) atomicAdd(p.spec_stat + 2, (unsigned long long)(c1 - c0));
