@@ -269,6 +269,15 @@ int stereo_trws_plan_strip_info(stereo_trws_plan *plan, int *nstrips, int *strip
 /* Development aid: completion flags (N, by rank: epoch of the last completed visit) and
  * [ticket, abort] of the plan's last launch. */
 int stereo_trws_plan_debug_flags(stereo_trws_plan *plan, int32_t *done, int32_t *ctl);
+/* The gateway on several devices.  With STEREO_HIP_GPUS=G (2 .. 16) in the environment stereo_trws -- what trws_mex
+ * reaches, cpp/trws_mex.cpp:149-164 -- cuts the problem into G row strips when the graph is the image grid of
+ * dispmap_super.m:279-302 (nodes col * H + row, 4-neighbourhood, H >= 2 G; K <= 128, or <= 256 with one positions vector
+ * in every column of q and qprim): strip g on device g when the process sees G devices (peer access over xGMI), all
+ * strips on the current device otherwise (logical strips, one fused launch per sweep).  Same labels, energy, bound and
+ * iteration count as on one device.  This call tells how many strips the calling thread's last stereo_trws ran on
+ * (1: the single-device plan).  No reference counterpart. */
+int stereo_trws_gateway_strips(void);
+
 /* Host only (no device): the speculative schedule of the graph's one long serial run, if it has one (DESIGN.md 4.5;
  * stereo_trws_plan_spec_stats).  info[0..5] = exists, the run of stereo_trws_schedule that is cut, its first schedule
  * position, one past its last, visits per segment, segments.  The arrays (may be NULL) describe the schedule with that

@@ -1086,7 +1086,15 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
       const int im = i + N;
       bool t = true;
       for (int a = g.aptr[im]; a < g.aptr[im + 1]; ++a) t = t && !(ldc(g.r + g.rev[a]) > 0);
-      return t;
+      if (!t) return false;
+      // ... and the mate really ends up with a sink arc (t1 < 0 in fix_to_zero, which a trivial step's h[mate] = 1 relies
+      // on): the doubled graph's symmetry says so -- excess stuck at an ambiguous node's mate is rounding residue --, but
+      // that is an argument; this is the check (the same INFTY, the same summation order)
+      const double tcap = ldc(g.ex + i) - ldc(g.snk + i);
+      double c1 = -tcap, c2 = tcap;
+      for (int a = g.aptr[i]; a < g.aptr[i + 1]; ++a) { c1 += ldc(g.r + a); c2 += ldc(g.r + g.rev[a]); }
+      const double INFTY = (c1 > c2 ? c1 : c2) + 1;
+      return ldc(g.ex + im) - ldc(g.snk + im) - INFTY < 0;
     };
     int mine = N;
     for (int j = improve_from + first; j < N; j += stride) {

@@ -1427,7 +1427,7 @@ namespace {
 // The environment switches a plan freezes at creation: part of the cache key (a cached plan must not outlive them).
 std::string trws_env_key() {
   std::string k;
-  for (const char *name : {"STEREO_HIP_TRWS_CERTIFICATE", "STEREO_HIP_TRWS_FAST", "STEREO_HIP_TRWS_SPIN_SECONDS", "STEREO_HIP_TRWS_PROF",
+  for (const char *name : {"STEREO_HIP_GPUS", "STEREO_HIP_TRWS_CERTIFICATE", "STEREO_HIP_TRWS_FAST", "STEREO_HIP_TRWS_SPIN_SECONDS", "STEREO_HIP_TRWS_PROF",
                            "STEREO_HIP_TRWS_TIMELINE", "STEREO_HIP_TRWS_SPEC", "STEREO_HIP_TRWS_SPEC_SEG", "STEREO_HIP_STRIPS_FINEGRAINED"}) {
     const char *v = std::getenv(name);
     k += v ? v : "-";
@@ -1436,9 +1436,11 @@ std::string trws_env_key() {
   return k;
 }
 
+struct TrwsStripSet;
 struct TrwsPlanCache {
   std::mutex mu;
   stereo_trws_plan *plan = nullptr;
+  TrwsStripSet *strips = nullptr;   // ... or the row strips of the problem (STEREO_HIP_GPUS)
   std::string env;
   int kernel = 0, K = 0, mode = 0, device = -1;
   int64_t N = 0, E = 0;
@@ -1492,14 +1494,131 @@ int trws_solve_on(stereo_trws_plan *P, const double *unary, const double *q, con
   return stereo_trws_plan_result(P, labelling, energy, lower_bound, iterations, err, errcap);
 }
 
+// ---- the gateway on several devices (STEREO_HIP_GPUS = G): row strips of the image grid ---------------------------
+// trws_mex hands over a graph, not an image; the image grid of dispmap_super.m:279-302 is recognised from it: nodes
+// col * H + row (:281-282), every edge joins vertical (|a - b| == 1, same column) or horizontal (|a - b| == H)
+// neighbours.  Band g of the rows goes to strip g; strip g runs on device g when the process sees at least G devices
+// (peer access, stereo_trws_plan_connect), otherwise all strips share the current device as logical strips (one fused
+// launch per sweep) -- the same kernels, the same hand-over protocol, the same bits.  Anything else (another graph, a
+// label count the strip kernels do not take) stays on one device.
+int64_t image_grid_height(int64_t N, int64_t E, const uint32_t *conn) {
+  int64_t H = 0;
+  for (int64_t e = 0; e < E; ++e) {
+    const int64_t a = conn[2 * e], b = conn[2 * e + 1];
+    const int64_t d = a > b ? a - b : b - a;
+    if (d == 1) continue;
+    if (H == 0) H = d;
+    if (d != H) return 0;
+  }
+  if (H < 2 || N % H != 0) return 0;
+  for (int64_t e = 0; e < E; ++e) {   // vertical edges stay inside a column
+    const int64_t a = conn[2 * e], b = conn[2 * e + 1];
+    if ((a > b ? a - b : b - a) == 1 && a / H != b / H) return 0;
+  }
+  return H;
+}
+
+struct TrwsStripSet {
+  std::vector<stereo_trws_plan *> plans;
+  std::vector<int32_t> owner;
+  bool one_device = true;
+  ~TrwsStripSet() { for (stereo_trws_plan *P : plans) if (P) stereo_trws_plan_destroy(P); }
+};
+
+int strips_create(int kernel, int K, int64_t N, int64_t E, const uint32_t *conn, int mode, int G, int64_t H, TrwsStripSet &S, char *err,
+                  size_t errcap) {
+  S.owner.resize(N);
+  for (int64_t i = 0; i < N; ++i) S.owner[i] = (int32_t)std::min<int64_t>((i % H) * G / H, G - 1);
+  const int ndev = stereo_hip_device_count();
+  S.one_device = ndev < G;
+  int home = 0;
+  if (hipGetDevice(&home) != hipSuccess) return fail("stereo_trws: no HIP device available (the HIP path has no CPU fallback)", err, errcap);
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, home);
+  const int per_strip = S.one_device ? std::max(2, cus / G) : 0;   // logical strips must all be resident together
+  S.plans.assign(G, nullptr);
+  int rc = 0;
+  for (int g = 0; g < G && !rc; ++g) {
+    if (!S.one_device && hipSetDevice(g) != hipSuccess) rc = fail("stereo_trws: hipSetDevice failed", err, errcap);
+    if (!rc) rc = stereo_trws_plan_create_strip(kernel, K, N, E, conn, mode, g == 0 ? S.owner.data() : nullptr, G, g, per_strip,
+                                                g ? S.plans[0] : nullptr, &S.plans[g], err, errcap);
+  }
+  (void)hipSetDevice(home);
+  for (int g = 0; g < G && !rc; ++g) {
+    if (g > 0) rc = stereo_trws_plan_connect(S.plans[g], 0, S.plans[g - 1], err, errcap);
+    if (!rc && g + 1 < G) rc = stereo_trws_plan_connect(S.plans[g], 1, S.plans[g + 1], err, errcap);
+  }
+  return rc;
+}
+
+int strips_solve(TrwsStripSet &S, const double *unary, const double *q, const double *qprim, const double *alphas, double tol,
+                 double maxiter, double max_relgap, double *labelling, double *energy, double *lower_bound, double *iterations, char *err,
+                 size_t errcap) {
+  const int G = (int)S.plans.size();
+  stereo_trws_plan *P0 = S.plans[0];
+  const bool shared = columns_are_one_vector(q, qprim, P0->K, P0->E);
+  for (int g = 0; g < G; ++g) {
+    const int rc = shared ? stereo_trws_plan_upload(S.plans[g], unary, nullptr, nullptr, q, alphas, tol, err, errcap)
+                          : stereo_trws_plan_upload(S.plans[g], unary, q, qprim, nullptr, alphas, tol, err, errcap);
+    if (rc) return rc;
+  }
+  int itmax = (int)maxiter;  // trws_mex.cpp:125; Minimize_TRW_S always runs at least one iteration (minimize.cpp:31,100-101)
+  if (itmax < 1) itmax = 1;
+  double lb = 0, en = 0;
+  int done = 0;
+  for (int it = 0; it < itmax; ++it) {
+    int rc = 0;
+    if (S.one_device) rc = stereo_trws_plans_issue(S.plans.data(), G, nullptr, err, errcap);
+    else for (int g = 0; g < G && !rc; ++g) rc = stereo_trws_plan_issue(S.plans[g], nullptr, err, errcap);
+    if (rc) return rc;
+    // the strips' partial sums, added in strip order (the only cross-strip reduction: two doubles)
+    lb = 0; en = 0;
+    for (int g = 0; g < G; ++g) {
+      double l = 0, e = 0;
+      if ((rc = stereo_trws_plan_collect(S.plans[g], &l, &e, err, errcap)) != 0) return rc;
+      lb += l; en += e;
+    }
+    for (int g = 0; g < G; ++g) (void)stereo_trws_plan_commit(S.plans[g], lb, en, err, errcap);
+    ++done;
+    if ((en - lb) / en < max_relgap) break;  // minimize.cpp:105
+  }
+  std::vector<double> part((size_t)P0->N);
+  for (int g = 0; g < G; ++g) {
+    const int rc = stereo_trws_plan_result(S.plans[g], part.data(), nullptr, nullptr, nullptr, err, errcap);
+    if (rc) return rc;
+    for (int64_t i = 0; i < P0->N; ++i)
+      if (S.owner[i] == g) labelling[i] = part[i];
+  }
+  *energy = en; *lower_bound = lb; *iterations = (double)done;
+  return 0;
+}
+
+thread_local int g_last_gateway_strips = 0;   // what the last stereo_trws call of this thread ran on (stereo_trws_gateway_strips)
+
+// how many strips the gateway should cut the problem into (1: the plain single-device plan)
+int gateway_strips(int K, int64_t N, int64_t E, const uint32_t *conn, const double *q, const double *qprim, int mode, int64_t *H_out) {
+  const char *ge = std::getenv("STEREO_HIP_GPUS");
+  const int G = ge ? std::atoi(ge) : 1;
+  if (G < 2 || G > kMaxGroup || mode != STEREO_TRWS_MESSAGES_EXACT || K > 4 * kWave) return 1;
+  // (the strip kernels take K <= 128 with any positions, up to 256 labels with one shared positions vector)
+  if (K > 2 * kWave && !columns_are_one_vector(q, qprim, K, E)) return 1;
+  const int64_t H = image_grid_height(N, E, conn);
+  if (H < 2 * G) return 1;
+  *H_out = H;
+  return G;
+}
+
 }  // namespace
 
 extern "C" {
+
+int stereo_trws_gateway_strips(void) { return g_last_gateway_strips; }
 
 void stereo_trws_cache_clear(void) {
   TrwsPlanCache &C = trws_plan_cache();
   std::lock_guard<std::mutex> lock(C.mu);
   if (C.plan) { stereo_trws_plan_destroy(C.plan); C.plan = nullptr; }
+  if (C.strips) { delete C.strips; C.strips = nullptr; }
   C.conn.clear(); C.conn.shrink_to_fit();
 }
 
@@ -1515,6 +1634,15 @@ int stereo_trws(int kernel, const double *unary, const uint32_t *conn, const dou
     if (std::string(m) == "minplus") mode = STEREO_TRWS_MESSAGES_MINPLUS;
   const char *ce = std::getenv("STEREO_HIP_TRWS_CACHE");
   const bool cached = (!ce || std::atoi(ce) != 0) && E > 0 && N > 0;
+  int64_t gridH = 0;
+  const int G = (E > 0 && N > 0) ? gateway_strips(K, N, E, conn, q, qprim, mode, &gridH) : 1;
+  g_last_gateway_strips = G;
+  if (G > 1 && !cached) {
+    TrwsStripSet S;
+    int rc = strips_create(kernel, K, N, E, conn, mode, G, gridH, S, err, errcap);
+    if (!rc) rc = strips_solve(S, unary, q, qprim, alphas, tol, maxiter, max_relgap, labelling, energy, lower_bound, iterations, err, errcap);
+    return rc;
+  }
   if (!cached) {
     stereo_trws_plan *P = nullptr;
     int rc = stereo_trws_plan_create(kernel, K, N, E, conn, mode, &P, err, errcap);
@@ -1529,10 +1657,25 @@ int stereo_trws(int kernel, const double *unary, const uint32_t *conn, const dou
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return fail("stereo_trws: no HIP device available (the HIP path has no CPU fallback)", err, errcap);
   const std::string env = trws_env_key();
-  const bool hit = C.plan && C.kernel == kernel && C.K == K && C.N == N && C.E == E && C.mode == mode && C.device == dev && C.env == env &&
+  const bool hit = (C.plan || C.strips) && C.kernel == kernel && C.K == K && C.N == N && C.E == E && C.mode == mode && C.device == dev && C.env == env &&
                    std::memcmp(C.conn.data(), conn, sizeof(uint32_t) * 2 * (size_t)E) == 0;
   if (!hit) {
     if (C.plan) { stereo_trws_plan_destroy(C.plan); C.plan = nullptr; }
+    if (C.strips) { delete C.strips; C.strips = nullptr; }
+    if (G > 1) {
+      TrwsStripSet *S = new TrwsStripSet;
+      const int rc = strips_create(kernel, K, N, E, conn, mode, G, gridH, *S, err, errcap);
+      if (rc) { delete S; return rc; }
+      C.strips = S; C.kernel = kernel; C.K = K; C.N = N; C.E = E; C.mode = mode; C.device = dev; C.env = env;
+      C.conn.assign(conn, conn + 2 * (size_t)E);
+    }
+  }
+  if (C.strips) {
+    const int rc = strips_solve(*C.strips, unary, q, qprim, alphas, tol, maxiter, max_relgap, labelling, energy, lower_bound, iterations, err, errcap);
+    if (rc) { delete C.strips; C.strips = nullptr; }   // never keep plans an error went through
+    return rc;
+  }
+  if (!hit) {
     stereo_trws_plan *P = nullptr;
     const int rc = stereo_trws_plan_create(kernel, K, N, E, conn, mode, &P, err, errcap);
     if (rc) return rc;

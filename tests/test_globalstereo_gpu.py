@@ -79,8 +79,8 @@ def _grid_leg(hip, oracle, ref, a, prop, U0, U1, seed):
     return n_ties, nu_r
 
 
-def _run(hip, oracle, im0, im1, disp_range, factor, seg, cells, seed0, kernel=1, tie_allowance=0.03, proposals=None,
-         grid_moves=()):
+def _run(hip, oracle, im0, im1, disp_range, factor, seg, cells, seed0, kernel=1, tie_allowance=0.005, proposals=None,
+         grid_moves=(), free_run=False):
     H, W = im0.shape[:2]
     N = H * W
     P = np.tile(np.hstack([np.eye(3), np.zeros((3, 1))])[:, :, None], (1, 1, 2))      # example_global.m:17-18
@@ -98,6 +98,13 @@ def _run(hip, oracle, im0, im1, disp_range, factor, seg, cells, seed0, kernel=1,
     assert gs.options["col_thresh"] == su["col_thresh"]
     ref = OracleGlobal(oracle, hip, im0, im1, su["P2"], su["d_min"], su["d_step"], su["col_thresh"], su["weights"],
                        su["tol"], kernel, gs.start_disparity)
+    # free_run: a second object of the product that is NEVER resynchronised with the reference's state -- what the near-tie
+    # contract means over a whole run
+    gs_free = None
+    if free_run:
+        gs_free = hip.dispmap_globalstereo([im0, im1], P, disp_range, factor, segment=seg, rng=np.random.default_rng(seed0),
+                                           options=dict(smoothness_kernel=kernel))
+        assert np.array_equal(gs_free.assignment, gs.assignment)
     assert np.array_equal(gs.assignment, ref.a)
     u = ref.unary(ref.a)
     assert np.max(np.abs(u - ref.unary_numpy(ref.a))) < 1e-11                          # device unary vs NumPy restatement
@@ -108,6 +115,7 @@ def _run(hip, oracle, im0, im1, disp_range, factor, seg, cells, seed0, kernel=1,
     tie_pixels = 0
     resync = []
     grid_ties = grid_extra = 0
+    all_ties = 0
     for k, cell in enumerate(cells if proposals is None else range(len(proposals))):
         prop = piecewise_planar(H, W, cell, rng, d_lo, d_hi) if proposals is None else proposals[k]
         U0, U1 = ref.unary(ref.a), ref.unary(prop)
@@ -118,6 +126,9 @@ def _run(hip, oracle, im0, im1, disp_range, factor, seg, cells, seed0, kernel=1,
         e_r, lb_r, nu_r = ref.binary_fusion(prop, seed=1000 + k)
         libc.srand(1000 + k)
         e, lb, nu = gs.binary_fusion(prop)
+        if gs_free is not None:
+            libc.srand(1000 + k)
+            gs_free.binary_fusion(prop)
         assert nu == nu_r, (k, nu, nu_r)
         assert _rel(e, e_r) < 1e-9, (k, e, e_r)
         assert _rel(gs.energy(), ref.energy()) < 1e-9
@@ -137,7 +148,10 @@ def _run(hip, oracle, im0, im1, disp_range, factor, seg, cells, seed0, kernel=1,
             # pixels; measured <= 2 % of the ties of a move; a regression inside a summed allowance would be invisible)
             n_diff, n_ties = int(differ.sum()), int((U0 == U1).sum())
             resync.append((k, n_diff, n_ties))
-            assert n_diff <= max(1, tie_allowance * n_ties), "move %d: %d tie pixels took the other plane (%d exact ties)" % (k, n_diff, n_ties)
+            # (round 6: measured per move 0-106 pixels = up to 0.3 % of the move's ties at full size, 58 of 3173 on the crop;
+            #  allowed: 0.5 % of the move's ties, or 64 pixels -- whole zero-capacity components flip together)
+            assert n_diff <= max(64, tie_allowance * n_ties), "move %d: %d tie pixels took the other plane (%d exact ties)" % (k, n_diff, n_ties)
+            all_ties += n_ties
             # ... and the SAME move on the exact 2^-30 grid, where no rounding is left, must not differ anywhere
             if not on_grid:
                 grid_ties += _grid_leg(hip, oracle, ref, a_before, prop, U0, U1, 2000 + k)[0]
@@ -145,10 +159,23 @@ def _run(hip, oracle, im0, im1, disp_range, factor, seg, cells, seed0, kernel=1,
             tie_pixels += n_diff
             gs.assignment = ref.a.copy()      # same state on both sides for the next move
         total_unlabelled += nu_r
+    # ... and over the whole run (measured: 278 of ~189 k ties on the Teddy pair's random-plane moves, 12 of ~114 k on the
+    # example's own SegPln moves, 61 of 6216 on the crop): 0.4 % of the ties of the moves that differed, or 96 pixels
+    assert tie_pixels <= max(96, 0.004 * all_ties), "%d tie pixels took the other plane over the run (%d ties in those moves)" % (tie_pixels, all_ties)
     # (shown with pytest -s / in the failure report: move, resynchronised pixels, exact ties of that move)
     n_moves = len(cells) if proposals is None else len(proposals)
     print("globalstereo parity: %d moves, %d pixels of %d resynchronised at exact ties, per move %s; exact-grid legs: %d moves, "
           "%d exact ties, all labels equal" % (n_moves, tie_pixels, N, resync, len(grid_moves) + grid_extra, grid_ties))
+    if gs_free is not None:
+        # The device's own trajectory against the one the reference's library drives on its own labels: planes may
+        # differ where a near-tie pixel took the other side in some move and nothing later overwrote it; the energies
+        # agree to the contract's per-move tolerance accumulated over the run.
+        other = int((gs_free.assignment != ref.a).any(0).sum())
+        e_free, e_ref = gs_free.energy(), ref.energy()
+        print("globalstereo free run: %d of %d pixels on another plane than the reference-driven trajectory after %d moves; "
+              "energy %.9f vs %.9f (rel %.2e)" % (other, N, n_moves, e_free, e_ref, _rel(e_free, e_ref)))
+        assert _rel(e_free, e_ref) < 1e-6, (e_free, e_ref)
+        assert other <= max(64, 0.002 * N), other
     return total_unlabelled, gs.energy()
 
 
@@ -208,7 +235,8 @@ def test_example_global_on_the_teddy_pair(hip, oracle):
     sg = np.load(os.path.join(GOLD, "teddy_segments.npz"))
     pl = np.load(os.path.join(GOLD, "teddy_segpln_planes.npz"))
     props = proposals_from_planes(sg["segments"], [pl["planes_%d" % b] for b in range(14)])
-    unl, _ = _run(hip, oracle, im0, im1, [0, 59], 4, sg["segment"], cells=None, seed0=5, proposals=props, grid_moves=(1, 6, 12))
+    unl, _ = _run(hip, oracle, im0, im1, [0, 59], 4, sg["segment"], cells=None, seed0=5, proposals=props, grid_moves=(1, 6, 12),
+                  free_run=True)
     assert unl > 0, "no move left nodes unlabelled: Improve was not exercised"
 
 

@@ -64,7 +64,7 @@ def _problem(seed, H, W, K, weights):
 CASES = [
     # seed, H, W, K, tol, step, weights, segment length
     (1, 30, 40, 16, 4.0, 1.0, "unit", None),
-    (2, 36, 52, 60, 8.0, 0.5, "random", None),
+    (2, 36, 52, 60, 8.0, 1.0, "random", None),
     (3, 41, 33, 7, 2.0, 1.0, "zeros", None),
     (4, 30, 40, 16, 3.0, 1.0, "pairs", "8"),       # window of three entries: one group of four; short segments
     (5, 64, 64, 33, 7.5, 1.0, "unit", "24"),       # window of seven; long segments

@@ -327,3 +327,33 @@ def test_strips_stop_test_with_zero_energy(hip, oracle):
     lab, en, lb, _ = s.result()
     s.close()
     assert en_o == 0.0 and en == 0.0 and done == it_o and np.array_equal(lab, lab_o)
+
+
+@pytest.mark.parametrize("G", [2, 4])
+def test_the_gateway_shards_over_strips(G, hip, monkeypatch):
+    """stereo_trws -- what trws_mex reaches -- with STEREO_HIP_GPUS=G: the image grid is recognised from the connectivity
+    and cut into G row strips (logical strips on this box's one device, device g on a node that has G), behind the
+    unchanged trws.m boundary: same labels, energy, bound, iteration count; a graph that is no image grid stays whole."""
+    from stereo_amd import _lib
+    from helpers import trws_problem
+    strips_used = lambda: int(_lib.lib().stereo_trws_gateway_strips())
+    for seed, H, W, K, kernel, kind, tol in ((41, 24, 19, 9, 1, "general", 2.0), (42, 20, 26, 16, 1, "fronto", 3.0),
+                                             (43, 18, 16, 7, 2, "general", 4.0), (44, 16, 12, 130, 1, "fronto", 20.0)):
+        p = trws_problem(seed, H, W, K, kind=kind)
+        args = (kernel, p["unary"].T, p["conn"].T + 1, p["q"].T, p["qprim"].T, p["alphas"], tol, dict(maxiter=5, max_relgap=0.0))
+        monkeypatch.delenv("STEREO_HIP_GPUS", raising=False)
+        lab0, en0, lb0, it0 = hip.trws(*args)
+        assert strips_used() == 1
+        monkeypatch.setenv("STEREO_HIP_GPUS", str(G))
+        lab, en, lb, it = hip.trws(*args)
+        assert strips_used() == G
+        assert it == it0 and np.array_equal(lab, lab0) and en == en0 and lb == lb0
+        lab2, en2, lb2, it2 = hip.trws(*args)     # the cached strips once more
+        assert np.array_equal(lab2, lab0) and en2 == en0 and lb2 == lb0
+    # not an image grid (a ring): one device, whatever the switch says
+    n = 40
+    rng = np.random.default_rng(5)
+    conn = np.stack([np.arange(n), (np.arange(n) + 1) % n]) + 1
+    q = rng.uniform(0, 8, (5, n)); qp = rng.uniform(0, 8, (5, n))
+    hip.trws(1, rng.uniform(0, 9, (5, n)), conn, q, qp, np.ones(n), 2.0, dict(maxiter=3))
+    assert strips_used() == 1
