@@ -1342,13 +1342,17 @@ int stereo_trws_plan_spec_stats(stereo_trws_plan *P, int64_t out[4]) {
   if (P->d_spec_stat.p) {
     unsigned long long v[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpy(v, P->d_spec_stat.p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 1;
-    if (v[8] && v[2])   // (-DSTEREO_HIP_RUNNER_PROFILE)
+    if (std::getenv("STEREO_HIP_TRWS_TIMELINE"))
+      std::fprintf(stderr, "[stereo_hip spec] last sweeps, roles done after (us): forward messages %.0f labels %.0f last loader %.0f publisher %.0f | backward messages %.0f "
+                           "last loader %.0f publisher %.0f\n", v[8] / 100.0, v[9] / 100.0, v[10] / 100.0, v[11] / 100.0, v[12] / 100.0, v[14] / 100.0, v[15] / 100.0);
+    if (false && v[8] && v[2])   // (-DSTEREO_HIP_RUNNER_PROFILE)
       std::fprintf(stderr, "[stereo_hip spec] message recurrence, cycles per visit: loop top %.0f | node in registers (incl. waits) %.0f | Di, next node asked for %.0f | "
                            "H, table, min H %.0f | window + row %.0f | publish, turn %.0f\n", (double)v[13] / v[2], (double)v[8] / v[2], (double)v[9] / v[2],
                    (double)v[10] / v[2], (double)v[11] / v[2], (double)v[12] / v[2]);
     out[1] = (int64_t)v[0]; out[2] = (int64_t)v[1]; out[3] = (int64_t)v[2];
     if (std::getenv("STEREO_HIP_TRWS_TIMELINE"))   // (development: how often, and for how long, the message recurrence found its next node not staged yet)
-      std::fprintf(stderr, "[stereo_hip spec] runner visits %llu, of them waited for the loaders %llu, %.1f us in all\n", v[2], v[3], (double)v[4] / 100.0);
+      std::fprintf(stderr, "[stereo_hip spec] runner visits %llu; the message recurrence found its node not staged yet: forward sweeps %llu times, %.1f us in all; "
+                           "backward %llu times, %.1f us (incl. the wait for the rows in front of the chain)\n", v[2], v[3], (double)v[4] / 100.0, v[5], (double)v[6] / 100.0);
   }
   return 0;
 }

@@ -152,7 +152,7 @@ __device__ __forceinline__ bool run_visit_m(const RunArgsM &a, double *rb, int *
     // (a real call's result arrives in a vector register: say that it is uniform, or the loop gets exec-mask exits)
     if (!__builtin_amdgcn_readfirstlane((int)run_wait_m((const int *)(rb + slot_off + kRunSc) + kRsTag, i + 1, abort_word, a.abort_flag, a.spin_ticks))) return false;
     run_request_m(rb + slot_off, lane, cur);
-    if (a.stat && lane == 0) { atomicAdd(a.stat + 3, 1ull); atomicAdd(a.stat + 4, (unsigned long long)((long long)wall_clock64() - t0_)); }
+    if (a.stat && lane == 0) { atomicAdd(a.stat + 3 + 2 * (BACKWARD ? 1 : 0), 1ull); atomicAdd(a.stat + 4 + 2 * (BACKWARD ? 1 : 0), (unsigned long long)((long long)wall_clock64() - t0_)); }
   }
   const int sw = cur.sw;
   const int key = __builtin_amdgcn_readlane(sw, kRsKinds), nmsg = __builtin_amdgcn_readlane(sw, kRsNmsg), cut = __builtin_amdgcn_readlane(sw, kRsCut);
@@ -182,11 +182,13 @@ __device__ __forceinline__ bool run_visit_m(const RunArgsM &a, double *rb, int *
   double R0 = 0, R1 = 0;
   for (int m = 0; m < nmsg; ++m) {
     const double alpha = readlane_f64(sd, m);
-    const double h = act ? gamma * Di - (m == 0 ? mold0 : mold1) : inf;
+    const double h = gamma * Di - (m == 0 ? mold0 : mold1);   // (lanes beyond K: the loader staged -inf as their old message, so h = +inf)
     double out = 0;   // (alpha == 0: typeStereoLinear.h:390-396, a constant row, normalised)
     if (alpha != 0) {
       *tabl = h;
-      if (alpha != alpha_have) {
+      if (__builtin_expect(alpha != alpha_have, 0)) {
+        // (a real branch: as a select the refresh costs every message 4 G multiplies and 8 G conditional moves)
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int d = 0; d < 4 * G; ++d) ad[d] = alpha * ((double)(d + 1) * a.step);
         alpha_have = alpha;
@@ -435,9 +437,9 @@ __device__ __attribute__((noinline)) void run_loader(const DevParams *pp_, int e
         if (stage_of[2] == k) sl[kRunRowS + 128 + lane] = r[k];
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (s0 == k) sl[kRunRowM + lane] = r[k];
-        if (s1 == k) sl[kRunRowM + 64 + lane] = r[k];
+      for (int k = 0; k < 4; ++k) {   // (lanes beyond K: -inf, which makes the recurrence's H = gamma Di - m = +inf there without a select)
+        if (s0 == k) sl[kRunRowM + lane] = lane < K ? r[k] : -__builtin_huge_val();
+        if (s1 == k) sl[kRunRowM + 64 + lane] = lane < K ? r[k] : -__builtin_huge_val();
       }
     }
     if (PRIMAL) {
@@ -534,10 +536,14 @@ __device__ __attribute__((noinline)) void chain_runner(const DevParams *pp_, int
   if (tid < 16) { rb[kRunTab + tid] = __builtin_huge_val(); rb[kRunTab + 80 + tid] = __builtin_huge_val(); }
   if (p.timeline && tid == 0) p.timeline[((size_t)2 * p.tl_stride + D) * 2] = wall_clock64();
   __syncthreads();
+  const unsigned long long trole0 = wall_clock64();
   if (wave == 0) { if (UPDATE) { __builtin_amdgcn_s_setprio(3); run_messages<BACKWARD>(pp_, rb_off, abort_off_); __builtin_amdgcn_s_setprio(0); } }
   else if (wave == 1) { if (PRIMAL) { __builtin_amdgcn_s_setprio(3); run_labels<BACKWARD>(pp_, rb_off, abort_off_); __builtin_amdgcn_s_setprio(0); } }
   else if (wave < 2 + kRunLoaders) run_loader<BACKWARD, PRIMAL, UPDATE>(pp_, epoch, rb_off, abort_off_, wave - 2);
   else if (wave == 2 + kRunLoaders) run_publisher<PRIMAL, UPDATE>(pp_, epoch, rb_off, abort_off_);
+  // (development: when each role was done, 100 MHz ticks since the roles started -- messages, labels, last loader, publisher)
+  if (p.timeline && p.spec_stat && lane == 0 && (wave <= 1 || wave == 1 + kRunLoaders || wave == 2 + kRunLoaders))
+    p.spec_stat[8 + 4 * D + (wave <= 1 ? wave : wave - kRunLoaders + 1)] = wall_clock64() - trole0;
   __syncthreads();
   if (p.timeline && tid == 0) p.timeline[((size_t)2 * p.tl_stride + D) * 2 + 1] = wall_clock64();
   if (p.spec_stat && tid == 0) atomicAdd(p.spec_stat + 2, (unsigned long long)(c1 - c0));

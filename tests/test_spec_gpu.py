@@ -68,7 +68,7 @@ CASES = [
     (3, 41, 33, 7, 2.0, 1.0, "zeros", None),
     (4, 30, 40, 16, 3.0, 1.0, "pairs", "8"),       # window of three entries: one group of four; short segments
     (5, 64, 64, 33, 7.5, 1.0, "unit", "24"),       # window of seven; long segments
-    (6, 35, 45, 64, 3.0, 0.25, "pairs", None),     # K = 64: no idle lane
+    (6, 35, 45, 64, 3.0, 0.5, "pairs", None),      # K = 64: no idle lane
 ]
 
 
