@@ -269,6 +269,11 @@ int stereo_trws_plan_strip_info(stereo_trws_plan *plan, int *nstrips, int *strip
 /* Development aid: completion flags (N, by rank: epoch of the last completed visit) and
  * [ticket, abort] of the plan's last launch. */
 int stereo_trws_plan_debug_flags(stereo_trws_plan *plan, int32_t *done, int32_t *ctl);
+/* Development aids: the lower-bound terms of the plan's last backward sweep in the order the host sums them (rank N - 1
+ * down to 0: the node's own term, minimize.cpp:79-83, then one per message it sent, :85-91), and the message rows as
+ * they lie in HBM (E x K doubles, edge-major).  No reference counterpart. */
+int stereo_trws_plan_debug_terms(stereo_trws_plan *plan, double *lb_terms, int64_t cap, int64_t *n_lb);
+int stereo_trws_plan_debug_messages(stereo_trws_plan *plan, double *out, int64_t count);
 /* The gateway on several devices.  With STEREO_HIP_GPUS=G (2 .. 16) in the environment stereo_trws -- what trws_mex
  * reaches, cpp/trws_mex.cpp:149-164 -- cuts the problem into G row strips when the graph is the image grid of
  * dispmap_super.m:279-302 (nodes col * H + row, 4-neighbourhood, H >= 2 G; K <= 128, or <= 256 with one positions vector

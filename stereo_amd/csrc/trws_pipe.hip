@@ -104,6 +104,11 @@ __device__ __forceinline__ void pipe_body(DevParams p, int epoch) {
     __syncthreads();
     const int run = __builtin_amdgcn_readfirstlane(ctl[0]);
     const int second_walk = SPEC ? __builtin_amdgcn_readfirstlane(ctl[3]) : 0;
+    // (the helpers' exchange flags show schedule positions: a second walk of a speculative segment visits the SAME
+    //  positions again, and a flag left by the first walk would pass for the helper's word of the second -- the
+    //  finishing wave would merge the first walk's partial minima, which are those of almost the same message.
+    //  Every wave is behind the last visit's barrier here: nothing is being published or collected.)
+    if (tid < kPipeCompute && !(p.debug & 131072)) xflag[tid] = 0;   // (development switch 131072: flags left as they are)
     __syncthreads();
     if (SPEC && tid == 0) ctl[3] = 0;
     if (run >= p.nruns[D]) break;

@@ -1271,6 +1271,22 @@ int stereo_trws_plan_debug_flags(stereo_trws_plan *P, int32_t *done, int32_t *ct
   return 0;
 }
 
+// Development aids: the lower-bound terms of the last backward sweep in the order the host sums them (rank N - 1 down to
+// 0: the node's own term, then one per message it sent), and the message rows as they lie in HBM (E x K, edge-major).
+int stereo_trws_plan_debug_terms(stereo_trws_plan *P, double *lb_terms, int64_t cap, int64_t *n_lb) {
+  if (!P) return 1;
+  if (n_lb) *n_lb = P->n_lb;
+  if (lb_terms) std::memcpy(lb_terms, P->h_lb.p, sizeof(double) * (size_t)std::min<int64_t>(cap, P->n_lb));
+  return 0;
+}
+int stereo_trws_plan_debug_messages(stereo_trws_plan *P, double *out, int64_t count) {
+  DeviceScope device_scope_(P ? P->device : -1);
+  if (!P || !out) return 1;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  const int64_t n = std::min<int64_t>(count, (int64_t)P->d_msg.n);
+  return hipMemcpy(out, P->d_msg.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+
 int stereo_trws_plan_strip_info(stereo_trws_plan *P, int *nstrips, int *strip, int64_t *own_nodes, int64_t *runs_forward,
                                 int64_t *runs_backward, int *needs_previous, int *needs_next) {
   if (!P) return 1;

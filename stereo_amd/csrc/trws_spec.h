@@ -497,6 +497,7 @@ __device__ __attribute__((noinline)) void run_publisher(const DevParams *pp_, in
       double a0 = pb[lk], a1 = pb[64 + lk];
       const int kinds = lds_load(rw + kRwKinds + ps);
       if ((p.debug & 16384) && s % 3 == 1 && lane == 0) a0 = __longlong_as_double(__double_as_longlong(a0) ^ 1ll);   // (development: a wrong row)
+      if ((p.debug & 65536) && s % 3 == 1 && (lane & 1)) a0 += 0.375;                                                // (development: a VERY wrong row)
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int kd = (kinds >> (4 * k)) & 15;

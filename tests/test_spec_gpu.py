@@ -5,7 +5,10 @@ routine side by side and commit in order after comparing what they started from 
 produced.  Whatever the runner hands over, the results must be the plain schedule's -- which the other tests pin to
 the oracle -- bit for bit after every iteration: labels, energy, bound.  The development switches 16384 / 32768 make the
 runner's rows / labels WRONG at every third / fifth cut: those segments must be walked a second time, and still nothing
-may change.
+may change.  (65536: rows wrong by a lot.  Round 6 found what a second walk must not inherit from the first: the helper
+waves' exchange flags show schedule positions, the second walk visits the same positions, and a flag left standing let
+the finishing wave merge the FIRST walk's partial minima -- bound differences of 1e-16 relative from iteration 368 of
+configs[1] on, tests/test_full_runs_gpu.py.)
 """
 import numpy as np
 import pytest
@@ -89,6 +92,11 @@ def test_speculative_schedule_equals_the_plain_one(case, hip, monkeypatch):
     both, st2 = _solve(monkeypatch, dict(base, STEREO_HIP_TRWS_DEBUG="49152"), 1, unary, conn, tol, 4, pos, alphas)
     assert st2["second_walks"] > st1["second_walks"], "a wrong label of the runner's must cost a second walk"
     assert _same(plain, both)
+    # a row that is wrong by a lot (every second entry + 0.375): the first walk's messages -- and what its helper waves
+    # left in their exchange areas for the twins' shared loops -- are far from the second walk's
+    far, st3 = _solve(monkeypatch, dict(base, STEREO_HIP_TRWS_DEBUG="65536"), 1, unary, conn, tol, 4, pos, alphas)
+    assert st3["second_walks"] > 0
+    assert _same(plain, far)
 
 
 def test_speculative_schedule_against_the_oracle(hip, oracle, monkeypatch):
