@@ -5,12 +5,14 @@ piecewise-planar proposals.
 
     python examples/example_global.py [im_left.png im_right.png] [--size H W] [--teddy]
 
---teddy: the example's own input -- the Teddy pair with the edge weights of the reference's mean-shift
-segmentation and the 14 SegPln proposals on the reference's 14 segmentation maps (all from committed
-fixtures, tests/golden/teddy_pair.npz / teddy_segments.npz; the segmenters themselves stay on the host,
-SURVEY.md 8(f3)), planes fitted on the device.  Otherwise the script uses deterministic stand-ins --
-block-wise random planes at several block sizes, and "same segment" = small colour difference across
-the edge -- on the given images or, without images, on a synthetic textured pair.
+--teddy: the example's own input, from the two images of the Teddy pair alone (tests/golden/teddy_pair.npz):
+the object segments the reference image (mean shift, stereo_amd/segment.py: filter on the device, region
+graph on the host) for its edge weights, segpln() makes the 14 segmentation maps (mean shift and the
+graph-based segmenter at seven scales each) and fits a plane per segment on the device -- the maps equal
+the reference's own (tests/golden/teddy_segments.npz, checked here when the file is present).  Otherwise
+the script uses deterministic stand-ins -- block-wise random planes at several block sizes, and "same
+segment" = small colour difference across the edge -- on the given images or, without images, on a
+synthetic textured pair.
 """
 import argparse
 import os
@@ -53,15 +55,24 @@ def main():
     from stereo_amd import terms as T
     if args.teddy:
         gold = os.path.join(ROOT, "tests", "golden")
-        g = np.load(os.path.join(gold, "teddy_pair.npz")); sg = np.load(os.path.join(gold, "teddy_segments.npz"))
+        g = np.load(os.path.join(gold, "teddy_pair.npz"))
         images = [g["im0"].astype(np.float64), g["im1"].astype(np.float64)]
         P = np.tile(np.hstack([np.eye(3), np.zeros((3, 1))])[:, :, None], (1, 1, 2)); P[0, 3, 1] = -0.25
         t0 = time.time()
-        dm = stereo_amd.dispmap_globalstereo(images, P, (0, 59), 4, segment=sg["segment"], rng=np.random.default_rng(0))
-        print("object + random start: %.2f s, energy %.6f" % (time.time() - t0, dm.energy()))
+        dm = stereo_amd.dispmap_globalstereo(images, P, (0, 59), 4, rng=np.random.default_rng(0))
+        print("object (mean-shift segmentation: %d segments) + random start: %.2f s, energy %.6f" % (
+            int(dm.segment.max()), time.time() - t0, dm.energy()))
         t1 = time.time()
-        proposals = dm.segpln([sg["segments"][:, :, b] for b in range(14)], seed=0)
-        print("SegPln: window matching + 14 maps, %.2f s" % (time.time() - t1))
+        maps = dm.segpln_segments()
+        t2 = time.time()
+        proposals = dm.segpln(seed=0)
+        print("SegPln: 14 segmentation maps %.2f s (%s segments), window matching + plane fits %.2f s" % (
+            t2 - t1, [int(maps[:, :, b].max()) for b in range(14)], time.time() - t2))
+        ref = os.path.join(gold, "teddy_segments.npz")
+        if os.path.exists(ref):
+            sg = np.load(ref)
+            print("maps equal to the reference's own segmenters' (tests/golden/teddy_segments.npz): edge-weight map %s, the 14 maps %s" % (
+                np.array_equal(dm.segment, sg["segment"]), np.array_equal(maps, sg["segments"])))
         t0 = time.time()
         for p in proposals:
             e, lb, unl = dm.binary_fusion(p)

@@ -25,8 +25,9 @@ extern "C" {
 /* Bumped whenever an entry point is added or a signature changes; the Python binding refuses a
  * library that reports another version (a stale libstereo_hip.so).  3: stereo_hip_device_cus, plan
  * entry points select their plan's device, wall-clock bound on cross-workgroup waits.  4: stereo_fusion_fit_planes,
- * stereo_fusion_fuse_until_convergence.  5: stereo_segpln_wta, stereo_segpln_planes. */
-#define STEREO_HIP_ABI_VERSION 5
+ * stereo_fusion_fuse_until_convergence.  5: stereo_segpln_wta, stereo_segpln_planes.  6: stereo_segment_* (the segmenters
+ * behind dispmap_globalstereo), stereo_trws_plan_debug_terms / _messages. */
+#define STEREO_HIP_ABI_VERSION 6
 
 /* ---- library ---------------------------------------------------------- */
 
@@ -510,6 +511,51 @@ int stereo_segpln_wta(const double *images, int n_images, int H, int W, int C, c
 int stereo_segpln_planes(const double *wta, const int32_t *segments, int H, int W, double rt, uint64_t seed,
                          int max_samples, double *proposal, int S, double *planes, int32_t *inliers, char *err,
                          size_t errcap);
+
+/* ---- Image segmentation: what dispmap_globalstereo takes its edge weights (:391-403) and the maps of
+ * its 14 SegPln proposals (:121-134) from.  A: H x W x 3 uint8, MATLAB column-major; out: H x W uint32, column-major.
+ *
+ * stereo_segment_ms = vgg_segment_ms(A, h_s, h_r, min_sz) (imrender/vgg/vgg_segment_ms.cxx:18-87 ->
+ * msImageProcessor::Segment(sigmaS, sigmaR, minRegion, HIGH_SPEEDUP), seg_ms/msImageProcessor.cpp:703-808): mean-shift
+ * filter in LUV (one thread per pixel on the device), then on the host connected components of the filtered image,
+ * transitive closure of the region graph and pruning of regions below min_sz pixels; labels from 1 in the reference's
+ * numbering.  The scalars are cast as the gateway casts them ((int) h_s, (float) h_r, (int) min_sz).  The optional
+ * fifth gateway argument (a weight map, :55-68) has no caller in the reference and is not offered.  The reference reads
+ * its speed-up threshold uninitialised (msImageProcessor.h:796); this entry point computes what the reference's own
+ * build and the fixtures made with it compute: the upper half of a stack address taken for a float, 4.59e-41 -- in
+ * effect "the colours are equal" (csrc/segment_host.h: kSpeedThreshold).
+ *
+ * stereo_segment_gb = vgg_segment_gb(A, sigma, k, min_sz, compress) (imrender/vgg/vgg_segment_gb.cxx:21-87 ->
+ * seg_gb/segment-image.h:181-247): Gaussian smoothing and the weights of the 8-neighbourhood's edges on the device,
+ * edges sorted by weight (std::sort, as in the reference: the order of equal weights is the library's), Kruskal with
+ * the threshold k / size, components below min_sz joined; the labels are the union-find roots, or -- compress != 0 --
+ * 1, 2, ... by first appearance in column-major order.  The library never writes its last row and column: they stay 0
+ * (compressed: the label value 0 gets).
+ *
+ * The staged entry points are the same computation cut at the device / host boundaries: _ms_luv (host: RGB -> LUV,
+ * L x 3 floats, pixel y * W + x); _ms_own (device: every pixel's own mode, same layout, and `events`, L bytes: 1 where
+ * another pixel's colour came within the reference's speed-up threshold of the pixel's trajectory -- in flat regions);
+ * _ms_finish (host: the pixels with events walked again in scan order with the reference's basin-of-attraction
+ * bookkeeping, msImageProcessor.cpp:4015-4022,4085-4127,4256-4270 -> the reference's filtered image; *walked = how many);
+ * _ms_filter = _ms_own + _ms_finish; _ms_regions (host: labels from a filtered image); _gb_weights (device: 4 floats per
+ * pixel y * W + x: to (x+1,y), (x,y+1), (x+1,y+1), (x+1,y-1); 0 where the edge leaves the image), _gb_regions (host).
+ * The host stages need no device. */
+int stereo_segment_ms(const uint8_t *A, int H, int W, double h_s, double h_r, double min_sz, uint32_t *out, char *err,
+                      size_t errcap);
+int stereo_segment_gb(const uint8_t *A, int H, int W, double sigma, double k, double min_sz, int compress, uint32_t *out,
+                      char *err, size_t errcap);
+int stereo_segment_ms_luv(const uint8_t *A, int H, int W, float *luv, char *err, size_t errcap);
+int stereo_segment_ms_own(const uint8_t *A, int H, int W, double h_s, double h_r, float *own, uint8_t *events, char *err,
+                          size_t errcap);
+int stereo_segment_ms_finish(const uint8_t *A, int H, int W, double h_s, double h_r, const float *own, const uint8_t *events,
+                             float *filtered, int64_t *walked, char *err, size_t errcap);
+int stereo_segment_ms_filter(const uint8_t *A, int H, int W, double h_s, double h_r, float *filtered, char *err,
+                             size_t errcap);
+int stereo_segment_ms_regions(const float *filtered, int H, int W, double h_r, double min_sz, uint32_t *out, char *err,
+                              size_t errcap);
+int stereo_segment_gb_weights(const uint8_t *A, int H, int W, double sigma, float *weights, char *err, size_t errcap);
+int stereo_segment_gb_regions(const float *weights, int H, int W, double k, double min_sz, int compress, uint32_t *out,
+                              char *err, size_t errcap);
 
 #ifdef __cplusplus
 }

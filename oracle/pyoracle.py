@@ -266,6 +266,33 @@ def ref_segment_ms(image, h_s=4, h_r=5.0, min_sz=0):
     return np.ascontiguousarray(out)
 
 
+# What msImageProcessor::speedThreshold holds when the reference's gateway reads it uninitialised (oracle/segment_oracle.c)
+MS_SPEED_THRESHOLD = float(np.float32(4.5912142885138307e-41))
+
+
+def rgb_to_luv(image):
+    """oracle/segment_oracle.c: msImageProcessor.cpp:835-875 on an H x W x 3 uint8 image -> H*W x 3 float32, row-major pixels."""
+    im = np.ascontiguousarray(image, dtype=np.uint8)
+    H, W, _ = im.shape
+    luv = np.zeros((H * W, 3), np.float32)
+    lib().oracle_rgb_to_luv(im.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int64(H * W), luv.ctypes.data_as(C.POINTER(C.c_float)))
+    return luv
+
+
+def ms_filter(luv, H, W, h_s, h_r, speed_threshold=MS_SPEED_THRESHOLD, event_threshold=MS_SPEED_THRESHOLD):
+    """oracle/segment_oracle.c: the reference's mean-shift filter (msImageProcessor.cpp:3803-4303) -> (filtered image
+    H*W x 3 float32, event flags H*W uint8).  speed_threshold 0: every pixel walks its own whole trajectory."""
+    luv = np.ascontiguousarray(luv, np.float32)
+    out = np.zeros_like(luv)
+    events = np.zeros(H * W, np.uint8)
+    rc = lib().oracle_ms_filter(luv.ctypes.data_as(C.POINTER(C.c_float)), C.c_int(H), C.c_int(W), C.c_int(int(h_s)), C.c_float(h_r),
+                                C.c_float(speed_threshold), C.c_float(event_threshold), events.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                out.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc:
+        raise MemoryError("oracle_ms_filter")
+    return out, events
+
+
 def ref_segment_gb(image, sigma, k, min_sz, compress=1):
     """The REFERENCE graph-based segmenter (imrender/vgg/seg_gb) behind the restated vgg_segment_gb
     gateway: image H x W x 3 uint8 -> H x W uint32 (dispmap_globalstereo.m:132)."""

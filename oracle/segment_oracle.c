@@ -14,11 +14,15 @@
  *
  * `speed_threshold` is the reference's msImageProcessor::speedThreshold (msImageProcessor.h:796).  Its
  * constructor (:64-108) never sets it and vgg_segment_ms.cxx never calls SetSpeedThreshold: the gateway
- * reads an uninitialised float.  The fixtures -- and every run of oracle/_ref here -- correspond to a
- * value that no squared distance is below (<= 0): the "basin of attraction" shortcuts of HIGH_SPEEDUP
- * (:4015-4022, :4096-4124, :4194-4201) never fire and every pixel runs its own mean-shift iteration.
- * The parameter is kept so that the restatement covers the shortcuts as well (threshold > 0: pixels are
- * processed in scan order and later ones inherit earlier modes).
+ * reads an uninitialised float.  In the reference's own build here (oracle/_ref, and a probe that printed
+ * the member) the object lies on the stack and the float holds the upper half of a stack address
+ * (0x00007ffc = 4.59e-41): a positive value below every squared distance that is not exactly zero.  The
+ * "basin of attraction" shortcuts of HIGH_SPEEDUP (:4015-4022, :4096-4124, :4194-4201) therefore fire
+ * exactly where a pixel's colour EQUALS the trajectory's -- flat image regions: the first pixel in scan
+ * order takes the equal pixels of its window along, they inherit its mode and are skipped.  The fixtures
+ * tests/golden/{teddy,baby2}_segments.npz were made by that build; any threshold in (0, 1e-30] reproduces them, 0
+ * (no shortcut at all) changes 5 of 25074 regions on the Teddy image.  kSpeedThreshold in the product
+ * (csrc/segment_host.h) is that value.
  */
 #include <math.h>
 #include <stdint.h>
@@ -59,13 +63,16 @@ typedef struct {
   const int *neigh;
   float smin;
   double hiLTr;
-  float thr;
+  float thr, event_thr;
+  int64_t self;           /* the pixel whose trajectory this is */
+  unsigned char *event;   /* set when a point other than `self` comes within event_thr (may be NULL) */
   unsigned char *mode_table;
   int *point_list;
   int *point_count;
 } Win;
 
 static void window_shift(const Win *w, const double *yk, double *Mh) {
+  /* (the event flag below: what the product's kernel reports next to a pixel's own mode, see oracle_ms_filter) */
   double wsum = 0;
   for (int j = 0; j < 5; ++j) Mh[j] = 0;
   const int c1 = (int)yk[0] + 1, c2 = (int)yk[1] + 1, c3 = (int)(yk[2] - w->smin) + 1;
@@ -90,6 +97,7 @@ static void window_shift(const Win *w, const double *yk, double *Mh) {
           const double weight = 1 - 0.0f;  /* weightMap is all zero without a fifth gateway argument (ms.cpp:478) */
           for (int k = 0; k < 5; ++k) Mh[k] += weight * s[k];
           wsum += weight;
+          if (w->event && d != w->self && diff < w->event_thr) *w->event = 1;
           if (diff < w->thr && w->mode_table[d] == 0) {
             w->point_list[(*w->point_count)++] = d;
             w->mode_table[d] = 2;
@@ -104,8 +112,13 @@ static void window_shift(const Win *w, const double *yk, double *Mh) {
 }
 
 /* luv: H*W x 3 floats (row-major: pixel i = y * W + x), out: the filtered image, same layout (msRawData).
+ * events (may be NULL): per pixel, 1 when on the pixel's trajectory AS WALKED HERE another pixel's colour came within
+ * event_threshold of the trajectory's -- in a window pass or at the rounded position (:4085-4100).  With
+ * speed_threshold <= 0 (every pixel walks its whole trajectory) this is what the product's kernel returns next to the
+ * pixels' own modes; its host stage then walks the flagged pixels again, in scan order, with the shortcuts.
  * Returns 0, or 1 when memory runs out. */
-int oracle_ms_filter(const float *luv, int H, int W, int sigmaS_i, float sigmaR, float speed_threshold, float *out) {
+int oracle_ms_filter(const float *luv, int H, int W, int sigmaS_i, float sigmaR, float speed_threshold, float event_threshold,
+                     unsigned char *events, float *out) {
   const int64_t L = (int64_t)H * W;
   const float sigmaS = (float)sigmaS_i;   /* Filter() passes (float)(sigmaS), :412 */
   float *sdata = (float *)malloc(sizeof(float) * 5 * L);
@@ -145,10 +158,12 @@ int oracle_ms_filter(const float *luv, int H, int W, int sigmaS_i, float sigmaR,
     for (int b = -1; b <= 1; ++b)
       for (int c = -1; c <= 1; ++c) neigh[n++] = a + nb1 * (b + nb2 * c);
   int point_count = 0;
-  Win w = {sdata, buckets, slist, nb1, nb2, neigh, smin, 80.0 / sigmaR, speed_threshold, mode_table, point_list, &point_count};
+  Win w = {sdata, buckets, slist, nb1, nb2, neigh, smin, 80.0 / sigmaR, speed_threshold, event_threshold, 0, NULL, mode_table, point_list, &point_count};
+  if (events) memset(events, 0, (size_t)L);
   for (int64_t i = 0; i < L; ++i) {   /* :3948-4287 */
     if (mode_table[i] == 1) continue;
     point_count = 0;
+    w.self = i; w.event = events ? events + i : NULL;
     double yk[5], Mh[5];
     for (int j = 0; j < 5; ++j) yk[j] = sdata[5 * i + j];
     window_shift(&w, yk, Mh);
@@ -159,6 +174,11 @@ int oracle_ms_filter(const float *luv, int H, int W, int sigmaS_i, float sigmaR,
       for (int j = 0; j < 5; ++j) yk[j] += Mh[j];
       const int cx = (int)(sigmaS * yk[0] + 0.5), cy = (int)(sigmaS * yk[1] + 0.5);
       const int64_t ci = (int64_t)cy * W + cx;
+      if (events && ci != i) {
+        double diff = 0;
+        for (int k = 2; k < 5; ++k) { const double el = sdata[5 * ci + k] - yk[k]; diff += el * el; }
+        if (diff < event_threshold) events[i] = 1;
+      }
       if (mode_table[ci] != 2 && ci != i) {   /* :4085-4127 */
         double diff = 0;
         for (int k = 2; k < 5; ++k) { const double el = sdata[5 * ci + k] - yk[k]; diff += el * el; }

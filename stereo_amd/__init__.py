@@ -11,8 +11,9 @@ from .trws import trws, TrwsPlan  # noqa: F401
 from .rd import rd  # noqa: F401
 from .dispmap import dispmap_super, dispmap_ncc, dispmap_globalstereo  # noqa: F401
 from .fusion import PlaneProposal  # noqa: F401
+from .segment import vgg_segment_ms, vgg_segment_gb  # noqa: F401
 
-__all__ = ["trws", "rd", "dispmap_super", "dispmap_ncc", "dispmap_globalstereo", "TrwsPlan", "PlaneProposal", "StereoHipError", "device_count", "LIB_PATH"]
+__all__ = ["trws", "rd", "dispmap_super", "dispmap_ncc", "dispmap_globalstereo", "TrwsPlan", "PlaneProposal", "vgg_segment_ms", "vgg_segment_gb", "StereoHipError", "device_count", "LIB_PATH"]
 
 # Load the library (and let the HIP runtime finish its one-time initialisation, which draws from
 # libc rand()) when the package is imported, not inside the first solver call: a caller that seeds

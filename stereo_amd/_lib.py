@@ -15,7 +15,7 @@ _dp = C.POINTER(C.c_double)
 _u32p = C.POINTER(C.c_uint32)
 _i64p = C.POINTER(C.c_int64)
 
-ABI_VERSION = 5   # include/stereo_hip.h: STEREO_HIP_ABI_VERSION
+ABI_VERSION = 6   # include/stereo_hip.h: STEREO_HIP_ABI_VERSION
 
 _lib = None
 

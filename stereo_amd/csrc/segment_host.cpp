@@ -93,6 +93,115 @@ void ms_lattice(const float *luv, int H, int W, int sigmaS_i, float sigmaR, MsLa
       for (int c = -1; c <= 1; ++c) lat.neigh[n++] = a + lat.nb1 * (b + lat.nb2 * c);
 }
 
+// ---- mean shift: the filter's serial part ---------------------------------------------------------------------------------
+// The reference filters pixels in scan order and lets a pixel take along ("basin of attraction") every pixel whose
+// colour comes within speedThreshold of its trajectory; those inherit its mode and are skipped (msImageProcessor.cpp:
+// 4015-4022, 4085-4127, 4194-4201, 4256-4270).  With the threshold the gateway ends up with (kSpeedThreshold,
+// segment_host.h) that happens where colours are EQUAL: in flat image regions.  The device walks every pixel's whole
+// trajectory on its own and reports, next to the pixel's own mode, whether any other pixel's colour ever came that
+// close (`events`).  A pixel without such an event neither takes anybody along nor stops early: its result is its own
+// mode, unless an earlier pixel took IT along.  The pixels with events -- and only those -- are walked here once more,
+// in scan order, with the reference's bookkeeping.
+namespace {
+
+struct Walk {
+  const MsLattice &lat;
+  std::vector<uint8_t> mode_table;   // 0 untouched, 1 has its mode, 2 in the basin of the pixel being walked
+  std::vector<int32_t> points;       // that basin
+  float thr;
+  double hiLTr;
+
+  void window(const double *yk, double *Mh) {
+    const float *sd = lat.sdata.data();
+    double wsum = 0;
+    for (int j = 0; j < 5; ++j) Mh[j] = 0;
+    const int c1 = (int)yk[0] + 1, c2 = (int)yk[1] + 1, c3 = (int)(yk[2] - lat.smin) + 1;
+    const int cb = c1 + lat.nb1 * (c2 + lat.nb2 * c3);
+    for (int j = 0; j < 27; ++j) {
+      const int b = cb + lat.neigh[j];
+      for (int e = lat.bucket_ptr[b]; e < lat.bucket_ptr[b + 1]; ++e) {
+        const int d = lat.bucket_items[e];
+        const float *s = sd + 5 * (size_t)d;
+        double el = s[0] - yk[0];
+        double diff = el * el;
+        el = s[1] - yk[1];
+        diff += el * el;
+        if (!(diff < 1.0)) continue;
+        el = s[2] - yk[2];
+        diff = yk[2] > hiLTr ? 4 * el * el : el * el;
+        el = s[3] - yk[3];
+        diff += el * el;
+        el = s[4] - yk[4];
+        diff += el * el;
+        if (!(diff < 1.0)) continue;
+        for (int k = 0; k < 5; ++k) Mh[k] += 1.0 * s[k];
+        wsum += 1.0;
+        if (diff < thr && mode_table[d] == 0) { points.push_back(d); mode_table[d] = 2; }
+      }
+    }
+    if (wsum > 0) for (int j = 0; j < 5; ++j) Mh[j] = Mh[j] / wsum - yk[j];
+    else for (int j = 0; j < 5; ++j) Mh[j] = 0;
+  }
+};
+
+}  // namespace
+
+int64_t ms_filter_finish(const MsLattice &lat, const float *own, const uint8_t *events, float thr, float *out) {
+  const int64_t L = (int64_t)lat.H * lat.W;
+  const int W = lat.W;
+  const float sigmaS = lat.sigmaS, sigmaR = lat.sigmaR;
+  const float *sd = lat.sdata.data();
+  Walk w{lat, std::vector<uint8_t>((size_t)L, 0), {}, thr, 80.0 / sigmaR};
+  int64_t walked = 0;
+  for (int64_t i = 0; i < L; ++i) {
+    if (w.mode_table[i] == 1) continue;
+    if (!events[i]) {
+      for (int k = 0; k < 3; ++k) out[3 * i + k] = own[3 * i + k];
+      w.mode_table[i] = 1;
+      continue;
+    }
+    ++walked;
+    w.points.clear();
+    double yk[5], Mh[5];
+    for (int j = 0; j < 5; ++j) yk[j] = sd[5 * i + j];
+    w.window(yk, Mh);
+    double mv = (Mh[0] * Mh[0] + Mh[1] * Mh[1]) * sigmaS * sigmaS;
+    mv += (Mh[2] * Mh[2] + Mh[3] * Mh[3] + Mh[4] * Mh[4]) * sigmaR * sigmaR;
+    int iter = 1;
+    while (mv >= 0.01 && iter < 100) {
+      for (int j = 0; j < 5; ++j) yk[j] += Mh[j];
+      const int cx = (int)(sigmaS * yk[0] + 0.5), cy = (int)(sigmaS * yk[1] + 0.5);
+      const int64_t ci = (int64_t)cy * W + cx;
+      if (w.mode_table[ci] != 2 && ci != i) {
+        double diff = 0;
+        for (int k = 2; k < 5; ++k) { const double el = sd[5 * ci + k] - yk[k]; diff += el * el; }
+        if (diff < thr) {
+          if (w.mode_table[ci] == 0) { w.points.push_back((int32_t)ci); w.mode_table[ci] = 2; }
+          else {   // a pixel that has its mode already: this trajectory ends there
+            for (int j = 0; j < 3; ++j) yk[j + 2] = out[3 * ci + j] / sigmaR;
+            w.mode_table[i] = 1;
+            mv = -1;
+            break;
+          }
+        }
+      }
+      w.window(yk, Mh);
+      mv = (Mh[0] * Mh[0] + Mh[1] * Mh[1]) * sigmaS * sigmaS;
+      mv += (Mh[2] * Mh[2] + Mh[3] * Mh[3] + Mh[4] * Mh[4]) * sigmaR * sigmaR;
+      ++iter;
+    }
+    if (mv >= 0) { for (int j = 0; j < 5; ++j) yk[j] += Mh[j]; w.mode_table[i] = 1; }
+    float mode[3];
+    for (int k = 0; k < 3; ++k) mode[k] = (float)(yk[k + 2] * sigmaR);
+    for (int32_t c : w.points) {
+      w.mode_table[c] = 1;
+      for (int k = 0; k < 3; ++k) out[3 * (size_t)c + k] = mode[k];
+    }
+    for (int k = 0; k < 3; ++k) out[3 * i + k] = mode[k];
+  }
+  return walked;
+}
+
 // ---- mean shift: regions of the filtered image -----------------------------------------------------------------------
 namespace {
 

@@ -1538,9 +1538,24 @@ int64_t image_grid_height(int64_t N, int64_t E, const uint32_t *conn) {
   return H;
 }
 
+// The terms of the bound and of the energy in the order ONE plan adds them (rank N - 1 down to 0: the node's own term, then
+// one per message; rank 0 up: one per node), as runs of consecutive terms of one strip: a strip numbers its terms in that
+// same order, so a run is as long as consecutive ranks stay with one owner (a band of rows: a few runs per image row at
+// most).  Summed this way the gateway's two scalars are the single plan's to the last bit -- and with them the stop test
+// and the iteration count (minimize.cpp:105).
+struct TermRuns {
+  std::vector<int32_t> strip;
+  std::vector<int64_t> start, count;
+  void add(int s, int64_t pos, int64_t n) {
+    if (!strip.empty() && strip.back() == s && start.back() + count.back() == pos) { count.back() += n; return; }
+    strip.push_back(s); start.push_back(pos); count.push_back(n);
+  }
+};
+
 struct TrwsStripSet {
   std::vector<stereo_trws_plan *> plans;
   std::vector<int32_t> owner;
+  TermRuns lb_runs, en_runs;
   bool one_device = true;
   ~TrwsStripSet() { for (stereo_trws_plan *P : plans) if (P) stereo_trws_plan_destroy(P); }
 };
@@ -1568,6 +1583,15 @@ int strips_create(int kernel, int K, int64_t N, int64_t E, const uint32_t *conn,
     if (g > 0) rc = stereo_trws_plan_connect(S.plans[g], 0, S.plans[g - 1], err, errcap);
     if (!rc && g + 1 < G) rc = stereo_trws_plan_connect(S.plans[g], 1, S.plans[g + 1], err, errcap);
   }
+  if (!rc) {
+    const TrwsGraph &g = *S.plans[0]->graph;
+    for (int64_t r = N - 1; r >= 0; --r) {
+      const int s = S.owner[g.order[r]];
+      S.lb_runs.add(s, g.lb_pos_node[r], 1);
+      for (int32_t k = g.bptr[r]; k < g.bptr[r + 1]; ++k) S.lb_runs.add(s, g.lb_pos_edge[g.bidx[k]], 1);
+    }
+    for (int64_t r = 0; r < N; ++r) S.en_runs.add(S.owner[g.order[r]], g.e_pos[r], 1);
+  }
   return rc;
 }
 
@@ -1591,12 +1615,17 @@ int strips_solve(TrwsStripSet &S, const double *unary, const double *q, const do
     if (S.one_device) rc = stereo_trws_plans_issue(S.plans.data(), G, nullptr, err, errcap);
     else for (int g = 0; g < G && !rc; ++g) rc = stereo_trws_plan_issue(S.plans[g], nullptr, err, errcap);
     if (rc) return rc;
-    // the strips' partial sums, added in strip order (the only cross-strip reduction: two doubles)
+    // every strip's terms are on the host behind its collect; they are added in the order one plan adds them (TermRuns)
+    for (int g = 0; g < G; ++g)
+      if ((rc = stereo_trws_plan_collect(S.plans[g], nullptr, nullptr, err, errcap)) != 0) return rc;
     lb = 0; en = 0;
-    for (int g = 0; g < G; ++g) {
-      double l = 0, e = 0;
-      if ((rc = stereo_trws_plan_collect(S.plans[g], &l, &e, err, errcap)) != 0) return rc;
-      lb += l; en += e;
+    for (size_t k = 0; k < S.lb_runs.strip.size(); ++k) {
+      const double *t = S.plans[S.lb_runs.strip[k]]->h_lb.p + S.lb_runs.start[k];
+      for (int64_t i = 0; i < S.lb_runs.count[k]; ++i) lb += t[i];
+    }
+    for (size_t k = 0; k < S.en_runs.strip.size(); ++k) {
+      const double *t = S.plans[S.en_runs.strip[k]]->h_en.p + S.en_runs.start[k];
+      for (int64_t i = 0; i < S.en_runs.count[k]; ++i) en += t[i];
     }
     for (int g = 0; g < G; ++g) (void)stereo_trws_plan_commit(S.plans[g], lb, en, err, errcap);
     ++done;

@@ -3,9 +3,9 @@ dispmap_ncc.m, dispmap_globalstereo.m): same method names, argument meaning and
 error behaviour, every array operation and both solvers running on the GPU through
 the C ABI.  Planes are 4 x N arrays, images H x W x C doubles.
 
-Not mirrored (out of scope for the hot path): proposal generators
-(generate_new_plane_RANSAC, segpln), mean-shift segmentation (edge weights enter as an
-array or a segment-label image), figures.
+The proposal generators (local plane fits, segpln) and the two segmenters behind
+dispmap_globalstereo (stereo_amd/segment.py) run through the same library; figures are
+not mirrored.
 """
 import numpy as np
 
@@ -420,13 +420,15 @@ class dispmap_ncc(dispmap_super):
 
 class dispmap_globalstereo(dispmap_super):
     """dispmap_globalstereo.m with the constants of ojw_default_options('cvpr08')
-    (imrender/ojw/ojw_default_options.m:58-80) as defaults.  The mean-shift segmentation of
-    preprocess() (:391) is out of scope: pass `segment` (H x W labels) or `smooth_weights`."""
+    (imrender/ojw/ojw_default_options.m:58-80) as defaults.  As in preprocess() (:377-403) the edge weights come
+    from the mean-shift segmentation of the reference image, vgg_segment_ms(Rorig, seg_params) with seg_params =
+    [4 5 0] (ojw_default_options.m:68; stereo_amd/segment.py); `segment` (H x W labels) or `smooth_weights`
+    replace it for a caller who has them."""
 
     def __init__(self, images, P, disp_range, disparity_factor, options=None, segment=None,
                  smooth_weights=None, start_disparity=None, rng=None):
         opt = dict(smoothness_kernel=1, disp_thresh=0.02, col_thresh=30.0, lambda_l=9.0, lambda_h=108.0,
-                   connect=4, improve=1)
+                   connect=4, improve=1, seg_params=(4, 5, 0))
         opt.update(options or {})
         super().__init__(images, opt["smoothness_kernel"])
         self.options = opt
@@ -445,6 +447,11 @@ class dispmap_globalstereo(dispmap_super):
         self._tol = opt["disp_thresh"]
         self._improve = opt["improve"] > 0
         nin = len(self.images)
+        if smooth_weights is None and segment is None:
+            from . import segment as _segment                                         # :378-392
+            sp = opt["seg_params"]
+            segment = _segment.vgg_segment_ms(_segment.to_uint8(self.images[0]), sp[0], sp[1], sp[2])
+        self.segment = None if segment is None else np.asarray(segment)
         if smooth_weights is not None:
             self.smooth_weights = np.asarray(smooth_weights, np.float64).reshape(-1)
         elif segment is not None:
@@ -493,12 +500,22 @@ class dispmap_globalstereo(dispmap_super):
                                             window=self.options.get("window", 2))
         return self._segpln_wta
 
-    def segpln(self, segment_maps, seed=0):
-        """dispmap_globalstereo.m:60-201: one piecewise-planar proposal (4 x N) per segmentation map -- the
-        reference makes 14 of them with mean-shift / Felzenszwalb segmentations at the scales `mults` (:122-137);
-        the segmenters are out of scope, so the maps (H x W labels 1 .. S, 0 = no segment) are the
-        caller's.  Window matching, LO-RANSAC and the plane fits run on the device (stereo_segpln_wta /
-        stereo_segpln_planes); `seed` stands for MATLAB's random stream (map b uses seed + b)."""
+    def segpln_segments(self):
+        """The 14 segmentation maps of segpln (:116-134), H x W x 14, once per object."""
+        if getattr(self, "_segpln_maps", None) is None:
+            from . import segment as _segment
+            self._segpln_maps = _segment.segpln_segments(self.images[0])
+        return self._segpln_maps
+
+    def segpln(self, segment_maps=None, seed=0):
+        """dispmap_globalstereo.m:60-201: one piecewise-planar proposal (4 x N) per segmentation map -- 14 of them,
+        on mean-shift / Felzenszwalb segmentations at the scales `mults` (:122-137; segpln_segments above), or on
+        the maps the caller passes (H x W labels 1 .. S, 0 = no segment).  Window matching, LO-RANSAC and the
+        plane fits run on the device (stereo_segpln_wta / stereo_segpln_planes); `seed` stands for MATLAB's
+        random stream (map b uses seed + b)."""
+        if segment_maps is None:
+            maps = self.segpln_segments()
+            segment_maps = [maps[:, :, b] for b in range(maps.shape[2])]
         wta = self.segpln_wta()
         return [T.segpln_planes(wta, seg, seed=int(seed) + b)[0] for b, seg in enumerate(segment_maps)]
 
