@@ -507,7 +507,8 @@ int stereo_segpln_wta(const double *images, int n_images, int H, int W, int C, c
  * (oracle/terms.py:segpln_sample -- the draw is an input of the parity test), the 3 x 3 systems are solved by
  * Cramer's rule and the least-squares planes through the normal equations in a fixed summation order (MATLAB's
  * mldivide is outside the reference tree; oracle/terms.py:segpln_planes is the definition, matched bit for
- * bit).  planes (3 x S) / inliers (S) may be NULL. */
+ * bit).  planes (3 x S) / inliers (S) may be NULL; so may proposal when planes is given (the caller expands the planes
+ * over the segments itself, or hands planes + segments to stereo_fusion_binary_planes). */
 int stereo_segpln_planes(const double *wta, const int32_t *segments, int H, int W, double rt, uint64_t seed,
                          int max_samples, double *proposal, int S, double *planes, int32_t *inliers, char *err,
                          size_t errcap);

@@ -179,106 +179,244 @@ struct FitArgs {
   double rt;
   uint64_t seed;
   double *px, *py, *pz;     // scratch: world coordinates of a segment's points, at the segment's offset in seg_idx
-  uint8_t *cur, *inl;       // scratch: inlier flags of the current trial / of the best one
+  uint8_t *cur, *tmp, *inl; // scratch: inlier flags of a batch of trials (bit b = trial b), of a re-estimated plane, of the best one
   double *proposal;         // 4 x N
   double *planes;           // 3 x S
   int32_t *ninl;            // S
   const int32_t *list;      // the segments of this launch
+  unsigned long long *prof; // development (STEREO_HIP_SEGPLN_TIMING): 100 MHz ticks per phase of the launch's first workgroup
 };
 
+constexpr int kFitBatch = 8;   // RANSAC trials judged per pass over a segment's points
+constexpr int kFitStage = 4096;   // points per LDS stage of the large segments' least-squares sums (3 doubles + a flag each)
+constexpr size_t kFitStageBytes = (size_t)kFitStage * (3 * sizeof(double) + 1);
+
+// One least-squares sum of the flagged points, as oracle/terms.py:_lstsq3 forms it: 64 strided partial sums (lane l adds
+// points l, l + 64, ... in order), then a tree.  K: x x, x y, x z, y y, y z, z z, -x, -y, -z.  Returns the sum in lane 0.
+template <int K>
+__device__ __forceinline__ double fit_sum(const double *X, const double *Y, const double *Z, const uint8_t *flags, int bit, int n, int lane) {
+  // (sixteen points' loads go out together -- they do not depend on each other --, the additions then follow in order:
+  //  one point per round trip to memory made a 150 000-point sum a third of a millisecond)
+  constexpr int U = 16;
+  double acc = 0;
+  for (int base = lane; base < n; base += 64 * U) {
+    double xv[U], yv[U], zv[U];
+    bool fv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + 64 * u, ic = i < n ? i : n - 1;
+      xv[u] = (K == 0 || K == 1 || K == 2 || K == 6) ? X[ic] : 0.0;
+      yv[u] = (K == 1 || K == 3 || K == 4 || K == 7) ? Y[ic] : 0.0;
+      zv[u] = (K == 2 || K == 4 || K == 5 || K == 8) ? Z[ic] : 0.0;
+      fv[u] = i < n && (flags == nullptr || ((flags[ic] >> bit) & 1));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double x = xv[u], y = yv[u], z = zv[u];
+      const double t = K == 0 ? x * x : K == 1 ? x * y : K == 2 ? x * z : K == 3 ? y * y : K == 4 ? y * z : K == 5 ? z * z : K == 6 ? -x : K == 7 ? -y : -z;
+      const double next = acc + t;
+      acc = fv[u] ? next : acc;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const double other = __shfl_down(acc, o, 64);
+    acc = acc + other;   // (lanes >= o hold values nobody reads afterwards)
+  }
+  return acc;
+}
+
 // One workgroup of T threads per segment (dispmap_globalstereo.m:164-191 + rplane :417-450).  Control flow is uniform:
-// every decision is made on a count or on values every thread holds.  The cost of a segment is its RANSAC trials, each
-// a pass over all of its points (`classify`: flags and an integer count, independent of who looks at which point) --
-// that pass is spread over all T threads (T = 1024 for the large segments of a coarse segmentation map: one of them on
-// ONE wave used to take 58 ms of the Teddy example's 119 ms of plane fitting); the least-squares sums, whose order of
-// addition is part of the definition (oracle/terms.py:_lstsq3: 64 strided partial sums, then a tree), stay with the
-// first wave, which hands the plane to the others through LDS.  They run a few times per segment, not once per trial.
+// every decision is made on a count or on values every thread holds.  What a segment costs and who does it:
+//   * world coordinates of its points, compacted in order: all waves, a chunk of T points per step (counts by ballot);
+//   * RANSAC trials: the plane through a trial's three points and its inlier count are pure functions of (seed,
+//     segment, trial) -- kFitBatch consecutive trials are drawn by as many lanes side by side and judged in ONE pass
+//     over the points (a bit per trial in `cur`, a count per trial), then looked at in order by the reference's
+//     bookkeeping (:426-447: which trial improves on the best, how many trials are still needed); trials drawn beyond
+//     the point where that bookkeeping stops are simply not looked at;
+//   * least squares of an inlier set: nine sums whose order of addition IS the definition (oracle/terms.py:_lstsq3) --
+//     one wave per sum where the workgroup has nine (a coarse map's 150 000-pixel segment on ONE wave used to take a
+//     third of a millisecond per fit, eleven fits);
+// same operations on the same operands in the same order as before, so the planes keep their bits (tests/test_segpln_gpu.py).
 template <int T>
 __global__ __launch_bounds__(T) void segpln_fit_kernel(FitArgs a) {
-  __shared__ int s_cnt[T / 64 > 0 ? T / 64 : 1];
-  __shared__ double s_plane[3];
+  constexpr int NW = T / 64;
+  constexpr int LW = NW < 9 ? NW : 9;   // waves that sum
+  __shared__ int s_cnt[NW * kFitBatch];
+  __shared__ int s_tot[kFitBatch];
+  __shared__ double s_N[3 * kFitBatch];
+  __shared__ double s_acc[9];
   const int s = a.list[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p0 = a.seg_ptr[s], p1 = a.seg_ptr[s + 1];
   if (p1 <= p0) { if (tid == 0) { a.ninl[s] = 0; a.planes[3 * s] = a.planes[3 * s + 1] = a.planes[3 * s + 2] = 0; } return; }
   double *X = a.px + p0, *Y = a.py + p0, *Z = a.pz + p0;
-  uint8_t *cur = a.cur + p0, *inl = a.inl + p0;
+  uint8_t *cur = a.cur + p0, *tmp = a.tmp + p0, *inl = a.inl + p0;
+  unsigned long long tmark = (unsigned long long)wall_clock64();   // (100 MHz)
+  auto stamp = [&](int k) {
+    if (a.prof && blockIdx.x == 0 && tid == 0) { const unsigned long long now = (unsigned long long)wall_clock64(); a.prof[k] += now - tmark; a.prof[8 + k] += 1; tmark = now; }
+  };
   // world coordinates [x y 1] / d of the segment's pixels (:141-145), those with WC(:,3) ~= 0 kept (:168), in order
   int n = 0;
-  if (wave == 0)
-  for (int base = p0; base < p1; base += 64) {
-    const int i = base + lane;
-    double z = 0, x = 0, y = 0;
-    bool keep = false;
-    if (i < p1) {
-      const int px = a.seg_idx[i];
-      z = 1.0 / a.wta[px];
-      x = z * (double)(px / a.H + 1); y = z * (double)(px % a.H + 1);
-      keep = z != 0;
+  for (int base = p0; base < p1; base += 4 * T) {   // (four chunks of T pixels per step: their loads go out together)
+    double zq[4];
+    int pxq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + u * T + tid;
+      pxq[u] = a.seg_idx[i < p1 ? i : p1 - 1];
     }
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-    const int at = n + __builtin_popcountll(m & ((1ull << lane) - 1));
-    if (keep) { X[at] = x; Y[at] = y; Z[at] = z; }
-    n += __builtin_popcountll(m);
-  }
-  if (T > 64) {
-    if (tid == 0) s_cnt[0] = n;
-    __threadfence_block();
-    __syncthreads();
-    n = s_cnt[0];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) zq[u] = a.wta[pxq[u]];
+    unsigned long long mq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      zq[u] = 1.0 / zq[u];
+      mq[u] = __builtin_amdgcn_ballot_w64(base + u * T + tid < p1 && zq[u] != 0);
+      if (NW > 1 && lane == 0) s_cnt[wave * 4 + u] = __builtin_popcountll(mq[u]);
+    }
+    if (NW > 1) __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int before = 0, total = __builtin_popcountll(mq[u]);
+      if (NW > 1) {
+        total = 0;
+        for (int w = 0; w < NW; ++w) { const int c = s_cnt[w * 4 + u]; before += w < wave ? c : 0; total += c; }
+      }
+      const int at = n + before + __builtin_popcountll(mq[u] & ((1ull << lane) - 1));
+      if ((mq[u] >> lane) & 1) {
+        const double z = zq[u];
+        X[at] = z * (double)(pxq[u] / a.H + 1); Y[at] = z * (double)(pxq[u] % a.H + 1); Z[at] = z;
+      }
+      n += total;
+    }
+    if (NW > 1) __syncthreads();
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
+  stamp(0);
   // distances of all points to the plane N . p = -1, flags into `dst`; returns the number of inliers
   auto classify = [&](const double N[3], uint8_t *dst) {
     int cnt = 0;
-    for (int i = tid; i < n; i += T) {
-      const double dist = fabs(((X[i] * N[0] + Y[i] * N[1]) + Z[i] * N[2]) + 1.0);
-      const bool v = dist < a.rt;
-      dst[i] = v ? 1 : 0;
-      cnt += v ? 1 : 0;
+    for (int base = tid; base < n; base += 8 * T) {
+      double xv[8], yv[8], zv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int i = base + u * T, ic = i < n ? i : n - 1; xv[u] = X[ic]; yv[u] = Y[ic]; zv[u] = Z[ic]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * T;
+        const double dist = fabs(((xv[u] * N[0] + yv[u] * N[1]) + zv[u] * N[2]) + 1.0);
+        const bool v = i < n && dist < a.rt;
+        if (i < n) dst[i] = v ? 1 : 0;
+        cnt += v ? 1 : 0;
+      }
     }
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    if (T > 64) {
+    if (NW > 1) {
       __syncthreads();   // (the last reader of s_cnt is done)
       if (lane == 0) s_cnt[wave] = cnt;
       __syncthreads();
       cnt = 0;
-      for (int w = 0; w < T / 64; ++w) cnt += s_cnt[w];
+      for (int w = 0; w < NW; ++w) cnt += s_cnt[w];
     }
     __syncthreads();
     return cnt;
   };
-  // least squares of the flagged points by the normal equations, summed as oracle/terms.py:_lstsq3 sums them
-  auto lstsq = [&](const uint8_t *flags, double N[3]) {
-    if (T > 64 && wave != 0) {   // (the first wave sums, in the definition's order; the others take the plane from LDS)
-      __syncthreads();
-      N[0] = s_plane[0]; N[1] = s_plane[1]; N[2] = s_plane[2];
-      __syncthreads();
-      return;
-    }
-    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = lane; i < n; i += 64) {
-      if (flags == nullptr || flags[i]) {
-        const double x = X[i], y = Y[i], z = Z[i];
-        acc[0] += x * x; acc[1] += x * y; acc[2] += x * z; acc[3] += y * y; acc[4] += y * z; acc[5] += z * z;
-        acc[6] += -x; acc[7] += -y; acc[8] += -z;
+  // least squares of the flagged points (bit `bit` of flags[i]; nullptr: all points) by the normal equations
+  auto lstsq = [&](const uint8_t *flags, int bit, double N[3]) {
+    __syncthreads();   // (flags written by other waves; the last readers of s_acc are done)
+    if (NW == 1) {
+      // one wave: the nine sums side by side in one pass (segments of a few hundred points at most)
+      double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = lane; i < n; i += 64) {
+        if (flags == nullptr || ((flags[i] >> bit) & 1)) {
+          const double x = X[i], y = Y[i], z = Z[i];
+          acc[0] += x * x; acc[1] += x * y; acc[2] += x * z; acc[3] += y * y; acc[4] += y * z; acc[5] += z * z;
+          acc[6] += -x; acc[7] += -y; acc[8] += -z;
+        }
+      }
+      for (int o = 32; o > 0; o >>= 1)
+        for (int k = 0; k < 9; ++k) {
+          const double other = __shfl_down(acc[k], o, 64);
+          acc[k] = acc[k] + other;   // (lanes >= o hold values nobody reads afterwards)
+        }
+      if (lane == 0) for (int k = 0; k < 9; ++k) s_acc[k] = acc[k];
+    } else if (NW >= 8) {
+      // large segments: ALL waves stream the points through LDS, kStage at a time (the next stage's loads are in flight
+      // while this one is summed), and waves 0 .. 7 add their sum's terms from there in order (wave 0 also the ninth) --
+      // a wave that pulls a 150 000-point segment through its own registers waits a memory round trip per 16 points
+      extern __shared__ __attribute__((aligned(16))) double fit_stage[];
+      constexpr int PER = kFitStage / T;
+      double *sX = fit_stage, *sY = sX + kFitStage, *sZ = sY + kFitStage;
+      uint8_t *sF = (uint8_t *)(sZ + kFitStage);
+      double rx[PER], ry[PER], rz[PER];
+      bool rf[PER];
+      auto request = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+          const int i = c0 + u * T + tid, ic = i < n ? i : n - 1;
+          rx[u] = X[ic]; ry[u] = Y[ic]; rz[u] = Z[ic];
+          rf[u] = i < n && (flags == nullptr || ((flags[ic] >> bit) & 1));
+        }
+      };
+      request(0);
+      double acc = 0, acc8 = 0;
+      for (int c0 = 0; c0 < n; c0 += kFitStage) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { const int j = u * T + tid; sX[j] = rx[u]; sY[j] = ry[u]; sZ[j] = rz[u]; sF[j] = rf[u] ? 1 : 0; }
+        __syncthreads();
+        if (c0 + kFitStage < n) request(c0 + kFitStage);
+        const int m = n - c0 < kFitStage ? n - c0 : kFitStage;
+        if (wave < 8) {
+          // (eight points' LDS reads go out together, the additions follow in order; a flag of 0 behind the stage's end)
+          const double *sA = (wave == 0 || wave == 1 || wave == 2 || wave == 6) ? sX : (wave == 3 || wave == 4 || wave == 7) ? sY : sZ;
+          const double *sB = (wave == 0) ? sX : (wave == 1 || wave == 3) ? sY : sZ;   // (second factor; waves 6, 7: unused)
+          for (int j0 = lane; j0 < m; j0 += 64 * 8) {
+            double av[8], bv[8], zv[8];
+            bool fv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int j = j0 + 64 * u, jc = j < m ? j : m - 1;
+              av[u] = sA[jc]; bv[u] = sB[jc]; zv[u] = wave == 0 ? sZ[jc] : 0.0;
+              fv[u] = j < m && sF[jc] != 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const double t = wave < 6 ? av[u] * bv[u] : -av[u];
+              const double next = acc + t;
+              acc = fv[u] ? next : acc;
+              if (wave == 0) { const double n8 = acc8 + (-zv[u]); acc8 = fv[u] ? n8 : acc8; }
+            }
+          }
+        }
+        __syncthreads();
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        const double other = __shfl_down(acc, o, 64), other8 = __shfl_down(acc8, o, 64);
+        acc = acc + other; acc8 = acc8 + other8;
+      }
+      if (lane == 0 && wave < 8) s_acc[wave] = acc;
+      if (lane == 0 && wave == 0) s_acc[8] = acc8;
+    } else {
+      for (int k = wave; k < 9; k += LW) {
+        double v = 0;
+        switch (k) {
+          case 0: v = fit_sum<0>(X, Y, Z, flags, bit, n, lane); break;
+          case 1: v = fit_sum<1>(X, Y, Z, flags, bit, n, lane); break;
+          case 2: v = fit_sum<2>(X, Y, Z, flags, bit, n, lane); break;
+          case 3: v = fit_sum<3>(X, Y, Z, flags, bit, n, lane); break;
+          case 4: v = fit_sum<4>(X, Y, Z, flags, bit, n, lane); break;
+          case 5: v = fit_sum<5>(X, Y, Z, flags, bit, n, lane); break;
+          case 6: v = fit_sum<6>(X, Y, Z, flags, bit, n, lane); break;
+          case 7: v = fit_sum<7>(X, Y, Z, flags, bit, n, lane); break;
+          default: v = fit_sum<8>(X, Y, Z, flags, bit, n, lane); break;
+        }
+        if (lane == 0) s_acc[k] = v;
       }
     }
-    for (int o = 32; o > 0; o >>= 1)
-      for (int k = 0; k < 9; ++k) {
-        const double other = __shfl_down(acc[k], o, 64);
-        acc[k] = acc[k] + other;   // (lanes >= o hold values nobody reads afterwards)
-      }
+    __syncthreads();
     double m[9], b[3];
-    for (int k = 0; k < 9; ++k) acc[k] = __shfl(acc[k], 0, 64);
-    m[0] = acc[0]; m[1] = acc[1]; m[2] = acc[2]; m[3] = acc[1]; m[4] = acc[3]; m[5] = acc[4]; m[6] = acc[2]; m[7] = acc[4]; m[8] = acc[5];
-    b[0] = acc[6]; b[1] = acc[7]; b[2] = acc[8];
-    solve3(m, b, N);
-    if (T > 64) {
-      if (lane == 0) { s_plane[0] = N[0]; s_plane[1] = N[1]; s_plane[2] = N[2]; }
-      __syncthreads();
-      __syncthreads();
-    }
+    m[0] = s_acc[0]; m[1] = s_acc[1]; m[2] = s_acc[2]; m[3] = s_acc[1]; m[4] = s_acc[3]; m[5] = s_acc[4]; m[6] = s_acc[2]; m[7] = s_acc[4]; m[8] = s_acc[5];
+    b[0] = s_acc[6]; b[1] = s_acc[7]; b[2] = s_acc[8];
+    solve3(m, b, N);   // (every thread, from the same nine sums)
   };
   int n_in = n;          // local_WC_points = N when there are too few points for RANSAC (:170)
   bool use_flags = false;
@@ -288,46 +426,103 @@ __global__ __launch_bounds__(T) void segpln_fit_kernel(FitArgs a) {
     for (int i = tid; i < n; i += T) inl[i] = 0;
     __syncthreads();
     while ((double)no_sam < max_sam) {
-      ++no_sam;
-      int sam[3], got = 0, attempt = 0;
-      while (got < 3) {   // oracle/terms.py:segpln_sample
-        const uint64_t key = a.seed * 0x100000001B3ull + (uint64_t)(s + 1) * 0x1000193ull + (uint64_t)no_sam * 64ull + (uint64_t)attempt;
-        const int v = (int)(splitmix64(key) % (uint64_t)n);
-        ++attempt;
-        bool dup = false;
-        for (int k = 0; k < got; ++k) dup = dup || sam[k] == v;
-        if (!dup) sam[got++] = v;
+      // trials no_sam + 1 .. no_sam + kFitBatch: lane b draws trial b's three points and solves for its plane
+      if (tid < kFitBatch) {
+        const int trial = no_sam + 1 + tid;
+        int sam[3], got = 0, attempt = 0;
+        while (got < 3) {   // oracle/terms.py:segpln_sample
+          const uint64_t key = a.seed * 0x100000001B3ull + (uint64_t)(s + 1) * 0x1000193ull + (uint64_t)trial * 64ull + (uint64_t)attempt;
+          const int v = (int)(splitmix64(key) % (uint64_t)n);
+          ++attempt;
+          bool dup = false;
+          for (int k = 0; k < got; ++k) dup = dup || sam[k] == v;
+          if (!dup) sam[got++] = v;
+        }
+        double m[9], N[3];
+        const double div[3] = {-1.0, -1.0, -1.0};
+        for (int k = 0; k < 3; ++k) { m[3 * k] = X[sam[k]]; m[3 * k + 1] = Y[sam[k]]; m[3 * k + 2] = Z[sam[k]]; }
+        solve3(m, div, N);
+        s_N[3 * tid] = N[0]; s_N[3 * tid + 1] = N[1]; s_N[3 * tid + 2] = N[2];
       }
-      double m[9], N[3];
-      const double div[3] = {-1.0, -1.0, -1.0};
-      for (int k = 0; k < 3; ++k) { m[3 * k] = X[sam[k]]; m[3 * k + 1] = Y[sam[k]]; m[3 * k + 2] = Z[sam[k]]; }
-      solve3(m, div, N);
-      const int no_i = classify(N, cur);
-      if (max_i < no_i) {
-        lstsq(cur, N);   // re-estimate plane and inliers (:437-440)
+      __syncthreads();
+      stamp(1);
+      {
+        double Nb[3 * kFitBatch];
+#pragma unroll
+        for (int k = 0; k < 3 * kFitBatch; ++k) Nb[k] = s_N[k];
+        int cnt[kFitBatch];
+#pragma unroll
+        for (int b = 0; b < kFitBatch; ++b) cnt[b] = 0;
+        for (int base = tid; base < n; base += 8 * T) {
+          double xv[8], yv[8], zv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { const int i = base + u * T, ic = i < n ? i : n - 1; xv[u] = X[ic]; yv[u] = Y[ic]; zv[u] = Z[ic]; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = base + u * T;
+            const double x = xv[u], y = yv[u], z = zv[u];
+            unsigned mask = 0;
+#pragma unroll
+            for (int b = 0; b < kFitBatch; ++b) {
+              const double dist = fabs(((x * Nb[3 * b] + y * Nb[3 * b + 1]) + z * Nb[3 * b + 2]) + 1.0);
+              const bool v = i < n && dist < a.rt;
+              mask |= v ? (1u << b) : 0u;
+              cnt[b] += v ? 1 : 0;
+            }
+            if (i < n) cur[i] = (uint8_t)mask;
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < kFitBatch; ++b) {
+          int c = cnt[b];
+          for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+          if (lane == 0) s_cnt[wave * kFitBatch + b] = c;
+        }
         __syncthreads();
-        const int cnt = classify(N, cur);
-        if (cnt > best) {
-          for (int i = tid; i < n; i += T) inl[i] = cur[i];
-          __syncthreads();
-          best = cnt;
-          max_i = no_i;
-          // nsamples(sum(inls), len, 3, conf) (:451-463)
-          double q = 1.0;
-          for (int k = 0; k < 3; ++k) q = q * ((double)(best - 3 + 1 + k) / (double)(n - 3 + 1 + k));
-          double c = 1.0;
-          if (!((1.0 - q) < 2.220446049250313e-16)) c = log(1.0 - 0.95) / log(1.0 - q);
-          if (c < 1.0) c = 1.0;
-          max_sam = c < max_sam ? c : max_sam;
+        if (tid < kFitBatch) {
+          int c = 0;
+          for (int w = 0; w < NW; ++w) c += s_cnt[w * kFitBatch + tid];
+          s_tot[tid] = c;
+        }
+        __syncthreads();
+      }
+      stamp(2);
+      // the reference's bookkeeping over the batch, trial by trial (:426-447)
+      for (int b = 0; b < kFitBatch && (double)no_sam < max_sam; ++b) {
+        ++no_sam;
+        const int no_i = s_tot[b];
+        if (max_i < no_i) {
+          double N[3];
+          stamp(3);
+          lstsq(cur, b, N);   // re-estimate plane and inliers (:437-440)
+          stamp(4);
+          const int cnt = classify(N, tmp);
+          stamp(5);
+          if (cnt > best) {
+            for (int i = tid; i < n; i += T) inl[i] = tmp[i];
+            __syncthreads();
+            best = cnt;
+            max_i = no_i;
+            // nsamples(sum(inls), len, 3, conf) (:451-463)
+            double q = 1.0;
+            for (int k = 0; k < 3; ++k) q = q * ((double)(best - 3 + 1 + k) / (double)(n - 3 + 1 + k));
+            double c = 1.0;
+            if (!((1.0 - q) < 2.220446049250313e-16)) c = log(1.0 - 0.95) / log(1.0 - q);
+            if (c < 1.0) c = 1.0;
+            max_sam = c < max_sam ? c : max_sam;
+          }
         }
       }
+      __syncthreads();   // (s_N, s_tot and cur are rewritten by the next batch)
+      stamp(3);
     }
     n_in = best;
     use_flags = true;
   }
   double N_[3] = {0, 0, 0};
   const bool fitted = n_in > 2;
-  if (fitted) lstsq(use_flags ? inl : nullptr, N_);
+  if (fitted) lstsq(use_flags ? inl : nullptr, 0, N_);
+  stamp(6);
   if (tid == 0) {
     a.ninl[s] = n_in;
     for (int k = 0; k < 3; ++k) a.planes[3 * s + k] = fitted ? N_[k] : 0.0;
@@ -340,6 +535,7 @@ __global__ __launch_bounds__(T) void segpln_fit_kernel(FitArgs a) {
       c[0] = v[0]; c[1] = v[1]; c[2] = v[2]; c[3] = v[3];
     }
   }
+  stamp(7);
 }
 
 __global__ void segpln_init_kernel(int64_t N, double *proposal) {
@@ -391,7 +587,7 @@ int stereo_segpln_wta(const double *images, int n_images, int H, int W, int C, c
 
 int stereo_segpln_planes(const double *wta, const int32_t *segments, int H, int W, double rt, uint64_t seed, int max_samples,
                          double *proposal, int S, double *planes, int32_t *inliers, char *err, size_t errcap) {
-  if (!wta || !segments || !proposal || H < 1 || W < 1 || S < 0 || max_samples < 1)
+  if (!wta || !segments || H < 1 || W < 1 || S < 0 || max_samples < 1 || (!proposal && !planes))
     return fail("stereo_segpln_planes: bad argument", err, errcap);
   const int64_t N = (int64_t)H * W;
   for (int64_t i = 0; i < N; ++i)
@@ -404,33 +600,98 @@ int stereo_segpln_planes(const double *wta, const int32_t *segments, int H, int 
     std::vector<int32_t> at(ptr.begin(), ptr.end() - 1);
     for (int64_t i = 0; i < N; ++i) idx[(size_t)at[segments[i]]++] = (int32_t)i;
     // (ptr[1 .. S + 1] delimit segments 1 .. S; the pixels of label 0 sit in front)
-    DevBuf<double> dw, px, py, pz, dprop, dpl;
-    DevBuf<int32_t> dptr, didx, dn;
-    DevBuf<uint8_t> cur, inl;
+    // (scratch kept from call to call on this thread: fourteen maps per object, a dozen allocations each otherwise)
+    struct Scratch {
+      DevBuf<double> dw, px, py, pz, dprop, dpl;
+      DevBuf<int32_t> dptr, didx, dn, dlist;
+      DevBuf<uint8_t> cur, tmp, inl;
+      PinnedBuf<double> hpl;     // planes and inlier counts come back through pinned memory: a small pageable copy that has
+      PinnedBuf<int32_t> hn;     // to wait for the kernels slept ~10 ms per call
+      size_t N = 0, S = 0;
+      int device = -1;
+      hipEvent_t done = nullptr;
+    };
+    static thread_local Scratch sc;
+    int device = 0;
+    STEREO_HIP_CHECK(hipGetDevice(&device));
+    if (sc.device != device) { sc.N = 0; sc.S = 0; sc.device = device; }   // (buffers of another device are released by the allocs below)
+    std::vector<int32_t> all;
+    if (sc.N < (size_t)N) {
+      sc.px.alloc(N); sc.py.alloc(N); sc.pz.alloc(N); sc.cur.alloc(N); sc.tmp.alloc(N); sc.inl.alloc(N); sc.dprop.alloc(4 * N);
+      sc.dw.alloc(N); sc.didx.alloc(N);
+      sc.N = (size_t)N;
+    }
+    if (sc.S < (size_t)S + 1) {
+      sc.dptr.alloc((size_t)S + 1); sc.dpl.alloc((size_t)3 * (S + 1)); sc.dn.alloc((size_t)S + 1); sc.dlist.alloc((size_t)S + 1);
+      sc.hpl.alloc((size_t)3 * (S + 1)); sc.hn.alloc((size_t)S + 1);
+      sc.S = (size_t)S + 1;
+    }
+    DevBuf<double> &dw = sc.dw, &px = sc.px, &py = sc.py, &pz = sc.pz, &dprop = sc.dprop, &dpl = sc.dpl;
+    DevBuf<int32_t> &dptr = sc.dptr, &didx = sc.didx, &dn = sc.dn, &dlist = sc.dlist;
     dw.upload(wta, N); dptr.upload(ptr.data() + 1, (size_t)S + 1); didx.upload(idx.data(), N);
-    px.alloc(N); py.alloc(N); pz.alloc(N); cur.alloc(N); inl.alloc(N); dprop.alloc(4 * N);
-    dpl.alloc((size_t)3 * std::max(S, 1)); dn.alloc((size_t)std::max(S, 1));
     hipLaunchKernelGGL(segpln_init_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, N, dprop.p);
     if (S > 0) {
-      // segments by size: a large one gets a workgroup of 1024 threads for its passes over the points, the others a wave
-      constexpr int kLargeSegment = 4096;
-      std::vector<int32_t> list[2];
-      for (int sg = 0; sg < S; ++sg) list[ptr[sg + 2] - ptr[sg + 1] > kLargeSegment ? 1 : 0].push_back(sg);
-      std::vector<int32_t> both(list[1]);
-      both.insert(both.end(), list[0].begin(), list[0].end());
-      DevBuf<int32_t> dlist;
-      dlist.upload(both.data(), both.size());
-      FitArgs a{dw.p, dptr.p, didx.p, H, W, S, max_samples, rt, seed, px.p, py.p, pz.p, cur.p, inl.p, dprop.p, dpl.p, dn.p, dlist.p};
-      if (!list[1].empty()) hipLaunchKernelGGL(segpln_fit_kernel<1024>, dim3((unsigned)list[1].size()), dim3(1024), 0, 0, a);
-      a.list = dlist.p + list[1].size();
+      // segments by size: the workgroup grows with the passes over the points it has to make
+      constexpr int kLargeSegment = 4096, kMediumSegment = 384;
+      std::vector<int32_t> list[3];
+      for (int sg = 0; sg < S; ++sg) {
+        const int len = ptr[sg + 2] - ptr[sg + 1];
+        list[len > kLargeSegment ? 2 : len > kMediumSegment ? 1 : 0].push_back(sg);
+      }
+      all = list[2];
+      all.insert(all.end(), list[1].begin(), list[1].end());
+      all.insert(all.end(), list[0].begin(), list[0].end());
+      dlist.upload(all.data(), all.size());
+      FitArgs a{dw.p, dptr.p, didx.p, H, W, S, max_samples, rt, seed, px.p, py.p, pz.p, sc.cur.p, sc.tmp.p, sc.inl.p, dprop.p, dpl.p, dn.p, dlist.p, nullptr};
+      static const bool timing = std::getenv("STEREO_HIP_SEGPLN_TIMING") != nullptr;   // (development: the three launches' device time)
+      hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+      if (timing) for (auto &e : ev) STEREO_HIP_CHECK(hipEventCreate(&e));
+      DevBuf<unsigned long long> dprof;
+      if (timing) { dprof.alloc(16); STEREO_HIP_CHECK(hipMemset(dprof.p, 0, 16 * sizeof(unsigned long long))); a.prof = dprof.p; }
+      if (timing) STEREO_HIP_CHECK(hipEventRecord(ev[0], 0));
+      if (!list[2].empty()) {
+        static const bool attr_set = [] {
+          return hipFuncSetAttribute((const void *)segpln_fit_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFitStageBytes) == hipSuccess;
+        }();
+        if (!attr_set) throw HipError{"stereo_segpln_planes: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"};
+        hipLaunchKernelGGL(segpln_fit_kernel<512>, dim3((unsigned)list[2].size()), dim3(512), kFitStageBytes, 0, a);
+      }
+      if (timing) STEREO_HIP_CHECK(hipEventRecord(ev[1], 0));
+      a.prof = nullptr;
+      a.list = dlist.p + list[2].size();
+      if (!list[1].empty()) hipLaunchKernelGGL(segpln_fit_kernel<256>, dim3((unsigned)list[1].size()), dim3(256), 0, 0, a);
+      if (timing) STEREO_HIP_CHECK(hipEventRecord(ev[2], 0));
+      a.list = dlist.p + list[2].size() + list[1].size();
       if (!list[0].empty()) hipLaunchKernelGGL(segpln_fit_kernel<64>, dim3((unsigned)list[0].size()), dim3(64), 0, 0, a);
       STEREO_HIP_CHECK(hipGetLastError());
-      STEREO_HIP_CHECK(hipDeviceSynchronize());   // (dlist lives until here)
+      if (timing) {
+        STEREO_HIP_CHECK(hipEventRecord(ev[3], 0));
+        STEREO_HIP_CHECK(hipEventSynchronize(ev[3]));
+        float t[3];
+        for (int k = 0; k < 3; ++k) STEREO_HIP_CHECK(hipEventElapsedTime(&t[k], ev[k], ev[k + 1]));
+        std::fprintf(stderr, "[stereo_hip segpln] S = %d: %zu large segments %.3f ms, %zu medium %.3f ms, %zu small %.3f ms\n", S, list[2].size(), t[0],
+                     list[1].size(), t[1], list[0].size(), t[2]);
+        unsigned long long pr[16];
+        STEREO_HIP_CHECK(hipMemcpy(pr, dprof.p, sizeof(pr), hipMemcpyDeviceToHost));
+        if (!list[2].empty())
+          std::fprintf(stderr, "[stereo_hip segpln]   first large segment, us (count): coordinates %.0f | draws %.0f (%llu) | batch passes %.0f (%llu) | bookkeeping %.0f | "
+                       "least squares %.0f (%llu) | re-classify + copy %.0f (%llu) | final fit %.0f | proposal %.0f\n", pr[0] / 100.0, pr[1] / 100.0, pr[9],
+                       pr[2] / 100.0, pr[10], pr[3] / 100.0, pr[4] / 100.0, pr[12], pr[5] / 100.0, pr[13], pr[6] / 100.0, pr[7] / 100.0);
+        for (auto &e : ev) (void)hipEventDestroy(e);
+      }
     }
     STEREO_HIP_CHECK(hipGetLastError());
-    STEREO_HIP_CHECK(hipMemcpy(proposal, dprop.p, sizeof(double) * 4 * N, hipMemcpyDeviceToHost));
-    if (planes && S > 0) STEREO_HIP_CHECK(hipMemcpy(planes, dpl.p, sizeof(double) * 3 * S, hipMemcpyDeviceToHost));
-    if (inliers && S > 0) STEREO_HIP_CHECK(hipMemcpy(inliers, dn.p, sizeof(int32_t) * S, hipMemcpyDeviceToHost));
+    if (proposal) STEREO_HIP_CHECK(hipMemcpy(proposal, dprop.p, sizeof(double) * 4 * N, hipMemcpyDeviceToHost));
+    if (S > 0) {
+      STEREO_HIP_CHECK(hipMemcpyAsync(sc.hpl.p, dpl.p, sizeof(double) * 3 * S, hipMemcpyDeviceToHost, 0));
+      STEREO_HIP_CHECK(hipMemcpyAsync(sc.hn.p, dn.p, sizeof(int32_t) * S, hipMemcpyDeviceToHost, 0));
+    }
+    if (!sc.done) STEREO_HIP_CHECK(hipEventCreateWithFlags(&sc.done, hipEventDisableTiming));
+    STEREO_HIP_CHECK(hipEventRecord(sc.done, 0));
+    STEREO_HIP_CHECK(hipEventSynchronize(sc.done));
+    if (planes && S > 0) std::memcpy(planes, sc.hpl.p, sizeof(double) * 3 * S);
+    if (inliers && S > 0) std::memcpy(inliers, sc.hn.p, sizeof(int32_t) * S);
+    // (the copies above wait for the kernels: the host vectors the uploads read from live until here)
   });
 }
 

@@ -138,20 +138,20 @@ def segpln_wta(images, P, disps, col_thresh=30.0, window=2, min_corr=0.07):
     return out
 
 
-def segpln_planes(wta, segments, seed=0, rt=0.1, max_samples=500):
+def segpln_planes(wta, segments, seed=0, rt=0.1, max_samples=500, want_proposal=True):
     """One SegPln proposal (dispmap_globalstereo.m:140-197) over a caller-supplied segmentation (labels 1 .. S,
     0 = no segment), LO-RANSAC + least-squares plane per segment on the device (stereo_segpln_planes).
-    -> (proposal 4 x N Fortran order, planes S x 3, inlier counts S)."""
+    -> (proposal 4 x N Fortran order -- None without want_proposal: the planes alone --, planes S x 3, inlier counts S)."""
     wta = _f(np.asarray(wta, np.float64))
     H, W = wta.shape
     seg = np.asfortranarray(np.asarray(segments).astype(np.int32))
     if seg.shape != (H, W):
         raise StereoHipError("segpln_planes: segments must have the image's shape")
     S = int(seg.max()) if seg.size else 0
-    prop = np.zeros((4, H * W), order="F")
+    prop = np.zeros((4, H * W), order="F") if want_proposal else None
     planes = np.zeros((3, max(S, 1)), order="F")
     ninl = np.zeros(max(S, 1), np.int32)
     _call(_lib.lib().stereo_segpln_planes, _p(wta), _p(seg, C.c_int32), C.c_int(H), C.c_int(W), C.c_double(float(rt)),
-          C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), C.c_int(int(max_samples)), _p(prop), C.c_int(S), _p(planes),
+          C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), C.c_int(int(max_samples)), _p(prop) if want_proposal else None, C.c_int(S), _p(planes),
           _p(ninl, C.c_int32))
     return prop, planes[:, :S].T.copy(), ninl[:S].copy()

@@ -15,3 +15,8 @@ for rep in range(2):
         t=time.perf_counter(); out = T.segpln_planes(wta, seg, seed=b); dt=(time.perf_counter()-t)*1e3; tot+=dt
         print("map %2d: S=%d largest=%d  %.1f ms" % (b, int(seg.max()), int(np.bincount(seg.ravel().astype(np.int64))[1:].max()), dt))
     print("total %.1f ms" % tot)
+maps = sg["segments"]
+t = time.perf_counter()
+for b in range(14):
+    T.segpln_planes(wta, maps[:, :, b], seed=b, want_proposal=False)
+print("planes only (no 4 x N array back to the host): total %.1f ms" % ((time.perf_counter() - t) * 1e3))
