@@ -254,7 +254,9 @@ size_t persistent_lds_bytes(int Kp) { return generic_lds_bytes(Kp); }
 // truncation window (rounded up to a multiple of four entries, at most eight: the runner keeps the window in registers).
 bool spec_active(const stereo_trws_plan *P) {
   // (and a handful of resident workgroups: the runner, the segment that commits, the segments in between)
-  return P->spec_allowed && P->grid_blocks >= 8 && P->fast && !P->wide && !P->fast2 && P->nstrips == 1 && P->kernel == 1 && P->certificate && P->pos != nullptr &&
+  // (trws_pipe_kernel, or trws_wide_kernel with an even label count: its vector loaders, trws_wspec.h)
+  const bool kernel_has_it = (P->fast && !P->wide && !P->fast2) || (P->wide && (P->K & 1) == 0 && P->mode == STEREO_TRWS_MESSAGES_EXACT);
+  return P->spec_allowed && P->grid_blocks >= 8 && kernel_has_it && P->nstrips == 1 && P->kernel == 1 && P->certificate && P->pos != nullptr &&
          P->pos_ascending && P->window <= 8 && P->uniform_step != 0 && P->spec_window;
 }
 
@@ -670,7 +672,8 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
     }
     {
       const TrwsGraph::Sweep::Spec &s0 = g.sweep[0].spec, &s1 = g.sweep[1].spec;
-      bool on = g.fast_ok && nstrips == 1 && s0.ok && s1.ok && s0.nseg == s1.nseg && s0.seg_len == s1.seg_len && K <= kWave;
+      bool on = g.fast_ok && nstrips == 1 && s0.ok && s1.ok && s0.nseg == s1.nseg && s0.seg_len == s1.seg_len &&
+                (K <= kWave || (K <= 256 && (K & 1) == 0 && kernel == 1));   // (trws_pipe_kernel; trws_wide_kernel with its vector loaders)
       if (const char *e = std::getenv("STEREO_HIP_TRWS_SPEC")) on = on && std::atoi(e) != 0;
       P->spec_allowed = on;
       if (on) {

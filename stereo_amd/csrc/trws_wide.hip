@@ -8,6 +8,7 @@
 #include "common.h"
 #include "trws_dev.h"
 #include "trws_launch.h"
+#include "trws_wspec.h"
 
 namespace stereo {
 namespace {
@@ -238,16 +239,111 @@ __device__ __forceinline__ void wide_collect(const double *xd, int *flag, int se
   }
 }
 
-template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE>
+// The commit of a speculative segment (SPEC instantiation below; the protocol is trws_spec.h's spec_commit): called by all
+// waves behind the barrier that ended the segment's last visit.  The segment in front commits first (its flag); then what
+// this segment started from is compared, bit for bit, with what that segment's last node really handed over: equal ->
+// the nodes' flags go up; different -> the overwritten rows are put back and the caller walks the visits again from the
+// real rows.  Returns 0 committed, 1 walk again (ctl[3] set), 2 gave up.
+template <bool BACKWARD, bool PRIMAL, bool UPDATE>
+__device__ __attribute__((noinline)) int wide_spec_commit(const DevParams *pp_, int epoch_, int p0_, int p1_, int seg_, int compare_, int ctl_off_) {
+  extern __shared__ __attribute__((aligned(16))) double wc_lds[];
+  const DevParams &p = *pp_;
+  const int epoch = epoch_, p0 = p0_, p1 = p1_, seg = seg_, compare = compare_;
+  constexpr int D = BACKWARD ? 1 : 0;
+  constexpr int DW = TrwsGraph::kDescWords;
+  const int32_t *desc = p.desc[D];
+  int *ctl = (int *)wc_lds + ctl_off_;   // [1] abort, [3] walk again, [4] (the first exchange flag, idle here) the verdict
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  const int K = p.K;
+  if (compare) {
+    if (wave == 0) {
+      int differ = 0;
+      if (!wait_flag(p, p.N + p.spec_nseg + seg, epoch, -2)) { if (lane == 0) ctl[1] = 1; }
+      else {
+        const int w = desc[(size_t)p0 * DW + lane];
+        const int f = WRLI(w, 2);
+        const int nout = f & 15, ntot = nout + ((f >> 4) & 15);
+        for (int j = nout; j < ntot; ++j) {
+          if (__builtin_amdgcn_readlane(w, 12 + j) < 0) continue;
+          if (UPDATE) {
+            const size_t ea = ((size_t)seg * 8 + j) * K, eb = (size_t)__builtin_amdgcn_readlane(w, 4 + j) * K;
+            for (int c = 0; c < 4; ++c) {
+              const int kk = c * kWave + lane, kc = kk < K ? kk : K - 1;
+              const double a = ld_sc1(p.spec_rows + ea + kc), b = ld_sc1(p.msg + eb + kc);
+              differ |= UNI(__double_as_longlong(a) != __double_as_longlong(b)) ? 1 : 0;
+            }
+          }
+          if (PRIMAL) differ |= ld_sc1(p.spec_x + seg) != ld_sc1(p.x + __builtin_amdgcn_readlane(w, 32 + j)) ? 1 : 0;
+        }
+      }
+      if (lane == 0) ctl[4] = differ;
+    }
+    __syncthreads();
+    const int differ = __builtin_amdgcn_readfirstlane(ctl[4]);
+    const int gave_up = __builtin_amdgcn_readfirstlane(ctl[1]);
+    __syncthreads();
+    if (tid == 0) ctl[4] = 0;
+    if (gave_up) return 2;
+    if (differ) {
+      if (UPDATE) {
+        for (int pos = p0 + wave; pos < p1; pos += kWideWaves) {
+          const int w = desc[(size_t)pos * DW + lane];
+          const int nout = WRLI(w, 2) & 15;
+          for (int j = 0; j < nout && j < 4; ++j) {
+            const size_t em = (size_t)__builtin_amdgcn_readlane(w, 4 + j) * K, eu = ((size_t)(seg * p.spec_max_len + (pos - p0)) * 4 + j) * K;
+            for (int c = 0; c < 4; ++c) {
+              const int kk = c * kWave + lane;
+              if (kk < K) st_sc1(p.msg + em + kk, ld_sc1(p.spec_undo + eu + kk));
+            }
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");   // (the second walk's plain loads must not find this CU's L1 holding anything of the first)
+      }
+      if (tid == 0) { ctl[3] = 1; if (p.spec_stat) atomicAdd(p.spec_stat, 1ull); }
+      __syncthreads();
+      return 1;
+    }
+  }
+  if (wave == 0) {
+    // the segment behind first (the commits are a serial chain), then the nodes' own flags
+    if (seg + 1 < p.spec_nseg && lane == 0) st_sc1(p.done + p.N + p.spec_nseg + seg + 1, epoch);
+    for (int pos = p0 + lane; pos < p1; pos += kWave) st_sc1(p.done + desc[(size_t)pos * DW + 1], epoch);
+    if (lane == 0 && p.spec_stat) atomicAdd(p.spec_stat + 1, 1ull);
+  }
+  return 0;
+}
+
+// SPEC: the instantiation that knows the speculative schedule of the long serial run (trws_wspec.h; even K, linear kernel,
+// uniformly spaced positions): a kernel of its own, launched only when a plan's sweeps use it.
+template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE, bool SPEC = false>
 __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
+  static_assert(!SPEC || KERNEL == 1, "the speculative schedule exists for the linear kernel");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const WidePtrs L = wide_carve(lds);
-  const int K = p.K;
-  const int C = (K + kWave - 1) / kWave;  // 64-label chunks
-  const double inf = __builtin_huge_val();
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
   constexpr int D = BACKWARD ? 1 : 0;
+  // The runner of the speculative schedule holds ticket 0 of either direction; the workgroup that draws it serves it HERE,
+  // before anything of the visit loops exists: its LDS overlays theirs, and nothing is live across the call.
+  bool have_ticket = false;
+  int first_ticket = 0;
+  if (SPEC) {
+    int *ent = (int *)lds;
+    if (tid == 0) {
+      const int t_ = atomicAdd(p.ticket, 1);
+      ent[0] = t_ < p.ntickets[D] ? (p.run_order[D] ? p.run_order[D][t_] : t_) : p.nruns[D];
+    }
+    __syncthreads();
+    first_ticket = __builtin_amdgcn_readfirstlane(ent[0]);
+    __syncthreads();
+    if (first_ticket == -1) wide_chain_runner<BACKWARD, PRIMAL, UPDATE>(p.self, epoch);
+    else have_ticket = true;
+  }
+  const int K = p.K;
+  const int C = (K + kWave - 1) / kWave;  // 64-label chunks
+  const double inf = __builtin_huge_val();
   constexpr int DW = TrwsGraph::kDescWords;
   const int32_t *desc = p.desc[D];
   for (int k = tid; k < kWS; k += kWideThreads) L.pos[k] = k < K ? p.pos[k] : inf;
@@ -255,7 +351,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
   // bit for bit): the min-plus source table then holds h only and alpha |d step| is formed once per d
   const double ustep = p.uniform_step;
   const bool uniform = ustep != 0;
-  if (tid == 0) { L.ctl[1] = 0; L.ctl[2] = 0; }
+  if (tid == 0) { L.ctl[0] = first_ticket; L.ctl[1] = 0; L.ctl[2] = 0; L.ctl[3] = 0; }
   if (tid < kWideCompute) L.xflag[tid] = 0;
   for (int k = tid; k < kWS; k += kWideThreads) L.zrow[k] = 0.0;
 #define WPOS(c) (L.pos[(c) * kWave + lane])        // this lane's four label positions (+inf beyond K)
@@ -268,12 +364,24 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
   __syncthreads();
 
   for (;;) {
-    if (tid == 0) { const int t_ = atomicAdd(p.ticket, 1); L.ctl[0] = t_ < p.ntickets[D] ? (p.run_order[D] ? p.run_order[D][t_] : t_) : p.nruns[D]; }
+    // (ctl[3]: the workgroup walks the speculative segment it holds a second time -- no new ticket)
+    if (tid == 0 && !(SPEC && (L.ctl[3] || have_ticket))) { const int t_ = atomicAdd(p.ticket, 1); L.ctl[0] = t_ < p.ntickets[D] ? (p.run_order[D] ? p.run_order[D][t_] : t_) : p.nruns[D]; }
+    have_ticket = false;
     __syncthreads();
     const int run = __builtin_amdgcn_readfirstlane(L.ctl[0]);
+    const int second_walk = SPEC ? __builtin_amdgcn_readfirstlane(L.ctl[3]) : 0;
+    // (the twins' exchange flags show schedule positions: a second walk visits the same positions, see trws_pipe.hip)
+    if (SPEC && tid < kWideCompute) L.xflag[tid] = 0;
     __syncthreads();
+    if (SPEC && tid == 0) L.ctl[3] = 0;
     if (run >= p.nruns[D]) break;
+    if (SPEC && run < 0) continue;   // (the runner's ticket is ticket 0: drawn and served above)
     const int p0 = p.run_ptr[D][run], p1 = p.run_ptr[D][run + 1];
+    // a segment of the speculative schedule: its first visit takes what the node in front hands over from the runner's
+    // rows, its completion flags wait for the commit below the visit loops
+    const int seg = (SPEC && p.spec_kind[D]) ? __builtin_amdgcn_readfirstlane(p.spec_kind[D][run]) - 1 : -1;
+    const bool spec_in = SPEC && seg > 0 && !second_walk;
+    (void)spec_in;
     const bool wprof = WIDE_PROF(p) && (p.prof_run < 0 || run == p.prof_run);  // STEREO_HIP_TRWS_PROF_RUN: one run only
     (void)wprof;
     if (p.timeline && tid == 0) p.timeline[((size_t)D * p.tl_stride + run) * 2] = wall_clock64();
@@ -884,7 +992,23 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           const int w = w1;
           const NodeDesc nx = decode_desc(w);
           int *stni = (int *)(stn + kWStI);
-          stni[lane] = w;
+          // (first visit of a speculative segment: the rows of the node in front come from the runner, behind the
+          //  segment's flag -- to everybody else in the workgroup they look like rows of another run)
+          const bool sfirst = SPEC && seg > 0 && pos + 1 == p0;
+          stni[lane] = (sfirst && lane >= 12 && lane < 20 && w >= 0) ? -1 : w;
+          if (SPEC && UPDATE && seg >= 0 && !second_walk) {
+            // a speculative segment keeps the rows its visits overwrite: a second walk starts from them
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (j < nx.nout) {
+                typedef double wide_v2d_ __attribute__((ext_vector_type(2)));
+                double *ub = p.spec_undo + ((size_t)(seg * p.spec_max_len + (pos + 1 - p0)) * 4 + j) * K + 2 * lane;
+                const wide_v2d_ lo_ = __builtin_bit_cast(wide_v2d_, rm[j][0]), hi_ = __builtin_bit_cast(wide_v2d_, rm[j][1]);
+                if (ok0) { st_sc1(ub, lo_.x); st_sc1(ub + 1, lo_.y); }
+                if (ok1) { st_sc1(ub + 2 * kWave, hi_.x); st_sc1(ub + 2 * kWave + 1, hi_.y); }
+              }
+            }
+          }
           {
             // where the compute waves find the node's message rows at visit pos + 1 (offsets into the
             // workgroup's LDS, in doubles): a message handed over inside the run sits in the ring of
@@ -893,7 +1017,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
             int sl = -1;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-              if (lane == j) sl = j >= nx.nout ? nx.slot[j] : -1;
+              if (lane == j) sl = (j >= nx.nout && !sfirst) ? nx.slot[j] : -1;
             const int hb1n = ((pos % 3) + 3) % 3, hb2n = (((pos - 1) % 3) + 3) % 3;  // hprev / hprev2 of visit pos + 1
             const int row = sl >= 8 ? (int)(L.hand - lds) + hb2n * 8 * kWS + (sl - 8) * kWS
                           : sl >= 0 ? (int)(L.hand - lds) + hb1n * 8 * kWS + sl * kWS
@@ -1032,7 +1156,10 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
         wide_v2d pr_; pr_.x = lo_; pr_.y = hi_;                                                           \
         DST = __builtin_bit_cast(wide_v4i, pr_);                                                          \
       } while (0)
-#define WIDE_REQUEST_FOREIGN(W)                                                                           \
+// (SF: the first node of a speculative segment -- the rows and the label of the node in front (slots >= 0) are the
+//  runner's, behind the segment's flag; a second walk takes them from the messages themselves: the segment in front has
+//  committed)
+#define WIDE_REQUEST_FOREIGN(W, SF)                                                                       \
       do {                                                                                                \
         const NodeDesc rq = decode_desc(W);                                                               \
         const int rtot = rq.nout + rq.nin;                                                                \
@@ -1041,16 +1168,19 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                   \
             if (lane == j) { xn = rq.xn[j]; sl = rq.slot[j]; }                                            \
         }                                                                                                 \
+        if (SPEC && (SF) && !wait_flag(p, p.N + seg, epoch, -2)) { if (lane == 0) L.ctl[1] = 1; }         \
         wait_for_dependencies(p, rq.ndep, rq.dep[0], rq.dep[1], rq.dep[2], rq.dep[3], rq.rank, epoch, lane, L.ctl + 1);                                             \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
-          if (UPDATE && j >= rq.nout && j < rtot && rq.slot[j] < 0) {                                     \
-            const double *mb = p.msg + (size_t)rq.e[j] * K + 2 * lane;                                    \
+          if (UPDATE && j >= rq.nout && j < rtot && (rq.slot[j] < 0 || (SPEC && (SF)))) {                 \
+            const double *mb = (SPEC && (SF) && spec_in && rq.slot[j] >= 0) ? p.spec_rows + ((size_t)seg * 8 + j) * K + 2 * lane \
+                                                                            : p.msg + (size_t)rq.e[j] * K + 2 * lane;            \
             if (ok0) WIDE_LOAD16_SC1(rb[j][0], mb, 0);                                                    \
             if (ok1) WIDE_LOAD16_SC1(rb[j][1], mb, 1024);                                                 \
           }                                                                                               \
         }                                                                                                 \
         pxv = 0;                                                                                          \
-        if (PRIMAL && lane < rtot && lane >= rq.nout && sl < 0) pxv = ld_sc1(p.x + xn);                   \
+        if (PRIMAL && lane < rtot && lane >= rq.nout && (sl < 0 || (SPEC && (SF))))                       \
+          pxv = ld_sc1((SPEC && (SF) && spec_in && sl >= 0) ? p.spec_x + seg : p.x + xn);                 \
       } while (0)
 #ifdef STEREO_HIP_MESSAGE_PROFILE
       unsigned long long lbacc[6] = {0, 0, 0, 0, 0, 0};
@@ -1065,13 +1195,14 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
         long long lbm = (long long)__builtin_readcyclecounter();
 #endif
         if (pos + 1 >= p0 && pos + 1 < p1) {
-          if (!parked) { WIDE_REQUEST_FOREIGN(w1); LBSTAMP(0); LBCOUNT(4); }
+          const bool sfirst = SPEC && seg > 0 && pos + 1 == p0;
+          if (!parked) { WIDE_REQUEST_FOREIGN(w1, sfirst); LBSTAMP(0); LBCOUNT(4); }
           const NodeDesc nx = decode_desc(w1);
           int *stni = (int *)(stn + kWStI);
           const int ntot = nx.nout + nx.nin;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            if (UPDATE && j >= nx.nout && j < ntot && nx.slot[j] < 0) {
+            if (UPDATE && j >= nx.nout && j < ntot && (nx.slot[j] < 0 || sfirst)) {
               if (ok0) *(wide_v4i *)(stn + kWS + j * kWS + 2 * lane) = rb[j][0];
               if (ok1) *(wide_v4i *)(stn + kWS + j * kWS + 2 * kWave + 2 * lane) = rb[j][1];
             }
@@ -1085,7 +1216,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           if (pos + 4 < p1) w4 = desc[(size_t)(pos + 4) * DW + lane];
           w1 = w2; w2 = w3; w3 = w4;
           parked = pos + 2 < p1 && ((__builtin_amdgcn_readlane(w1, 2) >> 12) & 1) != 0;
-          if (parked) { WIDE_REQUEST_FOREIGN(w1); LBSTAMP(2); LBCOUNT(5); }
+          if (parked) { WIDE_REQUEST_FOREIGN(w1, false); LBSTAMP(2); LBCOUNT(5); }
         }
       WIDE_VISITS_END
 #ifdef STEREO_HIP_MESSAGE_PROFILE
@@ -1166,7 +1297,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0) {
-            st_sc1(p.done + pd.rank, epoch);
+            if (!(SPEC && seg >= 0)) st_sc1(p.done + pd.rank, epoch);   // (a speculative segment raises its flags when it commits)
             if (pd.remote & (1 << 16)) st_sc1(p.peer_done0 + pd.pn[0], epoch);
             if (pd.remote & (1 << 17)) st_sc1(p.peer_done1 + pd.pn[1], epoch);
           }
@@ -1242,6 +1373,11 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
 #undef WIDE_VISITS_BEGIN
 #undef WIDE_VISITS_END
 #undef WIDE_VISITS_END_
+    if (SPEC && seg >= 0) {
+      const int verdict = wide_spec_commit<BACKWARD, PRIMAL, UPDATE>(p.self, epoch, p0, p1, seg, spec_in ? 1 : 0, (int)(L.ctl - (int *)lds));
+      if (verdict == 2) { if (tid == 0) st_sc1(p.abort_flag, 1); return; }
+      if (verdict == 1) continue;   // (ctl[3] is set: the same run once more)
+    }
     if (p.timeline && tid == 0) p.timeline[((size_t)D * p.tl_stride + run) * 2 + 1] = wall_clock64();
   }
 #undef WSTAMP
@@ -1262,6 +1398,10 @@ template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE>
 __global__ __launch_bounds__(kWideThreads) void trws_wide_kernel(DevParams p, int epoch) {
   wide_body<KERNEL, BACKWARD, PRIMAL, UPDATE>(p, epoch);
 }
+template <bool BACKWARD, bool PRIMAL, bool UPDATE>
+__global__ __launch_bounds__(kWideThreads) void trws_wide_spec_kernel(DevParams p, int epoch) {
+  wide_body<1, BACKWARD, PRIMAL, UPDATE, true>(p, epoch);
+}
 template <int KERNEL, bool BACKWARD, bool PRIMAL, bool UPDATE>
 __global__ __launch_bounds__(kWideThreads) void trws_wide_group_kernel(GroupArgs ga, int epoch) {
   wide_body<KERNEL, BACKWARD, PRIMAL, UPDATE>(ga.pp[group_strip(ga)], epoch);
@@ -1271,9 +1411,18 @@ __global__ __launch_bounds__(kWideThreads) void trws_wide_group_kernel(GroupArgs
 }  // namespace
 
 size_t wide_lds_bytes() { return sizeof(double) * kWideLdsDoubles; }
+// (the runner of the speculative schedule overlays the visit loops' LDS and needs a little more)
+static_assert(kWrDoubles * 8 <= 160 * 1024, "wide runner LDS");
+size_t wide_spec_lds_bytes() { return sizeof(double) * (size_t)(kWideLdsDoubles > kWrDoubles ? kWideLdsDoubles : kWrDoubles); }
 
 void wide_set_attributes() {
   const int wlds = (int)wide_lds_bytes();
+  {
+    const int slds = (int)wide_spec_lds_bytes();
+#define SET_S(BW, PR, UP) STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)trws_wide_spec_kernel<BW, PR, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, slds))
+    SET_S(false, false, true); SET_S(true, false, true); SET_S(false, true, true); SET_S(false, true, false);
+#undef SET_S
+  }
 #define SET_W(NAME)                                                                                                             \
   STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<1, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wlds)); \
   STEREO_HIP_CHECK(hipFuncSetAttribute((const void *)NAME<1, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wlds));  \
@@ -1310,7 +1459,22 @@ void wide_set_attributes() {
   }                                                                                                                \
   STEREO_HIP_CHECK(hipGetLastError());
 
-void launch_wide(int kernel, int what, int blocks, hipStream_t s, const DevParams &p, int epoch) { WIDE_SWITCH(trws_wide_kernel, p) }
+void launch_wide(int kernel, int what, int blocks, hipStream_t s, const DevParams &p, int epoch) {
+  if (p.spec_kind[0] != nullptr && p.spec_kind[1] != nullptr && kernel == 1) {
+    // the speculative schedule's kernel
+    const size_t slds = wide_spec_lds_bytes();
+    const dim3 grid(blocks), block(kWideThreads);
+    switch (what) {
+      case 0: hipLaunchKernelGGL((trws_wide_spec_kernel<false, false, true>), grid, block, slds, s, p, epoch); break;
+      case 1: hipLaunchKernelGGL((trws_wide_spec_kernel<true, false, true>), grid, block, slds, s, p, epoch); break;
+      case 2: hipLaunchKernelGGL((trws_wide_spec_kernel<false, true, true>), grid, block, slds, s, p, epoch); break;
+      default: hipLaunchKernelGGL((trws_wide_spec_kernel<false, true, false>), grid, block, slds, s, p, epoch); break;
+    }
+    STEREO_HIP_CHECK(hipGetLastError());
+    return;
+  }
+  WIDE_SWITCH(trws_wide_kernel, p)
+}
 void launch_wide_group(int kernel, int what, int blocks, hipStream_t s, const GroupArgs &ga, int epoch) { WIDE_SWITCH(trws_wide_group_kernel, ga) }
 #undef WIDE_SWITCH
 
