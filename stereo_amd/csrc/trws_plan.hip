@@ -687,8 +687,8 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
         P->d_spec_rows.alloc((size_t)s0.nseg * 8 * K);
         P->d_spec_undo.alloc((size_t)s0.nseg * ml * 4 * K);
         P->d_spec_x.alloc(s0.nseg);
-        P->d_spec_stat.alloc(16);
-        STEREO_HIP_CHECK(hipMemset(P->d_spec_stat.p, 0, 16 * sizeof(unsigned long long)));
+        P->d_spec_stat.alloc(32);
+        STEREO_HIP_CHECK(hipMemset(P->d_spec_stat.p, 0, 32 * sizeof(unsigned long long)));
         STEREO_HIP_CHECK(hipMemset(P->d_spec_rows.p, 0, sizeof(double) * (size_t)s0.nseg * 8 * K));
         STEREO_HIP_CHECK(hipMemset(P->d_spec_x.p, 0, sizeof(int32_t) * s0.nseg));
       }
@@ -1359,7 +1359,7 @@ int stereo_trws_plan_spec_stats(stereo_trws_plan *P, int64_t out[4]) {
   if (!P || !out) return 1;
   out[0] = spec_active(P) ? 1 : 0; out[1] = out[2] = out[3] = 0;
   if (P->d_spec_stat.p) {
-    unsigned long long v[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long v[32] = {0};
     if (hipMemcpy(v, P->d_spec_stat.p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 1;
     if (std::getenv("STEREO_HIP_TRWS_TIMELINE"))
       std::fprintf(stderr, "[stereo_hip spec] last sweeps, roles done after (us): forward messages %.0f labels %.0f last loader %.0f publisher %.0f | backward messages %.0f "
@@ -1369,6 +1369,10 @@ int stereo_trws_plan_spec_stats(stereo_trws_plan *P, int64_t out[4]) {
                            "H, table, min H %.0f | window + row %.0f | publish, turn %.0f\n", (double)v[13] / v[2], (double)v[8] / v[2], (double)v[9] / v[2],
                    (double)v[10] / v[2], (double)v[11] / v[2], (double)v[12] / v[2]);
     out[1] = (int64_t)v[0]; out[2] = (int64_t)v[1]; out[3] = (int64_t)v[2];
+    if (std::getenv("STEREO_HIP_TRWS_TIMELINE") && (v[16] || v[17]))   // (development, wide runner: where its roles wait, us in all)
+      std::fprintf(stderr, "[stereo_hip spec] wide runner, us in all launches: meetings of the message waves forward %.0f backward %.0f | label wave waiting for its node %.0f | "
+                           "loader 0: until the slot wait forward %.0f backward %.0f, slot wait %.0f / %.0f, staging %.0f / %.0f\n", v[16] / 100.0, v[17] / 100.0, v[18] / 100.0,
+                   v[21] / 100.0, v[22] / 100.0, v[19] / 100.0, v[20] / 100.0, v[23] / 100.0, v[24] / 100.0);
     if (std::getenv("STEREO_HIP_TRWS_TIMELINE"))   // (development: how often, and for how long, the message recurrence found its next node not staged yet)
       std::fprintf(stderr, "[stereo_hip spec] runner visits %llu; the message recurrence found its node not staged yet: forward sweeps %llu times, %.1f us in all; "
                            "backward %llu times, %.1f us (incl. the wait for the rows in front of the chain)\n", v[2], v[3], (double)v[4] / 100.0, v[5], (double)v[6] / 100.0);

@@ -38,7 +38,8 @@ constexpr int kWrTabDoubles = kWrK + 32;
 constexpr int kWrPm = kWrTab + 2 * kWrTabDoubles;   // partial minima of the four waves: [2 tables][4] for min H, [2][4] for min Di
 constexpr int kWrPub = kWrPm + 16;                  // 2 x (2 rows): what the publisher stores
 constexpr int kWrWords = kWrPub + 4 * kWrK;         // 64 ints
-constexpr int kWrDoubles = kWrWords + 32 + 32;      // (+ 64 words where lanes that have nothing to say store)
+constexpr int kWrPos = kWrWords + 32 + 32;          // (behind the words and the 64 words where lanes that have nothing to say store) the positions
+constexpr int kWrDoubles = kWrPos + kWrK;
 // words: labels consumed 13 | label published x 2: 16 | slots freed 18 | label x 2: 20 | node x 2: 22 | row kinds x 2: 24 |
 // rows published, per wave, x 2: 32-39 | arrival of the four message waves: 40-43 | nodes consumed by message wave w: 48-51
 constexpr int kWwConsP = 13, kWwPubP = 16, kWwFree = 18, kWwLabel = 20, kWwNode = 22, kWwKinds = 24, kWwPubM = 32, kWwArrive = 40, kWwConsM = 48;
@@ -47,8 +48,14 @@ constexpr int kWwConsP = 13, kWwPubP = 16, kWwFree = 18, kWwLabel = 20, kWwNode 
 // doubles 8-15: alpha x 2, gamma, alpha of the incoming rows x 4
 constexpr int kWsNt = 0, kWsKinds = 1, kWsNmsg = 2, kWsCut = 5, kWsPubKinds = 6, kWsNout = 7, kWsNin = 8, kWsSrc = 9, kWsMd = 13, kWsNode = 14, kWsTag = 15;
 
-__device__ __forceinline__ int wr_load(const int *w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void wr_store(int *w, int v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// (words of the runner's LDS, addressed AS LDS: through a generic pointer these become flat accesses, whose completion is
+//  counted together with the global loads -- a loader that polls a word would wait for the rows it has just requested
+//  for its next node; the fences are LDS-only for the same reason)
+typedef __attribute__((address_space(3))) int wr_lds_int;
+__device__ __forceinline__ int wr_load(const int *w) { return __hip_atomic_load((const wr_lds_int *)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void wr_store(int *w, int v) { __hip_atomic_store((wr_lds_int *)w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#define WR_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local")
+#define WR_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
 
 template <class T>
 __device__ __forceinline__ T wr_uniform(T v) {
@@ -90,16 +97,33 @@ __device__ __attribute__((noinline)) bool wr_wait(const int *word, int want, int
     if (t0 == 0) { t0 = now | 1; continue; }
     if (now - t0 > 4 * spin_ticks) { wr_store(abort_word, 1); return false; }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  WR_ACQUIRE();
   return true;
 }
-// ... until all four of words[0 .. 3] >= want
+// (the same, inlined: a call inside a loader's turn makes it spill the rows it holds in registers around the call)
+__device__ __forceinline__ bool wr_wait_i(const int *word, int want, int *abort_word, int32_t *abort_flag, long long spin_ticks) {
+  int spins = 0;
+  long long t0 = 0;
+  while (wr_load(word) < want) {
+    spins = (spins + 1) & 4095;
+    if (spins != 0) continue;
+    if (wr_load(abort_word) || ld_sc1(abort_flag)) return false;
+    const long long now = (long long)wall_clock64();
+    if (t0 == 0) { t0 = now | 1; continue; }
+    if (now - t0 > 4 * spin_ticks) { wr_store(abort_word, 1); return false; }
+  }
+  WR_ACQUIRE();
+  return true;
+}
+// ... until all four of words[0 .. 3] >= want (16-byte aligned: the four words come with ONE LDS read per look)
 __device__ __forceinline__ bool wr_wait4(const int *words, int want, int *abort_word, int32_t *abort_flag, long long spin_ticks) {
+  typedef int wr_v4i __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) const volatile wr_v4i wr_lds_v4i;
   int spins = 0;
   long long t0 = 0;
   for (;;) {
-    const int a = wr_load(words), b = wr_load(words + 1), c = wr_load(words + 2), d = wr_load(words + 3);
-    const int lo = min(min(a, b), min(c, d));
+    const wr_v4i v = *(wr_lds_v4i *)words;
+    const int lo = min(min(v.x, v.y), min(v.z, v.w));
     if (lo >= want) break;
     spins = (spins + 1) & 4095;
     if (spins != 0) continue;
@@ -108,7 +132,7 @@ __device__ __forceinline__ bool wr_wait4(const int *words, int want, int *abort_
     if (t0 == 0) { t0 = now | 1; continue; }
     if (now - t0 > 4 * spin_ticks) { wr_store(abort_word, 1); return false; }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  WR_ACQUIRE();
   return true;
 }
 
@@ -129,13 +153,17 @@ struct WrArgsM {
   double lambda, step;
   int32_t *abort_flag;
   long long spin_ticks;
+  unsigned long long *stat;
 };
 
 // The four waves meet: everybody's table entries and partial minimum are written, then read.  `seq` counts the meetings.
-__device__ __forceinline__ bool wr_meet(int *rw, int wv, int lane, int seq, int *abort_word, const WrArgsM &a) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+__device__ __forceinline__ bool wr_meet(int *rw, int wv, int lane, int seq, int *abort_word, const WrArgsM &a, int dir) {
+  const long long t0_ = a.stat ? (long long)wall_clock64() : 0;
+  WR_RELEASE();
   if (lane == 0) wr_store(rw + kWwArrive + wv, seq);
-  return wr_wait4(rw + kWwArrive, seq, abort_word, a.abort_flag, a.spin_ticks);
+  const bool ok = wr_wait4(rw + kWwArrive, seq, abort_word, a.abort_flag, a.spin_ticks);
+  if (a.stat && wv == 0 && lane == 0) atomicAdd(a.stat + 16 + dir, (unsigned long long)((long long)wall_clock64() - t0_));
+  return ok;
 }
 
 template <bool BACKWARD, int G>
@@ -156,8 +184,10 @@ __device__ __forceinline__ void wr_messages_g(const WrArgsM &a, double *rb, int 
   int slot_off = 0, seq = 0, tsel = 0, nsel = 0;
   for (int i = a.c0; i < a.c1; ++i) {
     if (__builtin_amdgcn_readlane(cur.sw, kWsTag) != i + 1) {   // (not there yet when it was asked for)
+      const long long t0_ = (long long)wall_clock64();
       if (!__builtin_amdgcn_readfirstlane((int)wr_wait((const int *)(rb + slot_off + kWrSc) + kWsTag, i + 1, abort_word, a.abort_flag, a.spin_ticks))) return;
       wr_request_m(rb + slot_off, lane, k, cur);
+      if (a.stat && wv == 0 && lane == 0) { atomicAdd(a.stat + 3 + 2 * (BACKWARD ? 1 : 0), 1ull); atomicAdd(a.stat + 4 + 2 * (BACKWARD ? 1 : 0), (unsigned long long)((long long)wall_clock64() - t0_)); }
     }
     const int sw = cur.sw;
     const int key = __builtin_amdgcn_readlane(sw, kWsKinds), nmsg = __builtin_amdgcn_readlane(sw, kWsNmsg), cut = __builtin_amdgcn_readlane(sw, kWsCut);
@@ -184,7 +214,7 @@ __device__ __forceinline__ void wr_messages_g(const WrArgsM &a, double *rb, int 
     if (BACKWARD) {   // minimize.cpp:79-83: the node's own lower-bound term leaves Di
       const double part = wave_min_dpp(act ? Di : inf);
       if (lane == 0) pm[8 + 4 * nsel + wv] = part;
-      if (!wr_meet(rw, wv, lane, ++seq, abort_word, a)) return;
+      if (!wr_meet(rw, wv, lane, ++seq, abort_word, a, BACKWARD ? 1 : 0)) return;
       Di -= min_raw(min_raw(pm[8 + 4 * nsel], pm[8 + 4 * nsel + 1]), min_raw(pm[8 + 4 * nsel + 2], pm[8 + 4 * nsel + 3]));
       nsel ^= 1;   // (two sets of partial minima in turn, like the tables: nobody writes what a wave one meeting behind still reads)
     }
@@ -204,7 +234,7 @@ __device__ __forceinline__ void wr_messages_g(const WrArgsM &a, double *rb, int 
           for (int d = 0; d < 4 * G; ++d) ad[d] = alpha * ((double)(d + 1) * a.step);
           alpha_have = alpha;
         }
-        if (!wr_meet(rw, wv, lane, ++seq, abort_word, a)) return;
+        if (!wr_meet(rw, wv, lane, ++seq, abort_word, a, BACKWARD ? 1 : 0)) return;
         const double hmin = min_raw(min_raw(pm[4 * tsel], pm[4 * tsel + 1]), min_raw(pm[4 * tsel + 2], pm[4 * tsel + 3]));
         const double vtrunc = hmin + alpha * a.lambda;
         double lo[4 * G], hi[4 * G];
@@ -227,7 +257,7 @@ __device__ __forceinline__ void wr_messages_g(const WrArgsM &a, double *rb, int 
       double *pb = rb + kWrPub + ps * 2 * kWrK;
       pb[k] = A0; pb[kWrK + k] = A1;
       if (wv == 0 && lane == 0) wr_store(rw + kWwKinds + ps, __builtin_amdgcn_readlane(sw, kWsPubKinds));
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      WR_RELEASE();
       if (lane == 0) wr_store(rw + kWwPubM + 4 * ps + wv, cut);
     }
     cur = nxt;
@@ -241,7 +271,7 @@ __device__ __attribute__((noinline)) void wr_messages(const DevParams *pp, int w
   WrArgsM a;
   a.K = wr_uniform(pp->K); a.c0 = wr_uniform(pp->spec_c0[D]); a.c1 = wr_uniform(pp->spec_c1[D]);
   a.lambda = wr_uniform(pp->lambda); a.step = wr_uniform(pp->uniform_step);
-  a.abort_flag = wr_uniform(pp->abort_flag); a.spin_ticks = wr_uniform(pp->spin_ticks);
+  a.abort_flag = wr_uniform(pp->abort_flag); a.spin_ticks = wr_uniform(pp->spin_ticks); a.stat = wr_uniform(pp->timeline) ? wr_uniform(pp->spec_stat) : nullptr;   // (development counters: with STEREO_HIP_TRWS_TIMELINE only)
   const int window = wr_uniform(pp->window);
   int *abort_word = (int *)(wr_lds + __builtin_amdgcn_readfirstlane(abort_off_));
   const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(wv_);
@@ -269,7 +299,11 @@ __device__ __attribute__((noinline)) void wr_labels(const DevParams *pp_, int ab
   int xprev = 0;
   for (int i = c0; i < c1; ++i) {
     const double *sl = rb + ((i - c0) % kWrSlots) * kWrSlotDoubles;
-    if (!wr_wait((const int *)(sl + kWrSc) + kWsTag, i + 1, abort_word, p.abort_flag, p.spin_ticks)) return;
+    {
+      const long long t0_ = (p.timeline && p.spec_stat) ? (long long)wall_clock64() : 0;
+      if (!wr_wait_i((const int *)(sl + kWrSc) + kWsTag, i + 1, abort_word, p.abort_flag, p.spin_ticks)) return;
+      if (p.timeline && p.spec_stat && lane == 0) atomicAdd(p.spec_stat + 18, (unsigned long long)((long long)wall_clock64() - t0_));
+    }
     const int sw = ((const int *)(sl + kWrSc))[lane & 15];
     const double sd = sl[kWrSc + 8 + (lane & 7)];
     const int nout = __builtin_amdgcn_readlane(sw, kWsNout), nin = __builtin_amdgcn_readlane(sw, kWsNin), md = __builtin_amdgcn_readlane(sw, kWsMd),
@@ -288,7 +322,7 @@ __device__ __attribute__((noinline)) void wr_labels(const DevParams *pp_, int ab
       if (j < nin) {
         const int src = __builtin_amdgcn_readlane(sw, kWsSrc + j);
         const int ks = src < 0 ? xprev : src;
-        const double pks = p.pos[ks];
+        const double pks = rb[kWrPos + ks];
         const double aj = readlane_f64(sd, 3 + j);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -320,7 +354,7 @@ __device__ __attribute__((noinline)) void wr_labels(const DevParams *pp_, int ab
       const int ps = cut & 1;
       if (!wr_wait(rw + kWwFree, cut - 2, abort_word, p.abort_flag, p.spin_ticks)) return;
       if (lane == 0) { rw[kWwLabel + ps] = xprev; rw[kWwNode + ps] = __builtin_amdgcn_readlane(sw, kWsNode); }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      WR_RELEASE();
       if (lane == 0) wr_store(rw + kWwPubP + ps, cut);
     }
   }
@@ -343,13 +377,50 @@ __device__ __attribute__((noinline)) void wr_loader(const DevParams *pp_, int ep
   int *rw = (int *)(rb + kWrWords);
   const int L = p.spec_len, nseg = p.spec_nseg;
   double *sl = rb + lw * kWrSlotDoubles;   // (six loaders, six slots: node i lives in slot i mod 6 = this wave's)
+  // The node's own data -- unary row and its (up to four) outgoing rows, which nobody writes before the segment that holds
+  // the node walks it -- is requested ONE TURN AHEAD (this wave's next node, six positions on) and waits in registers
+  // while the current node is staged: a loader's turn used to be one memory round trip longer than the six visits it has.
+  // (no load below is conditional on the lane: a label index beyond K reads label K - 1 again -- rows of such labels are
+  //  never looked at --, so that the requests of a node go out back to back instead of one exec-mask region each)
+  bool ok[4];
+  int lk[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { ok[c] = c * kWave + lane < K; lk[c] = ok[c] ? c * kWave + lane : K - 1; }
+  double theta_n[4] = {0, 0, 0, 0}, own_n[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) own_n[k][c] = 0;
+#define WR_REQUEST_OWN(W)                                                                                                        \
+  do {                                                                                                                         \
+    const int nout_ = WRLI((W), 2) & 15;                                                                                       \
+    const double *ua_ = p.unary + (size_t)((unsigned long long)(unsigned)WRLI((W), 0) * (unsigned long long)(unsigned)K);      \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) theta_n[c] = ua_[lk[c]];                                                     \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                                            \
+      if (k < nout_) {                                                                                                         \
+        const double *mb_ = p.msg + (size_t)((unsigned long long)(unsigned)WRLI((W), 4 + k) * (unsigned long long)(unsigned)K); \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) own_n[k][c] = mb_[lk[c]];                                                \
+      }                                                                                                                        \
+    }                                                                                                                          \
+  } while (0)
   int w2 = 0, wn2 = 0;
-  if (c0 + lw < c1) { w2 = desc[(size_t)(c0 + lw) * DW + lane]; wn2 = c0 + lw + 1 < c1 ? desc[(size_t)(c0 + lw + 1) * DW + lane] : 0; }
+  if (c0 + lw < c1) { w2 = desc[(size_t)(c0 + lw) * DW + lane]; wn2 = c0 + lw + 1 < c1 ? desc[(size_t)(c0 + lw + 1) * DW + lane] : 0; WR_REQUEST_OWN(w2); }
   for (int i = c0 + lw; i < c1; i += kWrLoaders) {
+    const long long tl0_ = (p.timeline && p.spec_stat && lw == 0) ? (long long)wall_clock64() : 0;
     const int w = w2, wn = wn2;
+    double theta[4], r[8][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      theta[c] = theta_n[c];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[k][c] = own_n[k][c];
+#pragma unroll
+      for (int k = 4; k < 8; ++k) r[k][c] = 0;
+    }
     if (i + kWrLoaders < c1) {
       w2 = desc[(size_t)(i + kWrLoaders) * DW + lane];
       wn2 = i + kWrLoaders + 1 < c1 ? desc[(size_t)(i + kWrLoaders + 1) * DW + lane] : 0;
+      WR_REQUEST_OWN(w2);
     }
     const int f = WRLI(w, 2), fn = WRLI(wn, 2);
     const int nout = f & 15, nin = (f >> 4) & 15, ndep = (f >> 8) & 15, md = (f >> 16) & 255, ntot = nout + nin;
@@ -388,19 +459,13 @@ __device__ __attribute__((noinline)) void wr_loader(const DevParams *pp_, int ep
     }
     // the node's own data (nobody writes it before the segment that holds the node walks it)
     const int fm = WRLI(w, kDescFetch) & 255;
-    bool ok[4];
-    double theta[4];
-    const double *ua = p.unary + (size_t)((unsigned long long)(unsigned)WRLI(w, 0) * (unsigned long long)(unsigned)K);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { ok[c] = c * kWave + lane < K; theta[c] = ok[c] ? ua[c * kWave + lane] : 0.0; }
     const double av = p.alpha[__shfl(w, 4 + j8, kWave)];
-    double r[8][4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 4; k < 8; ++k) {   // (own rows five to eight: no node of a cut run has them; fetched here for completeness)
+      if (k < nout) {
+        const double *mb = p.msg + (size_t)((unsigned long long)(unsigned)WRLI(w, 4 + k) * (unsigned long long)(unsigned)K);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        r[k][c] = 0;
-        if (k < nout && ok[c]) r[k][c] = *(p.msg + (size_t)((unsigned long long)(unsigned)WRLI(w, 4 + k) * (unsigned long long)(unsigned)K) + c * kWave + lane);
+        for (int c = 0; c < 4; ++c) r[k][c] = mb[lk[c]];
       }
     }
     // foreign dependencies (everything but the node in front), then their rows and labels
@@ -411,37 +476,60 @@ __device__ __attribute__((noinline)) void wr_loader(const DevParams *pp_, int ep
     for (int k = 0; k < 8; ++k) {
       if (k >= nout && k < ntot && ((fm >> k) & 1) && !((fr >> k) & 1)) {
         if (UPDATE) {
+          const double *mb = p.msg + (size_t)((unsigned long long)(unsigned)WRLI(w, 4 + k) * (unsigned long long)(unsigned)K);
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if (ok[c]) r[k][c] = ld_sc1(p.msg + (size_t)((unsigned long long)(unsigned)WRLI(w, 4 + k) * (unsigned long long)(unsigned)K) + c * kWave + lane);
+          for (int c = 0; c < 4; ++c) r[k][c] = ld_sc1(mb + lk[c]);
         }
         if (PRIMAL) { const int xv = ld_sc1(p.x + WRLI(w, 32 + k)); if (lane == k - nout) src = xv; }
       }
     }
     // the ring slot: all recurrences have taken the node that had it into their registers
     const int need = i - c0 - kWrSlots + 1;
+    const long long tl1_ = (p.timeline && p.spec_stat && lw == 0) ? (long long)wall_clock64() : 0;
     if (UPDATE && need > 0 && !wr_wait4(rw + kWwConsM, need, abort_word, p.abort_flag, p.spin_ticks)) return;
-    if (PRIMAL && need > 0 && !wr_wait(rw + kWwConsP, need, abort_word, p.abort_flag, p.spin_ticks)) return;
+    if (PRIMAL && need > 0 && !wr_wait_i(rw + kWwConsP, need, abort_word, p.abort_flag, p.spin_ticks)) return;
+    const long long tl2_ = (p.timeline && p.spec_stat && lw == 0) ? (long long)wall_clock64() : 0;
+    // (a row picked by a uniform index: one scalar branch tree per row instead of a select per candidate and chunk)
+#define WR_GET(KSEL, DST)                                                                         \
+    do {                                                                                          \
+      switch (KSEL) {                                                                             \
+        case 0: _Pragma("unroll") for (int c = 0; c < 4; ++c) DST[c] = r[0][c]; break;            \
+        case 1: _Pragma("unroll") for (int c = 0; c < 4; ++c) DST[c] = r[1][c]; break;            \
+        case 2: _Pragma("unroll") for (int c = 0; c < 4; ++c) DST[c] = r[2][c]; break;            \
+        case 3: _Pragma("unroll") for (int c = 0; c < 4; ++c) DST[c] = r[3][c]; break;            \
+        case 4: _Pragma("unroll") for (int c = 0; c < 4; ++c) DST[c] = r[4][c]; break;            \
+        case 5: _Pragma("unroll") for (int c = 0; c < 4; ++c) DST[c] = r[5][c]; break;            \
+        case 6: _Pragma("unroll") for (int c = 0; c < 4; ++c) DST[c] = r[6][c]; break;            \
+        default: _Pragma("unroll") for (int c = 0; c < 4; ++c) DST[c] = r[7][c]; break;           \
+      }                                                                                           \
+    } while (0)
+    double m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0};
     if (UPDATE) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const int kk = c * kWave + lane;
         double P = theta[c];
 #pragma unroll
         for (int k = 0; k < 8; ++k)
           if (k < kfirst) P += r[k][c];
-        sl[kWrRowP + kk] = P;
+        sl[kWrRowP + c * kWave + lane] = P;
+      }
+      for (int t = 0; t < 3; ++t) {   // (staged rows of the tail: none on an ordinary node of the run)
+        if (t < nstaged) {
+          double v[4];
+          WR_GET(stage_of[t], v);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          if (stage_of[0] == k) sl[kWrRowS + kk] = r[k][c];
-          if (stage_of[1] == k) sl[kWrRowS + kWrK + kk] = r[k][c];
-          if (stage_of[2] == k) sl[kWrRowS + 2 * kWrK + kk] = r[k][c];
+          for (int c = 0; c < 4; ++c) sl[kWrRowS + t * kWrK + c * kWave + lane] = v[c];
         }
+      }
+      if (s0 >= 0) {   // (labels beyond K: -inf, which makes the recurrence's H = gamma Di - m = +inf there)
+        WR_GET(s0, m0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {   // (labels beyond K: -inf, which makes the recurrence's H = gamma Di - m = +inf there)
-          if (s0 == k) sl[kWrRowM + kk] = ok[c] ? r[k][c] : -__builtin_huge_val();
-          if (s1 == k) sl[kWrRowM + kWrK + kk] = ok[c] ? r[k][c] : -__builtin_huge_val();
-        }
+        for (int c = 0; c < 4; ++c) sl[kWrRowM + c * kWave + lane] = ok[c] ? m0[c] : -__builtin_huge_val();
+      }
+      if (s1 >= 0) {
+        WR_GET(s1, m1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sl[kWrRowM + kWrK + c * kWave + lane] = ok[c] ? m1[c] : -__builtin_huge_val();
       }
     }
     if (PRIMAL) {
@@ -457,17 +545,13 @@ __device__ __attribute__((noinline)) void wr_loader(const DevParams *pp_, int ep
     // the two messages to the next node are ONE message if weights and old rows agree (positions are shared)
     int nmsg = s0 < 0 ? 0 : 1;
     if (UPDATE && s1 >= 0) {
-      bool same = WRLI(__double2hiint(av), s0) == WRLI(__double2hiint(av), s1) && WRLI(__double2loint(av), s0) == WRLI(__double2loint(av), s1);
+      bool differ = false;
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-          if (a != b && s0 == a && s1 == b) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) same = same && !UNI(ok[c] && __double_as_longlong(r[a][c]) != __double_as_longlong(r[b][c]));
-          }
+      for (int c = 0; c < 4; ++c) differ = differ | (ok[c] & (__double_as_longlong(m0[c]) != __double_as_longlong(m1[c])));
+      const bool same = WRLI(__double2hiint(av), s0) == WRLI(__double2hiint(av), s1) && WRLI(__double2loint(av), s0) == WRLI(__double2loint(av), s1) && !UNI(differ);
       nmsg = same ? 1 : 2;
     }
+#undef WR_GET
     {
       int word = 0;
       word = lane == kWsNt ? nt : lane == kWsKinds ? (kinds | (nt << 16)) : lane == kWsNmsg ? nmsg : lane == kWsCut ? cut
@@ -480,9 +564,15 @@ __device__ __attribute__((noinline)) void wr_loader(const DevParams *pp_, int ep
       const double g = (double)1 / (double)(nout > nin ? nout : nin > 0 ? nin : 1);
       if (lane < 8) sl[kWrSc + 8 + lane] = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? g : ain;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    WR_RELEASE();
     if (lane == 0) wr_store((int *)(sl + kWrSc) + kWsTag, i + 1);
+    if (p.timeline && p.spec_stat && lw == 0 && lane == 0) {
+      const long long tl3_ = (long long)wall_clock64();
+      atomicAdd(p.spec_stat + 21 + D, (unsigned long long)(tl1_ - tl0_)); atomicAdd(p.spec_stat + 19 + D, (unsigned long long)(tl2_ - tl1_));
+      atomicAdd(p.spec_stat + 23 + D, (unsigned long long)(tl3_ - tl2_));
+    }
   }
+#undef WR_REQUEST_OWN
 }
 
 // ---- wave 11: what a segment starts from, to global memory ------------------------------------------------------------
@@ -549,12 +639,17 @@ __device__ __attribute__((noinline)) void wide_chain_runner(const DevParams *pp_
     const int t = tid >> 5, e = tid & 31;
     rb[kWrTab + t * kWrTabDoubles + (e < 16 ? e : kWrK + e)] = __builtin_huge_val();
   }
+  for (int k = tid; k < kWrK; k += (int)blockDim.x) rb[kWrPos + k] = k < p.K ? p.pos[k] : 0.0;
   if (p.timeline && tid == 0) p.timeline[((size_t)2 * p.tl_stride + D) * 2] = wall_clock64();
   __syncthreads();
+  const unsigned long long trole0 = wall_clock64();
   if (wave < kWrMsg) { if (UPDATE) { __builtin_amdgcn_s_setprio(3); wr_messages<BACKWARD>(pp_, wave, abort_off); __builtin_amdgcn_s_setprio(0); } }
   else if (wave == kWrMsg) { if (PRIMAL) { __builtin_amdgcn_s_setprio(3); wr_labels<BACKWARD>(pp_, abort_off); __builtin_amdgcn_s_setprio(0); } }
   else if (wave < kWrMsg + 1 + kWrLoaders) wr_loader<BACKWARD, PRIMAL, UPDATE>(pp_, epoch, abort_off, wave - kWrMsg - 1);
   else wr_publisher<PRIMAL, UPDATE>(pp_, epoch, abort_off);
+  // (development: when each role was done, 100 MHz ticks since the roles started -- messages, labels, last loader, publisher)
+  if (p.timeline && p.spec_stat && (tid & (kWave - 1)) == 0 && (wave == 0 || wave == kWrMsg || wave == kWrMsg + kWrLoaders || wave == kWrMsg + 1 + kWrLoaders))
+    p.spec_stat[8 + 4 * D + (wave == 0 ? 0 : wave == kWrMsg ? 1 : wave == kWrMsg + kWrLoaders ? 2 : 3)] = wall_clock64() - trole0;
   __syncthreads();
   if (wr_load(abort_word) && tid == 0) st_sc1(p.abort_flag, 1);
   if (p.timeline && tid == 0) p.timeline[((size_t)2 * p.tl_stride + D) * 2 + 1] = wall_clock64();
