@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_ROUND = "r05"    # roofline.traffic is read from THIS round's committed PMC passes only (profiles/r05_*), never older ones
+PROFILE_ROUND = "r06"    # roofline.traffic is read from THIS round's committed PMC passes only (profiles/r06_*), never older ones
 
 
 def synthetic_volume(H, W, K, seed):
@@ -215,6 +215,8 @@ def scale_leg(args, rank, local_rank, world, dist, dev, index_order=False, minpl
             "ranks": ranks, "distinct_devices": len({(r["host"], r["device"]) for r in ranks}),
             "collective_backend": (dist.get_backend() if dist is not None and world > 1 else "none"),
             "n1_reference": n1,
+            "speculative_chain": (plan.spec_stats() if world == 1 and hasattr(plan, "spec_stats") else
+                                  {"active": False, "why": "strips keep the plain chain schedule"}),
             "note": "the north star's 1 -> N scaling curve (one image, strong scaling): at N > 1 this object IS the "
                     "top-level value; at N = 1 the top-level value is the Teddy headline and this is the curve's first point"}
 
@@ -403,6 +405,32 @@ def hard_moves_leg(which, H, W, im0_synth):
     return res
 
 
+def segmentation_leg():
+    """the segmenters behind dispmap_globalstereo on the Teddy pair's reference image -- vgg_segment_ms(R, 4, 5, 0)
+    for the edge weights (dispmap_globalstereo.m:391) and the 14 maps of segpln (:121-134) -- against the committed maps of the
+    reference's own segmenters and, where oracle/_ref travelled, against those segmenters timed on this host."""
+    from stereo_amd import segment as S
+    gold = os.path.join(ROOT, "tests", "golden")
+    im = np.load(os.path.join(gold, "teddy_pair.npz"))["im0"]
+    sg = np.load(os.path.join(gold, "teddy_segments.npz"))
+    S.vgg_segment_ms(np.ascontiguousarray(im[:48, :64]), 2, 3, 0)   # (first-call costs out of the figures)
+    t = time.perf_counter(); seg = S.vgg_segment_ms(im, 4, 5, 0); t_ms = time.perf_counter() - t
+    t = time.perf_counter(); maps = S.segpln_segments(im); t_maps = time.perf_counter() - t
+    t = time.perf_counter(); own, ev = S.ms_own(im, 4, 5); t_own = time.perf_counter() - t
+    out = {"what": "vgg_segment_ms(R, 4, 5, 0) and the 14 SegPln maps of the Teddy pair's reference image (450x375): mean-shift filter one "
+                   "thread per pixel on the device, the reference's scan-order shortcuts / region graph / sort + union-find on the host",
+           "segment_ms": t_ms * 1e3, "segments": int(seg.max()), "fourteen_maps_ms": t_maps * 1e3,
+           "filter_stage_ms": t_own * 1e3, "pixels_walked_again_on_the_host": int(ev.sum()),
+           "equal_to_the_reference_maps": bool(np.array_equal(seg, sg["segment"]) and np.array_equal(maps, sg["segments"]))}
+    from oracle import pyoracle
+    if pyoracle.have_ref_segment() and pyoracle.ref_segment_gb_lib() is not None:
+        t = time.perf_counter(); r = pyoracle.ref_segment_ms(im, 4, 5.0, 0); t_r = time.perf_counter() - t
+        t = time.perf_counter(); rm = pyoracle.ref_segpln_segments(im); t_rm = time.perf_counter() - t
+        out["cpu_reference"] = {"kind": "reference", "cores": 1, "segment_ms": t_r * 1e3, "fourteen_maps_ms": t_rm * 1e3,
+                                "equal": bool(np.array_equal(r, seg) and np.array_equal(rm, maps))}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -562,6 +590,7 @@ def main():
             traffic_source = "profiles/%s (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; NOT measured in this run)" % pmc
         elif pmc:
             traffic_source = "profiles/%s not committed yet" % pmc
+        spec_stats = plan.spec_stats()
         out = {
             "metric": "TRW-S fusion iterations/sec, 450x375x60 labels",
             "value": rate,
@@ -588,6 +617,10 @@ def main():
             "serial_envelope_messages": serial_msgs,
             "serial_envelope_fraction": serial_msgs / (2.0 * E * max(args.steps, 1)),  # 2E message updates per iteration
             "final_energy": energy, "final_lower_bound": lb, "iterations_done": iters,
+            "speculative_chain": dict(spec_stats, what="the border chain's schedule (DESIGN 4.5): a runner computes the chain's min-plus recurrence ahead, "
+                                      "segments of 16 visits recompute every visit certified, side by side, and commit in order after comparing "
+                                      "what they started from; second_walks = segments walked again because the runner's row was not the "
+                                      "reference's; STEREO_HIP_TRWS_SPEC=0 gives the plain schedule, same bits"),
             "index_order_option": {"iterations_per_s": args.steps / alt_dt, "ms_per_step": alt_dt / args.steps * 1e3,
                                    "energy": alt_en, "lower_bound": alt_lb,
                                    "note": "STEREO_TRWS_ORDER_INDEX on rank 0's volume: node index order (MRFEnergy without "
@@ -595,7 +628,8 @@ def main():
                                            "reported next to the headline, never as `value`"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": {4: "trws_pipe2_kernel", 3: "trws_wide_kernel", 2: "trws_pipe_kernel", 1: "trws_persistent_kernel", 0: "trws_sweep_kernel (per level)"}[plan.path()]
+                         "kernel": ({4: "trws_pipe2_kernel", 3: "trws_wide_kernel", 2: "trws_pipe_kernel", 1: "trws_persistent_kernel", 0: "trws_sweep_kernel (per level)"}[plan.path()]
+                                    if not spec_stats["active"] else {3: "trws_wide_spec_kernel", 2: "trws_pipe_spec_kernel"}[plan.path()])
                                    + " (one persistent launch per sweep)", "bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches_per_iter},
         }
@@ -738,6 +772,10 @@ def main():
                     except Exception as exc:
                         extra[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
                 out["binary_fusion"] = extra
+                try:
+                    out["segmentation"] = segmentation_leg()
+                except Exception as exc:
+                    out["segmentation"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
             except Exception as exc:  # the headline number must not depend on the secondary one
                 out["binary_fusion"] = {"error": str(exc)}
     # second leg: one large image tiled across all ranks (strong scaling); every rank takes part

@@ -8,7 +8,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-CLASS = {np.dtype("float64"): 6, np.dtype("int32"): 12, np.dtype("uint32"): 13, np.dtype("uint64"): 15}
+CLASS = {np.dtype("float64"): 6, np.dtype("uint8"): 9, np.dtype("int32"): 12, np.dtype("uint32"): 13, np.dtype("uint64"): 15}
 DTYPE = {v: k for k, v in CLASS.items()}
 
 

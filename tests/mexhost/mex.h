@@ -9,7 +9,7 @@
 
 typedef size_t mwSize;
 typedef size_t mwIndex;
-typedef enum { mxUNKNOWN_CLASS = 0, mxSTRUCT_CLASS = 2, mxCHAR_CLASS = 4, mxDOUBLE_CLASS = 6, mxINT32_CLASS = 12,
+typedef enum { mxUNKNOWN_CLASS = 0, mxSTRUCT_CLASS = 2, mxCHAR_CLASS = 4, mxDOUBLE_CLASS = 6, mxUINT8_CLASS = 9, mxINT32_CLASS = 12,
                mxUINT32_CLASS = 13, mxUINT64_CLASS = 15 } mxClassID;
 typedef enum { mxREAL = 0, mxCOMPLEX = 1 } mxComplexity;
 struct mxArray_tag;
@@ -26,6 +26,7 @@ void mxDestroyArray(mxArray *a);
 
 bool mxIsDouble(const mxArray *a);
 bool mxIsInt32(const mxArray *a);
+bool mxIsUint8(const mxArray *a);
 bool mxIsUint32(const mxArray *a);
 bool mxIsUint64(const mxArray *a);
 bool mxIsChar(const mxArray *a);

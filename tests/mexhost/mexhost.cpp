@@ -21,7 +21,7 @@ size_t elem_size(mxClassID c) {
   switch (c) {
     case mxDOUBLE_CLASS: case mxUINT64_CLASS: return 8;
     case mxINT32_CLASS: case mxUINT32_CLASS: return 4;
-    case mxCHAR_CLASS: return 1;
+    case mxCHAR_CLASS: case mxUINT8_CLASS: return 1;
     default: return 0;
   }
 }
@@ -57,6 +57,7 @@ void mxDestroyArray(mxArray *a) {
 bool mxIsDouble(const mxArray *a) { return a && a->cls == mxDOUBLE_CLASS; }
 bool mxIsInt32(const mxArray *a) { return a && a->cls == mxINT32_CLASS; }
 bool mxIsUint32(const mxArray *a) { return a && a->cls == mxUINT32_CLASS; }
+bool mxIsUint8(const mxArray *a) { return a && a->cls == mxUINT8_CLASS; }
 bool mxIsUint64(const mxArray *a) { return a && a->cls == mxUINT64_CLASS; }
 bool mxIsChar(const mxArray *a) { return a && a->cls == mxCHAR_CLASS; }
 bool mxIsStruct(const mxArray *a) { return a && a->cls == mxSTRUCT_CLASS; }

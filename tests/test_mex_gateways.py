@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "mex
 from helpers import grid_conn, trws_problem
 
 
-@pytest.mark.parametrize("name", ["rd_mex", "trws_mex", "fusion_mex"])
+@pytest.mark.parametrize("name", ["rd_mex", "trws_mex", "fusion_mex", "vgg_segment_ms", "vgg_segment_gb"])
 def test_gateway_compiles(name):
     import host
     assert os.path.exists(host.build(name))
@@ -47,6 +47,32 @@ def test_trws_gateway_argument_checks():
         g.call(4, *([1.0] + args[1:]))
     with pytest.raises(host.MexError, match="unary.M == q.M"):
         g.call(4, *(args[:3] + [np.zeros((K + 1, E))] + args[4:]))
+
+
+def test_segmenter_gateways_argument_checks():
+    """imrender/vgg/vgg_segment_ms.cxx:21-27, vgg_segment_gb.cxx:24-30: the reference's messages."""
+    import host
+    for name in ("vgg_segment_ms", "vgg_segment_gb"):
+        g = host.Gateway(name)
+        with pytest.raises(host.MexError, match="Unexpected number of input arguments."):
+            g.call(1, np.zeros((4, 5, 3), np.uint8), 4.0)
+        with pytest.raises(host.MexError, match="Unexpected number of output arguments."):
+            g.call(3, np.zeros((4, 5, 3), np.uint8), 4.0, 5.0, 0.0)
+        with pytest.raises(host.MexError, match="A must be an HxWx3 uint8 array."):
+            g.call(1, np.zeros((4, 5, 3)), 4.0, 5.0, 0.0)
+
+
+@pytest.mark.gpu
+def test_segmenter_gateways_equal_the_binding(hip):
+    import host
+    from stereo_amd import segment as S
+    im = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "teddy_crop.npz"))
+    key = [k for k in im.files if im[k].ndim == 3 and im[k].shape[2] == 3][0]
+    A = S.to_uint8(im[key])
+    ms = host.Gateway("vgg_segment_ms").call(1, A, 4.0, 5.0, 0.0)[0]
+    assert ms.dtype == np.uint32 and np.array_equal(ms, S.vgg_segment_ms(A, 4, 5, 0))
+    gb = host.Gateway("vgg_segment_gb").call(1, A, 0.0, 300.0, 30.0, 1.0)[0]
+    assert np.array_equal(gb, S.vgg_segment_gb(A, 0, 300, 30, 1))
 
 
 @pytest.mark.gpu
