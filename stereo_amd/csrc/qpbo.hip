@@ -767,11 +767,10 @@ __global__ __launch_bounds__(kMB) void qpbo_maxflow_kernel(QpboDev g, int32_t *c
       // The dirty marks are raw round numbers too: at the wrap both planes are cleared (by the thread that
       // then writes the tile's new mark, so the two stores are ordered), or marks left from the launch's
       // first rounds 2, 3, ... would compare equal to the restarted round numbers.
-      // -DSTEREO_HIP_QPBO_WRAP_AT=<n>: debug flavour that wraps early (tools/gpu_qpbo_wrap.sh).
-#ifndef STEREO_HIP_QPBO_WRAP_AT
-#define STEREO_HIP_QPBO_WRAP_AT 60000
-#endif
-      const bool wrap = G > STEREO_HIP_QPBO_WRAP_AT;
+      // STEREO_HIP_QPBO_WRAP_AT=<n> (1 .. 4095, development): wrap that early, so that a test reaches the wrap at all
+      // (tests/test_rd_gpu.py::test_round_numbers_wrap).
+      const int wrap_at = ((adaptive_in >> 18) & 0xfff) ? ((adaptive_in >> 18) & 0xfff) : 60000;
+      const bool wrap = G > wrap_at;
       if (wrap) { G = 0; hx_refresh_all = true; }
       for (int T = first; T < g.ntiles; T += stride) {
         if (wrap) { stc(g.dirty + T, 0); stc(g.dirty + (size_t)g.ntiles + T, 0); }
@@ -1624,6 +1623,7 @@ struct QpboSolver {
     if (const char *e = std::getenv("STEREO_HIP_QPBO_STALL_PERMILLE")) stall = std::min(999, std::max(0, std::atoi(e)));
     adaptive |= stall << 8;
     if (const char *e = std::getenv("STEREO_HIP_QPBO_FINAL_RELABEL")) if (std::atoi(e) != 0) adaptive |= 1 << 30;
+    if (const char *e = std::getenv("STEREO_HIP_QPBO_WRAP_AT")) adaptive |= std::min(4095, std::max(0, std::atoi(e))) << 18;   // (development)
     int improve_N = (int)P.N;
     void *args[] = {&gg, &ctl, &relabel_every, &max_rounds, &tiled, &switch_at, &incremental, &first_interval, &adaptive,
                     &improve_perm, &improve_N};

@@ -230,6 +230,30 @@ def test_large_grid_move_matches_reference(hip, oracle):
     assert _rel(b[1], r[1]) < 1e-9
 
 
+def test_round_numbers_wrap(hip, monkeypatch):
+    """The tiled rounds' marks and the hx words carry round numbers; long launches wrap them (qpbo.hip: mark_all_dirty).
+    STEREO_HIP_QPBO_WRAP_AT makes the wrap come after a handful of rounds: moves that need many tiled rounds -- a
+    frustrated problem with Improve, a large move with supermodular terms -- must give the labels of the default run."""
+    import ctypes
+    from stereo_amd.rd import RdPlan
+    cases = [(glass_problem(322, 120, 160, 3.0, True), (120, 160), True), (fusion_problem(323, 300, 400, nonsub_boost=3.0), (300, 400), False),
+             (glass_problem(324, 60, 70, 1.0, False), (60, 70), True)]
+    for p, grid, improve in cases:
+        args = (p["U0"], p["U1"], p["E00"], p["E01"], p["E10"], p["E11"])
+        out = []
+        for wrap in (None, "3", "17"):
+            if wrap is None:
+                monkeypatch.delenv("STEREO_HIP_QPBO_WRAP_AT", raising=False)
+            else:
+                monkeypatch.setenv("STEREO_HIP_QPBO_WRAP_AT", wrap)
+            plan = RdPlan(grid[0] * grid[1], p["conn"].T, grid=grid)
+            ctypes.CDLL(None).srand(11)
+            out.append(plan.solve(*args, improve=improve))
+            plan.close()
+        for o in out[1:]:
+            assert np.array_equal(o[0], out[0][0]) and o[3] == out[0][3] and o[1] == out[0][1]
+
+
 def test_gateway_keeps_the_plan_of_the_last_connectivity(hip, oracle, monkeypatch):
     """stereo_rd (what rd_mex calls) keeps the plan of the last connectivity it saw: same results as the
     stateless path on repeated moves, on a change of connectivity and back, with and without Improve."""
