@@ -1266,6 +1266,9 @@ __device__ __forceinline__ void coop_collect(const CoopPart &c, double &m1, doub
   int *flag = (int *)(coop_lds + kPipeXflagOff) + ((c.word >> 4) & 15);
   int spins = 0;
   while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (c.word >> 8) && ++spins < kCoopSpinLimit) { }
+  // (a partner that never publishes is a bug, not a state; what would be merged then is not a message: the launch gives up
+  //  through the workgroup's abort word, like a dependency wait that ran out of time)
+  if (spins >= kCoopSpinLimit && lane == 0) __hip_atomic_store((int *)(coop_lds + kPipeCtlOff) + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   const double b1 = xd[lane], b2 = xd[kWave + lane];
   cnt += ((const int *)(xd + 2 * kWave))[lane];

@@ -706,7 +706,7 @@ static int plan_create_impl(int kernel, int K, int64_t N, int64_t E, const uint3
       // a strip walks the chain schedule with one of the descriptor-driven kernels
       if (!(P->fast || P->wide_allowed || P->fast2))
         return fail("stereo_trws: row strips need a graph and label count the pipelined kernels take "
-                    "(<= 8 edges per node; K <= 64, or K <= 128 with the linear kernel, or K <= 256 with shared positions)", err, errcap);
+                    "(<= 8 edges per node; K <= 64, or K <= 128 with per-edge positions, or K <= 256 with shared ascending positions)", err, errcap);
     }
     if (strip_api) STEREO_HIP_CHECK(hipStreamCreateWithFlags(&P->own_stream, hipStreamNonBlocking));
     P->n_lb = nstrips > 1 ? g.strip_lb_terms[strip] : g.lb_terms;

@@ -223,9 +223,11 @@ __device__ __forceinline__ void wide_publish(double *xd, int *flag, int seq, con
   if (lane == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void wide_collect(const double *xd, int *flag, int seq, double (&m1)[4], double (&m2)[4], int &matches,
-                                             int lane) {
+                                             int lane, int *abort_word) {
   int spins = 0;
   while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != seq && ++spins < kCoopSpinLimit) { }
+  // (a partner that never publishes: the launch gives up through the abort word instead of merging whatever is there)
+  if (spins >= kCoopSpinLimit && lane == 0) __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   double b1[4], b2[4];
 #pragma unroll
@@ -768,7 +770,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                       }
                     }
                     if (coop_part) { wide_publish(xd, xfl, pos + 1, m1, m2, matches, lane); continue; }
-                    wide_collect(xd, xfl, pos + 1, m1, m2, matches, lane);
+                    wide_collect(xd, xfl, pos + 1, m1, m2, matches, lane, L.ctl + 1);
                   } else {
 #pragma unroll
                   for (int c = 0; c < 4; ++c) {
@@ -819,7 +821,7 @@ __device__ __forceinline__ void wide_body(DevParams p, int epoch) {
                   // (two waves: the first tests the keys, above; the helper walks the window, below)
                   if (coop_n > 1 && !coop_part) {
                     int none = 0;
-                    wide_collect(xd, xfl, pos + 1, m1, m2, none, lane);
+                    wide_collect(xd, xfl, pos + 1, m1, m2, none, lane, L.ctl + 1);
                   } else {
                   // source table (the scratch again): (h, q) pairs at index kWPad + k -- h only on uniform
                   // positions --, (+inf, 0) padding on both sides
