@@ -250,25 +250,38 @@ void connect(const float *f, Regions &R) {
 }
 
 // BuildRAM (:2085-2240): for every region the ascending list of the regions it touches to the right of or below one
-// of its pixels (both ways).
+// of its pixels (both ways).  Counted, filled and then sorted region by region (a region has a handful of neighbours):
+// one global sort of all boundary pairs was most of this stage's time on the fine maps.
 void adjacency(Regions &R) {
   const int H = R.H, W = R.W;
-  std::vector<int64_t> pairs;
-  auto touch = [&](int a, int b) {
-    if (a != b) { pairs.push_back(((int64_t)a << 32) | (uint32_t)b); pairs.push_back(((int64_t)b << 32) | (uint32_t)a); }
-  };
-  for (int y = 0; y < H; ++y)
-    for (int x = 0; x < W; ++x) {
-      const int c = R.labels[(size_t)y * W + x];
-      if (x + 1 < W) touch(c, R.labels[(size_t)y * W + x + 1]);
-      if (y + 1 < H) touch(c, R.labels[(size_t)(y + 1) * W + x]);
+  std::vector<int32_t> &ptr = R.adj_ptr;
+  ptr.assign((size_t)R.n + 1, 0);
+  auto each_pair = [&](auto &&f) {
+    for (int y = 0; y < H; ++y) {
+      const int32_t *row = &R.labels[(size_t)y * W], *below = y + 1 < H ? row + W : nullptr;
+      for (int x = 0; x < W; ++x) {
+        const int c = row[x];
+        if (x + 1 < W && row[x + 1] != c) f(c, row[x + 1]);
+        if (below && below[x] != c) f(c, below[x]);
+      }
     }
-  std::sort(pairs.begin(), pairs.end());
-  pairs.erase(std::unique(pairs.begin(), pairs.end()), pairs.end());
-  R.adj_ptr.assign((size_t)R.n + 1, 0);
-  R.adj.resize(pairs.size());
-  for (size_t k = 0; k < pairs.size(); ++k) { ++R.adj_ptr[(size_t)(pairs[k] >> 32) + 1]; R.adj[k] = (int32_t)(pairs[k] & 0xffffffff); }
-  for (int r = 0; r < R.n; ++r) R.adj_ptr[r + 1] += R.adj_ptr[r];
+  };
+  each_pair([&](int a, int b) { ++ptr[(size_t)a + 1]; ++ptr[(size_t)b + 1]; });
+  for (int r = 0; r < R.n; ++r) ptr[r + 1] += ptr[r];
+  std::vector<int32_t> raw((size_t)ptr[R.n]), at(ptr.begin(), ptr.end() - 1);
+  each_pair([&](int a, int b) { raw[at[a]++] = b; raw[at[b]++] = a; });
+  R.adj.clear();
+  R.adj.reserve(raw.size());
+  int32_t begin = 0;
+  for (int r = 0; r < R.n; ++r) {
+    const int32_t end = ptr[r + 1];
+    std::sort(raw.begin() + begin, raw.begin() + end);
+    const auto last = std::unique(raw.begin() + begin, raw.begin() + end);
+    ptr[r] = (int32_t)R.adj.size();
+    R.adj.insert(R.adj.end(), raw.begin() + begin, last);
+    begin = end;
+  }
+  ptr[R.n] = (int32_t)R.adj.size();
 }
 
 int find_root(const std::vector<int32_t> &parent, int i) {
