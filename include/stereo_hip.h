@@ -26,7 +26,7 @@ extern "C" {
  * library that reports another version (a stale libstereo_hip.so).  3: stereo_hip_device_cus, plan
  * entry points select their plan's device, wall-clock bound on cross-workgroup waits.  4: stereo_fusion_fit_planes,
  * stereo_fusion_fuse_until_convergence.  5: stereo_segpln_wta, stereo_segpln_planes.  6: stereo_segment_* (the segmenters
- * behind dispmap_globalstereo), stereo_trws_plan_debug_terms / _messages. */
+ * behind dispmap_globalstereo), stereo_trws_plan_debug_terms / _messages, stereo_segpln_planes_batch. */
 #define STEREO_HIP_ABI_VERSION 6
 
 /* ---- library ---------------------------------------------------------- */
@@ -512,6 +512,15 @@ int stereo_segpln_wta(const double *images, int n_images, int H, int W, int C, c
 int stereo_segpln_planes(const double *wta, const int32_t *segments, int H, int W, double rt, uint64_t seed,
                          int max_samples, double *proposal, int S, double *planes, int32_t *inliers, char *err,
                          size_t errcap);
+
+/* The same for M maps in one call (segpln fits fourteen, dispmap_globalstereo.m:122-197): segments[m], seeds[m], S[m],
+ * proposals[m] (or NULL), planes[m] (or NULL), inliers[m] (or NULL) are map m's arguments of stereo_segpln_planes and
+ * the results are those of M such calls, bit for bit -- the maps run side by side on the device (a stream each, the
+ * host grouping the next map's pixels meanwhile), which is what the call is for. */
+int stereo_segpln_planes_batch(const double *wta, const int32_t *const *segments, int M, int H, int W, double rt,
+                               const uint64_t *seeds, int max_samples, double *const *proposals, const int *S,
+                               double *const *planes, int32_t *const *inliers, char *err, size_t errcap);
+
 
 /* ---- Image segmentation: what dispmap_globalstereo takes its edge weights (:391-403) and the maps of
  * its 14 SegPln proposals (:121-134) from.  A: H x W x 3 uint8, MATLAB column-major; out: H x W uint32, column-major.

@@ -13,6 +13,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <memory>
+#include <stdexcept>
 #include <vector>
 
 #include "../../include/stereo_hip.h"
@@ -188,8 +190,8 @@ struct FitArgs {
 };
 
 constexpr int kFitBatch = 8;   // RANSAC trials judged per pass over a segment's points
-constexpr int kFitStage = 4096;   // points per LDS stage of the large segments' least-squares sums (3 doubles + a flag each)
-constexpr size_t kFitStageBytes = (size_t)kFitStage * (3 * sizeof(double) + 1);
+constexpr int kFitStage = 4096;   // points per LDS stage of the large segments' least-squares sums (3 doubles each)
+constexpr size_t kFitStageBytes = (size_t)kFitStage * 3 * sizeof(double);
 
 // One least-squares sum of the flagged points, as oracle/terms.py:_lstsq3 forms it: 64 strided partial sums (lane l adds
 // points l, l + 64, ... in order), then a tree.  K: x x, x y, x z, y y, y z, z z, -x, -y, -z.  Returns the sum in lane 0.
@@ -340,13 +342,15 @@ __global__ __launch_bounds__(T) void segpln_fit_kernel(FitArgs a) {
         }
       if (lane == 0) for (int k = 0; k < 9; ++k) s_acc[k] = acc[k];
     } else if (NW >= 8) {
-      // large segments: ALL waves stream the points through LDS, kStage at a time (the next stage's loads are in flight
-      // while this one is summed), and waves 0 .. 7 add their sum's terms from there in order (wave 0 also the ninth) --
-      // a wave that pulls a 150 000-point segment through its own registers waits a memory round trip per 16 points
+      // large segments: ALL waves stream the points through LDS, kFitStage at a time (the next stage's loads are in flight
+      // while this one is summed), and waves 0 .. 7 add their sum's terms from there in order (wave 7 also the ninth) --
+      // a wave that pulls a 150 000-point segment through its own registers waits a memory round trip per 16 points.
+      // A point that is not flagged (or lies behind the segment's end) is staged as (0, 0, 0): its terms are +0 or -0,
+      // and adding those leaves a partial sum as it is (a partial sum is never -0: it starts at +0, and +0 + -0 = +0) --
+      // the same bits as skipping the point, without a flag to read, an index to clamp or a select per addition.
       extern __shared__ __attribute__((aligned(16))) double fit_stage[];
       constexpr int PER = kFitStage / T;
       double *sX = fit_stage, *sY = sX + kFitStage, *sZ = sY + kFitStage;
-      uint8_t *sF = (uint8_t *)(sZ + kFitStage);
       double rx[PER], ry[PER], rz[PER];
       bool rf[PER];
       auto request = [&](int c0) {
@@ -358,32 +362,32 @@ __global__ __launch_bounds__(T) void segpln_fit_kernel(FitArgs a) {
         }
       };
       request(0);
+      const double *sA = (wave == 0 || wave == 1 || wave == 2 || wave == 6) ? sX : (wave == 3 || wave == 4 || wave == 7) ? sY : sZ;
+      const double *sB = (wave == 0) ? sX : (wave == 1 || wave == 3) ? sY : sZ;   // (second factor; wave 7: the ninth sum's; wave 6: unused)
       double acc = 0, acc8 = 0;
       for (int c0 = 0; c0 < n; c0 += kFitStage) {
 #pragma unroll
-        for (int u = 0; u < PER; ++u) { const int j = u * T + tid; sX[j] = rx[u]; sY[j] = ry[u]; sZ[j] = rz[u]; sF[j] = rf[u] ? 1 : 0; }
+        for (int u = 0; u < PER; ++u) {
+          const int j = u * T + tid;
+          sX[j] = rf[u] ? rx[u] : 0.0; sY[j] = rf[u] ? ry[u] : 0.0; sZ[j] = rf[u] ? rz[u] : 0.0;
+        }
         __syncthreads();
         if (c0 + kFitStage < n) request(c0 + kFitStage);
         const int m = n - c0 < kFitStage ? n - c0 : kFitStage;
+        const int rounds = (m + 64 * 8 - 1) / (64 * 8);   // (whole rounds of 8 x 64 entries: zeros behind the end)
         if (wave < 8) {
-          // (eight points' LDS reads go out together, the additions follow in order; a flag of 0 behind the stage's end)
-          const double *sA = (wave == 0 || wave == 1 || wave == 2 || wave == 6) ? sX : (wave == 3 || wave == 4 || wave == 7) ? sY : sZ;
-          const double *sB = (wave == 0) ? sX : (wave == 1 || wave == 3) ? sY : sZ;   // (second factor; waves 6, 7: unused)
-          for (int j0 = lane; j0 < m; j0 += 64 * 8) {
-            double av[8], bv[8], zv[8];
-            bool fv[8];
+          for (int r = 0; r < rounds; ++r) {
+            double av[8], bv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const int j = j0 + 64 * u, jc = j < m ? j : m - 1;
-              av[u] = sA[jc]; bv[u] = sB[jc]; zv[u] = wave == 0 ? sZ[jc] : 0.0;
-              fv[u] = j < m && sF[jc] != 0;
+            for (int u = 0; u < 8; ++u) {   // (eight points' LDS reads go out together, the additions follow in order)
+              const int j = (r * 8 + u) * 64 + lane;
+              av[u] = sA[j];
+              bv[u] = wave == 6 ? 0.0 : sB[j];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-              const double t = wave < 6 ? av[u] * bv[u] : -av[u];
-              const double next = acc + t;
-              acc = fv[u] ? next : acc;
-              if (wave == 0) { const double n8 = acc8 + (-zv[u]); acc8 = fv[u] ? n8 : acc8; }
+              acc = acc + (wave < 6 ? av[u] * bv[u] : -av[u]);
+              if (wave == 7) acc8 = acc8 + (-bv[u]);
             }
           }
         }
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(T) void segpln_fit_kernel(FitArgs a) {
         acc = acc + other; acc8 = acc8 + other8;
       }
       if (lane == 0 && wave < 8) s_acc[wave] = acc;
-      if (lane == 0 && wave == 0) s_acc[8] = acc8;
+      if (lane == 0 && wave == 7) s_acc[8] = acc8;
     } else {
       for (int k = wave; k < 9; k += LW) {
         double v = 0;
@@ -499,8 +503,7 @@ __global__ __launch_bounds__(T) void segpln_fit_kernel(FitArgs a) {
           const int cnt = classify(N, tmp);
           stamp(5);
           if (cnt > best) {
-            for (int i = tid; i < n; i += T) inl[i] = tmp[i];
-            __syncthreads();
+            { uint8_t *keep = inl; inl = tmp; tmp = keep; }   // (the best flags so far: the arrays swap roles, every thread alike)
             best = cnt;
             max_i = no_i;
             // nsamples(sum(inls), len, 3, conf) (:451-463)
@@ -585,114 +588,187 @@ int stereo_segpln_wta(const double *images, int n_images, int H, int W, int C, c
   });
 }
 
+int stereo_segpln_planes_batch(const double *wta, const int32_t *const *segments, int M, int H, int W, double rt, const uint64_t *seeds,
+                               int max_samples, double *const *proposals, const int *S, double *const *planes, int32_t *const *inliers,
+                               char *err, size_t errcap) {
+  if (!wta || !segments || !seeds || !S || M < 1 || H < 1 || W < 1 || max_samples < 1) return fail("stereo_segpln_planes: bad argument", err, errcap);
+  const int64_t N = (int64_t)H * W;
+  for (int m = 0; m < M; ++m)
+    if (!segments[m] || S[m] < 0 || (!(proposals && proposals[m]) && !(planes && planes[m])))
+      return fail("stereo_segpln_planes: bad argument", err, errcap);
+  return guarded("stereo_segpln_planes", err, errcap, [&] {
+    // The maps are independent of each other (a proposal per map, dispmap_globalstereo.m:140-197), and a map's launches fill
+    // a fraction of the device only (one workgroup per segment; a coarse map has a handful of segments, one of them most of
+    // the image).  So every map gets scratch of its own and a stream; the host groups map m + 1's pixels by segment while
+    // the device fits map m's planes; maps with the fewest segments -- the longest single workgroups -- are issued first.
+    // Everything is kept from call to call on this thread (fourteen maps per object, a dozen allocations each otherwise).
+    constexpr int kStreams = 4;
+    struct MapScratch {
+      DevBuf<double> px, py, pz, dprop, dpl;
+      DevBuf<int32_t> dptr, didx, dn, dlist;
+      DevBuf<uint8_t> cur, tmp, inl;
+      PinnedBuf<double> hpl;       // planes and inlier counts come back through pinned memory; the grouped pixel ids, segment
+      PinnedBuf<int32_t> hn, hidx, hptr, hlist;   // bounds and launch lists go up from pinned memory: copies that do not hold the host
+      size_t N = 0, S = 0;
+      size_t count[3] = {0, 0, 0};
+      hipEvent_t fitted = nullptr;   // the map's kernels are done
+    };
+    struct Pool {
+      DevBuf<double> dw;
+      size_t Nw = 0;
+      std::vector<std::unique_ptr<MapScratch>> maps;
+      hipStream_t stream[kStreams] = {nullptr, nullptr, nullptr, nullptr};
+      hipEvent_t uploaded = nullptr, done[kStreams] = {nullptr, nullptr, nullptr, nullptr};
+      int device = -1;
+    };
+    static thread_local Pool pool;
+    int device = 0;
+    STEREO_HIP_CHECK(hipGetDevice(&device));
+    if (pool.device != device) {   // (buffers of another device are released; its streams and events stay with it)
+      pool.maps.clear(); pool.Nw = 0; pool.device = device;
+      for (int k = 0; k < kStreams; ++k) {
+        STEREO_HIP_CHECK(hipStreamCreateWithFlags(&pool.stream[k], hipStreamNonBlocking));
+        STEREO_HIP_CHECK(hipEventCreateWithFlags(&pool.done[k], hipEventDisableTiming));
+      }
+      STEREO_HIP_CHECK(hipEventCreateWithFlags(&pool.uploaded, hipEventDisableTiming));
+    }
+    if (pool.Nw < (size_t)N) { pool.dw.alloc(N); pool.Nw = (size_t)N; }
+    while (pool.maps.size() < (size_t)M) pool.maps.emplace_back(new MapScratch);
+    static const bool attr_set = [] {
+      return hipFuncSetAttribute((const void *)segpln_fit_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFitStageBytes) == hipSuccess;
+    }();
+    if (!attr_set) throw HipError{"stereo_segpln_planes: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"};
+    static const bool timing = std::getenv("STEREO_HIP_SEGPLN_TIMING") != nullptr;   // (development: the three launches' device time, one map at a time)
+    struct Drain {   // whatever way this call ends, nothing of it is still running when the scratch is used again
+      Pool &pool;
+      ~Drain() { for (int k = 0; k < kStreams; ++k) (void)hipStreamSynchronize(pool.stream[k]); }
+    } drain{pool};
+    // (the disparity map: pageable memory, so this copy returns when the source has been read)
+    STEREO_HIP_CHECK(hipMemcpyAsync(pool.dw.p, wta, sizeof(double) * N, hipMemcpyHostToDevice, pool.stream[0]));
+    STEREO_HIP_CHECK(hipEventRecord(pool.uploaded, pool.stream[0]));
+    for (int k = 1; k < kStreams; ++k) STEREO_HIP_CHECK(hipStreamWaitEvent(pool.stream[k], pool.uploaded, 0));
+    std::vector<int> order((size_t)M);
+    for (int m = 0; m < M; ++m) order[m] = m;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return S[x] < S[y]; });
+    for (int r = 0; r < M; ++r) {
+      const int m = order[r], Sm = S[m];
+      // (the first map of the order has a stream to itself when there are several: its longest workgroup bounds the call)
+      const hipStream_t st = pool.stream[M > 1 && r > 0 ? 1 + (r - 1) % (kStreams - 1) : 0];
+      MapScratch &sc = *pool.maps[r];
+      if (sc.N < (size_t)N) {
+        sc.px.alloc(N); sc.py.alloc(N); sc.pz.alloc(N); sc.cur.alloc(N); sc.tmp.alloc(N); sc.inl.alloc(N); sc.dprop.alloc(4 * N);
+        sc.didx.alloc(N); sc.hidx.alloc(N);
+        sc.N = (size_t)N;
+      }
+      if (sc.S < (size_t)Sm + 2) {
+        const size_t cap = (size_t)Sm + 2;
+        sc.dptr.alloc(cap); sc.dpl.alloc(3 * cap); sc.dn.alloc(cap); sc.dlist.alloc(cap);
+        sc.hpl.alloc(3 * cap); sc.hn.alloc(cap); sc.hptr.alloc(cap); sc.hlist.alloc(cap);
+        sc.S = cap;
+      }
+      // pixels grouped by segment, ascending pixel id inside a segment (= MATLAB's logical indexing order); label 0 = none
+      const int32_t *seg = segments[m];
+      int32_t *ptr = sc.hptr.p, *idx = sc.hidx.p;   // ptr[l] .. ptr[l + 1]: the pixels of label l
+      std::fill(ptr, ptr + Sm + 2, 0);
+      {
+        uint32_t beyond = 0;   // (labels are checked where they are counted: one pass per map, the device busy with the maps before)
+        for (int64_t i = 0; i < N; ++i) {
+          const uint32_t l = (uint32_t)seg[i];
+          if (l <= (uint32_t)Sm) ++ptr[(size_t)l + 1]; else beyond = 1;
+        }
+        if (beyond) throw std::runtime_error("segment label out of range [0, S]");
+      }
+      for (int l = 0; l <= Sm; ++l) ptr[l + 1] += ptr[l];
+      {
+        std::vector<int32_t> at(ptr, ptr + Sm + 1);
+        for (int64_t i = 0; i < N; ++i) idx[(size_t)at[seg[i]]++] = (int32_t)i;
+      }
+      // segments by size: the workgroup grows with the passes over the points it has to make
+      constexpr int kLargeSegment = 4096, kMediumSegment = 384;
+      size_t *count = sc.count;
+      count[0] = count[1] = count[2] = 0;
+      for (int sg = 0; sg < Sm; ++sg) {
+        const int len = ptr[sg + 2] - ptr[sg + 1];
+        ++count[len > kLargeSegment ? 0 : len > kMediumSegment ? 1 : 2];
+      }
+      {
+        size_t at[3] = {0, count[0], count[0] + count[1]};
+        for (int sg = 0; sg < Sm; ++sg) {
+          const int len = ptr[sg + 2] - ptr[sg + 1];
+          sc.hlist.p[at[len > kLargeSegment ? 0 : len > kMediumSegment ? 1 : 2]++] = sg;
+        }
+      }
+      // (the kernels index segments 0 .. S - 1 = labels 1 .. S: the bounds go up from ptr + 1)
+      STEREO_HIP_CHECK(hipMemcpyAsync(sc.dptr.p, ptr + 1, sizeof(int32_t) * ((size_t)Sm + 1), hipMemcpyHostToDevice, st));
+      STEREO_HIP_CHECK(hipMemcpyAsync(sc.didx.p, idx, sizeof(int32_t) * N, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(segpln_init_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, sc.dprop.p);
+      if (Sm > 0) {
+        STEREO_HIP_CHECK(hipMemcpyAsync(sc.dlist.p, sc.hlist.p, sizeof(int32_t) * (size_t)Sm, hipMemcpyHostToDevice, st));
+        FitArgs a{pool.dw.p, sc.dptr.p, sc.didx.p, H, W, Sm, max_samples, rt, seeds[m], sc.px.p, sc.py.p, sc.pz.p, sc.cur.p, sc.tmp.p, sc.inl.p,
+                  sc.dprop.p, sc.dpl.p, sc.dn.p, sc.dlist.p, nullptr};
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        if (timing) for (auto &e : ev) STEREO_HIP_CHECK(hipEventCreate(&e));
+        DevBuf<unsigned long long> dprof;
+        if (timing) { dprof.alloc(16); STEREO_HIP_CHECK(hipMemset(dprof.p, 0, 16 * sizeof(unsigned long long))); a.prof = dprof.p; }
+        if (timing) STEREO_HIP_CHECK(hipEventRecord(ev[0], st));
+        if (count[0]) hipLaunchKernelGGL(segpln_fit_kernel<512>, dim3((unsigned)count[0]), dim3(512), kFitStageBytes, st, a);
+        if (timing) STEREO_HIP_CHECK(hipEventRecord(ev[1], st));
+        a.prof = nullptr;
+        a.list = sc.dlist.p + count[0];
+        if (count[1]) hipLaunchKernelGGL(segpln_fit_kernel<256>, dim3((unsigned)count[1]), dim3(256), 0, st, a);
+        if (timing) STEREO_HIP_CHECK(hipEventRecord(ev[2], st));
+        a.list = sc.dlist.p + count[0] + count[1];
+        if (count[2]) hipLaunchKernelGGL(segpln_fit_kernel<64>, dim3((unsigned)count[2]), dim3(64), 0, st, a);
+        STEREO_HIP_CHECK(hipGetLastError());
+        if (timing) {
+          STEREO_HIP_CHECK(hipEventRecord(ev[3], st));
+          STEREO_HIP_CHECK(hipEventSynchronize(ev[3]));
+          float t[3];
+          for (int k = 0; k < 3; ++k) STEREO_HIP_CHECK(hipEventElapsedTime(&t[k], ev[k], ev[k + 1]));
+          std::fprintf(stderr, "[stereo_hip segpln] S = %d: %zu large segments %.3f ms, %zu medium %.3f ms, %zu small %.3f ms\n", Sm, count[0], t[0],
+                       count[1], t[1], count[2], t[2]);
+          unsigned long long pr[16];
+          STEREO_HIP_CHECK(hipMemcpy(pr, dprof.p, sizeof(pr), hipMemcpyDeviceToHost));
+          if (count[0])
+            std::fprintf(stderr, "[stereo_hip segpln]   first large segment, us (count): coordinates %.0f | draws %.0f (%llu) | batch passes %.0f (%llu) | bookkeeping %.0f | "
+                         "least squares %.0f (%llu) | re-classify + copy %.0f (%llu) | final fit %.0f | proposal %.0f\n", pr[0] / 100.0, pr[1] / 100.0, pr[9],
+                         pr[2] / 100.0, pr[10], pr[3] / 100.0, pr[4] / 100.0, pr[12], pr[5] / 100.0, pr[13], pr[6] / 100.0, pr[7] / 100.0);
+          for (auto &e : ev) (void)hipEventDestroy(e);
+        }
+        STEREO_HIP_CHECK(hipMemcpyAsync(sc.hpl.p, sc.dpl.p, sizeof(double) * 3 * (size_t)Sm, hipMemcpyDeviceToHost, st));
+        STEREO_HIP_CHECK(hipMemcpyAsync(sc.hn.p, sc.dn.p, sizeof(int32_t) * (size_t)Sm, hipMemcpyDeviceToHost, st));
+      }
+      STEREO_HIP_CHECK(hipGetLastError());
+      if (!sc.fitted) STEREO_HIP_CHECK(hipEventCreateWithFlags(&sc.fitted, hipEventDisableTiming));
+      STEREO_HIP_CHECK(hipEventRecord(sc.fitted, st));
+    }
+    // everything is under way.  The proposals come back map by map as the maps finish -- the first of the order, the
+    // longest, last --, each behind its own event: a blocking copy into the caller's pageable memory (an asynchronous one
+    // pins the pages first, at five times the cost), which holds the host only while the other streams work on.
+    for (int q = 0; q < M; ++q) {
+      const int r = (q + 1) % M, m = order[r];
+      if (!(proposals && proposals[m])) continue;
+      STEREO_HIP_CHECK(hipEventSynchronize(pool.maps[r]->fitted));
+      STEREO_HIP_CHECK(hipMemcpy(proposals[m], pool.maps[r]->dprop.p, sizeof(double) * 4 * N, hipMemcpyDeviceToHost));
+    }
+    for (int k = 0; k < kStreams; ++k) {
+      STEREO_HIP_CHECK(hipEventRecord(pool.done[k], pool.stream[k]));
+      STEREO_HIP_CHECK(hipEventSynchronize(pool.done[k]));
+    }
+    for (int r = 0; r < M; ++r) {
+      const int m = order[r];
+      const MapScratch &sc = *pool.maps[r];
+      if (planes && planes[m] && S[m] > 0) std::memcpy(planes[m], sc.hpl.p, sizeof(double) * 3 * (size_t)S[m]);
+      if (inliers && inliers[m] && S[m] > 0) std::memcpy(inliers[m], sc.hn.p, sizeof(int32_t) * (size_t)S[m]);
+    }
+  });
+}
+
 int stereo_segpln_planes(const double *wta, const int32_t *segments, int H, int W, double rt, uint64_t seed, int max_samples,
                          double *proposal, int S, double *planes, int32_t *inliers, char *err, size_t errcap) {
   if (!wta || !segments || H < 1 || W < 1 || S < 0 || max_samples < 1 || (!proposal && !planes))
     return fail("stereo_segpln_planes: bad argument", err, errcap);
-  const int64_t N = (int64_t)H * W;
-  for (int64_t i = 0; i < N; ++i)
-    if (segments[i] < 0 || segments[i] > S) return fail("stereo_segpln_planes: segment label out of range [0, S]", err, errcap);
-  return guarded("stereo_segpln_planes", err, errcap, [&] {
-    // pixels grouped by segment, ascending pixel id inside a segment (= MATLAB's logical indexing order); label 0 = none
-    std::vector<int32_t> ptr((size_t)S + 2, 0), idx((size_t)N);
-    for (int64_t i = 0; i < N; ++i) ++ptr[(size_t)segments[i] + 1];
-    for (int s = 0; s <= S; ++s) ptr[s + 1] += ptr[s];
-    std::vector<int32_t> at(ptr.begin(), ptr.end() - 1);
-    for (int64_t i = 0; i < N; ++i) idx[(size_t)at[segments[i]]++] = (int32_t)i;
-    // (ptr[1 .. S + 1] delimit segments 1 .. S; the pixels of label 0 sit in front)
-    // (scratch kept from call to call on this thread: fourteen maps per object, a dozen allocations each otherwise)
-    struct Scratch {
-      DevBuf<double> dw, px, py, pz, dprop, dpl;
-      DevBuf<int32_t> dptr, didx, dn, dlist;
-      DevBuf<uint8_t> cur, tmp, inl;
-      PinnedBuf<double> hpl;     // planes and inlier counts come back through pinned memory: a small pageable copy that has
-      PinnedBuf<int32_t> hn;     // to wait for the kernels slept ~10 ms per call
-      size_t N = 0, S = 0;
-      int device = -1;
-      hipEvent_t done = nullptr;
-    };
-    static thread_local Scratch sc;
-    int device = 0;
-    STEREO_HIP_CHECK(hipGetDevice(&device));
-    if (sc.device != device) { sc.N = 0; sc.S = 0; sc.device = device; }   // (buffers of another device are released by the allocs below)
-    std::vector<int32_t> all;
-    if (sc.N < (size_t)N) {
-      sc.px.alloc(N); sc.py.alloc(N); sc.pz.alloc(N); sc.cur.alloc(N); sc.tmp.alloc(N); sc.inl.alloc(N); sc.dprop.alloc(4 * N);
-      sc.dw.alloc(N); sc.didx.alloc(N);
-      sc.N = (size_t)N;
-    }
-    if (sc.S < (size_t)S + 1) {
-      sc.dptr.alloc((size_t)S + 1); sc.dpl.alloc((size_t)3 * (S + 1)); sc.dn.alloc((size_t)S + 1); sc.dlist.alloc((size_t)S + 1);
-      sc.hpl.alloc((size_t)3 * (S + 1)); sc.hn.alloc((size_t)S + 1);
-      sc.S = (size_t)S + 1;
-    }
-    DevBuf<double> &dw = sc.dw, &px = sc.px, &py = sc.py, &pz = sc.pz, &dprop = sc.dprop, &dpl = sc.dpl;
-    DevBuf<int32_t> &dptr = sc.dptr, &didx = sc.didx, &dn = sc.dn, &dlist = sc.dlist;
-    dw.upload(wta, N); dptr.upload(ptr.data() + 1, (size_t)S + 1); didx.upload(idx.data(), N);
-    hipLaunchKernelGGL(segpln_init_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, N, dprop.p);
-    if (S > 0) {
-      // segments by size: the workgroup grows with the passes over the points it has to make
-      constexpr int kLargeSegment = 4096, kMediumSegment = 384;
-      std::vector<int32_t> list[3];
-      for (int sg = 0; sg < S; ++sg) {
-        const int len = ptr[sg + 2] - ptr[sg + 1];
-        list[len > kLargeSegment ? 2 : len > kMediumSegment ? 1 : 0].push_back(sg);
-      }
-      all = list[2];
-      all.insert(all.end(), list[1].begin(), list[1].end());
-      all.insert(all.end(), list[0].begin(), list[0].end());
-      dlist.upload(all.data(), all.size());
-      FitArgs a{dw.p, dptr.p, didx.p, H, W, S, max_samples, rt, seed, px.p, py.p, pz.p, sc.cur.p, sc.tmp.p, sc.inl.p, dprop.p, dpl.p, dn.p, dlist.p, nullptr};
-      static const bool timing = std::getenv("STEREO_HIP_SEGPLN_TIMING") != nullptr;   // (development: the three launches' device time)
-      hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-      if (timing) for (auto &e : ev) STEREO_HIP_CHECK(hipEventCreate(&e));
-      DevBuf<unsigned long long> dprof;
-      if (timing) { dprof.alloc(16); STEREO_HIP_CHECK(hipMemset(dprof.p, 0, 16 * sizeof(unsigned long long))); a.prof = dprof.p; }
-      if (timing) STEREO_HIP_CHECK(hipEventRecord(ev[0], 0));
-      if (!list[2].empty()) {
-        static const bool attr_set = [] {
-          return hipFuncSetAttribute((const void *)segpln_fit_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFitStageBytes) == hipSuccess;
-        }();
-        if (!attr_set) throw HipError{"stereo_segpln_planes: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"};
-        hipLaunchKernelGGL(segpln_fit_kernel<512>, dim3((unsigned)list[2].size()), dim3(512), kFitStageBytes, 0, a);
-      }
-      if (timing) STEREO_HIP_CHECK(hipEventRecord(ev[1], 0));
-      a.prof = nullptr;
-      a.list = dlist.p + list[2].size();
-      if (!list[1].empty()) hipLaunchKernelGGL(segpln_fit_kernel<256>, dim3((unsigned)list[1].size()), dim3(256), 0, 0, a);
-      if (timing) STEREO_HIP_CHECK(hipEventRecord(ev[2], 0));
-      a.list = dlist.p + list[2].size() + list[1].size();
-      if (!list[0].empty()) hipLaunchKernelGGL(segpln_fit_kernel<64>, dim3((unsigned)list[0].size()), dim3(64), 0, 0, a);
-      STEREO_HIP_CHECK(hipGetLastError());
-      if (timing) {
-        STEREO_HIP_CHECK(hipEventRecord(ev[3], 0));
-        STEREO_HIP_CHECK(hipEventSynchronize(ev[3]));
-        float t[3];
-        for (int k = 0; k < 3; ++k) STEREO_HIP_CHECK(hipEventElapsedTime(&t[k], ev[k], ev[k + 1]));
-        std::fprintf(stderr, "[stereo_hip segpln] S = %d: %zu large segments %.3f ms, %zu medium %.3f ms, %zu small %.3f ms\n", S, list[2].size(), t[0],
-                     list[1].size(), t[1], list[0].size(), t[2]);
-        unsigned long long pr[16];
-        STEREO_HIP_CHECK(hipMemcpy(pr, dprof.p, sizeof(pr), hipMemcpyDeviceToHost));
-        if (!list[2].empty())
-          std::fprintf(stderr, "[stereo_hip segpln]   first large segment, us (count): coordinates %.0f | draws %.0f (%llu) | batch passes %.0f (%llu) | bookkeeping %.0f | "
-                       "least squares %.0f (%llu) | re-classify + copy %.0f (%llu) | final fit %.0f | proposal %.0f\n", pr[0] / 100.0, pr[1] / 100.0, pr[9],
-                       pr[2] / 100.0, pr[10], pr[3] / 100.0, pr[4] / 100.0, pr[12], pr[5] / 100.0, pr[13], pr[6] / 100.0, pr[7] / 100.0);
-        for (auto &e : ev) (void)hipEventDestroy(e);
-      }
-    }
-    STEREO_HIP_CHECK(hipGetLastError());
-    if (proposal) STEREO_HIP_CHECK(hipMemcpy(proposal, dprop.p, sizeof(double) * 4 * N, hipMemcpyDeviceToHost));
-    if (S > 0) {
-      STEREO_HIP_CHECK(hipMemcpyAsync(sc.hpl.p, dpl.p, sizeof(double) * 3 * S, hipMemcpyDeviceToHost, 0));
-      STEREO_HIP_CHECK(hipMemcpyAsync(sc.hn.p, dn.p, sizeof(int32_t) * S, hipMemcpyDeviceToHost, 0));
-    }
-    if (!sc.done) STEREO_HIP_CHECK(hipEventCreateWithFlags(&sc.done, hipEventDisableTiming));
-    STEREO_HIP_CHECK(hipEventRecord(sc.done, 0));
-    STEREO_HIP_CHECK(hipEventSynchronize(sc.done));
-    if (planes && S > 0) std::memcpy(planes, sc.hpl.p, sizeof(double) * 3 * S);
-    if (inliers && S > 0) std::memcpy(inliers, sc.hn.p, sizeof(int32_t) * S);
-    // (the copies above wait for the kernels: the host vectors the uploads read from live until here)
-  });
+  return stereo_segpln_planes_batch(wta, &segments, 1, H, W, rt, &seed, max_samples, &proposal, &S, &planes, &inliers, err, errcap);
 }
 
 }  // extern "C"

@@ -517,6 +517,6 @@ class dispmap_globalstereo(dispmap_super):
             maps = self.segpln_segments()
             segment_maps = [maps[:, :, b] for b in range(maps.shape[2])]
         wta = self.segpln_wta()
-        return [T.segpln_planes(wta, seg, seed=int(seed) + b)[0] for b, seg in enumerate(segment_maps)]
+        return [out[0] for out in T.segpln_planes_batch(wta, list(segment_maps), [int(seed) + b for b in range(len(segment_maps))])]
 
     restart = init_solution

@@ -72,7 +72,10 @@ def segpln_segments(image):
     for b, m in enumerate(MULTS):
         sp = [p * m for p in SEGMENT_PARAMS]
         maps.append(vgg_segment_ms(R, sp[0], sp[1], sp[2]) if b < 7 else vgg_segment_gb(R, 0, sp[3], sp[2], 1))
-    return np.stack(maps, axis=2)
+    out = np.zeros((R.shape[0], R.shape[1], len(maps)), np.uint32, order="F")   # (map b = out[:, :, b] contiguous, column major:
+    for b, m in enumerate(maps):                                                 #  what the plane fits read without a copy)
+        out[:, :, b] = m
+    return out
 
 
 # ---- the stages, cut at the device / host boundaries (tests; a caller who keeps the filtered image) --------------------

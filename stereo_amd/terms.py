@@ -155,3 +155,35 @@ def segpln_planes(wta, segments, seed=0, rt=0.1, max_samples=500, want_proposal=
           C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), C.c_int(int(max_samples)), _p(prop) if want_proposal else None, C.c_int(S), _p(planes),
           _p(ninl, C.c_int32))
     return prop, planes[:, :S].T.copy(), ninl[:S].copy()
+
+
+def segpln_planes_batch(wta, segment_maps, seeds, rt=0.1, max_samples=500, want_proposal=True):
+    """segpln_planes for several maps in one call (stereo_segpln_planes_batch): the maps run side by side on the device,
+    the results are those of one call per map, bit for bit.  segment_maps: a sequence of H x W label arrays (or
+    H x W x M); seeds: one per map.  -> list of (proposal, planes, inlier counts), as segpln_planes returns them."""
+    wta = _f(np.asarray(wta, np.float64))
+    H, W = wta.shape
+    if isinstance(segment_maps, np.ndarray) and segment_maps.ndim == 3:
+        segment_maps = [segment_maps[:, :, b] for b in range(segment_maps.shape[2])]
+    def labels(seg):   # int32 or uint32, column major: passed as it is; anything else: one copy
+        seg = np.asarray(seg)
+        if seg.dtype in (np.int32, np.uint32) and seg.flags["F_CONTIGUOUS"]:
+            return seg.view(np.int32)
+        return np.array(seg, dtype=np.int32, order="F")
+    segs = [labels(seg) for seg in segment_maps]
+    M = len(segs)
+    seeds = [int(v) & 0xFFFFFFFFFFFFFFFF for v in seeds]
+    if M < 1 or len(seeds) != M or any(seg.shape != (H, W) for seg in segs):
+        raise StereoHipError("segpln_planes_batch: one seed and one H x W label array per map")
+    S = [int(seg.max()) if seg.size else 0 for seg in segs]
+    props = [np.zeros((4, H * W), order="F") if want_proposal else None for _ in range(M)]
+    planes = [np.zeros((3, max(s, 1)), order="F") for s in S]
+    ninl = [np.zeros(max(s, 1), np.int32) for s in S]
+    PD, PI = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    seg_p = (PI * M)(*[_p(seg, C.c_int32) for seg in segs])
+    prop_p = (PD * M)(*[(_p(a) if a is not None else None) for a in props])
+    plane_p = (PD * M)(*[_p(a) for a in planes])
+    ninl_p = (PI * M)(*[_p(a, C.c_int32) for a in ninl])
+    _call(_lib.lib().stereo_segpln_planes_batch, _p(wta), seg_p, C.c_int(M), C.c_int(H), C.c_int(W), C.c_double(float(rt)),
+          (C.c_uint64 * M)(*seeds), C.c_int(int(max_samples)), prop_p, (C.c_int * M)(*S), plane_p, ninl_p)
+    return [(props[m], planes[m][:, :S[m]].T.copy(), ninl[m][:S[m]].copy()) for m in range(M)]

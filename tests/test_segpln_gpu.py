@@ -166,3 +166,33 @@ def test_device_plane_fits_on_the_reference_segmentations_equal_the_golden_plane
         got = T.segpln_planes(pl["wta"], seg, seed=b)[0]
         assert np.array_equal(got, want[b], equal_nan=True), (pair, b, int((got != want[b]).any(axis=0).sum()))
     assert largest > 4096   # (the large-segment kernel was exercised)
+    # all fourteen in one call (stereo_segpln_planes_batch: a stream and scratch per map, the maps side by side on the
+    # device): the same proposals, planes and inlier counts as one call per map -- twice, the second time on warm scratch
+    for rep in range(2):
+        batch = T.segpln_planes_batch(pl["wta"], sg["segments"], list(range(14)))
+        for b in range(14):
+            assert np.array_equal(batch[b][0], want[b], equal_nan=True), (pair, b, rep)
+            one = T.segpln_planes(pl["wta"], sg["segments"][:, :, b], seed=b, want_proposal=False)
+            assert one[0] is None and np.array_equal(batch[b][1], one[1], equal_nan=True) and np.array_equal(batch[b][2], one[2]), (pair, b, rep)
+    # fewer maps than before on the same scratch, in another order, planes only
+    few = T.segpln_planes_batch(pl["wta"], [sg["segments"][:, :, b] for b in (13, 2, 7)], [13, 2, 7], want_proposal=False)
+    for out, b in zip(few, (13, 2, 7)):
+        one = T.segpln_planes(pl["wta"], sg["segments"][:, :, b], seed=b)
+        assert out[0] is None and np.array_equal(out[1], one[1], equal_nan=True) and np.array_equal(out[2], one[2]), (pair, b)
+
+
+@pytest.mark.gpu
+def test_batch_call_refuses_bad_arguments(hip):
+    import stereo_amd
+    from stereo_amd import terms as T
+    wta = np.ones((6, 7))
+    seg = np.ones((6, 7), np.int32)
+    with pytest.raises(stereo_amd.StereoHipError):
+        T.segpln_planes_batch(wta, [seg, seg], [0])            # a seed per map
+    with pytest.raises(stereo_amd.StereoHipError):
+        T.segpln_planes_batch(wta, [seg[:5]], [0])             # the image's shape
+    bad = seg.copy(); bad[0, 0] = -1
+    with pytest.raises(stereo_amd.StereoHipError):
+        T.segpln_planes_batch(wta, [seg, bad], [0, 1])         # labels 0 .. S
+    out = T.segpln_planes_batch(wta, [np.zeros((6, 7), np.int32)], [0])   # no segment at all: the default plane everywhere
+    assert out[0][1].shape == (0, 3) and np.array_equal(out[0][0], np.tile(np.array([[0.0], [0.0], [1.0], [0.0]]), (1, 42)))

@@ -20,3 +20,10 @@ t = time.perf_counter()
 for b in range(14):
     T.segpln_planes(wta, maps[:, :, b], seed=b, want_proposal=False)
 print("planes only (no 4 x N array back to the host): total %.1f ms" % ((time.perf_counter() - t) * 1e3))
+maps = np.asfortranarray(maps.astype(np.int32))   # (as dispmap_globalstereo.segpln_segments holds them: a map contiguous, column major)
+for want in (True, False):
+    for rep in range(3):
+        t = time.perf_counter()
+        T.segpln_planes_batch(wta, maps, list(range(14)), want_proposal=want)
+        dt = (time.perf_counter() - t) * 1e3
+    print("all 14 maps in one call (stereo_segpln_planes_batch)%s: %.1f ms" % ("" if want else ", planes only", dt))
