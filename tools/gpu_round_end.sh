@@ -13,6 +13,7 @@ export PYTHONUNBUFFERED=1
   timeout 400 python tools/stress_improve.py 120 513 2>&1 | tail -2
   timeout 400 python tools/stress_segment.py 120 514 2>&1 | tail -2
   timeout 400 python tools/stress_segpln.py 120 515 2>&1 | tail -2
+  timeout 400 python tools/stress_terms.py 120 516 2>&1 | tail -2
 } > $out/${r}_stress.txt 2>&1
 timeout 1500 python bench.py > $out/${r}_bench_default.json 2> $out/${r}_bench_default.err
 bash tools/profile_bench.sh ${r}_trws_teddy60 --steps 20 --warmup 3 > $out/${r}_profile_teddy.txt 2>&1
