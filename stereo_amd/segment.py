@@ -7,6 +7,7 @@ over stereo_segment_* of libstereo_hip.so (include/stereo_hip.h): the per-pixel 
 work on the host, label maps equal the reference's pixel for pixel.  Same argument meaning and error texts as the gateways.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -64,16 +65,29 @@ def vgg_segment_gb(A, sigma, k, min_sz, compress=0):
     return np.ascontiguousarray(out)
 
 
-def segpln_segments(image):
+def segpln_segments(image, workers=None):
     """The 14 segmentation maps segpln builds its proposals on (dispmap_globalstereo.m:121-134): mean shift at seven
-    scales, the graph-based segmenter at seven scales.  H x W x 14 uint32."""
+    scales, the graph-based segmenter at seven scales.  H x W x 14 uint32, map b = [:, :, b] contiguous (column major).
+    The maps do not depend on each other and most of a map's time is its host stage (region graph / std::sort +
+    union-find, one core each): they are made side by side by `workers` threads (default: one per map, at most the
+    host's cores) -- the library calls release the interpreter lock and share the device."""
     R = to_uint8(image)
-    maps = []
-    for b, m in enumerate(MULTS):
-        sp = [p * m for p in SEGMENT_PARAMS]
-        maps.append(vgg_segment_ms(R, sp[0], sp[1], sp[2]) if b < 7 else vgg_segment_gb(R, 0, sp[3], sp[2], 1))
-    out = np.zeros((R.shape[0], R.shape[1], len(maps)), np.uint32, order="F")   # (map b = out[:, :, b] contiguous, column major:
-    for b, m in enumerate(maps):                                                 #  what the plane fits read without a copy)
+
+    def one(b):
+        sp = [p * MULTS[b] for p in SEGMENT_PARAMS]
+        return vgg_segment_ms(R, sp[0], sp[1], sp[2]) if b < 7 else vgg_segment_gb(R, 0, sp[3], sp[2], 1)
+
+    nmaps = len(MULTS)
+    if workers is None:
+        workers = min(nmaps, os.cpu_count() or 1)
+    if workers > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(int(workers)) as pool:
+            maps = list(pool.map(one, range(nmaps)))
+    else:
+        maps = [one(b) for b in range(nmaps)]
+    out = np.zeros((R.shape[0], R.shape[1], nmaps), np.uint32, order="F")   # (map b = out[:, :, b] contiguous, column major:
+    for b, m in enumerate(maps):                                            #  what the plane fits read without a copy)
         out[:, :, b] = m
     return out
 

@@ -18,8 +18,10 @@ def stages(h_s, h_r, mn):
 seg, (a, b, c, walked) = stages(4, 5.0, 0)
 print("%s %dx%d vgg_segment_ms(4, 5, 0): device filter (incl. LUV, lattice, copies) %.1f ms, host finish %.1f ms (%d pixels walked), regions %.1f ms -> %d segments" % (
     name, W, H, a * 1e3, b * 1e3, walked, c * 1e3, int(seg.max())))
-t = time.perf_counter(); maps = S.segpln_segments(im); dt = time.perf_counter() - t
-print("the 14 SegPln maps: %.1f ms" % (dt * 1e3))
+t = time.perf_counter(); maps1 = S.segpln_segments(im, workers=1); dt1 = time.perf_counter() - t
+for rep in range(2):
+    t = time.perf_counter(); maps = S.segpln_segments(im); dt = time.perf_counter() - t
+print("the 14 SegPln maps: %.1f ms one after the other, %.1f ms side by side (%d host cores; equal: %s)" % (dt1 * 1e3, dt * 1e3, os.cpu_count() or 1, np.array_equal(maps, maps1)))
 for m in range(1, 8):
     _, (a, b, c, walked) = stages(m, 1.5 * m, 10 * m)
     print("   mean shift scale %d: filter %.1f ms, finish %.1f ms, regions %.1f ms" % (m, a * 1e3, b * 1e3, c * 1e3))
