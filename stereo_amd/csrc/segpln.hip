@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <future>
 #include <memory>
 #include <stdexcept>
 #include <vector>
@@ -621,7 +622,8 @@ int stereo_segpln_planes_batch(const double *wta, const int32_t *const *segments
       hipEvent_t uploaded = nullptr, done[kStreams] = {nullptr, nullptr, nullptr, nullptr};
       int device = -1;
     };
-    static thread_local Pool pool;
+    static thread_local Pool this_threads_pool;
+    Pool &pool = this_threads_pool;   // (a plain reference: the helper threads below must see THIS thread's pool, not theirs)
     int device = 0;
     STEREO_HIP_CHECK(hipGetDevice(&device));
     if (pool.device != device) {   // (buffers of another device are released; its streams and events stay with it)
@@ -650,10 +652,8 @@ int stereo_segpln_planes_batch(const double *wta, const int32_t *const *segments
     std::vector<int> order((size_t)M);
     for (int m = 0; m < M; ++m) order[m] = m;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return S[x] < S[y]; });
-    for (int r = 0; r < M; ++r) {
-      const int m = order[r], Sm = S[m];
-      // (the first map of the order has a stream to itself when there are several: its longest workgroup bounds the call)
-      const hipStream_t st = pool.stream[M > 1 && r > 0 ? 1 + (r - 1) % (kStreams - 1) : 0];
+    for (int r = 0; r < M; ++r) {   // scratch first: the helper threads below only write into it
+      const int Sm = S[order[r]];
       MapScratch &sc = *pool.maps[r];
       if (sc.N < (size_t)N) {
         sc.px.alloc(N); sc.py.alloc(N); sc.pz.alloc(N); sc.cur.alloc(N); sc.tmp.alloc(N); sc.inl.alloc(N); sc.dprop.alloc(4 * N);
@@ -666,18 +666,22 @@ int stereo_segpln_planes_batch(const double *wta, const int32_t *const *segments
         sc.hpl.alloc(3 * cap); sc.hn.alloc(cap); sc.hptr.alloc(cap); sc.hlist.alloc(cap);
         sc.S = cap;
       }
-      // pixels grouped by segment, ascending pixel id inside a segment (= MATLAB's logical indexing order); label 0 = none
+    }
+    // pixels grouped by segment, ascending pixel id inside a segment (= MATLAB's logical indexing order); label 0 = none.
+    // Host work, a map at a time in two passes over its labels -- and the maps do not depend on each other: every map
+    // but the first is grouped by a helper thread, the first (and a single map) here; false: a label beyond [0, S].
+    auto group = [&](int r) -> bool {
+      const int m = order[r], Sm = S[m];
+      MapScratch &sc = *pool.maps[r];
       const int32_t *seg = segments[m];
       int32_t *ptr = sc.hptr.p, *idx = sc.hidx.p;   // ptr[l] .. ptr[l + 1]: the pixels of label l
       std::fill(ptr, ptr + Sm + 2, 0);
-      {
-        uint32_t beyond = 0;   // (labels are checked where they are counted: one pass per map, the device busy with the maps before)
-        for (int64_t i = 0; i < N; ++i) {
-          const uint32_t l = (uint32_t)seg[i];
-          if (l <= (uint32_t)Sm) ++ptr[(size_t)l + 1]; else beyond = 1;
-        }
-        if (beyond) throw std::runtime_error("segment label out of range [0, S]");
+      uint32_t beyond = 0;   // (labels are checked where they are counted)
+      for (int64_t i = 0; i < N; ++i) {
+        const uint32_t l = (uint32_t)seg[i];
+        if (l <= (uint32_t)Sm) ++ptr[(size_t)l + 1]; else beyond = 1;
       }
+      if (beyond) return false;
       for (int l = 0; l <= Sm; ++l) ptr[l + 1] += ptr[l];
       {
         std::vector<int32_t> at(ptr, ptr + Sm + 1);
@@ -691,13 +695,27 @@ int stereo_segpln_planes_batch(const double *wta, const int32_t *const *segments
         const int len = ptr[sg + 2] - ptr[sg + 1];
         ++count[len > kLargeSegment ? 0 : len > kMediumSegment ? 1 : 2];
       }
-      {
-        size_t at[3] = {0, count[0], count[0] + count[1]};
-        for (int sg = 0; sg < Sm; ++sg) {
-          const int len = ptr[sg + 2] - ptr[sg + 1];
-          sc.hlist.p[at[len > kLargeSegment ? 0 : len > kMediumSegment ? 1 : 2]++] = sg;
-        }
+      size_t at[3] = {0, count[0], count[0] + count[1]};
+      for (int sg = 0; sg < Sm; ++sg) {
+        const int len = ptr[sg + 2] - ptr[sg + 1];
+        sc.hlist.p[at[len > kLargeSegment ? 0 : len > kMediumSegment ? 1 : 2]++] = sg;
       }
+      return true;
+    };
+    std::vector<std::future<bool>> grouped((size_t)M);
+    struct Join {   // (no helper outlives the call, whichever way it ends)
+      std::vector<std::future<bool>> &f;
+      ~Join() { for (auto &x : f) if (x.valid()) x.wait(); }
+    } join{grouped};
+    for (int r = 1; r < M; ++r) grouped[r] = std::async(std::launch::async, group, r);
+    for (int r = 0; r < M; ++r) {
+      const int m = order[r], Sm = S[m];
+      // (the first map of the order has a stream to itself when there are several: its longest workgroup bounds the call)
+      const hipStream_t st = pool.stream[M > 1 && r > 0 ? 1 + (r - 1) % (kStreams - 1) : 0];
+      MapScratch &sc = *pool.maps[r];
+      if (!(r == 0 ? group(0) : grouped[r].get())) throw std::runtime_error("segment label out of range [0, S]");
+      const int32_t *ptr = sc.hptr.p, *idx = sc.hidx.p;
+      const size_t *count = sc.count;
       // (the kernels index segments 0 .. S - 1 = labels 1 .. S: the bounds go up from ptr + 1)
       STEREO_HIP_CHECK(hipMemcpyAsync(sc.dptr.p, ptr + 1, sizeof(int32_t) * ((size_t)Sm + 1), hipMemcpyHostToDevice, st));
       STEREO_HIP_CHECK(hipMemcpyAsync(sc.didx.p, idx, sizeof(int32_t) * N, hipMemcpyHostToDevice, st));
