@@ -515,8 +515,8 @@ int stereo_segpln_planes(const double *wta, const int32_t *segments, int H, int 
 
 /* The same for M maps in one call (segpln fits fourteen, dispmap_globalstereo.m:122-197): segments[m], seeds[m], S[m],
  * proposals[m] (or NULL), planes[m] (or NULL), inliers[m] (or NULL) are map m's arguments of stereo_segpln_planes and
- * the results are those of M such calls, bit for bit -- the maps run side by side on the device (a stream each, the
- * host grouping the next map's pixels meanwhile), which is what the call is for. */
+ * the results are those of M such calls, bit for bit -- the segments of all maps run side by side on the device (one
+ * launch per workgroup size; pixels grouped and proposals delivered on helper threads), which is what the call is for. */
 int stereo_segpln_planes_batch(const double *wta, const int32_t *const *segments, int M, int H, int W, double rt,
                                const uint64_t *seeds, int max_samples, double *const *proposals, const int *S,
                                double *const *planes, int32_t *const *inliers, char *err, size_t errcap);

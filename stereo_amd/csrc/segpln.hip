@@ -186,9 +186,10 @@ struct FitArgs {
   double *proposal;         // 4 x N
   double *planes;           // 3 x S
   int32_t *ninl;            // S
-  const int32_t *list;      // the segments of this launch
   unsigned long long *prof; // development (STEREO_HIP_SEGPLN_TIMING): 100 MHz ticks per phase of the launch's first workgroup
 };
+
+struct FitWork { int32_t map, segment; };   // a workgroup's job: entry of the argument table, segment of that map
 
 constexpr int kFitBatch = 8;   // RANSAC trials judged per pass over a segment's points
 constexpr int kFitStage = 4096;   // points per LDS stage of the large segments' least-squares sums (3 doubles each)
@@ -241,14 +242,18 @@ __device__ __forceinline__ double fit_sum(const double *X, const double *Y, cons
 //     third of a millisecond per fit, eleven fits);
 // same operations on the same operands in the same order as before, so the planes keep their bits (tests/test_segpln_gpu.py).
 template <int T>
-__global__ __launch_bounds__(T) void segpln_fit_kernel(FitArgs a) {
+__global__ __launch_bounds__(T) void segpln_fit_kernel(const FitArgs *maps, const FitWork *work) {
   constexpr int NW = T / 64;
   constexpr int LW = NW < 9 ? NW : 9;   // waves that sum
   __shared__ int s_cnt[NW * kFitBatch];
   __shared__ int s_tot[kFitBatch];
   __shared__ double s_N[3 * kFitBatch];
   __shared__ double s_acc[9];
-  const int s = a.list[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (one launch holds segments of several maps: the workgroup's map and segment come from the work table, the map's
+  //  arguments -- uniform values -- from the argument table)
+  const FitWork job = work[blockIdx.x];
+  const FitArgs a = maps[job.map];
+  const int s = job.segment, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p0 = a.seg_ptr[s], p1 = a.seg_ptr[s + 1];
   if (p1 <= p0) { if (tid == 0) { a.ninl[s] = 0; a.planes[3 * s] = a.planes[3 * s + 1] = a.planes[3 * s + 2] = 0; } return; }
   double *X = a.px + p0, *Y = a.py + p0, *Z = a.pz + p0;
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(T) void segpln_fit_kernel(FitArgs a) {
       if (lane == 0) for (int k = 0; k < 9; ++k) s_acc[k] = acc[k];
     } else if (NW >= 8) {
       // large segments: ALL waves stream the points through LDS, kFitStage at a time (the next stage's loads are in flight
-      // while this one is summed), and waves 0 .. 7 add their sum's terms from there in order (wave 7 also the ninth) --
+      // while this one is summed), and three waves add the sums' terms from there in order (below) --
       // a wave that pulls a 150 000-point segment through its own registers waits a memory round trip per 16 points.
       // A point that is not flagged (or lies behind the segment's end) is staged as (0, 0, 0): its terms are +0 or -0,
       // and adding those leaves a partial sum as it is (a partial sum is never -0: it starts at +0, and +0 + -0 = +0) --
@@ -353,53 +358,65 @@ __global__ __launch_bounds__(T) void segpln_fit_kernel(FitArgs a) {
       constexpr int PER = kFitStage / T;
       double *sX = fit_stage, *sY = sX + kFitStage, *sZ = sY + kFitStage;
       double rx[PER], ry[PER], rz[PER];
-      bool rf[PER];
-      auto request = [&](int c0) {
+      unsigned rfb[PER];   // (the flag BYTES: a test of their bit here would wait for the loads it is meant to leave in flight --
+      auto request = [&](int c0) {   //  2.3 of a stage's 5.7 us)
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
           const int i = c0 + u * T + tid, ic = i < n ? i : n - 1;
           rx[u] = X[ic]; ry[u] = Y[ic]; rz[u] = Z[ic];
-          rf[u] = i < n && (flags == nullptr || ((flags[ic] >> bit) & 1));
+          rfb[u] = flags ? (unsigned)flags[ic] : 0xffu;
         }
       };
       request(0);
-      const double *sA = (wave == 0 || wave == 1 || wave == 2 || wave == 6) ? sX : (wave == 3 || wave == 4 || wave == 7) ? sY : sZ;
-      const double *sB = (wave == 0) ? sX : (wave == 1 || wave == 3) ? sY : sZ;   // (second factor; wave 7: the ninth sum's; wave 6: unused)
-      double acc = 0, acc8 = 0;
+      // three waves sum: wave 0 x x, x y, x z | wave 1 y y, y z, -y | wave 2 z z, -z, -x -- seven LDS reads per point
+      // instead of one or two per sum (the stage's reads were what bounded it), three independent chains per lane
+      double acc0 = 0, acc1 = 0, acc2 = 0;
       for (int c0 = 0; c0 < n; c0 += kFitStage) {
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
           const int j = u * T + tid;
-          sX[j] = rf[u] ? rx[u] : 0.0; sY[j] = rf[u] ? ry[u] : 0.0; sZ[j] = rf[u] ? rz[u] : 0.0;
+          const bool f = c0 + j < n && ((rfb[u] >> bit) & 1u);
+          sX[j] = f ? rx[u] : 0.0; sY[j] = f ? ry[u] : 0.0; sZ[j] = f ? rz[u] : 0.0;
         }
         __syncthreads();
         if (c0 + kFitStage < n) request(c0 + kFitStage);
         const int m = n - c0 < kFitStage ? n - c0 : kFitStage;
         const int rounds = (m + 64 * 8 - 1) / (64 * 8);   // (whole rounds of 8 x 64 entries: zeros behind the end)
-        if (wave < 8) {
+        // (eight points' LDS reads go out together, the additions follow in order)
+        if (wave == 0) {
           for (int r = 0; r < rounds; ++r) {
-            double av[8], bv[8];
+            double xv[8], yv[8], zv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {   // (eight points' LDS reads go out together, the additions follow in order)
-              const int j = (r * 8 + u) * 64 + lane;
-              av[u] = sA[j];
-              bv[u] = wave == 6 ? 0.0 : sB[j];
-            }
+            for (int u = 0; u < 8; ++u) { const int j = (r * 8 + u) * 64 + lane; xv[u] = sX[j]; yv[u] = sY[j]; zv[u] = sZ[j]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              acc = acc + (wave < 6 ? av[u] * bv[u] : -av[u]);
-              if (wave == 7) acc8 = acc8 + (-bv[u]);
-            }
+            for (int u = 0; u < 8; ++u) { acc0 = acc0 + xv[u] * xv[u]; acc1 = acc1 + xv[u] * yv[u]; acc2 = acc2 + xv[u] * zv[u]; }
+          }
+        } else if (wave == 1) {
+          for (int r = 0; r < rounds; ++r) {
+            double yv[8], zv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int j = (r * 8 + u) * 64 + lane; yv[u] = sY[j]; zv[u] = sZ[j]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc0 = acc0 + yv[u] * yv[u]; acc1 = acc1 + yv[u] * zv[u]; acc2 = acc2 + (-yv[u]); }
+          }
+        } else if (wave == 2) {
+          for (int r = 0; r < rounds; ++r) {
+            double zv[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int j = (r * 8 + u) * 64 + lane; zv[u] = sZ[j]; xv[u] = sX[j]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc0 = acc0 + zv[u] * zv[u]; acc1 = acc1 + (-zv[u]); acc2 = acc2 + (-xv[u]); }
           }
         }
         __syncthreads();
       }
       for (int o = 32; o > 0; o >>= 1) {
-        const double other = __shfl_down(acc, o, 64), other8 = __shfl_down(acc8, o, 64);
-        acc = acc + other; acc8 = acc8 + other8;
+        const double o0 = __shfl_down(acc0, o, 64), o1 = __shfl_down(acc1, o, 64), o2 = __shfl_down(acc2, o, 64);
+        acc0 = acc0 + o0; acc1 = acc1 + o1; acc2 = acc2 + o2;
       }
-      if (lane == 0 && wave < 8) s_acc[wave] = acc;
-      if (lane == 0 && wave == 7) s_acc[8] = acc8;
+      if (lane == 0 && wave == 0) { s_acc[0] = acc0; s_acc[1] = acc1; s_acc[2] = acc2; }
+      if (lane == 0 && wave == 1) { s_acc[3] = acc0; s_acc[4] = acc1; s_acc[7] = acc2; }
+      if (lane == 0 && wave == 2) { s_acc[5] = acc0; s_acc[8] = acc1; s_acc[6] = acc2; }
     } else {
       for (int k = wave; k < 9; k += LW) {
         double v = 0;
@@ -598,25 +615,30 @@ int stereo_segpln_planes_batch(const double *wta, const int32_t *const *segments
     if (!segments[m] || S[m] < 0 || (!(proposals && proposals[m]) && !(planes && planes[m])))
       return fail("stereo_segpln_planes: bad argument", err, errcap);
   return guarded("stereo_segpln_planes", err, errcap, [&] {
-    // The maps are independent of each other (a proposal per map, dispmap_globalstereo.m:140-197), and a map's launches fill
+    // The maps are independent of each other (a proposal per map, dispmap_globalstereo.m:140-197), and a map's segments fill
     // a fraction of the device only (one workgroup per segment; a coarse map has a handful of segments, one of them most of
-    // the image).  So every map gets scratch of its own and a stream; the host groups map m + 1's pixels by segment while
-    // the device fits map m's planes; maps with the fewest segments -- the longest single workgroups -- are issued first.
+    // the image).  So every map has scratch of its own, the host groups the maps' pixels by segment side by side (helper
+    // threads), and the segments of ALL maps go into one launch per workgroup size, the three launches on three streams.
     // Everything is kept from call to call on this thread (fourteen maps per object, a dozen allocations each otherwise).
     constexpr int kStreams = 4;
     struct MapScratch {
       DevBuf<double> px, py, pz, dprop, dpl;
-      DevBuf<int32_t> dptr, didx, dn, dlist;
+      DevBuf<int32_t> dptr, didx, dn;
       DevBuf<uint8_t> cur, tmp, inl;
       PinnedBuf<double> hpl;       // planes and inlier counts come back through pinned memory; the grouped pixel ids, segment
       PinnedBuf<int32_t> hn, hidx, hptr, hlist;   // bounds and launch lists go up from pinned memory: copies that do not hold the host
       size_t N = 0, S = 0;
       size_t count[3] = {0, 0, 0};
-      hipEvent_t fitted = nullptr;   // the map's kernels are done
+      PinnedBuf<double> hprop;     // the 4 x N proposal on its way to the caller's array
+      hipEvent_t copied = nullptr;
     };
     struct Pool {
       DevBuf<double> dw;
-      size_t Nw = 0;
+      DevBuf<FitArgs> dargs;       // a map's arguments; (map, segment) of every workgroup of the three launches
+      DevBuf<FitWork> dwork;
+      PinnedBuf<FitArgs> hargs;
+      PinnedBuf<FitWork> hwork;
+      size_t Nw = 0, cap_args = 0, cap_work = 0;
       std::vector<std::unique_ptr<MapScratch>> maps;
       hipStream_t stream[kStreams] = {nullptr, nullptr, nullptr, nullptr};
       hipEvent_t uploaded = nullptr, done[kStreams] = {nullptr, nullptr, nullptr, nullptr};
@@ -627,7 +649,7 @@ int stereo_segpln_planes_batch(const double *wta, const int32_t *const *segments
     int device = 0;
     STEREO_HIP_CHECK(hipGetDevice(&device));
     if (pool.device != device) {   // (buffers of another device are released; its streams and events stay with it)
-      pool.maps.clear(); pool.Nw = 0; pool.device = device;
+      pool.maps.clear(); pool.Nw = 0; pool.cap_args = 0; pool.cap_work = 0; pool.device = device;
       for (int k = 0; k < kStreams; ++k) {
         STEREO_HIP_CHECK(hipStreamCreateWithFlags(&pool.stream[k], hipStreamNonBlocking));
         STEREO_HIP_CHECK(hipEventCreateWithFlags(&pool.done[k], hipEventDisableTiming));
@@ -648,7 +670,6 @@ int stereo_segpln_planes_batch(const double *wta, const int32_t *const *segments
     // (the disparity map: pageable memory, so this copy returns when the source has been read)
     STEREO_HIP_CHECK(hipMemcpyAsync(pool.dw.p, wta, sizeof(double) * N, hipMemcpyHostToDevice, pool.stream[0]));
     STEREO_HIP_CHECK(hipEventRecord(pool.uploaded, pool.stream[0]));
-    for (int k = 1; k < kStreams; ++k) STEREO_HIP_CHECK(hipStreamWaitEvent(pool.stream[k], pool.uploaded, 0));
     std::vector<int> order((size_t)M);
     for (int m = 0; m < M; ++m) order[m] = m;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return S[x] < S[y]; });
@@ -662,7 +683,7 @@ int stereo_segpln_planes_batch(const double *wta, const int32_t *const *segments
       }
       if (sc.S < (size_t)Sm + 2) {
         const size_t cap = (size_t)Sm + 2;
-        sc.dptr.alloc(cap); sc.dpl.alloc(3 * cap); sc.dn.alloc(cap); sc.dlist.alloc(cap);
+        sc.dptr.alloc(cap); sc.dpl.alloc(3 * cap); sc.dn.alloc(cap);
         sc.hpl.alloc(3 * cap); sc.hn.alloc(cap); sc.hptr.alloc(cap); sc.hlist.alloc(cap);
         sc.S = cap;
       }
@@ -708,71 +729,130 @@ int stereo_segpln_planes_batch(const double *wta, const int32_t *const *segments
       ~Join() { for (auto &x : f) if (x.valid()) x.wait(); }
     } join{grouped};
     for (int r = 1; r < M; ++r) grouped[r] = std::async(std::launch::async, group, r);
+    // uploads and the default proposal of every map on the first stream, as the maps' groupings arrive
+    const hipStream_t st0 = pool.stream[0];
+    std::vector<FitArgs> args((size_t)M + 1);
+    size_t total[3] = {0, 0, 0};
     for (int r = 0; r < M; ++r) {
       const int m = order[r], Sm = S[m];
-      // (the first map of the order has a stream to itself when there are several: its longest workgroup bounds the call)
-      const hipStream_t st = pool.stream[M > 1 && r > 0 ? 1 + (r - 1) % (kStreams - 1) : 0];
       MapScratch &sc = *pool.maps[r];
       if (!(r == 0 ? group(0) : grouped[r].get())) throw std::runtime_error("segment label out of range [0, S]");
-      const int32_t *ptr = sc.hptr.p, *idx = sc.hidx.p;
-      const size_t *count = sc.count;
       // (the kernels index segments 0 .. S - 1 = labels 1 .. S: the bounds go up from ptr + 1)
-      STEREO_HIP_CHECK(hipMemcpyAsync(sc.dptr.p, ptr + 1, sizeof(int32_t) * ((size_t)Sm + 1), hipMemcpyHostToDevice, st));
-      STEREO_HIP_CHECK(hipMemcpyAsync(sc.didx.p, idx, sizeof(int32_t) * N, hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(segpln_init_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, sc.dprop.p);
-      if (Sm > 0) {
-        STEREO_HIP_CHECK(hipMemcpyAsync(sc.dlist.p, sc.hlist.p, sizeof(int32_t) * (size_t)Sm, hipMemcpyHostToDevice, st));
-        FitArgs a{pool.dw.p, sc.dptr.p, sc.didx.p, H, W, Sm, max_samples, rt, seeds[m], sc.px.p, sc.py.p, sc.pz.p, sc.cur.p, sc.tmp.p, sc.inl.p,
-                  sc.dprop.p, sc.dpl.p, sc.dn.p, sc.dlist.p, nullptr};
-        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-        if (timing) for (auto &e : ev) STEREO_HIP_CHECK(hipEventCreate(&e));
-        DevBuf<unsigned long long> dprof;
-        if (timing) { dprof.alloc(16); STEREO_HIP_CHECK(hipMemset(dprof.p, 0, 16 * sizeof(unsigned long long))); a.prof = dprof.p; }
-        if (timing) STEREO_HIP_CHECK(hipEventRecord(ev[0], st));
-        if (count[0]) hipLaunchKernelGGL(segpln_fit_kernel<512>, dim3((unsigned)count[0]), dim3(512), kFitStageBytes, st, a);
-        if (timing) STEREO_HIP_CHECK(hipEventRecord(ev[1], st));
-        a.prof = nullptr;
-        a.list = sc.dlist.p + count[0];
-        if (count[1]) hipLaunchKernelGGL(segpln_fit_kernel<256>, dim3((unsigned)count[1]), dim3(256), 0, st, a);
-        if (timing) STEREO_HIP_CHECK(hipEventRecord(ev[2], st));
-        a.list = sc.dlist.p + count[0] + count[1];
-        if (count[2]) hipLaunchKernelGGL(segpln_fit_kernel<64>, dim3((unsigned)count[2]), dim3(64), 0, st, a);
-        STEREO_HIP_CHECK(hipGetLastError());
-        if (timing) {
-          STEREO_HIP_CHECK(hipEventRecord(ev[3], st));
-          STEREO_HIP_CHECK(hipEventSynchronize(ev[3]));
-          float t[3];
-          for (int k = 0; k < 3; ++k) STEREO_HIP_CHECK(hipEventElapsedTime(&t[k], ev[k], ev[k + 1]));
-          std::fprintf(stderr, "[stereo_hip segpln] S = %d: %zu large segments %.3f ms, %zu medium %.3f ms, %zu small %.3f ms\n", Sm, count[0], t[0],
-                       count[1], t[1], count[2], t[2]);
-          unsigned long long pr[16];
-          STEREO_HIP_CHECK(hipMemcpy(pr, dprof.p, sizeof(pr), hipMemcpyDeviceToHost));
-          if (count[0])
-            std::fprintf(stderr, "[stereo_hip segpln]   first large segment, us (count): coordinates %.0f | draws %.0f (%llu) | batch passes %.0f (%llu) | bookkeeping %.0f | "
-                         "least squares %.0f (%llu) | re-classify + copy %.0f (%llu) | final fit %.0f | proposal %.0f\n", pr[0] / 100.0, pr[1] / 100.0, pr[9],
-                         pr[2] / 100.0, pr[10], pr[3] / 100.0, pr[4] / 100.0, pr[12], pr[5] / 100.0, pr[13], pr[6] / 100.0, pr[7] / 100.0);
-          for (auto &e : ev) (void)hipEventDestroy(e);
-        }
-        STEREO_HIP_CHECK(hipMemcpyAsync(sc.hpl.p, sc.dpl.p, sizeof(double) * 3 * (size_t)Sm, hipMemcpyDeviceToHost, st));
-        STEREO_HIP_CHECK(hipMemcpyAsync(sc.hn.p, sc.dn.p, sizeof(int32_t) * (size_t)Sm, hipMemcpyDeviceToHost, st));
+      STEREO_HIP_CHECK(hipMemcpyAsync(sc.dptr.p, sc.hptr.p + 1, sizeof(int32_t) * ((size_t)Sm + 1), hipMemcpyHostToDevice, st0));
+      STEREO_HIP_CHECK(hipMemcpyAsync(sc.didx.p, sc.hidx.p, sizeof(int32_t) * N, hipMemcpyHostToDevice, st0));
+      hipLaunchKernelGGL(segpln_init_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st0, N, sc.dprop.p);
+      args[r] = FitArgs{pool.dw.p, sc.dptr.p, sc.didx.p, H, W, Sm, max_samples, rt, seeds[m], sc.px.p, sc.py.p, sc.pz.p, sc.cur.p, sc.tmp.p, sc.inl.p,
+                        sc.dprop.p, sc.dpl.p, sc.dn.p, nullptr};
+      for (int c = 0; c < 3; ++c) total[c] += sc.count[c];
+    }
+    STEREO_HIP_CHECK(hipGetLastError());
+    // ONE launch per workgroup size for the segments of ALL maps (the device runs a few queues side by side, not fourteen:
+    // a stream per map left most maps waiting behind each other): work tables of (map, segment), the large segments by
+    // falling size -- the longest workgroup, which bounds the call, starts first
+    const size_t jobs = total[0] + total[1] + total[2];
+    if (pool.cap_work < jobs) { pool.dwork.alloc(jobs); pool.hwork.alloc(jobs); pool.cap_work = jobs; }
+    if (pool.cap_args < (size_t)M + 1) { pool.dargs.alloc((size_t)M + 1); pool.hargs.alloc((size_t)M + 1); pool.cap_args = (size_t)M + 1; }
+    {
+      std::vector<std::pair<int32_t, FitWork>> large;
+      large.reserve(total[0]);
+      size_t at[3] = {0, total[0], total[0] + total[1]};
+      for (int r = 0; r < M; ++r) {
+        const MapScratch &sc = *pool.maps[r];
+        const int32_t *l = sc.hlist.p, *ptr = sc.hptr.p;
+        for (size_t k = 0; k < sc.count[0]; ++k) large.push_back({ptr[l[k] + 2] - ptr[l[k] + 1], FitWork{r, l[k]}});
+        for (size_t k = 0; k < sc.count[1]; ++k) pool.hwork.p[at[1]++] = FitWork{r, l[sc.count[0] + k]};
+        for (size_t k = 0; k < sc.count[2]; ++k) pool.hwork.p[at[2]++] = FitWork{r, l[sc.count[0] + sc.count[1] + k]};
       }
+      std::stable_sort(large.begin(), large.end(), [](const std::pair<int32_t, FitWork> &x, const std::pair<int32_t, FitWork> &y) { return x.first > y.first; });
+      for (const auto &j : large) pool.hwork.p[at[0]++] = j.second;
+    }
+    DevBuf<unsigned long long> dprof;
+    if (timing && total[0]) {   // (development: the launch's first workgroup -- the largest segment -- keeps time per phase, through an entry of its own)
+      dprof.alloc(16);
+      STEREO_HIP_CHECK(hipMemset(dprof.p, 0, 16 * sizeof(unsigned long long)));
+      args[M] = args[pool.hwork.p[0].map];
+      args[M].prof = dprof.p;
+      pool.hwork.p[0].map = M;
+    }
+    std::copy(args.begin(), args.end(), pool.hargs.p);
+    STEREO_HIP_CHECK(hipMemcpyAsync(pool.dargs.p, pool.hargs.p, sizeof(FitArgs) * ((size_t)M + 1), hipMemcpyHostToDevice, st0));
+    if (jobs) STEREO_HIP_CHECK(hipMemcpyAsync(pool.dwork.p, pool.hwork.p, sizeof(FitWork) * jobs, hipMemcpyHostToDevice, st0));
+    STEREO_HIP_CHECK(hipEventRecord(pool.uploaded, st0));
+    const FitWork *w0 = pool.dwork.p, *w1 = w0 + total[0], *w2 = w1 + total[1];
+    if (!timing) {
+      for (int k = 1; k < 3; ++k) STEREO_HIP_CHECK(hipStreamWaitEvent(pool.stream[k], pool.uploaded, 0));
+      if (total[0]) hipLaunchKernelGGL(segpln_fit_kernel<512>, dim3((unsigned)total[0]), dim3(512), kFitStageBytes, st0, pool.dargs.p, w0);
+      if (total[1]) hipLaunchKernelGGL(segpln_fit_kernel<256>, dim3((unsigned)total[1]), dim3(256), 0, pool.stream[1], pool.dargs.p, w1);
+      if (total[2]) hipLaunchKernelGGL(segpln_fit_kernel<64>, dim3((unsigned)total[2]), dim3(64), 0, pool.stream[2], pool.dargs.p, w2);
       STEREO_HIP_CHECK(hipGetLastError());
-      if (!sc.fitted) STEREO_HIP_CHECK(hipEventCreateWithFlags(&sc.fitted, hipEventDisableTiming));
-      STEREO_HIP_CHECK(hipEventRecord(sc.fitted, st));
+      for (int k = 1; k < 3; ++k) {
+        STEREO_HIP_CHECK(hipEventRecord(pool.done[k], pool.stream[k]));
+        STEREO_HIP_CHECK(hipStreamWaitEvent(st0, pool.done[k], 0));
+      }
+    } else {   // one after the other, timed
+      hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+      for (auto &e : ev) STEREO_HIP_CHECK(hipEventCreate(&e));
+      STEREO_HIP_CHECK(hipEventRecord(ev[0], st0));
+      if (total[0]) hipLaunchKernelGGL(segpln_fit_kernel<512>, dim3((unsigned)total[0]), dim3(512), kFitStageBytes, st0, pool.dargs.p, w0);
+      STEREO_HIP_CHECK(hipEventRecord(ev[1], st0));
+      if (total[1]) hipLaunchKernelGGL(segpln_fit_kernel<256>, dim3((unsigned)total[1]), dim3(256), 0, st0, pool.dargs.p, w1);
+      STEREO_HIP_CHECK(hipEventRecord(ev[2], st0));
+      if (total[2]) hipLaunchKernelGGL(segpln_fit_kernel<64>, dim3((unsigned)total[2]), dim3(64), 0, st0, pool.dargs.p, w2);
+      STEREO_HIP_CHECK(hipGetLastError());
+      STEREO_HIP_CHECK(hipEventRecord(ev[3], st0));
+      STEREO_HIP_CHECK(hipEventSynchronize(ev[3]));
+      float t[3];
+      for (int k = 0; k < 3; ++k) STEREO_HIP_CHECK(hipEventElapsedTime(&t[k], ev[k], ev[k + 1]));
+      std::fprintf(stderr, "[stereo_hip segpln] %d map(s): %zu large segments %.3f ms, %zu medium %.3f ms, %zu small %.3f ms\n", M, total[0], t[0], total[1], t[1],
+                   total[2], t[2]);
+      if (total[0]) {
+        unsigned long long pr[16];
+        STEREO_HIP_CHECK(hipMemcpy(pr, dprof.p, sizeof(pr), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[stereo_hip segpln]   largest segment, us (count): coordinates %.0f | draws %.0f (%llu) | batch passes %.0f (%llu) | bookkeeping %.0f | "
+                     "least squares %.0f (%llu) | re-classify %.0f (%llu) | final fit %.0f | proposal %.0f\n", pr[0] / 100.0, pr[1] / 100.0, pr[9],
+                     pr[2] / 100.0, pr[10], pr[3] / 100.0, pr[4] / 100.0, pr[12], pr[5] / 100.0, pr[13], pr[6] / 100.0, pr[7] / 100.0);
+      }
+      for (auto &e : ev) (void)hipEventDestroy(e);
     }
-    // everything is under way.  The proposals come back map by map as the maps finish -- the first of the order, the
-    // longest, last --, each behind its own event: a blocking copy into the caller's pageable memory (an asynchronous one
-    // pins the pages first, at five times the cost), which holds the host only while the other streams work on.
-    for (int q = 0; q < M; ++q) {
-      const int r = (q + 1) % M, m = order[r];
+    for (int r = 0; r < M; ++r) {
+      const int Sm = S[order[r]];
+      MapScratch &sc = *pool.maps[r];
+      if (Sm > 0) {
+        STEREO_HIP_CHECK(hipMemcpyAsync(sc.hpl.p, sc.dpl.p, sizeof(double) * 3 * (size_t)Sm, hipMemcpyDeviceToHost, st0));
+        STEREO_HIP_CHECK(hipMemcpyAsync(sc.hn.p, sc.dn.p, sizeof(int32_t) * (size_t)Sm, hipMemcpyDeviceToHost, st0));
+      }
+    }
+    // The proposals (4 x N doubles per map, 75 MB for fourteen Teddy-sized maps) come back through pinned memory, a copy
+    // and an event per map, and go to the caller's arrays on helper threads: a copy straight into pageable memory holds
+    // the host for its length, and most of that length is first-touch page faults when the arrays are fresh -- which
+    // fourteen threads take side by side (14 - 40 ms for the copies alone before).
+    std::vector<std::future<bool>> delivered((size_t)M);
+    struct JoinCopies {
+      std::vector<std::future<bool>> &f;
+      ~JoinCopies() { for (auto &x : f) if (x.valid()) x.wait(); }
+    } join_copies{delivered};
+    for (int r = 0; r < M; ++r) {
+      const int m = order[r];
       if (!(proposals && proposals[m])) continue;
-      STEREO_HIP_CHECK(hipEventSynchronize(pool.maps[r]->fitted));
-      STEREO_HIP_CHECK(hipMemcpy(proposals[m], pool.maps[r]->dprop.p, sizeof(double) * 4 * N, hipMemcpyDeviceToHost));
+      MapScratch &sc = *pool.maps[r];
+      if (sc.hprop.n < (size_t)4 * N) sc.hprop.alloc((size_t)4 * N);
+      if (!sc.copied) STEREO_HIP_CHECK(hipEventCreateWithFlags(&sc.copied, hipEventDisableTiming));
+      STEREO_HIP_CHECK(hipMemcpyAsync(sc.hprop.p, sc.dprop.p, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, st0));
+      STEREO_HIP_CHECK(hipEventRecord(sc.copied, st0));
+      double *dst = proposals[m];
+      const double *src = sc.hprop.p;
+      const hipEvent_t ev = sc.copied;
+      const size_t bytes = sizeof(double) * 4 * (size_t)N;
+      delivered[r] = std::async(std::launch::async, [dst, src, ev, bytes, device]() -> bool {
+        if (hipSetDevice(device) != hipSuccess || hipEventSynchronize(ev) != hipSuccess) return false;
+        std::memcpy(dst, src, bytes);
+        return true;
+      });
     }
-    for (int k = 0; k < kStreams; ++k) {
-      STEREO_HIP_CHECK(hipEventRecord(pool.done[k], pool.stream[k]));
-      STEREO_HIP_CHECK(hipEventSynchronize(pool.done[k]));
-    }
+    STEREO_HIP_CHECK(hipEventRecord(pool.done[0], st0));
+    STEREO_HIP_CHECK(hipEventSynchronize(pool.done[0]));
+    for (auto &x : delivered)
+      if (x.valid() && !x.get()) throw HipError{"stereo_segpln_planes: a proposal's copy back failed"};
     for (int r = 0; r < M; ++r) {
       const int m = order[r];
       const MapScratch &sc = *pool.maps[r];
