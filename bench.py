@@ -422,6 +422,17 @@ def segmentation_leg():
            "segment_ms": t_ms * 1e3, "segments": int(seg.max()), "fourteen_maps_ms": t_maps * 1e3,
            "filter_stage_ms": t_own * 1e3, "pixels_walked_again_on_the_host": int(ev.sum()),
            "equal_to_the_reference_maps": bool(np.array_equal(seg, sg["segment"]) and np.array_equal(maps, sg["segments"]))}
+    # the plane fits on those maps (segpln :140-197, stereo_segpln_planes_batch) against the committed oracle planes
+    from stereo_amd import terms as T
+    pl = np.load(os.path.join(gold, "teddy_segpln_planes.npz"))
+    T.segpln_planes_batch(pl["wta"], maps, list(range(14)))
+    t = time.perf_counter(); fits = T.segpln_planes_batch(pl["wta"], maps, list(range(14))); t_fit = time.perf_counter() - t
+    t = time.perf_counter(); T.segpln_planes_batch(pl["wta"], maps, list(range(14)), want_proposal=False); t_fit0 = time.perf_counter() - t
+    out["plane_fits"] = {"what": "LO-RANSAC + least-squares plane of every segment of the 14 maps in one call (12 766 + 469 + 94 segments, the largest "
+                                 "154 396 pixels), seeds 0 .. 13, on the committed winner-takes-all map",
+                         "ms_with_the_14_proposal_arrays": t_fit * 1e3, "ms_planes_and_inlier_counts": t_fit0 * 1e3,
+                         "proposals_equal_to_the_oracle_fixture": bool(all(np.array_equal(
+                             fits[b][0], pl["planes_%d" % b][maps[:, :, b].T.reshape(-1).astype(np.int64) - 1].T, equal_nan=True) for b in range(14)))}
     from oracle import pyoracle
     if pyoracle.have_ref_segment() and pyoracle.ref_segment_gb_lib() is not None:
         t = time.perf_counter(); r = pyoracle.ref_segment_ms(im, 4, 5.0, 0); t_r = time.perf_counter() - t
