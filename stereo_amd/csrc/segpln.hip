@@ -475,12 +475,22 @@ __global__ __launch_bounds__(T) void segpln_fit_kernel(const FitArgs *maps, cons
         int cnt[kFitBatch];
 #pragma unroll
         for (int b = 0; b < kFitBatch; ++b) cnt[b] = 0;
-        for (int base = tid; base < n; base += 8 * T) {
-          double xv[8], yv[8], zv[8];
+        // (the next four points are asked for before these four are judged: a pass was half memory latency; eight and eight
+        //  did not fit the registers)
+        constexpr int U = 4;
+        double xn[U], yn[U], zn[U];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { const int i = base + u * T, ic = i < n ? i : n - 1; xv[u] = X[ic]; yv[u] = Y[ic]; zv[u] = Z[ic]; }
+        for (int u = 0; u < U; ++u) { const int i = tid + u * T, ic = i < n ? i : n - 1; xn[u] = X[ic]; yn[u] = Y[ic]; zn[u] = Z[ic]; }
+        for (int base = tid; base < n; base += U * T) {
+          double xv[U], yv[U], zv[U];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
+          for (int u = 0; u < U; ++u) { xv[u] = xn[u]; yv[u] = yn[u]; zv[u] = zn[u]; }
+          if (base + U * T < n) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int i = base + U * T + u * T, ic = i < n ? i : n - 1; xn[u] = X[ic]; yn[u] = Y[ic]; zn[u] = Z[ic]; }
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
             const int i = base + u * T;
             const double x = xv[u], y = yv[u], z = zv[u];
             unsigned mask = 0;
