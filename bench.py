@@ -442,6 +442,40 @@ def segmentation_leg():
     return out
 
 
+def gateway_leg(G, H=750, W=1000, K=60, iters=10):
+    """the C-ABI entry the reference's gateway reaches (stereo_trws, host arrays as trws.m:33 hands them)
+    sharding one image over G devices BY ITSELF (STEREO_HIP_GPUS=G: one process, row strips, peer access between the
+    devices -- or logical strips where the process sees fewer devices), against the same call on one device.  Runs in a
+    process of its own (python bench.py --gateway-leg G): at N > 1 rank 0 starts it after the ranks' own work."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import stereo_amd
+    from stereo_amd import _lib
+    from helpers import grid_conn
+    conn1 = grid_conn(H, W).T + 1
+    E = conn1.shape[1]
+    h_un = np.asfortranarray(synthetic_volume(H, W, K, 3).T)                                  # K x N
+    h_q = np.asfortranarray(np.tile(np.arange(K, dtype=np.float64)[:, None], (1, E)))          # K x E (dispmap_super.m:177-183)
+    opts = dict(maxiter=iters, max_relgap=-1e300)
+    res = {}
+    for tag, g in (("strips", G), ("one_device", 1)):
+        os.environ["STEREO_HIP_GPUS"] = str(g)
+        _lib.lib().stereo_trws_cache_clear()
+        t = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            r = stereo_amd.trws(1, h_un, conn1, h_q, h_q, np.ones(E), 8.0, opts)
+            t.append(time.perf_counter() - t0)
+        res[tag] = (r, t, int(_lib.lib().stereo_trws_gateway_strips()))
+    _lib.lib().stereo_trws_cache_clear()
+    (a, ta, sa), (b, tb, _) = res["strips"], res["one_device"]
+    return {"what": "stereo_trws with STEREO_HIP_GPUS=%d on a %dx%dx%d volume (host arrays, %d iterations, labels back) against the same call "
+                    "on one device" % (G, W, H, K, iters),
+            "strips": sa, "devices_visible": int(stereo_amd.device_count()), "distinct_devices": min(sa, int(stereo_amd.device_count())),
+            "first_call_s": ta[0], "second_call_s": ta[1], "one_device_second_call_s": tb[1],
+            "labels_equal": bool(np.array_equal(a[0], b[0])), "energy_equal": bool(a[1] == b[1]), "lower_bound_equal": bool(a[2] == b[2]),
+            "iterations_equal": bool(a[3] == b[3])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -463,6 +497,9 @@ def main():
                     help="image pair behind the NCC volume: the reference's Teddy pair (tests/golden/teddy_pair.npz = "
                          "data/teddy/im2.png, im6.png; 450x375 only) or the synthetic textured pair")
     ap.add_argument("--no-scale", action="store_true", help="skip the 3000x2000x256 strong-scaling leg")
+    ap.add_argument("--gateway-leg", type=int, default=0, metavar="G",
+                    help="run ONLY the gateway leg (stereo_trws sharding over G devices by itself) in this process and print its JSON")
+    ap.add_argument("--no-gateway-leg", action="store_true", help="N > 1: do not start the gateway leg's process")
     ap.add_argument("--scale-height", type=int, default=2000)
     ap.add_argument("--scale-width", type=int, default=3000)
     ap.add_argument("--scale-labels", type=int, default=256)
@@ -475,6 +512,9 @@ def main():
                          "(the curve's first point measured in the same job, and a label / energy cross-check of the strips)")
     ap.add_argument("--no-preflight", action="store_true")
     args = ap.parse_args()
+    if args.gateway_leg > 0:
+        print(json.dumps(gateway_leg(args.gateway_leg)))
+        return
 
     import torch
     from stereo_amd import dist as D
@@ -880,6 +920,18 @@ def main():
                                    "avg_launch_us": sc.get("sweep_launch_ms_rank0", 0.0) * 1e3, "launches_per_step": 2.0}
             else:
                 out["scale_error"] = sc.get("error", "scale leg skipped (--no-scale)")
+        if world > 1 and not args.no_gateway_leg:
+            # the gateway sharding by itself over the node's devices: a process of its own (the ranks' work is done; whatever
+            # happens there -- this path has only ever run on logical strips of one device -- the line above stands)
+            import subprocess
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
+                                                                     "LOCAL_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+            try:
+                pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--gateway-leg", str(world)], env=env, capture_output=True, text=True, timeout=420)
+                lines = [l for l in pr.stdout.strip().splitlines() if l.startswith("{")]
+                out["gateway"] = json.loads(lines[-1]) if lines else {"error": "exit %d: %s" % (pr.returncode, pr.stderr.strip()[-400:])}
+            except Exception as exc:
+                out["gateway"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
